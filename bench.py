@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Benchmark of the fem-shell hot path on MI355X: elements assembled/s and CG iterations/s.
+
+Workload (BASELINE.json, the 4M-tri configuration): 10x10 flat panel, 1414x1414 squares split
+into 3,998,792 TRI3 (2,002,225 nodes, 12,013,350 dofs), E=1e7, nu=0.3, t=0.5, all edges simply
+supported (boundary id 0), uniform pressure 300 as nodal Fz.  With --gpus N the same mesh is
+row-partitioned over N ranks (strong scaling, as BASELINE.json's 1/2/4/8-GPU curve asks).
+
+A "step" is one full assembly of K and F (inputs resident in HBM).  After the K timed assembly
+steps, K*cg_iters CG iterations are timed the same way (barrier + synchronize on both sides, max
+over ranks).  One JSON line is printed by rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def panel_mesh(nx):
+    """meshGen-equivalent structured triangle mesh (src/meshgen/main_all.cpp:144-224), ul_lr
+    diagonals, all four edges boundary id 0, uniform load 300 (main_all.cpp:373)."""
+    from tests.helpers import meshes
+
+    return meshes.structured(nx, nx, 0.0, 0.0, 10.0, 10.0, kind="t", ul_lr=True, bcids=(0, 0, 0, 0),
+                             factor=300.0, loading=2)
+
+
+def cpu_baseline(nx_sample=192, seconds=8.0):
+    """The CPU oracle (a scalar C port of the reference path) timed on this host, one core, on a
+    bounded sample: the same panel problem at nx_sample^2 squares."""
+    from tests.helpers import oracle
+
+    m = panel_mesh(nx_sample)
+    mat = oracle.material(0.3, 1e7, 0.5)
+    dmask = m.dirichlet_mask()
+    pattern = oracle.bsr_pattern(m.n_nodes, m.tri, m.quad)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        rowptr, colidx, vals, F = oracle.assemble(m.xyz, m.tri, m.quad, mat, dmask, m.loads, pattern=pattern)
+        reps += 1
+        if time.perf_counter() - t0 > seconds:
+            break
+    asm_rate = reps * len(m.tri) / (time.perf_counter() - t0)
+    its = 150
+    _, info = oracle.pcg(rowptr, colidx, vals, F, rtol=0.0, max_it=its)
+    it_rate = info["iterations"] / info["seconds"]
+    return {
+        "value": asm_rate, "unit": "elements/s", "cores": 1, "kind": "port",
+        "cg_iters_per_s_on_sample": it_rate,
+        "cg_dof_iters_per_s": it_rate * 6 * m.n_nodes,
+        "sample": "same panel problem at %dx%d squares (%d tri3, %d dofs): %d full assemblies, %d PCG iterations; "
+                  "oracle/femshell_oracle.c, gcc -O2, 1 thread" % (nx_sample, nx_sample, len(m.tri), 6 * m.n_nodes,
+                                                                   reps, its),
+    }
+
+
+def parity_probe(pkg, device):
+    """Displacements of the HIP path vs the CPU oracle's direct solve on a mesh the oracle finishes in seconds."""
+    from tests.helpers import oracle
+
+    m = panel_mesh(64)
+    fs = pkg.FemShell(0.3, 1e7, 0.5, device=device)
+    fs.set_mesh(m.xyz, m.tri)
+    fs.set_dirichlet(m.dirichlet_mask())
+    fs.set_loads(m.loads)
+    u, info = fs.solve(rtol=1e-12, max_it=20000)
+    mat = oracle.material(0.3, 1e7, 0.5)
+    r0, c0, v0, F0 = oracle.assemble(m.xyz, m.tri, m.quad, mat, m.dirichlet_mask(), m.loads)
+    u0 = oracle.direct_solve(r0, c0, v0, F0)
+    fs.close()
+    return {"mesh": "64x64 panel (8192 tri3)", "cg_iterations": info["iterations"],
+            "rel_displacement_error_vs_cpu": float(np.linalg.norm(u.ravel() - u0) / np.linalg.norm(u0))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nx", type=int, default=1414, help="squares per side (1414 -> 3,998,792 tri3)")
+    ap.add_argument("--cg-iters", type=int, default=50, help="CG iterations per step in the CG phase")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch  # first: its HIP runtime then serves libfemshell too (same SONAME)
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        # control plane only (unique-id broadcast, barriers, timing max); the data path
+        # (halo exchange, CG all-reduce) is RCCL inside libfemshell
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    pkg = importlib.import_module("fem-shell_amd")
+    m = panel_mesh(args.nx)
+    fs = pkg.FemShell(0.3, 1e7, 0.5, device=local_rank, rank=rank, world_size=world)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.from_numpy(pkg.comm_unique_id().copy())
+        dist.broadcast(uid, src=0)
+        fs.comm_init(uid.numpy())
+    t0 = time.perf_counter()
+    fs.set_mesh(m.xyz, m.tri)
+    setup_s = time.perf_counter() - t0
+    fs.set_dirichlet(m.dirichlet_mask())
+    fs.set_loads(m.loads)
+    n_elem, n_nodes = len(m.tri), m.n_nodes
+
+    # ---- warmup
+    for _ in range(args.warmup):
+        fs.assemble()
+    fs.solve(rtol=0.0, max_it=max(args.warmup, 1) * 5, fetch=False)
+
+    # ---- timed phase 1: K assembly steps
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fs.assemble()
+    fs.sync()
+    barrier()
+    t_asm = max_over_ranks(time.perf_counter() - t0)
+
+    # ---- timed phase 2: K * cg_iters CG iterations (one solve call, no host round trip inside)
+    n_it = args.steps * args.cg_iters
+    barrier()
+    t0 = time.perf_counter()
+    _, info = fs.solve(rtol=0.0, max_it=n_it, fetch=False)
+    fs.sync()
+    barrier()
+    t_cg = max_over_ranks(time.perf_counter() - t0)
+
+    # ---- per-kernel durations with HIP events on the library's stream
+    reps = max(5, args.steps)
+    spmv_ms, spmv_bytes = fs.time_kernel(pkg.KERNEL_SPMV, reps)
+    upd_ms, upd_bytes = fs.time_kernel(pkg.KERNEL_CG_UPDATE, reps)
+    dir_ms, dir_bytes = fs.time_kernel(pkg.KERNEL_CG_DIRECTION, reps)
+    asm_ms, asm_bytes = fs.time_kernel(pkg.KERNEL_ASSEMBLE, reps)
+
+    def roof(ms, nbytes):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "traffic": None, "ms_per_launch": ms, "algorithmic_bytes_per_launch": nbytes}
+
+    if rank == 0:
+        out = {
+            "metric": "elements assembled/s + CG iters/s, 4M-tri shell",
+            "value": n_elem * args.steps / t_asm,
+            "unit": "elements/s",
+            "cg_iters_per_s": info["iterations"] / t_cg,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * t_asm / args.steps,
+            "cg_ms_per_iter": 1e3 * t_cg / max(info["iterations"], 1),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "flat panel 10x10, %dx%d squares -> %d tri3, %d nodes, %d dofs, E=1e7 nu=0.3 t=0.5, "
+                                   "simply supported, uniform pressure 300 (BASELINE.json configs[3]; configs[2] has "
+                                   "the same size)" % (args.nx, args.nx, n_elem, n_nodes, 6 * n_nodes),
+                       "parallelism": "row-partition x%d" % world, "cg_iters_per_step": args.cg_iters,
+                       "preconditioner": "6x6 block-Jacobi", "symbolic_setup_s": setup_s},
+            "roofline": dict(roof(spmv_ms, spmv_bytes), kernel="k_spmv (q = K p, fused p.q)"),
+            "roofline_assembly": dict(roof(asm_ms, asm_bytes), kernel="k_assemble"),
+            "roofline_cg_update": dict(roof(upd_ms, upd_bytes), kernel="k_cg_update"),
+            "roofline_cg_direction": dict(roof(dir_ms, dir_bytes), kernel="k_cg_direction"),
+            "roofline_cg_iteration": roof(1e3 * t_cg / max(info["iterations"], 1), info["bytes_per_iteration"]),
+        }
+        if world == 1:
+            out["parity"] = parity_probe(pkg, local_rank)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    fs.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

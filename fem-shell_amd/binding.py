@@ -1,0 +1,273 @@
+"""ctypes mirror of include/femshell.h (no arithmetic here; see __init__.py)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+
+REF_Y21 = 0x1
+REF_DRILL_MAX = 0x2
+REASSEMBLE_EACH_SOLVE = 0x4
+REF_DEFAULT = REF_Y21 | REF_DRILL_MAX
+
+KERNEL_ASSEMBLE, KERNEL_SPMV, KERNEL_CG_UPDATE, KERNEL_CG_DIRECTION = 0, 1, 2, 3
+
+SYMBOLS = [
+    "femshell_create", "femshell_destroy", "femshell_last_error", "femshell_set_mesh",
+    "femshell_set_dirichlet", "femshell_set_loads", "femshell_assemble", "femshell_solve",
+    "femshell_get_solution", "femshell_residual_history", "femshell_element_matrices",
+    "femshell_nnz_blocks", "femshell_export_bsr", "femshell_spmv", "femshell_row_begin",
+    "femshell_row_end", "femshell_comm_unique_id", "femshell_comm_init", "femshell_time_kernel",
+    "femshell_sync",
+]
+
+
+class FemShellError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("femshell error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("nu", C.c_double), ("E", C.c_double), ("thickness", C.c_double), ("flags", C.c_uint32),
+                ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32)]
+
+
+class SolveInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("rel_residual", C.c_double),
+                ("assemble_seconds", C.c_double), ("setup_seconds", C.c_double), ("solve_seconds", C.c_double),
+                ("bytes_per_iteration", C.c_double)]
+
+
+def library_path():
+    return os.path.join(_HERE, "libfemshell.so")
+
+
+def build_library(force=False):
+    """Compile csrc/ for gfx950 with hipcc (in-tree, so the .so travels with the repo)."""
+    if force:
+        subprocess.check_call(["make", "-C", _CSRC, "-s", "clean"])
+    subprocess.check_call(["make", "-C", _CSRC, "-s"])
+    return library_path()
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libfemshell.so; raises if it has not been built (there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise FemShellError(-2, "libfemshell.so is missing: build it with `make -C fem-shell_amd/csrc` "
+                                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(path)
+    dp, ip, bp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    vp = C.c_void_p
+    L.femshell_last_error.restype = C.c_char_p
+    L.femshell_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.femshell_destroy.argtypes = [vp]
+    L.femshell_set_mesh.argtypes = [vp, C.c_int32, dp, C.c_int32, ip, C.c_int32, ip]
+    L.femshell_set_dirichlet.argtypes = [vp, C.c_int32, ip, bp]
+    L.femshell_set_loads.argtypes = [vp, C.c_int32, ip, dp]
+    L.femshell_assemble.argtypes = [vp]
+    L.femshell_solve.argtypes = [vp, C.c_double, C.c_int32, dp, C.POINTER(SolveInfo)]
+    L.femshell_get_solution.argtypes = [vp, dp]
+    L.femshell_residual_history.argtypes = [vp, dp, C.c_int32]
+    L.femshell_residual_history.restype = C.c_int32
+    L.femshell_element_matrices.argtypes = [vp, C.c_int32, C.c_int32, dp]
+    L.femshell_nnz_blocks.argtypes = [vp]
+    L.femshell_nnz_blocks.restype = C.c_int64
+    L.femshell_export_bsr.argtypes = [vp, ip, ip, dp, dp]
+    L.femshell_spmv.argtypes = [vp, dp, dp]
+    L.femshell_row_begin.argtypes = [vp]
+    L.femshell_row_begin.restype = C.c_int32
+    L.femshell_row_end.argtypes = [vp]
+    L.femshell_row_end.restype = C.c_int32
+    L.femshell_comm_unique_id.argtypes = [bp]
+    L.femshell_comm_init.argtypes = [vp, bp]
+    L.femshell_time_kernel.argtypes = [vp, C.c_int, C.c_int32, dp, dp]
+    L.femshell_sync.argtypes = [vp]
+    for name in SYMBOLS:
+        if name != "femshell_last_error" and not name.startswith("femshell_nnz") and \
+                not name.startswith("femshell_row") and name != "femshell_residual_history":
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def _d(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def _b(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8)) if a is not None else None
+
+
+def _check(rc):
+    if rc != 0:
+        raise FemShellError(rc, load_library().femshell_last_error().decode())
+
+
+def comm_unique_id():
+    buf = np.zeros(128, dtype=np.uint8)
+    _check(load_library().femshell_comm_unique_id(_b(buf)))
+    return buf
+
+
+class FemShell:
+    """One context = one GPU = one rank of the row partition."""
+
+    def __init__(self, nu, E, thickness, flags=REF_DEFAULT, device=-1, rank=0, world_size=1):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        cfg = Config(float(nu), float(E), float(thickness), int(flags), int(device), int(rank), int(world_size))
+        _check(self._L.femshell_create(C.byref(cfg), C.byref(self._h)))
+        self.n_nodes = 0
+        self.n_tri = 0
+        self.n_quad = 0
+
+    def close(self):
+        if self._h:
+            self._L.femshell_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def comm_init(self, unique_id):
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        assert uid.size == 128
+        _check(self._L.femshell_comm_init(self._h, _b(uid)))
+
+    def set_mesh(self, xyz, tri=None, quad=None):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        tri = np.zeros((0, 3), np.int32) if tri is None else np.ascontiguousarray(tri, dtype=np.int32).reshape(-1, 3)
+        quad = np.zeros((0, 4), np.int32) if quad is None else np.ascontiguousarray(quad, dtype=np.int32).reshape(-1, 4)
+        _check(self._L.femshell_set_mesh(self._h, len(xyz), _d(xyz), len(tri), _i(tri), len(quad), _i(quad)))
+        self.n_nodes, self.n_tri, self.n_quad = len(xyz), len(tri), len(quad)
+
+    def set_dirichlet(self, mask, node_ids=None):
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        ids = None if node_ids is None else np.ascontiguousarray(node_ids, dtype=np.int32)
+        _check(self._L.femshell_set_dirichlet(self._h, len(mask), _i(ids), _b(mask)))
+
+    def set_loads(self, f6, node_ids=None):
+        f6 = np.ascontiguousarray(f6, dtype=np.float64).reshape(-1, 6)
+        ids = None if node_ids is None else np.ascontiguousarray(node_ids, dtype=np.int32)
+        _check(self._L.femshell_set_loads(self._h, len(f6), _i(ids), _d(f6)))
+
+    def assemble(self):
+        _check(self._L.femshell_assemble(self._h))
+
+    def solve(self, rtol=1e-10, max_it=10000, fetch=True):
+        u = np.zeros((self.n_nodes, 6)) if fetch else None
+        info = SolveInfo()
+        _check(self._L.femshell_solve(self._h, float(rtol), int(max_it), _d(u), C.byref(info)))
+        d = {f[0]: getattr(info, f[0]) for f in SolveInfo._fields_}
+        return u, d
+
+    def get_solution(self):
+        u = np.zeros((self.n_nodes, 6))
+        _check(self._L.femshell_get_solution(self._h, _d(u)))
+        return u
+
+    def residual_history(self, cap=1 << 20):
+        h = np.zeros(cap)
+        n = self._L.femshell_residual_history(self._h, _d(h), cap)
+        return h[:n].copy()
+
+    def element_matrices(self, first, count):
+        size = 324 if first < self.n_tri else 576
+        out = np.zeros((count, size))
+        _check(self._L.femshell_element_matrices(self._h, int(first), int(count), _d(out)))
+        n = 18 if size == 324 else 24
+        return out.reshape(count, n, n)
+
+    def nnz_blocks(self):
+        return int(self._L.femshell_nnz_blocks(self._h))
+
+    def export_bsr(self):
+        nb = self.nnz_blocks()
+        rowptr = np.zeros(self.n_nodes + 1, dtype=np.int32)
+        colidx = np.zeros(nb, dtype=np.int32)
+        vals = np.zeros((nb, 6, 6))
+        F = np.zeros(6 * self.n_nodes)
+        _check(self._L.femshell_export_bsr(self._h, _i(rowptr), _i(colidx), _d(vals), _d(F)))
+        return rowptr, colidx, vals, F
+
+    def spmv(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        y = np.zeros_like(x)
+        _check(self._L.femshell_spmv(self._h, _d(x), _d(y)))
+        return y
+
+    def row_range(self):
+        return int(self._L.femshell_row_begin(self._h)), int(self._L.femshell_row_end(self._h))
+
+    def time_kernel(self, which, reps=10):
+        ms = C.c_double()
+        by = C.c_double()
+        _check(self._L.femshell_time_kernel(self._h, int(which), int(reps), C.byref(ms), C.byref(by)))
+        return ms.value, by.value
+
+    def sync(self):
+        _check(self._L.femshell_sync(self._h))
+
+
+# ---- host-only plan inspection (include/femshell_plan.h); needs no GPU -----------------------
+
+PLAN_INFO = ["n_own", "n_pad", "n_ghost", "n_slices", "n_ltri", "n_lquad", "total_slots", "n_pairs",
+             "n_peers", "row_begin", "row_end", "nnz_blocks"]
+PLAN_ARRAYS = {
+    "ghost_global": (0, np.int32), "tri_local": (1, np.int32), "tri_global_id": (2, np.int32),
+    "quad_local": (3, np.int32), "quad_global_id": (4, np.int32), "slice_width": (5, np.int32),
+    "slice_base": (6, np.int64), "cols": (7, np.int32), "pair_ptr": (8, np.int32), "pairs": (9, np.uint32),
+    "xyz_local": (10, np.float64), "peer_ranks": (11, np.int32), "peer_recv_offset": (12, np.int32),
+    "peer_recv_count": (13, np.int32), "peer_send_ptr": (14, np.int32), "peer_send_nodes": (15, np.int32),
+}
+
+
+def build_plan(xyz, tri=None, quad=None, rank=0, world_size=1):
+    """Returns the symbolic plan of one rank as a dict of numpy arrays (CPU only)."""
+    L = load_library()
+    L.femshell_plan_create.argtypes = [C.c_int32, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_int32),
+                                       C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32,
+                                       C.POINTER(C.c_void_p)]
+    L.femshell_plan_create.restype = C.c_int
+    L.femshell_plan_destroy.argtypes = [C.c_void_p]
+    L.femshell_plan_destroy.restype = None
+    L.femshell_plan_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.femshell_plan_array.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.femshell_plan_array.restype = C.c_int64
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    tri = np.zeros((0, 3), np.int32) if tri is None else np.ascontiguousarray(tri, dtype=np.int32).reshape(-1, 3)
+    quad = np.zeros((0, 4), np.int32) if quad is None else np.ascontiguousarray(quad, dtype=np.int32).reshape(-1, 4)
+    h = C.c_void_p()
+    _check(L.femshell_plan_create(len(xyz), _d(xyz), len(tri), _i(tri), len(quad), _i(quad), rank, world_size,
+                                  C.byref(h)))
+    try:
+        info = np.zeros(len(PLAN_INFO), dtype=np.int64)
+        _check(L.femshell_plan_info(h, info.ctypes.data_as(C.POINTER(C.c_int64))))
+        out = {k: int(v) for k, v in zip(PLAN_INFO, info)}
+        for name, (which, dt) in PLAN_ARRAYS.items():
+            n = L.femshell_plan_array(h, which, None)
+            a = np.zeros(n, dtype=dt)
+            if n:
+                L.femshell_plan_array(h, which, a.ctypes.data_as(C.c_void_p))
+            out[name] = a
+    finally:
+        L.femshell_plan_destroy(h)
+    return out

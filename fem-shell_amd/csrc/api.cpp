@@ -1,0 +1,835 @@
+// api.cpp -- the C ABI of libfemshell (include/femshell.h): context, host<->HBM plumbing and
+// the CG driver.  All arithmetic of the hot path runs in the kernels of kernels.hip; there
+// is no CPU fallback anywhere in this library.
+#include "femshell.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "comm.hpp"
+#include "kernels.hpp"
+#include "plan.hpp"
+
+using namespace femshell;
+
+namespace {
+
+thread_local std::string g_err;
+
+int set_err(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define FS_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return set_err(FEMSHELL_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count)
+    {
+        if (count == n && p) return hipSuccess;
+        release();
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t upload(const std::vector<T> &h, hipStream_t st)
+    {
+        hipError_t e = alloc(h.size());
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st);
+    }
+    hipError_t zero(hipStream_t st) { return n ? hipMemsetAsync(p, 0, n * sizeof(T), st) : hipSuccess; }
+};
+
+} // namespace
+
+struct femshell_ctx {
+    femshell_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    MatConst mc{};
+    Plan plan;
+    bool have_mesh = false, matrix_valid = false, rhs_valid = false, jacobi_valid = false, have_solution = false;
+
+    std::vector<uint8_t> dmask_global;  // n_nodes
+    std::vector<double> loads_global;   // n_nodes*6
+
+    DevBuf<double> xyz, vals, minv, loads, F;
+    DevBuf<int32_t> tri, quad, slice_width, cols, pair_ptr, status;
+    DevBuf<int64_t> slice_base;
+    DevBuf<uint32_t> pairs;
+    DevBuf<uint8_t> dmask;
+    // CG state
+    DevBuf<double> x, r, z, p, q, partials, hist, sendbuf, ufull;
+    DevBuf<CgScalars> scal;
+    DevBuf<int32_t> send_nodes;
+    std::vector<int32_t> send_offsets; // per peer, in nodes
+    // scratch for femshell_time_kernel
+    DevBuf<double> bx, br, bz, bp, bq, bpart;
+    DevBuf<CgScalars> bscal;
+
+    DeviceMatrix dm{};
+    Comm comm;
+    std::vector<int32_t> all_begin, all_end;
+
+    double last_assemble_s = 0.0, last_setup_s = 0.0;
+    std::vector<double> hist_host;
+    int32_t last_iters = 0;
+};
+
+namespace {
+
+int select_device(femshell_ctx *c)
+{
+    FS_HIP(hipSetDevice(c->device));
+    return FEMSHELL_OK;
+}
+
+int64_t real_blocks(const femshell_ctx *c) { return c->plan.nnz_blocks; }
+
+double bytes_assemble(const femshell_ctx *c)
+{
+    const Plan &p = c->plan;
+    return 12.0 * p.n_ltri() + 16.0 * p.n_lquad() + 24.0 * (p.n_own + p.n_ghost) + 292.0 * (double)p.nnz_blocks +
+           4.0 * (p.n_own + 1) + 48.0 * p.n_own;
+}
+double bytes_spmv(const femshell_ctx *c)
+{
+    const Plan &p = c->plan;
+    return 292.0 * (double)p.nnz_blocks + 4.0 * (p.n_own + 1) + 96.0 * p.n_own;
+}
+double bytes_update(const femshell_ctx *c) { return (7.0 * 48.0 + 288.0) * c->plan.n_own; }
+double bytes_direction(const femshell_ctx *c) { return 3.0 * 48.0 * c->plan.n_own; }
+
+int check_status(femshell_ctx *c, const char *what)
+{
+    int32_t st = 0;
+    FS_HIP(hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(hipStreamSynchronize(c->stream));
+    if (st == 0) return FEMSHELL_OK;
+    FS_HIP(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), c->stream));
+    char buf[160];
+    if (st > 0) {
+        const int32_t le = st - 1;
+        const Plan &p = c->plan;
+        if (le < p.n_ltri())
+            snprintf(buf, sizeof buf, "%s: triangle %d is degenerate (zero area or zero-length first edge)", what,
+                     p.tri_global_id[le]);
+        else if (le - p.n_ltri() < p.n_lquad())
+            snprintf(buf, sizeof buf, "%s: quad %d is degenerate or QUAD4 is unsupported by this kernel", what,
+                     p.quad_global_id[le - p.n_ltri()]);
+        else
+            snprintf(buf, sizeof buf, "%s: element %d failed", what, le);
+        return set_err(FEMSHELL_ERR_MESH, buf);
+    }
+    snprintf(buf, sizeof buf, "%s: diagonal block of node %d is not positive definite", what,
+             c->plan.row_begin + (-st - 1));
+    return set_err(FEMSHELL_ERR_BREAKDOWN, buf);
+}
+
+// scatter the global per-node arrays into the rank-local numbering and upload
+int upload_node_data(femshell_ctx *c)
+{
+    const Plan &p = c->plan;
+    std::vector<uint8_t> dm((size_t)p.n_local_nodes(), 0);
+    std::vector<double> ld((size_t)p.n_pad * 6, 0.0);
+    for (int32_t a = 0; a < p.n_own; a++) {
+        dm[a] = c->dmask_global[p.row_begin + a];
+        std::memcpy(&ld[6ull * a], &c->loads_global[6ull * (p.row_begin + a)], 6 * sizeof(double));
+    }
+    for (int32_t g = 0; g < p.n_ghost; g++) dm[p.n_pad + g] = c->dmask_global[p.ghost_global[g]];
+    FS_HIP(c->dmask.upload(dm, c->stream));
+    FS_HIP(c->loads.upload(ld, c->stream));
+    FS_HIP(hipStreamSynchronize(c->stream)); // host vectors go out of scope
+    c->dm.dmask = c->dmask.p;
+    return FEMSHELL_OK;
+}
+
+int do_assemble(femshell_ctx *c)
+{
+    if (!c->have_mesh) return set_err(FEMSHELL_ERR_INVALID, "femshell_assemble: no mesh set");
+    int rc = select_device(c);
+    if (rc) return rc;
+    if (c->plan.n_lquad() > 0)
+        return set_err(FEMSHELL_ERR_UNSUPPORTED, "QUAD4 elements are not yet assembled on the device");
+    FS_HIP(hipEventRecord(c->ev0, c->stream));
+    launch_assemble(c->dm, c->mc, c->stream);
+    launch_rhs(c->dm, c->loads.p, c->F.p, c->stream);
+    FS_HIP(hipEventRecord(c->ev1, c->stream));
+    FS_HIP(hipGetLastError());
+    rc = check_status(c, "femshell_assemble");
+    if (rc) return rc;
+    float ms = 0.f;
+    FS_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_assemble_s = 1e-3 * ms;
+    c->matrix_valid = true;
+    c->rhs_valid = true;
+    c->jacobi_valid = false;
+    return FEMSHELL_OK;
+}
+
+int do_rhs(femshell_ctx *c)
+{
+    launch_rhs(c->dm, c->loads.p, c->F.p, c->stream);
+    FS_HIP(hipGetLastError());
+    c->rhs_valid = true;
+    return FEMSHELL_OK;
+}
+
+int do_jacobi(femshell_ctx *c)
+{
+    FS_HIP(hipEventRecord(c->ev0, c->stream));
+    launch_block_jacobi(c->dm, c->stream);
+    FS_HIP(hipEventRecord(c->ev1, c->stream));
+    FS_HIP(hipGetLastError());
+    int rc = check_status(c, "block-Jacobi setup");
+    if (rc) return rc;
+    float ms = 0.f;
+    FS_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_setup_s = 1e-3 * ms;
+    c->jacobi_valid = true;
+    return FEMSHELL_OK;
+}
+
+CgVectors cg_vectors(femshell_ctx *c)
+{
+    CgVectors v;
+    v.x = c->x.p;
+    v.r = c->r.p;
+    v.z = c->z.p;
+    v.p = c->p.p;
+    v.q = c->q.p;
+    v.b = c->F.p;
+    v.partials = c->partials.p;
+    v.s = c->scal.p;
+    v.hist = c->hist.p;
+    v.hist_cap = (int32_t)c->hist.n;
+    return v;
+}
+
+int halo_exchange(femshell_ctx *c, double *p)
+{
+    if (!c->comm.active() || c->plan.peers.empty()) return FEMSHELL_OK;
+    const Plan &pl = c->plan;
+    for (size_t i = 0; i < pl.peers.size(); i++)
+        launch_pack(p, c->send_nodes.p + c->send_offsets[i], (int32_t)pl.peers[i].send_nodes.size(),
+                    c->sendbuf.p + 6ll * c->send_offsets[i], c->stream);
+    std::string e;
+    if (!comm_halo(c->comm, pl.peers, c->send_offsets, c->sendbuf.p, p + 6ll * pl.n_pad, c->stream, &e))
+        return set_err(FEMSHELL_ERR_COMM, e);
+    return FEMSHELL_OK;
+}
+
+int scalar_step(femshell_ctx *c, const CgVectors &v, int nsums, CgPhase phase, double rtol)
+{
+    if (c->comm.active()) {
+        launch_cg_scalar(c->dm, v, true, nsums, CG_PHASE_NONE, rtol, c->stream);
+        std::string e;
+        double *red = reinterpret_cast<double *>(reinterpret_cast<char *>(v.s) + offsetof(CgScalars, red));
+        if (!comm_allreduce_sum(c->comm, red, nsums, c->stream, &e)) return set_err(FEMSHELL_ERR_COMM, e);
+        launch_cg_scalar(c->dm, v, false, nsums, phase, rtol, c->stream);
+    } else {
+        launch_cg_scalar(c->dm, v, true, nsums, phase, rtol, c->stream);
+    }
+    return FEMSHELL_OK;
+}
+
+} // namespace
+
+// =========================================================================================
+
+extern "C" {
+
+const char *femshell_last_error(void) { return g_err.c_str(); }
+
+int femshell_create(const femshell_config *cfg, femshell_ctx **out)
+{
+    if (!cfg || !out) return set_err(FEMSHELL_ERR_INVALID, "femshell_create: null argument");
+    *out = nullptr;
+    if (!(cfg->nu > -1.0 && cfg->nu < 0.5 + 1e-12) || !(cfg->E > 0.0) || !(cfg->thickness > 0.0))
+        return set_err(FEMSHELL_ERR_INVALID, "femshell_create: need -1 < nu <= 0.5, E > 0, thickness > 0");
+    if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size)
+        return set_err(FEMSHELL_ERR_INVALID, "femshell_create: invalid rank/world_size");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_err(FEMSHELL_ERR_NO_DEVICE, "femshell_create: no HIP device (this library has no CPU path)");
+    int dev = cfg->device;
+    if (dev < 0) FS_HIP(hipGetDevice(&dev));
+    if (dev >= ndev) return set_err(FEMSHELL_ERR_NO_DEVICE, "femshell_create: device ordinal out of range");
+    femshell_ctx *c = new femshell_ctx();
+    c->cfg = *cfg;
+    c->device = dev;
+    hipError_t e = hipSetDevice(dev);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = c->status.alloc(1);
+    if (e == hipSuccess) e = c->status.zero(c->stream);
+    if (e == hipSuccess) e = c->scal.alloc(1);
+    if (e == hipSuccess) e = c->scal.zero(c->stream);
+    if (e != hipSuccess) {
+        delete c;
+        return set_err(FEMSHELL_ERR_HIP, std::string("femshell_create: ") + hipGetErrorString(e));
+    }
+    const double nu = cfg->nu, E = cfg->E, t = cfg->thickness;
+    c->mc.cm = E / (1.0 - nu * nu);
+    c->mc.cp = E * t * t * t / (12.0 * (1.0 - nu * nu));
+    c->mc.nu = nu;
+    c->mc.g = (1.0 - nu) / 2.0;
+    c->mc.t = t;
+    c->mc.flags = cfg->flags;
+    c->mc.pad = 0;
+    *out = c;
+    return FEMSHELL_OK;
+}
+
+int femshell_destroy(femshell_ctx *c)
+{
+    if (!c) return FEMSHELL_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    comm_destroy(c->comm);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return FEMSHELL_OK;
+}
+
+int femshell_comm_unique_id(uint8_t id_out[128])
+{
+    std::string e;
+    if (!id_out) return set_err(FEMSHELL_ERR_INVALID, "femshell_comm_unique_id: null argument");
+    if (!comm_unique_id(id_out, &e)) return set_err(FEMSHELL_ERR_COMM, e);
+    return FEMSHELL_OK;
+}
+
+int femshell_comm_init(femshell_ctx *c, const uint8_t id[128])
+{
+    if (!c || !id) return set_err(FEMSHELL_ERR_INVALID, "femshell_comm_init: null argument");
+    if (c->cfg.world_size == 1) return FEMSHELL_OK;
+    int rc = select_device(c);
+    if (rc) return rc;
+    std::string e;
+    if (!comm_init(c->comm, id, c->cfg.rank, c->cfg.world_size, &e)) return set_err(FEMSHELL_ERR_COMM, e);
+    return FEMSHELL_OK;
+}
+
+int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri,
+                      int32_t n_quad, const int32_t *quad)
+{
+    if (!c || !xyz || (n_tri > 0 && !tri) || (n_quad > 0 && !quad))
+        return set_err(FEMSHELL_ERR_INVALID, "femshell_set_mesh: null argument");
+    if (c->cfg.world_size > 1 && !c->comm.active())
+        return set_err(FEMSHELL_ERR_INVALID, "femshell_set_mesh: call femshell_comm_init first on a multi-rank context");
+    int rc = select_device(c);
+    if (rc) return rc;
+    for (int64_t i = 0; i < 3ll * n_nodes; i++)
+        if (!std::isfinite(xyz[i])) return set_err(FEMSHELL_ERR_MESH, "femshell_set_mesh: non-finite coordinate");
+    std::string e;
+    c->have_mesh = false;
+    if (!build_plan(n_nodes, xyz, n_tri, tri, n_quad, quad, c->cfg.rank, c->cfg.world_size, &c->plan, &e))
+        return set_err(FEMSHELL_ERR_MESH, "femshell_set_mesh: " + e);
+    const Plan &p = c->plan;
+    hipStream_t st = c->stream;
+    FS_HIP(c->xyz.upload(p.xyz_local, st));
+    FS_HIP(c->tri.upload(p.tri_local, st));
+    FS_HIP(c->quad.upload(p.quad_local, st));
+    FS_HIP(c->slice_width.upload(p.slice_width, st));
+    FS_HIP(c->slice_base.upload(p.slice_base, st));
+    FS_HIP(c->cols.upload(p.cols, st));
+    FS_HIP(c->pair_ptr.upload(p.pair_ptr, st));
+    FS_HIP(c->pairs.upload(p.pairs, st));
+    const size_t nrow = (size_t)p.n_pad * 6, nrow_ext = (size_t)p.n_local_nodes() * 6;
+    FS_HIP(c->vals.alloc((size_t)p.total_slots() * 36));
+    FS_HIP(c->minv.alloc((size_t)p.n_slices * 6 * kSliceRows));
+    FS_HIP(c->F.alloc(nrow));
+    FS_HIP(c->x.alloc(nrow));
+    FS_HIP(c->r.alloc(nrow));
+    FS_HIP(c->z.alloc(nrow));
+    FS_HIP(c->q.alloc(nrow));
+    FS_HIP(c->p.alloc(nrow_ext));
+    FS_HIP(c->x.zero(st));
+    FS_HIP(c->p.zero(st));
+    FS_HIP(c->q.zero(st));
+    c->dm = DeviceMatrix();
+    c->dm.n_own = p.n_own;
+    c->dm.n_pad = p.n_pad;
+    c->dm.n_ghost = p.n_ghost;
+    c->dm.n_slices = p.n_slices;
+    c->dm.n_ltri = p.n_ltri();
+    c->dm.n_lquad = p.n_lquad();
+    c->dm.xyz = c->xyz.p;
+    c->dm.tri = c->tri.p;
+    c->dm.quad = c->quad.p;
+    c->dm.slice_width = c->slice_width.p;
+    c->dm.slice_base = c->slice_base.p;
+    c->dm.cols = c->cols.p;
+    c->dm.pair_ptr = c->pair_ptr.p;
+    c->dm.pairs = c->pairs.p;
+    c->dm.vals = c->vals.p;
+    c->dm.minv = c->minv.p;
+    c->dm.status = c->status.p;
+    FS_HIP(c->partials.alloc(2 * (size_t)slice_grid(c->dm)));
+    // halo lists
+    c->send_offsets.clear();
+    std::vector<int32_t> flat;
+    for (const HaloPeer &h : p.peers) {
+        c->send_offsets.push_back((int32_t)flat.size());
+        flat.insert(flat.end(), h.send_nodes.begin(), h.send_nodes.end());
+    }
+    FS_HIP(c->send_nodes.upload(flat, st));
+    FS_HIP(c->sendbuf.alloc(flat.size() * 6));
+    c->all_begin.resize(p.world);
+    c->all_end.resize(p.world);
+    for (int r = 0; r < p.world; r++) partition_rows(n_nodes, p.world, r, &c->all_begin[r], &c->all_end[r]);
+    c->dmask_global.assign((size_t)n_nodes, 0);
+    c->loads_global.assign((size_t)n_nodes * 6, 0.0);
+    rc = upload_node_data(c);
+    if (rc) return rc;
+    FS_HIP(hipStreamSynchronize(st));
+    c->have_mesh = true;
+    c->matrix_valid = c->rhs_valid = c->jacobi_valid = c->have_solution = false;
+    return FEMSHELL_OK;
+}
+
+int femshell_set_dirichlet(femshell_ctx *c, int32_t n, const int32_t *node_ids, const uint8_t *mask6)
+{
+    if (!c || (n > 0 && !mask6)) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_dirichlet: null argument");
+    if (!c->have_mesh) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_dirichlet: call femshell_set_mesh first");
+    const int32_t nn = c->plan.n_nodes;
+    if (!node_ids && n != nn) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_dirichlet: dense form needs n == n_nodes");
+    std::vector<uint8_t> m((size_t)nn, 0);
+    for (int32_t i = 0; i < n; i++) {
+        const int32_t a = node_ids ? node_ids[i] : i;
+        if (a < 0 || a >= nn) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_dirichlet: node id out of range");
+        if (mask6[i] & ~0x3Fu) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_dirichlet: mask has bits above dof 5");
+        m[a] |= mask6[i];
+    }
+    int rc = select_device(c);
+    if (rc) return rc;
+    c->dmask_global.swap(m);
+    rc = upload_node_data(c);
+    if (rc) return rc;
+    c->matrix_valid = c->rhs_valid = c->jacobi_valid = false;
+    return FEMSHELL_OK;
+}
+
+int femshell_set_loads(femshell_ctx *c, int32_t n, const int32_t *node_ids, const double *f6)
+{
+    if (!c || (n > 0 && !f6)) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_loads: null argument");
+    if (!c->have_mesh) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_loads: call femshell_set_mesh first");
+    const int32_t nn = c->plan.n_nodes;
+    if (!node_ids && n != nn) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_loads: dense form needs n == n_nodes");
+    std::vector<double> l((size_t)nn * 6, 0.0);
+    for (int32_t i = 0; i < n; i++) {
+        const int32_t a = node_ids ? node_ids[i] : i;
+        if (a < 0 || a >= nn) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_loads: node id out of range");
+        for (int v = 0; v < 6; v++) {
+            if (!std::isfinite(f6[6ll * i + v])) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_loads: non-finite load");
+            l[6ull * a + v] = f6[6ll * i + v];
+        }
+    }
+    int rc = select_device(c);
+    if (rc) return rc;
+    c->loads_global.swap(l);
+    rc = upload_node_data(c);
+    if (rc) return rc;
+    c->rhs_valid = false;
+    return FEMSHELL_OK;
+}
+
+int femshell_assemble(femshell_ctx *c)
+{
+    if (!c) return set_err(FEMSHELL_ERR_INVALID, "femshell_assemble: null context");
+    return do_assemble(c);
+}
+
+int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, femshell_solve_info *info)
+{
+    if (!c) return set_err(FEMSHELL_ERR_INVALID, "femshell_solve: null context");
+    if (!c->have_mesh) return set_err(FEMSHELL_ERR_INVALID, "femshell_solve: no mesh set");
+    if (max_it < 0) return set_err(FEMSHELL_ERR_INVALID, "femshell_solve: max_it < 0");
+    int rc = select_device(c);
+    if (rc) return rc;
+    double asm_s = 0.0;
+    if (!c->matrix_valid || (c->cfg.flags & FEMSHELL_REASSEMBLE_EACH_SOLVE)) {
+        rc = do_assemble(c);
+        if (rc) return rc;
+        asm_s = c->last_assemble_s;
+    } else if (!c->rhs_valid) {
+        rc = do_rhs(c);
+        if (rc) return rc;
+    }
+    double setup_s = 0.0;
+    if (!c->jacobi_valid) {
+        rc = do_jacobi(c);
+        if (rc) return rc;
+        setup_s = c->last_setup_s;
+    }
+    hipStream_t st = c->stream;
+    FS_HIP(c->hist.alloc((size_t)std::max(max_it, 1)));
+    CgVectors v = cg_vectors(c);
+    const DeviceMatrix &m = c->dm;
+
+    FS_HIP(hipEventRecord(c->ev0, st));
+    launch_cg_init(m, v, st);
+    rc = scalar_step(c, v, 2, CG_PHASE_INIT, rtol);
+    if (rc) return rc;
+    CgScalars hs{};
+    int32_t next_check = 8;
+    for (int32_t it = 0; it < max_it; it++) {
+        rc = halo_exchange(c, v.p);
+        if (rc) return rc;
+        launch_spmv(m, v.p, v.q, v.partials, v.s, st);
+        rc = scalar_step(c, v, 1, CG_PHASE_ALPHA, rtol);
+        if (rc) return rc;
+        launch_cg_update(m, v, st);
+        rc = scalar_step(c, v, 2, CG_PHASE_BETA, rtol);
+        if (rc) return rc;
+        launch_cg_direction(m, v, st);
+        if (it + 1 == next_check && it + 1 < max_it) {
+            FS_HIP(hipMemcpyAsync(&hs, v.s, sizeof hs, hipMemcpyDeviceToHost, st));
+            FS_HIP(hipStreamSynchronize(st));
+            if (hs.done != 0) break;
+            next_check += (next_check < 64) ? next_check : 64;
+        }
+    }
+    FS_HIP(hipEventRecord(c->ev1, st));
+    FS_HIP(hipMemcpyAsync(&hs, v.s, sizeof hs, hipMemcpyDeviceToHost, st));
+    FS_HIP(hipStreamSynchronize(st));
+    FS_HIP(hipGetLastError());
+    float ms = 0.f;
+    FS_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_iters = hs.iters;
+    c->hist_host.assign((size_t)std::min<int32_t>(hs.iters, max_it), 0.0);
+    if (!c->hist_host.empty())
+        FS_HIP(hipMemcpy(c->hist_host.data(), c->hist.p, c->hist_host.size() * sizeof(double), hipMemcpyDeviceToHost));
+    c->have_solution = true;
+    if (info) {
+        info->iterations = hs.iters;
+        info->converged = hs.done == 1 ? 1 : 0;
+        info->rel_residual = hs.bb > 0.0 ? std::sqrt(hs.rr / hs.bb) : 0.0;
+        info->assemble_seconds = asm_s;
+        info->setup_seconds = setup_s;
+        info->solve_seconds = 1e-3 * ms;
+        info->bytes_per_iteration = bytes_spmv(c) + bytes_update(c) + bytes_direction(c);
+    }
+    if (hs.done < 0)
+        return set_err(FEMSHELL_ERR_BREAKDOWN, "femshell_solve: CG breakdown, p.Ap <= 0 (matrix not positive definite)");
+    if (u_out) return femshell_get_solution(c, u_out);
+    return FEMSHELL_OK;
+}
+
+int femshell_get_solution(femshell_ctx *c, double *u_out)
+{
+    if (!c || !u_out) return set_err(FEMSHELL_ERR_INVALID, "femshell_get_solution: null argument");
+    if (!c->have_solution) return set_err(FEMSHELL_ERR_INVALID, "femshell_get_solution: no solve has run");
+    int rc = select_device(c);
+    if (rc) return rc;
+    const Plan &p = c->plan;
+    if (!c->comm.active()) {
+        FS_HIP(hipMemcpyAsync(u_out, c->x.p, (size_t)p.n_own * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        FS_HIP(hipStreamSynchronize(c->stream));
+        return FEMSHELL_OK;
+    }
+    FS_HIP(c->ufull.alloc((size_t)p.n_nodes * 6));
+    std::string e;
+    if (!comm_gather_rows(c->comm, c->x.p, c->ufull.p, c->all_begin, c->all_end, c->stream, &e))
+        return set_err(FEMSHELL_ERR_COMM, e);
+    FS_HIP(hipMemcpyAsync(u_out, c->ufull.p, (size_t)p.n_nodes * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(hipStreamSynchronize(c->stream));
+    return FEMSHELL_OK;
+}
+
+int32_t femshell_residual_history(femshell_ctx *c, double *hist, int32_t cap)
+{
+    if (!c || !hist || cap < 0) return 0;
+    const int32_t n = std::min<int32_t>(cap, (int32_t)c->hist_host.size());
+    for (int32_t i = 0; i < n; i++) hist[i] = std::sqrt(c->hist_host[i]);
+    return n;
+}
+
+int femshell_element_matrices(femshell_ctx *c, int32_t first, int32_t count, double *Ke_out)
+{
+    if (!c || !Ke_out) return set_err(FEMSHELL_ERR_INVALID, "femshell_element_matrices: null argument");
+    if (!c->have_mesh) return set_err(FEMSHELL_ERR_INVALID, "femshell_element_matrices: no mesh set");
+    if (c->cfg.world_size != 1) return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_element_matrices: single-rank contexts only");
+    const Plan &p = c->plan;
+    if (first < 0 || count < 0 || (int64_t)first + count > (int64_t)p.n_tri + p.n_quad)
+        return set_err(FEMSHELL_ERR_INVALID, "femshell_element_matrices: range out of bounds");
+    if (count == 0) return FEMSHELL_OK;
+    const bool quads = first >= p.n_tri;
+    if (!quads && first + count > p.n_tri)
+        return set_err(FEMSHELL_ERR_INVALID, "femshell_element_matrices: range mixes triangles and quads");
+    if (quads) return set_err(FEMSHELL_ERR_UNSUPPORTED, "QUAD4 elements are not yet computed on the device");
+    int rc = select_device(c);
+    if (rc) return rc;
+    DevBuf<double> out;
+    FS_HIP(out.alloc((size_t)count * 324));
+    launch_element_matrices(c->dm, c->mc, first, count, out.p, c->stream);
+    FS_HIP(hipGetLastError());
+    rc = check_status(c, "femshell_element_matrices");
+    if (rc) return rc;
+    FS_HIP(hipMemcpy(Ke_out, out.p, (size_t)count * 324 * sizeof(double), hipMemcpyDeviceToHost));
+    return FEMSHELL_OK;
+}
+
+int64_t femshell_nnz_blocks(femshell_ctx *c) { return (c && c->have_mesh) ? real_blocks(c) : 0; }
+
+int femshell_export_bsr(femshell_ctx *c, int32_t *rowptr, int32_t *colidx, double *vals, double *F)
+{
+    if (!c || !rowptr || !colidx || !vals) return set_err(FEMSHELL_ERR_INVALID, "femshell_export_bsr: null argument");
+    if (!c->matrix_valid) return set_err(FEMSHELL_ERR_INVALID, "femshell_export_bsr: call femshell_assemble first");
+    if (c->cfg.world_size != 1) return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_export_bsr: single-rank contexts only");
+    int rc = select_device(c);
+    if (rc) return rc;
+    const Plan &p = c->plan;
+    std::vector<double> h((size_t)p.total_slots() * 36);
+    FS_HIP(hipMemcpyAsync(h.data(), c->vals.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (F) {
+        if (!c->rhs_valid) {
+            rc = do_rhs(c);
+            if (rc) return rc;
+        }
+        FS_HIP(hipMemcpyAsync(F, c->F.p, (size_t)p.n_own * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    FS_HIP(hipStreamSynchronize(c->stream));
+    int64_t nb = 0;
+    rowptr[0] = 0;
+    std::vector<std::pair<int32_t, int>> order;
+    for (int32_t a = 0; a < p.n_own; a++) {
+        const int s = a / kSliceNodes, n = a % kSliceNodes;
+        const int64_t base = p.slice_base[s];
+        order.clear();
+        for (int k = 0; k < p.slice_width[s]; k++) {
+            const int64_t slot = Plan::slot_index(base, k, n);
+            if (p.pair_ptr[slot + 1] > p.pair_ptr[slot]) order.push_back({p.cols[slot], k});
+        }
+        std::sort(order.begin(), order.end());
+        for (auto &ck : order) {
+            colidx[nb] = ck.first; // single rank: local id == global id
+            double *blk = vals + 36 * nb;
+            const double *src = h.data() + base * 36;
+            for (int i = 0; i < 6; i++)
+                for (int j = 0; j < 6; j++)
+                    blk[6 * i + j] = src[(((int64_t)ck.second * 3 + j / 2) * kSliceRows + n * 6 + i) * 2 + (j & 1)];
+            nb++;
+        }
+        rowptr[a + 1] = (int32_t)nb;
+    }
+    return FEMSHELL_OK;
+}
+
+int femshell_spmv(femshell_ctx *c, const double *x, double *y)
+{
+    if (!c || !x || !y) return set_err(FEMSHELL_ERR_INVALID, "femshell_spmv: null argument");
+    if (!c->matrix_valid) return set_err(FEMSHELL_ERR_INVALID, "femshell_spmv: call femshell_assemble first");
+    if (c->cfg.world_size != 1) return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_spmv: single-rank contexts only");
+    int rc = select_device(c);
+    if (rc) return rc;
+    const Plan &p = c->plan;
+    DevBuf<double> dx, dy;
+    FS_HIP(dx.alloc((size_t)p.n_local_nodes() * 6));
+    FS_HIP(dy.alloc((size_t)p.n_pad * 6));
+    FS_HIP(dx.zero(c->stream));
+    FS_HIP(hipMemcpyAsync(dx.p, x, (size_t)p.n_own * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    launch_spmv(c->dm, dx.p, dy.p, nullptr, nullptr, c->stream);
+    FS_HIP(hipGetLastError());
+    FS_HIP(hipMemcpyAsync(y, dy.p, (size_t)p.n_own * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(hipStreamSynchronize(c->stream));
+    return FEMSHELL_OK;
+}
+
+int32_t femshell_row_begin(femshell_ctx *c) { return (c && c->have_mesh) ? c->plan.row_begin : 0; }
+int32_t femshell_row_end(femshell_ctx *c) { return (c && c->have_mesh) ? c->plan.row_end : 0; }
+
+int femshell_time_kernel(femshell_ctx *c, femshell_kernel which, int32_t reps, double *mean_ms_out, double *bytes_out)
+{
+    if (!c || !mean_ms_out) return set_err(FEMSHELL_ERR_INVALID, "femshell_time_kernel: null argument");
+    if (!c->have_mesh || reps <= 0) return set_err(FEMSHELL_ERR_INVALID, "femshell_time_kernel: no mesh or reps <= 0");
+    int rc = select_device(c);
+    if (rc) return rc;
+    if (which != FEMSHELL_KERNEL_ASSEMBLE && !c->matrix_valid) {
+        rc = do_assemble(c);
+        if (rc) return rc;
+    }
+    if (which != FEMSHELL_KERNEL_ASSEMBLE && !c->rhs_valid) {
+        rc = do_rhs(c);
+        if (rc) return rc;
+    }
+    if (which != FEMSHELL_KERNEL_ASSEMBLE && !c->jacobi_valid) {
+        rc = do_jacobi(c);
+        if (rc) return rc;
+    }
+    hipStream_t st = c->stream;
+    const Plan &p = c->plan;
+    const size_t nrow = (size_t)p.n_pad * 6, nrow_ext = (size_t)p.n_local_nodes() * 6;
+    CgVectors v;
+    if (which != FEMSHELL_KERNEL_ASSEMBLE) {
+        FS_HIP(c->bx.alloc(nrow));
+        FS_HIP(c->br.alloc(nrow));
+        FS_HIP(c->bz.alloc(nrow));
+        FS_HIP(c->bq.alloc(nrow));
+        FS_HIP(c->bp.alloc(nrow_ext));
+        FS_HIP(c->bpart.alloc(2 * (size_t)slice_grid(c->dm)));
+        FS_HIP(c->bscal.alloc(1));
+        v.x = c->bx.p; v.r = c->br.p; v.z = c->bz.p; v.p = c->bp.p; v.q = c->bq.p;
+        v.b = c->F.p; v.partials = c->bpart.p; v.s = c->bscal.p; v.hist = nullptr; v.hist_cap = 0;
+        FS_HIP(c->bp.zero(st));
+        launch_cg_init(c->dm, v, st);                       // x=0, r=b, z=M^-1 b, p=z
+        launch_cg_scalar(c->dm, v, true, 2, CG_PHASE_INIT, 0.0, st);
+        launch_spmv(c->dm, v.p, v.q, v.partials, v.s, st);  // q = A p
+        launch_cg_scalar(c->dm, v, true, 1, CG_PHASE_ALPHA, 0.0, st);
+    }
+    FS_HIP(hipStreamSynchronize(st));
+    FS_HIP(hipEventRecord(c->ev0, st));
+    double bytes = 0.0;
+    for (int32_t i = 0; i < reps; i++) {
+        switch (which) {
+        case FEMSHELL_KERNEL_ASSEMBLE: launch_assemble(c->dm, c->mc, st); bytes = bytes_assemble(c); break;
+        case FEMSHELL_KERNEL_SPMV: launch_spmv(c->dm, v.p, v.q, v.partials, v.s, st); bytes = bytes_spmv(c); break;
+        case FEMSHELL_KERNEL_CG_UPDATE: launch_cg_update(c->dm, v, st); bytes = bytes_update(c); break;
+        case FEMSHELL_KERNEL_CG_DIRECTION: launch_cg_direction(c->dm, v, st); bytes = bytes_direction(c); break;
+        default: return set_err(FEMSHELL_ERR_INVALID, "femshell_time_kernel: unknown kernel");
+        }
+    }
+    FS_HIP(hipEventRecord(c->ev1, st));
+    FS_HIP(hipStreamSynchronize(st));
+    FS_HIP(hipGetLastError());
+    float ms = 0.f;
+    FS_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *mean_ms_out = (double)ms / reps;
+    if (bytes_out) *bytes_out = bytes;
+    if (which == FEMSHELL_KERNEL_ASSEMBLE) {
+        rc = check_status(c, "femshell_time_kernel");
+        if (rc) return rc;
+        c->matrix_valid = true;
+        c->jacobi_valid = false;
+    }
+    return FEMSHELL_OK;
+}
+
+int femshell_sync(femshell_ctx *c)
+{
+    if (!c) return set_err(FEMSHELL_ERR_INVALID, "femshell_sync: null context");
+    int rc = select_device(c);
+    if (rc) return rc;
+    FS_HIP(hipStreamSynchronize(c->stream));
+    return FEMSHELL_OK;
+}
+
+} // extern "C"
+
+// =========================================================================================
+// host-only plan inspection (include/femshell_plan.h); touches no GPU state
+// =========================================================================================
+#include "femshell_plan.h"
+
+struct femshell_plan {
+    Plan p;
+};
+
+extern "C" {
+
+int femshell_plan_create(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri, int32_t n_quad,
+                         const int32_t *quad, int32_t rank, int32_t world_size, femshell_plan **out)
+{
+    if (!out || !xyz) return set_err(FEMSHELL_ERR_INVALID, "femshell_plan_create: null argument");
+    *out = nullptr;
+    femshell_plan *pl = new femshell_plan();
+    std::string e;
+    if (!build_plan(n_nodes, xyz, n_tri, tri, n_quad, quad, rank, world_size, &pl->p, &e)) {
+        delete pl;
+        return set_err(FEMSHELL_ERR_MESH, "femshell_plan_create: " + e);
+    }
+    *out = pl;
+    return FEMSHELL_OK;
+}
+
+void femshell_plan_destroy(femshell_plan *plan) { delete plan; }
+
+int femshell_plan_info(const femshell_plan *plan, int64_t *info)
+{
+    if (!plan || !info) return set_err(FEMSHELL_ERR_INVALID, "femshell_plan_info: null argument");
+    const Plan &p = plan->p;
+    info[FEMSHELL_PLAN_N_OWN] = p.n_own;
+    info[FEMSHELL_PLAN_N_PAD] = p.n_pad;
+    info[FEMSHELL_PLAN_N_GHOST] = p.n_ghost;
+    info[FEMSHELL_PLAN_N_SLICES] = p.n_slices;
+    info[FEMSHELL_PLAN_N_LTRI] = p.n_ltri();
+    info[FEMSHELL_PLAN_N_LQUAD] = p.n_lquad();
+    info[FEMSHELL_PLAN_TOTAL_SLOTS] = p.total_slots();
+    info[FEMSHELL_PLAN_N_PAIRS] = (int64_t)p.pairs.size();
+    info[FEMSHELL_PLAN_N_PEERS] = (int64_t)p.peers.size();
+    info[FEMSHELL_PLAN_ROW_BEGIN] = p.row_begin;
+    info[FEMSHELL_PLAN_ROW_END] = p.row_end;
+    info[FEMSHELL_PLAN_NNZ_BLOCKS] = p.nnz_blocks;
+    return FEMSHELL_OK;
+}
+
+int64_t femshell_plan_array(const femshell_plan *plan, int which, void *out)
+{
+    if (!plan) return -1;
+    const Plan &p = plan->p;
+    auto give = [&](const auto &v) -> int64_t {
+        if (out && !v.empty()) std::memcpy(out, v.data(), v.size() * sizeof(v[0]));
+        return (int64_t)v.size();
+    };
+    std::vector<int32_t> tmp;
+    switch (which) {
+    case FEMSHELL_PLAN_GHOST_GLOBAL: return give(p.ghost_global);
+    case FEMSHELL_PLAN_TRI_LOCAL: return give(p.tri_local);
+    case FEMSHELL_PLAN_TRI_GLOBAL_ID: return give(p.tri_global_id);
+    case FEMSHELL_PLAN_QUAD_LOCAL: return give(p.quad_local);
+    case FEMSHELL_PLAN_QUAD_GLOBAL_ID: return give(p.quad_global_id);
+    case FEMSHELL_PLAN_SLICE_WIDTH: return give(p.slice_width);
+    case FEMSHELL_PLAN_SLICE_BASE: return give(p.slice_base);
+    case FEMSHELL_PLAN_COLS: return give(p.cols);
+    case FEMSHELL_PLAN_PAIR_PTR: return give(p.pair_ptr);
+    case FEMSHELL_PLAN_PAIRS: return give(p.pairs);
+    case FEMSHELL_PLAN_XYZ_LOCAL: return give(p.xyz_local);
+    case FEMSHELL_PLAN_PEER_RANKS:
+        for (auto &h : p.peers) tmp.push_back(h.rank);
+        return give(tmp);
+    case FEMSHELL_PLAN_PEER_RECV_OFFSET:
+        for (auto &h : p.peers) tmp.push_back(h.recv_offset);
+        return give(tmp);
+    case FEMSHELL_PLAN_PEER_RECV_COUNT:
+        for (auto &h : p.peers) tmp.push_back(h.recv_count);
+        return give(tmp);
+    case FEMSHELL_PLAN_PEER_SEND_PTR:
+        tmp.push_back(0);
+        for (auto &h : p.peers) tmp.push_back(tmp.back() + (int32_t)h.send_nodes.size());
+        return give(tmp);
+    case FEMSHELL_PLAN_PEER_SEND_NODES:
+        for (auto &h : p.peers) tmp.insert(tmp.end(), h.send_nodes.begin(), h.send_nodes.end());
+        return give(tmp);
+    default: return -1;
+    }
+}
+
+} // extern "C"

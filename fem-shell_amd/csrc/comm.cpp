@@ -1,0 +1,142 @@
+// comm.cpp -- RCCL wiring (see comm.hpp).
+#include "comm.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+namespace femshell {
+
+namespace {
+
+struct Api {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+Api g_api;
+
+bool load_api(std::string *err)
+{
+    if (g_api.lib) return true;
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) {
+        if (err) *err = std::string("cannot open librccl: ") + dlerror();
+        return false;
+    }
+    Api a;
+    a.lib = lib;
+#define FS_SYM(name)                                                              \
+    a.name = reinterpret_cast<decltype(a.name)>(dlsym(lib, "nccl" #name));         \
+    if (!a.name) {                                                                \
+        if (err) *err = "librccl lacks nccl" #name;                               \
+        return false;                                                             \
+    }
+    FS_SYM(GetUniqueId)
+    FS_SYM(CommInitRank)
+    FS_SYM(CommDestroy)
+    FS_SYM(AllReduce)
+    FS_SYM(Broadcast)
+    FS_SYM(Send)
+    FS_SYM(Recv)
+    FS_SYM(GroupStart)
+    FS_SYM(GroupEnd)
+    FS_SYM(GetErrorString)
+#undef FS_SYM
+    g_api = a;
+    return true;
+}
+
+bool check(ncclResult_t r, const char *what, std::string *err)
+{
+    if (r == ncclSuccess) return true;
+    if (err) *err = std::string(what) + ": " + (g_api.GetErrorString ? g_api.GetErrorString(r) : "rccl error");
+    return false;
+}
+
+} // namespace
+
+bool comm_unique_id(uint8_t id_out[128], std::string *err)
+{
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    if (!load_api(err)) return false;
+    ncclUniqueId id;
+    if (!check(g_api.GetUniqueId(&id), "ncclGetUniqueId", err)) return false;
+    std::memcpy(id_out, &id, 128);
+    return true;
+}
+
+bool comm_init(Comm &c, const uint8_t id_bytes[128], int rank, int world, std::string *err)
+{
+    if (!load_api(err)) return false;
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, 128);
+    ncclComm_t comm = nullptr;
+    if (!check(g_api.CommInitRank(&comm, world, id, rank), "ncclCommInitRank", err)) return false;
+    c.lib = g_api.lib;
+    c.comm = comm;
+    c.rank = rank;
+    c.world = world;
+    return true;
+}
+
+void comm_destroy(Comm &c)
+{
+    if (c.comm && g_api.CommDestroy) g_api.CommDestroy(static_cast<ncclComm_t>(c.comm));
+    c.comm = nullptr;
+}
+
+bool comm_allreduce_sum(Comm &c, double *buf, int count, hipStream_t st, std::string *err)
+{
+    return check(g_api.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, static_cast<ncclComm_t>(c.comm), st),
+                 "ncclAllReduce", err);
+}
+
+bool comm_halo(Comm &c, const std::vector<HaloPeer> &peers, const std::vector<int32_t> &send_offsets,
+               const double *sendbuf, double *p_ghost, hipStream_t st, std::string *err)
+{
+    ncclComm_t comm = static_cast<ncclComm_t>(c.comm);
+    if (!check(g_api.GroupStart(), "ncclGroupStart", err)) return false;
+    bool ok = true;
+    for (size_t i = 0; i < peers.size() && ok; i++) {
+        const HaloPeer &h = peers[i];
+        if (!h.send_nodes.empty())
+            ok = check(g_api.Send(sendbuf + 6ll * send_offsets[i], 6 * h.send_nodes.size(), ncclDouble, h.rank, comm, st),
+                       "ncclSend", err);
+        if (ok && h.recv_count > 0)
+            ok = check(g_api.Recv(p_ghost + 6ll * h.recv_offset, 6 * (size_t)h.recv_count, ncclDouble, h.rank, comm, st),
+                       "ncclRecv", err);
+    }
+    const bool ended = check(g_api.GroupEnd(), "ncclGroupEnd", ok ? err : nullptr);
+    return ok && ended;
+}
+
+bool comm_gather_rows(Comm &c, const double *x_owned, double *full, const std::vector<int32_t> &row_begin,
+                      const std::vector<int32_t> &row_end, hipStream_t st, std::string *err)
+{
+    ncclComm_t comm = static_cast<ncclComm_t>(c.comm);
+    if (!check(g_api.GroupStart(), "ncclGroupStart", err)) return false;
+    bool ok = true;
+    for (int r = 0; r < c.world && ok; r++) {
+        const size_t cnt = 6 * (size_t)(row_end[r] - row_begin[r]);
+        if (cnt == 0) continue;
+        double *dst = full + 6ll * row_begin[r];
+        ok = check(g_api.Broadcast(r == c.rank ? x_owned : dst, dst, cnt, ncclDouble, r, comm, st), "ncclBroadcast", err);
+    }
+    const bool ended = check(g_api.GroupEnd(), "ncclGroupEnd", ok ? err : nullptr);
+    return ok && ended;
+}
+
+} // namespace femshell

@@ -1,0 +1,46 @@
+// comm.hpp -- RCCL (xGMI) communication of the row-partitioned solve.
+//
+// Replaces the implicit MPI traffic of the reference: PETSc's VecScatter halo exchange and
+// MPI_Allreduce inside KSPSolve, and the gather/broadcast of build_solution_vector
+// (fem-shell.cpp:141; fem-shell_precice.cpp:274-280).  Assembly needs no communication
+// (interface elements are recomputed on both sides), so there is no counterpart of PETSc's
+// MatSetValues stash exchange.
+//
+// librccl is opened with dlopen when a multi-rank context initialises its communicator, so
+// single-GPU use has no RCCL dependency.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "plan.hpp"
+
+namespace femshell {
+
+struct Comm {
+    void *lib = nullptr;
+    void *comm = nullptr; // ncclComm_t
+    int rank = 0, world = 1;
+    bool active() const { return comm != nullptr; }
+};
+
+bool comm_unique_id(uint8_t id_out[128], std::string *err);
+bool comm_init(Comm &c, const uint8_t id[128], int rank, int world, std::string *err);
+void comm_destroy(Comm &c);
+
+// in-place sum of `count` doubles across ranks, stream-ordered
+bool comm_allreduce_sum(Comm &c, double *buf, int count, hipStream_t st, std::string *err);
+
+// one grouped send/recv per peer: sendbuf holds the packed owned entries peer after peer
+// (send_offsets in nodes), ghosts of `p` start at p + 6*n_pad
+bool comm_halo(Comm &c, const std::vector<HaloPeer> &peers, const std::vector<int32_t> &send_offsets,
+               const double *sendbuf, double *p_ghost, hipStream_t st, std::string *err);
+
+// all ranks receive every rank's owned rows: full[6*row_begin(r) ...] <- rank r's x
+bool comm_gather_rows(Comm &c, const double *x_owned, double *full, const std::vector<int32_t> &row_begin,
+                      const std::vector<int32_t> &row_end, hipStream_t st, std::string *err);
+
+} // namespace femshell

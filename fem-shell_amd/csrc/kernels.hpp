@@ -1,0 +1,83 @@
+// kernels.hpp -- host-callable launchers of the gfx950 kernels (defined in kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "shell_element.hpp"
+
+namespace femshell {
+
+// Device view of the mesh + matrix structure of one rank (see plan.hpp for the layout).
+struct DeviceMatrix {
+    int32_t n_own = 0, n_pad = 0, n_ghost = 0, n_slices = 0;
+    int32_t n_ltri = 0, n_lquad = 0;
+    const double *xyz = nullptr;        // (n_pad+n_ghost) x 3
+    const int32_t *tri = nullptr;       // n_ltri x 3, local node ids
+    const int32_t *quad = nullptr;      // n_lquad x 4
+    const int32_t *slice_width = nullptr;
+    const int64_t *slice_base = nullptr;
+    const int32_t *cols = nullptr;      // per slot
+    const int32_t *pair_ptr = nullptr;  // per slot + 1
+    const uint32_t *pairs = nullptr;
+    const uint8_t *dmask = nullptr;     // per local node (owned, padding, ghosts)
+    double *vals = nullptr;             // total_slots x 36, sliced layout
+    double *minv = nullptr;             // n_slices x 6 x 192: inverse diagonal blocks
+    int32_t *status = nullptr;          // device int: 0 ok, e+1 = first degenerate local element,
+                                        // -(node+1) = singular diagonal block
+};
+
+// Scalars of the CG recurrence, resident in HBM (no host round trip per iteration).
+struct CgScalars {
+    double rz;     // r.z of the current iterate
+    double alpha;
+    double beta;
+    double rr;     // r.r
+    double bb;     // b.b
+    double tol2;   // rtol^2 * b.b
+    double red[2]; // local sums before / global sums after the all-reduce
+    int32_t done;  // 0 running, 1 converged, -1 breakdown
+    int32_t iters; // iterations performed
+};
+
+struct CgVectors {
+    double *x = nullptr;  // solution, n_pad*6
+    double *r = nullptr;  // residual
+    double *z = nullptr;  // preconditioned residual
+    double *p = nullptr;  // search direction, (n_pad+n_ghost)*6 (ghost part filled by the halo exchange)
+    double *q = nullptr;  // A p
+    const double *b = nullptr; // right-hand side
+    double *partials = nullptr; // 2 x grid doubles
+    CgScalars *s = nullptr;
+    double *hist = nullptr; // r.r / b.b per iteration
+    int32_t hist_cap = 0;
+};
+
+enum CgPhase : int { CG_PHASE_NONE = 0, CG_PHASE_INIT = 1, CG_PHASE_ALPHA = 2, CG_PHASE_BETA = 3 };
+
+int slice_grid(const DeviceMatrix &m); // workgroups of the per-slice kernels (8 * ceil(n_slices/8))
+
+void launch_assemble(const DeviceMatrix &m, const MatConst &mc, hipStream_t st);
+void launch_rhs(const DeviceMatrix &m, const double *loads /* n_pad x 6 */, double *F, hipStream_t st);
+void launch_block_jacobi(const DeviceMatrix &m, hipStream_t st);
+void launch_element_matrices(const DeviceMatrix &m, const MatConst &mc, int32_t first, int32_t count,
+                             double *Ke_out, hipStream_t st);
+
+// y = K x; when partials != nullptr also partials[wg] = sum over the workgroup's rows of x*y
+// (s != nullptr: no-op once s->done != 0)
+void launch_spmv(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
+                 hipStream_t st);
+
+// CG steps; every kernel is a no-op once s->done != 0
+void launch_cg_init(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);      // x=0, r=b, z=M^-1 r, p=z
+void launch_cg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);    // x,r,z + partial r.z, r.r
+void launch_cg_direction(const DeviceMatrix &m, const CgVectors &v, hipStream_t st); // p = z + beta p
+// single-workgroup scalar step: optional reduction of `nsums` partial arrays into s->red, then the
+// scalar update of `phase` (rtol only used by CG_PHASE_INIT)
+void launch_cg_scalar(const DeviceMatrix &m, const CgVectors &v, bool reduce, int nsums, CgPhase phase,
+                      double rtol, hipStream_t st);
+
+// halo: gather owned entries of p into a contiguous send buffer
+void launch_pack(const double *p, const int32_t *send_nodes, int32_t count, double *sendbuf, hipStream_t st);
+
+} // namespace femshell

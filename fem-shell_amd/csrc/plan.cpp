@@ -1,0 +1,281 @@
+// plan.cpp -- host-side symbolic phase (see plan.hpp).
+#include "plan.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace femshell {
+
+void partition_rows(int32_t n_nodes, int world, int rank, int32_t *begin, int32_t *end)
+{
+    const int64_t slices = ((int64_t)n_nodes + kSliceNodes - 1) / kSliceNodes;
+    const int64_t s0 = slices * rank / world, s1 = slices * (rank + 1) / world;
+    *begin = (int32_t)std::min<int64_t>(s0 * kSliceNodes, n_nodes);
+    *end = (int32_t)std::min<int64_t>(s1 * kSliceNodes, n_nodes);
+}
+
+static int owner_of(int32_t node, int32_t n_nodes, int world)
+{
+    const int64_t slices = ((int64_t)n_nodes + kSliceNodes - 1) / kSliceNodes;
+    const int64_t s = node / kSliceNodes;
+    // smallest r with slices*(r+1)/world > s
+    int r = (int)((s * world) / slices);
+    while (r + 1 < world && slices * (r + 1) / world <= s) r++;
+    while (r > 0 && slices * r / world > s) r--;
+    return r;
+}
+
+bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri, int32_t n_quad,
+                const int32_t *quad, int rank, int world, Plan *P, std::string *err)
+{
+    auto fail = [&](const std::string &m) {
+        if (err) *err = m;
+        return false;
+    };
+    if (n_nodes <= 0) return fail("mesh has no nodes");
+    if (n_tri < 0 || n_quad < 0 || (int64_t)n_tri + n_quad <= 0) return fail("mesh has no elements");
+    if (world < 1 || rank < 0 || rank >= world) return fail("invalid rank/world_size");
+    if ((int64_t)n_tri + n_quad >= (1ll << 28)) return fail("more than 2^28 elements");
+    for (int64_t q = 0; q < 3ll * n_tri; q++)
+        if (tri[q] < 0 || tri[q] >= n_nodes) return fail("triangle " + std::to_string(q / 3) + " references a node out of range");
+    for (int64_t q = 0; q < 4ll * n_quad; q++)
+        if (quad[q] < 0 || quad[q] >= n_nodes) return fail("quad " + std::to_string(q / 4) + " references a node out of range");
+    for (int32_t e = 0; e < n_tri; e++) {
+        const int32_t *c = tri + 3ll * e;
+        if (c[0] == c[1] || c[1] == c[2] || c[0] == c[2]) return fail("triangle " + std::to_string(e) + " repeats a node");
+    }
+    for (int32_t e = 0; e < n_quad; e++) {
+        const int32_t *c = quad + 4ll * e;
+        for (int i = 0; i < 4; i++)
+            for (int j = i + 1; j < 4; j++)
+                if (c[i] == c[j]) return fail("quad " + std::to_string(e) + " repeats a node");
+    }
+
+    Plan &p = *P;
+    p = Plan();
+    p.n_nodes = n_nodes;
+    p.n_tri = n_tri;
+    p.n_quad = n_quad;
+    p.rank = rank;
+    p.world = world;
+    partition_rows(n_nodes, world, rank, &p.row_begin, &p.row_end);
+    const int32_t g0 = p.row_begin, g1 = p.row_end;
+    p.n_own = g1 - g0;
+    p.n_pad = (p.n_own + kSliceNodes - 1) / kSliceNodes * kSliceNodes;
+    p.n_slices = p.n_pad / kSliceNodes;
+
+    // ---- node -> element adjacency for the owned nodes; entries (element << 2 | index in element),
+    //      element = combined id (triangles first), ascending per node
+    const int32_t n_own = p.n_own;
+    std::vector<int64_t> adj_ptr((size_t)n_own + 1, 0);
+    auto count = [&](const int32_t *conn, int nn, int32_t ne) {
+        for (int64_t q = 0; q < (int64_t)nn * ne; q++) {
+            const int32_t a = conn[q];
+            if (a >= g0 && a < g1) adj_ptr[a - g0 + 1]++;
+        }
+    };
+    count(tri, 3, n_tri);
+    count(quad, 4, n_quad);
+    for (int32_t a = 0; a < n_own; a++) {
+        if (adj_ptr[a + 1] == 0) return fail("node " + std::to_string(g0 + a) + " is not attached to any element");
+        adj_ptr[a + 1] += adj_ptr[a];
+    }
+    std::vector<uint32_t> adj((size_t)adj_ptr[n_own]);
+    {
+        std::vector<int64_t> fill(adj_ptr.begin(), adj_ptr.end() - 1);
+        for (int32_t e = 0; e < n_tri; e++)
+            for (int i = 0; i < 3; i++) {
+                const int32_t a = tri[3ll * e + i];
+                if (a >= g0 && a < g1) adj[fill[a - g0]++] = ((uint32_t)e << 2) | (uint32_t)i;
+            }
+        for (int32_t e = 0; e < n_quad; e++)
+            for (int i = 0; i < 4; i++) {
+                const int32_t a = quad[4ll * e + i];
+                if (a >= g0 && a < g1) adj[fill[a - g0]++] = ((uint32_t)(n_tri + e) << 2) | (uint32_t)i;
+            }
+    }
+
+    // ---- local elements: every element touching an owned node
+    std::vector<int32_t> elem_local((size_t)n_tri + n_quad, -1);
+    for (uint32_t v : adj) elem_local[v >> 2] = 0;
+    for (int32_t e = 0; e < n_tri; e++)
+        if (elem_local[e] == 0) {
+            elem_local[e] = (int32_t)p.tri_global_id.size();
+            p.tri_global_id.push_back(e);
+        }
+    const int32_t n_ltri = (int32_t)p.tri_global_id.size();
+    for (int32_t e = 0; e < n_quad; e++)
+        if (elem_local[n_tri + e] == 0) {
+            elem_local[n_tri + e] = n_ltri + (int32_t)p.quad_global_id.size();
+            p.quad_global_id.push_back(e);
+        }
+
+    // ---- per owned node: block slots (slot 0 = diagonal, then ascending global column) and
+    //      the gather list of every slot
+    struct Slot {
+        int32_t col;   // global node id
+        int32_t first; // head of a singly linked list into tmp_pairs (ascending element order)
+        int32_t last;
+        int32_t count;
+    };
+    std::vector<int32_t> node_slot_ptr((size_t)n_own + 1, 0);
+    std::vector<int32_t> slot_col;                         // global ids, per node contiguous
+    std::vector<int32_t> slot_pair_ptr(1, 0);              // per slot
+    std::vector<uint32_t> slot_pairs;
+    slot_col.reserve((size_t)n_own * 8);
+    slot_pair_ptr.reserve((size_t)n_own * 8 + 1);
+    slot_pairs.reserve((size_t)adj.size() * 3);
+    std::vector<Slot> slots;
+    std::vector<uint32_t> tmp_pairs; // packed pair
+    std::vector<int32_t> tmp_next;
+    std::vector<int> order;
+    for (int32_t a = 0; a < n_own; a++) {
+        slots.clear();
+        tmp_pairs.clear();
+        tmp_next.clear();
+        slots.push_back({g0 + a, -1, -1, 0});
+        for (int64_t q = adj_ptr[a]; q < adj_ptr[a + 1]; q++) {
+            const uint32_t ge = adj[q] >> 2, ia = adj[q] & 3u;
+            const bool is_tri = ge < (uint32_t)n_tri;
+            const int nn = is_tri ? 3 : 4;
+            const int32_t *c = is_tri ? tri + 3ll * ge : quad + 4ll * (ge - n_tri);
+            const uint32_t le = (uint32_t)elem_local[ge];
+            for (int ib = 0; ib < nn; ib++) {
+                const int32_t b = c[ib];
+                size_t s = 0;
+                for (; s < slots.size(); s++)
+                    if (slots[s].col == b) break;
+                if (s == slots.size()) slots.push_back({b, -1, -1, 0});
+                const int32_t id = (int32_t)tmp_pairs.size();
+                tmp_pairs.push_back((le << 4) | (ia << 2) | (uint32_t)ib);
+                tmp_next.push_back(-1);
+                if (slots[s].first < 0) slots[s].first = id; else tmp_next[slots[s].last] = id;
+                slots[s].last = id;
+                slots[s].count++;
+            }
+        }
+        order.resize(slots.size());
+        for (size_t s = 0; s < slots.size(); s++) order[s] = (int)s;
+        std::sort(order.begin() + 1, order.end(), [&](int x, int y) { return slots[x].col < slots[y].col; });
+        for (int s : order) {
+            slot_col.push_back(slots[s].col);
+            for (int32_t id = slots[s].first; id >= 0; id = tmp_next[id]) slot_pairs.push_back(tmp_pairs[id]);
+            slot_pair_ptr.push_back((int32_t)slot_pairs.size());
+        }
+        node_slot_ptr[a + 1] = (int32_t)slot_col.size();
+        if (slot_pairs.size() > 0x7fffff00ull) return fail("gather list exceeds 2^31 entries");
+    }
+    p.nnz_blocks = (int64_t)slot_col.size();
+
+    // ---- ghosts: referenced columns outside the owned range, ascending
+    {
+        std::vector<int32_t> g;
+        for (int32_t c : slot_col)
+            if (c < g0 || c >= g1) g.push_back(c);
+        std::sort(g.begin(), g.end());
+        g.erase(std::unique(g.begin(), g.end()), g.end());
+        p.ghost_global.swap(g);
+        p.n_ghost = (int32_t)p.ghost_global.size();
+    }
+    auto to_local = [&](int32_t gid) -> int32_t {
+        if (gid >= g0 && gid < g1) return gid - g0;
+        const auto it = std::lower_bound(p.ghost_global.begin(), p.ghost_global.end(), gid);
+        return p.n_pad + (int32_t)(it - p.ghost_global.begin());
+    };
+
+    // ---- local copies of connectivity and coordinates
+    p.tri_local.resize((size_t)n_ltri * 3);
+    for (int32_t le = 0; le < n_ltri; le++)
+        for (int i = 0; i < 3; i++) p.tri_local[3ll * le + i] = to_local(tri[3ll * p.tri_global_id[le] + i]);
+    p.quad_local.resize(p.quad_global_id.size() * 4);
+    for (size_t le = 0; le < p.quad_global_id.size(); le++)
+        for (int i = 0; i < 4; i++) p.quad_local[4 * le + i] = to_local(quad[4ll * p.quad_global_id[le] + i]);
+    p.xyz_local.assign((size_t)p.n_local_nodes() * 3, 0.0);
+    for (int32_t a = 0; a < n_own; a++)
+        for (int d = 0; d < 3; d++) p.xyz_local[3ll * a + d] = xyz[3ll * (g0 + a) + d];
+    for (int32_t a = n_own; a < p.n_pad; a++) // padding rows: harmless copies of a real point
+        for (int d = 0; d < 3; d++) p.xyz_local[3ll * a + d] = xyz[3ll * g0 + d];
+    for (int32_t q = 0; q < p.n_ghost; q++)
+        for (int d = 0; d < 3; d++) p.xyz_local[3ll * (p.n_pad + q) + d] = xyz[3ll * p.ghost_global[q] + d];
+
+    // ---- pack into slices
+    p.slice_width.assign(p.n_slices, 1);
+    p.slice_base.assign((size_t)p.n_slices + 1, 0);
+    for (int32_t s = 0; s < p.n_slices; s++) {
+        int w = 1;
+        for (int n = 0; n < kSliceNodes; n++) {
+            const int32_t a = s * kSliceNodes + n;
+            if (a < n_own) w = std::max(w, node_slot_ptr[a + 1] - node_slot_ptr[a]);
+        }
+        p.slice_width[s] = w;
+        p.slice_base[s + 1] = p.slice_base[s] + (int64_t)w * kSliceNodes;
+    }
+    const int64_t total = p.slice_base[p.n_slices];
+    if (total * 36 >= (1ll << 40)) return fail("matrix too large");
+    p.cols.resize((size_t)total);
+    p.pair_ptr.resize((size_t)total + 1);
+    p.pairs.clear();
+    p.pairs.reserve(slot_pairs.size());
+    // slot order inside a slice is (k, n); the gather list follows the same order
+    for (int32_t s = 0; s < p.n_slices; s++) {
+        const int w = p.slice_width[s];
+        for (int k = 0; k < w; k++)
+            for (int n = 0; n < kSliceNodes; n++) {
+                const int64_t idx = Plan::slot_index(p.slice_base[s], k, n);
+                const int32_t a = s * kSliceNodes + n;
+                p.pair_ptr[idx] = (int32_t)p.pairs.size();
+                if (a < n_own && k < node_slot_ptr[a + 1] - node_slot_ptr[a]) {
+                    const int32_t q = node_slot_ptr[a] + k;
+                    p.cols[idx] = to_local(slot_col[q]);
+                    p.pairs.insert(p.pairs.end(), slot_pairs.begin() + slot_pair_ptr[q],
+                                   slot_pairs.begin() + slot_pair_ptr[q + 1]);
+                } else {
+                    p.cols[idx] = std::min(a, p.n_pad - 1); // padding slot: zero block on the own row
+                }
+            }
+    }
+    p.pair_ptr[total] = (int32_t)p.pairs.size();
+
+    // ---- halo exchange lists
+    if (world > 1) {
+        // receive side: ghosts grouped by owner (ghost_global is ascending, ranges are contiguous)
+        std::vector<HaloPeer> peers;
+        for (int32_t q = 0; q < p.n_ghost;) {
+            const int r = owner_of(p.ghost_global[q], n_nodes, world);
+            HaloPeer hp;
+            hp.rank = r;
+            hp.recv_offset = q;
+            while (q < p.n_ghost && owner_of(p.ghost_global[q], n_nodes, world) == r) q++;
+            hp.recv_count = q - hp.recv_offset;
+            peers.push_back(hp);
+        }
+        // send side: owned node a goes to rank r iff a has a neighbour owned by r (adjacency is symmetric)
+        std::vector<std::vector<int32_t>> send(world);
+        for (int32_t a = 0; a < n_own; a++) {
+            int last = -1;
+            for (int32_t q = node_slot_ptr[a] + 1; q < node_slot_ptr[a + 1]; q++) {
+                const int32_t c = slot_col[q];
+                if (c >= g0 && c < g1) continue;
+                const int r = owner_of(c, n_nodes, world);
+                if (r != last && (send[r].empty() || send[r].back() != a)) send[r].push_back(a);
+                last = r;
+            }
+        }
+        for (int r = 0; r < world; r++) {
+            if (send[r].empty()) continue;
+            auto it = std::find_if(peers.begin(), peers.end(), [&](const HaloPeer &h) { return h.rank == r; });
+            if (it == peers.end()) {
+                HaloPeer hp;
+                hp.rank = r;
+                peers.push_back(hp);
+                it = peers.end() - 1;
+            }
+            it->send_nodes.swap(send[r]);
+        }
+        std::sort(peers.begin(), peers.end(), [](const HaloPeer &x, const HaloPeer &y) { return x.rank < y.rank; });
+        p.peers.swap(peers);
+    }
+    return true;
+}
+
+} // namespace femshell

@@ -1,0 +1,77 @@
+// plan.hpp -- host-side symbolic phase of libfemshell.
+//
+// The reference leaves this to libMesh (EquationSystems::init builds the dof map and the
+// sparsity pattern, fem-shell.cpp:125) and to PETSc (MatSetValues stash, matrix->close()).
+// Here it produces the device data layout once per mesh:
+//
+//  * row ownership: node rows are split into contiguous ranges, one per rank (GPU), in
+//    units of 32-node slices; a rank keeps its owned nodes, the ghost nodes they couple to
+//    and every element that touches an owned node (interface elements are recomputed on
+//    both sides, so assembly needs no communication);
+//  * K in "sliced block ELL": a slice is 32 consecutive node rows = 192 scalar rows; every
+//    node row has `width` block slots; slot 0 is the diagonal block, the others are the
+//    neighbour blocks in ascending column order; values are stored so that the 192 scalar
+//    rows of a slice are the fastest index (one lane per scalar row, 16-byte loads):
+//        vals[(slot_base(s) + k*32)*36 + ((jp*192) + n*6 + i)*2 + jj],  j = 2*jp + jj
+//    for slice s, slot k, node-in-slice n, block row i, block column j;
+//  * gather lists: for every block slot the (element, local row node, local column node)
+//    triples that contribute to it, ordered by element id, so that the assembly kernel
+//    writes every block exactly once, without atomics and in a fixed summation order.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace femshell {
+
+constexpr int kSliceNodes = 32;             // node rows per slice
+constexpr int kSliceRows = 6 * kSliceNodes; // scalar rows per slice
+
+struct HaloPeer {
+    int rank = -1;
+    int32_t recv_offset = 0;          // first ghost index (into the ghost list) owned by this peer
+    int32_t recv_count = 0;           // ghost nodes received from this peer
+    std::vector<int32_t> send_nodes;  // owned local node ids this peer needs, ascending
+};
+
+struct Plan {
+    // global problem
+    int32_t n_nodes = 0, n_tri = 0, n_quad = 0;
+    int rank = 0, world = 1;
+    int32_t row_begin = 0, row_end = 0; // owned global node range
+    // local numbering: owned [0,n_own), padding [n_own,n_pad), ghosts [n_pad, n_pad+n_ghost)
+    int32_t n_own = 0, n_pad = 0, n_ghost = 0;
+    std::vector<int32_t> ghost_global;  // ascending global ids
+    // local elements (those touching an owned node), local node ids
+    std::vector<int32_t> tri_global_id, quad_global_id;
+    std::vector<int32_t> tri_local, quad_local; // 3*n_ltri, 4*n_lquad
+    std::vector<double> xyz_local;              // (n_pad+n_ghost)*3
+    // sliced block ELL structure over the owned rows
+    int32_t n_slices = 0;
+    std::vector<int32_t> slice_width;  // n_slices
+    std::vector<int64_t> slice_base;   // n_slices+1, in slots (one slot = one 6x6 block of one node)
+    std::vector<int32_t> cols;         // per slot: local column node id (padding slots: own row, no pairs)
+    std::vector<int32_t> pair_ptr;     // per slot + 1
+    std::vector<uint32_t> pairs;       // (local element << 4) | (row node in element << 2) | column node in element
+                                       // local element index: triangles [0,n_ltri), quads n_ltri + q
+    int64_t nnz_blocks = 0;            // real (non-padding) blocks
+    std::vector<HaloPeer> peers;
+
+    int64_t total_slots() const { return slice_base.empty() ? 0 : slice_base.back(); }
+    int32_t n_local_nodes() const { return n_pad + n_ghost; }
+    int32_t n_ltri() const { return (int32_t)tri_global_id.size(); }
+    int32_t n_lquad() const { return (int32_t)quad_global_id.size(); }
+    // slot index of (slice s, slot k, node n)
+    static inline int64_t slot_index(int64_t base, int k, int n) { return base + (int64_t)k * kSliceNodes + n; }
+};
+
+// owned node range of `rank` when n_nodes rows are split over `world` ranks
+void partition_rows(int32_t n_nodes, int world, int rank, int32_t *begin, int32_t *end);
+
+// Builds the plan.  Returns false and sets err on invalid input (index out of range,
+// repeated node in an element, too many elements).
+bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri, int32_t n_quad,
+                const int32_t *quad, int rank, int world, Plan *plan, std::string *err);
+
+} // namespace femshell

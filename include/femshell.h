@@ -1,0 +1,161 @@
+/*
+ * femshell.h -- C ABI of libfemshell, the MI355X (gfx950) implementation of
+ * fem-shell's hot path: per-element flat-shell stiffness assembly and the
+ * sparse solve for nodal displacements.
+ *
+ * This is the drop-in boundary.  Every entry point names the reference
+ * interface it replaces ("SA" = src/fem-shell/fem-shell.cpp, "PC" =
+ * src/fem-shell/preCICE/fem-shell_precice.cpp of precice/fem-shell).  The
+ * reference-side bindings (libMesh assemble callback, LinearSolver subclass,
+ * preCICE adapter loop) are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C, host pointers, caller-owned buffers; the library copies in/out
+ *  - every call returns FEMSHELL_OK (0) or a negative femshell_status; the text
+ *    of the last error of the calling thread is femshell_last_error()
+ *  - no exceptions cross the boundary
+ *  - one context per host thread / MPI-style rank; a context is not thread-safe,
+ *    distinct contexts are independent
+ *  - all floating point is IEEE double (libMesh Real/Number), node ids are
+ *    int32, dof of (node, var) is 6*node + var with var = u,v,w,tx,ty,tz
+ *    (the layout of build_solution_vector, SA:141, 163-169)
+ *  - there is NO CPU fallback: without a HIP device every compute call fails
+ *    with FEMSHELL_ERR_NO_DEVICE
+ */
+#ifndef FEMSHELL_H
+#define FEMSHELL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FEMSHELL_VERSION 1
+
+typedef enum femshell_status {
+    FEMSHELL_OK = 0,
+    FEMSHELL_ERR_INVALID = -1,     /* bad argument / call order */
+    FEMSHELL_ERR_NO_DEVICE = -2,   /* no usable HIP device */
+    FEMSHELL_ERR_HIP = -3,         /* HIP runtime error */
+    FEMSHELL_ERR_MESH = -4,        /* index out of range, degenerate element */
+    FEMSHELL_ERR_BREAKDOWN = -5,   /* CG breakdown: p.Ap <= 0 (matrix not SPD) */
+    FEMSHELL_ERR_COMM = -6,        /* RCCL error */
+    FEMSHELL_ERR_UNSUPPORTED = -7
+} femshell_status;
+
+/* behaviour flags; FEMSHELL_REF_DEFAULT reproduces the reference as coded */
+#define FEMSHELL_REF_Y21        0x1u /* SA:586: Y(2,1) = -2*x31*x31 instead of the thesis' -2*x31*y31 */
+#define FEMSHELL_REF_DRILL_MAX  0x2u /* SA:1035-1052: drilling stiffness max(..)/1000 on every node block */
+#define FEMSHELL_REASSEMBLE_EACH_SOLVE 0x4u /* PC:271: rebuild K on every solve (the reference does; K is constant) */
+#define FEMSHELL_REF_DEFAULT    (FEMSHELL_REF_Y21 | FEMSHELL_REF_DRILL_MAX)
+
+typedef struct femshell_config {
+    double nu;          /* Poisson's ratio  -nu (SA:217) */
+    double E;           /* Young's modulus  -e  (SA:225) */
+    double thickness;   /* shell thickness  -t  (SA:233) */
+    uint32_t flags;     /* FEMSHELL_REF_* | FEMSHELL_REASSEMBLE_EACH_SOLVE */
+    int32_t device;     /* HIP device ordinal; -1 = the calling thread's current device */
+    int32_t rank;       /* this process' index in the row partition (0 for one GPU) */
+    int32_t world_size; /* number of processes = GPUs sharing the mesh (1 for one GPU) */
+} femshell_config;
+
+typedef struct femshell_ctx femshell_ctx;
+
+/* replaces: global state nu/em/thickness/Dp/Dm + initMaterialMatrices (SA:273-294, fem-shell.h:46-52) */
+int femshell_create(const femshell_config *cfg, femshell_ctx **out);
+int femshell_destroy(femshell_ctx *ctx);
+const char *femshell_last_error(void);
+
+/* replaces: what assemble_elasticity reads through es.get_mesh()/DofMap (SA:1166-1205):
+ * the replicated mesh (SA:35-37).  xyz[n_nodes][3]; tri[n_tri][3]; quad[n_quad][4]
+ * (either count may be 0).  Every rank passes the same global mesh; the library keeps
+ * the node rows [femshell_row_begin, femshell_row_end) of its rank plus the ghost
+ * nodes/elements they touch, and builds the block sparsity (libMesh does this in
+ * EquationSystems::init, SA:125). */
+int femshell_set_mesh(femshell_ctx *ctx, int32_t n_nodes, const double *xyz, int32_t n_tri,
+                      const int32_t *tri, int32_t n_quad, const int32_t *quad);
+
+/* replaces: DirichletBoundary {0,20}->u,v,w and {1,21}->all six (SA:90-120).  mask6 bit v
+ * fixes dof v of the node to 0.  node_ids == NULL: mask6 has one byte per node (n == n_nodes).
+ * Calling it again replaces the previous set. */
+int femshell_set_dirichlet(femshell_ctx *ctx, int32_t n, const int32_t *node_ids, const uint8_t *mask6);
+
+/* replaces: the global `forces` vector read by contribRHS (SA:44-67, 1118-1153; PC:1377-1438).
+ * f6[n][6] nodal forces and moments; node_ids == NULL: one row per node (n == n_nodes).
+ * Nodes not listed get zero load.  Only the right-hand side is rebuilt. */
+int femshell_set_loads(femshell_ctx *ctx, int32_t n, const int32_t *node_ids, const double *f6);
+
+/* replaces: assemble_elasticity (SA:1160-1233): element stiffness (initElement, calcPlane,
+ * calcPlate, constructStiffnessMatrix, localToGlobalTrafo), constraint handling, add_matrix /
+ * add_vector.  K and F stay in HBM. */
+int femshell_assemble(femshell_ctx *ctx);
+
+typedef struct femshell_solve_info {
+    int32_t iterations;     /* CG iterations performed */
+    int32_t converged;      /* 1: ||r|| <= rtol*||b||, 0: max_it reached */
+    double rel_residual;    /* recurrence ||r||_2 / ||b||_2 at exit */
+    double assemble_seconds;/* device time of the assembly done inside this call (0 if reused) */
+    double setup_seconds;   /* block-Jacobi factorisation */
+    double solve_seconds;   /* CG loop, device time */
+    double bytes_per_iteration; /* algorithmic HBM bytes of one CG iteration on this rank */
+} femshell_solve_info;
+
+/* replaces: equation_systems.solve() -> PETSc KSPSolve (SA:138, PC:271) followed by
+ * build_solution_vector (SA:141; PC:274-280 broadcast): 6x6-block-Jacobi preconditioned CG,
+ * x0 = 0, stop at ||r||_2 <= rtol*||b||_2 or max_it.  rtol <= 0 runs exactly max_it iterations.
+ * u_out[n_nodes][6] receives the full solution on every rank; NULL leaves it in HBM
+ * (fetch with femshell_get_solution).  Assembles first if needed. */
+int femshell_solve(femshell_ctx *ctx, double rtol, int32_t max_it, double *u_out,
+                   femshell_solve_info *info);
+int femshell_get_solution(femshell_ctx *ctx, double *u_out);
+/* ||r||/||b|| after each iteration of the last solve; returns the count written (<= cap) */
+int32_t femshell_residual_history(femshell_ctx *ctx, double *hist, int32_t cap);
+
+/* ---- parity / debug exports (single-rank contexts) --------------------------------- */
+
+/* element matrices in the reference's variable-major element ordering Ke(n*alpha+i, n*beta+j)
+ * (SA:1105-1109), unconstrained, as localToGlobalTrafo leaves them.  Triangles are elements
+ * [0,n_tri), quads [n_tri, n_tri+n_quad); the range must not mix the two kinds.
+ * Ke_out: count x 324 (TRI3) or count x 576 (QUAD4) doubles. */
+int femshell_element_matrices(femshell_ctx *ctx, int32_t first, int32_t count, double *Ke_out);
+
+int64_t femshell_nnz_blocks(femshell_ctx *ctx); /* number of 6x6 blocks of K on this rank */
+/* K as block CSR with sorted columns (vals: nnzb x 36 row-major) and F (6*n_nodes), after
+ * femshell_assemble -- what system.matrix / system.rhs hold after the callback (SA:1230-1231) */
+int femshell_export_bsr(femshell_ctx *ctx, int32_t *rowptr, int32_t *colidx, double *vals, double *F);
+/* y = K x on the device */
+int femshell_spmv(femshell_ctx *ctx, const double *x, double *y);
+
+/* ---- row partition over several GPUs (one process per GPU, RCCL over xGMI) ---------- */
+
+int32_t femshell_row_begin(femshell_ctx *ctx); /* first owned node row */
+int32_t femshell_row_end(femshell_ctx *ctx);   /* one past the last owned node row */
+/* rank 0 creates the id, the host program distributes it (e.g. a torch.distributed or MPI
+ * broadcast), every rank then calls femshell_comm_init before femshell_set_mesh.
+ * replaces: LibMeshInit / init.comm() (SA:28, 35) */
+int femshell_comm_unique_id(uint8_t id_out[128]);
+int femshell_comm_init(femshell_ctx *ctx, const uint8_t id[128]);
+
+/* ---- measurement ----------------------------------------------------------------- */
+
+typedef enum femshell_kernel {
+    FEMSHELL_KERNEL_ASSEMBLE = 0, /* element stiffness + block-row gather into K */
+    FEMSHELL_KERNEL_SPMV = 1,     /* q = K p with fused p.q */
+    FEMSHELL_KERNEL_CG_UPDATE = 2,/* x,r update + block-Jacobi apply + dots */
+    FEMSHELL_KERNEL_CG_DIRECTION = 3 /* p = z + beta p */
+} femshell_kernel;
+
+/* launches the kernel `reps` times back to back on the library's stream between two HIP
+ * events and returns the mean duration; bytes_out = algorithmic HBM bytes of one launch on
+ * this rank (DESIGN.md section "algorithmic bytes").  The state of a solve is not disturbed. */
+int femshell_time_kernel(femshell_ctx *ctx, femshell_kernel which, int32_t reps, double *mean_ms_out,
+                         double *bytes_out);
+
+/* hipStreamSynchronize on the library's stream */
+int femshell_sync(femshell_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

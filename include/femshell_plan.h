@@ -1,0 +1,58 @@
+/*
+ * femshell_plan.h -- host-only inspection of libfemshell's symbolic phase (row partition,
+ * block sparsity, gather lists, halo lists).  No GPU is touched: these entry points exist so
+ * that the partition / halo logic of the multi-GPU path can be tested on CPU-only machines
+ * (tests/test_plan_cpu.py, tests/test_partition_gloo.py).  They are not part of the drop-in
+ * boundary; the reference's counterpart is libMesh's DofMap/sparsity build inside
+ * EquationSystems::init (fem-shell.cpp:125) and PETSc's parallel Mat/Vec layout.
+ */
+#ifndef FEMSHELL_PLAN_H
+#define FEMSHELL_PLAN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct femshell_plan femshell_plan;
+
+int femshell_plan_create(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri,
+                         int32_t n_quad, const int32_t *quad, int32_t rank, int32_t world_size,
+                         femshell_plan **out);
+void femshell_plan_destroy(femshell_plan *plan);
+
+enum {
+    FEMSHELL_PLAN_N_OWN = 0, FEMSHELL_PLAN_N_PAD, FEMSHELL_PLAN_N_GHOST, FEMSHELL_PLAN_N_SLICES,
+    FEMSHELL_PLAN_N_LTRI, FEMSHELL_PLAN_N_LQUAD, FEMSHELL_PLAN_TOTAL_SLOTS, FEMSHELL_PLAN_N_PAIRS,
+    FEMSHELL_PLAN_N_PEERS, FEMSHELL_PLAN_ROW_BEGIN, FEMSHELL_PLAN_ROW_END, FEMSHELL_PLAN_NNZ_BLOCKS,
+    FEMSHELL_PLAN_INFO_COUNT
+};
+/* fills info[FEMSHELL_PLAN_INFO_COUNT] */
+int femshell_plan_info(const femshell_plan *plan, int64_t *info);
+
+enum {
+    FEMSHELL_PLAN_GHOST_GLOBAL = 0, /* int32 [n_ghost]       global ids of the ghost nodes        */
+    FEMSHELL_PLAN_TRI_LOCAL,        /* int32 [n_ltri*3]      local node ids                        */
+    FEMSHELL_PLAN_TRI_GLOBAL_ID,    /* int32 [n_ltri]                                              */
+    FEMSHELL_PLAN_QUAD_LOCAL,       /* int32 [n_lquad*4]                                           */
+    FEMSHELL_PLAN_QUAD_GLOBAL_ID,   /* int32 [n_lquad]                                             */
+    FEMSHELL_PLAN_SLICE_WIDTH,      /* int32 [n_slices]                                            */
+    FEMSHELL_PLAN_SLICE_BASE,       /* int64 [n_slices+1]                                          */
+    FEMSHELL_PLAN_COLS,             /* int32 [total_slots]   local column node per slot            */
+    FEMSHELL_PLAN_PAIR_PTR,         /* int32 [total_slots+1]                                       */
+    FEMSHELL_PLAN_PAIRS,            /* uint32 [n_pairs]      (local element<<4)|(ia<<2)|ib         */
+    FEMSHELL_PLAN_XYZ_LOCAL,        /* double [(n_pad+n_ghost)*3]                                  */
+    FEMSHELL_PLAN_PEER_RANKS,       /* int32 [n_peers]                                             */
+    FEMSHELL_PLAN_PEER_RECV_OFFSET, /* int32 [n_peers]       first ghost index received from peer  */
+    FEMSHELL_PLAN_PEER_RECV_COUNT,  /* int32 [n_peers]                                             */
+    FEMSHELL_PLAN_PEER_SEND_PTR,    /* int32 [n_peers+1]     offsets into PEER_SEND_NODES          */
+    FEMSHELL_PLAN_PEER_SEND_NODES   /* int32 [sum]           owned local nodes sent to each peer   */
+};
+/* returns the element count of the array; copies it to out when out != NULL */
+int64_t femshell_plan_array(const femshell_plan *plan, int which, void *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

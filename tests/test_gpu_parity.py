@@ -1,0 +1,242 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on
+the same inputs.  Tolerances (FP64): element matrices and assembled K <= 1e-12 relative
+(Frobenius / max-entry scaled); displacements < 1e-10 relative to the oracle's direct solve
+where CG can attain it (small meshes), otherwise as stated per test."""
+import numpy as np
+import pytest
+
+from tests.helpers import meshes, oracle
+from tests.helpers.product import ensure_built
+
+pytestmark = pytest.mark.gpu
+pkg = ensure_built()
+
+
+def make_ctx(m, nu, E, t, flags=None, with_bc=True, with_loads=True):
+    fs = pkg.FemShell(nu, E, t, flags=pkg.REF_DEFAULT if flags is None else flags)
+    fs.set_mesh(m.xyz, m.tri, m.quad)
+    if with_bc:
+        fs.set_dirichlet(m.dirichlet_mask())
+    if with_loads:
+        fs.set_loads(m.loads)
+    return fs
+
+
+def random_tris(n, seed):
+    rng = np.random.default_rng(seed)
+    xyz = rng.normal(size=(3 * n, 3)) * rng.uniform(0.1, 10.0, size=(3 * n, 1))
+    tri = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    return xyz, tri
+
+
+# ------------------------------------------------------------------ element matrices
+
+@pytest.mark.parametrize("flags", [3, 2, 1, 0])
+def test_element_matrices_random_3d_triangles(flags):
+    xyz, tri = random_tris(257, seed=11 + flags)
+    fs = pkg.FemShell(0.3, 2.1e5, 0.37, flags=flags)
+    fs.set_mesh(xyz, tri)
+    Ke = fs.element_matrices(0, len(tri))
+    mat = oracle.material(0.3, 2.1e5, 0.37, flags)
+    worst = 0.0
+    for e in range(len(tri)):
+        ref = oracle.element_tri3(xyz[tri[e]], mat)
+        worst = max(worst, np.linalg.norm(Ke[e] - ref) / np.linalg.norm(ref))
+    assert worst <= 1e-12, worst
+
+
+def test_element_matrices_special_shapes():
+    # axis-aligned isosceles, 2:1 right, obtuse skew in 3-D, near-degenerate sliver
+    shapes = [
+        [[0, 0, 0], [1, 0, 0], [0, 1, 0]],
+        [[0, 0, 0], [2, 0, 0], [0, 1, 0]],
+        [[0.3, -1.0, 2.0], [4.1, 0.2, 2.5], [-2.0, 0.7, 3.1]],
+        [[0, 0, 0], [1, 0, 0], [0.5, 1e-3, 0]],
+        [[5, 5, 5], [5, 6, 5], [5, 5, 6.5]],
+    ]
+    xyz = np.array(shapes, dtype=np.float64).reshape(-1, 3)
+    tri = np.arange(len(xyz), dtype=np.int32).reshape(-1, 3)
+    fs = pkg.FemShell(0.25, 30000.0, 1.0)
+    fs.set_mesh(xyz, tri)
+    Ke = fs.element_matrices(0, len(tri))
+    mat = oracle.material(0.25, 30000.0, 1.0)
+    for e in range(len(tri)):
+        ref = oracle.element_tri3(xyz[tri[e]], mat)
+        assert np.linalg.norm(Ke[e] - ref) <= 1e-11 * np.linalg.norm(ref), e
+        assert np.abs(Ke[e] - Ke[e].T).max() <= 1e-12 * np.abs(Ke[e]).max()
+
+
+def test_element_matrices_match_committed_goldens():
+    g = np.load(meshes.GOLDEN + "/tri3_elements.npz")
+    fs = pkg.FemShell(float(g["nu"]), float(g["E"]), float(g["t"]))
+    fs.set_mesh(g["xyz"], g["tri"])
+    Ke = fs.element_matrices(0, len(g["tri"]))
+    for e in range(len(g["tri"])):
+        assert np.linalg.norm(Ke[e] - g["Ke"][e]) <= 1e-12 * np.linalg.norm(g["Ke"][e])
+
+
+# ------------------------------------------------------------------ assembled K, F, SpMV
+
+@pytest.mark.parametrize("name,nu,E,t", [("test_A_uv_t", 0.25, 30000.0, 1.0), ("test_C_w_tA16", 0.3, 10.92, 1.0),
+                                         ("test_E_uvw_t", 0.25, 10000.0, 0.25),
+                                         ("bending_tower_tri_test", 0.3, 1e6, 0.1)])
+def test_assembled_matrix_equals_oracle(name, nu, E, t):
+    m = meshes.load_example(name)
+    fs = make_ctx(m, nu, E, t)
+    fs.assemble()
+    rowptr, colidx, vals, F = fs.export_bsr()
+    mat = oracle.material(nu, E, t)
+    r0, c0, v0, F0 = oracle.assemble(m.xyz, m.tri, m.quad, mat, m.dirichlet_mask(), m.loads)
+    np.testing.assert_array_equal(rowptr, r0)
+    np.testing.assert_array_equal(colidx, c0)
+    assert np.linalg.norm(vals - v0) <= 1e-12 * np.linalg.norm(v0)
+    assert np.abs(vals - v0).max() <= 1e-12 * np.abs(v0).max()
+    np.testing.assert_array_equal(F, F0)
+
+
+def curved_mesh(nx, ny, seed=3):
+    m = meshes.structured(nx, ny, 0, 0, 4, 3, kind="t", ul_lr=bool(seed & 1), bcids=(0, -1, 1, -1))
+    rng = np.random.default_rng(seed)
+    m.xyz[:, 2] = 0.3 * np.sin(1.3 * m.xyz[:, 0]) * np.cos(0.7 * m.xyz[:, 1])
+    m.xyz[:, :2] += rng.uniform(-0.02, 0.02, size=(m.n_nodes, 2))
+    m.loads = rng.normal(size=(m.n_nodes, 6))
+    return m
+
+
+def test_assembly_spmv_on_curved_ragged_mesh():
+    m = curved_mesh(37, 29)  # 1140 nodes: last slice is ragged (1140 = 35*32 + 20)
+    fs = make_ctx(m, 0.3, 7.0e4, 0.05)
+    fs.assemble()
+    mat = oracle.material(0.3, 7.0e4, 0.05)
+    r0, c0, v0, F0 = oracle.assemble(m.xyz, m.tri, m.quad, mat, m.dirichlet_mask(), m.loads)
+    _, _, vals, F = fs.export_bsr()
+    assert np.abs(vals - v0).max() <= 1e-12 * np.abs(v0).max()
+    np.testing.assert_array_equal(F, F0)
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=6 * m.n_nodes)
+    y = fs.spmv(x)
+    y0 = oracle.spmv(r0, c0, v0, x)
+    assert np.linalg.norm(y - y0) <= 1e-13 * np.linalg.norm(y0)
+
+
+def test_assembly_is_bitwise_reproducible():
+    m = curved_mesh(20, 20)
+    fs = make_ctx(m, 0.3, 7.0e4, 0.05)
+    fs.assemble()
+    a = fs.export_bsr()[2].copy()
+    fs.assemble()
+    b = fs.export_bsr()[2]
+    assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ solve
+
+def test_known_answers_on_device():
+    # thesis values (doc/validation.tex:62-65, 200) straight from the HIP path
+    m = meshes.load_example("test_A_uv_t")
+    fs = make_ctx(m, 0.25, 30000.0, 1.0)
+    u, info = fs.solve(rtol=1e-12, max_it=5000)
+    assert info["converged"] == 1
+    assert u[22, 0] == pytest.approx(-0.0255988, abs=6e-8)
+    assert u[26, 1] == pytest.approx(0.1944070, abs=6e-7)
+    m = meshes.load_example("test_C_w_tA16")
+    fs = make_ctx(m, 0.3, 10.92, 1.0)
+    u, info = fs.solve(rtol=1e-12, max_it=20000)
+    assert info["converged"] == 1
+    assert u[144, 2] == pytest.approx(1.15169, abs=6e-6)
+
+
+@pytest.mark.parametrize("name,nu,E,t", [("test_A_uv_t", 0.25, 30000.0, 1.0), ("test_C_w_tA16", 0.3, 10.92, 1.0),
+                                         ("test_E_uvw_t", 0.25, 10000.0, 0.25)])
+def test_displacements_match_oracle_direct_solve(name, nu, E, t):
+    m = meshes.load_example(name)
+    fs = make_ctx(m, nu, E, t)
+    u, info = fs.solve(rtol=1e-13, max_it=50000)
+    mat = oracle.material(nu, E, t)
+    r0, c0, v0, F0 = oracle.assemble(m.xyz, m.tri, m.quad, mat, m.dirichlet_mask(), m.loads)
+    u0 = oracle.direct_solve(r0, c0, v0, F0)
+    err = np.linalg.norm(u.ravel() - u0) / np.linalg.norm(u0)
+    assert info["converged"] == 1
+    assert err < 1e-10, err
+    # true residual of the returned solution
+    res = np.linalg.norm(F0 - oracle.spmv(r0, c0, v0, u.ravel())) / np.linalg.norm(F0)
+    assert res < 1e-11, res
+
+
+def test_cg_follows_oracle_cg_iteration_by_iteration():
+    m = meshes.structured(16, 16, 0, 0, 10, 10, kind="t", ul_lr=True, bcids=(0, 0, 0, 0), factor=300.0, loading=2)
+    fs = make_ctx(m, 0.3, 1e7, 0.5)
+    u, info = fs.solve(rtol=1e-10, max_it=5000)
+    mat = oracle.material(0.3, 1e7, 0.5)
+    r0, c0, v0, F0 = oracle.assemble(m.xyz, m.tri, m.quad, mat, m.dirichlet_mask(), m.loads)
+    u0, info0 = oracle.pcg(r0, c0, v0, F0, rtol=1e-10, max_it=5000, history=True)
+    assert info["converged"] == 1 and info0["converged"] == 1
+    assert abs(info["iterations"] - info0["iterations"]) <= 2
+    h = fs.residual_history()
+    k = min(len(h), len(info0["history"]), 60)
+    np.testing.assert_allclose(h[:k], info0["history"][:k], rtol=1e-6)
+    assert np.linalg.norm(u.ravel() - u0) <= 1e-9 * np.linalg.norm(u0)
+
+
+def test_fixed_iteration_mode_and_resolve_with_new_loads():
+    m = curved_mesh(24, 18)
+    fs = make_ctx(m, 0.3, 7.0e4, 0.05)
+    _, info = fs.solve(rtol=0.0, max_it=37, fetch=False)
+    assert info["iterations"] == 37 and info["converged"] == 0
+    # linearity: solving with 2x the loads gives 2x the displacements (K, preconditioner reused)
+    u1, i1 = fs.solve(rtol=1e-12, max_it=40000)
+    fs.set_loads(2.0 * m.loads)
+    u2, i2 = fs.solve(rtol=1e-12, max_it=40000)
+    assert i2["assemble_seconds"] == 0.0
+    assert np.linalg.norm(u2 - 2.0 * u1) <= 1e-9 * np.linalg.norm(u2)
+
+
+# ------------------------------------------------------------------ size-independent properties at scale
+
+def test_large_mesh_properties():
+    # 512x512 squares -> 524,288 triangles, 263,169 nodes (config-2 class size)
+    nx = 512
+    m = meshes.structured(nx, nx, 0, 0, 10, 10, kind="t", ul_lr=True, bcids=(0, 0, 0, 0), factor=300.0, loading=2)
+    fs = make_ctx(m, 0.3, 1e7, 0.5, with_bc=False)
+    fs.assemble()
+    rng = np.random.default_rng(7)
+    x = rng.normal(size=6 * m.n_nodes)
+    y = rng.normal(size=6 * m.n_nodes)
+    Kx, Ky = fs.spmv(x), fs.spmv(y)
+    # symmetry: y.Kx == x.Ky
+    assert abs(y @ Kx - x @ Ky) <= 1e-11 * (np.linalg.norm(y) * np.linalg.norm(Kx))
+    # rigid-body translations and an in-plane rotation produce no force without constraints
+    scale = np.linalg.norm(Kx) / np.linalg.norm(x)
+    for mode in range(3):
+        v = np.zeros((m.n_nodes, 6))
+        v[:, mode] = 1.0
+        assert np.linalg.norm(fs.spmv(v.ravel())) <= 1e-9 * scale * np.sqrt(m.n_nodes)
+    v = np.zeros((m.n_nodes, 6))
+    v[:, 0], v[:, 1], v[:, 5] = -m.xyz[:, 1], m.xyz[:, 0], 1.0  # rotation about z
+    assert np.linalg.norm(fs.spmv(v.ravel())) <= 1e-8 * scale * np.linalg.norm(v)
+    # with supports: CG residual drops monotonically-ish and the solve is repeatable bit for bit
+    fs.set_dirichlet(m.dirichlet_mask())
+    u1, i1 = fs.solve(rtol=0.0, max_it=200)
+    u2, i2 = fs.solve(rtol=0.0, max_it=200)
+    assert np.array_equal(u1, u2)
+    h = fs.residual_history()
+    assert len(h) == 200 and np.isfinite(h).all()
+
+
+# ------------------------------------------------------------------ error behaviour
+
+def test_errors_are_reported_not_swallowed():
+    xyz = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0], [0, 1, 0]], dtype=np.float64)
+    tri = np.array([[0, 1, 2], [0, 1, 3]], dtype=np.int32)  # first triangle is collinear
+    fs = pkg.FemShell(0.3, 1.0, 1.0)
+    fs.set_mesh(xyz, tri)
+    with pytest.raises(pkg.FemShellError) as ei:
+        fs.assemble()
+    assert ei.value.code == -4 and "triangle 0" in str(ei.value)
+    with pytest.raises(pkg.FemShellError):
+        pkg.FemShell(0.3, 1.0, 1.0).assemble()  # no mesh
+    with pytest.raises(pkg.FemShellError):
+        pkg.FemShell(0.3, -1.0, 1.0)
+    fs2 = pkg.FemShell(0.3, 1.0, 1.0)
+    with pytest.raises(pkg.FemShellError):
+        fs2.set_mesh(xyz, np.array([[0, 1, 7]], dtype=np.int32))

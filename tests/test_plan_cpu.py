@@ -1,0 +1,135 @@
+"""CPU tests of the host logic: the C-ABI library loads and exports every declared symbol, the
+symbolic plan (block slots, gather lists, slices) reproduces the oracle's assembled matrix, and
+the row partition covers the mesh consistently.  No GPU compute call is made."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.helpers import meshes, oracle, sell
+from tests.helpers.product import ROOT, ensure_built
+
+pkg = ensure_built()
+
+
+def declared_symbols():
+    names = set()
+    for hdr in ("femshell.h", "femshell_plan.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(femshell_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(pkg.library_path())
+    syms = declared_symbols()
+    assert len(syms) >= 24
+    for name in syms:
+        assert hasattr(lib, name), name
+
+
+def test_no_device_fails_loudly():
+    import shutil
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.FemShellError) as ei:
+        pkg.FemShell(0.3, 1e7, 0.5)
+    assert ei.value.code == -2
+    assert "no CPU path" in str(ei.value)
+
+
+def plan_matrix(plan, mat, dmask_global):
+    n_local = plan["n_pad"] + plan["n_ghost"]
+    dm = np.zeros(n_local, dtype=np.uint8)
+    for a in range(plan["n_own"]):
+        dm[a] = dmask_global[plan["row_begin"] + a]
+    for g in range(plan["n_ghost"]):
+        dm[plan["n_pad"] + g] = dmask_global[plan["ghost_global"][g]]
+    return sell.assemble_from_plan(plan, mat, oracle, dm)
+
+
+@pytest.mark.parametrize("name,nu,E,t", [("test_A_uv_t", 0.25, 30000.0, 1.0), ("test_E_uvw_t", 0.25, 10000.0, 0.25),
+                                         ("test_B_uv_q", 0.25, 30000.0, 1.0)])
+def test_gather_lists_reproduce_oracle_matrix(name, nu, E, t):
+    m = meshes.load_example(name)
+    mat = oracle.material(nu, E, t)
+    dmask = m.dirichlet_mask()
+    rowptr, colidx, vals, _ = oracle.assemble(m.xyz, m.tri, m.quad, mat, dmask, m.loads)
+    plan = pkg.build_plan(m.xyz, m.tri, m.quad)
+    assert plan["nnz_blocks"] == len(colidx)
+    blocks = plan_matrix(plan, mat, dmask)
+    assert len(blocks) == len(colidx)
+    scale = np.abs(vals).max()
+    for slot, (row, col, blk) in blocks.items():
+        q = rowptr[row] + np.searchsorted(colidx[rowptr[row]:rowptr[row + 1]], col)
+        assert colidx[q] == col
+        assert np.abs(blk - vals[q]).max() <= 1e-13 * scale
+
+
+def test_diagonal_is_slot_zero_and_columns_ascend():
+    m = meshes.structured(7, 5, 0, 0, 7, 5, kind="t", ul_lr=False)
+    plan = pkg.build_plan(m.xyz, m.tri, m.quad)
+    for s in range(plan["n_slices"]):
+        base, w = int(plan["slice_base"][s]), int(plan["slice_width"][s])
+        for n in range(32):
+            row = s * 32 + n
+            if row >= plan["n_own"]:
+                continue
+            assert plan["cols"][base + n] == row
+            prev = -1
+            for k in range(1, w):
+                slot = base + k * 32 + n
+                if plan["pair_ptr"][slot + 1] > plan["pair_ptr"][slot]:
+                    assert plan["cols"][slot] > prev
+                    prev = plan["cols"][slot]
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_partition_covers_all_rows_and_halo_lists_match(world):
+    m = meshes.structured(23, 17, 0, 0, 1, 1, kind="t", ul_lr=True)
+    plans = [pkg.build_plan(m.xyz, m.tri, m.quad, rank=r, world_size=world) for r in range(world)]
+    # contiguous cover
+    assert plans[0]["row_begin"] == 0 and plans[-1]["row_end"] == m.n_nodes
+    for a, b in zip(plans[:-1], plans[1:]):
+        assert a["row_end"] == b["row_begin"]
+    assert sum(p["nnz_blocks"] for p in plans) == pkg.build_plan(m.xyz, m.tri, m.quad)["nnz_blocks"]
+    # what r sends to q is exactly what q expects from r, in the same order
+    for r, pr in enumerate(plans):
+        for i, q in enumerate(pr["peer_ranks"]):
+            send = pr["peer_send_nodes"][pr["peer_send_ptr"][i]:pr["peer_send_ptr"][i + 1]] + pr["row_begin"]
+            pq = plans[q]
+            j = list(pq["peer_ranks"]).index(r)
+            off, cnt = pq["peer_recv_offset"][j], pq["peer_recv_count"][j]
+            np.testing.assert_array_equal(send, pq["ghost_global"][off:off + cnt])
+
+
+def test_partitioned_matrix_equals_global_matrix():
+    m = meshes.structured(9, 11, 0, 0, 3, 2, kind="t", ul_lr=True, bcids=(0, 0, 1, -1))
+    m.xyz[:, 2] = 0.1 * np.sin(m.xyz[:, 0]) * m.xyz[:, 1]  # curved, so frames differ per element
+    mat = oracle.material(0.3, 2.0e5, 0.02)
+    dmask = m.dirichlet_mask()
+    rowptr, colidx, vals, _ = oracle.assemble(m.xyz, m.tri, m.quad, mat, dmask, None)
+    K = oracle.to_scipy(rowptr, colidx, vals).toarray()
+    scale = np.abs(K).max()
+    for r in range(3):
+        plan = pkg.build_plan(m.xyz, m.tri, m.quad, rank=r, world_size=3)
+        for slot, (row, col, blk) in plan_matrix(plan, mat, dmask).items():
+            gr, gc = sell.to_global_id(plan, row), sell.to_global_id(plan, col)
+            assert np.abs(K[6 * gr:6 * gr + 6, 6 * gc:6 * gc + 6] - blk).max() <= 1e-13 * scale
+
+
+def test_invalid_meshes_are_rejected():
+    m = meshes.structured(2, 2, 0, 0, 1, 1)
+    bad = m.tri.copy()
+    bad[0, 0] = 99
+    with pytest.raises(pkg.FemShellError):
+        pkg.build_plan(m.xyz, bad)
+    bad = m.tri.copy()
+    bad[1, 1] = bad[1, 0]
+    with pytest.raises(pkg.FemShellError):
+        pkg.build_plan(m.xyz, bad)
+    with pytest.raises(pkg.FemShellError):  # node 8 unused
+        pkg.build_plan(m.xyz, m.tri[:-2])
