@@ -80,7 +80,8 @@ struct femshell_ctx {
     DevBuf<double> xyz, vals, minv, loads, F;
     DevBuf<int32_t> tri, quad, slice_width, cols, pair_ptr, status;
     DevBuf<int64_t> slice_base;
-    DevBuf<uint32_t> pairs;
+    DevBuf<int32_t> slice_elem_ptr, slice_elem_nodes, item_ptr;
+    DevBuf<Plan::Item> items;
     DevBuf<uint8_t> dmask;
     // CG state
     DevBuf<double> x, r, z, p, q, partials, hist, sendbuf, ufull;
@@ -133,8 +134,10 @@ int check_status(femshell_ctx *c, const char *what)
     FS_HIP(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), c->stream));
     char buf[160];
     if (st > 0) {
-        const int32_t le = st - 1;
         const Plan &p = c->plan;
+        // the kernel reports an index into the per-slice element lists
+        const int32_t le = st >= kStatusDirect ? st - kStatusDirect
+                           : ((st - 1 < (int32_t)p.slice_elems.size()) ? p.slice_elems[st - 1] : st - 1);
         if (le < p.n_ltri())
             snprintf(buf, sizeof buf, "%s: triangle %d is degenerate (zero area or zero-length first edge)", what,
                      p.tri_global_id[le]);
@@ -362,7 +365,10 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     FS_HIP(c->slice_base.upload(p.slice_base, st));
     FS_HIP(c->cols.upload(p.cols, st));
     FS_HIP(c->pair_ptr.upload(p.pair_ptr, st));
-    FS_HIP(c->pairs.upload(p.pairs, st));
+    FS_HIP(c->slice_elem_ptr.upload(p.slice_elem_ptr, st));
+    FS_HIP(c->slice_elem_nodes.upload(p.slice_elem_nodes, st));
+    FS_HIP(c->item_ptr.upload(p.item_ptr, st));
+    FS_HIP(c->items.upload(p.items, st));
     const size_t nrow = (size_t)p.n_pad * 6, nrow_ext = (size_t)p.n_local_nodes() * 6;
     FS_HIP(c->vals.alloc((size_t)p.total_slots() * 36));
     FS_HIP(c->minv.alloc((size_t)p.n_slices * 6 * kSliceRows));
@@ -389,7 +395,23 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     c->dm.slice_base = c->slice_base.p;
     c->dm.cols = c->cols.p;
     c->dm.pair_ptr = c->pair_ptr.p;
-    c->dm.pairs = c->pairs.p;
+    c->dm.slice_elem_ptr = c->slice_elem_ptr.p;
+    c->dm.slice_elem_nodes = reinterpret_cast<const int4 *>(c->slice_elem_nodes.p);
+    c->dm.max_slice_elems = p.max_slice_elems;
+    c->dm.item_ptr = c->item_ptr.p;
+    c->dm.items = reinterpret_cast<const uint4 *>(c->items.p);
+    c->dm.max_stage_rows = p.max_stage_rows;
+    {
+        // LDS of k_assemble: output tile (kOutSlots block slots x 32 nodes x 288 B per pass) +
+        // ownership mask + element records + partial-sum staging
+        const size_t work = ((size_t)p.max_slice_elems * kRecDoubles + (size_t)p.max_stage_rows * 36) * sizeof(double);
+        const size_t tile = (size_t)kOutSlots * kSliceNodes * 36 * sizeof(double) + 256;
+        const size_t lds = work + tile;
+        if (p.max_slice_width > 64) return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_set_mesh: a node has more than 63 neighbours");
+        if (lds > 96 * 1024)
+            return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_set_mesh: a 32-node slice touches too many elements for the LDS staging");
+        c->dm.lds_bytes = (int32_t)lds;
+    }
     c->dm.vals = c->vals.p;
     c->dm.minv = c->minv.p;
     c->dm.status = c->status.p;

@@ -11,18 +11,46 @@
 #include "kernels.hpp"
 #include "plan.hpp"
 
+#include <cstdlib>
+
 namespace femshell {
 
 static_assert(kSliceNodes == 32 && kSliceRows == 192, "kernels assume 32-node slices");
 
-__device__ __forceinline__ int slice_of_block(int b, int n_slices)
+// Workgroup b belongs to XCD group x = b%8 and walks the slices x*per + j, j = b/8, b/8 + G/8, ...
+// of that group's contiguous eighth of the rows (per = ceil(S/8), G = gridDim.x).
+struct SliceWalk {
+    int per, first, last, step, s;
+    __device__ __forceinline__ SliceWalk(int n_slices)
+    {
+        per = (n_slices + 7) >> 3;
+        const int x = blockIdx.x & 7;
+        first = x * per;
+        last = min(first + per, n_slices);
+        step = gridDim.x >> 3;
+        s = first + (blockIdx.x >> 3);
+    }
+    __device__ __forceinline__ bool valid() const { return s < last; }
+    __device__ __forceinline__ void next() { s += step; }
+};
+
+static int assemble_grid(const DeviceMatrix &m)
 {
-    const int per = (n_slices + 7) >> 3;
-    const int s = (b & 7) * per + (b >> 3);
-    return s < n_slices ? s : -1;
+    static const int cap = [] {
+        const char *e = getenv("FEMSHELL_ASM_GRID");
+        return e ? atoi(e) : 2048;
+    }();
+    const int g = 8 * ((m.n_slices + 7) / 8);
+    return g < cap ? g : cap;
 }
 
-int slice_grid(const DeviceMatrix &m) { return 8 * ((m.n_slices + 7) / 8); }
+constexpr int kMaxGrid = 2560; // 256 CUs x 10 resident 192-thread workgroups
+
+int slice_grid(const DeviceMatrix &m)
+{
+    const int g = 8 * ((m.n_slices + 7) / 8);
+    return g < kMaxGrid ? g : kMaxGrid;
+}
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -57,65 +85,175 @@ __device__ __forceinline__ double block_sum(double v, double *sh)
 // rows and columns of fixed dofs are zero, the diagonal entry is the number of elements
 // touching the node.
 // =====================================================================================
-__global__ __launch_bounds__(256) void k_assemble(DeviceMatrix m, MatConst mc)
+template <int kWavesPerSimd>
+__global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m, MatConst mc)
 {
-    const int s = slice_of_block(blockIdx.x, m.n_slices);
-    if (s < 0) return;
-    const int64_t base = m.slice_base[s];
-    const int W = m.slice_width[s];
-    const int n = threadIdx.x & 31;
-    const int row = s * kSliceNodes + n;
-    const uint32_t mrow = m.dmask[row];
-    double2 *out = reinterpret_cast<double2 *>(m.vals + base * 36);
-    for (int k = threadIdx.x >> 5; k < W; k += 8) {
-        const int64_t slot = base + (int64_t)k * kSliceNodes + n;
-        const int p0 = m.pair_ptr[slot], p1 = m.pair_ptr[slot + 1];
-        double acc[36];
-#pragma unroll
-        for (int i = 0; i < 36; i++) acc[i] = 0.0;
-        for (int q = p0; q < p1; q++) {
-            const uint32_t pr = m.pairs[q];
-            const int le = (int)(pr >> 4), ia = (int)((pr >> 2) & 3u), ib = (int)(pr & 3u);
+    // LDS: [output tile | ownership mask | element records | partial-sum staging]
+    extern __shared__ double lds[];
+    double2 *lds_tile = reinterpret_cast<double2 *>(lds);                                  // kOutSlots*32*36 doubles
+    uint32_t *lds_mask = reinterpret_cast<uint32_t *>(lds + kOutSlots * kSliceNodes * 36); // 64 words
+    double *lds_rec = lds + kOutSlots * kSliceNodes * 36 + 32;
+    double *lds_stage = lds_rec + (size_t)m.max_slice_elems * kRecDoubles;
+    const int tid = threadIdx.x;
+
+    SliceWalk w(m.n_slices);
+    if (!w.valid()) return;
+    // software pipeline over slices: the node ids of the next slice's elements are fetched while
+    // the current slice computes, so that a slice exposes one dependent load (the coordinates)
+    int e0 = m.slice_elem_ptr[w.s], ne = m.slice_elem_ptr[w.s + 1] - e0;
+    int4 nd = make_int4(0, 0, 0, -1);
+    if (tid < ne) nd = m.slice_elem_nodes[e0 + tid];
+
+    for (; w.valid(); w.next()) {
+        const int s = w.s;
+        const int64_t base = m.slice_base[s];
+        const int W = m.slice_width[s];
+        const int i0 = m.item_ptr[s], ni = m.item_ptr[s + 1] - i0;
+        uint4 item = make_uint4(0, 0, 0, 0);
+        if (tid < ni) item = m.items[i0 + tid]; // in flight during phase A
+
+        // ---- phase A: one record per element touching the slice
+        for (int i = tid; i < ne; i += blockDim.x) {
+            const int4 c = (i == tid) ? nd : m.slice_elem_nodes[e0 + i];
+            double rec[kRecDoubles];
             bool ok = false;
-            if (le < m.n_ltri) {
-                const int32_t *c = m.tri + 3 * (int64_t)le;
+            if (c.w < 0) {
                 double X[9];
+                const double *pa = m.xyz + 3 * (int64_t)c.x, *pb = m.xyz + 3 * (int64_t)c.y,
+                             *pc = m.xyz + 3 * (int64_t)c.z;
+                X[0] = pa[0]; X[1] = pa[1]; X[2] = pa[2];
+                X[3] = pb[0]; X[4] = pb[1]; X[5] = pb[2];
+                X[6] = pc[0]; X[7] = pc[1]; X[8] = pc[2];
+                ok = tri3_record(X, mc, rec);
+            } else {
 #pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    const double *pt = m.xyz + 3 * (int64_t)c[i];
-                    X[3 * i + 0] = pt[0];
-                    X[3 * i + 1] = pt[1];
-                    X[3 * i + 2] = pt[2];
+                for (int q = 0; q < kRecDoubles; q++) rec[q] = 0.0;
+            }
+            if (!ok) atomicCAS(m.status, 0, e0 + i + 1);
+            double2 *dst = reinterpret_cast<double2 *>(lds_rec + (size_t)i * kRecDoubles);
+#pragma unroll
+            for (int q = 0; q < kRecDoubles / 2; q++) dst[q] = make_double2(rec[2 * q], rec[2 * q + 1]);
+        }
+        // prefetch the next slice's element node ids
+        {
+            const int s2 = s + w.step;
+            if (s2 < w.last) {
+                e0 = m.slice_elem_ptr[s2];
+                ne = m.slice_elem_ptr[s2 + 1] - e0;
+                if (tid < ne) nd = m.slice_elem_nodes[e0 + tid];
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B: one lane per work item (at most kItemPairs element contributions), in
+        //      rounds of 256 items; each round's finished blocks leave through the LDS tile so
+        //      that every store instruction covers 1 KiB of consecutive addresses
+        double2 *out = reinterpret_cast<double2 *>(m.vals + base * 36);
+        const bool multi = ni > (int)blockDim.x; // several rounds: the tile is only partly owned per round
+        for (int r0 = 0; r0 < ni; r0 += blockDim.x) {
+            const int it = r0 + tid;
+            const bool live = it < ni;
+            if (r0 > 0) {
+                item = make_uint4(0, 0, 0, 0);
+                if (live) item = m.items[i0 + it];
+            }
+            if (multi && tid < 64) lds_mask[tid] = 0u;
+            const int slot_in_slice = (int)(item.x & 0xffffu), chunk = (int)((item.x >> 16) & 0xffu),
+                      nchunks = (int)(item.x >> 24);
+            const int cnt = (int)(item.z >> 16);
+            double blk[36];
+#pragma unroll
+            for (int i = 0; i < 36; i++) blk[i] = 0.0;
+            for (int q = 0; q < cnt; q++) {
+                const uint32_t pr = (q == 0) ? (item.y & 0xffffu) : (q == 1 ? (item.y >> 16) : (item.z & 0xffffu));
+                tri3_block_add_rec(lds_rec + (size_t)(pr >> 4) * kRecDoubles, (int)((pr >> 2) & 3u), (int)(pr & 3u), mc,
+                                   blk);
+            }
+            const bool owner = live && chunk == 0 && nchunks > 0; // nchunks == 0: padding item
+            // column node and Dirichlet masks of the slot (needed after the reduction)
+            int col = 0, valence = 0;
+            uint32_t mrow = 0, mcol = 0;
+            if (owner) {
+                const int64_t slot = base + slot_in_slice;
+                col = m.cols[slot];
+                mrow = m.dmask[s * kSliceNodes + (slot_in_slice & 31)];
+                mcol = m.dmask[col];
+                valence = m.pair_ptr[slot + 1] - m.pair_ptr[slot];
+            }
+            if (live && chunk > 0) {
+                double2 *st = reinterpret_cast<double2 *>(lds_stage + (size_t)item.w * 36);
+#pragma unroll
+                for (int i = 0; i < 18; i++) st[i] = make_double2(blk[2 * i], blk[2 * i + 1]);
+            }
+            __syncthreads();
+            if (owner) {
+                // chunks > 0 sort after chunk 0, so with several rounds they may not have run yet:
+                // plan.cpp keeps all chunks of a slot in one round when a slice has several rounds
+                for (int c = 1; c < nchunks; c++) {
+                    const double2 *st = reinterpret_cast<const double2 *>(lds_stage + (size_t)(item.w + c - 1) * 36);
+#pragma unroll
+                    for (int i = 0; i < 18; i++) {
+                        const double2 v = st[i];
+                        blk[2 * i] += v.x;
+                        blk[2 * i + 1] += v.y;
+                    }
                 }
-                ok = tri3_block_add(X, ia, ib, mc, acc);
+                if (mrow | mcol) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++)
+#pragma unroll
+                        for (int j = 0; j < 6; j++)
+                            if (((mrow >> i) & 1u) | ((mcol >> j) & 1u)) blk[6 * i + j] = 0.0;
+                    if (col == s * kSliceNodes + (slot_in_slice & 31)) {
+#pragma unroll
+                        for (int i = 0; i < 6; i++)
+                            if ((mrow >> i) & 1u) blk[7 * i] = (double)valence;
+                    }
+                }
+                if (multi) atomicOr(&lds_mask[slot_in_slice >> 5], 1u << (slot_in_slice & 31));
             }
-            if (!ok) atomicCAS(m.status, 0, le + 1);
-        }
-        const int col = m.cols[slot];
-        const uint32_t mcol = m.dmask[col];
-        if (mrow | mcol) {
+            const int my_k = slot_in_slice >> 5, my_n = slot_in_slice & 31;
+            for (int k0 = 0; k0 < W; k0 += kOutSlots) {
+                if (owner && my_k >= k0 && my_k < k0 + kOutSlots) {
+                    double2 *t = lds_tile + (size_t)(my_k - k0) * 3 * kSliceRows + my_n * 6;
 #pragma unroll
-            for (int i = 0; i < 6; i++)
+                    for (int jp = 0; jp < 3; jp++)
 #pragma unroll
-                for (int j = 0; j < 6; j++)
-                    if (((mrow >> i) & 1u) | ((mcol >> j) & 1u)) acc[6 * i + j] = 0.0;
-            if (col == row) {
-#pragma unroll
-                for (int i = 0; i < 6; i++)
-                    if ((mrow >> i) & 1u) acc[7 * i] = (double)(p1 - p0);
+                        for (int i = 0; i < 6; i++)
+                            t[jp * kSliceRows + i] = make_double2(blk[6 * i + 2 * jp], blk[6 * i + 2 * jp + 1]);
+                }
+                __syncthreads();
+                const int nk = min(kOutSlots, W - k0);
+                const int words = nk * 3 * kSliceRows; // double2 words of this pass
+                double2 *dst = out + (size_t)k0 * 3 * kSliceRows;
+                if (!multi) {
+                    for (int q = tid; q < words; q += blockDim.x) dst[q] = lds_tile[q];
+                } else {
+                    for (int q = tid; q < words; q += blockDim.x) {
+                        const int kk = k0 + q / (3 * kSliceRows), nn = (q % kSliceRows) / 6;
+                        if ((lds_mask[kk] >> nn) & 1u) dst[q] = lds_tile[q];
+                    }
+                }
+                __syncthreads();
             }
         }
-#pragma unroll
-        for (int jp = 0; jp < 3; jp++)
-#pragma unroll
-            for (int i = 0; i < 6; i++)
-                out[(k * 3 + jp) * kSliceRows + n * 6 + i] = make_double2(acc[6 * i + 2 * jp], acc[6 * i + 2 * jp + 1]);
     }
 }
 
 void launch_assemble(const DeviceMatrix &m, const MatConst &mc, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_assemble, dim3(slice_grid(m)), dim3(256), 0, st, m, mc);
+    const size_t lds = (size_t)m.lds_bytes;
+    static const int variant = [] {
+        const char *e = getenv("FEMSHELL_ASM_WAVES"); // tuning knob: waves per SIMD the kernel is compiled for
+        return e ? atoi(e) : 2;
+    }();
+    const int g = assemble_grid(m);
+    switch (variant) {
+    case 1: hipLaunchKernelGGL(k_assemble<1>, dim3(g), dim3(256), lds, st, m, mc); break;
+    case 3: hipLaunchKernelGGL(k_assemble<3>, dim3(g), dim3(256), lds, st, m, mc); break;
+    case 4: hipLaunchKernelGGL(k_assemble<4>, dim3(g), dim3(256), lds, st, m, mc); break;
+    default: hipLaunchKernelGGL(k_assemble<2>, dim3(g), dim3(256), lds, st, m, mc); break;
+    }
 }
 
 // Right-hand side: contribRHS (fem-shell.cpp:1118-1153) is a masked copy -- every node's load
@@ -151,7 +289,7 @@ __global__ __launch_bounds__(128) void k_element_matrices(DeviceMatrix m, MatCon
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0.0;
-    if (!tri3_block_add(X, ia, ib, mc, acc)) atomicCAS(m.status, 0, first + e + 1);
+    if (!tri3_block_add(X, ia, ib, mc, acc)) atomicCAS(m.status, 0, kStatusDirect + first + e);
     double *Ke = out + (int64_t)e * 324;
 #pragma unroll
     for (int al = 0; al < 6; al++)
@@ -251,12 +389,12 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
 {
     __shared__ double sh[3];
     if (s != nullptr && s->done != 0) return;
-    const int sl = slice_of_block(blockIdx.x, m.n_slices);
+    const int t = threadIdx.x;
     double dotv = 0.0;
-    if (sl >= 0) {
+    for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
+        const int sl = w.s;
         const int64_t base = m.slice_base[sl];
         const int W = m.slice_width[sl];
-        const int t = threadIdx.x;
         const int32_t *c = m.cols + base + t / 6;
         const double2 *v = reinterpret_cast<const double2 *>(m.vals + base * 36) + t;
         double acc = 0.0;
@@ -276,7 +414,7 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
         }
         const int64_t row = (int64_t)sl * kSliceRows + t;
         y[row] = acc;
-        if (partials != nullptr) dotv = acc * x[row];
+        if (partials != nullptr) dotv += acc * x[row];
     }
     if (partials != nullptr) {
         const double tot = block_sum(dotv, sh);
@@ -309,13 +447,13 @@ __global__ __launch_bounds__(192) void k_cg_init(DeviceMatrix m, CgVectors v)
 {
     __shared__ double rs[kSliceRows];
     __shared__ double sh[3];
-    const int G = gridDim.x;
-    const int sl = slice_of_block(blockIdx.x, m.n_slices);
+    const int G = gridDim.x, t = threadIdx.x;
     double d0 = 0.0, d1 = 0.0;
-    if (sl >= 0) {
-        const int t = threadIdx.x;
+    for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
+        const int sl = w.s;
         const int64_t row = (int64_t)sl * kSliceRows + t;
         const double bv = v.b[row];
+        __syncthreads();
         rs[t] = bv;
         __syncthreads();
         const double z = apply_minv(m, sl, t, rs);
@@ -323,8 +461,8 @@ __global__ __launch_bounds__(192) void k_cg_init(DeviceMatrix m, CgVectors v)
         v.r[row] = bv;
         v.z[row] = z;
         v.p[row] = z;
-        d0 = bv * z;
-        d1 = bv * bv;
+        d0 += bv * z;
+        d1 += bv * bv;
     }
     const double t0 = block_sum(d0, sh);
     const double t1 = block_sum(d1, sh);
@@ -345,23 +483,23 @@ __global__ __launch_bounds__(192) void k_cg_update(DeviceMatrix m, CgVectors v)
     __shared__ double rs[kSliceRows];
     __shared__ double sh[3];
     if (v.s->done != 0) return;
-    const int G = gridDim.x;
+    const int G = gridDim.x, t = threadIdx.x;
     const double alpha = v.s->alpha;
-    const int sl = slice_of_block(blockIdx.x, m.n_slices);
     double d0 = 0.0, d1 = 0.0;
-    if (sl >= 0) {
-        const int t = threadIdx.x;
+    for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
+        const int sl = w.s;
         const int64_t row = (int64_t)sl * kSliceRows + t;
         const double pv = v.p[row], qv = v.q[row];
         v.x[row] += alpha * pv;
         const double rn = v.r[row] - alpha * qv;
         v.r[row] = rn;
+        __syncthreads();
         rs[t] = rn;
         __syncthreads();
         const double z = apply_minv(m, sl, t, rs);
         v.z[row] = z;
-        d0 = rn * z;
-        d1 = rn * rn;
+        d0 += rn * z;
+        d1 += rn * rn;
     }
     const double t0 = block_sum(d0, sh);
     const double t1 = block_sum(d1, sh);

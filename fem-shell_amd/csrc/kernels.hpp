@@ -8,6 +8,9 @@
 
 namespace femshell {
 
+constexpr int kOutSlots = 4;               // block slots per output pass of k_assemble (LDS tile = 36,864 B)
+constexpr int32_t kStatusDirect = 0x40000000; // status values above this carry a local element id directly
+
 // Device view of the mesh + matrix structure of one rank (see plan.hpp for the layout).
 struct DeviceMatrix {
     int32_t n_own = 0, n_pad = 0, n_ghost = 0, n_slices = 0;
@@ -19,7 +22,13 @@ struct DeviceMatrix {
     const int64_t *slice_base = nullptr;
     const int32_t *cols = nullptr;      // per slot
     const int32_t *pair_ptr = nullptr;  // per slot + 1
-    const uint32_t *pairs = nullptr;
+    const int32_t *slice_elem_ptr = nullptr; // n_slices+1
+    const int4 *slice_elem_nodes = nullptr;  // per slice element: its local node ids (w = -1 for TRI3)
+    int32_t max_slice_elems = 0;
+    const int32_t *item_ptr = nullptr;       // n_slices+1
+    const uint4 *items = nullptr;            // assembly work items (plan.hpp)
+    int32_t max_stage_rows = 0;
+    int32_t lds_bytes = 0;                   // dynamic LDS of k_assemble
     const uint8_t *dmask = nullptr;     // per local node (owned, padding, ghosts)
     double *vals = nullptr;             // total_slots x 36, sliced layout
     double *minv = nullptr;             // n_slices x 6 x 192: inverse diagonal blocks
@@ -55,7 +64,7 @@ struct CgVectors {
 
 enum CgPhase : int { CG_PHASE_NONE = 0, CG_PHASE_INIT = 1, CG_PHASE_ALPHA = 2, CG_PHASE_BETA = 3 };
 
-int slice_grid(const DeviceMatrix &m); // workgroups of the per-slice kernels (8 * ceil(n_slices/8))
+int slice_grid(const DeviceMatrix &m); // workgroups of the per-slice kernels (multiple of 8, at most 2560)
 
 void launch_assemble(const DeviceMatrix &m, const MatConst &mc, hipStream_t st);
 void launch_rhs(const DeviceMatrix &m, const double *loads /* n_pad x 6 */, double *F, hipStream_t st);

@@ -208,6 +208,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             if (a < n_own) w = std::max(w, node_slot_ptr[a + 1] - node_slot_ptr[a]);
         }
         p.slice_width[s] = w;
+        p.max_slice_width = std::max(p.max_slice_width, w);
         p.slice_base[s + 1] = p.slice_base[s] + (int64_t)w * kSliceNodes;
     }
     const int64_t total = p.slice_base[p.n_slices];
@@ -235,6 +236,98 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             }
     }
     p.pair_ptr[total] = (int32_t)p.pairs.size();
+
+    // ---- per-slice element lists and slice-relative 16-bit gather entries
+    p.slice_elem_ptr.assign((size_t)p.n_slices + 1, 0);
+    p.pairs16.resize(p.pairs.size());
+    {
+        std::vector<int32_t> ids;
+        for (int32_t s = 0; s < p.n_slices; s++) {
+            const int32_t q0 = p.pair_ptr[p.slice_base[s]], q1 = p.pair_ptr[p.slice_base[s + 1]];
+            ids.clear();
+            for (int32_t q = q0; q < q1; q++) ids.push_back((int32_t)(p.pairs[q] >> 4));
+            std::sort(ids.begin(), ids.end());
+            ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+            if (ids.size() > 4095) return fail("more than 4095 elements touch one 32-node slice");
+            p.max_slice_elems = std::max<int32_t>(p.max_slice_elems, (int32_t)ids.size());
+            for (int32_t q = q0; q < q1; q++) {
+                const int32_t le = (int32_t)(p.pairs[q] >> 4);
+                const int32_t idx = (int32_t)(std::lower_bound(ids.begin(), ids.end(), le) - ids.begin());
+                p.pairs16[q] = (uint16_t)((idx << 4) | (p.pairs[q] & 15u));
+            }
+            p.slice_elems.insert(p.slice_elems.end(), ids.begin(), ids.end());
+            for (int32_t le : ids) {
+                if (le < p.n_ltri()) {
+                    for (int i = 0; i < 3; i++) p.slice_elem_nodes.push_back(p.tri_local[3ll * le + i]);
+                    p.slice_elem_nodes.push_back(-1);
+                } else {
+                    for (int i = 0; i < 4; i++) p.slice_elem_nodes.push_back(p.quad_local[4ll * (le - p.n_ltri()) + i]);
+                }
+            }
+            p.slice_elem_ptr[s + 1] = (int32_t)p.slice_elems.size();
+        }
+    }
+
+    // ---- assembly work items
+    p.item_ptr.assign((size_t)p.n_slices + 1, 0);
+    {
+        std::vector<Plan::Item> tmp;
+        for (int32_t s = 0; s < p.n_slices; s++) {
+            tmp.clear();
+            int32_t stage = 0;
+            const int w = p.slice_width[s];
+            for (int k = 0; k < w; k++)
+                for (int n = 0; n < kSliceNodes; n++) {
+                    const int64_t idx = Plan::slot_index(p.slice_base[s], k, n);
+                    const int32_t q0 = p.pair_ptr[idx], cnt = p.pair_ptr[idx + 1] - q0;
+                    const int nchunks = std::max(1, (cnt + kItemPairs - 1) / kItemPairs);
+                    if (nchunks > 255) return fail("a block slot has more than 765 contributions");
+                    const int32_t stage0 = stage;
+                    for (int c = 0; c < nchunks; c++) {
+                        const int32_t b = q0 + c * kItemPairs, e = std::min(q0 + cnt, b + kItemPairs);
+                        const int np = std::max(0, e - b);
+                        uint32_t pr[3] = {0, 0, 0};
+                        for (int q = 0; q < np; q++) pr[q] = p.pairs16[b + q];
+                        Plan::Item it;
+                        it.x = (uint32_t)(k * kSliceNodes + n) | ((uint32_t)c << 16) | ((uint32_t)nchunks << 24);
+                        it.y = pr[0] | (pr[1] << 16);
+                        it.z = pr[2] | ((uint32_t)np << 16);
+                        it.w = (uint32_t)(c == 0 ? stage0 : stage0 + c - 1);
+                        tmp.push_back(it);
+                    }
+                    stage += nchunks - 1;
+                }
+            if (tmp.size() <= 256) {
+                // one round: order by decreasing work so that the waves are uniform
+                std::stable_sort(tmp.begin(), tmp.end(),
+                                 [](const Plan::Item &a, const Plan::Item &b) { return (a.z >> 16) > (b.z >> 16); });
+            } else {
+                // several rounds of 256 items: a slot's chunks must share a round (they meet in LDS),
+                // so fill rounds greedily with whole slots, then order each round by work
+                std::vector<Plan::Item> packed;
+                size_t i = 0;
+                while (i < tmp.size()) {
+                    const size_t round_begin = packed.size();
+                    while (i < tmp.size()) {
+                        const size_t nch = tmp[i].x >> 24;
+                        if (packed.size() - round_begin + nch > 256) break;
+                        for (size_t c = 0; c < nch; c++) packed.push_back(tmp[i + c]);
+                        i += nch;
+                    }
+                    std::stable_sort(packed.begin() + round_begin, packed.end(),
+                                     [](const Plan::Item &a, const Plan::Item &b) { return (a.z >> 16) > (b.z >> 16); });
+                    if (i < tmp.size()) {
+                        Plan::Item pad{0xffffu, 0, 0, 0}; // inert item: slot 0xffff, chunk 0, 0 chunks
+                        while (packed.size() - round_begin < 256) packed.push_back(pad);
+                    }
+                }
+                tmp.swap(packed);
+            }
+            p.max_stage_rows = std::max(p.max_stage_rows, stage);
+            p.items.insert(p.items.end(), tmp.begin(), tmp.end());
+            p.item_ptr[s + 1] = (int32_t)p.items.size();
+        }
+    }
 
     // ---- halo exchange lists
     if (world > 1) {

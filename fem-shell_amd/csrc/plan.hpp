@@ -27,6 +27,7 @@ namespace femshell {
 
 constexpr int kSliceNodes = 32;             // node rows per slice
 constexpr int kSliceRows = 6 * kSliceNodes; // scalar rows per slice
+constexpr int kItemPairs = 3;                // element contributions per assembly work item
 
 struct HaloPeer {
     int rank = -1;
@@ -55,6 +56,29 @@ struct Plan {
     std::vector<int32_t> pair_ptr;     // per slot + 1
     std::vector<uint32_t> pairs;       // (local element << 4) | (row node in element << 2) | column node in element
                                        // local element index: triangles [0,n_ltri), quads n_ltri + q
+    // per slice: the distinct local elements its gather lists reference (ascending); the device
+    // kernel stages one record per such element in LDS and addresses it with the 16-bit entries
+    //   pairs16 = (index into the slice's element list << 4) | (row node << 2) | column node
+    std::vector<int32_t> slice_elem_ptr; // n_slices+1
+    std::vector<int32_t> slice_elems;
+    std::vector<uint16_t> pairs16;       // same order as pairs
+    int32_t max_slice_elems = 0;
+    std::vector<int32_t> slice_elem_nodes; // 4 local node ids per entry of slice_elems (4th = -1 for TRI3)
+    // work items of the assembly kernel: a block slot's gather list is cut into chunks of at most
+    // kItemPairs contributions so that every lane has the same amount of work; chunk 0 owns the
+    // slot (it adds the other chunks' partial sums in chunk order and writes the block).  Per
+    // slice the items are ordered by decreasing contribution count.  An item carries its
+    // contributions (pairs16 entries) itself, so the kernel has no dependent index loads:
+    //   x = slot in slice (k*32+n) | chunk index << 16 | number of chunks << 24
+    //   y = pair 0 | pair 1 << 16
+    //   z = pair 2 | pair count << 16
+    //   w = LDS staging row of this chunk's partial sum (chunks > 0), or first staging row of
+    //       the slot's other chunks (chunk 0)
+    struct Item { uint32_t x, y, z, w; };
+    std::vector<int32_t> item_ptr; // n_slices+1
+    std::vector<Item> items;
+    int32_t max_stage_rows = 0;    // staging rows (36 doubles each) a slice needs at most
+    int32_t max_slice_width = 0;
     int64_t nnz_blocks = 0;            // real (non-padding) blocks
     std::vector<HaloPeer> peers;
 
