@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--nx", type=int, default=1414, help="squares per side (1414 -> 3,998,792 tri3)")
     ap.add_argument("--cg-iters", type=int, default=50, help="CG iterations per step in the CG phase")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile", action="store_true",
+                    help="for rocprofv3 runs: only the 4M-tri workload (no small-mesh parity probe, no CPU baseline)")
     args = ap.parse_args()
 
     import torch  # first: its HIP runtime then serves libfemshell too (same SONAME)
@@ -194,7 +196,7 @@ def main():
             "roofline_cg_direction": dict(roof(dir_ms, dir_bytes), kernel="k_cg_direction"),
             "roofline_cg_iteration": roof(1e3 * t_cg / max(info["iterations"], 1), info["bytes_per_iteration"]),
         }
-        if world == 1:
+        if world == 1 and not args.profile:
             out["parity"] = parity_probe(pkg, local_rank)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()

@@ -10,29 +10,13 @@
 // by neighbouring slices.
 #include "kernels.hpp"
 #include "plan.hpp"
+#include "assemble_kernel.hpp"
 
 #include <cstdlib>
 
 namespace femshell {
 
 static_assert(kSliceNodes == 32 && kSliceRows == 192, "kernels assume 32-node slices");
-
-// Workgroup b belongs to XCD group x = b%8 and walks the slices x*per + j, j = b/8, b/8 + G/8, ...
-// of that group's contiguous eighth of the rows (per = ceil(S/8), G = gridDim.x).
-struct SliceWalk {
-    int per, first, last, step, s;
-    __device__ __forceinline__ SliceWalk(int n_slices)
-    {
-        per = (n_slices + 7) >> 3;
-        const int x = blockIdx.x & 7;
-        first = x * per;
-        last = min(first + per, n_slices);
-        step = gridDim.x >> 3;
-        s = first + (blockIdx.x >> 3);
-    }
-    __device__ __forceinline__ bool valid() const { return s < last; }
-    __device__ __forceinline__ void next() { s += step; }
-};
 
 static int assemble_grid(const DeviceMatrix &m)
 {
@@ -44,12 +28,14 @@ static int assemble_grid(const DeviceMatrix &m)
     return g < cap ? g : cap;
 }
 
-constexpr int kMaxGrid = 2560; // 256 CUs x 10 resident 192-thread workgroups
-
 int slice_grid(const DeviceMatrix &m)
 {
+    static const int cap = [] {
+        const char *e = getenv("FEMSHELL_SLICE_GRID"); // tuning knob
+        return e ? atoi(e) : 20480; // ~3 slices per workgroup at 4M triangles: measured optimum of SpMV vs reduction cost
+    }();
     const int g = 8 * ((m.n_slices + 7) / 8);
-    return g < kMaxGrid ? g : kMaxGrid;
+    return g < cap ? g : cap;
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -71,173 +57,6 @@ __device__ __forceinline__ double block_sum(double v, double *sh)
         for (int i = 0; i < nw; i++) t += sh[i];
     __syncthreads();
     return t;
-}
-
-// =====================================================================================
-// Assembly: replaces the element loop of assemble_elasticity (fem-shell.cpp:1197-1232).
-// One lane owns one 6x6 block slot of K (slot k of node n of the slice) and sums the
-// contributions K_e(ia,ib) of the elements in the slot's gather list, in element order.
-// Slot 0 is the diagonal block (about six elements), the other slots are edge blocks
-// (two elements), so putting the diagonal slots of a slice into one wave keeps the other
-// waves divergence-free.  Every block is written exactly once: no atomics, no zero-fill
-// pass, bitwise reproducible.
-// Dirichlet dofs follow libMesh's constrain_element_matrix_and_vector (fem-shell.cpp:1227):
-// rows and columns of fixed dofs are zero, the diagonal entry is the number of elements
-// touching the node.
-// =====================================================================================
-template <int kWavesPerSimd>
-__global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m, MatConst mc)
-{
-    // LDS: [output tile | ownership mask | element records | partial-sum staging]
-    extern __shared__ double lds[];
-    double2 *lds_tile = reinterpret_cast<double2 *>(lds);                                  // kOutSlots*32*36 doubles
-    uint32_t *lds_mask = reinterpret_cast<uint32_t *>(lds + kOutSlots * kSliceNodes * 36); // 64 words
-    double *lds_rec = lds + kOutSlots * kSliceNodes * 36 + 32;
-    double *lds_stage = lds_rec + (size_t)m.max_slice_elems * kRecDoubles;
-    const int tid = threadIdx.x;
-
-    SliceWalk w(m.n_slices);
-    if (!w.valid()) return;
-    // software pipeline over slices: the node ids of the next slice's elements are fetched while
-    // the current slice computes, so that a slice exposes one dependent load (the coordinates)
-    int e0 = m.slice_elem_ptr[w.s], ne = m.slice_elem_ptr[w.s + 1] - e0;
-    int4 nd = make_int4(0, 0, 0, -1);
-    if (tid < ne) nd = m.slice_elem_nodes[e0 + tid];
-
-    for (; w.valid(); w.next()) {
-        const int s = w.s;
-        const int64_t base = m.slice_base[s];
-        const int W = m.slice_width[s];
-        const int i0 = m.item_ptr[s], ni = m.item_ptr[s + 1] - i0;
-        uint4 item = make_uint4(0, 0, 0, 0);
-        if (tid < ni) item = m.items[i0 + tid]; // in flight during phase A
-
-        // ---- phase A: one record per element touching the slice
-        for (int i = tid; i < ne; i += blockDim.x) {
-            const int4 c = (i == tid) ? nd : m.slice_elem_nodes[e0 + i];
-            double rec[kRecDoubles];
-            bool ok = false;
-            if (c.w < 0) {
-                double X[9];
-                const double *pa = m.xyz + 3 * (int64_t)c.x, *pb = m.xyz + 3 * (int64_t)c.y,
-                             *pc = m.xyz + 3 * (int64_t)c.z;
-                X[0] = pa[0]; X[1] = pa[1]; X[2] = pa[2];
-                X[3] = pb[0]; X[4] = pb[1]; X[5] = pb[2];
-                X[6] = pc[0]; X[7] = pc[1]; X[8] = pc[2];
-                ok = tri3_record(X, mc, rec);
-            } else {
-#pragma unroll
-                for (int q = 0; q < kRecDoubles; q++) rec[q] = 0.0;
-            }
-            if (!ok) atomicCAS(m.status, 0, e0 + i + 1);
-            double2 *dst = reinterpret_cast<double2 *>(lds_rec + (size_t)i * kRecDoubles);
-#pragma unroll
-            for (int q = 0; q < kRecDoubles / 2; q++) dst[q] = make_double2(rec[2 * q], rec[2 * q + 1]);
-        }
-        // prefetch the next slice's element node ids
-        {
-            const int s2 = s + w.step;
-            if (s2 < w.last) {
-                e0 = m.slice_elem_ptr[s2];
-                ne = m.slice_elem_ptr[s2 + 1] - e0;
-                if (tid < ne) nd = m.slice_elem_nodes[e0 + tid];
-            }
-        }
-        __syncthreads();
-
-        // ---- phase B: one lane per work item (at most kItemPairs element contributions), in
-        //      rounds of 256 items; each round's finished blocks leave through the LDS tile so
-        //      that every store instruction covers 1 KiB of consecutive addresses
-        double2 *out = reinterpret_cast<double2 *>(m.vals + base * 36);
-        const bool multi = ni > (int)blockDim.x; // several rounds: the tile is only partly owned per round
-        for (int r0 = 0; r0 < ni; r0 += blockDim.x) {
-            const int it = r0 + tid;
-            const bool live = it < ni;
-            if (r0 > 0) {
-                item = make_uint4(0, 0, 0, 0);
-                if (live) item = m.items[i0 + it];
-            }
-            if (multi && tid < 64) lds_mask[tid] = 0u;
-            const int slot_in_slice = (int)(item.x & 0xffffu), chunk = (int)((item.x >> 16) & 0xffu),
-                      nchunks = (int)(item.x >> 24);
-            const int cnt = (int)(item.z >> 16);
-            double blk[36];
-#pragma unroll
-            for (int i = 0; i < 36; i++) blk[i] = 0.0;
-            for (int q = 0; q < cnt; q++) {
-                const uint32_t pr = (q == 0) ? (item.y & 0xffffu) : (q == 1 ? (item.y >> 16) : (item.z & 0xffffu));
-                tri3_block_add_rec(lds_rec + (size_t)(pr >> 4) * kRecDoubles, (int)((pr >> 2) & 3u), (int)(pr & 3u), mc,
-                                   blk);
-            }
-            const bool owner = live && chunk == 0 && nchunks > 0; // nchunks == 0: padding item
-            // column node and Dirichlet masks of the slot (needed after the reduction)
-            int col = 0, valence = 0;
-            uint32_t mrow = 0, mcol = 0;
-            if (owner) {
-                const int64_t slot = base + slot_in_slice;
-                col = m.cols[slot];
-                mrow = m.dmask[s * kSliceNodes + (slot_in_slice & 31)];
-                mcol = m.dmask[col];
-                valence = m.pair_ptr[slot + 1] - m.pair_ptr[slot];
-            }
-            if (live && chunk > 0) {
-                double2 *st = reinterpret_cast<double2 *>(lds_stage + (size_t)item.w * 36);
-#pragma unroll
-                for (int i = 0; i < 18; i++) st[i] = make_double2(blk[2 * i], blk[2 * i + 1]);
-            }
-            __syncthreads();
-            if (owner) {
-                // chunks > 0 sort after chunk 0, so with several rounds they may not have run yet:
-                // plan.cpp keeps all chunks of a slot in one round when a slice has several rounds
-                for (int c = 1; c < nchunks; c++) {
-                    const double2 *st = reinterpret_cast<const double2 *>(lds_stage + (size_t)(item.w + c - 1) * 36);
-#pragma unroll
-                    for (int i = 0; i < 18; i++) {
-                        const double2 v = st[i];
-                        blk[2 * i] += v.x;
-                        blk[2 * i + 1] += v.y;
-                    }
-                }
-                if (mrow | mcol) {
-#pragma unroll
-                    for (int i = 0; i < 6; i++)
-#pragma unroll
-                        for (int j = 0; j < 6; j++)
-                            if (((mrow >> i) & 1u) | ((mcol >> j) & 1u)) blk[6 * i + j] = 0.0;
-                    if (col == s * kSliceNodes + (slot_in_slice & 31)) {
-#pragma unroll
-                        for (int i = 0; i < 6; i++)
-                            if ((mrow >> i) & 1u) blk[7 * i] = (double)valence;
-                    }
-                }
-                if (multi) atomicOr(&lds_mask[slot_in_slice >> 5], 1u << (slot_in_slice & 31));
-            }
-            const int my_k = slot_in_slice >> 5, my_n = slot_in_slice & 31;
-            for (int k0 = 0; k0 < W; k0 += kOutSlots) {
-                if (owner && my_k >= k0 && my_k < k0 + kOutSlots) {
-                    double2 *t = lds_tile + (size_t)(my_k - k0) * 3 * kSliceRows + my_n * 6;
-#pragma unroll
-                    for (int jp = 0; jp < 3; jp++)
-#pragma unroll
-                        for (int i = 0; i < 6; i++)
-                            t[jp * kSliceRows + i] = make_double2(blk[6 * i + 2 * jp], blk[6 * i + 2 * jp + 1]);
-                }
-                __syncthreads();
-                const int nk = min(kOutSlots, W - k0);
-                const int words = nk * 3 * kSliceRows; // double2 words of this pass
-                double2 *dst = out + (size_t)k0 * 3 * kSliceRows;
-                if (!multi) {
-                    for (int q = tid; q < words; q += blockDim.x) dst[q] = lds_tile[q];
-                } else {
-                    for (int q = tid; q < words; q += blockDim.x) {
-                        const int kk = k0 + q / (3 * kSliceRows), nn = (q % kSliceRows) / 6;
-                        if ((lds_mask[kk] >> nn) & 1u) dst[q] = lds_tile[q];
-                    }
-                }
-                __syncthreads();
-            }
-        }
-    }
 }
 
 void launch_assemble(const DeviceMatrix &m, const MatConst &mc, hipStream_t st)
@@ -539,17 +358,26 @@ void launch_cg_direction(const DeviceMatrix &m, const CgVectors &v, hipStream_t 
 
 // single workgroup: deterministic reduction of the per-workgroup partial sums, then the
 // scalar recurrence step
-__global__ __launch_bounds__(256) void k_cg_scalar(CgVectors v, int G, int do_reduce, int nsums, int phase,
-                                                   double rtol)
+__global__ __launch_bounds__(1024) void k_cg_scalar(CgVectors v, int G, int do_reduce, int nsums, int phase,
+                                                    double rtol)
 {
-    __shared__ double sh[4];
+    __shared__ double sh[16];
     CgScalars *s = v.s;
     if (phase != CG_PHASE_INIT && s->done != 0) return;
     if (do_reduce) {
         for (int a = 0; a < nsums; a++) {
-            double t = 0.0;
-            for (int i = threadIdx.x; i < G; i += blockDim.x) t += v.partials[(int64_t)a * G + i];
-            const double tot = block_sum(t, sh);
+            const double *pa = v.partials + (int64_t)a * G;
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+            int i = threadIdx.x;
+            const int B = blockDim.x;
+            for (; i + 3 * B < G; i += 4 * B) {
+                t0 += pa[i];
+                t1 += pa[i + B];
+                t2 += pa[i + 2 * B];
+                t3 += pa[i + 3 * B];
+            }
+            for (; i < G; i += B) t0 += pa[i];
+            const double tot = block_sum((t0 + t1) + (t2 + t3), sh);
             if (threadIdx.x == 0) s->red[a] = tot;
         }
     }
@@ -584,7 +412,7 @@ __global__ __launch_bounds__(256) void k_cg_scalar(CgVectors v, int G, int do_re
 void launch_cg_scalar(const DeviceMatrix &m, const CgVectors &v, bool reduce, int nsums, CgPhase phase,
                       double rtol, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_cg_scalar, dim3(1), dim3(256), 0, st, v, slice_grid(m), reduce ? 1 : 0, nsums, (int)phase,
+    hipLaunchKernelGGL(k_cg_scalar, dim3(1), dim3(1024), 0, st, v, slice_grid(m), reduce ? 1 : 0, nsums, (int)phase,
                        rtol);
 }
 

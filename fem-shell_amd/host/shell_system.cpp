@@ -1,0 +1,193 @@
+// shell_system.cpp -- see shell_system.hpp
+#include "shell_system.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+
+namespace femshell_host {
+
+namespace {
+
+void check(int rc, const char *what)
+{
+    if (rc != FEMSHELL_OK) throw std::runtime_error(std::string(what) + ": " + femshell_last_error());
+}
+
+// GetPot-like lookup: value following `flag`, if present
+const char *arg_after(int argc, char **argv, const char *flag)
+{
+    for (int i = 1; i + 1 < argc; i++)
+        if (std::strcmp(argv[i], flag) == 0) return argv[i + 1];
+    return nullptr;
+}
+
+bool has_flag(int argc, char **argv, const char *flag)
+{
+    for (int i = 1; i < argc; i++)
+        if (std::strcmp(argv[i], flag) == 0) return true;
+    return false;
+}
+
+} // namespace
+
+bool read_parameters(int argc, char **argv, Parameters &p, std::ostream &out, std::ostream &err)
+{
+    if (argc < 5) {
+        err << "Error, must choose valid parameters.\n"
+            << "Usage: " << argv[0] << " -nu -e -t -mesh [-out] [-d]\n"
+            << "-nu:\t Possion's ratio (required)\n"
+            << "-e:\t Elastic/Young's modulus E (required)\n"
+            << "-t:\t Thickness (required)\n"
+            << "-mesh:\t Input mesh file (*.xda, required)\n"
+            << "-out:\t Output file name (without extension, optional)\n"
+            << "-d:\t Additional (debug) messages (1=on, 0=off (default))\n"
+            << "-tol:\t relative residual tolerance of the CG solve (optional, default 1e-12)\n"
+            << "-max_it:\t iteration limit of the CG solve (optional, default 100000)\n";
+        return false;
+    }
+    bool failed = false;
+    if (const char *v = arg_after(argc, argv, "-d")) p.debug = std::atoi(v) == 1;
+    if (has_flag(argc, argv, "-nu")) {
+        const char *v = arg_after(argc, argv, "-nu");
+        p.nu = v ? std::atof(v) : 0.3;
+    } else {
+        err << "ERROR: Poisson's ratio nu not specified!\n";
+        failed = true;
+    }
+    if (has_flag(argc, argv, "-e")) {
+        const char *v = arg_after(argc, argv, "-e");
+        p.em = v ? std::atof(v) : 1.0e6;
+    } else {
+        err << "ERROR: Elastic modulus E not specified!\n";
+        failed = true;
+    }
+    if (has_flag(argc, argv, "-t")) {
+        const char *v = arg_after(argc, argv, "-t");
+        p.thickness = v ? std::atof(v) : 1.0;
+    } else {
+        err << "ERROR: Mesh thickness t not specified!\n";
+        failed = true;
+    }
+    if (has_flag(argc, argv, "-mesh")) {
+        const char *v = arg_after(argc, argv, "-mesh");
+        p.in_filename = v ? v : "mesh.xda";
+    } else {
+        err << "ERROR: Mesh file not specified!\n";
+        failed = true;
+    }
+    if (has_flag(argc, argv, "-out")) {
+        const char *v = arg_after(argc, argv, "-out");
+        p.out_filename = v ? v : "out";
+        p.isOutfileSet = true;
+    } else {
+        p.isOutfileSet = false;
+    }
+    if (const char *v = arg_after(argc, argv, "-tol")) p.tol = std::atof(v);
+    if (const char *v = arg_after(argc, argv, "-max_it")) p.max_it = std::atoi(v);
+
+    out << "Run program with parameters:"
+        << " debug messages = " << (p.debug ? "true" : "false") << ", nu = " << p.nu << ", E = " << p.em
+        << ", t = " << p.thickness << ", mesh file = " << p.in_filename;
+    if (p.isOutfileSet) out << ", out-file = " << p.out_filename;
+    out << std::endl;
+    return !failed;
+}
+
+ShellSystem::ShellSystem(const Parameters &p, int device, int rank, int world_size, unsigned flags)
+{
+    femshell_config cfg{};
+    cfg.nu = p.nu;
+    cfg.E = p.em;
+    cfg.thickness = p.thickness;
+    cfg.flags = flags;
+    cfg.device = device;
+    cfg.rank = rank;
+    cfg.world_size = world_size;
+    check(femshell_create(&cfg, &ctx_), "femshell_create");
+}
+
+ShellSystem::~ShellSystem() { femshell_destroy(ctx_); }
+
+void ShellSystem::comm_init(const unsigned char id[128]) { check(femshell_comm_init(ctx_, id), "femshell_comm_init"); }
+
+void ShellSystem::set_mesh(const ShellMesh &m)
+{
+    n_nodes_ = m.n_nodes();
+    check(femshell_set_mesh(ctx_, m.n_nodes(), m.xyz.data(), m.n_tri(), m.tri.data(), m.n_quad(), m.quad.data()),
+          "femshell_set_mesh");
+    const std::vector<uint8_t> mask = m.dirichlet_mask();
+    check(femshell_set_dirichlet(ctx_, m.n_nodes(), nullptr, mask.data()), "femshell_set_dirichlet");
+    if (!m.loads.empty()) set_forces(m.loads);
+}
+
+void ShellSystem::set_forces(const std::vector<double> &f6)
+{
+    if ((int)(f6.size() / 6) != n_nodes_) throw std::runtime_error("set_forces: need one row of 6 per mesh node");
+    check(femshell_set_loads(ctx_, n_nodes_, nullptr, f6.data()), "femshell_set_loads");
+}
+
+void ShellSystem::assemble_elasticity(const std::string &system_name)
+{
+    // libmesh_assert_equal_to (system_name, "Elasticity"), SA:1163
+    if (system_name != "Elasticity") throw std::runtime_error("assemble_elasticity: system_name must be \"Elasticity\"");
+    check(femshell_assemble(ctx_), "femshell_assemble");
+}
+
+SolveResult ShellSystem::solve(double tol, int max_it)
+{
+    SolveResult r;
+    sols_.assign((size_t)n_nodes_ * 6, 0.0);
+    check(femshell_solve(ctx_, tol, max_it, sols_.data(), &r.info), "femshell_solve");
+    r.iterations = (unsigned)r.info.iterations;
+    r.final_residual = r.info.rel_residual;
+    r.converged = r.info.converged == 1;
+    return r;
+}
+
+const std::vector<double> &ShellSystem::build_solution_vector() { return sols_; }
+
+int fem_shell_main(int argc, char **argv, std::ostream &out, std::ostream &err)
+{
+    Parameters p;
+    if (read_parameters(argc, argv, p, out, err)) {
+        out << "Read command-line arguments.......OK" << std::endl;
+    } else {
+        out << "Read command-line arguments.......FAILED" << std::endl;
+        return -1;
+    }
+    try {
+        ShellMesh mesh = read_xda(p.in_filename);
+        out << " Mesh Information:\n  n_nodes()=" << mesh.n_nodes() << "\n  n_elem()=" << mesh.n_tri() + mesh.n_quad()
+            << "\n";
+        // CONVENTION: force file = mesh file name without extension + "_f" (SA:42-50); a missing
+        // file means no loads, as in the reference (SA:52)
+        try {
+            mesh.loads = read_forces(force_file_name(p.in_filename), mesh.n_nodes());
+        } catch (const std::exception &) {
+            mesh.loads.assign((size_t)mesh.n_nodes() * 6, 0.0);
+        }
+        ShellSystem system(p);
+        system.set_mesh(mesh);
+        const SolveResult res = system.solve(p.tol, p.max_it);
+        const std::vector<double> &sols = system.build_solution_vector();
+        out << "Linear solver: 6x6 block-Jacobi CG on MI355X, " << res.iterations << " iterations, ||r||/||b|| = "
+            << res.final_residual << (res.converged ? "" : " (NOT converged)") << std::endl;
+        out << "Solution: u_vec = [";
+        for (int32_t id = 0; id < mesh.n_nodes(); id++) {
+            const double *s = &sols[6 * (size_t)id];
+            out << "u= " << s[0] << ", v= " << s[1] << ", w= " << s[2];
+            out << ", tx= " << s[3] << ", ty= " << s[4] << ", tz= " << s[5] << "]" << std::endl;
+        }
+        out << "]" << std::endl << std::endl;
+        if (p.isOutfileSet) write_vtk(mesh, sols, p.out_filename + ".vtk");
+        out << "All done :)\n";
+        return res.converged ? 0 : 2;
+    } catch (const std::exception &e) {
+        err << "ERROR: " << e.what() << std::endl;
+        return 1;
+    }
+}
+
+} // namespace femshell_host

@@ -224,6 +224,14 @@ def test_large_mesh_properties():
     assert len(h) == 200 and np.isfinite(h).all()
 
 
+def test_rccl_can_be_loaded_on_the_gpu_box():
+    # the multi-rank path opens librccl lazily; make sure that works where the GPUs are
+    uid = pkg.comm_unique_id()
+    assert uid.shape == (128,) and uid.any()
+    fs = pkg.FemShell(0.3, 1.0, 1.0, rank=0, world_size=1)
+    fs.comm_init(uid)  # no-op for one rank
+
+
 # ------------------------------------------------------------------ error behaviour
 
 def test_errors_are_reported_not_swallowed():

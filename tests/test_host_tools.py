@@ -1,0 +1,76 @@
+"""Host programs above the C ABI: meshGen twin, XDA/_f formats, FEM-shell command line.
+CPU part: formats and error behaviour.  GPU part: the shipped examples through the CLI."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.helpers import meshes
+from tests.helpers.product import ROOT
+
+HOST = os.path.join(ROOT, "fem-shell_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def tools():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "fem-shell_amd", "csrc"), "-s"])
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    return os.path.join(HOST, "FEM-shell"), os.path.join(HOST, "meshGen")
+
+
+@pytest.mark.parametrize("kind,ul_lr,dead,bc,loading", [("t", 1, "z", "0,0,0,0", 2), ("t", 0, "y", "2,20,2,2", 1),
+                                                        ("q", 1, "z", "-1,1,0,-1", 2), ("t", 1, "x", "-1,-1,-1,21", 0)])
+def test_meshgen_twin_matches_generator(tools, tmp_path, kind, ul_lr, dead, bc, loading):
+    _, meshgen = tools
+    name = str(tmp_path / "m")
+    subprocess.check_call([meshgen, kind, "7", "5", "-1.5", "0", "2", "3", bc, "2.5", str(loading), str(ul_lr), dead, name])
+    got = meshes.read_xda(name + ".xda")
+    ids = tuple(int(v) for v in bc.split(","))
+    want = meshes.structured(7, 5, -1.5, 0, 2, 3, kind=kind, ul_lr=bool(ul_lr), dead_axis=dead, bcids=ids,
+                             factor=2.5, loading=loading)
+    np.testing.assert_allclose(got.xyz, want.xyz, rtol=0, atol=1e-15)
+    np.testing.assert_array_equal(got.tri, want.tri)
+    np.testing.assert_array_equal(got.quad, want.quad)
+    assert got.bcs == want.bcs
+    np.testing.assert_array_equal(got.dirichlet_mask(), want.dirichlet_mask())
+    if loading:
+        loads = meshes.read_forces(name + "_f", got.n_nodes)
+        np.testing.assert_allclose(loads, want.loads, rtol=1e-5)  # the file keeps 6 significant digits
+        assert np.all(loads[-1] == 0.0)  # meshGen writes n-1 rows (main_all.cpp:352,377)
+    else:
+        assert not os.path.exists(name + "_f")
+
+
+def test_cli_usage_and_missing_arguments(tools):
+    fem, _ = tools
+    r = subprocess.run([fem], capture_output=True, text=True)
+    assert r.returncode != 0 and "Usage:" in r.stderr and "-nu -e -t -mesh [-out] [-d]" in r.stderr
+    r = subprocess.run([fem, "-nu", "0.3", "-e", "1", "-mesh", "x.xda", "-d", "0"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Mesh thickness t not specified" in r.stderr
+    r = subprocess.run([fem, "-nu", "0.3", "-e", "1", "-t", "1", "-mesh", "/nonexistent.xda"], capture_output=True, text=True)
+    assert r.returncode != 0 and "cannot open" in r.stderr
+
+
+def parse_solution(stdout):
+    rows = re.findall(r"u= (\S+), v= (\S+), w= (\S+), tx= (\S+), ty= (\S+), tz= (\S+)\]", stdout)
+    return np.array(rows, dtype=np.float64)
+
+
+@pytest.mark.gpu
+def test_cli_reproduces_thesis_values(tools, tmp_path):
+    fem, _ = tools
+    mesh = os.path.join(meshes.MESH_DIR, "test_A_uv_t.xda")
+    r = subprocess.run([fem, "-nu", "0.25", "-e", "30000", "-t", "1.0", "-mesh", mesh, "-out", str(tmp_path / "A")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    u = parse_solution(r.stdout)
+    assert u.shape == (27, 6)
+    assert u[22, 0] == pytest.approx(-0.0255988, abs=6e-8) and u[22, 1] == pytest.approx(0.0629549, abs=6e-8)
+    assert u[26, 0] == pytest.approx(-0.0342621, abs=6e-8) and u[26, 1] == pytest.approx(0.1944070, abs=6e-7)
+    assert os.path.exists(str(tmp_path / "A.vtk"))
+    mesh = os.path.join(meshes.MESH_DIR, "test_C_w_tA16.xda")
+    r = subprocess.run([fem, "-nu", "0.3", "-e", "10.92", "-t", "1.0", "-mesh", mesh], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert parse_solution(r.stdout)[144, 2] == pytest.approx(1.15169, abs=6e-6)
