@@ -176,8 +176,6 @@ int do_assemble(femshell_ctx *c)
     if (!c->have_mesh) return set_err(FEMSHELL_ERR_INVALID, "femshell_assemble: no mesh set");
     int rc = select_device(c);
     if (rc) return rc;
-    if (c->plan.n_lquad() > 0)
-        return set_err(FEMSHELL_ERR_UNSUPPORTED, "QUAD4 elements are not yet assembled on the device");
     FS_HIP(hipEventRecord(c->ev0, c->stream));
     launch_assemble(c->dm, c->mc, c->stream);
     launch_rhs(c->dm, c->loads.p, c->F.p, c->stream);
@@ -607,16 +605,16 @@ int femshell_element_matrices(femshell_ctx *c, int32_t first, int32_t count, dou
     const bool quads = first >= p.n_tri;
     if (!quads && first + count > p.n_tri)
         return set_err(FEMSHELL_ERR_INVALID, "femshell_element_matrices: range mixes triangles and quads");
-    if (quads) return set_err(FEMSHELL_ERR_UNSUPPORTED, "QUAD4 elements are not yet computed on the device");
     int rc = select_device(c);
     if (rc) return rc;
     DevBuf<double> out;
-    FS_HIP(out.alloc((size_t)count * 324));
+    const size_t per = quads ? 576 : 324;
+    FS_HIP(out.alloc((size_t)count * per));
     launch_element_matrices(c->dm, c->mc, first, count, out.p, c->stream);
     FS_HIP(hipGetLastError());
     rc = check_status(c, "femshell_element_matrices");
     if (rc) return rc;
-    FS_HIP(hipMemcpy(Ke_out, out.p, (size_t)count * 324 * sizeof(double), hipMemcpyDeviceToHost));
+    FS_HIP(hipMemcpy(Ke_out, out.p, (size_t)count * per * sizeof(double), hipMemcpyDeviceToHost));
     return FEMSHELL_OK;
 }
 

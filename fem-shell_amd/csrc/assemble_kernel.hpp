@@ -85,8 +85,16 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                     ok = tri3_record(X, mc, rec);
                 }
             } else {
+                double X[12];
+                const int nid[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
-                for (int q = 0; q < kRecDoubles; q++) rec[q] = 0.0;
+                for (int q = 0; q < 4; q++) {
+                    const double *pt = m.xyz + 3 * (int64_t)nid[q];
+                    X[3 * q + 0] = pt[0];
+                    X[3 * q + 1] = pt[1];
+                    X[3 * q + 2] = pt[2];
+                }
+                ok = quad4_record(X, mc, rec);
             }
             if (!ok) atomicCAS(m.status, 0, e0 + i + 1);
             double2 *dst = reinterpret_cast<double2 *>(lds_rec + (size_t)i * kRecDoubles);
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
 #pragma unroll
                     for (int i = 0; i < 26; i++) blk[i] += rec[i];
                 } else {
-                    tri3_block_add_rec(rec, (int)((pr >> 2) & 3u), (int)(pr & 3u), mc, blk);
+                    block_add_rec(rec, (int)((pr >> 2) & 3u), (int)(pr & 3u), mc, blk);
                 }
             }
             const bool owner = live && chunk == 0 && nchunks > 0; // nchunks == 0: padding item

@@ -94,32 +94,50 @@ void launch_rhs(const DeviceMatrix &m, const double *loads, double *F, hipStream
 
 // Unconstrained element matrices in the reference's variable-major ordering
 // (fem-shell.cpp:1105-1109); one lane per node block.  Parity/debug export only.
+// Elements [0,n_ltri) are triangles (9 blocks each), the rest quads (16 blocks each).
 __global__ __launch_bounds__(128) void k_element_matrices(DeviceMatrix m, MatConst mc, int first, int count, double *out)
 {
+    const bool quads = first >= m.n_ltri;
+    const int nn = quads ? 4 : 3, nb = nn * nn;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)count * 9) return;
-    const int e = (int)(t / 9), pr = (int)(t % 9), ia = pr / 3, ib = pr % 3;
-    const int32_t *c = m.tri + 3 * (int64_t)(first + e);
-    double X[9];
+    if (t >= (int64_t)count * nb) return;
+    const int e = (int)(t / nb), pr = (int)(t % nb), ia = pr / nn, ib = pr % nn;
+    double rec[kRecDoubles];
+    bool ok;
+    if (!quads) {
+        const int32_t *c = m.tri + 3 * (int64_t)(first + e);
+        double X[9];
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+        for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int d = 0; d < 3; d++) X[3 * i + d] = m.xyz[3 * (int64_t)c[i] + d];
+            for (int d = 0; d < 3; d++) X[3 * i + d] = m.xyz[3 * (int64_t)c[i] + d];
+        ok = tri3_record(X, mc, rec);
+    } else {
+        const int32_t *c = m.quad + 4 * (int64_t)(first + e - m.n_ltri);
+        double X[12];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int d = 0; d < 3; d++) X[3 * i + d] = m.xyz[3 * (int64_t)c[i] + d];
+        ok = quad4_record(X, mc, rec);
+    }
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0.0;
-    if (!tri3_block_add(X, ia, ib, mc, acc)) atomicCAS(m.status, 0, kStatusDirect + first + e);
-    double *Ke = out + (int64_t)e * 324;
+    if (ok) block_add_rec(rec, ia, ib, mc, acc);
+    else atomicCAS(m.status, 0, kStatusDirect + first + e);
+    const int N = 6 * nn;
+    double *Ke = out + (int64_t)e * N * N;
 #pragma unroll
     for (int al = 0; al < 6; al++)
 #pragma unroll
-        for (int be = 0; be < 6; be++) Ke[(3 * al + ia) * 18 + 3 * be + ib] = acc[6 * al + be];
+        for (int be = 0; be < 6; be++) Ke[(nn * al + ia) * N + nn * be + ib] = acc[6 * al + be];
 }
 
 void launch_element_matrices(const DeviceMatrix &m, const MatConst &mc, int32_t first, int32_t count,
                              double *Ke_out, hipStream_t st)
 {
-    const int64_t n = (int64_t)count * 9;
+    const int64_t n = (int64_t)count * (first >= m.n_ltri ? 16 : 9);
     hipLaunchKernelGGL(k_element_matrices, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, m, mc, first,
                        count, Ke_out);
 }

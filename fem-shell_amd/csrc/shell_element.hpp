@@ -298,4 +298,207 @@ __device__ __forceinline__ bool tri3_block_add(const double X[9], int ia, int ib
     return true;
 }
 
+// =========================================================================================
+// QUAD4: bilinear iso-parametric membrane (SA:469-541) + DKQ plate (SA:604-687, 901-990), 2x2 Gauss.
+// Record: [0..8] ex,ey,ez  [9..12] local x of the 4 nodes  [13..16] local y  [26] = 2.0 if valid.
+// =========================================================================================
+
+// SA:342-375: frame from the mid-side points; local coordinates are T*X without translation.
+__device__ __forceinline__ bool quad4_record(const double X[12], const MatConst &mc, double rec[kRecDoubles])
+{
+    (void)mc;
+#pragma unroll
+    for (int i = 0; i < kRecDoubles; i++) rec[i] = 0.0;
+    double ex[3], ey[3], ez[3], vr[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const double mI = X[d] + 0.5 * (X[3 + d] - X[d]);          // mid AB
+        const double mJ = X[3 + d] + 0.5 * (X[6 + d] - X[3 + d]);  // mid BC
+        const double mK = X[6 + d] + 0.5 * (X[9 + d] - X[6 + d]);  // mid CD
+        const double mL = X[9 + d] + 0.5 * (X[d] - X[9 + d]);      // mid DA
+        ex[d] = mJ - mL;
+        vr[d] = mK - mI;
+    }
+    const double lx2 = ex[0] * ex[0] + ex[1] * ex[1] + ex[2] * ex[2];
+    if (!(lx2 > 0.0)) return false;
+    const double ilx = 1.0 / sqrt(lx2);
+#pragma unroll
+    for (int d = 0; d < 3; d++) ex[d] *= ilx;
+    ez[0] = ex[1] * vr[2] - ex[2] * vr[1];
+    ez[1] = ex[2] * vr[0] - ex[0] * vr[2];
+    ez[2] = ex[0] * vr[1] - ex[1] * vr[0];
+    const double lz2 = ez[0] * ez[0] + ez[1] * ez[1] + ez[2] * ez[2];
+    if (!(lz2 > 0.0)) return false;
+    const double ilz = 1.0 / sqrt(lz2);
+#pragma unroll
+    for (int d = 0; d < 3; d++) ez[d] *= ilz;
+    ey[0] = ez[1] * ex[2] - ez[2] * ex[1];
+    ey[1] = ez[2] * ex[0] - ez[0] * ex[2];
+    ey[2] = ez[0] * ex[1] - ez[1] * ex[0];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        rec[d] = ex[d];
+        rec[3 + d] = ey[d];
+        rec[6 + d] = ez[d];
+    }
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        rec[9 + n] = ex[0] * X[3 * n] + ex[1] * X[3 * n + 1] + ex[2] * X[3 * n + 2];
+        rec[13 + n] = ey[0] * X[3 * n] + ey[1] * X[3 * n + 1] + ey[2] * X[3 * n + 2];
+    }
+    // the Jacobian determinant must not vanish at the Gauss points; a zero-area quad is rejected here
+    double a2 = 0.0;
+#pragma unroll
+    for (int n = 0; n < 4; n++) a2 += rec[9 + n] * rec[13 + (n + 1) % 4] - rec[9 + (n + 1) % 4] * rec[13 + n];
+    if (!(fabs(a2) > 0.0)) return false;
+    rec[26] = 2.0;
+    return true;
+}
+
+// DKQ curvature columns of node n at one Gauss point: B[r][c], r = (kxx, kyy, kxy), c = (w, tx, ty).
+// xs/ys of the two sides meeting at the node (sa = n: towards the next node, sb = n-1: from the
+// previous node), serendipity derivatives of the corner and the two mid-side functions.
+__device__ __forceinline__ void dkq_node_block(double xa, double ya, double xb, double yb, double Nxn, double Nen,
+                                               double Nxa, double Nea, double Nxb, double Neb, const double Ji[4],
+                                               double B[3][3])
+{
+    const double la = 1.0 / (xa * xa + ya * ya), lb = 1.0 / (xb * xb + yb * yb);
+    // SA:613-621
+    const double a_a = -xa * la, b_a = 0.75 * xa * ya * la, c_a = (0.25 * xa * xa - 0.5 * ya * ya) * la;
+    const double d_a = -ya * la, e_a = (0.25 * ya * ya - 0.5 * xa * xa) * la;
+    const double a_b = -xb * lb, b_b = 0.75 * xb * yb * lb, c_b = (0.25 * xb * xb - 0.5 * yb * yb) * lb;
+    const double d_b = -yb * lb, e_b = (0.25 * yb * yb - 0.5 * xb * xb) * lb;
+    // SA:931-981, xi then eta derivatives
+    const double Hxx[3] = {1.5 * (a_a * Nxa - a_b * Nxb), b_a * Nxa + b_b * Nxb, Nxn - c_a * Nxa - c_b * Nxb};
+    const double Hxe[3] = {1.5 * (a_a * Nea - a_b * Neb), b_a * Nea + b_b * Neb, Nen - c_a * Nea - c_b * Neb};
+    const double Hyx[3] = {1.5 * (d_a * Nxa - d_b * Nxb), -Nxn + e_a * Nxa + e_b * Nxb, -Hxx[1]};
+    const double Hye[3] = {1.5 * (d_a * Nea - d_b * Neb), -Nen + e_a * Nea + e_b * Neb, -Hxe[1]};
+#pragma unroll
+    for (int c = 0; c < 3; c++) { // SA:984-989
+        B[0][c] = Ji[0] * Hxx[c] + Ji[1] * Hxe[c];
+        B[1][c] = Ji[2] * Hyx[c] + Ji[3] * Hye[c];
+        B[2][c] = Ji[0] * Hyx[c] + Ji[1] * Hye[c] + Ji[2] * Hxx[c] + Ji[3] * Hxe[c];
+    }
+}
+
+// Adds the global-axes 6x6 block K_e(ia, ib) of the QUAD4 element described by rec to acc.
+__device__ __forceinline__ void quad4_block_add_rec(const double *rec, int ia, int ib, const MatConst &mc,
+                                                    double acc[36])
+{
+    double x[4], y[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        x[n] = rec[9 + n];
+        y[n] = rec[13 + n];
+    }
+    // node data by dynamic index straight from the record (LDS or registers), no selects
+    const int ia_p = (ia + 3) & 3, ia_n = (ia + 1) & 3, ib_p = (ib + 3) & 3, ib_n = (ib + 1) & 3;
+    const double xi_ = rec[9 + ia], yi_ = rec[13 + ia], xj_ = rec[9 + ib], yj_ = rec[13 + ib];
+    // side differences (SA:413-424): side s = node s - node s+1
+    const double xa_i = xi_ - rec[9 + ia_n], ya_i = yi_ - rec[13 + ia_n];   // side sa = ia
+    const double xb_i = rec[9 + ia_p] - xi_, yb_i = rec[13 + ia_p] - yi_;   // side sb = ia-1
+    const double xa_j = xj_ - rec[9 + ib_n], ya_j = yj_ - rec[13 + ib_n];
+    const double xb_j = rec[9 + ib_p] - xj_, yb_j = rec[13 + ib_p] - yj_;
+    // natural coordinates of the corner nodes: (-1,-1), (1,-1), (1,1), (-1,1)
+    const double ri = (ia == 1 || ia == 2) ? 1.0 : -1.0, si = (ia >= 2) ? 1.0 : -1.0;
+    const double rj = (ib == 1 || ib == 2) ? 1.0 : -1.0, sj = (ib >= 2) ? 1.0 : -1.0;
+    const double x12 = x[0] - x[1], y12 = y[0] - y[1], x23 = x[1] - x[2], y23 = y[1] - y[2];
+    const double x34 = x[2] - x[3], y34 = y[2] - y[3], x41 = x[3] - x[0], y41 = y[3] - y[0];
+
+    double m00 = 0.0, m01 = 0.0, m10 = 0.0, m11 = 0.0;
+    double p[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    const double root = 0.57735026918962576451; // sqrt(1/3)
+#pragma unroll 1
+    for (int gp = 0; gp < 4; gp++) {
+        const double r = (gp & 2) ? -root : root, s = (gp & 1) ? -root : root; // SA:482-487 order
+        // ---- membrane (SA:489-538)
+        {
+            constexpr double rn[4] = {-1.0, 1.0, 1.0, -1.0}, sn[4] = {-1.0, -1.0, 1.0, 1.0};
+            double J00 = 0.0, J01 = 0.0, J10 = 0.0, J11 = 0.0;
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                const double dr = 0.25 * rn[n] * (1.0 + sn[n] * s), ds = 0.25 * sn[n] * (1.0 + rn[n] * r);
+                J00 += dr * x[n];
+                J01 += dr * y[n];
+                J10 += ds * x[n];
+                J11 += ds * y[n];
+            }
+            const double det = J00 * J11 - J01 * J10, idet = 1.0 / det;
+            const double dri = 0.25 * ri * (1.0 + si * s), dsi = 0.25 * si * (1.0 + ri * r);
+            const double drj = 0.25 * rj * (1.0 + sj * s), dsj = 0.25 * sj * (1.0 + rj * r);
+            const double bi = (J11 * dri - J01 * dsi) * idet, gi = (-J10 * dri + J00 * dsi) * idet; // dN/dx, dN/dy
+            const double bj = (J11 * drj - J01 * dsj) * idet, gj = (-J10 * drj + J00 * dsj) * idet;
+            const double w = det * mc.t * mc.cm;
+            m00 += w * (bi * bj + mc.g * gi * gj);
+            m01 += w * (mc.nu * bi * gj + mc.g * gi * bj);
+            m10 += w * (mc.nu * gi * bj + mc.g * bi * gj);
+            m11 += w * (gi * gj + mc.g * bi * bj);
+        }
+        // ---- plate (SA:641-684)
+        {
+            const double J00 = 0.25 * ((x12 + x34) * s - x12 + x34), J01 = 0.25 * ((y12 + y34) * s - y12 + y34);
+            const double J10 = 0.25 * ((x12 + x34) * r - x23 + x41), J11 = 0.25 * ((y12 + y34) * r - y23 + y41);
+            const double det = J00 * J11 - J01 * J10, idet = 1.0 / det;
+            const double Ji[4] = {J11 * idet, -J01 * idet, -J10 * idet, J00 * idet};
+            // serendipity derivatives (SA:906-923): corner n, mid-side of side s (nodes 5..8)
+            auto corner_x = [&](double rr, double ss) { return 0.25 * rr * (1.0 + s * ss) * (2.0 * r * rr + s * ss); };
+            auto corner_e = [&](double rr, double ss) { return 0.25 * ss * (1.0 + r * rr) * (2.0 * s * ss + r * rr); };
+            auto mid_x = [&](int sd) {
+                return sd == 0 ? -r * (1.0 - s) : (sd == 1 ? 0.5 * (1.0 - s * s) : (sd == 2 ? -r * (1.0 + s) : -0.5 * (1.0 - s * s)));
+            };
+            auto mid_e = [&](int sd) {
+                return sd == 0 ? -0.5 * (1.0 - r * r) : (sd == 1 ? -s * (1.0 + r) : (sd == 2 ? 0.5 * (1.0 - r * r) : -s * (1.0 - r)));
+            };
+            double Bi[3][3], Bj[3][3];
+            dkq_node_block(xa_i, ya_i, xb_i, yb_i, corner_x(ri, si), corner_e(ri, si), mid_x(ia), mid_e(ia), mid_x(ia_p),
+                           mid_e(ia_p), Ji, Bi);
+            dkq_node_block(xa_j, ya_j, xb_j, yb_j, corner_x(rj, sj), corner_e(rj, sj), mid_x(ib), mid_e(ib), mid_x(ib_p),
+                           mid_e(ib_p), Ji, Bj);
+            const double w = det * mc.cp;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double M0 = w * (Bj[0][c] + mc.nu * Bj[1][c]);
+                const double M1 = w * (mc.nu * Bj[0][c] + Bj[1][c]);
+                const double M2 = w * mc.g * Bj[2][c];
+#pragma unroll
+                for (int a = 0; a < 3; a++) p[a][c] += Bi[0][a] * M0 + Bi[1][a] * M1 + Bi[2][a] * M2;
+            }
+        }
+    }
+
+    double d;
+    if (mc.flags & kRefDrillMax) {
+        d = fmax(fmax(fmax(m00, m11), fmax(p[0][0], p[1][1])), p[2][2]) / 1000.0;
+    } else {
+        d = (ia == ib) ? fmin(fmin(fmin(m00, m11), fmin(p[0][0], p[1][1])), p[2][2]) / 1000.0 : 0.0;
+    }
+    const double ex[3] = {rec[0], rec[1], rec[2]}, ey[3] = {rec[3], rec[4], rec[5]}, ez[3] = {rec[6], rec[7], rec[8]};
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const double a_x = m00 * ex[s] + m01 * ey[s];
+        const double a_y = m10 * ex[s] + m11 * ey[s];
+        const double a_z = p[0][0] * ez[s];
+        const double b_z = p[0][1] * ex[s] + p[0][2] * ey[s];
+        const double c_x = p[1][0] * ez[s];
+        const double c_y = p[2][0] * ez[s];
+        const double d_x = p[1][1] * ex[s] + p[1][2] * ey[s];
+        const double d_y = p[2][1] * ex[s] + p[2][2] * ey[s];
+        const double d_z = d * ez[s];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            acc[6 * r + s] += ex[r] * a_x + ey[r] * a_y + ez[r] * a_z;
+            acc[6 * r + 3 + s] += ez[r] * b_z;
+            acc[6 * (3 + r) + s] += ex[r] * c_x + ey[r] * c_y;
+            acc[6 * (3 + r) + 3 + s] += ex[r] * d_x + ey[r] * d_y + ez[r] * d_z;
+        }
+    }
+}
+
+// dispatch on the record's element kind
+__device__ __forceinline__ void block_add_rec(const double *rec, int ia, int ib, const MatConst &mc, double acc[36])
+{
+    if (rec[26] == 2.0) quad4_block_add_rec(rec, ia, ib, mc, acc);
+    else tri3_block_add_rec(rec, ia, ib, mc, acc);
+}
+
 } // namespace femshell

@@ -75,11 +75,78 @@ def test_element_matrices_match_committed_goldens():
         assert np.linalg.norm(Ke[e] - g["Ke"][e]) <= 1e-12 * np.linalg.norm(g["Ke"][e])
 
 
+def random_quads(n, seed):
+    """planar, convex, randomly placed and oriented quadrilaterals"""
+    rng = np.random.default_rng(seed)
+    xyz = np.zeros((4 * n, 3))
+    for e in range(n):
+        base = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.float64)
+        base += rng.uniform(-0.25, 0.25, size=(4, 2))
+        base *= rng.uniform(0.2, 5.0)
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        xyz[4 * e:4 * e + 4] = (np.c_[base, np.zeros(4)] @ q.T) + rng.normal(size=3) * 3.0
+    quad = np.arange(4 * n, dtype=np.int32).reshape(n, 4)
+    return xyz, quad
+
+
+@pytest.mark.parametrize("flags", [3, 0])
+def test_element_matrices_random_planar_quads(flags):
+    xyz, quad = random_quads(129, seed=5 + flags)
+    fs = pkg.FemShell(0.3, 2.1e5, 0.37, flags=flags)
+    fs.set_mesh(xyz, None, quad)
+    Ke = fs.element_matrices(0, len(quad))
+    assert Ke.shape == (len(quad), 24, 24)
+    mat = oracle.material(0.3, 2.1e5, 0.37, flags)
+    worst = 0.0
+    for e in range(len(quad)):
+        ref = oracle.element_quad4(xyz[quad[e]], mat)
+        worst = max(worst, np.linalg.norm(Ke[e] - ref) / np.linalg.norm(ref))
+    assert worst <= 1e-12, worst
+
+
+def test_mixed_tri_quad_mesh_matches_oracle():
+    # left half quads, right half triangles, curved so that every element has its own frame...
+    # quads must stay planar: bend only along x (cylindrical surface), rows of constant x are straight
+    q = meshes.structured(6, 9, 0, 0, 3, 4.5, kind="q", bcids=(-1, 1, -1, -1))
+    t = meshes.structured(6, 9, 3, 0, 6, 4.5, kind="t", ul_lr=True)
+    # merge: the triangle mesh's left column coincides with the quad mesh's right column
+    nq = q.n_nodes
+    remap = np.arange(t.n_nodes) + nq
+    for j in range(10):
+        remap[j * 7] = j * 7 + 6
+    keep = np.ones(t.n_nodes, dtype=bool)
+    keep[::7] = False
+    new_id = np.cumsum(keep) - 1 + nq
+    final = np.where(keep, new_id, remap)
+    xyz = np.vstack([q.xyz, t.xyz[keep]])
+    tri = final[t.tri].astype(np.int32)
+    xyz[:, 2] = 0.4 * np.sin(0.9 * xyz[:, 0])  # z depends on x only; quad edges along y stay parallel
+    dmask = np.zeros(len(xyz), dtype=np.uint8)
+    dmask[:7] = 0x3F
+    rng = np.random.default_rng(2)
+    loads = rng.normal(size=(len(xyz), 6))
+    fs = pkg.FemShell(0.3, 5.0e4, 0.08)
+    fs.set_mesh(xyz, tri, q.quad)
+    fs.set_dirichlet(dmask)
+    fs.set_loads(loads)
+    fs.assemble()
+    _, _, vals, F = fs.export_bsr()
+    mat = oracle.material(0.3, 5.0e4, 0.08)
+    r0, c0, v0, F0 = oracle.assemble(xyz, tri, q.quad, mat, dmask, loads)
+    assert np.abs(vals - v0).max() <= 1e-12 * np.abs(v0).max()
+    u, info = fs.solve(rtol=1e-13, max_it=100000)
+    u0 = oracle.direct_solve(r0, c0, v0, F0)
+    assert info["converged"] == 1
+    assert np.linalg.norm(u.ravel() - u0) <= 1e-9 * np.linalg.norm(u0)
+
+
 # ------------------------------------------------------------------ assembled K, F, SpMV
 
 @pytest.mark.parametrize("name,nu,E,t", [("test_A_uv_t", 0.25, 30000.0, 1.0), ("test_C_w_tA16", 0.3, 10.92, 1.0),
                                          ("test_E_uvw_t", 0.25, 10000.0, 0.25),
-                                         ("bending_tower_tri_test", 0.3, 1e6, 0.1)])
+                                         ("bending_tower_tri_test", 0.3, 1e6, 0.1),
+                                         ("test_B_uv_q", 0.25, 30000.0, 1.0), ("test_D_w_q_uni16", 0.3, 1e7, 0.5),
+                                         ("test_F_032_ss_uni", 0.3, 1.7472e7, 0.01)])
 def test_assembled_matrix_equals_oracle(name, nu, E, t):
     m = meshes.load_example(name)
     fs = make_ctx(m, nu, E, t)
@@ -144,6 +211,20 @@ def test_known_answers_on_device():
     u, info = fs.solve(rtol=1e-12, max_it=20000)
     assert info["converged"] == 1
     assert u[144, 2] == pytest.approx(1.15169, abs=6e-6)
+    # quads: B (:133-136), D (:289), F (:474), G (:518)
+    m = meshes.load_example("test_B_uv_q")
+    u, info = make_ctx(m, 0.25, 30000.0, 1.0).solve(rtol=1e-12, max_it=20000)
+    assert info["converged"] == 1
+    assert u[22, 0] == pytest.approx(-0.0427728, abs=6e-8) and u[26, 1] == pytest.approx(0.3160560, abs=6e-7)
+    m = meshes.load_example("test_D_w_q_uni16")
+    u, info = make_ctx(m, 0.3, 1e7, 0.5).solve(rtol=1e-12, max_it=50000)
+    assert info["converged"] == 1 and u[144, 2] == pytest.approx(0.106454, abs=6e-7)
+    m = meshes.load_example("test_F_032_ss_uni")
+    u, info = make_ctx(m, 0.3, 1.7472e7, 0.01).solve(rtol=1e-12, max_it=200000)
+    assert info["converged"] == 1 and u[544, 2] == pytest.approx(12.9640e-6, abs=6e-11)
+    m = meshes.load_example("test_G_mpi_64_q")
+    u, info = make_ctx(m, 0.3, 1e7, 0.5).solve(rtol=1e-12, max_it=200000)
+    assert info["converged"] == 1 and u[2112, 2] == pytest.approx(0.106465, abs=6e-7)
 
 
 @pytest.mark.parametrize("name,nu,E,t", [("test_A_uv_t", 0.25, 30000.0, 1.0), ("test_C_w_tA16", 0.3, 10.92, 1.0),
