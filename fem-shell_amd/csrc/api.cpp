@@ -403,7 +403,7 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
         // LDS of k_assemble: output tile (kOutSlots block slots x 32 nodes x 288 B per pass) +
         // ownership mask + element records + partial-sum staging
         const size_t work = ((size_t)p.max_slice_elems * kRecDoubles + (size_t)p.max_stage_rows * 36) * sizeof(double);
-        const size_t tile = (size_t)kOutSlots * kSliceNodes * 36 * sizeof(double) + 256;
+        const size_t tile = (size_t)kOutSlots * kSliceNodes * 36 * sizeof(double) + 256 + kSpechtTableDoubles * sizeof(double);
         const size_t lds = work + tile;
         if (p.max_slice_width > 64) return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_set_mesh: a node has more than 63 neighbours");
         if (lds > 96 * 1024)

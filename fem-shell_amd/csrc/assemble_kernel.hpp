@@ -38,19 +38,22 @@ struct SliceWalk {
 // =====================================================================================
 // kAblate (profiling builds only, 0 in the product): 1 = skip global stores, 2 = every lane reads
 // record 0, 4 = skip the block math, 8 = skip the record math, 16 = skip the LDS tile transposition
-template <int kWavesPerSimd, int kAblate = 0>
+// kHasQuads = false compiles the QUAD4 code out (meshes of triangles only: every BASELINE config)
+template <int kWavesPerSimd, int kAblate = 0, bool kHasQuads = false>
 __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m, MatConst mc)
 {
-    // LDS: [output tile | ownership mask | element records | partial-sum staging]
+    // LDS: [output tile | ownership mask | Specht table | element records | partial-sum staging]
     extern __shared__ double lds[];
     double2 *lds_tile = reinterpret_cast<double2 *>(lds);                                  // kOutSlots*32*36 doubles
     uint32_t *lds_mask = reinterpret_cast<uint32_t *>(lds + kOutSlots * kSliceNodes * 36); // 64 words
-    double *lds_rec = lds + kOutSlots * kSliceNodes * 36 + 32;
+    double *lds_tab = lds + kOutSlots * kSliceNodes * 36 + 32;                             // kSpechtTableDoubles
+    double *lds_rec = lds_tab + kSpechtTableDoubles;
     double *lds_stage = lds_rec + (size_t)m.max_slice_elems * kRecDoubles;
     const int tid = threadIdx.x;
 
     SliceWalk w(m.n_slices);
     if (!w.valid()) return;
+    specht_table_fill(lds_tab, tid, blockDim.x); // visible after the first barrier below
     // software pipeline over slices: the node ids of the next slice's elements are fetched while
     // the current slice computes, so that a slice exposes one dependent load (the coordinates)
     int e0 = m.slice_elem_ptr[w.s], ne = m.slice_elem_ptr[w.s + 1] - e0;
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
             const int4 c = (i == tid) ? nd : m.slice_elem_nodes[e0 + i];
             double rec[kRecDoubles];
             bool ok = false;
-            if (c.w < 0) {
+            if (!kHasQuads || c.w < 0) {
                 double X[9];
                 const double *pa = m.xyz + 3 * (int64_t)c.x, *pb = m.xyz + 3 * (int64_t)c.y,
                              *pc = m.xyz + 3 * (int64_t)c.z;
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
 #pragma unroll
                     for (int i = 0; i < 26; i++) blk[i] += rec[i];
                 } else {
-                    block_add_rec(rec, (int)((pr >> 2) & 3u), (int)(pr & 3u), mc, blk);
+                    block_add_rec<kHasQuads>(rec, lds_tab, (int)((pr >> 2) & 3u), (int)(pr & 3u), mc, blk);
                 }
             }
             const bool owner = live && chunk == 0 && nchunks > 0; // nchunks == 0: padding item

@@ -84,35 +84,6 @@ __device__ __forceinline__ bool tri3_frame(const double X[9], TriFrame &f)
     return true;
 }
 
-// Specht curvature block of node i at the three Gauss points: Bt[g][r][c], r = (d11, d22, 2 d12),
-// c = (w, theta_x, theta_y).  Q[i][g][r] are the curvatures of chi7..chi9.
-__device__ __forceinline__ void specht_node_block(int i, const TriFrame &f, const double Q[3][3][3],
-                                                  double Bt[3][3][3])
-{
-    constexpr double C456[3][3] = SPECHT_C456_INIT;
-    const int k = (i == 0) ? 2 : i - 1; // (i+2)%3
-    // coordinate differences seen from node i: rows of (xs,ys) are (12),(31),(23);
-    // (x_ki,y_ki) = row {1,0,2}[i], (x_ji,y_ji) = -row {0,2,1}[i]
-    const double xki = sel3(i, f.xs[1], f.xs[0], f.xs[2]);
-    const double yki = sel3(i, f.ys[1], f.ys[0], f.ys[2]);
-    const double xji = -sel3(i, f.xs[0], f.xs[2], f.xs[1]);
-    const double yji = -sel3(i, f.ys[0], f.ys[2], f.ys[1]);
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const double ci = sel3(i, C456[0][r], C456[1][r], C456[2][r]);
-        const double ck = sel3(k, C456[0][r], C456[1][r], C456[2][r]);
-#pragma unroll
-        for (int g = 0; g < 3; g++) {
-            const double qi = sel3(i, Q[0][g][r], Q[1][g][r], Q[2][g][r]);
-            const double qk = sel3(k, Q[0][g][r], Q[1][g][r], Q[2][g][r]);
-            const double P = qk - ck;                       // chi_{k+6} - chi_{k+3}
-            Bt[g][r][0] = (ck - ci) + 2.0 * (qi - qk);      // N_w
-            Bt[g][r][1] = yji * qi - yki * P;               // N_theta_x
-            Bt[g][r][2] = xki * P - xji * qi;               // N_theta_y
-        }
-    }
-}
-
 // ---- per-element record ---------------------------------------------------------------
 // Everything about a TRI3 element that does not depend on which node block is wanted.  The
 // assembly kernel computes it once per element and slice and keeps it in LDS.
@@ -172,74 +143,102 @@ __device__ __forceinline__ bool tri3_record(const double X[9], const MatConst &m
     return true;
 }
 
-// Adds the global-axes 6x6 block K_e(ia, ib) of the element described by rec to acc (row-major).
-__device__ __forceinline__ void tri3_block_add_rec(const double *rec, int ia, int ib, const MatConst &mc,
-                                                   double acc[36])
+// Shared Specht table (one copy per workgroup, in LDS): for node i and Gauss point g
+//   [ (i*3+g)*6 + 0..2 ] = QA[i][g][r]   [ (i*3+g)*6 + 3..5 ] = QB[i][g][r]      (54 doubles)
+//   [ 54 + i*6 + 0..2 ]  = C456[k][r] - C456[i][r], k = (i+2)%3                  (18 doubles)
+//   [ 54 + i*6 + 3..5 ]  = C456[k][r]
+constexpr int kSpechtTableDoubles = 72;
+
+__device__ __forceinline__ void specht_table_fill(double *tab, int tid, int nthreads)
 {
-    TriFrame f;
+    constexpr double QA[3][3][3] = SPECHT_QA_INIT;
+    constexpr double QB[3][3][3] = SPECHT_QB_INIT;
+    constexpr double C456[3][3] = SPECHT_C456_INIT;
+    for (int q = tid; q < kSpechtTableDoubles; q += nthreads) {
+        double v;
+        if (q < 54) {
+            const int i = q / 18, g = (q / 6) % 3, c = q % 6;
+            double va = 0.0, vb = 0.0;
 #pragma unroll
-    for (int d = 0; d < 3; d++) {
-        f.ex[d] = rec[d];
-        f.ey[d] = rec[3 + d];
-        f.ez[d] = rec[6 + d];
-        f.xs[d] = rec[9 + d];
-        f.ys[d] = rec[12 + d];
+            for (int ii = 0; ii < 3; ii++)
+#pragma unroll
+                for (int gg = 0; gg < 3; gg++)
+#pragma unroll
+                    for (int rr = 0; rr < 3; rr++)
+                        if (ii == i && gg == g && rr == c % 3) {
+                            va = QA[ii][gg][rr];
+                            vb = QB[ii][gg][rr];
+                        }
+            v = c < 3 ? va : vb;
+        } else {
+            const int i = (q - 54) / 6, c = (q - 54) % 6, r = c % 3, k = (i + 2) % 3;
+            double ci = 0.0, ck = 0.0;
+#pragma unroll
+            for (int ii = 0; ii < 3; ii++)
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++) {
+                    if (ii == i && rr == r) ci = C456[ii][rr];
+                    if (ii == k && rr == r) ck = C456[ii][rr];
+                }
+            v = c < 3 ? ck - ci : ck;
+        }
+        tab[q] = v;
     }
-    const double mu[3] = {rec[15], rec[16], rec[17]};
-    double Dt[3][3];
-    Dt[0][0] = rec[18]; Dt[0][1] = rec[19]; Dt[0][2] = rec[20];
-    Dt[1][1] = rec[21]; Dt[1][2] = rec[22]; Dt[2][2] = rec[23];
-    Dt[1][0] = Dt[0][1]; Dt[2][0] = Dt[0][2]; Dt[2][1] = Dt[1][2];
-    const double sm = rec[24], sp = rec[25];
+}
+
+// Specht curvature block of node i at Gauss point g from the shared table and the element record:
+// B[r][c], r = (d11, d22, 2 d12), c = (w, theta_x, theta_y).  No selects: everything that depends
+// on the (runtime) node index is fetched by address.
+__device__ __forceinline__ void specht_node_block_tab(const double *rec, const double *tab, int i, int k, int g,
+                                                      double xki, double yki, double xji, double yji, double B[3][3])
+{
+    const double *ti = tab + (i * 3 + g) * 6, *tk = tab + (k * 3 + g) * 6, *tc = tab + 54 + i * 6;
+    const double mi = rec[15 + k];                      // chi_{7+i} pairs with mu_{(i+2)%3}
+    const double mk = rec[15 + ((k == 0) ? 2 : k - 1)]; // chi_{7+k} pairs with mu_{(k+2)%3}
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const double qi = ti[r] + mi * ti[3 + r];
+        const double qk = tk[r] + mk * tk[3 + r];
+        const double P = qk - tc[3 + r];         // chi_{k+6} - chi_{k+3}
+        B[r][0] = tc[r] + 2.0 * (qi - qk);       // N_w
+        B[r][1] = yji * qi - yki * P;            // N_theta_x
+        B[r][2] = xki * P - xji * qi;            // N_theta_y
+    }
+}
+
+// Adds the global-axes 6x6 block K_e(ia, ib) of the element described by rec to acc (row-major).
+// rec and tab may live in LDS (assembly kernel) or in registers/global (export kernel).
+__device__ __forceinline__ void tri3_block_add_rec(const double *rec, const double *tab, int ia, int ib,
+                                                   const MatConst &mc, double acc[36])
+{
+    const int ka = (ia == 0) ? 2 : ia - 1, kb = (ib == 0) ? 2 : ib - 1; // (i+2)%3
+    // rows of (xs,ys) are (12),(31),(23).  Seen from node i: (x_ki,y_ki) = row {1,0,2}[i],
+    // (x_ji,y_ji) = -row {0,2,1}[i]; membrane: beta = y of row {2,1,0}[i], gamma = -x of that row
+    const int rki_a = (ia == 2) ? 2 : 1 - ia, rji_a = (ia == 0) ? 0 : 3 - ia;
+    const int rki_b = (ib == 2) ? 2 : 1 - ib, rji_b = (ib == 0) ? 0 : 3 - ib;
+    const double xki_a = rec[9 + rki_a], yki_a = rec[12 + rki_a], xji_a = -rec[9 + rji_a], yji_a = -rec[12 + rji_a];
+    const double xki_b = rec[9 + rki_b], yki_b = rec[12 + rki_b], xji_b = -rec[9 + rji_b], yji_b = -rec[12 + rji_b];
+    const double bi = rec[12 + 2 - ia], gi = -rec[9 + 2 - ia];
+    const double bj = rec[12 + 2 - ib], gj = -rec[9 + 2 - ib];
 
     // ---- membrane block (2x2), closed form of t*A*B_i^T Dm B_j  (SA:448-467)
-    // node n has beta = y of row {2,1,0}[n], gamma = -x of that row
-    const double bi = sel3(ia, f.ys[2], f.ys[1], f.ys[0]), gi = -sel3(ia, f.xs[2], f.xs[1], f.xs[0]);
-    const double bj = sel3(ib, f.ys[2], f.ys[1], f.ys[0]), gj = -sel3(ib, f.xs[2], f.xs[1], f.xs[0]);
+    const double sm = rec[24];
     const double m00 = sm * (bi * bj + mc.g * gi * gj);
     const double m01 = sm * (mc.nu * bi * gj + mc.g * gi * bj);
     const double m10 = sm * (mc.nu * gi * bj + mc.g * bi * gj);
     const double m11 = sm * (gi * gj + mc.g * bi * bj);
 
-    // ---- plate block (3x3)  (SA:555-603), one Gauss point at a time to keep the live set small
-    constexpr double QA[3][3][3] = SPECHT_QA_INIT;
-    constexpr double QB[3][3][3] = SPECHT_QB_INIT;
-    constexpr double C456[3][3] = SPECHT_C456_INIT;
-    const int ka = (ia == 0) ? 2 : ia - 1, kb = (ib == 0) ? 2 : ib - 1; // (i+2)%3
-    // coordinate differences seen from node i: (x_ki,y_ki) = row {1,0,2}[i], (x_ji,y_ji) = -row {0,2,1}[i]
-    const double xki_a = sel3(ia, f.xs[1], f.xs[0], f.xs[2]), yki_a = sel3(ia, f.ys[1], f.ys[0], f.ys[2]);
-    const double xji_a = -sel3(ia, f.xs[0], f.xs[2], f.xs[1]), yji_a = -sel3(ia, f.ys[0], f.ys[2], f.ys[1]);
-    const double xki_b = sel3(ib, f.xs[1], f.xs[0], f.xs[2]), yki_b = sel3(ib, f.ys[1], f.ys[0], f.ys[2]);
-    const double xji_b = -sel3(ib, f.xs[0], f.xs[2], f.xs[1]), yji_b = -sel3(ib, f.ys[0], f.ys[2], f.ys[1]);
+    // ---- plate block (3x3)  (SA:555-603), one Gauss point at a time
+    double Dt[3][3];
+    Dt[0][0] = rec[18]; Dt[0][1] = rec[19]; Dt[0][2] = rec[20];
+    Dt[1][1] = rec[21]; Dt[1][2] = rec[22]; Dt[2][2] = rec[23];
+    Dt[1][0] = Dt[0][1]; Dt[2][0] = Dt[0][2]; Dt[2][1] = Dt[1][2];
     double p[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #pragma unroll
     for (int g = 0; g < 3; g++) {
-        double Bi[3][3], Bj[3][3]; // [r][c]: r = (d11, d22, 2 d12), c = (w, theta_x, theta_y)
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            // curvatures of chi7..chi9 at this Gauss point: chi_{7+i} pairs with mu_{(i+2)%3}
-            const double q0 = QA[0][g][r] + mu[2] * QB[0][g][r];
-            const double q1 = QA[1][g][r] + mu[0] * QB[1][g][r];
-            const double q2 = QA[2][g][r] + mu[1] * QB[2][g][r];
-            {
-                const double qi = sel3(ia, q0, q1, q2), qk = sel3(ka, q0, q1, q2);
-                const double ci = sel3(ia, C456[0][r], C456[1][r], C456[2][r]);
-                const double ck = sel3(ka, C456[0][r], C456[1][r], C456[2][r]);
-                const double P = qk - ck;                  // chi_{k+6} - chi_{k+3}
-                Bi[r][0] = (ck - ci) + 2.0 * (qi - qk);    // N_w
-                Bi[r][1] = yji_a * qi - yki_a * P;         // N_theta_x
-                Bi[r][2] = xki_a * P - xji_a * qi;         // N_theta_y
-            }
-            {
-                const double qi = sel3(ib, q0, q1, q2), qk = sel3(kb, q0, q1, q2);
-                const double ci = sel3(ib, C456[0][r], C456[1][r], C456[2][r]);
-                const double ck = sel3(kb, C456[0][r], C456[1][r], C456[2][r]);
-                const double P = qk - ck;
-                Bj[r][0] = (ck - ci) + 2.0 * (qi - qk);
-                Bj[r][1] = yji_b * qi - yki_b * P;
-                Bj[r][2] = xki_b * P - xji_b * qi;
-            }
-        }
+        double Bi[3][3], Bj[3][3];
+        specht_node_block_tab(rec, tab, ia, ka, g, xki_a, yki_a, xji_a, yji_a, Bi);
+        specht_node_block_tab(rec, tab, ib, kb, g, xki_b, yki_b, xji_b, yji_b, Bj);
         double M[3][3];
 #pragma unroll
         for (int r = 0; r < 3; r++)
@@ -249,8 +248,8 @@ __device__ __forceinline__ void tri3_block_add_rec(const double *rec, int ia, in
         for (int a = 0; a < 3; a++)
 #pragma unroll
             for (int c = 0; c < 3; c++) p[a][c] += Bi[0][a] * M[0][c] + Bi[1][a] * M[1][c] + Bi[2][a] * M[2][c];
-        __builtin_amdgcn_sched_barrier(0);
     }
+    const double sp = rec[25];
 #pragma unroll
     for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -266,7 +265,7 @@ __device__ __forceinline__ void tri3_block_add_rec(const double *rec, int ia, in
 
     // ---- rotation: [T^T A11 T, T^T A12 T; T^T A21 T, T^T A22 T] as outer products of the
     //      frame axes (SA:1084-1102 with TSub = diag(T,T))
-    const double *ex = f.ex, *ey = f.ey, *ez = f.ez;
+    const double ex[3] = {rec[0], rec[1], rec[2]}, ey[3] = {rec[3], rec[4], rec[5]}, ez[3] = {rec[6], rec[7], rec[8]};
 #pragma unroll
     for (int s = 0; s < 3; s++) {
         const double a_x = m00 * ex[s] + m01 * ey[s]; // row ex of A11
@@ -286,16 +285,6 @@ __device__ __forceinline__ void tri3_block_add_rec(const double *rec, int ia, in
             acc[6 * (3 + r) + 3 + s] += ex[r] * d_x + ey[r] * d_y + ez[r] * d_z;
         }
     }
-}
-
-// One-shot form (record kept in registers): used by the element-matrix export.
-__device__ __forceinline__ bool tri3_block_add(const double X[9], int ia, int ib, const MatConst &mc,
-                                               double acc[36])
-{
-    double rec[kRecDoubles];
-    if (!tri3_record(X, mc, rec)) return false;
-    tri3_block_add_rec(rec, ia, ib, mc, acc);
-    return true;
 }
 
 // =========================================================================================
@@ -495,10 +484,12 @@ __device__ __forceinline__ void quad4_block_add_rec(const double *rec, int ia, i
 }
 
 // dispatch on the record's element kind
-__device__ __forceinline__ void block_add_rec(const double *rec, int ia, int ib, const MatConst &mc, double acc[36])
+template <bool kHasQuads>
+__device__ __forceinline__ void block_add_rec(const double *rec, const double *tab, int ia, int ib, const MatConst &mc,
+                                              double acc[36])
 {
-    if (rec[26] == 2.0) quad4_block_add_rec(rec, ia, ib, mc, acc);
-    else tri3_block_add_rec(rec, ia, ib, mc, acc);
+    if (kHasQuads && rec[26] == 2.0) quad4_block_add_rec(rec, ia, ib, mc, acc);
+    else tri3_block_add_rec(rec, tab, ia, ib, mc, acc);
 }
 
 } // namespace femshell
