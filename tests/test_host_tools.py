@@ -74,3 +74,59 @@ def test_cli_reproduces_thesis_values(tools, tmp_path):
     r = subprocess.run([fem, "-nu", "0.3", "-e", "10.92", "-t", "1.0", "-mesh", mesh], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert parse_solution(r.stdout)[144, 2] == pytest.approx(1.15169, abs=6e-6)
+
+
+# ---------------------------------------------------------------- coupled program (preCICE adapter twin)
+
+@pytest.fixture(scope="module")
+def coupled_tool(tools):
+    return os.path.join(HOST, "FEM-shell-precice")
+
+
+TOWER = os.path.join(meshes.MESH_DIR, "bending_tower_tri_test.xda")
+CONFIG = os.path.join(meshes.GOLDEN, "coupling", "inprocess_config.xml")
+
+
+def test_coupled_cli_finds_the_43_interface_nodes(coupled_tool):
+    # fluid_solver.cpp:45-47 and run_example.sh:53 hard-wire N = 43 for this mesh
+    r = subprocess.run([coupled_tool, "-nu", "0.3", "-e", "1e6", "-t", "0.1", "-mesh", TOWER, "-config", CONFIG,
+                        "-dt", "0.01", "-axis", "y"], capture_output=True, text=True)
+    assert "coupling interface nodes = 43" in r.stdout
+    m = meshes.read_xda(TOWER)
+    assert len(m.interface_nodes()) == 43
+    assert sorted(np.nonzero(m.dirichlet_mask())[0].tolist()) == [0, 1, 2]
+    r = subprocess.run([coupled_tool, "-nu", "0.3", "-e", "1e6", "-t", "0.1", "-mesh", TOWER], capture_output=True, text=True)
+    assert r.returncode != 0 and "preCICE configuration file not specified" in r.stderr  # PC:489
+    r = subprocess.run([coupled_tool, "-nu", "0.3"], capture_output=True, text=True)
+    assert r.returncode != 0 and "-config -dt [-axis]" in r.stderr
+
+
+@pytest.mark.gpu
+def test_coupled_run_reproduces_the_quasi_static_time_series(coupled_tool):
+    from tests.helpers import oracle
+
+    steps = 6
+    r = subprocess.run([coupled_tool, "-nu", "0.3", "-e", "1e6", "-t", "0.1", "-mesh", TOWER, "-config", CONFIG, "-dt", "0.01",
+                        "-axis", "y", "-steps", str(steps)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    tips = [float(v) for v in re.findall(r"tip\[\d+\] node \d+ = (\S+)", r.stdout)]
+    probe = int(re.search(r"tip\[0\] node (\d+)", r.stdout).group(1))
+    assert len(tips) == steps
+    assert r.stdout.count("Iterate") == steps  # two coupling iterations per time step
+    # oracle: K u = F with the dummy fluid's forces f_x = 1 + sin(t/25.01) on its 21 left-edge vertices
+    # (fluid_solver.cpp:95-118, 187-199), mapped nearest-neighbour (consistent) onto the structure's
+    # interface nodes; in the shipped mesh the flagged sides put interior node 4 on the interface and
+    # leave corner node 0 out, so this follows the file, not the geometry
+    m = meshes.read_xda(TOWER)
+    mat = oracle.material(0.3, 1e6, 0.1)
+    fluid = np.array([[3.0, k * 0.1] for k in range(21)] + [[3.25, k * 0.1] for k in range(21)] + [[3.125, 2.0]])
+    loads = np.zeros((m.n_nodes, 6))
+    for n in m.interface_nodes():
+        d2 = ((fluid - m.xyz[n, [0, 2]]) ** 2).sum(axis=1)
+        if int(np.argmin(d2)) < 21:
+            loads[n, 0] = 1.0
+    assert int(loads[:, 0].sum()) == 21  # 20 left-edge nodes + the tie-broken interior node 4
+    r0, c0, v0, F0 = oracle.assemble(m.xyz, m.tri, m.quad, mat, m.dirichlet_mask(), loads)
+    u_unit = oracle.direct_solve(r0, c0, v0, F0).reshape(-1, 6)
+    want = [(1.0 + np.sin(t / 25.01)) * u_unit[probe, 0] for t in range(steps)]
+    np.testing.assert_allclose(tips, want, rtol=1e-5)
