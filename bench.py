@@ -35,6 +35,22 @@ def panel_mesh(nx):
                              factor=300.0, loading=2)
 
 
+def workload_mesh(name, nx):
+    """BASELINE.json configurations: panel = configs[3] (flat panel, the default and the 1/2/4/8-GPU curve),
+    cylinder = configs[2] (pinched cylinder, same size), roof = configs[1] (Scordelis-Lo, 354x354 squares)."""
+    from tests.helpers import meshes
+
+    if name == "panel":
+        return panel_mesh(nx), (0.3, 1e7, 0.5)
+    if name == "cylinder":
+        m = meshes.pinched_cylinder(nx, nx)
+        return m, m.material
+    if name == "roof":
+        m = meshes.scordelis_lo(nx)
+        return m, m.material
+    raise SystemExit("unknown workload " + name)
+
+
 def cpu_baseline(nx_sample=192, seconds=8.0):
     """The CPU oracle (a scalar C port of the reference path) timed on this host, one core, on a
     bounded sample: the same panel problem at nx_sample^2 squares."""
@@ -88,7 +104,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--nx", type=int, default=1414, help="squares per side (1414 -> 3,998,792 tri3)")
+    ap.add_argument("--nx", type=int, default=None, help="squares per side (default 1414 -> 3,998,792 tri3; roof: 354)")
+    ap.add_argument("--workload", default="panel", choices=["panel", "cylinder", "roof"])
     ap.add_argument("--cg-iters", type=int, default=50, help="CG iterations per step in the CG phase")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile", action="store_true",
@@ -124,8 +141,10 @@ def main():
         return float(t[0])
 
     pkg = importlib.import_module("fem-shell_amd")
-    m = panel_mesh(args.nx)
-    fs = pkg.FemShell(0.3, 1e7, 0.5, device=local_rank, rank=rank, world_size=world)
+    if args.nx is None:
+        args.nx = 354 if args.workload == "roof" else 1414
+    m, (nu, E, thick) = workload_mesh(args.workload, args.nx)
+    fs = pkg.FemShell(nu, E, thick, device=local_rank, rank=rank, world_size=world)
     if world > 1:
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
@@ -185,9 +204,12 @@ def main():
             "cg_ms_per_iter": 1e3 * t_cg / max(info["iterations"], 1),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "flat panel 10x10, %dx%d squares -> %d tri3, %d nodes, %d dofs, E=1e7 nu=0.3 t=0.5, "
-                                   "simply supported, uniform pressure 300 (BASELINE.json configs[3]; configs[2] has "
-                                   "the same size)" % (args.nx, args.nx, n_elem, n_nodes, 6 * n_nodes),
+            "config": {"workload": {"panel": "flat panel 10x10, simply supported, uniform pressure 300, E=1e7 nu=0.3 t=0.5 "
+                                             "(BASELINE.json configs[3]; configs[2] has the same size)",
+                                    "cylinder": "pinched cylinder R=300 L=600 t=3, E=3e6 nu=0.3 (BASELINE.json configs[2])",
+                                    "roof": "Scordelis-Lo roof R=25 L=50 80deg t=0.25, E=4.32e8 nu=0 (BASELINE.json configs[1])"
+                                    }[args.workload] + ": %dx%d squares -> %d tri3, %d nodes, %d dofs"
+                                   % (args.nx, args.nx, n_elem, n_nodes, 6 * n_nodes),
                        "parallelism": "row-partition x%d" % world, "cg_iters_per_step": args.cg_iters,
                        "preconditioner": "6x6 block-Jacobi", "symbolic_setup_s": setup_s},
             "roofline": dict(roof(spmv_ms, spmv_bytes), kernel="k_spmv (q = K p, fused p.q)"),

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -331,7 +332,10 @@ int femshell_comm_unique_id(uint8_t id_out[128])
 int femshell_comm_init(femshell_ctx *c, const uint8_t id[128])
 {
     if (!c || !id) return set_err(FEMSHELL_ERR_INVALID, "femshell_comm_init: null argument");
-    if (c->cfg.world_size == 1) return FEMSHELL_OK;
+    // one rank needs no communicator; FEMSHELL_FORCE_COMM=1 creates a 1-rank RCCL communicator anyway so
+    // that the RCCL code path (all-reduce on the stream, row gather) can be exercised on a single GPU
+    if (c->cfg.world_size == 1 && !(getenv("FEMSHELL_FORCE_COMM") && atoi(getenv("FEMSHELL_FORCE_COMM")) == 1))
+        return FEMSHELL_OK;
     int rc = select_device(c);
     if (rc) return rc;
     std::string e;

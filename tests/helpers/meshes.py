@@ -211,3 +211,55 @@ def map_surface(mesh, fn):
     p, s = mesh.xyz[:, 0].copy(), mesh.xyz[:, 1].copy()
     mesh.xyz = np.ascontiguousarray(np.stack(fn(p, s), axis=1), dtype=np.float64)
     return mesh
+
+
+# ---- BASELINE.json configurations 2 and 3 -------------------------------------
+
+def scordelis_lo(n, ul_lr=True):
+    """Scordelis-Lo roof: R=25, L=50, 80 degree arc, n x n squares split into triangles; the two curved
+    ends carry boundary id 0 (the reference cannot express diaphragm/symmetry constraints, SA:90-116);
+    gravity 90 per unit area as area-weighted nodal Fz.  Material: E=4.32e8, nu=0, t=0.25."""
+    R, L, arc = 25.0, 50.0, np.deg2rad(80.0)
+    m = structured(n, n, 0.0, 0.0, 1.0, 1.0, kind="t", ul_lr=ul_lr, bcids=(0, 0, -1, -1))
+    th = (m.xyz[:, 0] - 0.5) * arc  # primary axis -> angle, secondary -> length
+    y = m.xyz[:, 1] * L
+    m.xyz = np.ascontiguousarray(np.stack([R * np.sin(th), y, R * np.cos(th)], axis=1))
+    # lumped gravity: a third of each triangle's area to each of its nodes
+    p, q, r = m.xyz[m.tri[:, 0]], m.xyz[m.tri[:, 1]], m.xyz[m.tri[:, 2]]
+    area = 0.5 * np.linalg.norm(np.cross(q - p, r - p), axis=1)
+    w = np.zeros(m.n_nodes)
+    for k in range(3):
+        np.add.at(w, m.tri[:, k], area / 3.0)
+    m.loads = np.zeros((m.n_nodes, 6))
+    m.loads[:, 2] = -90.0 * w
+    m.material = (0.0, 4.32e8, 0.25)
+    return m
+
+
+def pinched_cylinder(n_theta, n_axial):
+    """Pinched cylinder: R=300, L=600, closed in theta (periodic connectivity), both end rings boundary
+    id 0, two opposite radial unit loads at mid-length.  Material: E=3e6, nu=0.3, t=3."""
+    R, L = 300.0, 600.0
+    nt, na = n_theta, n_axial
+    n_nodes = nt * (na + 1)
+    jj, ii = np.meshgrid(np.arange(na + 1), np.arange(nt), indexing="ij")
+    th = 2.0 * np.pi * ii.ravel() / nt
+    xyz = np.stack([R * np.cos(th), R * np.sin(th), L * jj.ravel() / na], axis=1)
+    a, b = np.meshgrid(np.arange(na), np.arange(nt), indexing="ij")
+    n00 = (b + a * nt).ravel()
+    n10 = ((b + 1) % nt + a * nt).ravel()
+    n01 = n00 + nt
+    n11 = n10 + nt
+    tri = np.empty((2 * nt * na, 3), dtype=np.int32)
+    tri[0::2] = np.stack([n00, n10, n01], axis=1)
+    tri[1::2] = np.stack([n10, n11, n01], axis=1)
+    bcs = []
+    for i in range(nt):
+        bcs.append((2 * i, 0, 0))                          # bottom ring: side (n00, n10)
+        bcs.append((2 * (nt * (na - 1) + i) + 1, 1, 0))    # top ring: side (n11, n01)
+    m = Mesh(xyz, tri, np.zeros((0, 4), dtype=np.int32), bcs)
+    mid = (na // 2) * nt
+    m.loads[mid, 0] = -1.0                 # at theta = 0, pointing inwards
+    m.loads[mid + nt // 2, 0] = 1.0        # at theta = pi
+    m.material = (0.3, 3.0e6, 3.0)
+    return m

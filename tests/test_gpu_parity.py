@@ -313,6 +313,25 @@ def test_rccl_can_be_loaded_on_the_gpu_box():
     fs.comm_init(uid)  # no-op for one rank
 
 
+def test_solve_through_a_one_rank_rccl_communicator(monkeypatch):
+    # the all-reduce / gather calls of the multi-rank driver, on the one GPU a test box has
+    monkeypatch.setenv("FEMSHELL_FORCE_COMM", "1")
+    m = meshes.load_example("test_C_w_tA16")
+    fs = pkg.FemShell(0.3, 10.92, 1.0, rank=0, world_size=1)
+    fs.comm_init(pkg.comm_unique_id())
+    fs.set_mesh(m.xyz, m.tri, m.quad)
+    fs.set_dirichlet(m.dirichlet_mask())
+    fs.set_loads(m.loads)
+    u, info = fs.solve(rtol=1e-12, max_it=20000)
+    assert info["converged"] == 1
+    assert u[144, 2] == pytest.approx(1.15169, abs=6e-6)
+    monkeypatch.delenv("FEMSHELL_FORCE_COMM")
+    fs2 = make_ctx(m, 0.3, 10.92, 1.0)
+    u2, info2 = fs2.solve(rtol=1e-12, max_it=20000)
+    assert info2["iterations"] == info["iterations"]
+    assert np.array_equal(u, u2)
+
+
 # ------------------------------------------------------------------ error behaviour
 
 def test_errors_are_reported_not_swallowed():
@@ -330,3 +349,47 @@ def test_errors_are_reported_not_swallowed():
     fs2 = pkg.FemShell(0.3, 1.0, 1.0)
     with pytest.raises(pkg.FemShellError):
         fs2.set_mesh(xyz, np.array([[0, 1, 7]], dtype=np.int32))
+
+
+# ------------------------------------------------------------------ BASELINE.json configurations (scaled down)
+
+def _solve_and_compare(m, nu, E, t, rtol=1e-13, tol_disp=1e-10, max_it=200000):
+    fs = make_ctx(m, nu, E, t)
+    u, info = fs.solve(rtol=rtol, max_it=max_it)
+    mat = oracle.material(nu, E, t)
+    r0, c0, v0, F0 = oracle.assemble(m.xyz, m.tri, m.quad, mat, m.dirichlet_mask(), m.loads)
+    _, _, vals, F = fs.export_bsr()
+    assert np.abs(vals - v0).max() <= 1e-12 * np.abs(v0).max()
+    u0 = oracle.direct_solve(r0, c0, v0, F0)
+    err = np.linalg.norm(u.ravel() - u0) / np.linalg.norm(u0)
+    assert info["converged"] == 1
+    assert err < tol_disp, err
+    return u, info
+
+
+@pytest.mark.parametrize("ul_lr", [True, False])
+def test_config1_cantilever_1k_tri_tip_load(ul_lr):
+    # BASELINE configs[0]: cantilever 48x12, 32x16 squares -> 1024 tri3, left edge clamped (id 1), tip load
+    m = meshes.structured(32, 16, 0, 0, 48, 12, kind="t", ul_lr=ul_lr, bcids=(-1, -1, 1, -1))
+    tip = 8 * 33 + 32
+    m.loads[tip, 2] = 1.0        # bending
+    m.loads[tip, 1] = 40.0       # in-plane shear, Test-A style
+    u, info = _solve_and_compare(m, 0.25, 30000.0, 1.0)
+    assert u[tip, 2] > 0 and u[tip, 1] > 0
+
+
+def test_config2_scordelis_lo_roof_scaled():
+    # BASELINE configs[1] at 40x40 squares (3200 tri3); the full 354x354 case runs in bench.py --workload roof
+    m = meshes.scordelis_lo(40)
+    nu, E, t = m.material
+    _solve_and_compare(m, nu, E, t, tol_disp=1e-9)
+
+
+def test_config3_pinched_cylinder_scaled():
+    # BASELINE configs[2] at 64 x 32 squares (periodic in theta)
+    m = meshes.pinched_cylinder(64, 32)
+    nu, E, t = m.material
+    u, _ = _solve_and_compare(m, nu, E, t, tol_disp=1e-9)
+    mid = 16 * 64
+    assert u[mid, 0] < 0 < u[mid + 32, 0]  # both load points move inwards
+    assert abs(u[mid, 0] + u[mid + 32, 0]) <= 1e-9 * abs(u[mid, 0])  # symmetry of the pinch
