@@ -38,7 +38,7 @@ class Config(C.Structure):
 
 class SolveInfo(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("rel_residual", C.c_double),
-                ("assemble_seconds", C.c_double), ("setup_seconds", C.c_double), ("solve_seconds", C.c_double),
+                ("true_rel_residual", C.c_double), ("assemble_seconds", C.c_double), ("setup_seconds", C.c_double), ("solve_seconds", C.c_double),
                 ("bytes_per_iteration", C.c_double)]
 
 

@@ -286,7 +286,7 @@ __device__ __forceinline__ double apply_minv(const DeviceMatrix &m, int sl, int 
     return z;
 }
 
-__global__ __launch_bounds__(192) void k_cg_init(DeviceMatrix m, CgVectors v)
+__global__ __launch_bounds__(192) void k_cg_init(DeviceMatrix m, CgVectors v, int restart)
 {
     __shared__ double rs[kSliceRows];
     __shared__ double sh[3];
@@ -295,12 +295,12 @@ __global__ __launch_bounds__(192) void k_cg_init(DeviceMatrix m, CgVectors v)
     for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
         const int sl = w.s;
         const int64_t row = (int64_t)sl * kSliceRows + t;
-        const double bv = v.b[row];
+        const double bv = restart ? v.b[row] - v.q[row] : v.b[row]; // the residual to start from
         __syncthreads();
         rs[t] = bv;
         __syncthreads();
         const double z = apply_minv(m, sl, t, rs);
-        v.x[row] = 0.0;
+        if (!restart) v.x[row] = 0.0;
         v.r[row] = bv;
         v.z[row] = z;
         v.p[row] = z;
@@ -315,9 +315,23 @@ __global__ __launch_bounds__(192) void k_cg_init(DeviceMatrix m, CgVectors v)
     }
 }
 
-void launch_cg_init(const DeviceMatrix &m, const CgVectors &v, hipStream_t st)
+void launch_cg_init(const DeviceMatrix &m, const CgVectors &v, bool restart, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_cg_init, dim3(slice_grid(m)), dim3(192), 0, st, m, v);
+    hipLaunchKernelGGL(k_cg_init, dim3(slice_grid(m)), dim3(192), 0, st, m, v, restart ? 1 : 0);
+}
+
+__global__ __launch_bounds__(256) void k_copy(const double2 *src, double2 *dst, int64_t n2)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+void launch_copy_x_to_p(const DeviceMatrix &m, const CgVectors &v, hipStream_t st)
+{
+    const int64_t n2 = (int64_t)m.n_pad * 3;
+    const int64_t blocks = (n2 + 255) / 256;
+    hipLaunchKernelGGL(k_copy, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st,
+                       reinterpret_cast<const double2 *>(v.x), reinterpret_cast<double2 *>(v.p), n2);
 }
 
 // x += alpha p ; r -= alpha q ; z = M^-1 r ; partial sums of r.z and r.r
@@ -387,7 +401,7 @@ __global__ __launch_bounds__(1024) void k_cg_scalar(CgVectors v, int G, int do_r
 {
     __shared__ double sh[16];
     CgScalars *s = v.s;
-    if (phase != CG_PHASE_INIT && s->done != 0) return;
+    if (phase != CG_PHASE_INIT && phase != CG_PHASE_RESTART && s->done != 0) return;
     if (do_reduce) {
         for (int a = 0; a < nsums; a++) {
             const double *pa = v.partials + (int64_t)a * G;
@@ -415,6 +429,11 @@ __global__ __launch_bounds__(1024) void k_cg_scalar(CgVectors v, int G, int do_r
         s->beta = 0.0;
         s->iters = 0;
         s->done = (s->red[1] == 0.0) ? 1 : 0;
+    } else if (phase == CG_PHASE_RESTART) {
+        // explicit residual r = b - K x: red[0] = r.z, red[1] = r.r
+        s->rz = s->red[0];
+        s->rr = s->red[1];
+        s->done = (s->red[1] <= s->tol2) ? 1 : 0;
     } else if (phase == CG_PHASE_ALPHA) {
         const double pq = s->red[0];
         if (!(pq > 0.0)) s->done = -1;

@@ -62,7 +62,7 @@ struct CgVectors {
     int32_t hist_cap = 0;
 };
 
-enum CgPhase : int { CG_PHASE_NONE = 0, CG_PHASE_INIT = 1, CG_PHASE_ALPHA = 2, CG_PHASE_BETA = 3 };
+enum CgPhase : int { CG_PHASE_NONE = 0, CG_PHASE_INIT = 1, CG_PHASE_ALPHA = 2, CG_PHASE_BETA = 3, CG_PHASE_RESTART = 4 };
 
 int slice_grid(const DeviceMatrix &m); // workgroups of the per-slice kernels (multiple of 8, at most 2560)
 
@@ -78,7 +78,11 @@ void launch_spmv(const DeviceMatrix &m, const double *x, double *y, double *part
                  hipStream_t st);
 
 // CG steps; every kernel is a no-op once s->done != 0
-void launch_cg_init(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);      // x=0, r=b, z=M^-1 r, p=z
+// restart = false: x=0, r=b;  restart = true: x kept, r = b - q (q = K x computed by the caller);
+// then z = M^-1 r, p = z, partial sums of r.z and (b.b | r.r)
+void launch_cg_init(const DeviceMatrix &m, const CgVectors &v, bool restart, hipStream_t st);
+// p[owned rows] = x (to run q = K x through the SpMV kernel, whose input carries the ghost entries)
+void launch_copy_x_to_p(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);
 void launch_cg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);    // x,r,z + partial r.z, r.r
 void launch_cg_direction(const DeviceMatrix &m, const CgVectors &v, hipStream_t st); // p = z + beta p
 // single-workgroup scalar step: optional reduction of `nsums` partial arrays into s->red, then the

@@ -94,7 +94,11 @@ int femshell_assemble(femshell_ctx *ctx);
 typedef struct femshell_solve_info {
     int32_t iterations;     /* CG iterations performed */
     int32_t converged;      /* 1: ||r|| <= rtol*||b||, 0: max_it reached */
-    double rel_residual;    /* recurrence ||r||_2 / ||b||_2 at exit */
+    double rel_residual;    /* recurrence ||r||_2 / ||b||_2 at exit (what the stopping rule tests) */
+    double true_rel_residual; /* ||b - K u||_2 / ||b||_2 recomputed explicitly after a converged solve, -1 if not
+                               computed (rtol <= 0, iteration limit, breakdown).  On ill-conditioned shells the
+                               recurrence drifts and this floors near kappa*eps; it is reported, not enforced:
+                               restarting CG from the explicit residual was tried and made the error worse */
     double assemble_seconds;/* device time of the assembly done inside this call (0 if reused) */
     double setup_seconds;   /* block-Jacobi factorisation */
     double solve_seconds;   /* CG loop, device time */

@@ -224,3 +224,22 @@ def direct_solve(rowptr, colidx, vals, F):
 
     K = to_scipy(rowptr, colidx, vals).tocsc()
     return spla.spsolve(K, F)
+
+
+def refined_solve(rowptr, colidx, vals, F, sweeps=4):
+    """Sparse LU followed by iterative refinement with the residual accumulated in extended precision
+    (numpy longdouble).  On the ill-conditioned shell systems plain LU is only good to ~kappa*eps
+    (1e-10 on a 1k-element cantilever); this is the reference the displacement parity tests use."""
+    import scipy.sparse.linalg as spla
+
+    K = to_scipy(rowptr, colidx, vals).tocsc()
+    lu = spla.splu(K)
+    coo = K.tocoo()
+    data = coo.data.astype(np.longdouble)
+    Fl = F.astype(np.longdouble)
+    u = lu.solve(F).astype(np.longdouble)
+    for _ in range(sweeps):
+        res = Fl.copy()
+        np.subtract.at(res, coo.row, data * u[coo.col])
+        u = u + lu.solve(res.astype(np.float64)).astype(np.longdouble)
+    return u.astype(np.float64)
