@@ -188,10 +188,25 @@ def main():
     dir_ms, dir_bytes = fs.time_kernel(pkg.KERNEL_CG_DIRECTION, reps)
     asm_ms, asm_bytes = fs.time_kernel(pkg.KERNEL_ASSEMBLE, reps)
 
-    def roof(ms, nbytes):
+    # HBM traffic per launch cannot be read inside this process (rocprofv3 --pmc has to own the run); the
+    # committed summary of this round's separate FETCH_SIZE / WRITE_SIZE passes over the same command
+    # (profiles/*_pmc_hbm_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) is
+    # attached when the workload matches (default 4M-tri panel on one GPU), else null
+    traffic = {}
+    if world == 1 and args.workload == "panel" and args.nx == 1414:
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_hbm_traffic.json"))
+        if cands:
+            with open(os.path.join(ROOT, "profiles", cands[-1])) as f:
+                pm = json.load(f)
+            for kname, v in pm.items():
+                traffic[kname.split("::")[-1].split("<")[0]] = v["read_bytes_x2_gfx950"] + v["write_bytes"]
+            traffic["_source"] = "profiles/" + cands[-1]
+
+    def roof(ms, nbytes, kernel=None):
         gbs = nbytes / (ms * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": None, "ms_per_launch": ms, "algorithmic_bytes_per_launch": nbytes}
+                "traffic": traffic.get(kernel), "traffic_source": traffic.get("_source") if kernel in traffic else None,
+                "ms_per_launch": ms, "algorithmic_bytes_per_launch": nbytes}
 
     if rank == 0:
         out = {
@@ -212,10 +227,10 @@ def main():
                                    % (args.nx, args.nx, n_elem, n_nodes, 6 * n_nodes),
                        "parallelism": "row-partition x%d" % world, "cg_iters_per_step": args.cg_iters,
                        "preconditioner": "6x6 block-Jacobi", "symbolic_setup_s": setup_s},
-            "roofline": dict(roof(spmv_ms, spmv_bytes), kernel="k_spmv (q = K p, fused p.q)"),
-            "roofline_assembly": dict(roof(asm_ms, asm_bytes), kernel="k_assemble"),
-            "roofline_cg_update": dict(roof(upd_ms, upd_bytes), kernel="k_cg_update"),
-            "roofline_cg_direction": dict(roof(dir_ms, dir_bytes), kernel="k_cg_direction"),
+            "roofline": dict(roof(spmv_ms, spmv_bytes, "k_spmv"), kernel="k_spmv (q = K p, fused p.q)"),
+            "roofline_assembly": dict(roof(asm_ms, asm_bytes, "k_assemble"), kernel="k_assemble"),
+            "roofline_cg_update": dict(roof(upd_ms, upd_bytes, "k_cg_update"), kernel="k_cg_update"),
+            "roofline_cg_direction": dict(roof(dir_ms, dir_bytes, "k_cg_direction"), kernel="k_cg_direction"),
             "roofline_cg_iteration": roof(1e3 * t_cg / max(info["iterations"], 1), info["bytes_per_iteration"]),
         }
         if world == 1 and not args.profile:

@@ -59,14 +59,18 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
     int e0 = m.slice_elem_ptr[w.s], ne = m.slice_elem_ptr[w.s + 1] - e0;
     int4 nd = make_int4(0, 0, 0, -1);
     if (tid < ne) nd = m.slice_elem_nodes[e0 + tid];
+    uint4 item_pre = make_uint4(0, 0, 0, 0);
+    {
+        const int i2 = m.item_ptr[w.s];
+        if (tid < m.item_ptr[w.s + 1] - i2) item_pre = m.items[i2 + tid];
+    }
 
     for (; w.valid(); w.next()) {
         const int s = w.s;
         const int64_t base = m.slice_base[s];
         const int W = m.slice_width[s];
         const int i0 = m.item_ptr[s], ni = m.item_ptr[s + 1] - i0;
-        uint4 item = make_uint4(0, 0, 0, 0);
-        if (tid < ni) item = m.items[i0 + tid]; // in flight during phase A
+        uint4 item = item_pre; // fetched during the previous slice's block math
 
         // ---- phase A: one record per element touching the slice
         for (int i = tid; i < ne; i += blockDim.x) {
@@ -104,16 +108,20 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
 #pragma unroll
             for (int q = 0; q < kRecDoubles / 2; q++) dst[q] = make_double2(rec[2 * q], rec[2 * q + 1]);
         }
-        // prefetch the next slice's element node ids
+        __syncthreads();
+        // prefetch the next slice's element node ids and first items now: the loads overlap the block
+        // math below (issued before the barrier above they would be drained by its vmcnt(0))
+        uint4 item_next = make_uint4(0, 0, 0, 0);
         {
             const int s2 = s + w.step;
             if (s2 < w.last) {
                 e0 = m.slice_elem_ptr[s2];
                 ne = m.slice_elem_ptr[s2 + 1] - e0;
                 if (tid < ne) nd = m.slice_elem_nodes[e0 + tid];
+                const int i2 = m.item_ptr[s2];
+                if (tid < m.item_ptr[s2 + 1] - i2) item_next = m.items[i2 + tid];
             }
         }
-        __syncthreads();
 
         // ---- phase B: one lane per work item (at most kItemPairs element contributions), in
         //      rounds of 256 items; each round's finished blocks leave through the LDS tile so
@@ -216,6 +224,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                 __syncthreads();
             }
         }
+        item_pre = item_next;
     }
 }
 
