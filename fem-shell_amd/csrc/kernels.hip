@@ -32,7 +32,7 @@ int slice_grid(const DeviceMatrix &m)
 {
     static const int cap = [] {
         const char *e = getenv("FEMSHELL_SLICE_GRID"); // tuning knob
-        return e ? atoi(e) : 20480; // ~3 slices per workgroup at 4M triangles: measured optimum of SpMV vs reduction cost
+        return e ? atoi(e) : 65536; // one slice per workgroup up to 2M node rows: best SpMV rate; more rows share workgroups
     }();
     const int g = 8 * ((m.n_slices + 7) / 8);
     return g < cap ? g : cap;
@@ -226,6 +226,49 @@ void launch_block_jacobi(const DeviceMatrix &m, hipStream_t st)
 // words; neighbouring slices share them through L2).  Optionally fuses the partial sums of
 // x.y needed by CG (p.Ap).
 // =====================================================================================
+// kChunk block slots are handled together: their column indices are fetched first, then all value and
+// x loads are issued back to back, so a row costs two dependent memory latencies per chunk instead of
+// two per block slot.
+template <int kChunk>
+__device__ __forceinline__ double spmv_row(const int32_t *__restrict__ c, const double2 *__restrict__ v,
+                                           const double *__restrict__ x, int W)
+{
+    double acc = 0.0;
+    for (int k0 = 0; k0 < W; k0 += kChunk) {
+        int col[kChunk];
+#pragma unroll
+        for (int q = 0; q < kChunk; q++) col[q] = (k0 + q < W) ? c[(k0 + q) * kSliceNodes] : -1;
+        double2 a[kChunk][3], xx[kChunk][3];
+#pragma unroll
+        for (int q = 0; q < kChunk; q++) {
+            if (col[q] >= 0) {
+                const double2 *xv = reinterpret_cast<const double2 *>(x + 6 * (int64_t)col[q]);
+                const double2 *vv = v + (size_t)(k0 + q) * 3 * kSliceRows;
+                a[q][0] = vv[0];
+                a[q][1] = vv[kSliceRows];
+                a[q][2] = vv[2 * kSliceRows];
+                xx[q][0] = xv[0];
+                xx[q][1] = xv[1];
+                xx[q][2] = xv[2];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 3; t++) a[q][t] = xx[q][t] = make_double2(0.0, 0.0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kChunk; q++) {
+            acc += a[q][0].x * xx[q][0].x;
+            acc += a[q][0].y * xx[q][0].y;
+            acc += a[q][1].x * xx[q][1].x;
+            acc += a[q][1].y * xx[q][1].y;
+            acc += a[q][2].x * xx[q][2].x;
+            acc += a[q][2].y * xx[q][2].y;
+        }
+    }
+    return acc;
+}
+
+template <int kChunk>
 __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__restrict__ x,
                                               double *__restrict__ y, double *__restrict__ partials,
                                               const CgScalars *s)
@@ -240,21 +283,7 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
         const int W = m.slice_width[sl];
         const int32_t *c = m.cols + base + t / 6;
         const double2 *v = reinterpret_cast<const double2 *>(m.vals + base * 36) + t;
-        double acc = 0.0;
-        for (int k = 0; k < W; k++) {
-            const int col = c[k * kSliceNodes];
-            const double2 *xv = reinterpret_cast<const double2 *>(x + 6 * (int64_t)col);
-            const double2 a0 = v[(k * 3 + 0) * kSliceRows];
-            const double2 a1 = v[(k * 3 + 1) * kSliceRows];
-            const double2 a2 = v[(k * 3 + 2) * kSliceRows];
-            const double2 x0 = xv[0], x1 = xv[1], x2 = xv[2];
-            acc += a0.x * x0.x;
-            acc += a0.y * x0.y;
-            acc += a1.x * x1.x;
-            acc += a1.y * x1.y;
-            acc += a2.x * x2.x;
-            acc += a2.y * x2.y;
-        }
+        const double acc = spmv_row<kChunk>(c, v, x, W);
         const int64_t row = (int64_t)sl * kSliceRows + t;
         y[row] = acc;
         if (partials != nullptr) dotv += acc * x[row];
@@ -268,7 +297,17 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
 void launch_spmv(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
                  hipStream_t st)
 {
-    hipLaunchKernelGGL(k_spmv, dim3(slice_grid(m)), dim3(192), 0, st, m, x, y, partials, s);
+    static const int chunk = [] {
+        const char *e = getenv("FEMSHELL_SPMV_CHUNK"); // tuning knob: block slots loaded together
+        return e ? atoi(e) : 4;
+    }();
+    const dim3 g(slice_grid(m)), b(192);
+    switch (chunk) {
+    case 1: hipLaunchKernelGGL(k_spmv<1>, g, b, 0, st, m, x, y, partials, s); break;
+    case 2: hipLaunchKernelGGL(k_spmv<2>, g, b, 0, st, m, x, y, partials, s); break;
+    case 8: hipLaunchKernelGGL(k_spmv<8>, g, b, 0, st, m, x, y, partials, s); break;
+    default: hipLaunchKernelGGL(k_spmv<4>, g, b, 0, st, m, x, y, partials, s); break;
+    }
 }
 
 // =====================================================================================
@@ -405,17 +444,17 @@ __global__ __launch_bounds__(1024) void k_cg_scalar(CgVectors v, int G, int do_r
     if (do_reduce) {
         for (int a = 0; a < nsums; a++) {
             const double *pa = v.partials + (int64_t)a * G;
-            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-            int i = threadIdx.x;
+            // 16 independent loads per thread and round: the reduction of ~60k partial sums is latency-bound
+            double acc = 0.0;
             const int B = blockDim.x;
-            for (; i + 3 * B < G; i += 4 * B) {
-                t0 += pa[i];
-                t1 += pa[i + B];
-                t2 += pa[i + 2 * B];
-                t3 += pa[i + 3 * B];
+            for (int i0 = threadIdx.x; i0 < G; i0 += 16 * B) {
+                double t[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) t[q] = (i0 + q * B < G) ? pa[i0 + q * B] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc += t[q];
             }
-            for (; i < G; i += B) t0 += pa[i];
-            const double tot = block_sum((t0 + t1) + (t2 + t3), sh);
+            const double tot = block_sum(acc, sh);
             if (threadIdx.x == 0) s->red[a] = tot;
         }
     }
