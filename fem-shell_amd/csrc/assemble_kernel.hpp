@@ -51,8 +51,20 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
     double *lds_stage = lds_rec + (size_t)m.max_slice_elems * kRecDoubles;
     const int tid = threadIdx.x;
 
+    // profiling build (kAblate & 32): s_memtime stamps at the phase boundaries, summed per wave and written to
+    // m.stamps[wave][8]; never compiled into the product kernel
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int slot) {
+        if (kAblate & 32) {
+            unsigned long long tnow;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
+            if (slot >= 0) tacc[slot] += tnow - tprev;
+            tprev = tnow;
+        }
+    };
     SliceWalk w(m.n_slices);
     if (!w.valid()) return;
+    stamp(-1);
     specht_table_fill(lds_tab, tid, blockDim.x); // visible after the first barrier below
     // software pipeline over slices: the node ids of the next slice's elements are fetched while
     // the current slice computes, so that a slice exposes one dependent load (the coordinates)
@@ -108,7 +120,9 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
 #pragma unroll
             for (int q = 0; q < kRecDoubles / 2; q++) dst[q] = make_double2(rec[2 * q], rec[2 * q + 1]);
         }
+        stamp(0); // phase A (coordinate gather + record math + LDS writes)
         __syncthreads();
+        stamp(1); // barrier after phase A
         // prefetch the next slice's element node ids and first items now: the loads overlap the block
         // math below (issued before the barrier above they would be drained by its vmcnt(0))
         uint4 item_next = make_uint4(0, 0, 0, 0);
@@ -163,12 +177,14 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                 mcol = m.dmask[col];
                 valence = m.pair_ptr[slot + 1] - m.pair_ptr[slot];
             }
+            stamp(2); // item decode + block math
             if (live && chunk > 0) {
                 double2 *st = reinterpret_cast<double2 *>(lds_stage + (size_t)item.w * 36);
 #pragma unroll
                 for (int i = 0; i < 18; i++) st[i] = make_double2(blk[2 * i], blk[2 * i + 1]);
             }
             __syncthreads();
+            stamp(3); // staging write + barrier
             if (owner) {
                 // chunks > 0 sort after chunk 0, so with several rounds they may not have run yet:
                 // plan.cpp keeps all chunks of a slot in one round when a slice has several rounds
@@ -196,6 +212,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                 if (multi) atomicOr(&lds_mask[slot_in_slice >> 5], 1u << (slot_in_slice & 31));
             }
             const int my_k = slot_in_slice >> 5, my_n = slot_in_slice & 31;
+            stamp(4); // partial-sum reduction + constraints
             for (int k0 = 0; k0 < W; k0 += kOutSlots) {
                 if (owner && my_k >= k0 && my_k < k0 + kOutSlots) {
                     double2 *t = lds_tile + (size_t)(my_k - k0) * 3 * kSliceRows + my_n * 6;
@@ -206,6 +223,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                             t[jp * kSliceRows + i] = make_double2(blk[6 * i + 2 * jp], blk[6 * i + 2 * jp + 1]);
                 }
                 __syncthreads();
+                stamp(5); // tile write + barrier
                 const int nk = min(kOutSlots, W - k0);
                 const int words = nk * 3 * kSliceRows; // double2 words of this pass
                 double2 *dst = out + (size_t)k0 * 3 * kSliceRows;
@@ -221,10 +239,18 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                         if ((lds_mask[kk] >> nn) & 1u) dst[q] = lds_tile[q];
                     }
                 }
+                stamp(6); // tile read + global stores
                 __syncthreads();
+                stamp(7); // barrier after the copy-out
             }
         }
         item_pre = item_next;
+    }
+    if (kAblate & 32) {
+        if ((tid & 63) == 0) {
+            unsigned long long *dst = m.stamps + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 8;
+            for (int q = 0; q < 8; q++) dst[q] = tacc[q];
+        }
     }
 }
 

@@ -32,6 +32,7 @@ struct DeviceMatrix {
     const uint8_t *dmask = nullptr;     // per local node (owned, padding, ghosts)
     double *vals = nullptr;             // total_slots x 36, sliced layout
     double *minv = nullptr;             // n_slices x 6 x 192: inverse diagonal blocks
+    unsigned long long *stamps = nullptr; // profiling builds of k_assemble only (tools/lab)
     int32_t *status = nullptr;          // device int: 0 ok, e+1 = first degenerate local element,
                                         // -(node+1) = singular diagonal block
 };

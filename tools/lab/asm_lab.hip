@@ -48,14 +48,19 @@ int main(int argc, char **argv)
     mc.cm = E / (1 - nu * nu); mc.cp = E * t * t * t / (12 * (1 - nu * nu)); mc.nu = nu; mc.g = (1 - nu) / 2; mc.t = t; mc.flags = 3; mc.pad = 0;
     printf("nx=%d slices=%d max_elems=%d max_stage=%d items=%zu lds=%d grid=%d\n", nx, p.n_slices, p.max_slice_elems, p.max_stage_rows, p.items.size(), m.lds_bytes, grid);
     const int R = 5;
-    printf("W1 full               : %.3f ms\n", run<1, 0>(m, mc, grid, R));
     printf("W2 full               : %.3f ms\n", run<2, 0>(m, mc, grid, R));
-    printf("W2 no stores          : %.3f ms\n", run<2, 1>(m, mc, grid, R));
-    printf("W2 rec0 broadcast     : %.3f ms\n", run<2, 2>(m, mc, grid, R));
-    printf("W2 no block math      : %.3f ms\n", run<2, 4>(m, mc, grid, R));
-    printf("W2 no record math     : %.3f ms\n", run<2, 8>(m, mc, grid, R));
-    printf("W2 nostore+noblock    : %.3f ms\n", run<2, 5>(m, mc, grid, R));
-    printf("W2 nostore+noblk+norec: %.3f ms\n", run<2, 13>(m, mc, grid, R));
-    printf("W2 noblock+norec      : %.3f ms\n", run<2, 12>(m, mc, grid, R));
+    {
+        unsigned long long *st; CK(hipMalloc(&st, (size_t)grid * 4 * 8 * 8)); CK(hipMemset(st, 0, (size_t)grid * 4 * 8 * 8));
+        m.stamps = st;
+        const float ms = run<2, 32>(m, mc, grid, 1); // warm-up launch + 1 timed launch accumulate into the same array
+        std::vector<unsigned long long> h((size_t)grid * 4 * 8);
+        CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+        const char *names[8] = {"phase A (gather+record+LDS)", "barrier after A", "item decode + block math", "staging + barrier",
+                                "reduce + constraints", "tile write + barrier", "tile read + global stores", "barrier after copy-out"};
+        double tot[8] = {0}; double all = 0;
+        for (size_t w_ = 0; w_ < (size_t)grid * 4; w_++) for (int q = 0; q < 8; q++) { tot[q] += (double)h[w_ * 8 + q]; all += (double)h[w_ * 8 + q]; }
+        printf("stamped build: %.3f ms per launch; share of wave cycles per phase (two launches summed):\n", ms);
+        for (int q = 0; q < 8; q++) printf("  %-32s %5.1f %%   (%.0f cycles per wave per slice)\n", names[q], 100.0 * tot[q] / all, tot[q] / 2 / ((double)p.n_slices * 4));
+    }
     return 0;
 }
