@@ -50,6 +50,8 @@ struct TriFrame {
 // SA:318-340, 378-411.  Returns false for a degenerate triangle.
 __device__ __forceinline__ bool tri3_frame(const double X[9], TriFrame &f)
 {
+#pragma clang fp reassociate(on) contract(fast) // element math only; parity bar is 1e-12, not bitwise
+
     double U[3], V[3], W[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
@@ -93,6 +95,8 @@ constexpr int kRecDoubles = 28; // 224 B: 16-byte aligned rows for ds_read_b128
 
 __device__ __forceinline__ bool tri3_record(const double X[9], const MatConst &mc, double rec[kRecDoubles])
 {
+#pragma clang fp reassociate(on) contract(fast) // element math only; parity bar is 1e-12, not bitwise
+
     TriFrame f;
     const bool ok = tri3_frame(X, f);
     if (!ok) {
@@ -192,6 +196,8 @@ __device__ __forceinline__ void specht_table_fill(double *tab, int tid, int nthr
 __device__ __forceinline__ void specht_node_block_tab(const double *rec, const double *tab, int i, int k, int g,
                                                       double xki, double yki, double xji, double yji, double B[3][3])
 {
+#pragma clang fp reassociate(on) contract(fast) // element math only; parity bar is 1e-12, not bitwise
+
     const double *ti = tab + (i * 3 + g) * 6, *tk = tab + (k * 3 + g) * 6, *tc = tab + 54 + i * 6;
     const double mi = rec[15 + k];                      // chi_{7+i} pairs with mu_{(i+2)%3}
     const double mk = rec[15 + ((k == 0) ? 2 : k - 1)]; // chi_{7+k} pairs with mu_{(k+2)%3}
@@ -211,6 +217,8 @@ __device__ __forceinline__ void specht_node_block_tab(const double *rec, const d
 __device__ __forceinline__ void tri3_block_add_rec(const double *rec, const double *tab, int ia, int ib,
                                                    const MatConst &mc, double acc[36])
 {
+#pragma clang fp reassociate(on) contract(fast) // element math only; parity bar is 1e-12, not bitwise
+
     const int ka = (ia == 0) ? 2 : ia - 1, kb = (ib == 0) ? 2 : ib - 1; // (i+2)%3
     // rows of (xs,ys) are (12),(31),(23).  Seen from node i: (x_ki,y_ki) = row {1,0,2}[i],
     // (x_ji,y_ji) = -row {0,2,1}[i]; membrane: beta = y of row {2,1,0}[i], gamma = -x of that row
