@@ -314,14 +314,25 @@ void launch_spmv(const DeviceMatrix &m, const double *x, double *y, double *part
 // CG vector kernels (one lane per scalar row, one workgroup per slice)
 // =====================================================================================
 
-// z_row = sum_j Minv[row][j] * r[node*6+j], r of the slice staged in LDS
-__device__ __forceinline__ double apply_minv(const DeviceMatrix &m, int sl, int t, const double *rs)
+// z_row = sum_j Minv[row][j] * r[node*6+j].  The six Minv entries of the row are fetched before the
+// residual of the slice is exchanged through LDS, so their latency overlaps the barrier.
+struct MinvRow {
+    double a[6];
+};
+__device__ __forceinline__ MinvRow load_minv(const DeviceMatrix &m, int sl, int t)
 {
     const double *mi = m.minv + (int64_t)sl * 6 * kSliceRows + t;
+    MinvRow r;
+#pragma unroll
+    for (int j = 0; j < 6; j++) r.a[j] = mi[j * kSliceRows];
+    return r;
+}
+__device__ __forceinline__ double apply_minv(const MinvRow &mr, int t, const double *rs)
+{
     const int nb = (t / 6) * 6;
     double z = 0.0;
 #pragma unroll
-    for (int j = 0; j < 6; j++) z += mi[j * kSliceRows] * rs[nb + j];
+    for (int j = 0; j < 6; j++) z += mr.a[j] * rs[nb + j];
     return z;
 }
 
@@ -334,11 +345,12 @@ __global__ __launch_bounds__(192) void k_cg_init(DeviceMatrix m, CgVectors v, in
     for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
         const int sl = w.s;
         const int64_t row = (int64_t)sl * kSliceRows + t;
+        const MinvRow mr = load_minv(m, sl, t);
         const double bv = restart ? v.b[row] - v.q[row] : v.b[row]; // the residual to start from
         __syncthreads();
         rs[t] = bv;
         __syncthreads();
-        const double z = apply_minv(m, sl, t, rs);
+        const double z = apply_minv(mr, t, rs);
         if (!restart) v.x[row] = 0.0;
         v.r[row] = bv;
         v.z[row] = z;
@@ -385,14 +397,15 @@ __global__ __launch_bounds__(192) void k_cg_update(DeviceMatrix m, CgVectors v)
     for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
         const int sl = w.s;
         const int64_t row = (int64_t)sl * kSliceRows + t;
-        const double pv = v.p[row], qv = v.q[row];
-        v.x[row] += alpha * pv;
-        const double rn = v.r[row] - alpha * qv;
+        const MinvRow mr = load_minv(m, sl, t);
+        const double pv = v.p[row], qv = v.q[row], xv = v.x[row], rv = v.r[row];
+        v.x[row] = xv + alpha * pv;
+        const double rn = rv - alpha * qv;
         v.r[row] = rn;
         __syncthreads();
         rs[t] = rn;
         __syncthreads();
-        const double z = apply_minv(m, sl, t, rs);
+        const double z = apply_minv(mr, t, rs);
         v.z[row] = z;
         d0 += rn * z;
         d1 += rn * rn;
