@@ -31,12 +31,27 @@ DummyFluid DummyFluid::tower(int dimensions)
     }
     d.grid[(size_t)42 * dimensions] = 3.125; // top
     d.grid[(size_t)42 * dimensions + 1] = 2.0;
+    for (int i = 0; i < 21; i++) d.forced.push_back(i); // fluid_solver.cpp:190-195
+    return d;
+}
+
+DummyFluid DummyFluid::left_edge(int dimensions, const std::vector<double> &pos)
+{
+    DummyFluid d;
+    d.dimensions = dimensions;
+    d.grid = pos;
+    d.f.assign(pos.size(), 0.0);
+    const int n = (int)(pos.size() / dimensions);
+    double xmin = 1e300;
+    for (int i = 0; i < n; i++) xmin = std::min(xmin, pos[(size_t)i * dimensions]);
+    for (int i = 0; i < n; i++)
+        if (pos[(size_t)i * dimensions] <= xmin + 1e-12 * (1.0 + std::fabs(xmin))) d.forced.push_back(i);
     return d;
 }
 
 void DummyFluid::compute_forces()
 {
-    for (int i = 0; i < 21; i++) {
+    for (int i : forced) {
         f[(size_t)i * dimensions] = 1.0 + std::sin(t / 25.01);
         if (dimensions == 3) f[(size_t)i * dimensions + 1] = 0.0;
     }
@@ -262,7 +277,9 @@ int fem_shell_precice_main(int argc, char **argv, std::ostream &out, std::ostrea
             << "\t\t the in-process stand-in, the dummy fluid of fluid_solver.cpp is built in)\n"
             << "-dt:\t (preCICE) max time step length (required, recommended to set same as in config XML)\n"
             << "-axis:\t (preCICE) dead axis ([x,y,z] optional)\n"
-            << "-steps:\t stop after this many time steps (optional)\n";
+            << "-steps:\t stop after this many time steps (optional)\n"
+            << "-fluid:\t dummy fluid geometry: tower (fluid_solver.cpp, default) or edge (forces on the interface's\n"
+            << "\t\t minimal-first-coordinate edge, for other meshes)\n";
         out << "Read command-line arguments.......FAILED" << std::endl;
         return -1;
     }
@@ -288,7 +305,14 @@ int fem_shell_precice_main(int argc, char **argv, std::ostream &out, std::ostrea
         ShellMesh mesh = read_xda(p.in_filename);
         int dims = 2;
         const InProcessCoupling::Scheme scheme = scheme_from_xml(config, &dims);
-        InProcessCoupling interface(DummyFluid::tower(dims), scheme);
+        const char *fluid = arg_after(argc, argv, "-fluid"); // extension: "tower" (default) | "edge"
+        DummyFluid dummy = DummyFluid::tower(dims);
+        if (fluid && std::string(fluid) == "edge") {
+            CoupledStructure probe_cs;
+            probe_cs.init(mesh, dims, deadAxis);
+            dummy = DummyFluid::left_edge(dims, probe_cs.grid);
+        }
+        InProcessCoupling interface(dummy, scheme);
         out << "preCICE configured... (in-process stand-in, " << dims << "D, " << scheme.max_time / scheme.timestep
             << " time steps)" << std::endl;
         // probe: the highest interface node, displacement along the first live axis

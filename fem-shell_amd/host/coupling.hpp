@@ -52,6 +52,10 @@ struct DummyFluid {
     int t = 0;                 // finished time steps
     // fluid_solver.cpp:95-118: 21 left-edge, 21 right-edge vertices and one on top of the tower
     static DummyFluid tower(int dimensions);
+    // the same load pattern on any interface (BASELINE config 5, the perpendicular flap): fluid vertices
+    // coincide with the given interface vertices; the forced ones are those on the minimal first coordinate
+    static DummyFluid left_edge(int dimensions, const std::vector<double> &interface_positions);
+    std::vector<int> forced; // vertices that carry f_x = 1 + sin(t/25.01)
     // fluid_solver.cpp:187-199: f_x = 1 + sin(t/25.01) on the 21 left-edge vertices
     void compute_forces();
     int n() const { return (int)(grid.size() / dimensions); }

@@ -130,3 +130,32 @@ def test_coupled_run_reproduces_the_quasi_static_time_series(coupled_tool):
     u_unit = oracle.direct_solve(r0, c0, v0, F0).reshape(-1, 6)
     want = [(1.0 + np.sin(t / 25.01)) * u_unit[probe, 0] for t in range(steps)]
     np.testing.assert_allclose(tips, want, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_coupled_flap_config5_scaled(tools, coupled_tool, tmp_path):
+    """BASELINE configs[4] scaled down: flap 0.1 x 1 in the x-z plane (dead axis y), bottom edge id 20, other
+    edges id 2, E=1e6 nu=0.3 t=0.1, forces f_x = 1 + sin(t/25.01) on the left-edge interface nodes."""
+    from tests.helpers import oracle
+
+    _, meshgen = tools
+    name = str(tmp_path / "flap")
+    nx, nz = 10, 100
+    subprocess.check_call([meshgen, "t", str(nx), str(nz), "0", "0", "0.1", "1", "2,20,2,2", "1", "0", "1", "y", name])
+    steps = 4
+    r = subprocess.run([coupled_tool, "-nu", "0.3", "-e", "1e6", "-t", "0.1", "-mesh", name + ".xda", "-config", CONFIG,
+                        "-dt", "0.01", "-axis", "y", "-steps", str(steps), "-fluid", "edge"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    tips = [float(v) for v in re.findall(r"tip\[\d+\] node \d+ = (\S+)", r.stdout)]
+    probe = int(re.search(r"tip\[0\] node (\d+)", r.stdout).group(1))
+    m = meshes.read_xda(name + ".xda")
+    ifn = m.interface_nodes()
+    left = [n for n in ifn if abs(m.xyz[n, 0]) < 1e-12]
+    assert len(left) == nz + 1
+    loads = np.zeros((m.n_nodes, 6))
+    loads[left, 0] = 1.0
+    mat = oracle.material(0.3, 1e6, 0.1)
+    r0, c0, v0, F0 = oracle.assemble(m.xyz, m.tri, m.quad, mat, m.dirichlet_mask(), loads)
+    u_unit = oracle.refined_solve(r0, c0, v0, F0).reshape(-1, 6)
+    want = [(1.0 + np.sin(t / 25.01)) * u_unit[probe, 0] for t in range(steps)]
+    np.testing.assert_allclose(tips, want, rtol=1e-5)
