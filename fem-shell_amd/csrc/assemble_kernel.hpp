@@ -64,6 +64,11 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
     };
     SliceWalk w(m.n_slices);
     if (!w.valid()) return;
+    unsigned long long rt0 = 0, ct0 = 0;
+    if (kAblate & 32) {
+        rt0 = __builtin_amdgcn_s_memrealtime();
+        ct0 = __builtin_amdgcn_s_memtime();
+    }
     stamp(-1);
     specht_table_fill(lds_tab, tid, blockDim.x); // visible after the first barrier below
     // software pipeline over slices: the node ids of the next slice's elements are fetched while
@@ -250,6 +255,10 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         if ((tid & 63) == 0) {
             unsigned long long *dst = m.stamps + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 8;
             for (int q = 0; q < 8; q++) dst[q] = tacc[q];
+            if (blockIdx.x == 0 && tid == 0) { // clock estimate: shader cycles per 100 MHz tick
+                m.stamps[(size_t)gridDim.x * 32] = __builtin_amdgcn_s_memtime() - ct0;
+                m.stamps[(size_t)gridDim.x * 32 + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+            }
         }
     }
 }
