@@ -446,32 +446,18 @@ void launch_cg_direction(const DeviceMatrix &m, const CgVectors &v, hipStream_t 
     hipLaunchKernelGGL(k_cg_direction, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, v, n2);
 }
 
-// single workgroup: deterministic reduction of the per-workgroup partial sums, then the
-// scalar recurrence step
-__global__ __launch_bounds__(1024) void k_cg_scalar(CgVectors v, int G, int do_reduce, int nsums, int phase,
-                                                    double rtol)
+// Deterministic two-stage reduction of the per-workgroup partial sums followed by the scalar recurrence
+// step, in one launch: kReduceGroups workgroups each sum a contiguous chunk (fixed order), publish their
+// result and take a ticket; the workgroup that draws the last ticket adds the stage-1 sums in index order
+// and updates alpha / beta / the convergence flag.  Publication follows the agent-scope release/acquire
+// recipe of the CDNA programming guide (Guideline 16): plain store -> release fence -> vmcnt(0) -> relaxed
+// atomic ticket; last arriver: acquire fence -> vmcnt(0) -> plain loads.  Which workgroup is last does
+// not change the result.
+constexpr int kReduceGroups = 64;
+
+__device__ __forceinline__ void cg_scalar_phase(const CgVectors &v, int phase, double rtol)
 {
-    __shared__ double sh[16];
     CgScalars *s = v.s;
-    if (phase != CG_PHASE_INIT && phase != CG_PHASE_RESTART && s->done != 0) return;
-    if (do_reduce) {
-        for (int a = 0; a < nsums; a++) {
-            const double *pa = v.partials + (int64_t)a * G;
-            // 16 independent loads per thread and round: the reduction of ~60k partial sums is latency-bound
-            double acc = 0.0;
-            const int B = blockDim.x;
-            for (int i0 = threadIdx.x; i0 < G; i0 += 16 * B) {
-                double t[16];
-#pragma unroll
-                for (int q = 0; q < 16; q++) t[q] = (i0 + q * B < G) ? pa[i0 + q * B] : 0.0;
-#pragma unroll
-                for (int q = 0; q < 16; q++) acc += t[q];
-            }
-            const double tot = block_sum(acc, sh);
-            if (threadIdx.x == 0) s->red[a] = tot;
-        }
-    }
-    if (threadIdx.x != 0) return;
     if (phase == CG_PHASE_INIT) {
         s->rz = s->red[0];
         s->bb = s->red[1];
@@ -504,11 +490,55 @@ __global__ __launch_bounds__(1024) void k_cg_scalar(CgVectors v, int G, int do_r
     }
 }
 
+__global__ __launch_bounds__(256) void k_cg_scalar(CgVectors v, int G, int do_reduce, int nsums, int phase,
+                                                   double rtol)
+{
+    __shared__ double sh[4];
+    CgScalars *s = v.s;
+    if (phase != CG_PHASE_INIT && phase != CG_PHASE_RESTART && s->done != 0) return; // same decision in every workgroup
+    if (!do_reduce) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) cg_scalar_phase(v, phase, rtol);
+        return;
+    }
+    const int nwg = gridDim.x;
+    const int chunk = (G + nwg - 1) / nwg;
+    const int lo = blockIdx.x * chunk, hi = min(G, lo + chunk);
+    for (int a = 0; a < nsums; a++) {
+        const double *pa = v.partials + (int64_t)a * G;
+        double acc = 0.0;
+        const int B = blockDim.x;
+        for (int i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * B) {
+            double t[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) t[q] = (i0 + q * B < hi) ? pa[i0 + q * B] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc += t[q];
+        }
+        const double tot = block_sum(acc, sh);
+        if (threadIdx.x == 0) s->stage[a][blockIdx.x] = tot;
+    }
+    if (threadIdx.x != 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t ticket = __hip_atomic_fetch_add(&s->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket != (uint32_t)nwg - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int a = 0; a < nsums; a++) {
+        double tot = 0.0;
+        for (int w = 0; w < nwg; w++) tot += s->stage[a][w];
+        s->red[a] = tot;
+    }
+    __hip_atomic_store(&s->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
+    cg_scalar_phase(v, phase, rtol);
+}
+
 void launch_cg_scalar(const DeviceMatrix &m, const CgVectors &v, bool reduce, int nsums, CgPhase phase,
                       double rtol, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_cg_scalar, dim3(1), dim3(1024), 0, st, v, slice_grid(m), reduce ? 1 : 0, nsums, (int)phase,
-                       rtol);
+    const int G = slice_grid(m);
+    const int groups = reduce ? (G >= 4096 ? kReduceGroups : 1) : 1;
+    hipLaunchKernelGGL(k_cg_scalar, dim3(groups), dim3(256), 0, st, v, G, reduce ? 1 : 0, nsums, (int)phase, rtol);
 }
 
 __global__ void k_pack(const double *p, const int32_t *nodes, int32_t count, double *buf)

@@ -48,6 +48,9 @@ struct CgScalars {
     double red[2]; // local sums before / global sums after the all-reduce
     int32_t done;  // 0 running, 1 converged, -1 breakdown
     int32_t iters; // iterations performed
+    uint32_t ticket;     // arrival counter of the two-stage reduction (0 between launches)
+    uint32_t pad;
+    double stage[2][64]; // stage-1 sums of the reduction workgroups
 };
 
 struct CgVectors {
