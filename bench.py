@@ -122,6 +122,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if os.environ.get("FEMSHELL_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0  # test hook: several ranks on the one GPU of a test box (with the fake RCCL of tests/helpers)
     torch.cuda.set_device(local_rank)
     if world > 1:
         # control plane only (unique-id broadcast, barriers, timing max); the data path

@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 
 namespace femshell {
@@ -29,7 +30,13 @@ Api g_api;
 bool load_api(std::string *err)
 {
     if (g_api.lib) return true;
-    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // FEMSHELL_RCCL_LIB: tests point this at tests/helpers/fake_rccl (several ranks on one GPU)
+    const char *override_path = getenv("FEMSHELL_RCCL_LIB");
+    void *lib = override_path ? dlopen(override_path, RTLD_NOW | RTLD_LOCAL) : dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib && override_path) {
+        if (err) *err = std::string("cannot open FEMSHELL_RCCL_LIB=") + override_path + ": " + dlerror();
+        return false;
+    }
     if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) {

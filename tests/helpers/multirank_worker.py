@@ -1,0 +1,56 @@
+"""One rank of a multi-rank solve on a shared GPU (tests/test_multirank_gpu.py launches several of these
+with FEMSHELL_RCCL_LIB pointing at the fake RCCL).  argv: rank world uid_file out_file mesh_kind"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from tests.helpers import meshes  # noqa: E402
+
+
+def build_problem(kind):
+    if kind == "panel":
+        m = meshes.structured(40, 56, 0, 0, 4, 5.6, kind="t", ul_lr=True, bcids=(0, 0, 1, -1), factor=3.0, loading=2)
+        m.xyz[:, 2] = 0.2 * np.sin(1.1 * m.xyz[:, 0]) * np.cos(0.6 * m.xyz[:, 1])
+        return m, (0.3, 2.0e5, 0.05)
+    if kind == "cylinder":
+        m = meshes.pinched_cylinder(48, 40)
+        return m, m.material
+    raise SystemExit("unknown mesh kind")
+
+
+def main():
+    rank, world = int(sys.argv[1]), int(sys.argv[2])
+    uid_file, out_file, kind = sys.argv[3], sys.argv[4], sys.argv[5]
+    pkg = importlib.import_module("fem-shell_amd")
+    m, (nu, E, t) = build_problem(kind)
+    fs = pkg.FemShell(nu, E, t, device=0, rank=rank, world_size=world)
+    if world > 1:
+        if rank == 0:
+            uid = pkg.comm_unique_id()
+            np.save(uid_file + ".tmp.npy", uid)
+            os.replace(uid_file + ".tmp.npy", uid_file)
+        else:
+            t0 = time.time()
+            while not os.path.exists(uid_file):
+                if time.time() - t0 > 60:
+                    raise SystemExit("timeout waiting for the unique id")
+                time.sleep(0.01)
+            uid = np.load(uid_file)
+        fs.comm_init(uid)
+    fs.set_mesh(m.xyz, m.tri, m.quad)
+    fs.set_dirichlet(m.dirichlet_mask())
+    fs.set_loads(m.loads)
+    u, info = fs.solve(rtol=1e-11, max_it=100000)
+    b, e = fs.row_range()
+    np.savez(out_file, u=u, iterations=info["iterations"], converged=info["converged"], begin=b, end=e,
+             true_res=info["true_rel_residual"])
+    fs.close()
+
+
+if __name__ == "__main__":
+    main()
