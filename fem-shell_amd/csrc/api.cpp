@@ -515,7 +515,7 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
         setup_s = c->last_setup_s;
     }
     hipStream_t st = c->stream;
-    FS_HIP(c->hist.alloc((size_t)std::max(max_it, 1)));
+    FS_HIP(c->hist.alloc((size_t)std::min<int64_t>(std::max(max_it, 1), 1 << 22))); // history of the first 4M iterations
     CgVectors v = cg_vectors(c);
     const DeviceMatrix &m = c->dm;
 
@@ -570,7 +570,7 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
     float ms = 0.f;
     FS_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last_iters = hs.iters;
-    c->hist_host.assign((size_t)std::min<int32_t>(hs.iters, max_it), 0.0);
+    c->hist_host.assign((size_t)std::min<int64_t>(hs.iters, (int64_t)c->hist.n), 0.0);
     if (!c->hist_host.empty())
         FS_HIP(hipMemcpy(c->hist_host.data(), c->hist.p, c->hist_host.size() * sizeof(double), hipMemcpyDeviceToHost));
     c->have_solution = true;
