@@ -71,6 +71,10 @@ struct femshell_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // halo exchange beside the interior SpMV (multi-rank contexts): second stream + hand-off events
+    hipStream_t halo_stream = nullptr;
+    hipEvent_t ev_p_ready = nullptr, ev_halo_done = nullptr;
+    bool halo_overlap = false;
     MatConst mc{};
     Plan plan;
     bool have_mesh = false, matrix_valid = false, rhs_valid = false, jacobi_valid = false, have_solution = false;
@@ -87,7 +91,7 @@ struct femshell_ctx {
     // CG state
     DevBuf<double> x, r, z, p, q, partials, hist, sendbuf, ufull;
     DevBuf<CgScalars> scal;
-    DevBuf<int32_t> send_nodes;
+    DevBuf<int32_t> send_nodes, spmv_order;
     std::vector<int32_t> send_offsets; // per peer, in nodes
     // scratch for femshell_time_kernel
     DevBuf<double> bx, br, bz, bp, bq, bpart;
@@ -232,29 +236,57 @@ CgVectors cg_vectors(femshell_ctx *c)
     return v;
 }
 
-int halo_exchange(femshell_ctx *c, double *p)
+int halo_exchange(femshell_ctx *c, double *p, hipStream_t st)
 {
     if (!c->comm.active() || c->plan.peers.empty()) return FEMSHELL_OK;
     const Plan &pl = c->plan;
     for (size_t i = 0; i < pl.peers.size(); i++)
         launch_pack(p, c->send_nodes.p + c->send_offsets[i], (int32_t)pl.peers[i].send_nodes.size(),
-                    c->sendbuf.p + 6ll * c->send_offsets[i], c->stream);
+                    c->sendbuf.p + 6ll * c->send_offsets[i], st);
     std::string e;
-    if (!comm_halo(c->comm, pl.peers, c->send_offsets, c->sendbuf.p, p + 6ll * pl.n_pad, c->stream, &e))
+    if (!comm_halo(c->comm, pl.peers, c->send_offsets, c->sendbuf.p, p + 6ll * pl.n_pad, st, &e))
         return set_err(FEMSHELL_ERR_COMM, e);
     return FEMSHELL_OK;
 }
 
-int scalar_step(femshell_ctx *c, const CgVectors &v, int nsums, CgPhase phase, double rtol)
+// q = K p with the fused p.q partial sums.  Multi-rank contexts: the ghost entries of p travel on
+// halo_stream (pack, grouped send/recv) while the main stream multiplies the slices that read owned
+// columns only; the slices with ghost columns follow once the halo has landed.  Returns the number of
+// partial sums written through *n_partials (0 = slice_grid).
+int spmv_with_halo(femshell_ctx *c, const CgVectors &v, int *n_partials)
+{
+    hipStream_t st = c->stream;
+    *n_partials = 0;
+    if (!c->halo_overlap) {
+        int rc = halo_exchange(c, v.p, st);
+        if (rc) return rc;
+        launch_spmv(c->dm, v.p, v.q, v.partials, v.s, st);
+        return FEMSHELL_OK;
+    }
+    const Plan &pl = c->plan;
+    FS_HIP(hipEventRecord(c->ev_p_ready, st));
+    FS_HIP(hipStreamWaitEvent(c->halo_stream, c->ev_p_ready, 0));
+    int rc = halo_exchange(c, v.p, c->halo_stream);
+    if (rc) return rc;
+    FS_HIP(hipEventRecord(c->ev_halo_done, c->halo_stream));
+    const int ni = pl.n_interior_slices, nb = pl.n_slices - ni;
+    const int gi = launch_spmv_span(c->dm, v.p, v.q, v.partials, v.s, c->spmv_order.p, 0, ni, 0, st);
+    FS_HIP(hipStreamWaitEvent(st, c->ev_halo_done, 0));
+    const int gb = launch_spmv_span(c->dm, v.p, v.q, v.partials, v.s, c->spmv_order.p, ni, nb, gi, st);
+    *n_partials = gi + gb;
+    return FEMSHELL_OK;
+}
+
+int scalar_step(femshell_ctx *c, const CgVectors &v, int nsums, CgPhase phase, double rtol, int n_partials = 0)
 {
     if (c->comm.active()) {
-        launch_cg_scalar(c->dm, v, true, nsums, CG_PHASE_NONE, rtol, c->stream);
+        launch_cg_scalar(c->dm, v, true, nsums, CG_PHASE_NONE, rtol, c->stream, n_partials);
         std::string e;
         double *red = reinterpret_cast<double *>(reinterpret_cast<char *>(v.s) + offsetof(CgScalars, red));
         if (!comm_allreduce_sum(c->comm, red, nsums, c->stream, &e)) return set_err(FEMSHELL_ERR_COMM, e);
         launch_cg_scalar(c->dm, v, false, nsums, phase, rtol, c->stream);
     } else {
-        launch_cg_scalar(c->dm, v, true, nsums, phase, rtol, c->stream);
+        launch_cg_scalar(c->dm, v, true, nsums, phase, rtol, c->stream, n_partials);
     }
     return FEMSHELL_OK;
 }
@@ -314,6 +346,10 @@ int femshell_destroy(femshell_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     comm_destroy(c->comm);
+    if (c->halo_stream) (void)hipStreamSynchronize(c->halo_stream);
+    if (c->ev_p_ready) (void)hipEventDestroy(c->ev_p_ready);
+    if (c->ev_halo_done) (void)hipEventDestroy(c->ev_halo_done);
+    if (c->halo_stream) (void)hipStreamDestroy(c->halo_stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -427,6 +463,18 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     }
     FS_HIP(c->send_nodes.upload(flat, st));
     FS_HIP(c->sendbuf.alloc(flat.size() * 6));
+    // overlap of the halo exchange with the interior SpMV (FEMSHELL_HALO_OVERLAP=0 keeps everything on one stream)
+    c->halo_overlap = false;
+    if (c->comm.active() && !p.peers.empty() && p.n_interior_slices > 0 &&
+        !(getenv("FEMSHELL_HALO_OVERLAP") && atoi(getenv("FEMSHELL_HALO_OVERLAP")) == 0)) {
+        if (!c->halo_stream) {
+            FS_HIP(hipStreamCreateWithFlags(&c->halo_stream, hipStreamNonBlocking));
+            FS_HIP(hipEventCreateWithFlags(&c->ev_p_ready, hipEventDisableTiming));
+            FS_HIP(hipEventCreateWithFlags(&c->ev_halo_done, hipEventDisableTiming));
+        }
+        FS_HIP(c->spmv_order.upload(p.spmv_order, st));
+        c->halo_overlap = true;
+    }
     c->all_begin.resize(p.world);
     c->all_end.resize(p.world);
     for (int r = 0; r < p.world; r++) partition_rows(n_nodes, p.world, r, &c->all_begin[r], &c->all_end[r]);
@@ -526,10 +574,10 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
     CgScalars hs{};
     int32_t next_check = 8, check_step = 8;
     for (int32_t it = 0; it < max_it; it++) {
-        rc = halo_exchange(c, v.p);
+        int n_partials = 0;
+        rc = spmv_with_halo(c, v, &n_partials);
         if (rc) return rc;
-        launch_spmv(m, v.p, v.q, v.partials, v.s, st);
-        rc = scalar_step(c, v, 1, CG_PHASE_ALPHA, rtol);
+        rc = scalar_step(c, v, 1, CG_PHASE_ALPHA, rtol, n_partials);
         if (rc) return rc;
         launch_cg_update(m, v, st);
         rc = scalar_step(c, v, 2, CG_PHASE_BETA, rtol);
@@ -552,7 +600,7 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
         // explicit residual r = b - K x (reported, not enforced): q = K x through the SpMV kernel, whose
         // input vector carries the ghost entries; the CG state is dead at this point
         launch_copy_x_to_p(m, v, st);
-        rc = halo_exchange(c, v.p);
+        rc = halo_exchange(c, v.p, st);
         if (rc) return rc;
         launch_spmv(m, v.p, v.q, nullptr, nullptr, st);
         launch_cg_init(m, v, true, st);
@@ -834,6 +882,7 @@ int femshell_plan_info(const femshell_plan *plan, int64_t *info)
     info[FEMSHELL_PLAN_ROW_BEGIN] = p.row_begin;
     info[FEMSHELL_PLAN_ROW_END] = p.row_end;
     info[FEMSHELL_PLAN_NNZ_BLOCKS] = p.nnz_blocks;
+    info[FEMSHELL_PLAN_N_INTERIOR_SLICES] = p.n_interior_slices;
     return FEMSHELL_OK;
 }
 
@@ -858,6 +907,7 @@ int64_t femshell_plan_array(const femshell_plan *plan, int which, void *out)
     case FEMSHELL_PLAN_PAIR_PTR: return give(p.pair_ptr);
     case FEMSHELL_PLAN_PAIRS: return give(p.pairs);
     case FEMSHELL_PLAN_XYZ_LOCAL: return give(p.xyz_local);
+    case FEMSHELL_PLAN_SPMV_ORDER: return give(p.spmv_order);
     case FEMSHELL_PLAN_PEER_RANKS:
         for (auto &h : p.peers) tmp.push_back(h.rank);
         return give(tmp);

@@ -271,14 +271,14 @@ __device__ __forceinline__ double spmv_row(const int32_t *__restrict__ c, const 
 template <int kChunk>
 __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__restrict__ x,
                                               double *__restrict__ y, double *__restrict__ partials,
-                                              const CgScalars *s)
+                                              const CgScalars *s, const int32_t *__restrict__ order, int count)
 {
     __shared__ double sh[3];
     if (s != nullptr && s->done != 0) return;
     const int t = threadIdx.x;
     double dotv = 0.0;
-    for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
-        const int sl = w.s;
+    for (SliceWalk w(count); w.valid(); w.next()) {
+        const int sl = order != nullptr ? order[w.s] : w.s;
         const int64_t base = m.slice_base[sl];
         const int W = m.slice_width[sl];
         const int32_t *c = m.cols + base + t / 6;
@@ -294,20 +294,41 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
     }
 }
 
-void launch_spmv(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
-                 hipStream_t st)
+static void spmv_dispatch(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
+                          const int32_t *order, int count, int grid, hipStream_t st)
 {
     static const int chunk = [] {
         const char *e = getenv("FEMSHELL_SPMV_CHUNK"); // tuning knob: block slots loaded together
         return e ? atoi(e) : 4;
     }();
-    const dim3 g(slice_grid(m)), b(192);
+    const dim3 g(grid), b(192);
     switch (chunk) {
-    case 1: hipLaunchKernelGGL(k_spmv<1>, g, b, 0, st, m, x, y, partials, s); break;
-    case 2: hipLaunchKernelGGL(k_spmv<2>, g, b, 0, st, m, x, y, partials, s); break;
-    case 8: hipLaunchKernelGGL(k_spmv<8>, g, b, 0, st, m, x, y, partials, s); break;
-    default: hipLaunchKernelGGL(k_spmv<4>, g, b, 0, st, m, x, y, partials, s); break;
+    case 1: hipLaunchKernelGGL(k_spmv<1>, g, b, 0, st, m, x, y, partials, s, order, count); break;
+    case 2: hipLaunchKernelGGL(k_spmv<2>, g, b, 0, st, m, x, y, partials, s, order, count); break;
+    case 8: hipLaunchKernelGGL(k_spmv<8>, g, b, 0, st, m, x, y, partials, s, order, count); break;
+    default: hipLaunchKernelGGL(k_spmv<4>, g, b, 0, st, m, x, y, partials, s, order, count); break;
     }
+}
+
+void launch_spmv(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
+                 hipStream_t st)
+{
+    spmv_dispatch(m, x, y, partials, s, nullptr, m.n_slices, slice_grid(m), st);
+}
+
+int span_grid(const DeviceMatrix &m, int count)
+{
+    const int g = 8 * ((count + 7) / 8), cap = slice_grid(m);
+    return g < cap ? g : cap;
+}
+
+int launch_spmv_span(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
+                     const int32_t *order, int begin, int count, int partial_offset, hipStream_t st)
+{
+    if (count <= 0) return 0;
+    const int grid = span_grid(m, count);
+    spmv_dispatch(m, x, y, partials != nullptr ? partials + partial_offset : nullptr, s, order + begin, count, grid, st);
+    return grid;
 }
 
 // =====================================================================================
@@ -534,9 +555,9 @@ __global__ __launch_bounds__(256) void k_cg_scalar(CgVectors v, int G, int do_re
 }
 
 void launch_cg_scalar(const DeviceMatrix &m, const CgVectors &v, bool reduce, int nsums, CgPhase phase,
-                      double rtol, hipStream_t st)
+                      double rtol, hipStream_t st, int n_partials)
 {
-    const int G = slice_grid(m);
+    const int G = n_partials > 0 ? n_partials : slice_grid(m);
     const int groups = reduce ? (G >= 4096 ? kReduceGroups : 1) : 1;
     hipLaunchKernelGGL(k_cg_scalar, dim3(groups), dim3(256), 0, st, v, G, reduce ? 1 : 0, nsums, (int)phase, rtol);
 }

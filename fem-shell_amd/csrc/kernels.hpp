@@ -80,6 +80,10 @@ void launch_element_matrices(const DeviceMatrix &m, const MatConst &mc, int32_t 
 // (s != nullptr: no-op once s->done != 0)
 void launch_spmv(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
                  hipStream_t st);
+// the same over the slices order[begin, begin+count) only (interior / boundary halves of an overlapped
+// halo exchange); the partial sums go to partials[partial_offset ...]; returns the number written
+int launch_spmv_span(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
+                     const int32_t *order, int begin, int count, int partial_offset, hipStream_t st);
 
 // CG steps; every kernel is a no-op once s->done != 0
 // restart = false: x=0, r=b;  restart = true: x kept, r = b - q (q = K x computed by the caller);
@@ -91,8 +95,9 @@ void launch_cg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st)
 void launch_cg_direction(const DeviceMatrix &m, const CgVectors &v, hipStream_t st); // p = z + beta p
 // single-workgroup scalar step: optional reduction of `nsums` partial arrays into s->red, then the
 // scalar update of `phase` (rtol only used by CG_PHASE_INIT)
+// (n_partials > 0: length of each partial array, default slice_grid(m))
 void launch_cg_scalar(const DeviceMatrix &m, const CgVectors &v, bool reduce, int nsums, CgPhase phase,
-                      double rtol, hipStream_t st);
+                      double rtol, hipStream_t st, int n_partials = 0);
 
 // halo: gather owned entries of p into a contiguous send buffer
 void launch_pack(const double *p, const int32_t *send_nodes, int32_t count, double *sendbuf, hipStream_t st);

@@ -368,6 +368,19 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         std::sort(peers.begin(), peers.end(), [](const HaloPeer &x, const HaloPeer &y) { return x.rank < y.rank; });
         p.peers.swap(peers);
     }
+    // SpMV order: slices whose blocks couple to owned columns only come first; they can be multiplied
+    // while the halo exchange is in flight
+    {
+        std::vector<int32_t> boundary;
+        p.spmv_order.clear();
+        for (int32_t s = 0; s < p.n_slices; s++) {
+            bool ghost = false;
+            for (int64_t i = p.slice_base[s]; i < p.slice_base[s + 1] && !ghost; i++) ghost = p.cols[i] >= p.n_pad;
+            (ghost ? boundary : p.spmv_order).push_back(s);
+        }
+        p.n_interior_slices = (int32_t)p.spmv_order.size();
+        p.spmv_order.insert(p.spmv_order.end(), boundary.begin(), boundary.end());
+    }
     return true;
 }
 

@@ -81,6 +81,9 @@ struct Plan {
     int32_t max_slice_width = 0;
     int64_t nnz_blocks = 0;            // real (non-padding) blocks
     std::vector<HaloPeer> peers;
+    // slices in SpMV order: the first n_interior_slices read no ghost column (they overlap the halo exchange)
+    std::vector<int32_t> spmv_order;
+    int32_t n_interior_slices = 0;
 
     int64_t total_slots() const { return slice_base.empty() ? 0 : slice_base.back(); }
     int32_t n_local_nodes() const { return n_pad + n_ghost; }

@@ -26,6 +26,7 @@ enum {
     FEMSHELL_PLAN_N_OWN = 0, FEMSHELL_PLAN_N_PAD, FEMSHELL_PLAN_N_GHOST, FEMSHELL_PLAN_N_SLICES,
     FEMSHELL_PLAN_N_LTRI, FEMSHELL_PLAN_N_LQUAD, FEMSHELL_PLAN_TOTAL_SLOTS, FEMSHELL_PLAN_N_PAIRS,
     FEMSHELL_PLAN_N_PEERS, FEMSHELL_PLAN_ROW_BEGIN, FEMSHELL_PLAN_ROW_END, FEMSHELL_PLAN_NNZ_BLOCKS,
+    FEMSHELL_PLAN_N_INTERIOR_SLICES, /* slices that read no ghost column: multiplied while the halo is in flight */
     FEMSHELL_PLAN_INFO_COUNT
 };
 /* fills info[FEMSHELL_PLAN_INFO_COUNT] */
@@ -47,7 +48,8 @@ enum {
     FEMSHELL_PLAN_PEER_RECV_OFFSET, /* int32 [n_peers]       first ghost index received from peer  */
     FEMSHELL_PLAN_PEER_RECV_COUNT,  /* int32 [n_peers]                                             */
     FEMSHELL_PLAN_PEER_SEND_PTR,    /* int32 [n_peers+1]     offsets into PEER_SEND_NODES          */
-    FEMSHELL_PLAN_PEER_SEND_NODES   /* int32 [sum]           owned local nodes sent to each peer   */
+    FEMSHELL_PLAN_PEER_SEND_NODES,  /* int32 [sum]           owned local nodes sent to each peer   */
+    FEMSHELL_PLAN_SPMV_ORDER        /* int32 [n_slices]      interior slices first, then boundary  */
 };
 /* returns the element count of the array; copies it to out when out != NULL */
 int64_t femshell_plan_array(const femshell_plan *plan, int which, void *out);

@@ -16,10 +16,11 @@ FAKE_DIR = os.path.join(ROOT, "tests", "helpers", "fake_rccl")
 WORKER = os.path.join(ROOT, "tests", "helpers", "multirank_worker.py")
 
 
-def run_ranks(world, kind, tmp_path):
+def run_ranks(world, kind, tmp_path, overlap=True):
     ensure_built()
     subprocess.check_call(["make", "-C", FAKE_DIR, "-s"])
-    env = dict(os.environ, FEMSHELL_RCCL_LIB=os.path.join(FAKE_DIR, "libfake_rccl.so"))
+    env = dict(os.environ, FEMSHELL_RCCL_LIB=os.path.join(FAKE_DIR, "libfake_rccl.so"),
+               FEMSHELL_HALO_OVERLAP="1" if overlap else "0")
     uid = str(tmp_path / ("uid_%d_%s.npy" % (world, kind)))
     outs = [str(tmp_path / ("out_%d_%s_%d.npz" % (world, kind, r))) for r in range(world)]
     procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), uid, outs[r], kind], env=env,
@@ -55,3 +56,16 @@ def test_partitioned_solve_on_one_gpu_matches_single_rank(world, kind, tmp_path)
     assert covered.all()
     err = np.linalg.norm(ranks[0]["u"] - single["u"]) / np.linalg.norm(single["u"])
     assert err < 1e-8, err  # two CG runs with different summation order on an ill-conditioned system
+
+
+def test_halo_overlap_and_single_stream_exchange_agree(tmp_path):
+    # the halo exchange beside the interior SpMV (second stream, the default) and the single-stream
+    # exchange multiply the same rows by the same numbers; only the order of the p.q partial sums differs
+    (tmp_path / "on").mkdir()
+    (tmp_path / "off").mkdir()
+    a = run_ranks(2, "panel", tmp_path / "on", overlap=True)[0]
+    b = run_ranks(2, "panel", tmp_path / "off", overlap=False)[0]
+    assert a["converged"] == 1 and b["converged"] == 1
+    assert abs(int(a["iterations"]) - int(b["iterations"])) <= 3
+    err = np.linalg.norm(a["u"] - b["u"]) / np.linalg.norm(b["u"])
+    assert err < 1e-8, err

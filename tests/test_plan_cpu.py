@@ -104,6 +104,17 @@ def test_partition_covers_all_rows_and_halo_lists_match(world):
             j = list(pq["peer_ranks"]).index(r)
             off, cnt = pq["peer_recv_offset"][j], pq["peer_recv_count"][j]
             np.testing.assert_array_equal(send, pq["ghost_global"][off:off + cnt])
+    # SpMV order: a permutation of the slices; the interior part reads owned columns only, every
+    # boundary slice reads at least one ghost column (those wait for the halo exchange)
+    for pr in plans:
+        order, ni = pr["spmv_order"], pr["n_interior_slices"]
+        np.testing.assert_array_equal(np.sort(order), np.arange(pr["n_slices"]))
+        assert 0 < ni < pr["n_slices"]
+        for pos, s in enumerate(order):
+            cols = pr["cols"][pr["slice_base"][s]:pr["slice_base"][s + 1]]
+            assert (cols.max() >= pr["n_pad"]) == (pos >= ni)
+    single = pkg.build_plan(m.xyz, m.tri, m.quad)
+    assert single["n_interior_slices"] == single["n_slices"]
 
 
 def test_partitioned_matrix_equals_global_matrix():
