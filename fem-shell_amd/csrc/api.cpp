@@ -442,13 +442,12 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     {
         // LDS of k_assemble: output tile (kOutSlots block slots x 32 nodes x 288 B per pass) +
         // ownership mask + element records + partial-sum staging
-        const size_t work = ((size_t)p.max_slice_elems * kRecDoubles + (size_t)p.max_stage_rows * 36) * sizeof(double);
-        const size_t tile = (size_t)kOutSlots * kSliceNodes * 36 * sizeof(double) + 256 + kSpechtTableDoubles * sizeof(double);
-        const size_t lds = work + tile;
+        int32_t max_items = 0;
+        for (int32_t s = 0; s < p.n_slices; s++) max_items = std::max(max_items, p.item_ptr[s + 1] - p.item_ptr[s]);
+        const size_t lds = assemble_lds_layout(c->dm, p.max_slice_elems, p.max_stage_rows, max_items);
         if (p.max_slice_width > 64) return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_set_mesh: a node has more than 63 neighbours");
-        if (lds > 96 * 1024)
+        if (lds > 160 * 1024) // one workgroup per CU at most; well-numbered meshes need about 50 KB (three per CU)
             return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_set_mesh: a 32-node slice touches too many elements for the LDS staging");
-        c->dm.lds_bytes = (int32_t)lds;
     }
     c->dm.vals = c->vals.p;
     c->dm.minv = c->minv.p;

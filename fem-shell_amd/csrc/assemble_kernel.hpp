@@ -42,13 +42,14 @@ struct SliceWalk {
 template <int kWavesPerSimd, int kAblate = 0, bool kHasQuads = false>
 __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m, MatConst mc)
 {
-    // LDS: [output tile | ownership mask | Specht table | element records | partial-sum staging]
+    // LDS: [ownership mask | element records | partial-sum staging], output tile (kOutSlots*32*36 doubles) either
+    // on top of the records (they are dead once the block math is done; single-round slices only) or behind
+    // the staging rows (see assemble_lds_layout)
     extern __shared__ double lds[];
-    double2 *lds_tile = reinterpret_cast<double2 *>(lds);                                  // kOutSlots*32*36 doubles
-    uint32_t *lds_mask = reinterpret_cast<uint32_t *>(lds + kOutSlots * kSliceNodes * 36); // 64 words
-    double *lds_tab = lds + kOutSlots * kSliceNodes * 36 + 32;                             // kSpechtTableDoubles
-    double *lds_rec = lds_tab + kSpechtTableDoubles;
-    double *lds_stage = lds_rec + (size_t)m.max_slice_elems * kRecDoubles;
+    uint32_t *lds_mask = reinterpret_cast<uint32_t *>(lds); // 64 words
+    double2 *lds_tile = reinterpret_cast<double2 *>(lds + m.lds_tile_off);
+    double *lds_rec = lds + m.lds_rec_off;
+    double *lds_stage = lds + m.lds_stage_off;
     const int tid = threadIdx.x;
 
     // profiling build (kAblate & 32): s_memtime stamps at the phase boundaries, summed per wave and written to
@@ -70,7 +71,6 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         ct0 = __builtin_amdgcn_s_memtime();
     }
     stamp(-1);
-    specht_table_fill(lds_tab, tid, blockDim.x); // visible after the first barrier below
     // software pipeline over slices: the node ids of the next slice's elements are fetched while
     // the current slice computes, so that a slice exposes one dependent load (the coordinates)
     int e0 = m.slice_elem_ptr[w.s], ne = m.slice_elem_ptr[w.s + 1] - e0;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
 #pragma unroll
                     for (int i = 0; i < 26; i++) blk[i] += rec[i];
                 } else {
-                    block_add_rec<kHasQuads>(rec, lds_tab, (int)((pr >> 2) & 3u), (int)(pr & 3u), mc, blk);
+                    block_add_rec<kHasQuads>(rec, (int)((pr >> 2) & 3u), (int)(pr & 3u), mc, blk);
                 }
             }
             const bool owner = live && chunk == 0 && nchunks > 0; // nchunks == 0: padding item

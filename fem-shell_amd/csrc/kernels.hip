@@ -67,15 +67,20 @@ void launch_assemble(const DeviceMatrix &m, const MatConst &mc, hipStream_t st)
         return e ? atoi(e) : 2;
     }();
     const int g = assemble_grid(m);
+    auto launch = [&](auto kernel) {
+        if (lds > 64 * 1024) // beyond the default dynamic-LDS limit
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kernel, dim3(g), dim3(256), lds, st, m, mc);
+    };
     if (m.n_lquad > 0) {
-        hipLaunchKernelGGL((k_assemble<2, 0, true>), dim3(g), dim3(256), lds, st, m, mc);
+        launch(k_assemble<2, 0, true>);
         return;
     }
     switch (variant) {
-    case 1: hipLaunchKernelGGL((k_assemble<1, 0, false>), dim3(g), dim3(256), lds, st, m, mc); break;
-    case 3: hipLaunchKernelGGL((k_assemble<3, 0, false>), dim3(g), dim3(256), lds, st, m, mc); break;
-    case 4: hipLaunchKernelGGL((k_assemble<4, 0, false>), dim3(g), dim3(256), lds, st, m, mc); break;
-    default: hipLaunchKernelGGL((k_assemble<2, 0, false>), dim3(g), dim3(256), lds, st, m, mc); break;
+    case 1: launch(k_assemble<1, 0, false>); break;
+    case 3: launch(k_assemble<3, 0, false>); break;
+    case 4: launch(k_assemble<4, 0, false>); break;
+    default: launch(k_assemble<2, 0, false>); break;
     }
 }
 
@@ -125,12 +130,10 @@ __global__ __launch_bounds__(128) void k_element_matrices(DeviceMatrix m, MatCon
             for (int d = 0; d < 3; d++) X[3 * i + d] = m.xyz[3 * (int64_t)c[i] + d];
         ok = quad4_record(X, mc, rec);
     }
-    double tab[kSpechtTableDoubles];
-    specht_table_fill(tab, 0, 1);
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0.0;
-    if (ok) block_add_rec<true>(rec, tab, ia, ib, mc, acc);
+    if (ok) block_add_rec<true>(rec, ia, ib, mc, acc);
     else atomicCAS(m.status, 0, kStatusDirect + first + e);
     const int N = 6 * nn;
     double *Ke = out + (int64_t)e * N * N;

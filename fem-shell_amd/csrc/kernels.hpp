@@ -28,7 +28,8 @@ struct DeviceMatrix {
     const int32_t *item_ptr = nullptr;       // n_slices+1
     const uint4 *items = nullptr;            // assembly work items (plan.hpp)
     int32_t max_stage_rows = 0;
-    int32_t lds_bytes = 0;                   // dynamic LDS of k_assemble
+    int32_t lds_bytes = 0;                   // dynamic LDS of k_assemble (assemble_lds_layout)
+    int32_t lds_tile_off = 0, lds_rec_off = 0, lds_stage_off = 0; // offsets in doubles
     const uint8_t *dmask = nullptr;     // per local node (owned, padding, ghosts)
     double *vals = nullptr;             // total_slots x 36, sliced layout
     double *minv = nullptr;             // n_slices x 6 x 192: inverse diagonal blocks
@@ -36,6 +37,28 @@ struct DeviceMatrix {
     int32_t *status = nullptr;          // device int: 0 ok, e+1 = first degenerate local element,
                                         // -(node+1) = singular diagonal block
 };
+
+// LDS layout of k_assemble for a plan with at most max_slice_elems element records, max_stage_rows partial-sum
+// rows and max_slice_items work items per slice: [mask 256 B | records | staging | tile].  When every slice
+// finishes its items in one round of 256 the records are dead by the time the output tile is written, and
+// the tile lies on top of them.  Returns the dynamic LDS size in bytes.
+inline size_t assemble_lds_layout(DeviceMatrix &m, int32_t max_slice_elems, int32_t max_stage_rows, int32_t max_slice_items)
+{
+    const size_t mask = 32, rec = (size_t)max_slice_elems * kRecDoubles, stage = (size_t)max_stage_rows * 36,
+                 tile = (size_t)kOutSlots * 32 * 36;
+    m.lds_rec_off = (int32_t)mask;
+    if (max_slice_items <= 256) {
+        const size_t un = rec > tile ? rec : tile;
+        m.lds_tile_off = (int32_t)mask;
+        m.lds_stage_off = (int32_t)(mask + un);
+        m.lds_bytes = (int32_t)((mask + un + stage) * sizeof(double));
+    } else {
+        m.lds_stage_off = (int32_t)(mask + rec);
+        m.lds_tile_off = (int32_t)(mask + rec + stage);
+        m.lds_bytes = (int32_t)((mask + rec + stage + tile) * sizeof(double));
+    }
+    return (size_t)m.lds_bytes;
+}
 
 // Scalars of the CG recurrence, resident in HBM (no host round trip per iteration).
 struct CgScalars {

@@ -89,14 +89,37 @@ __device__ __forceinline__ bool tri3_frame(const double X[9], TriFrame &f)
 // ---- per-element record ---------------------------------------------------------------
 // Everything about a TRI3 element that does not depend on which node block is wanted.  The
 // assembly kernel computes it once per element and slice and keeps it in LDS.
-constexpr int kRecDoubles = 28; // 224 B: 16-byte aligned rows for ds_read_b128
-// [0..8] ex,ey,ez  [9..11] xs  [12..14] ys  [15..17] mu  [18..23] Dt (00,01,02,11,12,22)
-// [24] membrane scale t*cm/(4A)  [25] plate scale A/3  [26] 1.0 if valid  [27] unused
+//
+// Plate part.  Specht's curvature matrix of node i at Gauss point g factors as
+//     B_i(g) = Q_i(g) u_i^T + Q_k(g) v_i^T + C_k (e0 + w_i)^T - C_i e0^T,       k = (i+2)%3,
+// with Q_n(g)[r] = QA[n][g][r] + mu_{(n+2)%3} QB[n][g][r] (curvatures of chi_{7+n}), the constant
+// curvatures C_n of chi_{4+n}, and u_i = (2, y_ji, -x_ji), v_i = (-2, -y_ki, x_ki), w_i = (0, y_ki, -x_ki),
+// e0 = (1,0,0).  Hence the 3x3 plate block of nodes (i,j),
+//     p_ij = A/3 sum_g B_i(g)^T Dt B_j(g) = L_i^T S L_j,
+// needs only the element-level Gram tables
+//     QQ[n][m] = A/3 sum_g Q_n(g)^T Dt Q_m(g),  QC[n][m] = A/3 (sum_g Q_n(g))^T Dt C_m,  CC[n][m] = A C_n^T Dt C_m
+// (27 doubles): S is a 4x4 pick from them and L_i has the rows u_i, v_i, e0 + w_i, -e0.
+// 38 doubles = 304 B: 16-byte aligned, and 76 = 4*19 dwords, so the 16 lanes of a ds_read_b128 group that read
+// the same field of consecutive records hit 16 different bank quads (40 doubles = 4*20 dwords was 50 % slower)
+constexpr int kRecDoubles = 38;
+constexpr int kRecKind = 16;    // 1.0 = TRI3, 2.0 = QUAD4, 0.0 = degenerate
+// [0..8] ex,ey,ez  [9..11] xs  [12..14] ys  [15] membrane scale t*cm/(4A)  [16] kind
+// [17..22] QQ (symmetric: 00,01,02,11,12,22)  [23..31] QC (row-major 3x3)  [32..37] CC (symmetric)
+constexpr int kRecQQ = 17, kRecQC = 23, kRecCC = 32;
+constexpr int kQuadX = 18, kQuadY = 22; // QUAD4 records: local x and y of the four nodes
+// index of entry (n,m) of a symmetric 3x3 table stored as 00,01,02,11,12,22
+__device__ __forceinline__ int sym3(int n, int m)
+{
+    const int lo = n < m ? n : m, hi = n < m ? m : n;
+    return ((lo * (5 - lo)) >> 1) + hi;
+}
 
 __device__ __forceinline__ bool tri3_record(const double X[9], const MatConst &mc, double rec[kRecDoubles])
 {
 #pragma clang fp reassociate(on) contract(fast) // element math only; parity bar is 1e-12, not bitwise
 
+    constexpr double QA[3][3][3] = SPECHT_QA_INIT;
+    constexpr double QB[3][3][3] = SPECHT_QB_INIT;
     TriFrame f;
     const bool ok = tri3_frame(X, f);
     if (!ok) {
@@ -112,12 +135,12 @@ __device__ __forceinline__ bool tri3_record(const double X[9], const MatConst &m
         rec[9 + d] = f.xs[d];
         rec[12 + d] = f.ys[d];
     }
-    double C[3];
+    double C[3], mu[3];
 #pragma unroll
     for (int e = 0; e < 3; e++) C[e] = f.xs[e] * f.xs[e] + f.ys[e] * f.ys[e];
-    rec[15] = (C[0] - C[1]) / C[2]; // SA:702-704
-    rec[16] = (C[2] - C[0]) / C[1];
-    rec[17] = (C[1] - C[2]) / C[0];
+    mu[0] = (C[0] - C[1]) / C[2]; // SA:702-704
+    mu[1] = (C[2] - C[0]) / C[1];
+    mu[2] = (C[1] - C[2]) / C[0];
     // Y (SA:578-588) and Dt = Y^T Dp Y (symmetric)
     const double A = f.area;
     const double x31 = f.xs[1], y31 = f.ys[1], x23 = f.xs[2], y23 = f.ys[2];
@@ -128,94 +151,76 @@ __device__ __forceinline__ bool tri3_record(const double X[9], const MatConst &m
     Y[2][0] = -2.0 * x23 * y23 * sY;
     Y[2][1] = ((mc.flags & kRefY21) ? -2.0 * x31 * x31 : -2.0 * x31 * y31) * sY;
     Y[2][2] = (-x23 * y31 - x31 * y23) * sY;
+    const double sp = A / 3.0; // 2A * (Gauss weight 1/6), folded into Dt
     double DY[3][3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        DY[0][c] = mc.cp * (Y[0][c] + mc.nu * Y[1][c]);
-        DY[1][c] = mc.cp * (mc.nu * Y[0][c] + Y[1][c]);
-        DY[2][c] = mc.cp * mc.g * Y[2][c];
+        DY[0][c] = sp * mc.cp * (Y[0][c] + mc.nu * Y[1][c]);
+        DY[1][c] = sp * mc.cp * (mc.nu * Y[0][c] + Y[1][c]);
+        DY[2][c] = sp * mc.cp * mc.g * Y[2][c];
     }
-    int q = 18;
+    double Dt[3][3];
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int c = r; c < 3; c++) rec[q++] = Y[0][r] * DY[0][c] + Y[1][r] * DY[1][c] + Y[2][r] * DY[2][c];
-    rec[24] = mc.t * mc.cm / (4.0 * A);
-    rec[25] = A / 3.0; // 2A * (Gauss weight 1/6)
-    rec[26] = 1.0;
-    rec[27] = 0.0;
+        for (int c = r; c < 3; c++) Dt[r][c] = Dt[c][r] = Y[0][r] * DY[0][c] + Y[1][r] * DY[1][c] + Y[2][r] * DY[2][c];
+    // Q_n(g), Dt Q_n(g) and the Gram tables
+    double sQ[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    double QQ[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        double Q[3][3], DQ[3][3]; // [n][r]: Q_n(g) and Dt Q_n(g)
+#pragma unroll
+        for (int n = 0; n < 3; n++) {
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                Q[n][r] = QA[n][g][r] + mu[(n + 2) % 3] * QB[n][g][r];
+                sQ[n][r] += Q[n][r];
+            }
+#pragma unroll
+            for (int r = 0; r < 3; r++) DQ[n][r] = Dt[r][0] * Q[n][0] + Dt[r][1] * Q[n][1] + Dt[r][2] * Q[n][2];
+        }
+#pragma unroll
+        for (int n = 0; n < 3; n++)
+#pragma unroll
+            for (int m = n; m < 3; m++) QQ[n][m] += Q[n][0] * DQ[m][0] + Q[n][1] * DQ[m][1] + Q[n][2] * DQ[m][2];
+    }
+    // Dt C_m with C_0 = (0,0,2), C_1 = (0,-2,-2), C_2 = (-2,0,-2)  (curvatures of L1L2, L2L3, L3L1)
+    double DC[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        DC[0][r] = 2.0 * Dt[r][2];
+        DC[1][r] = -2.0 * (Dt[r][1] + Dt[r][2]);
+        DC[2][r] = -2.0 * (Dt[r][0] + Dt[r][2]);
+    }
+    {
+        int q = kRecQQ;
+#pragma unroll
+        for (int n = 0; n < 3; n++)
+#pragma unroll
+            for (int m = n; m < 3; m++) rec[q++] = QQ[n][m];
+    }
+#pragma unroll
+    for (int n = 0; n < 3; n++)
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+            rec[kRecQC + 3 * n + m] = sQ[n][0] * DC[m][0] + sQ[n][1] * DC[m][1] + sQ[n][2] * DC[m][2];
+    // CC[n][m] = 3 C_n . Dt C_m (symmetric): rows C_0 = (0,0,2), C_1 = (0,-2,-2), C_2 = (-2,0,-2)
+    rec[kRecCC + 0] = 6.0 * DC[0][2];
+    rec[kRecCC + 1] = 6.0 * DC[1][2];
+    rec[kRecCC + 2] = 6.0 * DC[2][2];
+    rec[kRecCC + 3] = -6.0 * (DC[1][1] + DC[1][2]);
+    rec[kRecCC + 4] = -6.0 * (DC[2][1] + DC[2][2]);
+    rec[kRecCC + 5] = -6.0 * (DC[2][0] + DC[2][2]);
+    rec[15] = mc.t * mc.cm / (4.0 * A);
+    rec[kRecKind] = 1.0;
     return true;
 }
 
-// Shared Specht table (one copy per workgroup, in LDS): for node i and Gauss point g
-//   [ (i*3+g)*6 + 0..2 ] = QA[i][g][r]   [ (i*3+g)*6 + 3..5 ] = QB[i][g][r]      (54 doubles)
-//   [ 54 + i*6 + 0..2 ]  = C456[k][r] - C456[i][r], k = (i+2)%3                  (18 doubles)
-//   [ 54 + i*6 + 3..5 ]  = C456[k][r]
-constexpr int kSpechtTableDoubles = 72;
-
-__device__ __forceinline__ void specht_table_fill(double *tab, int tid, int nthreads)
-{
-    constexpr double QA[3][3][3] = SPECHT_QA_INIT;
-    constexpr double QB[3][3][3] = SPECHT_QB_INIT;
-    constexpr double C456[3][3] = SPECHT_C456_INIT;
-    for (int q = tid; q < kSpechtTableDoubles; q += nthreads) {
-        double v;
-        if (q < 54) {
-            const int i = q / 18, g = (q / 6) % 3, c = q % 6;
-            double va = 0.0, vb = 0.0;
-#pragma unroll
-            for (int ii = 0; ii < 3; ii++)
-#pragma unroll
-                for (int gg = 0; gg < 3; gg++)
-#pragma unroll
-                    for (int rr = 0; rr < 3; rr++)
-                        if (ii == i && gg == g && rr == c % 3) {
-                            va = QA[ii][gg][rr];
-                            vb = QB[ii][gg][rr];
-                        }
-            v = c < 3 ? va : vb;
-        } else {
-            const int i = (q - 54) / 6, c = (q - 54) % 6, r = c % 3, k = (i + 2) % 3;
-            double ci = 0.0, ck = 0.0;
-#pragma unroll
-            for (int ii = 0; ii < 3; ii++)
-#pragma unroll
-                for (int rr = 0; rr < 3; rr++) {
-                    if (ii == i && rr == r) ci = C456[ii][rr];
-                    if (ii == k && rr == r) ck = C456[ii][rr];
-                }
-            v = c < 3 ? ck - ci : ck;
-        }
-        tab[q] = v;
-    }
-}
-
-// Specht curvature block of node i at Gauss point g from the shared table and the element record:
-// B[r][c], r = (d11, d22, 2 d12), c = (w, theta_x, theta_y).  No selects: everything that depends
-// on the (runtime) node index is fetched by address.
-__device__ __forceinline__ void specht_node_block_tab(const double *rec, const double *tab, int i, int k, int g,
-                                                      double xki, double yki, double xji, double yji, double B[3][3])
-{
-#pragma clang fp reassociate(on) contract(fast) // element math only; parity bar is 1e-12, not bitwise
-
-    const double *ti = tab + (i * 3 + g) * 6, *tk = tab + (k * 3 + g) * 6, *tc = tab + 54 + i * 6;
-    const double mi = rec[15 + k];                      // chi_{7+i} pairs with mu_{(i+2)%3}
-    const double mk = rec[15 + ((k == 0) ? 2 : k - 1)]; // chi_{7+k} pairs with mu_{(k+2)%3}
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const double qi = ti[r] + mi * ti[3 + r];
-        const double qk = tk[r] + mk * tk[3 + r];
-        const double P = qk - tc[3 + r];         // chi_{k+6} - chi_{k+3}
-        B[r][0] = tc[r] + 2.0 * (qi - qk);       // N_w
-        B[r][1] = yji * qi - yki * P;            // N_theta_x
-        B[r][2] = xki * P - xji * qi;            // N_theta_y
-    }
-}
-
 // Adds the global-axes 6x6 block K_e(ia, ib) of the element described by rec to acc (row-major).
-// rec and tab may live in LDS (assembly kernel) or in registers/global (export kernel).
-__device__ __forceinline__ void tri3_block_add_rec(const double *rec, const double *tab, int ia, int ib,
-                                                   const MatConst &mc, double acc[36])
+// rec may live in LDS (assembly kernel) or in registers/global (export kernel).  No selects: everything
+// that depends on the (runtime) node indices is fetched by address.
+__device__ __forceinline__ void tri3_block_add_rec(const double *rec, int ia, int ib, const MatConst &mc, double acc[36])
 {
 #pragma clang fp reassociate(on) contract(fast) // element math only; parity bar is 1e-12, not bitwise
 
@@ -230,38 +235,36 @@ __device__ __forceinline__ void tri3_block_add_rec(const double *rec, const doub
     const double bj = rec[12 + 2 - ib], gj = -rec[9 + 2 - ib];
 
     // ---- membrane block (2x2), closed form of t*A*B_i^T Dm B_j  (SA:448-467)
-    const double sm = rec[24];
+    const double sm = rec[15];
     const double m00 = sm * (bi * bj + mc.g * gi * gj);
     const double m01 = sm * (mc.nu * bi * gj + mc.g * gi * bj);
     const double m10 = sm * (mc.nu * gi * bj + mc.g * bi * gj);
     const double m11 = sm * (gi * gj + mc.g * bi * bj);
 
-    // ---- plate block (3x3)  (SA:555-603), one Gauss point at a time
-    double Dt[3][3];
-    Dt[0][0] = rec[18]; Dt[0][1] = rec[19]; Dt[0][2] = rec[20];
-    Dt[1][1] = rec[21]; Dt[1][2] = rec[22]; Dt[2][2] = rec[23];
-    Dt[1][0] = Dt[0][1]; Dt[2][0] = Dt[0][2]; Dt[2][1] = Dt[1][2];
-    double p[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    // ---- plate block (3x3)  (SA:555-603): p = L_i^T S L_j from the record's Gram tables
+    const double *QQ = rec + kRecQQ, *QC = rec + kRecQC, *CC = rec + kRecCC;
+    const int s_ab = sym3(ia, ib), s_akb = sym3(ia, kb), s_kab = sym3(ka, ib), s_kakb = sym3(ka, kb);
+    double S[4][4];
+    S[0][0] = QQ[s_ab];        S[0][1] = QQ[s_akb];       S[0][2] = QC[3 * ia + kb]; S[0][3] = QC[3 * ia + ib];
+    S[1][0] = QQ[s_kab];       S[1][1] = QQ[s_kakb];      S[1][2] = QC[3 * ka + kb]; S[1][3] = QC[3 * ka + ib];
+    S[2][0] = QC[3 * ib + ka]; S[2][1] = QC[3 * kb + ka]; S[2][2] = CC[s_kakb];      S[2][3] = CC[s_kab];
+    S[3][0] = QC[3 * ib + ia]; S[3][1] = QC[3 * kb + ia]; S[3][2] = CC[s_akb];       S[3][3] = CC[s_ab];
+    double Xm[4][3];
 #pragma unroll
-    for (int g = 0; g < 3; g++) {
-        double Bi[3][3], Bj[3][3];
-        specht_node_block_tab(rec, tab, ia, ka, g, xki_a, yki_a, xji_a, yji_a, Bi);
-        specht_node_block_tab(rec, tab, ib, kb, g, xki_b, yki_b, xji_b, yji_b, Bj);
-        double M[3][3];
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) M[r][c] = Dt[r][0] * Bj[0][c] + Dt[r][1] * Bj[1][c] + Dt[r][2] * Bj[2][c];
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) p[a][c] += Bi[0][a] * M[0][c] + Bi[1][a] * M[1][c] + Bi[2][a] * M[2][c];
+    for (int m = 0; m < 4; m++) {
+        const double d = S[m][2] - S[m][1];
+        Xm[m][0] = 2.0 * (S[m][0] - S[m][1]) + (S[m][2] - S[m][3]);
+        Xm[m][1] = yji_b * S[m][0] + yki_b * d;
+        Xm[m][2] = -(xji_b * S[m][0] + xki_b * d);
     }
-    const double sp = rec[25];
+    double p[3][3];
 #pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) p[a][c] *= sp;
+    for (int c = 0; c < 3; c++) {
+        const double d = Xm[2][c] - Xm[1][c];
+        p[0][c] = 2.0 * (Xm[0][c] - Xm[1][c]) + (Xm[2][c] - Xm[3][c]);
+        p[1][c] = yji_a * Xm[0][c] + yki_a * d;
+        p[2][c] = -(xji_a * Xm[0][c] + xki_a * d);
+    }
 
     // ---- drilling stiffness of this block  (SA:1035-1052)
     double d;
@@ -297,7 +300,7 @@ __device__ __forceinline__ void tri3_block_add_rec(const double *rec, const doub
 
 // =========================================================================================
 // QUAD4: bilinear iso-parametric membrane (SA:469-541) + DKQ plate (SA:604-687, 901-990), 2x2 Gauss.
-// Record: [0..8] ex,ey,ez  [9..12] local x of the 4 nodes  [13..16] local y  [26] = 2.0 if valid.
+// Record: [0..8] ex,ey,ez  [kRecKind] = 2.0 if valid  [kQuadX..+3] local x of the 4 nodes  [kQuadY..+3] local y.
 // =========================================================================================
 
 // SA:342-375: frame from the mid-side points; local coordinates are T*X without translation.
@@ -340,15 +343,15 @@ __device__ __forceinline__ bool quad4_record(const double X[12], const MatConst 
     }
 #pragma unroll
     for (int n = 0; n < 4; n++) {
-        rec[9 + n] = ex[0] * X[3 * n] + ex[1] * X[3 * n + 1] + ex[2] * X[3 * n + 2];
-        rec[13 + n] = ey[0] * X[3 * n] + ey[1] * X[3 * n + 1] + ey[2] * X[3 * n + 2];
+        rec[kQuadX + n] = ex[0] * X[3 * n] + ex[1] * X[3 * n + 1] + ex[2] * X[3 * n + 2];
+        rec[kQuadY + n] = ey[0] * X[3 * n] + ey[1] * X[3 * n + 1] + ey[2] * X[3 * n + 2];
     }
     // the Jacobian determinant must not vanish at the Gauss points; a zero-area quad is rejected here
     double a2 = 0.0;
 #pragma unroll
-    for (int n = 0; n < 4; n++) a2 += rec[9 + n] * rec[13 + (n + 1) % 4] - rec[9 + (n + 1) % 4] * rec[13 + n];
+    for (int n = 0; n < 4; n++) a2 += rec[kQuadX + n] * rec[kQuadY + (n + 1) % 4] - rec[kQuadX + (n + 1) % 4] * rec[kQuadY + n];
     if (!(fabs(a2) > 0.0)) return false;
-    rec[26] = 2.0;
+    rec[kRecKind] = 2.0;
     return true;
 }
 
@@ -385,17 +388,17 @@ __device__ __forceinline__ void quad4_block_add_rec(const double *rec, int ia, i
     double x[4], y[4];
 #pragma unroll
     for (int n = 0; n < 4; n++) {
-        x[n] = rec[9 + n];
-        y[n] = rec[13 + n];
+        x[n] = rec[kQuadX + n];
+        y[n] = rec[kQuadY + n];
     }
     // node data by dynamic index straight from the record (LDS or registers), no selects
     const int ia_p = (ia + 3) & 3, ia_n = (ia + 1) & 3, ib_p = (ib + 3) & 3, ib_n = (ib + 1) & 3;
-    const double xi_ = rec[9 + ia], yi_ = rec[13 + ia], xj_ = rec[9 + ib], yj_ = rec[13 + ib];
+    const double xi_ = rec[kQuadX + ia], yi_ = rec[kQuadY + ia], xj_ = rec[kQuadX + ib], yj_ = rec[kQuadY + ib];
     // side differences (SA:413-424): side s = node s - node s+1
-    const double xa_i = xi_ - rec[9 + ia_n], ya_i = yi_ - rec[13 + ia_n];   // side sa = ia
-    const double xb_i = rec[9 + ia_p] - xi_, yb_i = rec[13 + ia_p] - yi_;   // side sb = ia-1
-    const double xa_j = xj_ - rec[9 + ib_n], ya_j = yj_ - rec[13 + ib_n];
-    const double xb_j = rec[9 + ib_p] - xj_, yb_j = rec[13 + ib_p] - yj_;
+    const double xa_i = xi_ - rec[kQuadX + ia_n], ya_i = yi_ - rec[kQuadY + ia_n];   // side sa = ia
+    const double xb_i = rec[kQuadX + ia_p] - xi_, yb_i = rec[kQuadY + ia_p] - yi_;   // side sb = ia-1
+    const double xa_j = xj_ - rec[kQuadX + ib_n], ya_j = yj_ - rec[kQuadY + ib_n];
+    const double xb_j = rec[kQuadX + ib_p] - xj_, yb_j = rec[kQuadY + ib_p] - yj_;
     // natural coordinates of the corner nodes: (-1,-1), (1,-1), (1,1), (-1,1)
     const double ri = (ia == 1 || ia == 2) ? 1.0 : -1.0, si = (ia >= 2) ? 1.0 : -1.0;
     const double rj = (ib == 1 || ib == 2) ? 1.0 : -1.0, sj = (ib >= 2) ? 1.0 : -1.0;
@@ -493,11 +496,10 @@ __device__ __forceinline__ void quad4_block_add_rec(const double *rec, int ia, i
 
 // dispatch on the record's element kind
 template <bool kHasQuads>
-__device__ __forceinline__ void block_add_rec(const double *rec, const double *tab, int ia, int ib, const MatConst &mc,
-                                              double acc[36])
+__device__ __forceinline__ void block_add_rec(const double *rec, int ia, int ib, const MatConst &mc, double acc[36])
 {
-    if (kHasQuads && rec[26] == 2.0) quad4_block_add_rec(rec, ia, ib, mc, acc);
-    else tri3_block_add_rec(rec, tab, ia, ib, mc, acc);
+    if (kHasQuads && rec[kRecKind] == 2.0) quad4_block_add_rec(rec, ia, ib, mc, acc);
+    else tri3_block_add_rec(rec, ia, ib, mc, acc);
 }
 
 } // namespace femshell

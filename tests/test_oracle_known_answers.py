@@ -86,3 +86,30 @@ def test_non_isosceles_as_coded_Y(nx, ny, wc):
     u = oracle.direct_solve(rowptr, colidx, vals, F).reshape(-1, 6)
     centre = (ny // 2) * (nx + 1) + nx // 2
     assert u[centre, 2] == pytest.approx(wc, rel=2e-6)
+
+
+def test_committed_goldens_are_what_the_oracle_computes():
+    """tests/golden/*.npz are oracle outputs (tools/gen_golden_elements.py, tools/gen_golden_solutions.py):
+    a change of the oracle that moves them must be deliberate."""
+    g = np.load(meshes.GOLDEN + "/tri3_elements.npz")
+    mat = oracle.material(float(g["nu"]), float(g["E"]), float(g["t"]))
+    for e, c in enumerate(g["tri"]):
+        ke = oracle.element_tri3(g["xyz"][c], mat)
+        assert np.abs(ke - g["Ke"][e]).max() <= 1e-13 * np.abs(ke).max()
+    g = np.load(meshes.GOLDEN + "/quad4_elements.npz")
+    mat = oracle.material(float(g["nu"]), float(g["E"]), float(g["t"]))
+    for e, c in enumerate(g["quad"]):
+        ke, parts = oracle.element_quad4(g["xyz"][c], mat, want_parts=True)
+        assert np.abs(ke - g["Ke"][e]).max() <= 1e-13 * np.abs(ke).max()
+        assert np.abs(parts["Ke_m"] - g["Ke_m"][e]).max() <= 1e-13 * np.abs(parts["Ke_m"]).max()
+        assert np.abs(parts["Ke_p"] - g["Ke_p"][e]).max() <= 1e-13 * np.abs(parts["Ke_p"]).max()
+        # element matrices are symmetric with exactly six zero modes (SURVEY section 9)
+        w = np.linalg.eigvalsh(0.5 * (ke + ke.T))
+        assert (np.abs(w) < 1e-9 * w.max()).sum() == 6 and w.min() > -1e-9 * w.max()
+    sols = np.load(meshes.GOLDEN + "/example_solutions.npz")
+    for name in ("test_A_uv_t", "test_B_uv_q", "test_C_w_tA16", "test_E_uvw_t"):
+        nu, E, t = sols[name + "_params"]
+        m = meshes.load_example(name)
+        r, c, v, F = oracle.assemble(m.xyz, m.tri, m.quad, oracle.material(nu, E, t), m.dirichlet_mask(), m.loads)
+        u = oracle.direct_solve(r, c, v, F).reshape(-1, 6)
+        assert np.linalg.norm(u - sols[name]) <= 1e-9 * np.linalg.norm(sols[name])

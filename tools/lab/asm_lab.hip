@@ -40,7 +40,11 @@ int main(int argc, char **argv)
     m.cols = up(p.cols); m.pair_ptr = up(p.pair_ptr); m.slice_elem_ptr = up(p.slice_elem_ptr);
     m.slice_elem_nodes = reinterpret_cast<const int4 *>(up(p.slice_elem_nodes)); m.max_slice_elems = p.max_slice_elems; m.item_ptr = up(p.item_ptr);
     m.items = reinterpret_cast<const uint4 *>(up(p.items)); m.max_stage_rows = p.max_stage_rows;
-    m.lds_bytes = (int)(((size_t)p.max_slice_elems * kRecDoubles + (size_t)p.max_stage_rows * 36) * 8 + (size_t)kOutSlots * 32 * 36 * 8 + 256 + kSpechtTableDoubles * 8);
+    {
+        int32_t max_items = 0;
+        for (int32_t s = 0; s < p.n_slices; s++) max_items = std::max(max_items, p.item_ptr[s + 1] - p.item_ptr[s]);
+        assemble_lds_layout(m, p.max_slice_elems, p.max_stage_rows, max_items);
+    }
     std::vector<uint8_t> dm(p.n_local_nodes(), 0); m.dmask = up(dm);
     std::vector<int32_t> st(1, 0); m.status = up(st);
     double *vals; CK(hipMalloc(&vals, (size_t)p.total_slots() * 36 * 8)); m.vals = vals;
