@@ -24,6 +24,14 @@ struct SliceWalk {
     __device__ __forceinline__ void next() { s += step; }
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding
+// global stores (s_waitcnt vmcnt(0)), which would expose the latency of the K stores of every output pass;
+// nothing in k_assemble reads global memory written by the same launch, so the stores may stay in flight.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // =====================================================================================
 // Assembly: replaces the element loop of assemble_elasticity (fem-shell.cpp:1197-1232).
 // One lane owns one 6x6 block slot of K (slot k of node n of the slice) and sums the
@@ -71,11 +79,27 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         ct0 = __builtin_amdgcn_s_memtime();
     }
     stamp(-1);
-    // software pipeline over slices: the node ids of the next slice's elements are fetched while
-    // the current slice computes, so that a slice exposes one dependent load (the coordinates)
+    // software pipeline over slices, two deep: while slice s computes its blocks, the coordinates of this
+    // lane's element of slice s+1 (node ids fetched one slice earlier) and the node ids of slice s+2 are in
+    // flight, so phase A starts with its operands in registers
+    auto fetch_coords = [&](const int4 &c, double X[9]) {
+        const double *pa = m.xyz + 3 * (int64_t)c.x, *pb = m.xyz + 3 * (int64_t)c.y, *pc = m.xyz + 3 * (int64_t)c.z;
+        X[0] = pa[0]; X[1] = pa[1]; X[2] = pa[2];
+        X[3] = pb[0]; X[4] = pb[1]; X[5] = pb[2];
+        X[6] = pc[0]; X[7] = pc[1]; X[8] = pc[2];
+    };
     int e0 = m.slice_elem_ptr[w.s], ne = m.slice_elem_ptr[w.s + 1] - e0;
     int4 nd = make_int4(0, 0, 0, -1);
     if (tid < ne) nd = m.slice_elem_nodes[e0 + tid];
+    double Xcur[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (!kHasQuads && tid < ne) fetch_coords(nd, Xcur);
+    int e0_n = 0, ne_n = 0; // slice s+1
+    int4 nd_n = make_int4(0, 0, 0, -1);
+    if (w.s + w.step < w.last) {
+        e0_n = m.slice_elem_ptr[w.s + w.step];
+        ne_n = m.slice_elem_ptr[w.s + w.step + 1] - e0_n;
+        if (tid < ne_n) nd_n = m.slice_elem_nodes[e0_n + tid];
+    }
     uint4 item_pre = make_uint4(0, 0, 0, 0);
     {
         const int i2 = m.item_ptr[w.s];
@@ -96,11 +120,12 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
             bool ok = false;
             if (!kHasQuads || c.w < 0) {
                 double X[9];
-                const double *pa = m.xyz + 3 * (int64_t)c.x, *pb = m.xyz + 3 * (int64_t)c.y,
-                             *pc = m.xyz + 3 * (int64_t)c.z;
-                X[0] = pa[0]; X[1] = pa[1]; X[2] = pa[2];
-                X[3] = pb[0]; X[4] = pb[1]; X[5] = pb[2];
-                X[6] = pc[0]; X[7] = pc[1]; X[8] = pc[2];
+                if (!kHasQuads && i == tid) {
+#pragma unroll
+                    for (int q = 0; q < 9; q++) X[q] = Xcur[q];
+                } else {
+                    fetch_coords(c, X);
+                }
                 if (kAblate & 8) {
 #pragma unroll
                     for (int q = 0; q < kRecDoubles; q++) rec[q] = 1.0 + 0.01 * q + X[q % 9] * 1e-9;
@@ -126,19 +151,26 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
             for (int q = 0; q < kRecDoubles / 2; q++) dst[q] = make_double2(rec[2 * q], rec[2 * q + 1]);
         }
         stamp(0); // phase A (coordinate gather + record math + LDS writes)
-        __syncthreads();
+        lds_barrier();
         stamp(1); // barrier after phase A
-        // prefetch the next slice's element node ids and first items now: the loads overlap the block
-        // math below (issued before the barrier above they would be drained by its vmcnt(0))
+        // prefetches that overlap the block math below: coordinates and first items of slice s+1, element node
+        // ids of slice s+2
         uint4 item_next = make_uint4(0, 0, 0, 0);
         {
-            const int s2 = s + w.step;
+            const int s2 = s + w.step, s3 = s2 + w.step;
+            e0 = e0_n;
+            ne = ne_n;
+            nd = nd_n;
+            if (!kHasQuads && tid < ne) fetch_coords(nd, Xcur);
             if (s2 < w.last) {
-                e0 = m.slice_elem_ptr[s2];
-                ne = m.slice_elem_ptr[s2 + 1] - e0;
-                if (tid < ne) nd = m.slice_elem_nodes[e0 + tid];
                 const int i2 = m.item_ptr[s2];
                 if (tid < m.item_ptr[s2 + 1] - i2) item_next = m.items[i2 + tid];
+            }
+            ne_n = 0;
+            if (s3 < w.last) {
+                e0_n = m.slice_elem_ptr[s3];
+                ne_n = m.slice_elem_ptr[s3 + 1] - e0_n;
+                if (tid < ne_n) nd_n = m.slice_elem_nodes[e0_n + tid];
             }
         }
 
@@ -188,7 +220,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
 #pragma unroll
                 for (int i = 0; i < 18; i++) st[i] = make_double2(blk[2 * i], blk[2 * i + 1]);
             }
-            __syncthreads();
+            lds_barrier();
             stamp(3); // staging write + barrier
             if (owner) {
                 // chunks > 0 sort after chunk 0, so with several rounds they may not have run yet:
@@ -227,7 +259,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                         for (int i = 0; i < 6; i++)
                             t[jp * kSliceRows + i] = make_double2(blk[6 * i + 2 * jp], blk[6 * i + 2 * jp + 1]);
                 }
-                __syncthreads();
+                lds_barrier();
                 stamp(5); // tile write + barrier
                 const int nk = min(kOutSlots, W - k0);
                 const int words = nk * 3 * kSliceRows; // double2 words of this pass
@@ -237,7 +269,12 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                     for (int q = tid; q < words; q += blockDim.x) { v.x += lds_tile[q].x; v.y += lds_tile[q].y; }
                     if (v.x == 1.2345e300) dst[0] = v;
                 } else if (!multi) {
-                    for (int q = tid; q < words; q += blockDim.x) dst[q] = lds_tile[q];
+                    for (int q = tid; q < words; q += blockDim.x) {
+                        const double2 v = lds_tile[q];
+                        typedef double v2d __attribute__((ext_vector_type(2)));
+                        v2d vv; vv.x = v.x; vv.y = v.y;
+                        __builtin_nontemporal_store(vv, reinterpret_cast<v2d *>(dst + q));
+                    }
                 } else {
                     for (int q = tid; q < words; q += blockDim.x) {
                         const int kk = k0 + q / (3 * kSliceRows), nn = (q % kSliceRows) / 6;
@@ -245,7 +282,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                     }
                 }
                 stamp(6); // tile read + global stores
-                __syncthreads();
+                lds_barrier();
                 stamp(7); // barrier after the copy-out
             }
         }

@@ -8,7 +8,7 @@
 
 namespace femshell {
 
-constexpr int kOutSlots = 4;               // block slots per output pass of k_assemble (LDS tile = 36,864 B)
+constexpr int kOutSlots = 7;               // block slots per output pass of k_assemble (LDS tile = 64,512 B: one pass for 7-wide slices)
 constexpr int32_t kStatusDirect = 0x40000000; // status values above this carry a local element id directly
 
 // Device view of the mesh + matrix structure of one rank (see plan.hpp for the layout).

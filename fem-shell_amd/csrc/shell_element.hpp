@@ -45,6 +45,7 @@ struct TriFrame {
     double ex[3], ey[3], ez[3]; // rows of trafo
     double xs[3], ys[3];        // coordinate differences, rows (12), (31), (23)
     double area;
+    double inv2a;               // 1 / (2 area)
 };
 
 // SA:318-340, 378-411.  Returns false for a degenerate triangle.
@@ -64,9 +65,10 @@ __device__ __forceinline__ bool tri3_frame(const double X[9], TriFrame &f)
     const double lw2 = W[0] * W[0] + W[1] * W[1] + W[2] * W[2];
     const double lu2 = U[0] * U[0] + U[1] * U[1] + U[2] * U[2];
     if (!(lw2 > 0.0) || !(lu2 > 0.0)) return false;
-    const double lw = sqrt(lw2), lu = sqrt(lu2);
-    f.area = 0.5 * lw;
-    const double iu = 1.0 / lu, iw = 1.0 / lw;
+    // two reciprocal square roots instead of two square roots and two divisions
+    const double iu = rsqrt(lu2), iw = rsqrt(lw2);
+    f.area = 0.5 * lw2 * iw;
+    f.inv2a = iw;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
         f.ex[d] = U[d] * iu;
@@ -138,20 +140,24 @@ __device__ __forceinline__ bool tri3_record(const double X[9], const MatConst &m
     double C[3], mu[3];
 #pragma unroll
     for (int e = 0; e < 3; e++) C[e] = f.xs[e] * f.xs[e] + f.ys[e] * f.ys[e];
-    mu[0] = (C[0] - C[1]) / C[2]; // SA:702-704
-    mu[1] = (C[2] - C[0]) / C[1];
-    mu[2] = (C[1] - C[2]) / C[0];
+    {
+        // SA:702-704: (C0-C1)/C2, (C2-C0)/C1, (C1-C2)/C0 with one division
+        const double c01 = C[0] * C[1], rall = 1.0 / (c01 * C[2]);
+        mu[0] = (C[0] - C[1]) * (c01 * rall);
+        mu[1] = (C[2] - C[0]) * (C[0] * C[2] * rall);
+        mu[2] = (C[1] - C[2]) * (C[1] * C[2] * rall);
+    }
     // Y (SA:578-588) and Dt = Y^T Dp Y (symmetric)
     const double A = f.area;
     const double x31 = f.xs[1], y31 = f.ys[1], x23 = f.xs[2], y23 = f.ys[2];
-    const double sY = 1.0 / (4.0 * A * A);
+    const double sY = f.inv2a * f.inv2a; // 1 / (4 A^2)
     double Y[3][3];
     Y[0][0] = y23 * y23 * sY; Y[0][1] = y31 * y31 * sY; Y[0][2] = y23 * y31 * sY;
     Y[1][0] = x23 * x23 * sY; Y[1][1] = x31 * x31 * sY; Y[1][2] = x31 * x23 * sY;
     Y[2][0] = -2.0 * x23 * y23 * sY;
     Y[2][1] = ((mc.flags & kRefY21) ? -2.0 * x31 * x31 : -2.0 * x31 * y31) * sY;
     Y[2][2] = (-x23 * y31 - x31 * y23) * sY;
-    const double sp = A / 3.0; // 2A * (Gauss weight 1/6), folded into Dt
+    const double sp = A * (1.0 / 3.0); // 2A * (Gauss weight 1/6), folded into Dt
     double DY[3][3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -212,7 +218,7 @@ __device__ __forceinline__ bool tri3_record(const double X[9], const MatConst &m
     rec[kRecCC + 3] = -6.0 * (DC[1][1] + DC[1][2]);
     rec[kRecCC + 4] = -6.0 * (DC[2][1] + DC[2][2]);
     rec[kRecCC + 5] = -6.0 * (DC[2][0] + DC[2][2]);
-    rec[15] = mc.t * mc.cm / (4.0 * A);
+    rec[15] = mc.t * mc.cm * (0.5 * f.inv2a); // t*cm/(4A)
     rec[kRecKind] = 1.0;
     return true;
 }
@@ -269,9 +275,9 @@ __device__ __forceinline__ void tri3_block_add_rec(const double *rec, int ia, in
     // ---- drilling stiffness of this block  (SA:1035-1052)
     double d;
     if (mc.flags & kRefDrillMax) {
-        d = fmax(fmax(fmax(m00, m11), fmax(p[0][0], p[1][1])), p[2][2]) / 1000.0;
+        d = fmax(fmax(fmax(m00, m11), fmax(p[0][0], p[1][1])), p[2][2]) * 1.0e-3;
     } else {
-        d = (ia == ib) ? fmin(fmin(fmin(m00, m11), fmin(p[0][0], p[1][1])), p[2][2]) / 1000.0 : 0.0;
+        d = (ia == ib) ? fmin(fmin(fmin(m00, m11), fmin(p[0][0], p[1][1])), p[2][2]) * 1.0e-3 : 0.0;
     }
 
     // ---- rotation: [T^T A11 T, T^T A12 T; T^T A21 T, T^T A22 T] as outer products of the
@@ -468,9 +474,9 @@ __device__ __forceinline__ void quad4_block_add_rec(const double *rec, int ia, i
 
     double d;
     if (mc.flags & kRefDrillMax) {
-        d = fmax(fmax(fmax(m00, m11), fmax(p[0][0], p[1][1])), p[2][2]) / 1000.0;
+        d = fmax(fmax(fmax(m00, m11), fmax(p[0][0], p[1][1])), p[2][2]) * 1.0e-3;
     } else {
-        d = (ia == ib) ? fmin(fmin(fmin(m00, m11), fmin(p[0][0], p[1][1])), p[2][2]) / 1000.0 : 0.0;
+        d = (ia == ib) ? fmin(fmin(fmin(m00, m11), fmin(p[0][0], p[1][1])), p[2][2]) * 1.0e-3 : 0.0;
     }
     const double ex[3] = {rec[0], rec[1], rec[2]}, ey[3] = {rec[3], rec[4], rec[5]}, ez[3] = {rec[6], rec[7], rec[8]};
 #pragma unroll

@@ -53,6 +53,13 @@ int main(int argc, char **argv)
     printf("nx=%d slices=%d max_elems=%d max_stage=%d items=%zu lds=%d grid=%d\n", nx, p.n_slices, p.max_slice_elems, p.max_stage_rows, p.items.size(), m.lds_bytes, grid);
     const int R = 5;
     printf("W2 full               : %.3f ms\n", run<2, 0>(m, mc, grid, R));
+    printf("W3 full               : %.3f ms\n", run<3, 0>(m, mc, grid, R));
+    printf("W2 no global stores   : %.3f ms\n", run<2, 1>(m, mc, grid, R));
+    printf("W2 no block math      : %.3f ms\n", run<2, 4>(m, mc, grid, R));
+    printf("W2 no record math     : %.3f ms\n", run<2, 8>(m, mc, grid, R));
+    printf("W2 no stores+block    : %.3f ms\n", run<2, 5>(m, mc, grid, R));
+    printf("W2 skeleton (1+4+8)   : %.3f ms\n", run<2, 13>(m, mc, grid, R));
+    printf("W2 no block+record    : %.3f ms\n", run<2, 12>(m, mc, grid, R));
     {
         unsigned long long *st; CK(hipMalloc(&st, (size_t)grid * 4 * 8 * 8 + 16)); CK(hipMemset(st, 0, (size_t)grid * 4 * 8 * 8 + 16));
         m.stamps = st;
