@@ -250,10 +250,21 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
             if (ids.size() > 4095) return fail("more than 4095 elements touch one 32-node slice");
             p.max_slice_elems = std::max<int32_t>(p.max_slice_elems, (int32_t)ids.size());
+            // LDS position of the records: even-ranked elements first, then the odd-ranked ones.  Neighbouring
+            // lanes (neighbouring node rows) gather from neighbouring cells; mesh generators emit the two
+            // triangles of a cell back to back, so in ascending order those records are two apart and a
+            // wave's LDS reads fall on half of the banks; de-interleaved they are adjacent.
+            const int32_t n_even = ((int32_t)ids.size() + 1) / 2;
+            auto lds_pos = [&](int32_t rank) { return (rank & 1) ? n_even + (rank >> 1) : (rank >> 1); };
             for (int32_t q = q0; q < q1; q++) {
                 const int32_t le = (int32_t)(p.pairs[q] >> 4);
-                const int32_t idx = (int32_t)(std::lower_bound(ids.begin(), ids.end(), le) - ids.begin());
+                const int32_t idx = lds_pos((int32_t)(std::lower_bound(ids.begin(), ids.end(), le) - ids.begin()));
                 p.pairs16[q] = (uint16_t)((idx << 4) | (p.pairs[q] & 15u));
+            }
+            {
+                std::vector<int32_t> placed(ids.size());
+                for (size_t r = 0; r < ids.size(); r++) placed[lds_pos((int32_t)r)] = ids[r];
+                ids.swap(placed);
             }
             p.slice_elems.insert(p.slice_elems.end(), ids.begin(), ids.end());
             for (int32_t le : ids) {

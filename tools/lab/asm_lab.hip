@@ -55,6 +55,8 @@ int main(int argc, char **argv)
     printf("W2 full               : %.3f ms\n", run<2, 0>(m, mc, grid, R));
     printf("W3 full               : %.3f ms\n", run<3, 0>(m, mc, grid, R));
     printf("W2 no global stores   : %.3f ms\n", run<2, 1>(m, mc, grid, R));
+    printf("W2 all lanes record 0 : %.3f ms\n", run<2, 2>(m, mc, grid, R));
+    printf("W2 rec0 + no stores   : %.3f ms\n", run<2, 3>(m, mc, grid, R));
     printf("W2 no block math      : %.3f ms\n", run<2, 4>(m, mc, grid, R));
     printf("W2 no record math     : %.3f ms\n", run<2, 8>(m, mc, grid, R));
     printf("W2 no stores+block    : %.3f ms\n", run<2, 5>(m, mc, grid, R));
