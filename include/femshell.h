@@ -150,9 +150,11 @@ typedef enum femshell_kernel {
     FEMSHELL_KERNEL_CG_DIRECTION = 3 /* p = z + beta p */
 } femshell_kernel;
 
-/* launches the kernel `reps` times back to back on the library's stream between two HIP
- * events and returns the mean duration; bytes_out = algorithmic HBM bytes of one launch on
- * this rank (DESIGN.md section "algorithmic bytes").  The state of a solve is not disturbed. */
+/* mean duration of one launch of the kernel from HIP events on the library's stream, over `reps` launches:
+ * the assembly kernel back to back; a CG kernel inside `reps` iterations of the recurrence on scratch vectors
+ * (this rank's rows, no communication), an event pair around that kernel of every iteration -- where it runs,
+ * not back to back with itself.  bytes_out = algorithmic HBM bytes of one launch on this rank (DESIGN.md
+ * section "algorithmic bytes").  The state of a solve is not disturbed. */
 int femshell_time_kernel(femshell_ctx *ctx, femshell_kernel which, int32_t reps, double *mean_ms_out,
                          double *bytes_out);
 
