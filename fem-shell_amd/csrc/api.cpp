@@ -89,7 +89,7 @@ struct femshell_ctx {
     DevBuf<Plan::Item> items;
     DevBuf<uint8_t> dmask;
     // CG state
-    DevBuf<double> x, r, z, p, q, partials, hist, sendbuf, ufull;
+    DevBuf<double> x, r, z, p, q, sv, partials, hist, sendbuf, ufull;
     DevBuf<CgScalars> scal;
     DevBuf<int32_t> send_nodes, spmv_order;
     std::vector<int32_t> send_offsets; // per peer, in nodes
@@ -129,6 +129,8 @@ double bytes_spmv(const femshell_ctx *c)
 }
 double bytes_update(const femshell_ctx *c) { return (7.0 * 48.0 + 288.0) * c->plan.n_own; }
 double bytes_direction(const femshell_ctx *c) { return 3.0 * 48.0 * c->plan.n_own; }
+// single-reduction recurrence: z, w, p, s, x, r read, p, s, x, r, z written, Minv read
+double bytes_update_single_reduction(const femshell_ctx *c) { return (11.0 * 48.0 + 288.0) * c->plan.n_own; }
 
 int check_status(femshell_ctx *c, const char *what)
 {
@@ -228,6 +230,7 @@ CgVectors cg_vectors(femshell_ctx *c)
     v.z = c->z.p;
     v.p = c->p.p;
     v.q = c->q.p;
+    v.sv = c->sv.p;
     v.b = c->F.p;
     v.partials = c->partials.p;
     v.s = c->scal.p;
@@ -253,42 +256,126 @@ int halo_exchange(femshell_ctx *c, double *p, hipStream_t st)
 // halo_stream (pack, grouped send/recv) while the main stream multiplies the slices that read owned
 // columns only; the slices with ghost columns follow once the halo has landed.  Returns the number of
 // partial sums written through *n_partials (0 = slice_grid).
-int spmv_with_halo(femshell_ctx *c, const CgVectors &v, int *n_partials)
+// (xin: input vector with ghost space, yout = K xin, partial sums of xin.yout from partials[0] on)
+int spmv_with_halo(femshell_ctx *c, const CgVectors &v, double *xin, double *yout, double *partials, int *n_partials)
 {
     hipStream_t st = c->stream;
     *n_partials = 0;
     if (!c->halo_overlap) {
-        int rc = halo_exchange(c, v.p, st);
+        int rc = halo_exchange(c, xin, st);
         if (rc) return rc;
-        launch_spmv(c->dm, v.p, v.q, v.partials, v.s, st);
+        launch_spmv(c->dm, xin, yout, partials, v.s, st);
         return FEMSHELL_OK;
     }
     const Plan &pl = c->plan;
     FS_HIP(hipEventRecord(c->ev_p_ready, st));
     FS_HIP(hipStreamWaitEvent(c->halo_stream, c->ev_p_ready, 0));
-    int rc = halo_exchange(c, v.p, c->halo_stream);
+    int rc = halo_exchange(c, xin, c->halo_stream);
     if (rc) return rc;
     FS_HIP(hipEventRecord(c->ev_halo_done, c->halo_stream));
     const int ni = pl.n_interior_slices, nb = pl.n_slices - ni;
-    const int gi = launch_spmv_span(c->dm, v.p, v.q, v.partials, v.s, c->spmv_order.p, 0, ni, 0, st);
+    const int gi = launch_spmv_span(c->dm, xin, yout, partials, v.s, c->spmv_order.p, 0, ni, 0, st);
     FS_HIP(hipStreamWaitEvent(st, c->ev_halo_done, 0));
-    const int gb = launch_spmv_span(c->dm, v.p, v.q, v.partials, v.s, c->spmv_order.p, ni, nb, gi, st);
+    const int gb = launch_spmv_span(c->dm, xin, yout, partials, v.s, c->spmv_order.p, ni, nb, gi, st);
     *n_partials = gi + gb;
     return FEMSHELL_OK;
 }
 
-int scalar_step(femshell_ctx *c, const CgVectors &v, int nsums, CgPhase phase, double rtol, int n_partials = 0)
+// (len3: length of the third partial array when nsums == 3)
+int scalar_step(femshell_ctx *c, const CgVectors &v, int nsums, CgPhase phase, double rtol, int n_partials = 0, int len3 = 0)
 {
     if (c->comm.active()) {
-        launch_cg_scalar(c->dm, v, true, nsums, CG_PHASE_NONE, rtol, c->stream, n_partials);
+        launch_cg_scalar(c->dm, v, true, nsums, CG_PHASE_NONE, rtol, c->stream, n_partials, len3);
         std::string e;
         double *red = reinterpret_cast<double *>(reinterpret_cast<char *>(v.s) + offsetof(CgScalars, red));
         if (!comm_allreduce_sum(c->comm, red, nsums, c->stream, &e)) return set_err(FEMSHELL_ERR_COMM, e);
         launch_cg_scalar(c->dm, v, false, nsums, phase, rtol, c->stream);
     } else {
-        launch_cg_scalar(c->dm, v, true, nsums, phase, rtol, c->stream, n_partials);
+        launch_cg_scalar(c->dm, v, true, nsums, phase, rtol, c->stream, n_partials, len3);
     }
     return FEMSHELL_OK;
+}
+
+// host side of the stopping test: the done flag is fetched at an 8 -> 64 iteration cadence
+struct DonePoll {
+    int32_t next_check = 8, check_step = 8;
+    // returns 1 when the solve has finished (every further kernel would be a no-op), 0 to go on, < 0 on error
+    int operator()(femshell_ctx *c, const CgVectors &v, int32_t it, int32_t max_it, CgScalars *hs)
+    {
+        if (it + 1 != next_check || it + 1 >= max_it) return 0;
+        FS_HIP(hipMemcpyAsync(hs, v.s, sizeof *hs, hipMemcpyDeviceToHost, c->stream));
+        FS_HIP(hipStreamSynchronize(c->stream));
+        if (hs->done != 0) return 1;
+        if (check_step < 64) check_step *= 2;
+        next_check += check_step;
+        return 0;
+    }
+};
+
+// classic preconditioned CG: two reductions per iteration (p.q before the update, r.z and r.r after it); the
+// iterates are those of the oracle's fso_pcg_block_jacobi
+int cg_classic(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it)
+{
+    const DeviceMatrix &m = c->dm;
+    hipStream_t st = c->stream;
+    launch_cg_init(m, v, false, st);
+    int rc = scalar_step(c, v, 2, CG_PHASE_INIT, rtol);
+    if (rc) return rc;
+    CgScalars hs{};
+    DonePoll poll;
+    for (int32_t it = 0; it < max_it; it++) {
+        int n_partials = 0;
+        rc = spmv_with_halo(c, v, v.p, v.q, v.partials, &n_partials);
+        if (rc) return rc;
+        rc = scalar_step(c, v, 1, CG_PHASE_ALPHA, rtol, n_partials);
+        if (rc) return rc;
+        launch_cg_update(m, v, st);
+        rc = scalar_step(c, v, 2, CG_PHASE_BETA, rtol);
+        if (rc) return rc;
+        launch_cg_direction(m, v, st);
+        rc = poll(c, v, it, max_it, &hs);
+        if (rc < 0) return rc;
+        if (rc == 1) break;
+    }
+    return FEMSHELL_OK;
+}
+
+// single-reduction preconditioned CG (Chronopoulos & Gear, SIAM J. Sci. Stat. Comput. 1989): the same Krylov
+// iterates in exact arithmetic, with s = A p carried by recurrence so that r.z, r.r and z.Az are reduced together --
+// one all-reduce of three doubles and one vector kernel per iteration (multi-rank solves)
+int cg_single_reduction(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it)
+{
+    const DeviceMatrix &m = c->dm;
+    hipStream_t st = c->stream;
+    const int G = slice_grid(m);
+    double *spmv_partials = v.partials + 2 * (size_t)G; // third partial array
+    launch_cgcg_init(m, v, st);
+    int len3 = 0;
+    int rc = spmv_with_halo(c, v, v.z, v.q, spmv_partials, &len3);
+    if (rc) return rc;
+    rc = scalar_step(c, v, 3, CG_PHASE_FUSED_INIT, rtol, G, len3 > 0 ? len3 : G);
+    if (rc) return rc;
+    CgScalars hs{};
+    DonePoll poll;
+    for (int32_t it = 0; it < max_it; it++) {
+        launch_cgcg_update(m, v, st);
+        rc = spmv_with_halo(c, v, v.z, v.q, spmv_partials, &len3);
+        if (rc) return rc;
+        rc = scalar_step(c, v, 3, CG_PHASE_FUSED_STEP, rtol, G, len3 > 0 ? len3 : G);
+        if (rc) return rc;
+        rc = poll(c, v, it, max_it, &hs);
+        if (rc < 0) return rc;
+        if (rc == 1) break;
+    }
+    return FEMSHELL_OK;
+}
+
+// multi-rank contexts use the single-reduction recurrence; FEMSHELL_CG_SINGLE_REDUCTION=0/1 overrides
+bool use_single_reduction(const femshell_ctx *c)
+{
+    const char *e = getenv("FEMSHELL_CG_SINGLE_REDUCTION");
+    if (e) return atoi(e) != 0;
+    return c->comm.active();
 }
 
 } // namespace
@@ -413,12 +500,14 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     FS_HIP(c->F.alloc(nrow));
     FS_HIP(c->x.alloc(nrow));
     FS_HIP(c->r.alloc(nrow));
-    FS_HIP(c->z.alloc(nrow));
+    FS_HIP(c->z.alloc(nrow_ext)); // ghost space: the single-reduction recurrence multiplies K by z
+    FS_HIP(c->sv.alloc(nrow));
     FS_HIP(c->q.alloc(nrow));
     FS_HIP(c->p.alloc(nrow_ext));
     FS_HIP(c->x.zero(st));
     FS_HIP(c->p.zero(st));
     FS_HIP(c->q.zero(st));
+    FS_HIP(c->z.zero(st));
     c->dm = DeviceMatrix();
     c->dm.n_own = p.n_own;
     c->dm.n_pad = p.n_pad;
@@ -452,7 +541,7 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     c->dm.vals = c->vals.p;
     c->dm.minv = c->minv.p;
     c->dm.status = c->status.p;
-    FS_HIP(c->partials.alloc(2 * (size_t)slice_grid(c->dm)));
+    FS_HIP(c->partials.alloc(4 * (size_t)slice_grid(c->dm))); // r.z | r.r | the SpMV's dot (up to 2 x grid when split)
     // halo lists
     c->send_offsets.clear();
     std::vector<int32_t> flat;
@@ -567,29 +656,13 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
     const DeviceMatrix &m = c->dm;
 
     FS_HIP(hipEventRecord(c->ev0, st));
-    launch_cg_init(m, v, false, st);
-    rc = scalar_step(c, v, 2, CG_PHASE_INIT, rtol);
+    // a previous solve leaves done = 1 behind; the reduction launch in front of an all-reduce carries no phase and
+    // would skip its work on it (multi-rank re-solves, e.g. every coupling iteration)
+    FS_HIP(c->scal.zero(st));
+    const bool single_reduction = use_single_reduction(c);
+    rc = single_reduction ? cg_single_reduction(c, v, rtol, max_it) : cg_classic(c, v, rtol, max_it);
     if (rc) return rc;
     CgScalars hs{};
-    int32_t next_check = 8, check_step = 8;
-    for (int32_t it = 0; it < max_it; it++) {
-        int n_partials = 0;
-        rc = spmv_with_halo(c, v, &n_partials);
-        if (rc) return rc;
-        rc = scalar_step(c, v, 1, CG_PHASE_ALPHA, rtol, n_partials);
-        if (rc) return rc;
-        launch_cg_update(m, v, st);
-        rc = scalar_step(c, v, 2, CG_PHASE_BETA, rtol);
-        if (rc) return rc;
-        launch_cg_direction(m, v, st);
-        if (it + 1 == next_check && it + 1 < max_it) {
-            FS_HIP(hipMemcpyAsync(&hs, v.s, sizeof hs, hipMemcpyDeviceToHost, st));
-            FS_HIP(hipStreamSynchronize(st));
-            if (hs.done != 0) break; // from here on every kernel would be a no-op
-            if (check_step < 64) check_step *= 2;
-            next_check += check_step;
-        }
-    }
     FS_HIP(hipMemcpyAsync(&hs, v.s, sizeof hs, hipMemcpyDeviceToHost, st));
     FS_HIP(hipStreamSynchronize(st));
     const bool recurrence_converged = hs.done == 1;
@@ -629,7 +702,8 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
         info->assemble_seconds = asm_s;
         info->setup_seconds = setup_s;
         info->solve_seconds = 1e-3 * ms;
-        info->bytes_per_iteration = bytes_spmv(c) + bytes_update(c) + bytes_direction(c);
+        info->bytes_per_iteration = single_reduction ? bytes_spmv(c) + bytes_update_single_reduction(c)
+                                                     : bytes_spmv(c) + bytes_update(c) + bytes_direction(c);
     }
     if (hs.done < 0)
         return set_err(FEMSHELL_ERR_BREAKDOWN, "femshell_solve: CG breakdown, p.Ap <= 0 (matrix not positive definite)");

@@ -447,6 +447,83 @@ void launch_cg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st)
     hipLaunchKernelGGL(k_cg_update, dim3(slice_grid(m)), dim3(192), 0, st, m, v);
 }
 
+// ---- single-reduction recurrence (multi-rank solves): see kernels.hpp
+__global__ __launch_bounds__(192) void k_cgcg_init(DeviceMatrix m, CgVectors v)
+{
+    __shared__ double rs[kSliceRows];
+    __shared__ double sh[3];
+    const int G = gridDim.x, t = threadIdx.x;
+    double d0 = 0.0, d1 = 0.0;
+    for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
+        const int sl = w.s;
+        const int64_t row = (int64_t)sl * kSliceRows + t;
+        const MinvRow mr = load_minv(m, sl, t);
+        const double bv = v.b[row];
+        __syncthreads();
+        rs[t] = bv;
+        __syncthreads();
+        const double z = apply_minv(mr, t, rs);
+        v.x[row] = 0.0;
+        v.r[row] = bv;
+        v.z[row] = z;
+        v.p[row] = 0.0;
+        v.sv[row] = 0.0;
+        d0 += bv * z;
+        d1 += bv * bv;
+    }
+    const double t0 = block_sum(d0, sh);
+    const double t1 = block_sum(d1, sh);
+    if (threadIdx.x == 0) {
+        v.partials[blockIdx.x] = t0;
+        v.partials[G + blockIdx.x] = t1;
+    }
+}
+
+void launch_cgcg_init(const DeviceMatrix &m, const CgVectors &v, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_cgcg_init, dim3(slice_grid(m)), dim3(192), 0, st, m, v);
+}
+
+__global__ __launch_bounds__(192) void k_cgcg_update(DeviceMatrix m, CgVectors v)
+{
+    __shared__ double rs[kSliceRows];
+    __shared__ double sh[3];
+    if (v.s->done != 0) return;
+    const int G = gridDim.x, t = threadIdx.x;
+    const double alpha = v.s->alpha, beta = v.s->beta;
+    double d0 = 0.0, d1 = 0.0;
+    for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
+        const int sl = w.s;
+        const int64_t row = (int64_t)sl * kSliceRows + t;
+        const MinvRow mr = load_minv(m, sl, t);
+        const double uv = v.z[row], wv = v.q[row], pv = v.p[row], sv = v.sv[row], xv = v.x[row], rv = v.r[row];
+        const double pn = uv + beta * pv, sn = wv + beta * sv;
+        v.p[row] = pn;
+        v.sv[row] = sn;
+        v.x[row] = xv + alpha * pn;
+        const double rn = rv - alpha * sn;
+        v.r[row] = rn;
+        __syncthreads();
+        rs[t] = rn;
+        __syncthreads();
+        const double z = apply_minv(mr, t, rs);
+        v.z[row] = z;
+        d0 += rn * z;
+        d1 += rn * rn;
+    }
+    const double t0 = block_sum(d0, sh);
+    const double t1 = block_sum(d1, sh);
+    if (threadIdx.x == 0) {
+        v.partials[blockIdx.x] = t0;
+        v.partials[G + blockIdx.x] = t1;
+    }
+}
+
+void launch_cgcg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_cgcg_update, dim3(slice_grid(m)), dim3(192), 0, st, m, v);
+}
+
 // p = z + beta p over the owned (padded) rows, 16 bytes per lane
 __global__ __launch_bounds__(256) void k_cg_direction(CgVectors v, int64_t n2)
 {
@@ -500,6 +577,38 @@ __device__ __forceinline__ void cg_scalar_phase(const CgVectors &v, int phase, d
         const double pq = s->red[0];
         if (!(pq > 0.0)) s->done = -1;
         else s->alpha = s->rz / pq;
+    } else if (phase == CG_PHASE_FUSED_INIT) {
+        // red = (r.z, r.r = b.b, z.Az) of the initial residual
+        s->rz = s->red[0];
+        s->bb = s->red[1];
+        s->rr = s->red[1];
+        s->tol2 = rtol > 0.0 ? rtol * rtol * s->red[1] : 0.0;
+        s->beta = 0.0;
+        s->alpha = 0.0;
+        s->iters = 0;
+        s->done = (s->red[1] == 0.0) ? 1 : 0;
+        if (s->done == 0) {
+            if (!(s->red[2] > 0.0)) s->done = -1;
+            else s->alpha = s->red[0] / s->red[2];
+        }
+    } else if (phase == CG_PHASE_FUSED_STEP) {
+        // red = (r.z, r.r, z.Az) of the new residual: beta = rz'/rz, alpha = rz' / (z.Az - beta rz'/alpha)
+        const double rzn = s->red[0], rr = s->red[1], zaz = s->red[2];
+        s->rr = rr;
+        const int it = s->iters + 1;
+        s->iters = it;
+        if (v.hist != nullptr && it <= v.hist_cap) v.hist[it - 1] = rr / s->bb;
+        if (rr <= s->tol2) s->done = 1;
+        else {
+            const double beta = rzn / s->rz;
+            const double denom = zaz - beta * rzn / s->alpha;
+            if (!(denom > 0.0)) s->done = -1;
+            else {
+                s->beta = beta;
+                s->alpha = rzn / denom;
+                s->rz = rzn;
+            }
+        }
     } else if (phase == CG_PHASE_BETA) {
         const double rzn = s->red[0], rr = s->red[1];
         s->rr = rr;
@@ -515,19 +624,21 @@ __device__ __forceinline__ void cg_scalar_phase(const CgVectors &v, int phase, d
 }
 
 __global__ __launch_bounds__(256) void k_cg_scalar(CgVectors v, int G, int do_reduce, int nsums, int phase,
-                                                   double rtol)
+                                                   double rtol, int len3)
 {
     __shared__ double sh[4];
     CgScalars *s = v.s;
-    if (phase != CG_PHASE_INIT && phase != CG_PHASE_RESTART && s->done != 0) return; // same decision in every workgroup
+    if (phase != CG_PHASE_INIT && phase != CG_PHASE_RESTART && phase != CG_PHASE_FUSED_INIT && s->done != 0)
+        return; // same decision in every workgroup
     if (!do_reduce) {
         if (blockIdx.x == 0 && threadIdx.x == 0) cg_scalar_phase(v, phase, rtol);
         return;
     }
     const int nwg = gridDim.x;
-    const int chunk = (G + nwg - 1) / nwg;
-    const int lo = blockIdx.x * chunk, hi = min(G, lo + chunk);
     for (int a = 0; a < nsums; a++) {
+        const int len = (a == 2) ? len3 : G; // the third array (single-reduction CG: the SpMV's) has its own length
+        const int chunk = (len + nwg - 1) / nwg;
+        const int lo = blockIdx.x * chunk, hi = min(len, lo + chunk);
         const double *pa = v.partials + (int64_t)a * G;
         double acc = 0.0;
         const int B = blockDim.x;
@@ -558,11 +669,11 @@ __global__ __launch_bounds__(256) void k_cg_scalar(CgVectors v, int G, int do_re
 }
 
 void launch_cg_scalar(const DeviceMatrix &m, const CgVectors &v, bool reduce, int nsums, CgPhase phase,
-                      double rtol, hipStream_t st, int n_partials)
+                      double rtol, hipStream_t st, int n_partials, int len3)
 {
     const int G = n_partials > 0 ? n_partials : slice_grid(m);
     const int groups = reduce ? (G >= 4096 ? kReduceGroups : 1) : 1;
-    hipLaunchKernelGGL(k_cg_scalar, dim3(groups), dim3(256), 0, st, v, G, reduce ? 1 : 0, nsums, (int)phase, rtol);
+    hipLaunchKernelGGL(k_cg_scalar, dim3(groups), dim3(256), 0, st, v, G, reduce ? 1 : 0, nsums, (int)phase, rtol, len3);
 }
 
 __global__ void k_pack(const double *p, const int32_t *nodes, int32_t count, double *buf)

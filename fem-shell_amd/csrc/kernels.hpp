@@ -68,12 +68,12 @@ struct CgScalars {
     double rr;     // r.r
     double bb;     // b.b
     double tol2;   // rtol^2 * b.b
-    double red[2]; // local sums before / global sums after the all-reduce
+    double red[3]; // local sums before / global sums after the all-reduce
     int32_t done;  // 0 running, 1 converged, -1 breakdown
     int32_t iters; // iterations performed
     uint32_t ticket;     // arrival counter of the two-stage reduction (0 between launches)
     uint32_t pad;
-    double stage[2][64]; // stage-1 sums of the reduction workgroups
+    double stage[3][64]; // stage-1 sums of the reduction workgroups
 };
 
 struct CgVectors {
@@ -81,7 +81,8 @@ struct CgVectors {
     double *r = nullptr;  // residual
     double *z = nullptr;  // preconditioned residual
     double *p = nullptr;  // search direction, (n_pad+n_ghost)*6 (ghost part filled by the halo exchange)
-    double *q = nullptr;  // A p
+    double *q = nullptr;  // A p (single-reduction recurrence: w = A z)
+    double *sv = nullptr; // single-reduction recurrence only: s = A p by recurrence
     const double *b = nullptr; // right-hand side
     double *partials = nullptr; // 2 x grid doubles
     CgScalars *s = nullptr;
@@ -89,7 +90,10 @@ struct CgVectors {
     int32_t hist_cap = 0;
 };
 
-enum CgPhase : int { CG_PHASE_NONE = 0, CG_PHASE_INIT = 1, CG_PHASE_ALPHA = 2, CG_PHASE_BETA = 3, CG_PHASE_RESTART = 4 };
+enum CgPhase : int {
+    CG_PHASE_NONE = 0, CG_PHASE_INIT = 1, CG_PHASE_ALPHA = 2, CG_PHASE_BETA = 3, CG_PHASE_RESTART = 4,
+    CG_PHASE_FUSED_INIT = 5, CG_PHASE_FUSED_STEP = 6 // single-reduction (Chronopoulos-Gear) recurrence
+};
 
 int slice_grid(const DeviceMatrix &m); // workgroups of the per-slice kernels (multiple of 8, at most 2560)
 
@@ -118,9 +122,17 @@ void launch_cg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st)
 void launch_cg_direction(const DeviceMatrix &m, const CgVectors &v, hipStream_t st); // p = z + beta p
 // single-workgroup scalar step: optional reduction of `nsums` partial arrays into s->red, then the
 // scalar update of `phase` (rtol only used by CG_PHASE_INIT)
-// (n_partials > 0: length of each partial array, default slice_grid(m))
+// (n_partials > 0: length of each partial array, default slice_grid(m); nsums == 3: the third array, the SpMV's,
+// starts at 2 * n_partials and holds len3 entries)
 void launch_cg_scalar(const DeviceMatrix &m, const CgVectors &v, bool reduce, int nsums, CgPhase phase,
-                      double rtol, hipStream_t st, int n_partials = 0);
+                      double rtol, hipStream_t st, int n_partials = 0, int len3 = 0);
+
+// Single-reduction preconditioned CG (Chronopoulos & Gear): one all-reduce of (r.z, r.r, z.Az) per iteration.
+//   init:   x = 0, r = b, z = M^-1 r, p = s = 0, partial sums of r.z and r.r
+//   update: p = z + beta p, s = w + beta s, x += alpha p, r -= alpha s, z = M^-1 r, partial sums of r.z and r.r
+// with w = A z (v.q) from the SpMV kernel, whose fused dot is z.w
+void launch_cgcg_init(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);
+void launch_cgcg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);
 
 // halo: gather owned entries of p into a contiguous send buffer
 void launch_pack(const double *p, const int32_t *send_nodes, int32_t count, double *sendbuf, hipStream_t st);

@@ -109,7 +109,10 @@ typedef struct femshell_solve_info {
  * build_solution_vector (SA:141; PC:274-280 broadcast): 6x6-block-Jacobi preconditioned CG,
  * x0 = 0, stop at ||r||_2 <= rtol*||b||_2 or max_it.  rtol <= 0 runs exactly max_it iterations.
  * u_out[n_nodes][6] receives the full solution on every rank; NULL leaves it in HBM
- * (fetch with femshell_get_solution).  Assembles first if needed. */
+ * (fetch with femshell_get_solution).  Assembles first if needed.
+ * Contexts with a communicator (femshell_comm_init) run the single-reduction form of the same method
+ * (Chronopoulos & Gear: one all-reduce of r.z, r.r, z.Az per iteration); the iterates agree with the classic
+ * recurrence up to rounding.  FEMSHELL_CG_SINGLE_REDUCTION=0/1 in the environment overrides the choice. */
 int femshell_solve(femshell_ctx *ctx, double rtol, int32_t max_it, double *u_out,
                    femshell_solve_info *info);
 int femshell_get_solution(femshell_ctx *ctx, double *u_out);

@@ -47,8 +47,11 @@ def main():
     fs.set_loads(m.loads)
     u, info = fs.solve(rtol=1e-11, max_it=100000)
     b, e = fs.row_range()
+    # a second solve on the same context with doubled loads (the coupled program re-solves every coupling iteration)
+    fs.set_loads(2.0 * m.loads)
+    u2, info2 = fs.solve(rtol=1e-11, max_it=100000)
     np.savez(out_file, u=u, iterations=info["iterations"], converged=info["converged"], begin=b, end=e,
-             true_res=info["true_rel_residual"])
+             true_res=info["true_rel_residual"], u2=u2, converged2=info2["converged"], iterations2=info2["iterations"])
     fs.close()
 
 

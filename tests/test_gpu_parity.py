@@ -284,6 +284,33 @@ def test_cg_follows_oracle_cg_iteration_by_iteration():
     assert np.linalg.norm(u.ravel() - u0) <= 1e-9 * np.linalg.norm(u0)
 
 
+def test_single_reduction_recurrence_matches_classic_and_oracle(monkeypatch):
+    # the recurrence multi-rank solves use (Chronopoulos-Gear: r.z, r.r, z.Az reduced together), forced on one rank
+    m = meshes.structured(24, 20, 0, 0, 10, 8, kind="t", ul_lr=True, bcids=(0, 0, 0, 0), factor=300.0, loading=2)
+    m.xyz[:, 2] = 0.3 * np.sin(0.5 * m.xyz[:, 0]) * np.cos(0.4 * m.xyz[:, 1])
+    fs = make_ctx(m, 0.3, 1e7, 0.5)
+    u0, info0 = fs.solve(rtol=1e-11, max_it=20000)
+    h0 = fs.residual_history()
+    monkeypatch.setenv("FEMSHELL_CG_SINGLE_REDUCTION", "1")
+    u1, info1 = fs.solve(rtol=1e-11, max_it=20000)
+    h1 = fs.residual_history()
+    monkeypatch.delenv("FEMSHELL_CG_SINGLE_REDUCTION")
+    assert info0["converged"] == 1 and info1["converged"] == 1
+    assert abs(info0["iterations"] - info1["iterations"]) <= 2
+    k = min(len(h0), len(h1), 80)
+    np.testing.assert_allclose(h1[:k], h0[:k], rtol=1e-6)
+    assert np.linalg.norm(u1 - u0) <= 1e-9 * np.linalg.norm(u0)
+    assert 0 <= info1["true_rel_residual"] < 1e-9
+    mat = oracle.material(0.3, 1e7, 0.5)
+    r0, c0, v0, F0 = oracle.assemble(m.xyz, m.tri, m.quad, mat, m.dirichlet_mask(), m.loads)
+    uo, infoo = oracle.pcg(r0, c0, v0, F0, rtol=1e-11, max_it=20000)
+    assert np.linalg.norm(u1.ravel() - uo) <= 1e-8 * np.linalg.norm(uo)
+    # rtol = 0 runs exactly max_it iterations here as well
+    monkeypatch.setenv("FEMSHELL_CG_SINGLE_REDUCTION", "1")
+    _, info2 = fs.solve(rtol=0.0, max_it=37)
+    assert info2["iterations"] == 37 and info2["converged"] == 0
+
+
 def test_fixed_iteration_mode_and_resolve_with_new_loads():
     m = curved_mesh(24, 18)
     fs = make_ctx(m, 0.3, 7.0e4, 0.05)
@@ -347,14 +374,21 @@ def test_solve_through_a_one_rank_rccl_communicator(monkeypatch):
     fs.set_mesh(m.xyz, m.tri, m.quad)
     fs.set_dirichlet(m.dirichlet_mask())
     fs.set_loads(m.loads)
+    # a context with a communicator defaults to the single-reduction recurrence (all-reduce of three sums)
     u, info = fs.solve(rtol=1e-12, max_it=20000)
     assert info["converged"] == 1
     assert u[144, 2] == pytest.approx(1.15169, abs=6e-6)
+    # the classic recurrence through the communicator (all-reduces of one and two sums)
+    monkeypatch.setenv("FEMSHELL_CG_SINGLE_REDUCTION", "0")
+    uc, infoc = fs.solve(rtol=1e-12, max_it=20000)
+    monkeypatch.delenv("FEMSHELL_CG_SINGLE_REDUCTION")
     monkeypatch.delenv("FEMSHELL_FORCE_COMM")
     fs2 = make_ctx(m, 0.3, 10.92, 1.0)
     u2, info2 = fs2.solve(rtol=1e-12, max_it=20000)
-    assert info2["iterations"] == info["iterations"]
-    assert np.array_equal(u, u2)
+    assert infoc["iterations"] == info2["iterations"]
+    assert np.array_equal(uc, u2)  # a one-rank all-reduce changes nothing
+    assert abs(info["iterations"] - info2["iterations"]) <= 3
+    assert np.linalg.norm(u - u2) <= 1e-9 * np.linalg.norm(u2)
 
 
 # ------------------------------------------------------------------ error behaviour

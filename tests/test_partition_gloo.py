@@ -1,8 +1,10 @@
 """N>1 path on CPU: two (and three) gloo ranks run the row-partitioned block-Jacobi CG with
-exactly the communication pattern of the device driver (api.cpp: halo exchange of p before every
-SpMV following the plan's peer lists, one all-reduce for p.Ap, one for (r.z, r.r)); the local
-matrices come from each rank's plan (gather lists) with the oracle's element arithmetic.  The
-partitioned solve must reproduce the single-process oracle solve."""
+exactly the communication pattern of the device driver (api.cpp): halo exchange of the SpMV input
+following the plan's peer lists before every SpMV, and either the classic recurrence (one all-reduce
+for p.Ap, one for (r.z, r.r)) or the single-reduction recurrence multi-rank device solves default to
+(one all-reduce of (r.z, r.r, z.Az)); the local matrices come from each rank's plan (gather lists)
+with the oracle's element arithmetic.  The partitioned solve must reproduce the single-process
+oracle solve."""
 import os
 import sys
 import tempfile
@@ -22,7 +24,7 @@ def problem():
     return m, (0.3, 3.0e4, 0.1)
 
 
-def _rank_main(rank, world, init_file, out_dir):
+def _rank_main(rank, world, init_file, out_dir, single_reduction):
     import torch
     import torch.distributed as dist
 
@@ -79,13 +81,44 @@ def _rank_main(rank, world, init_file, out_dir):
         dist.all_reduce(tt)
         return tt.tolist()
 
+    def precond(v):
+        return np.einsum("aij,aj->ai", minv, v.reshape(-1, 6)).ravel()
+
     x = np.zeros(6 * n_own)
     r = b.copy()
-    z = np.einsum("aij,aj->ai", minv, r.reshape(-1, 6)).ravel()
+    its = 0
+    if single_reduction:
+        # api.cpp cg_single_reduction: z carries the ghost entries, s = A p by recurrence
+        z_ext = np.zeros(6 * (n_pad + n_ghost))
+        z_ext[:6 * n_own] = precond(r)
+        p = np.zeros(6 * n_own)
+        s = np.zeros(6 * n_own)
+        halo(z_ext)
+        w = spmv(z_ext)
+        rz, bb, zaz = allsum(r @ z_ext[:6 * n_own], b @ b, z_ext[:6 * n_own] @ w)
+        alpha, beta = rz / zaz, 0.0
+        for its in range(1, 20001):
+            p = z_ext[:6 * n_own] + beta * p
+            s = w + beta * s
+            x += alpha * p
+            r -= alpha * s
+            z_ext[:6 * n_own] = precond(r)
+            halo(z_ext)
+            w = spmv(z_ext)
+            rz_new, rr, zaz = allsum(r @ z_ext[:6 * n_own], r @ r, z_ext[:6 * n_own] @ w)
+            if rr <= 1e-24 * bb:
+                break
+            beta = rz_new / rz
+            alpha = rz_new / (zaz - beta * rz_new / alpha)
+            rz = rz_new
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x=x, begin=plan["row_begin"], end=plan["row_end"], its=its)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    z = precond(r)
     p_ext = np.zeros(6 * (n_pad + n_ghost))
     p_ext[:6 * n_own] = z
     rz, bb = allsum(r @ z, b @ b)
-    its = 0
     for its in range(1, 20001):
         halo(p_ext)
         q = spmv(p_ext)
@@ -104,8 +137,8 @@ def _rank_main(rank, world, init_file, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_row_partitioned_cg_matches_single_process(world):
+@pytest.mark.parametrize("world,single_reduction", [(2, False), (3, False), (2, True), (3, True)])
+def test_row_partitioned_cg_matches_single_process(world, single_reduction):
     import torch.multiprocessing as mp
 
     m, (nu, E, t) = problem()
@@ -115,7 +148,7 @@ def test_row_partitioned_cg_matches_single_process(world):
     _, info = oracle.pcg(r0, c0, v0, F0, rtol=1e-12, max_it=20000)
     with tempfile.TemporaryDirectory() as d:
         init_file = os.path.join(d, "rendezvous")
-        mp.spawn(_rank_main, args=(world, init_file, d), nprocs=world, join=True)
+        mp.spawn(_rank_main, args=(world, init_file, d, single_reduction), nprocs=world, join=True)
         u = np.zeros(6 * m.n_nodes)
         its = []
         for r in range(world):
