@@ -45,7 +45,7 @@ __device__ __forceinline__ void lds_barrier()
 // touching the node.
 // =====================================================================================
 // kAblate (profiling builds only, 0 in the product): 1 = skip global stores, 2 = every lane reads
-// record 0, 4 = skip the block math, 8 = skip the record math, 16 = skip the LDS tile transposition
+// record 0, 4 = skip the block math, 8 = skip the record math, 32 = s_memtime stamps at the phase boundaries
 // kHasQuads = false compiles the QUAD4 code out (meshes of triangles only: every BASELINE config)
 template <int kWavesPerSimd, int kAblate = 0, bool kHasQuads = false>
 __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m, MatConst mc)

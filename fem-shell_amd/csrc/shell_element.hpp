@@ -11,9 +11,9 @@
 //   plate (Specht), node block 3x3   calcPlate + evalBTri      SA:555-603, 698-891
 //   drilling stiffness               constructStiffnessMatrix  SA:1035-1052
 //   rotation to global axes          localToGlobalTrafo        SA:1084-1102
-// The arithmetic is reorganised (closed-form CST blocks, Specht curvatures from the
-// tabulated Gauss-point values of specht_tables.h, rotation as outer products of the frame
-// axes); results agree with the reference's formulation to rounding.
+// The arithmetic is reorganised (closed-form CST blocks; Specht plate blocks from element-level Gram tables
+// over the tabulated Gauss-point curvatures of specht_tables.h, see tri3_record; rotation as outer products
+// of the frame axes); results agree with the reference's formulation to rounding.
 #pragma once
 
 #include <hip/hip_runtime.h>
