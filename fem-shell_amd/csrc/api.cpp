@@ -87,6 +87,7 @@ struct femshell_ctx {
     DevBuf<int64_t> slice_base;
     DevBuf<int32_t> slice_elem_ptr, slice_elem_nodes, item_ptr;
     DevBuf<Plan::Item> items;
+    DevBuf<uint32_t> item_flags;
     DevBuf<uint8_t> dmask;
     // CG state
     DevBuf<double> x, r, z, p, q, sv, partials, hist, sendbuf, ufull;
@@ -175,6 +176,8 @@ int upload_node_data(femshell_ctx *c)
     FS_HIP(c->loads.upload(ld, c->stream));
     FS_HIP(hipStreamSynchronize(c->stream)); // host vectors go out of scope
     c->dm.dmask = c->dmask.p;
+    launch_item_flags(c->dm, (int64_t)p.items.size(), c->stream); // the Dirichlet set may have changed
+    FS_HIP(hipGetLastError());
     return FEMSHELL_OK;
 }
 
@@ -527,6 +530,8 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     c->dm.max_slice_elems = p.max_slice_elems;
     c->dm.item_ptr = c->item_ptr.p;
     c->dm.items = reinterpret_cast<const uint4 *>(c->items.p);
+    FS_HIP(c->item_flags.alloc(p.items.size()));
+    c->dm.item_flags = c->item_flags.p;
     c->dm.max_stage_rows = p.max_stage_rows;
     {
         // LDS of k_assemble: output tile (kOutSlots block slots x 32 nodes x 288 B per pass) +

@@ -101,9 +101,13 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         if (tid < ne_n) nd_n = m.slice_elem_nodes[e0_n + tid];
     }
     uint4 item_pre = make_uint4(0, 0, 0, 0);
+    uint32_t flags_pre = 0u;
     {
         const int i2 = m.item_ptr[w.s];
-        if (tid < m.item_ptr[w.s + 1] - i2) item_pre = m.items[i2 + tid];
+        if (tid < m.item_ptr[w.s + 1] - i2) {
+            item_pre = m.items[i2 + tid];
+            flags_pre = m.item_flags[i2 + tid];
+        }
     }
 
     for (; w.valid(); w.next()) {
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         const int W = m.slice_width[s];
         const int i0 = m.item_ptr[s], ni = m.item_ptr[s + 1] - i0;
         uint4 item = item_pre; // fetched during the previous slice's block math
+        uint32_t flags = flags_pre;
 
         // ---- phase A: one record per element touching the slice
         for (int i = tid; i < ne; i += blockDim.x) {
@@ -156,6 +161,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         // prefetches that overlap the block math below: coordinates and first items of slice s+1, element node
         // ids of slice s+2
         uint4 item_next = make_uint4(0, 0, 0, 0);
+        uint32_t flags_next = 0u;
         {
             const int s2 = s + w.step, s3 = s2 + w.step;
             e0 = e0_n;
@@ -164,7 +170,10 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
             if (!kHasQuads && tid < ne) fetch_coords(nd, Xcur);
             if (s2 < w.last) {
                 const int i2 = m.item_ptr[s2];
-                if (tid < m.item_ptr[s2 + 1] - i2) item_next = m.items[i2 + tid];
+                if (tid < m.item_ptr[s2 + 1] - i2) {
+                    item_next = m.items[i2 + tid];
+                    flags_next = m.item_flags[i2 + tid];
+                }
             }
             ne_n = 0;
             if (s3 < w.last) {
@@ -184,7 +193,11 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
             const bool live = it < ni;
             if (r0 > 0) {
                 item = make_uint4(0, 0, 0, 0);
-                if (live) item = m.items[i0 + it];
+                flags = 0u;
+                if (live) {
+                    item = m.items[i0 + it];
+                    flags = m.item_flags[i0 + it];
+                }
             }
             if (multi && tid < 64) lds_mask[tid] = 0u;
             const int slot_in_slice = (int)(item.x & 0xffffu), chunk = (int)((item.x >> 16) & 0xffu),
@@ -204,16 +217,12 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                 }
             }
             const bool owner = live && chunk == 0 && nchunks > 0; // nchunks == 0: padding item
-            // column node and Dirichlet masks of the slot (needed after the reduction)
-            int col = 0, valence = 0;
-            uint32_t mrow = 0, mcol = 0;
-            if (owner) {
-                const int64_t slot = base + slot_in_slice;
-                col = m.cols[slot];
-                mrow = m.dmask[s * kSliceNodes + (slot_in_slice & 31)];
-                mcol = m.dmask[col];
-                valence = m.pair_ptr[slot + 1] - m.pair_ptr[slot];
-            }
+            // Dirichlet masks of the slot's row and column node, contributions in the slot, diagonal slot or
+            // not: the item's constraint word (no global load in this phase: vmcnt retires in order, so waiting
+            // for one would also wait for the previous slice's K stores)
+            const uint32_t mrow = flags & 63u, mcol = (flags >> 6) & 63u;
+            const int valence = (int)((flags >> 12) & 255u);
+            const bool diag_slot = (flags >> 20) & 1u;
             stamp(2); // item decode + block math
             if (live && chunk > 0) {
                 double2 *st = reinterpret_cast<double2 *>(lds_stage + (size_t)item.w * 36);
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
 #pragma unroll
                         for (int j = 0; j < 6; j++)
                             if (((mrow >> i) & 1u) | ((mcol >> j) & 1u)) blk[6 * i + j] = 0.0;
-                    if (col == s * kSliceNodes + (slot_in_slice & 31)) {
+                    if (diag_slot) {
 #pragma unroll
                         for (int i = 0; i < 6; i++)
                             if ((mrow >> i) & 1u) blk[7 * i] = (double)valence;
@@ -287,6 +296,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
             }
         }
         item_pre = item_next;
+        flags_pre = flags_next;
     }
     if (kAblate & 32) {
         if ((tid & 63) == 0) {

@@ -84,6 +84,35 @@ void launch_assemble(const DeviceMatrix &m, const MatConst &mc, hipStream_t st)
     }
 }
 
+// Constraint word of every assembly work item (DeviceMatrix::item_flags): the assembly kernel fetches it together
+// with the item, one slice ahead, instead of chasing cols -> dmask[col] in its block phase.
+__global__ __launch_bounds__(256) void k_item_flags(DeviceMatrix m)
+{
+    for (int s = blockIdx.x; s < m.n_slices; s += gridDim.x) {
+        const int64_t base = m.slice_base[s];
+        const int i0 = m.item_ptr[s], ni = m.item_ptr[s + 1] - i0;
+        for (int it = threadIdx.x; it < ni; it += blockDim.x) {
+            const uint32_t x = m.items[i0 + it].x;
+            const int slot_in_slice = (int)(x & 0xffffu), chunk = (int)((x >> 16) & 0xffu), nchunks = (int)(x >> 24);
+            uint32_t f = 0u;
+            if (chunk == 0 && nchunks > 0) {
+                const int64_t slot = base + slot_in_slice;
+                const int row = s * kSliceNodes + (slot_in_slice & 31), col = m.cols[slot];
+                const uint32_t valence = (uint32_t)(m.pair_ptr[slot + 1] - m.pair_ptr[slot]);
+                f = (uint32_t)m.dmask[row] | ((uint32_t)m.dmask[col] << 6) | ((valence < 255u ? valence : 255u) << 12) |
+                    (col == row ? 1u << 20 : 0u);
+            }
+            m.item_flags[i0 + it] = f;
+        }
+    }
+}
+
+void launch_item_flags(const DeviceMatrix &m, int64_t n_items, hipStream_t st)
+{
+    if (n_items == 0 || m.n_slices == 0) return;
+    hipLaunchKernelGGL(k_item_flags, dim3(m.n_slices < 8192 ? m.n_slices : 8192), dim3(256), 0, st, m);
+}
+
 // Right-hand side: contribRHS (fem-shell.cpp:1118-1153) is a masked copy -- every node's load
 // enters once, fixed dofs get 0 (fem-shell.cpp:1227).
 __global__ void k_rhs(DeviceMatrix m, const double *loads, double *F)

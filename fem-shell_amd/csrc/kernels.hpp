@@ -27,6 +27,10 @@ struct DeviceMatrix {
     int32_t max_slice_elems = 0;
     const int32_t *item_ptr = nullptr;       // n_slices+1
     const uint4 *items = nullptr;            // assembly work items (plan.hpp)
+    uint32_t *item_flags = nullptr;          // per item: what its owner lane needs to know about the slot besides the
+                                             // contributions (k_item_flags): Dirichlet mask of the row node (bits 0-5)
+                                             // and of the column node (6-11), contributions in the slot (12-19), bit 20
+                                             // = diagonal slot; 0 for items that do not own their slot
     int32_t max_stage_rows = 0;
     int32_t lds_bytes = 0;                   // dynamic LDS of k_assemble (assemble_lds_layout)
     int32_t lds_tile_off = 0, lds_rec_off = 0, lds_stage_off = 0; // offsets in doubles
@@ -99,6 +103,8 @@ int slice_grid(const DeviceMatrix &m); // workgroups of the per-slice kernels (m
 
 void launch_assemble(const DeviceMatrix &m, const MatConst &mc, hipStream_t st);
 void launch_rhs(const DeviceMatrix &m, const double *loads /* n_pad x 6 */, double *F, hipStream_t st);
+// fills m.item_flags from cols / dmask / pair_ptr (after every change of the Dirichlet set)
+void launch_item_flags(const DeviceMatrix &m, int64_t n_items, hipStream_t st);
 void launch_block_jacobi(const DeviceMatrix &m, hipStream_t st);
 void launch_element_matrices(const DeviceMatrix &m, const MatConst &mc, int32_t first, int32_t count,
                              double *Ke_out, hipStream_t st);

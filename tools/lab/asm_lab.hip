@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <type_traits>
 #include "assemble_kernel.hpp"
 using namespace femshell;
 
@@ -46,6 +47,7 @@ int main(int argc, char **argv)
         assemble_lds_layout(m, p.max_slice_elems, p.max_stage_rows, max_items);
     }
     std::vector<uint8_t> dm(p.n_local_nodes(), 0); m.dmask = up(dm);
+    std::vector<uint32_t> fl(p.items.size(), 0u); m.item_flags = up(fl); // no Dirichlet nodes in the lab mesh
     std::vector<int32_t> st(1, 0); m.status = up(st);
     double *vals; CK(hipMalloc(&vals, (size_t)p.total_slots() * 36 * 8)); m.vals = vals;
     MatConst mc; const double nu = 0.3, E = 1e7, t = 0.5;
@@ -62,10 +64,11 @@ int main(int argc, char **argv)
     printf("W2 no stores+block    : %.3f ms\n", run<2, 5>(m, mc, grid, R));
     printf("W2 skeleton (1+4+8)   : %.3f ms\n", run<2, 13>(m, mc, grid, R));
     printf("W2 no block+record    : %.3f ms\n", run<2, 12>(m, mc, grid, R));
-    {
+    auto stamps = [&](auto tag, const char *title) {
+        constexpr int F = decltype(tag)::value;
         unsigned long long *st; CK(hipMalloc(&st, (size_t)grid * 4 * 8 * 8 + 16)); CK(hipMemset(st, 0, (size_t)grid * 4 * 8 * 8 + 16));
         m.stamps = st;
-        const float ms = run<2, 32>(m, mc, grid, 1); // every launch overwrites the stamp array: one launch's data
+        const float ms = run<2, F>(m, mc, grid, 1); // every launch overwrites the stamp array: one launch's data
         std::vector<unsigned long long> h((size_t)grid * 4 * 8);
         CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
         const char *names[8] = {"phase A (gather+record+LDS)", "barrier after A", "item decode + block math", "staging + barrier",
@@ -74,8 +77,11 @@ int main(int argc, char **argv)
         for (size_t w_ = 0; w_ < (size_t)grid * 4; w_++) for (int q = 0; q < 8; q++) { tot[q] += (double)h[w_ * 8 + q]; all += (double)h[w_ * 8 + q]; }
         unsigned long long clk[2]; CK(hipMemcpy(clk, st + (size_t)grid * 32, 16, hipMemcpyDeviceToHost));
         printf("in-kernel clock: %llu shader cycles per %llu ticks of 100 MHz -> %.3f GHz\n", clk[0], clk[1], 0.1 * (double)clk[0] / (double)clk[1]);
-        printf("stamped build: %.3f ms per launch; share of wave cycles per phase:\n", ms);
+        printf("%s: %.3f ms per launch; share of wave cycles per phase:\n", title, ms);
         for (int q = 0; q < 8; q++) printf("  %-32s %5.1f %%   (%.0f cycles per wave per slice)\n", names[q], 100.0 * tot[q] / all, tot[q] / ((double)p.n_slices * 4));
-    }
+    };
+    stamps(std::integral_constant<int, 32>(), "stamped build");
+    stamps(std::integral_constant<int, 32 + 13>(), "stamped skeleton (no stores, no block math, no record math)");
+    stamps(std::integral_constant<int, 32 + 1>(), "stamped, no global stores");
     return 0;
 }
