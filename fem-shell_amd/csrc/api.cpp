@@ -85,7 +85,7 @@ struct femshell_ctx {
     DevBuf<double> xyz, vals, minv, loads, F;
     DevBuf<int32_t> tri, quad, slice_width, cols, pair_ptr, status;
     DevBuf<int64_t> slice_base;
-    DevBuf<int32_t> slice_elem_ptr, slice_elem_nodes, item_ptr;
+    DevBuf<int32_t> slice_elem_ptr, slice_elem_nodes, item_ptr, slice_desc;
     DevBuf<Plan::Item> items;
     DevBuf<uint32_t> item_flags;
     DevBuf<uint8_t> dmask;
@@ -496,6 +496,7 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     FS_HIP(c->slice_elem_ptr.upload(p.slice_elem_ptr, st));
     FS_HIP(c->slice_elem_nodes.upload(p.slice_elem_nodes, st));
     FS_HIP(c->item_ptr.upload(p.item_ptr, st));
+    FS_HIP(c->slice_desc.upload(p.slice_desc, st));
     FS_HIP(c->items.upload(p.items, st));
     const size_t nrow = (size_t)p.n_pad * 6, nrow_ext = (size_t)p.n_local_nodes() * 6;
     FS_HIP(c->vals.alloc((size_t)p.total_slots() * 36));
@@ -529,6 +530,7 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     c->dm.slice_elem_nodes = reinterpret_cast<const int4 *>(c->slice_elem_nodes.p);
     c->dm.max_slice_elems = p.max_slice_elems;
     c->dm.item_ptr = c->item_ptr.p;
+    c->dm.slice_desc = reinterpret_cast<const int4 *>(c->slice_desc.p);
     c->dm.items = reinterpret_cast<const uint4 *>(c->items.p);
     FS_HIP(c->item_flags.alloc(p.items.size()));
     c->dm.item_flags = c->item_flags.p;

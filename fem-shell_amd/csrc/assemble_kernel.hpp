@@ -88,33 +88,43 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         X[3] = pb[0]; X[4] = pb[1]; X[5] = pb[2];
         X[6] = pc[0]; X[7] = pc[1]; X[8] = pc[2];
     };
-    int e0 = m.slice_elem_ptr[w.s], ne = m.slice_elem_ptr[w.s + 1] - e0;
+    // The bookkeeping of a slice (element range, item range, slot base, width) is one 32-byte descriptor, fetched
+    // with scalar loads three slices ahead, so that no phase waits for a scalar round trip either.
+    struct Desc {
+        int e0, ne, i0, ni;
+        int64_t base;
+        int W;
+    };
+    auto load_desc = [&](int s_) {
+        Desc d = {0, 0, 0, 0, 0, 0};
+        if (s_ < w.last) {
+            const int4 a = m.slice_desc[2 * s_], b = m.slice_desc[2 * s_ + 1];
+            d.e0 = a.x; d.ne = a.y; d.i0 = a.z; d.ni = a.w;
+            d.base = (int64_t)(((uint64_t)(uint32_t)b.y << 32) | (uint32_t)b.x);
+            d.W = b.z;
+        }
+        return d;
+    };
+    Desc d0 = load_desc(w.s), d1 = load_desc(w.s + w.step), d2 = load_desc(w.s + 2 * w.step);
+    int e0 = d0.e0, ne = d0.ne;
     int4 nd = make_int4(0, 0, 0, -1);
     if (tid < ne) nd = m.slice_elem_nodes[e0 + tid];
     double Xcur[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (!kHasQuads && tid < ne) fetch_coords(nd, Xcur);
-    int e0_n = 0, ne_n = 0; // slice s+1
-    int4 nd_n = make_int4(0, 0, 0, -1);
-    if (w.s + w.step < w.last) {
-        e0_n = m.slice_elem_ptr[w.s + w.step];
-        ne_n = m.slice_elem_ptr[w.s + w.step + 1] - e0_n;
-        if (tid < ne_n) nd_n = m.slice_elem_nodes[e0_n + tid];
-    }
+    int4 nd_n = make_int4(0, 0, 0, -1); // slice s+1
+    if (tid < d1.ne) nd_n = m.slice_elem_nodes[d1.e0 + tid];
     uint4 item_pre = make_uint4(0, 0, 0, 0);
     uint32_t flags_pre = 0u;
-    {
-        const int i2 = m.item_ptr[w.s];
-        if (tid < m.item_ptr[w.s + 1] - i2) {
-            item_pre = m.items[i2 + tid];
-            flags_pre = m.item_flags[i2 + tid];
-        }
+    if (tid < d0.ni) {
+        item_pre = m.items[d0.i0 + tid];
+        flags_pre = m.item_flags[d0.i0 + tid];
     }
 
     for (; w.valid(); w.next()) {
         const int s = w.s;
-        const int64_t base = m.slice_base[s];
-        const int W = m.slice_width[s];
-        const int i0 = m.item_ptr[s], ni = m.item_ptr[s + 1] - i0;
+        const int64_t base = d0.base;
+        const int W = d0.W;
+        const int i0 = d0.i0, ni = d0.ni;
         uint4 item = item_pre; // fetched during the previous slice's block math
         uint32_t flags = flags_pre;
 
@@ -159,29 +169,19 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         lds_barrier();
         stamp(1); // barrier after phase A
         // prefetches that overlap the block math below: coordinates and first items of slice s+1, element node
-        // ids of slice s+2
+        // ids of slice s+2, descriptor of slice s+3
         uint4 item_next = make_uint4(0, 0, 0, 0);
         uint32_t flags_next = 0u;
-        {
-            const int s2 = s + w.step, s3 = s2 + w.step;
-            e0 = e0_n;
-            ne = ne_n;
-            nd = nd_n;
-            if (!kHasQuads && tid < ne) fetch_coords(nd, Xcur);
-            if (s2 < w.last) {
-                const int i2 = m.item_ptr[s2];
-                if (tid < m.item_ptr[s2 + 1] - i2) {
-                    item_next = m.items[i2 + tid];
-                    flags_next = m.item_flags[i2 + tid];
-                }
-            }
-            ne_n = 0;
-            if (s3 < w.last) {
-                e0_n = m.slice_elem_ptr[s3];
-                ne_n = m.slice_elem_ptr[s3 + 1] - e0_n;
-                if (tid < ne_n) nd_n = m.slice_elem_nodes[e0_n + tid];
-            }
+        const Desc d3 = load_desc(s + 3 * w.step);
+        e0 = d1.e0;
+        ne = d1.ne;
+        nd = nd_n;
+        if (!kHasQuads && tid < ne) fetch_coords(nd, Xcur);
+        if (tid < d1.ni) {
+            item_next = m.items[d1.i0 + tid];
+            flags_next = m.item_flags[d1.i0 + tid];
         }
+        if (tid < d2.ne) nd_n = m.slice_elem_nodes[d2.e0 + tid];
 
         // ---- phase B: one lane per work item (at most kItemPairs element contributions), in
         //      rounds of 256 items; each round's finished blocks leave through the LDS tile so
@@ -297,6 +297,9 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         }
         item_pre = item_next;
         flags_pre = flags_next;
+        d0 = d1;
+        d1 = d2;
+        d2 = d3;
     }
     if (kAblate & 32) {
         if ((tid & 63) == 0) {

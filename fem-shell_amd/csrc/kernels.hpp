@@ -23,6 +23,8 @@ struct DeviceMatrix {
     const int32_t *cols = nullptr;      // per slot
     const int32_t *pair_ptr = nullptr;  // per slot + 1
     const int32_t *slice_elem_ptr = nullptr; // n_slices+1
+    const int4 *slice_desc = nullptr;        // 2 per slice: {elem begin, elem count, item begin, item count},
+                                             // {slot base lo, hi, width, 0} -- what k_assemble needs of a slice
     const int4 *slice_elem_nodes = nullptr;  // per slice element: its local node ids (w = -1 for TRI3)
     int32_t max_slice_elems = 0;
     const int32_t *item_ptr = nullptr;       // n_slices+1

@@ -339,6 +339,18 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             p.item_ptr[s + 1] = (int32_t)p.items.size();
         }
     }
+    // ---- per-slice descriptors of the assembly kernel
+    p.slice_desc.assign((size_t)p.n_slices * 8, 0);
+    for (int32_t s = 0; s < p.n_slices; s++) {
+        int32_t *d = &p.slice_desc[(size_t)s * 8];
+        d[0] = p.slice_elem_ptr[s];
+        d[1] = p.slice_elem_ptr[s + 1] - p.slice_elem_ptr[s];
+        d[2] = p.item_ptr[s];
+        d[3] = p.item_ptr[s + 1] - p.item_ptr[s];
+        d[4] = (int32_t)(uint32_t)((uint64_t)p.slice_base[s] & 0xffffffffu);
+        d[5] = (int32_t)(uint32_t)((uint64_t)p.slice_base[s] >> 32);
+        d[6] = p.slice_width[s];
+    }
 
     // ---- halo exchange lists
     if (world > 1) {

@@ -76,6 +76,7 @@ struct Plan {
     //       the slot's other chunks (chunk 0)
     struct Item { uint32_t x, y, z, w; };
     std::vector<int32_t> item_ptr; // n_slices+1
+    std::vector<int32_t> slice_desc; // 8 per slice: elem begin, elem count, item begin, item count, slot base lo, hi, width, 0
     std::vector<Item> items;
     int32_t max_stage_rows = 0;    // staging rows (36 doubles each) a slice needs at most
     int32_t max_slice_width = 0;

@@ -40,6 +40,7 @@ int main(int argc, char **argv)
     m.xyz = up(p.xyz_local); m.tri = up(p.tri_local); m.slice_width = up(p.slice_width); m.slice_base = up(p.slice_base);
     m.cols = up(p.cols); m.pair_ptr = up(p.pair_ptr); m.slice_elem_ptr = up(p.slice_elem_ptr);
     m.slice_elem_nodes = reinterpret_cast<const int4 *>(up(p.slice_elem_nodes)); m.max_slice_elems = p.max_slice_elems; m.item_ptr = up(p.item_ptr);
+    m.slice_desc = reinterpret_cast<const int4 *>(up(p.slice_desc));
     m.items = reinterpret_cast<const uint4 *>(up(p.items)); m.max_stage_rows = p.max_stage_rows;
     {
         int32_t max_items = 0;
