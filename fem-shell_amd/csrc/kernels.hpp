@@ -8,7 +8,10 @@
 
 namespace femshell {
 
-constexpr int kOutSlots = 7;               // block slots per output pass of k_assemble (LDS tile = 64,512 B: one pass for 7-wide slices)
+#ifndef FEMSHELL_OUT_SLOTS
+#define FEMSHELL_OUT_SLOTS 7
+#endif
+constexpr int kOutSlots = FEMSHELL_OUT_SLOTS;               // block slots per output pass of k_assemble (LDS tile = 64,512 B: one pass for 7-wide slices)
 constexpr int32_t kStatusDirect = 0x40000000; // status values above this carry a local element id directly
 
 // Device view of the mesh + matrix structure of one rank (see plan.hpp for the layout).
