@@ -1,0 +1,55 @@
+"""Randomised matrix parity sweep on the GPU (one-off stress run, slower than the test suite):
+random Delaunay and structured meshes, tri / quad / mixed, random Dirichlet sets and behaviour flags, sorted and
+shuffled node numbering; the assembled K and F must equal the oracle's (1e-12 relative to max |K|), and after a
+change of the Dirichlet set on the same context as well.   python tools/stress_parity.py [cases] [seed]"""
+import importlib, sys
+import numpy as np
+sys.path.insert(0, '.')
+from tests.helpers import meshes, oracle
+from tests.test_gpu_parity import delaunay_shell
+pkg = importlib.import_module("fem-shell_amd")
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+worst = 0.0
+for case in range(cases):
+    kind = rng.choice(["delaunay", "tri", "quad", "mixed"])
+    if kind == "delaunay":
+        xyz, tri = delaunay_shell(int(rng.integers(60, 6000)), int(rng.integers(1, 1 << 30)))
+        quad = np.zeros((0, 4), np.int32)
+        if rng.random() < 0.5:  # sort along x: narrow slices; otherwise keep the shuffled numbering
+            order = np.argsort(xyz[:, 0]); inv = np.empty_like(order); inv[order] = np.arange(len(order))
+            xyz, tri = xyz[order], inv[tri].astype(np.int32)
+    else:
+        nx, ny = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+        m = meshes.structured(nx, ny, 0, 0, float(rng.uniform(0.5, 9)), float(rng.uniform(0.5, 9)),
+                              kind="t" if kind == "tri" else "q", ul_lr=bool(rng.integers(0, 2)))
+        xyz, tri, quad = m.xyz.copy(), m.tri.copy(), m.quad.copy()
+        xyz[:, 2] = (0.0 if kind != "tri" else 0.2 * np.sin(xyz[:, 0]) * np.cos(0.7 * xyz[:, 1]))
+        if kind == "mixed" and len(quad):  # split a random half of the quads into triangles
+            pick = rng.random(len(quad)) < 0.5
+            q = quad[pick]
+            tri = np.concatenate([tri.reshape(-1, 3), q[:, [0, 1, 2]], q[:, [0, 2, 3]]]).astype(np.int32)
+            quad = quad[~pick]
+        if kind != "tri":  # planar quads, tilted rigidly
+            qm, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+            xyz = xyz @ qm.T
+    n = len(xyz)
+    flags = int(rng.integers(0, 4))
+    nu, E, t = float(rng.uniform(0.0, 0.45)), float(10 ** rng.uniform(1, 8)), float(10 ** rng.uniform(-2, 0.3))
+    fs = pkg.FemShell(nu, E, t, flags=flags)
+    fs.set_mesh(xyz, tri, quad)
+    mat = oracle.material(nu, E, t, flags)
+    for rep in range(2):
+        dmask = np.where(rng.random(n) < rng.uniform(0, 0.3), rng.integers(1, 64, n), 0).astype(np.uint8)
+        loads = rng.normal(size=(n, 6))
+        fs.set_dirichlet(dmask); fs.set_loads(loads); fs.assemble()
+        rg, cg, vg, Fg = fs.export_bsr()
+        r0, c0, v0, F0 = oracle.assemble(xyz, tri, quad, mat, dmask, loads)
+        assert np.array_equal(rg, r0) and np.array_equal(cg, c0), (case, kind)
+        err = np.abs(vg - v0).max() / np.abs(v0).max()
+        worst = max(worst, err)
+        assert err <= 1e-12, (case, kind, err)
+        assert np.array_equal(Fg, F0), (case, kind)
+    fs.close()
+    print("case %3d %-9s nodes %6d tri %6d quad %5d flags %d  ok" % (case, kind, n, len(tri), len(quad), flags), flush=True)
+print("all %d cases equal to the oracle; worst relative difference %.2e" % (cases, worst))
