@@ -1,27 +1,21 @@
-// api.cpp -- the C ABI of libfemshell (include/femshell.h): context, host<->HBM plumbing and
-// the CG driver.  All arithmetic of the hot path runs in the kernels of kernels.hip; there
-// is no CPU fallback anywhere in this library.
-#include "femshell.h"
-
-#include <hip/hip_runtime.h>
+// api.cpp -- the C ABI of libfemshell (include/femshell.h): context, host<->HBM plumbing, measurement hooks.
+// The CG driver is cg_driver.cpp, the plan inspection entry points plan_api.cpp.  All arithmetic of the hot path
+// runs in the kernels of kernels.hip; there is no CPU fallback anywhere in this library.
+#include "context.hpp"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <string>
-#include <vector>
-
-#include "comm.hpp"
-#include "kernels.hpp"
-#include "plan.hpp"
 
 using namespace femshell;
 
-namespace {
+namespace femshell {
 
+namespace {
 thread_local std::string g_err;
+}
 
 int set_err(int code, const std::string &msg)
 {
@@ -29,83 +23,9 @@ int set_err(int code, const std::string &msg)
     return code;
 }
 
-#define FS_HIP(call)                                                                                   \
-    do {                                                                                               \
-        hipError_t e_ = (call);                                                                        \
-        if (e_ != hipSuccess)                                                                          \
-            return set_err(FEMSHELL_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));       \
-    } while (0)
+const std::string &last_err() { return g_err; }
 
-template <class T> struct DevBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    ~DevBuf() { release(); }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        n = 0;
-    }
-    hipError_t alloc(size_t count)
-    {
-        if (count == n && p) return hipSuccess;
-        release();
-        if (count == 0) return hipSuccess;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
-        if (e == hipSuccess) n = count;
-        return e;
-    }
-    hipError_t upload(const std::vector<T> &h, hipStream_t st)
-    {
-        hipError_t e = alloc(h.size());
-        if (e != hipSuccess || h.empty()) return e;
-        return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st);
-    }
-    hipError_t zero(hipStream_t st) { return n ? hipMemsetAsync(p, 0, n * sizeof(T), st) : hipSuccess; }
-};
-
-} // namespace
-
-struct femshell_ctx {
-    femshell_config cfg{};
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // halo exchange beside the interior SpMV (multi-rank contexts): second stream + hand-off events
-    hipStream_t halo_stream = nullptr;
-    hipEvent_t ev_p_ready = nullptr, ev_halo_done = nullptr;
-    bool halo_overlap = false;
-    MatConst mc{};
-    Plan plan;
-    bool have_mesh = false, matrix_valid = false, rhs_valid = false, jacobi_valid = false, have_solution = false;
-
-    std::vector<uint8_t> dmask_global;  // n_nodes
-    std::vector<double> loads_global;   // n_nodes*6
-
-    DevBuf<double> xyz, vals, minv, loads, F;
-    DevBuf<int32_t> tri, quad, slice_width, cols, pair_ptr, status;
-    DevBuf<int64_t> slice_base;
-    DevBuf<int32_t> slice_elem_ptr, slice_elem_nodes, item_ptr, slice_desc;
-    DevBuf<Plan::Item> items;
-    DevBuf<uint32_t> item_flags;
-    DevBuf<uint8_t> dmask;
-    // CG state
-    DevBuf<double> x, r, z, p, q, sv, partials, hist, sendbuf, ufull;
-    DevBuf<CgScalars> scal;
-    DevBuf<int32_t> send_nodes, spmv_order;
-    std::vector<int32_t> send_offsets; // per peer, in nodes
-    // scratch for femshell_time_kernel
-    DevBuf<double> bx, br, bz, bp, bq, bpart;
-    DevBuf<CgScalars> bscal;
-
-    DeviceMatrix dm{};
-    Comm comm;
-    std::vector<int32_t> all_begin, all_end;
-
-    double last_assemble_s = 0.0, last_setup_s = 0.0;
-    std::vector<double> hist_host;
-    int32_t last_iters = 0;
-};
+} // namespace femshell
 
 namespace {
 
@@ -225,6 +145,10 @@ int do_jacobi(femshell_ctx *c)
     return FEMSHELL_OK;
 }
 
+} // namespace
+
+namespace femshell {
+
 CgVectors cg_vectors(femshell_ctx *c)
 {
     CgVectors v;
@@ -242,152 +166,13 @@ CgVectors cg_vectors(femshell_ctx *c)
     return v;
 }
 
-int halo_exchange(femshell_ctx *c, double *p, hipStream_t st)
-{
-    if (!c->comm.active() || c->plan.peers.empty()) return FEMSHELL_OK;
-    const Plan &pl = c->plan;
-    for (size_t i = 0; i < pl.peers.size(); i++)
-        launch_pack(p, c->send_nodes.p + c->send_offsets[i], (int32_t)pl.peers[i].send_nodes.size(),
-                    c->sendbuf.p + 6ll * c->send_offsets[i], st);
-    std::string e;
-    if (!comm_halo(c->comm, pl.peers, c->send_offsets, c->sendbuf.p, p + 6ll * pl.n_pad, st, &e))
-        return set_err(FEMSHELL_ERR_COMM, e);
-    return FEMSHELL_OK;
-}
-
-// q = K p with the fused p.q partial sums.  Multi-rank contexts: the ghost entries of p travel on
-// halo_stream (pack, grouped send/recv) while the main stream multiplies the slices that read owned
-// columns only; the slices with ghost columns follow once the halo has landed.  Returns the number of
-// partial sums written through *n_partials (0 = slice_grid).
-// (xin: input vector with ghost space, yout = K xin, partial sums of xin.yout from partials[0] on)
-int spmv_with_halo(femshell_ctx *c, const CgVectors &v, double *xin, double *yout, double *partials, int *n_partials)
-{
-    hipStream_t st = c->stream;
-    *n_partials = 0;
-    if (!c->halo_overlap) {
-        int rc = halo_exchange(c, xin, st);
-        if (rc) return rc;
-        launch_spmv(c->dm, xin, yout, partials, v.s, st);
-        return FEMSHELL_OK;
-    }
-    const Plan &pl = c->plan;
-    FS_HIP(hipEventRecord(c->ev_p_ready, st));
-    FS_HIP(hipStreamWaitEvent(c->halo_stream, c->ev_p_ready, 0));
-    int rc = halo_exchange(c, xin, c->halo_stream);
-    if (rc) return rc;
-    FS_HIP(hipEventRecord(c->ev_halo_done, c->halo_stream));
-    const int ni = pl.n_interior_slices, nb = pl.n_slices - ni;
-    const int gi = launch_spmv_span(c->dm, xin, yout, partials, v.s, c->spmv_order.p, 0, ni, 0, st);
-    FS_HIP(hipStreamWaitEvent(st, c->ev_halo_done, 0));
-    const int gb = launch_spmv_span(c->dm, xin, yout, partials, v.s, c->spmv_order.p, ni, nb, gi, st);
-    *n_partials = gi + gb;
-    return FEMSHELL_OK;
-}
-
-// (len3: length of the third partial array when nsums == 3)
-int scalar_step(femshell_ctx *c, const CgVectors &v, int nsums, CgPhase phase, double rtol, int n_partials = 0, int len3 = 0)
-{
-    if (c->comm.active()) {
-        launch_cg_scalar(c->dm, v, true, nsums, CG_PHASE_NONE, rtol, c->stream, n_partials, len3);
-        std::string e;
-        double *red = reinterpret_cast<double *>(reinterpret_cast<char *>(v.s) + offsetof(CgScalars, red));
-        if (!comm_allreduce_sum(c->comm, red, nsums, c->stream, &e)) return set_err(FEMSHELL_ERR_COMM, e);
-        launch_cg_scalar(c->dm, v, false, nsums, phase, rtol, c->stream);
-    } else {
-        launch_cg_scalar(c->dm, v, true, nsums, phase, rtol, c->stream, n_partials, len3);
-    }
-    return FEMSHELL_OK;
-}
-
-// host side of the stopping test: the done flag is fetched at an 8 -> 64 iteration cadence
-struct DonePoll {
-    int32_t next_check = 8, check_step = 8;
-    // returns 1 when the solve has finished (every further kernel would be a no-op), 0 to go on, < 0 on error
-    int operator()(femshell_ctx *c, const CgVectors &v, int32_t it, int32_t max_it, CgScalars *hs)
-    {
-        if (it + 1 != next_check || it + 1 >= max_it) return 0;
-        FS_HIP(hipMemcpyAsync(hs, v.s, sizeof *hs, hipMemcpyDeviceToHost, c->stream));
-        FS_HIP(hipStreamSynchronize(c->stream));
-        if (hs->done != 0) return 1;
-        if (check_step < 64) check_step *= 2;
-        next_check += check_step;
-        return 0;
-    }
-};
-
-// classic preconditioned CG: two reductions per iteration (p.q before the update, r.z and r.r after it); the
-// iterates are those of the oracle's fso_pcg_block_jacobi
-int cg_classic(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it)
-{
-    const DeviceMatrix &m = c->dm;
-    hipStream_t st = c->stream;
-    launch_cg_init(m, v, false, st);
-    int rc = scalar_step(c, v, 2, CG_PHASE_INIT, rtol);
-    if (rc) return rc;
-    CgScalars hs{};
-    DonePoll poll;
-    for (int32_t it = 0; it < max_it; it++) {
-        int n_partials = 0;
-        rc = spmv_with_halo(c, v, v.p, v.q, v.partials, &n_partials);
-        if (rc) return rc;
-        rc = scalar_step(c, v, 1, CG_PHASE_ALPHA, rtol, n_partials);
-        if (rc) return rc;
-        launch_cg_update(m, v, st);
-        rc = scalar_step(c, v, 2, CG_PHASE_BETA, rtol);
-        if (rc) return rc;
-        launch_cg_direction(m, v, st);
-        rc = poll(c, v, it, max_it, &hs);
-        if (rc < 0) return rc;
-        if (rc == 1) break;
-    }
-    return FEMSHELL_OK;
-}
-
-// single-reduction preconditioned CG (Chronopoulos & Gear, SIAM J. Sci. Stat. Comput. 1989): the same Krylov
-// iterates in exact arithmetic, with s = A p carried by recurrence so that r.z, r.r and z.Az are reduced together --
-// one all-reduce of three doubles and one vector kernel per iteration (multi-rank solves)
-int cg_single_reduction(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it)
-{
-    const DeviceMatrix &m = c->dm;
-    hipStream_t st = c->stream;
-    const int G = slice_grid(m);
-    double *spmv_partials = v.partials + 2 * (size_t)G; // third partial array
-    launch_cgcg_init(m, v, st);
-    int len3 = 0;
-    int rc = spmv_with_halo(c, v, v.z, v.q, spmv_partials, &len3);
-    if (rc) return rc;
-    rc = scalar_step(c, v, 3, CG_PHASE_FUSED_INIT, rtol, G, len3 > 0 ? len3 : G);
-    if (rc) return rc;
-    CgScalars hs{};
-    DonePoll poll;
-    for (int32_t it = 0; it < max_it; it++) {
-        launch_cgcg_update(m, v, st);
-        rc = spmv_with_halo(c, v, v.z, v.q, spmv_partials, &len3);
-        if (rc) return rc;
-        rc = scalar_step(c, v, 3, CG_PHASE_FUSED_STEP, rtol, G, len3 > 0 ? len3 : G);
-        if (rc) return rc;
-        rc = poll(c, v, it, max_it, &hs);
-        if (rc < 0) return rc;
-        if (rc == 1) break;
-    }
-    return FEMSHELL_OK;
-}
-
-// multi-rank contexts use the single-reduction recurrence; FEMSHELL_CG_SINGLE_REDUCTION=0/1 overrides
-bool use_single_reduction(const femshell_ctx *c)
-{
-    const char *e = getenv("FEMSHELL_CG_SINGLE_REDUCTION");
-    if (e) return atoi(e) != 0;
-    return c->comm.active();
-}
-
-} // namespace
+} // namespace femshell
 
 // =========================================================================================
 
 extern "C" {
 
-const char *femshell_last_error(void) { return g_err.c_str(); }
+const char *femshell_last_error(void) { return last_err().c_str(); }
 
 int femshell_create(const femshell_config *cfg, femshell_ctx **out)
 {
@@ -936,98 +721,6 @@ int femshell_sync(femshell_ctx *c)
     if (rc) return rc;
     FS_HIP(hipStreamSynchronize(c->stream));
     return FEMSHELL_OK;
-}
-
-} // extern "C"
-
-// =========================================================================================
-// host-only plan inspection (include/femshell_plan.h); touches no GPU state
-// =========================================================================================
-#include "femshell_plan.h"
-
-struct femshell_plan {
-    Plan p;
-};
-
-extern "C" {
-
-int femshell_plan_create(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri, int32_t n_quad,
-                         const int32_t *quad, int32_t rank, int32_t world_size, femshell_plan **out)
-{
-    if (!out || !xyz) return set_err(FEMSHELL_ERR_INVALID, "femshell_plan_create: null argument");
-    *out = nullptr;
-    femshell_plan *pl = new femshell_plan();
-    std::string e;
-    if (!build_plan(n_nodes, xyz, n_tri, tri, n_quad, quad, rank, world_size, &pl->p, &e)) {
-        delete pl;
-        return set_err(FEMSHELL_ERR_MESH, "femshell_plan_create: " + e);
-    }
-    *out = pl;
-    return FEMSHELL_OK;
-}
-
-void femshell_plan_destroy(femshell_plan *plan) { delete plan; }
-
-int femshell_plan_info(const femshell_plan *plan, int64_t *info)
-{
-    if (!plan || !info) return set_err(FEMSHELL_ERR_INVALID, "femshell_plan_info: null argument");
-    const Plan &p = plan->p;
-    info[FEMSHELL_PLAN_N_OWN] = p.n_own;
-    info[FEMSHELL_PLAN_N_PAD] = p.n_pad;
-    info[FEMSHELL_PLAN_N_GHOST] = p.n_ghost;
-    info[FEMSHELL_PLAN_N_SLICES] = p.n_slices;
-    info[FEMSHELL_PLAN_N_LTRI] = p.n_ltri();
-    info[FEMSHELL_PLAN_N_LQUAD] = p.n_lquad();
-    info[FEMSHELL_PLAN_TOTAL_SLOTS] = p.total_slots();
-    info[FEMSHELL_PLAN_N_PAIRS] = (int64_t)p.pairs.size();
-    info[FEMSHELL_PLAN_N_PEERS] = (int64_t)p.peers.size();
-    info[FEMSHELL_PLAN_ROW_BEGIN] = p.row_begin;
-    info[FEMSHELL_PLAN_ROW_END] = p.row_end;
-    info[FEMSHELL_PLAN_NNZ_BLOCKS] = p.nnz_blocks;
-    info[FEMSHELL_PLAN_N_INTERIOR_SLICES] = p.n_interior_slices;
-    return FEMSHELL_OK;
-}
-
-int64_t femshell_plan_array(const femshell_plan *plan, int which, void *out)
-{
-    if (!plan) return -1;
-    const Plan &p = plan->p;
-    auto give = [&](const auto &v) -> int64_t {
-        if (out && !v.empty()) std::memcpy(out, v.data(), v.size() * sizeof(v[0]));
-        return (int64_t)v.size();
-    };
-    std::vector<int32_t> tmp;
-    switch (which) {
-    case FEMSHELL_PLAN_GHOST_GLOBAL: return give(p.ghost_global);
-    case FEMSHELL_PLAN_TRI_LOCAL: return give(p.tri_local);
-    case FEMSHELL_PLAN_TRI_GLOBAL_ID: return give(p.tri_global_id);
-    case FEMSHELL_PLAN_QUAD_LOCAL: return give(p.quad_local);
-    case FEMSHELL_PLAN_QUAD_GLOBAL_ID: return give(p.quad_global_id);
-    case FEMSHELL_PLAN_SLICE_WIDTH: return give(p.slice_width);
-    case FEMSHELL_PLAN_SLICE_BASE: return give(p.slice_base);
-    case FEMSHELL_PLAN_COLS: return give(p.cols);
-    case FEMSHELL_PLAN_PAIR_PTR: return give(p.pair_ptr);
-    case FEMSHELL_PLAN_PAIRS: return give(p.pairs);
-    case FEMSHELL_PLAN_XYZ_LOCAL: return give(p.xyz_local);
-    case FEMSHELL_PLAN_SPMV_ORDER: return give(p.spmv_order);
-    case FEMSHELL_PLAN_PEER_RANKS:
-        for (auto &h : p.peers) tmp.push_back(h.rank);
-        return give(tmp);
-    case FEMSHELL_PLAN_PEER_RECV_OFFSET:
-        for (auto &h : p.peers) tmp.push_back(h.recv_offset);
-        return give(tmp);
-    case FEMSHELL_PLAN_PEER_RECV_COUNT:
-        for (auto &h : p.peers) tmp.push_back(h.recv_count);
-        return give(tmp);
-    case FEMSHELL_PLAN_PEER_SEND_PTR:
-        tmp.push_back(0);
-        for (auto &h : p.peers) tmp.push_back(tmp.back() + (int32_t)h.send_nodes.size());
-        return give(tmp);
-    case FEMSHELL_PLAN_PEER_SEND_NODES:
-        for (auto &h : p.peers) tmp.insert(tmp.end(), h.send_nodes.begin(), h.send_nodes.end());
-        return give(tmp);
-    default: return -1;
-    }
 }
 
 } // extern "C"

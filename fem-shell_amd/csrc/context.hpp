@@ -1,0 +1,113 @@
+// context.hpp -- what the translation units of libfemshell share: error reporting, device buffers, the context
+// behind a femshell_ctx handle and the CG driver's entry points (cg_driver.cpp).
+#pragma once
+
+#include "femshell.h"
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "comm.hpp"
+#include "kernels.hpp"
+#include "plan.hpp"
+
+namespace femshell {
+
+// records the message femshell_last_error() returns on the calling thread and passes `code` through
+int set_err(int code, const std::string &msg);
+const std::string &last_err();
+
+#define FS_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return set_err(FEMSHELL_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count)
+    {
+        if (count == n && p) return hipSuccess;
+        release();
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t upload(const std::vector<T> &h, hipStream_t st)
+    {
+        hipError_t e = alloc(h.size());
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st);
+    }
+    hipError_t zero(hipStream_t st) { return n ? hipMemsetAsync(p, 0, n * sizeof(T), st) : hipSuccess; }
+};
+
+} // namespace femshell
+
+struct femshell_ctx {
+    // (global namespace: the opaque type of include/femshell.h)
+    femshell_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // halo exchange beside the interior SpMV (multi-rank contexts): second stream + hand-off events
+    hipStream_t halo_stream = nullptr;
+    hipEvent_t ev_p_ready = nullptr, ev_halo_done = nullptr;
+    bool halo_overlap = false;
+    femshell::MatConst mc{};
+    femshell::Plan plan;
+    bool have_mesh = false, matrix_valid = false, rhs_valid = false, jacobi_valid = false, have_solution = false;
+
+    std::vector<uint8_t> dmask_global;  // n_nodes
+    std::vector<double> loads_global;   // n_nodes*6
+
+    femshell::DevBuf<double> xyz, vals, minv, loads, F;
+    femshell::DevBuf<int32_t> tri, quad, slice_width, cols, pair_ptr, status;
+    femshell::DevBuf<int64_t> slice_base;
+    femshell::DevBuf<int32_t> slice_elem_ptr, slice_elem_nodes, item_ptr, slice_desc;
+    femshell::DevBuf<femshell::Plan::Item> items;
+    femshell::DevBuf<uint32_t> item_flags;
+    femshell::DevBuf<uint8_t> dmask;
+    // CG state
+    femshell::DevBuf<double> x, r, z, p, q, sv, partials, hist, sendbuf, ufull;
+    femshell::DevBuf<femshell::CgScalars> scal;
+    femshell::DevBuf<int32_t> send_nodes, spmv_order;
+    std::vector<int32_t> send_offsets; // per peer, in nodes
+    // scratch for femshell_time_kernel
+    femshell::DevBuf<double> bx, br, bz, bp, bq, bpart;
+    femshell::DevBuf<femshell::CgScalars> bscal;
+
+    femshell::DeviceMatrix dm{};
+    femshell::Comm comm;
+    std::vector<int32_t> all_begin, all_end;
+
+    double last_assemble_s = 0.0, last_setup_s = 0.0;
+    std::vector<double> hist_host;
+    int32_t last_iters = 0;
+};
+
+namespace femshell {
+
+CgVectors cg_vectors(femshell_ctx *c);
+// pack + grouped send/recv of the ghost entries of vec (owned | padding | ghosts) on stream st
+int halo_exchange(femshell_ctx *c, double *vec, hipStream_t st);
+// the two recurrences (cg_driver.cpp); the CG state is left in the context's vectors and scalars
+int cg_classic(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it);
+int cg_single_reduction(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it);
+bool use_single_reduction(const femshell_ctx *c);
+// reduction of the partial sums [+ all-reduce on contexts with a communicator] + scalar step
+int scalar_step(femshell_ctx *c, const CgVectors &v, int nsums, CgPhase phase, double rtol, int n_partials = 0, int len3 = 0);
+
+} // namespace femshell

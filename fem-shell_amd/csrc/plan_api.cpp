@@ -1,0 +1,97 @@
+// plan_api.cpp -- host-only inspection of the symbolic phase (include/femshell_plan.h); touches no GPU state.
+#include "femshell_plan.h"
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "context.hpp"
+
+using namespace femshell;
+
+struct femshell_plan {
+    Plan p;
+};
+
+extern "C" {
+
+int femshell_plan_create(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri, int32_t n_quad,
+                         const int32_t *quad, int32_t rank, int32_t world_size, femshell_plan **out)
+{
+    if (!out || !xyz) return set_err(FEMSHELL_ERR_INVALID, "femshell_plan_create: null argument");
+    *out = nullptr;
+    femshell_plan *pl = new femshell_plan();
+    std::string e;
+    if (!build_plan(n_nodes, xyz, n_tri, tri, n_quad, quad, rank, world_size, &pl->p, &e)) {
+        delete pl;
+        return set_err(FEMSHELL_ERR_MESH, "femshell_plan_create: " + e);
+    }
+    *out = pl;
+    return FEMSHELL_OK;
+}
+
+void femshell_plan_destroy(femshell_plan *plan) { delete plan; }
+
+int femshell_plan_info(const femshell_plan *plan, int64_t *info)
+{
+    if (!plan || !info) return set_err(FEMSHELL_ERR_INVALID, "femshell_plan_info: null argument");
+    const Plan &p = plan->p;
+    info[FEMSHELL_PLAN_N_OWN] = p.n_own;
+    info[FEMSHELL_PLAN_N_PAD] = p.n_pad;
+    info[FEMSHELL_PLAN_N_GHOST] = p.n_ghost;
+    info[FEMSHELL_PLAN_N_SLICES] = p.n_slices;
+    info[FEMSHELL_PLAN_N_LTRI] = p.n_ltri();
+    info[FEMSHELL_PLAN_N_LQUAD] = p.n_lquad();
+    info[FEMSHELL_PLAN_TOTAL_SLOTS] = p.total_slots();
+    info[FEMSHELL_PLAN_N_PAIRS] = (int64_t)p.pairs.size();
+    info[FEMSHELL_PLAN_N_PEERS] = (int64_t)p.peers.size();
+    info[FEMSHELL_PLAN_ROW_BEGIN] = p.row_begin;
+    info[FEMSHELL_PLAN_ROW_END] = p.row_end;
+    info[FEMSHELL_PLAN_NNZ_BLOCKS] = p.nnz_blocks;
+    info[FEMSHELL_PLAN_N_INTERIOR_SLICES] = p.n_interior_slices;
+    return FEMSHELL_OK;
+}
+
+int64_t femshell_plan_array(const femshell_plan *plan, int which, void *out)
+{
+    if (!plan) return -1;
+    const Plan &p = plan->p;
+    auto give = [&](const auto &v) -> int64_t {
+        if (out && !v.empty()) std::memcpy(out, v.data(), v.size() * sizeof(v[0]));
+        return (int64_t)v.size();
+    };
+    std::vector<int32_t> tmp;
+    switch (which) {
+    case FEMSHELL_PLAN_GHOST_GLOBAL: return give(p.ghost_global);
+    case FEMSHELL_PLAN_TRI_LOCAL: return give(p.tri_local);
+    case FEMSHELL_PLAN_TRI_GLOBAL_ID: return give(p.tri_global_id);
+    case FEMSHELL_PLAN_QUAD_LOCAL: return give(p.quad_local);
+    case FEMSHELL_PLAN_QUAD_GLOBAL_ID: return give(p.quad_global_id);
+    case FEMSHELL_PLAN_SLICE_WIDTH: return give(p.slice_width);
+    case FEMSHELL_PLAN_SLICE_BASE: return give(p.slice_base);
+    case FEMSHELL_PLAN_COLS: return give(p.cols);
+    case FEMSHELL_PLAN_PAIR_PTR: return give(p.pair_ptr);
+    case FEMSHELL_PLAN_PAIRS: return give(p.pairs);
+    case FEMSHELL_PLAN_XYZ_LOCAL: return give(p.xyz_local);
+    case FEMSHELL_PLAN_SPMV_ORDER: return give(p.spmv_order);
+    case FEMSHELL_PLAN_PEER_RANKS:
+        for (auto &h : p.peers) tmp.push_back(h.rank);
+        return give(tmp);
+    case FEMSHELL_PLAN_PEER_RECV_OFFSET:
+        for (auto &h : p.peers) tmp.push_back(h.recv_offset);
+        return give(tmp);
+    case FEMSHELL_PLAN_PEER_RECV_COUNT:
+        for (auto &h : p.peers) tmp.push_back(h.recv_count);
+        return give(tmp);
+    case FEMSHELL_PLAN_PEER_SEND_PTR:
+        tmp.push_back(0);
+        for (auto &h : p.peers) tmp.push_back(tmp.back() + (int32_t)h.send_nodes.size());
+        return give(tmp);
+    case FEMSHELL_PLAN_PEER_SEND_NODES:
+        for (auto &h : p.peers) tmp.insert(tmp.end(), h.send_nodes.begin(), h.send_nodes.end());
+        return give(tmp);
+    default: return -1;
+    }
+}
+
+} // extern "C"

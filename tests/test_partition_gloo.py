@@ -1,5 +1,5 @@
 """N>1 path on CPU: two (and three) gloo ranks run the row-partitioned block-Jacobi CG with
-exactly the communication pattern of the device driver (api.cpp): halo exchange of the SpMV input
+exactly the communication pattern of the device driver (cg_driver.cpp): halo exchange of the SpMV input
 following the plan's peer lists before every SpMV, and either the classic recurrence (one all-reduce
 for p.Ap, one for (r.z, r.r)) or the single-reduction recurrence multi-rank device solves default to
 (one all-reduce of (r.z, r.r, z.Az)); the local matrices come from each rank's plan (gather lists)
@@ -88,7 +88,7 @@ def _rank_main(rank, world, init_file, out_dir, single_reduction):
     r = b.copy()
     its = 0
     if single_reduction:
-        # api.cpp cg_single_reduction: z carries the ghost entries, s = A p by recurrence
+        # cg_driver.cpp cg_single_reduction: z carries the ghost entries, s = A p by recurrence
         z_ext = np.zeros(6 * (n_pad + n_ghost))
         z_ext[:6 * n_own] = precond(r)
         p = np.zeros(6 * n_own)
