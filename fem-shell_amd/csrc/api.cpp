@@ -107,8 +107,9 @@ int do_assemble(femshell_ctx *c)
     int rc = select_device(c);
     if (rc) return rc;
     FS_HIP(hipEventRecord(c->ev0, c->stream));
-    launch_assemble(c->dm, c->mc, c->stream);
-    launch_rhs(c->dm, c->loads.p, c->F.p, c->stream);
+    c->dm.rhs_loads = c->loads.p;
+    c->dm.rhs_F = c->F.p;
+    launch_assemble(c->dm, c->mc, c->stream); // K and F (k_rhs alone serves changes of the loads)
     FS_HIP(hipEventRecord(c->ev1, c->stream));
     FS_HIP(hipGetLastError());
     rc = check_status(c, "femshell_assemble");

@@ -113,6 +113,17 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
     if (!kHasQuads && tid < ne) fetch_coords(nd, Xcur);
     int4 nd_n = make_int4(0, 0, 0, -1); // slice s+1
     if (tid < d1.ne) nd_n = m.slice_elem_nodes[d1.e0 + tid];
+    // right-hand side of the slice (contribRHS, fem-shell.cpp:1118-1153: a masked copy of the nodal loads): loaded
+    // one slice ahead in front of the coordinate prefetch, stored where phase A waits for the coordinates anyway
+    double rhs_pre = 0.0;
+    uint32_t rhs_mask = 0u;
+    auto fetch_rhs = [&](int s_) {
+        if (m.rhs_F != nullptr && s_ < w.last && tid < kSliceRows) {
+            rhs_pre = m.rhs_loads[(int64_t)s_ * kSliceRows + tid];
+            rhs_mask = m.dmask[s_ * kSliceNodes + tid / 6];
+        }
+    };
+    fetch_rhs(w.s);
     uint4 item_pre = make_uint4(0, 0, 0, 0);
     uint32_t flags_pre = 0u;
     if (tid < d0.ni) {
@@ -128,6 +139,10 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         uint4 item = item_pre; // fetched during the previous slice's block math
         uint32_t flags = flags_pre;
 
+        if (m.rhs_F != nullptr && tid < kSliceRows) {
+            const bool fixed = (rhs_mask >> (tid % 6)) & 1u;
+            m.rhs_F[(int64_t)s * kSliceRows + tid] = (fixed || s * kSliceNodes + tid / 6 >= m.n_own) ? 0.0 : rhs_pre;
+        }
         // ---- phase A: one record per element touching the slice
         for (int i = tid; i < ne; i += blockDim.x) {
             const int4 c = (i == tid) ? nd : m.slice_elem_nodes[e0 + i];
@@ -173,6 +188,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         uint4 item_next = make_uint4(0, 0, 0, 0);
         uint32_t flags_next = 0u;
         const Desc d3 = load_desc(s + 3 * w.step);
+        fetch_rhs(s + w.step);
         e0 = d1.e0;
         ne = d1.ne;
         nd = nd_n;

@@ -41,6 +41,8 @@ struct DeviceMatrix {
     int32_t lds_tile_off = 0, lds_rec_off = 0, lds_stage_off = 0; // offsets in doubles
     const uint8_t *dmask = nullptr;     // per local node (owned, padding, ghosts)
     double *vals = nullptr;             // total_slots x 36, sliced layout
+    const double *rhs_loads = nullptr;  // n_pad x 6 nodal loads and
+    double *rhs_F = nullptr;            // the right-hand side k_assemble fills beside K (nullptr: K only)
     double *minv = nullptr;             // n_slices x 6 x 192: inverse diagonal blocks
     unsigned long long *stamps = nullptr; // profiling builds of k_assemble only (tools/lab)
     int32_t *status = nullptr;          // device int: 0 ok, e+1 = first degenerate local element,
