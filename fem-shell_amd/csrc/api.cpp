@@ -315,6 +315,7 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     c->dm.slice_elem_ptr = c->slice_elem_ptr.p;
     c->dm.slice_elem_nodes = reinterpret_cast<const int4 *>(c->slice_elem_nodes.p);
     c->dm.max_slice_elems = p.max_slice_elems;
+    c->dm.max_slice_width = p.max_slice_width;
     c->dm.item_ptr = c->item_ptr.p;
     c->dm.slice_desc = reinterpret_cast<const int4 *>(c->slice_desc.p);
     c->dm.items = reinterpret_cast<const uint4 *>(c->items.p);
@@ -322,8 +323,7 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     c->dm.item_flags = c->item_flags.p;
     c->dm.max_stage_rows = p.max_stage_rows;
     {
-        // LDS of k_assemble: output tile (kOutSlots block slots x 32 nodes x 288 B per pass) +
-        // ownership mask + element records + partial-sum staging
+        // LDS of k_assemble: element records + partial-sum staging
         int32_t max_items = 0;
         for (int32_t s = 0; s < p.n_slices; s++) max_items = std::max(max_items, p.item_ptr[s + 1] - p.item_ptr[s]);
         const size_t lds = assemble_lds_layout(c->dm, p.max_slice_elems, p.max_stage_rows, max_items);
@@ -596,7 +596,7 @@ int femshell_export_bsr(femshell_ctx *c, int32_t *rowptr, int32_t *colidx, doubl
             const double *src = h.data() + base * 36;
             for (int i = 0; i < 6; i++)
                 for (int j = 0; j < 6; j++)
-                    blk[6 * i + j] = src[(((int64_t)ck.second * 3 + j / 2) * kSliceRows + n * 6 + i) * 2 + (j & 1)];
+                    blk[6 * i + j] = src[((((int64_t)ck.second * 3 + j / 2) * 6 + i) * kSliceNodes + n) * 2 + (j & 1)];
             nb++;
         }
         rowptr[a + 1] = (int32_t)nb;

@@ -50,12 +50,8 @@ __device__ __forceinline__ void lds_barrier()
 template <int kWavesPerSimd, int kAblate = 0, bool kHasQuads = false>
 __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m, MatConst mc)
 {
-    // LDS: [ownership mask | element records | partial-sum staging], output tile (kOutSlots*32*36 doubles) either
-    // on top of the records (they are dead once the block math is done; single-round slices only) or behind
-    // the staging rows (see assemble_lds_layout)
+    // LDS: [element records | partial-sum staging] (assemble_lds_layout)
     extern __shared__ double lds[];
-    uint32_t *lds_mask = reinterpret_cast<uint32_t *>(lds); // 64 words
-    double2 *lds_tile = reinterpret_cast<double2 *>(lds + m.lds_tile_off);
     double *lds_rec = lds + m.lds_rec_off;
     double *lds_stage = lds + m.lds_stage_off;
     const int tid = threadIdx.x;
@@ -134,7 +130,6 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
     for (; w.valid(); w.next()) {
         const int s = w.s;
         const int64_t base = d0.base;
-        const int W = d0.W;
         const int i0 = d0.i0, ni = d0.ni;
         uint4 item = item_pre; // fetched during the previous slice's block math
         uint32_t flags = flags_pre;
@@ -199,11 +194,11 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         }
         if (tid < d2.ne) nd_n = m.slice_elem_nodes[d2.e0 + tid];
 
-        // ---- phase B: one lane per work item (at most kItemPairs element contributions), in
-        //      rounds of 256 items; each round's finished blocks leave through the LDS tile so
-        //      that every store instruction covers 1 KiB of consecutive addresses
+        // ---- phase B: one lane per work item (at most kItemPairs element contributions), in rounds of 256
+        //      items; the lane that owns a block slot stores its finished block straight to K: in the layout of
+        //      plan.hpp the lanes of a slot (consecutive nodes) write consecutive 16-byte words with every store
         double2 *out = reinterpret_cast<double2 *>(m.vals + base * 36);
-        const bool multi = ni > (int)blockDim.x; // several rounds: the tile is only partly owned per round
+        const bool multi = ni > (int)blockDim.x; // several rounds
         for (int r0 = 0; r0 < ni; r0 += blockDim.x) {
             const int it = r0 + tid;
             const bool live = it < ni;
@@ -215,7 +210,6 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                     flags = m.item_flags[i0 + it];
                 }
             }
-            if (multi && tid < 64) lds_mask[tid] = 0u;
             const int slot_in_slice = (int)(item.x & 0xffffu), chunk = (int)((item.x >> 16) & 0xffu),
                       nchunks = (int)(item.x >> 24);
             const int cnt = (int)(item.z >> 16);
@@ -271,45 +265,22 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                             if ((mrow >> i) & 1u) blk[7 * i] = (double)valence;
                     }
                 }
-                if (multi) atomicOr(&lds_mask[slot_in_slice >> 5], 1u << (slot_in_slice & 31));
-            }
-            const int my_k = slot_in_slice >> 5, my_n = slot_in_slice & 31;
-            stamp(4); // partial-sum reduction + constraints
-            for (int k0 = 0; k0 < W; k0 += kOutSlots) {
-                if (owner && my_k >= k0 && my_k < k0 + kOutSlots) {
-                    double2 *t = lds_tile + (size_t)(my_k - k0) * 3 * kSliceRows + my_n * 6;
+                if (!(kAblate & 1)) {
+                    typedef double v2d __attribute__((ext_vector_type(2)));
+                    v2d *dst = reinterpret_cast<v2d *>(out) + (size_t)(slot_in_slice >> 5) * 3 * kSliceRows + (slot_in_slice & 31);
 #pragma unroll
                     for (int jp = 0; jp < 3; jp++)
 #pragma unroll
-                        for (int i = 0; i < 6; i++)
-                            t[jp * kSliceRows + i] = make_double2(blk[6 * i + 2 * jp], blk[6 * i + 2 * jp + 1]);
+                        for (int i = 0; i < 6; i++) {
+                            v2d vv; vv.x = blk[6 * i + 2 * jp]; vv.y = blk[6 * i + 2 * jp + 1];
+                            __builtin_nontemporal_store(vv, dst + (jp * 6 + i) * kSliceNodes);
+                        }
+                } else if (blk[0] == 1.2345e300) {
+                    out[0] = make_double2(blk[1], blk[2]);
                 }
-                lds_barrier();
-                stamp(5); // tile write + barrier
-                const int nk = min(kOutSlots, W - k0);
-                const int words = nk * 3 * kSliceRows; // double2 words of this pass
-                double2 *dst = out + (size_t)k0 * 3 * kSliceRows;
-                if (kAblate & 1) {
-                    double2 v = make_double2(0, 0);
-                    for (int q = tid; q < words; q += blockDim.x) { v.x += lds_tile[q].x; v.y += lds_tile[q].y; }
-                    if (v.x == 1.2345e300) dst[0] = v;
-                } else if (!multi) {
-                    for (int q = tid; q < words; q += blockDim.x) {
-                        const double2 v = lds_tile[q];
-                        typedef double v2d __attribute__((ext_vector_type(2)));
-                        v2d vv; vv.x = v.x; vv.y = v.y;
-                        __builtin_nontemporal_store(vv, reinterpret_cast<v2d *>(dst + q));
-                    }
-                } else {
-                    for (int q = tid; q < words; q += blockDim.x) {
-                        const int kk = k0 + q / (3 * kSliceRows), nn = (q % kSliceRows) / 6;
-                        if ((lds_mask[kk] >> nn) & 1u) dst[q] = lds_tile[q];
-                    }
-                }
-                stamp(6); // tile read + global stores
-                lds_barrier();
-                stamp(7); // barrier after the copy-out
             }
+            stamp(4); // partial-sum reduction + constraints + K stores
+            if (multi) lds_barrier(); // the next round reuses the partial-sum rows
         }
         item_pre = item_next;
         flags_pre = flags_next;

@@ -203,7 +203,7 @@ __global__ void k_block_jacobi(DeviceMatrix m)
     for (int jp = 0; jp < 3; jp++)
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            const double2 v = src[jp * kSliceRows + n * 6 + i];
+            const double2 v = src[(jp * 6 + i) * kSliceNodes + n];
             A[i][2 * jp] = v.x;
             A[i][2 * jp + 1] = v.y;
         }
@@ -252,49 +252,48 @@ void launch_block_jacobi(const DeviceMatrix &m, hipStream_t st)
 }
 
 // =====================================================================================
-// SpMV y = K x on the sliced block ELL layout, one lane per scalar row.  Per block slot a
-// lane issues three 16-byte loads of K (consecutive lanes -> consecutive 16-byte words, 1 KiB
-// per wave instruction) and three 16-byte loads of x (the six lanes of a node read the same
-// words; neighbouring slices share them through L2).  Optionally fuses the partial sums of
+// SpMV y = K x on the sliced block ELL layout, one lane per scalar row: lane t of a slice holds block row
+// i = t / 32 of node n = t % 32, so that the words of K it needs are the t-th of every 192-word group and
+// consecutive lanes read consecutive 16-byte words (1 KiB per wave instruction).  The x entries of the slice's
+// block columns (48 bytes per slot and node) are staged through LDS once per slice -- the six lanes of a node sit
+// in three different waves in this mapping -- and read back as broadcasts.  Optionally fuses the partial sums of
 // x.y needed by CG (p.Ap).
 // =====================================================================================
-// kChunk block slots are handled together: their column indices are fetched first, then all value and
-// x loads are issued back to back, so a row costs two dependent memory latencies per chunk instead of
-// two per block slot.
+// kChunk block slots are handled together: all their K loads are issued back to back; the loads of the first
+// chunk are issued before the x staging (spmv_load), so that their latency overlaps it.
+template <int kChunk> struct SpmvChunk {
+    double2 a[kChunk][3];
+};
 template <int kChunk>
-__device__ __forceinline__ double spmv_row(const int32_t *__restrict__ c, const double2 *__restrict__ v,
-                                           const double *__restrict__ x, int W)
+__device__ __forceinline__ void spmv_load(SpmvChunk<kChunk> &c, const double2 *__restrict__ v, int k0, int W)
 {
-    double acc = 0.0;
-    for (int k0 = 0; k0 < W; k0 += kChunk) {
-        int col[kChunk];
 #pragma unroll
-        for (int q = 0; q < kChunk; q++) col[q] = (k0 + q < W) ? c[(k0 + q) * kSliceNodes] : -1;
-        double2 a[kChunk][3], xx[kChunk][3];
+    for (int q = 0; q < kChunk; q++) {
+        if (k0 + q < W) {
+            const double2 *vv = v + (size_t)(k0 + q) * 3 * kSliceRows;
+            c.a[q][0] = vv[0];
+            c.a[q][1] = vv[kSliceRows];
+            c.a[q][2] = vv[2 * kSliceRows];
+        } else {
 #pragma unroll
-        for (int q = 0; q < kChunk; q++) {
-            if (col[q] >= 0) {
-                const double2 *xv = reinterpret_cast<const double2 *>(x + 6 * (int64_t)col[q]);
-                const double2 *vv = v + (size_t)(k0 + q) * 3 * kSliceRows;
-                a[q][0] = vv[0];
-                a[q][1] = vv[kSliceRows];
-                a[q][2] = vv[2 * kSliceRows];
-                xx[q][0] = xv[0];
-                xx[q][1] = xv[1];
-                xx[q][2] = xv[2];
-            } else {
-#pragma unroll
-                for (int t = 0; t < 3; t++) a[q][t] = xx[q][t] = make_double2(0.0, 0.0);
-            }
+            for (int t = 0; t < 3; t++) c.a[q][t] = make_double2(0.0, 0.0);
         }
+    }
+}
+template <int kChunk>
+__device__ __forceinline__ double spmv_fma(const SpmvChunk<kChunk> &c, const double2 *__restrict__ xs, int k0, int W, double acc)
+{
 #pragma unroll
-        for (int q = 0; q < kChunk; q++) {
-            acc += a[q][0].x * xx[q][0].x;
-            acc += a[q][0].y * xx[q][0].y;
-            acc += a[q][1].x * xx[q][1].x;
-            acc += a[q][1].y * xx[q][1].y;
-            acc += a[q][2].x * xx[q][2].x;
-            acc += a[q][2].y * xx[q][2].y;
+    for (int q = 0; q < kChunk; q++) {
+        if (k0 + q < W) {
+            const double2 *xx = xs + (size_t)(k0 + q) * 3 * kSliceNodes;
+            const double2 x0 = xx[0], x1 = xx[1], x2 = xx[2];
+            acc += c.a[q][0].x * x0.x;
+            acc += c.a[q][0].y * x0.y;
+            acc += c.a[q][1].x * x1.x;
+            acc += c.a[q][1].y * x1.y;
+            acc += c.a[q][2].x * x2.x;
+            acc += c.a[q][2].y * x2.y;
         }
     }
     return acc;
@@ -305,18 +304,35 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
                                               double *__restrict__ y, double *__restrict__ partials,
                                               const CgScalars *s, const int32_t *__restrict__ order, int count)
 {
+    extern __shared__ double2 xs_all[]; // max_slice_width x 32 nodes x 3 words: x of the slice's block columns
     __shared__ double sh[3];
     if (s != nullptr && s->done != 0) return;
     const int t = threadIdx.x;
+    const double2 *x2 = reinterpret_cast<const double2 *>(x);
     double dotv = 0.0;
     for (SliceWalk w(count); w.valid(); w.next()) {
         const int sl = order != nullptr ? order[w.s] : w.s;
         const int64_t base = m.slice_base[sl];
         const int W = m.slice_width[sl];
-        const int32_t *c = m.cols + base + t / 6;
         const double2 *v = reinterpret_cast<const double2 *>(m.vals + base * 36) + t;
-        const double acc = spmv_row<kChunk>(c, v, x, W);
-        const int64_t row = (int64_t)sl * kSliceRows + t;
+        SpmvChunk<kChunk> ch;
+        spmv_load<kChunk>(ch, v, 0, W);
+        __syncthreads(); // the previous slice's readers are done with xs_all
+        for (int e = t; e < W * kSliceNodes; e += kSliceRows) {
+            const double2 *xv = x2 + 3 * (int64_t)m.cols[base + e];
+            const double2 x0 = xv[0], x1 = xv[1], x2w = xv[2];
+            xs_all[3 * e] = x0;
+            xs_all[3 * e + 1] = x1;
+            xs_all[3 * e + 2] = x2w;
+        }
+        __syncthreads();
+        const double2 *xs = xs_all + 3 * (t & 31);
+        double acc = spmv_fma<kChunk>(ch, xs, 0, W, 0.0);
+        for (int k0 = kChunk; k0 < W; k0 += kChunk) {
+            spmv_load<kChunk>(ch, v, k0, W);
+            acc = spmv_fma<kChunk>(ch, xs, k0, W, acc);
+        }
+        const int64_t row = (int64_t)sl * kSliceRows + (t & 31) * 6 + (t >> 5);
         y[row] = acc;
         if (partials != nullptr) dotv += acc * x[row];
     }
@@ -331,14 +347,20 @@ static void spmv_dispatch(const DeviceMatrix &m, const double *x, double *y, dou
 {
     static const int chunk = [] {
         const char *e = getenv("FEMSHELL_SPMV_CHUNK"); // tuning knob: block slots loaded together
-        return e ? atoi(e) : 4;
+        return e ? atoi(e) : 8;
     }();
     const dim3 g(grid), b(192);
+    const size_t lds = (size_t)m.max_slice_width * kSliceNodes * 3 * sizeof(double2); // x of the block columns
+    auto launch = [&](auto kernel) {
+        if (lds > 64 * 1024) // beyond the default dynamic-LDS limit (slices wider than 42 blocks)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kernel, g, b, lds, st, m, x, y, partials, s, order, count);
+    };
     switch (chunk) {
-    case 1: hipLaunchKernelGGL(k_spmv<1>, g, b, 0, st, m, x, y, partials, s, order, count); break;
-    case 2: hipLaunchKernelGGL(k_spmv<2>, g, b, 0, st, m, x, y, partials, s, order, count); break;
-    case 8: hipLaunchKernelGGL(k_spmv<8>, g, b, 0, st, m, x, y, partials, s, order, count); break;
-    default: hipLaunchKernelGGL(k_spmv<4>, g, b, 0, st, m, x, y, partials, s, order, count); break;
+    case 1: launch(k_spmv<1>); break;
+    case 2: launch(k_spmv<2>); break;
+    case 4: launch(k_spmv<4>); break;
+    default: launch(k_spmv<8>); break;
     }
 }
 

@@ -8,10 +8,6 @@
 
 namespace femshell {
 
-#ifndef FEMSHELL_OUT_SLOTS
-#define FEMSHELL_OUT_SLOTS 7
-#endif
-constexpr int kOutSlots = FEMSHELL_OUT_SLOTS;               // block slots per output pass of k_assemble (LDS tile = 64,512 B: one pass for 7-wide slices)
 constexpr int32_t kStatusDirect = 0x40000000; // status values above this carry a local element id directly
 
 // Device view of the mesh + matrix structure of one rank (see plan.hpp for the layout).
@@ -30,6 +26,7 @@ struct DeviceMatrix {
                                              // {slot base lo, hi, width, 0} -- what k_assemble needs of a slice
     const int4 *slice_elem_nodes = nullptr;  // per slice element: its local node ids (w = -1 for TRI3)
     int32_t max_slice_elems = 0;
+    int32_t max_slice_width = 0;             // widest slice (block slots per node row)
     const int32_t *item_ptr = nullptr;       // n_slices+1
     const uint4 *items = nullptr;            // assembly work items (plan.hpp)
     uint32_t *item_flags = nullptr;          // per item: what its owner lane needs to know about the slot besides the
@@ -38,7 +35,7 @@ struct DeviceMatrix {
                                              // = diagonal slot; 0 for items that do not own their slot
     int32_t max_stage_rows = 0;
     int32_t lds_bytes = 0;                   // dynamic LDS of k_assemble (assemble_lds_layout)
-    int32_t lds_tile_off = 0, lds_rec_off = 0, lds_stage_off = 0; // offsets in doubles
+    int32_t lds_rec_off = 0, lds_stage_off = 0; // offsets in doubles
     const uint8_t *dmask = nullptr;     // per local node (owned, padding, ghosts)
     double *vals = nullptr;             // total_slots x 36, sliced layout
     const double *rhs_loads = nullptr;  // n_pad x 6 nodal loads and
@@ -49,28 +46,16 @@ struct DeviceMatrix {
                                         // -(node+1) = singular diagonal block
 };
 
-// LDS layout of k_assemble for a plan with at most max_slice_elems element records, max_stage_rows partial-sum
-// rows and max_slice_items work items per slice: [mask 256 B | records | staging | tile].  When every slice
-// finishes its items in one round of 256 the records are dead by the time the output tile is written, and
-// the tile lies on top of them.  Returns the dynamic LDS size in bytes.
+// LDS layout of k_assemble for a plan with at most max_slice_elems element records and max_stage_rows partial-sum
+// rows per slice: [records | partial sums].  Returns the dynamic LDS size in bytes.
 inline size_t assemble_lds_layout(DeviceMatrix &m, int32_t max_slice_elems, int32_t max_stage_rows, int32_t max_slice_items)
 {
-    const size_t mask = 32, rec = (size_t)max_slice_elems * kRecDoubles, stage = (size_t)max_stage_rows * 36,
-                 tile = (size_t)kOutSlots * 32 * 36;
-    m.lds_rec_off = (int32_t)mask;
-    if (max_slice_items <= 256) {
-        const size_t un = rec > tile ? rec : tile;
-        m.lds_tile_off = (int32_t)mask;
-        m.lds_stage_off = (int32_t)(mask + un);
-        m.lds_bytes = (int32_t)((mask + un + stage) * sizeof(double));
-    } else {
-        m.lds_stage_off = (int32_t)(mask + rec);
-        m.lds_tile_off = (int32_t)(mask + rec + stage);
-        m.lds_bytes = (int32_t)((mask + rec + stage + tile) * sizeof(double));
-    }
+    (void)max_slice_items;
+    m.lds_rec_off = 0;
+    m.lds_stage_off = max_slice_elems * kRecDoubles;
+    m.lds_bytes = (int32_t)(((size_t)max_slice_elems * kRecDoubles + (size_t)max_stage_rows * 36) * sizeof(double));
     return (size_t)m.lds_bytes;
 }
-
 // Scalars of the CG recurrence, resident in HBM (no host round trip per iteration).
 struct CgScalars {
     double rz;     // r.z of the current iterate

@@ -12,7 +12,7 @@
 //    node row has `width` block slots; slot 0 is the diagonal block, the others are the
 //    neighbour blocks in ascending column order; values are stored so that the 192 scalar
 //    rows of a slice are the fastest index (one lane per scalar row, 16-byte loads):
-//        vals[(slot_base(s) + k*32)*36 + ((jp*192) + n*6 + i)*2 + jj],  j = 2*jp + jj
+//        vals[(slot_base(s) + k*32)*36 + ((jp*6 + i)*32 + n)*2 + jj],  j = 2*jp + jj
 //    for slice s, slot k, node-in-slice n, block row i, block column j;
 //  * gather lists: for every block slot the (element, local row node, local column node)
 //    triples that contribute to it, ordered by element id, so that the assembly kernel
