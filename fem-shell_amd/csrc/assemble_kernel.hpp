@@ -233,26 +233,8 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
             const uint32_t mrow = flags & 63u, mcol = (flags >> 6) & 63u;
             const int valence = (int)((flags >> 12) & 255u);
             const bool diag_slot = (flags >> 20) & 1u;
-            stamp(2); // item decode + block math
-            if (live && chunk > 0) {
-                double2 *st = reinterpret_cast<double2 *>(lds_stage + (size_t)item.w * 36);
-#pragma unroll
-                for (int i = 0; i < 18; i++) st[i] = make_double2(blk[2 * i], blk[2 * i + 1]);
-            }
-            lds_barrier();
-            stamp(3); // staging write + barrier
-            if (owner) {
-                // chunks > 0 sort after chunk 0, so with several rounds they may not have run yet:
-                // plan.cpp keeps all chunks of a slot in one round when a slice has several rounds
-                for (int c = 1; c < nchunks; c++) {
-                    const double2 *st = reinterpret_cast<const double2 *>(lds_stage + (size_t)(item.w + c - 1) * 36);
-#pragma unroll
-                    for (int i = 0; i < 18; i++) {
-                        const double2 v = st[i];
-                        blk[2 * i] += v.x;
-                        blk[2 * i + 1] += v.y;
-                    }
-                }
+            // constraints (libMesh constrain_element_matrix_and_vector semantics) and the 18 stores of a finished block
+            auto finish_block = [&]() {
                 if (mrow | mcol) {
 #pragma unroll
                     for (int i = 0; i < 6; i++)
@@ -278,6 +260,31 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                 } else if (blk[0] == 1.2345e300) {
                     out[0] = make_double2(blk[1], blk[2]);
                 }
+            };
+            // slots with a single work item are complete now: their lanes store before the barrier, while the
+            // lanes of the split (diagonal) slots are still in their last contribution
+            if (owner && nchunks == 1) finish_block();
+            stamp(2); // item decode + block math (+ stores of the single-item slots)
+            if (live && chunk > 0) {
+                double2 *st = reinterpret_cast<double2 *>(lds_stage + (size_t)item.w * 36);
+#pragma unroll
+                for (int i = 0; i < 18; i++) st[i] = make_double2(blk[2 * i], blk[2 * i + 1]);
+            }
+            lds_barrier();
+            stamp(3); // staging write + barrier
+            if (owner && nchunks > 1) {
+                // chunks > 0 sort after chunk 0, so with several rounds they may not have run yet:
+                // plan.cpp keeps all chunks of a slot in one round when a slice has several rounds
+                for (int c = 1; c < nchunks; c++) {
+                    const double2 *st = reinterpret_cast<const double2 *>(lds_stage + (size_t)(item.w + c - 1) * 36);
+#pragma unroll
+                    for (int i = 0; i < 18; i++) {
+                        const double2 v = st[i];
+                        blk[2 * i] += v.x;
+                        blk[2 * i + 1] += v.y;
+                    }
+                }
+                finish_block();
             }
             stamp(4); // partial-sum reduction + constraints + K stores
             if (multi) lds_barrier(); // the next round reuses the partial-sum rows
