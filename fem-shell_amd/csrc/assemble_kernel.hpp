@@ -55,11 +55,18 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
     double *lds_rec = lds + m.lds_rec_off;
     double *lds_stage = lds + m.lds_stage_off;
     const int tid = threadIdx.x;
+    // element records are built by the lanes counted from the END of the workgroup (element i of the slice by lane
+    // 255 - i): the diagonal slots' work items, three contributions each, sit in the first wave, which would
+    // otherwise also carry 64 of the 130 records of a structured slice; the last waves have two contributions per
+    // lane and start the next slice's records while the first wave still finishes its blocks
+    const int etid = (int)blockDim.x - 1 - tid;
 
     // profiling build (kAblate & 32): s_memtime stamps at the phase boundaries, summed per wave and written to
     // m.stamps[wave][8]; never compiled into the product kernel
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int slot) {
+        if (kAblate & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (kAblate & 128) asm volatile("s_nop 0" ::: "memory");
         if (kAblate & 32) {
             unsigned long long tnow;
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
@@ -104,11 +111,11 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
     Desc d0 = load_desc(w.s), d1 = load_desc(w.s + w.step), d2 = load_desc(w.s + 2 * w.step);
     int e0 = d0.e0, ne = d0.ne;
     int4 nd = make_int4(0, 0, 0, -1);
-    if (tid < ne) nd = m.slice_elem_nodes[e0 + tid];
+    if (etid < ne) nd = m.slice_elem_nodes[e0 + etid];
     double Xcur[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (!kHasQuads && tid < ne) fetch_coords(nd, Xcur);
+    if (!kHasQuads && etid < ne) fetch_coords(nd, Xcur);
     int4 nd_n = make_int4(0, 0, 0, -1); // slice s+1
-    if (tid < d1.ne) nd_n = m.slice_elem_nodes[d1.e0 + tid];
+    if (etid < d1.ne) nd_n = m.slice_elem_nodes[d1.e0 + etid];
     // right-hand side of the slice (contribRHS, fem-shell.cpp:1118-1153: a masked copy of the nodal loads): loaded
     // one slice ahead in front of the coordinate prefetch, stored where phase A waits for the coordinates anyway
     double rhs_pre = 0.0;
@@ -139,13 +146,13 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
             m.rhs_F[(int64_t)s * kSliceRows + tid] = (fixed || s * kSliceNodes + tid / 6 >= m.n_own) ? 0.0 : rhs_pre;
         }
         // ---- phase A: one record per element touching the slice
-        for (int i = tid; i < ne; i += blockDim.x) {
-            const int4 c = (i == tid) ? nd : m.slice_elem_nodes[e0 + i];
+        for (int i = etid; i < ne; i += blockDim.x) {
+            const int4 c = (i == etid) ? nd : m.slice_elem_nodes[e0 + i];
             double rec[kRecDoubles];
             bool ok = false;
             if (!kHasQuads || c.w < 0) {
                 double X[9];
-                if (!kHasQuads && i == tid) {
+                if (!kHasQuads && i == etid) {
 #pragma unroll
                     for (int q = 0; q < 9; q++) X[q] = Xcur[q];
                 } else {
@@ -187,12 +194,12 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         e0 = d1.e0;
         ne = d1.ne;
         nd = nd_n;
-        if (!kHasQuads && tid < ne) fetch_coords(nd, Xcur);
+        if (!kHasQuads && etid < ne) fetch_coords(nd, Xcur);
         if (tid < d1.ni) {
             item_next = m.items[d1.i0 + tid];
             flags_next = m.item_flags[d1.i0 + tid];
         }
-        if (tid < d2.ne) nd_n = m.slice_elem_nodes[d2.e0 + tid];
+        if (etid < d2.ne) nd_n = m.slice_elem_nodes[d2.e0 + etid];
 
         // ---- phase B: one lane per work item (at most kItemPairs element contributions), in rounds of 256
         //      items; the lane that owns a block slot stores its finished block straight to K: in the layout of
