@@ -13,7 +13,10 @@ using namespace femshell;
 template <int W, int F> float run(const DeviceMatrix &m, const MatConst &mc, int grid, int reps)
 {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    hipLaunchKernelGGL((k_assemble<W, F>), dim3(grid), dim3(256), m.lds_bytes, 0, m, mc);
+    // the first ~20 launches of a process run ~12 % slow (clocks, TLBs): warm up before timing
+    static bool warm = false;
+    for (int i = 0; i < (warm ? 2 : 25); i++) hipLaunchKernelGGL((k_assemble<W, F>), dim3(grid), dim3(256), m.lds_bytes, 0, m, mc);
+    warm = true;
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
     for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_assemble<W, F>), dim3(grid), dim3(256), m.lds_bytes, 0, m, mc);
