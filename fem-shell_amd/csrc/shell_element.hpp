@@ -361,24 +361,36 @@ __device__ __forceinline__ bool quad4_record(const double X[12], const MatConst 
     return true;
 }
 
+// DKQ side coefficients (SA:613-621) of one element side with difference vector (x, y): they do not depend on
+// the Gauss point, so a block computes them once per side it needs
+struct DkqSide {
+    double a, b, c, d, e;
+};
+__device__ __forceinline__ DkqSide dkq_side(double x, double y)
+{
+    const double l = 1.0 / (x * x + y * y);
+    DkqSide s;
+    s.a = -x * l;
+    s.b = 0.75 * x * y * l;
+    s.c = (0.25 * x * x - 0.5 * y * y) * l;
+    s.d = -y * l;
+    s.e = (0.25 * y * y - 0.5 * x * x) * l;
+    return s;
+}
+
 // DKQ curvature columns of node n at one Gauss point: B[r][c], r = (kxx, kyy, kxy), c = (w, tx, ty).
-// xs/ys of the two sides meeting at the node (sa = n: towards the next node, sb = n-1: from the
-// previous node), serendipity derivatives of the corner and the two mid-side functions.
-__device__ __forceinline__ void dkq_node_block(double xa, double ya, double xb, double yb, double Nxn, double Nen,
+// sa / sb: the two sides meeting at the node (sa = n: towards the next node, sb = n-1: from the previous node);
+// serendipity derivatives of the corner and the two mid-side functions.
+__device__ __forceinline__ void dkq_node_block(const DkqSide &sa, const DkqSide &sb, double Nxn, double Nen,
                                                double Nxa, double Nea, double Nxb, double Neb, const double Ji[4],
                                                double B[3][3])
 {
-    const double la = 1.0 / (xa * xa + ya * ya), lb = 1.0 / (xb * xb + yb * yb);
-    // SA:613-621
-    const double a_a = -xa * la, b_a = 0.75 * xa * ya * la, c_a = (0.25 * xa * xa - 0.5 * ya * ya) * la;
-    const double d_a = -ya * la, e_a = (0.25 * ya * ya - 0.5 * xa * xa) * la;
-    const double a_b = -xb * lb, b_b = 0.75 * xb * yb * lb, c_b = (0.25 * xb * xb - 0.5 * yb * yb) * lb;
-    const double d_b = -yb * lb, e_b = (0.25 * yb * yb - 0.5 * xb * xb) * lb;
+#pragma clang fp reassociate(on) contract(fast) // element math only; parity bar is 1e-12, not bitwise
     // SA:931-981, xi then eta derivatives
-    const double Hxx[3] = {1.5 * (a_a * Nxa - a_b * Nxb), b_a * Nxa + b_b * Nxb, Nxn - c_a * Nxa - c_b * Nxb};
-    const double Hxe[3] = {1.5 * (a_a * Nea - a_b * Neb), b_a * Nea + b_b * Neb, Nen - c_a * Nea - c_b * Neb};
-    const double Hyx[3] = {1.5 * (d_a * Nxa - d_b * Nxb), -Nxn + e_a * Nxa + e_b * Nxb, -Hxx[1]};
-    const double Hye[3] = {1.5 * (d_a * Nea - d_b * Neb), -Nen + e_a * Nea + e_b * Neb, -Hxe[1]};
+    const double Hxx[3] = {1.5 * (sa.a * Nxa - sb.a * Nxb), sa.b * Nxa + sb.b * Nxb, Nxn - sa.c * Nxa - sb.c * Nxb};
+    const double Hxe[3] = {1.5 * (sa.a * Nea - sb.a * Neb), sa.b * Nea + sb.b * Neb, Nen - sa.c * Nea - sb.c * Neb};
+    const double Hyx[3] = {1.5 * (sa.d * Nxa - sb.d * Nxb), -Nxn + sa.e * Nxa + sb.e * Nxb, -Hxx[1]};
+    const double Hye[3] = {1.5 * (sa.d * Nea - sb.d * Neb), -Nen + sa.e * Nea + sb.e * Neb, -Hxe[1]};
 #pragma unroll
     for (int c = 0; c < 3; c++) { // SA:984-989
         B[0][c] = Ji[0] * Hxx[c] + Ji[1] * Hxe[c];
@@ -410,6 +422,8 @@ __device__ __forceinline__ void quad4_block_add_rec(const double *rec, int ia, i
     const double rj = (ib == 1 || ib == 2) ? 1.0 : -1.0, sj = (ib >= 2) ? 1.0 : -1.0;
     const double x12 = x[0] - x[1], y12 = y[0] - y[1], x23 = x[1] - x[2], y23 = y[1] - y[2];
     const double x34 = x[2] - x[3], y34 = y[2] - y[3], x41 = x[3] - x[0], y41 = y[3] - y[0];
+    const DkqSide sa_i = dkq_side(xa_i, ya_i), sb_i = dkq_side(xb_i, yb_i), sa_j = dkq_side(xa_j, ya_j),
+                  sb_j = dkq_side(xb_j, yb_j);
 
     double m00 = 0.0, m01 = 0.0, m10 = 0.0, m11 = 0.0;
     double p[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
@@ -417,19 +431,13 @@ __device__ __forceinline__ void quad4_block_add_rec(const double *rec, int ia, i
 #pragma unroll 1
     for (int gp = 0; gp < 4; gp++) {
         const double r = (gp & 2) ? -root : root, s = (gp & 1) ? -root : root; // SA:482-487 order
-        // ---- membrane (SA:489-538)
+        // the Jacobian of the bilinear map at this Gauss point serves the membrane (SA:489-538) and the plate
+        // (SA:641-684): both formulas of the reference give the same four numbers
+        const double J00 = 0.25 * ((x12 + x34) * s - x12 + x34), J01 = 0.25 * ((y12 + y34) * s - y12 + y34);
+        const double J10 = 0.25 * ((x12 + x34) * r - x23 + x41), J11 = 0.25 * ((y12 + y34) * r - y23 + y41);
+        const double det = J00 * J11 - J01 * J10, idet = 1.0 / det;
+        // ---- membrane
         {
-            constexpr double rn[4] = {-1.0, 1.0, 1.0, -1.0}, sn[4] = {-1.0, -1.0, 1.0, 1.0};
-            double J00 = 0.0, J01 = 0.0, J10 = 0.0, J11 = 0.0;
-#pragma unroll
-            for (int n = 0; n < 4; n++) {
-                const double dr = 0.25 * rn[n] * (1.0 + sn[n] * s), ds = 0.25 * sn[n] * (1.0 + rn[n] * r);
-                J00 += dr * x[n];
-                J01 += dr * y[n];
-                J10 += ds * x[n];
-                J11 += ds * y[n];
-            }
-            const double det = J00 * J11 - J01 * J10, idet = 1.0 / det;
             const double dri = 0.25 * ri * (1.0 + si * s), dsi = 0.25 * si * (1.0 + ri * r);
             const double drj = 0.25 * rj * (1.0 + sj * s), dsj = 0.25 * sj * (1.0 + rj * r);
             const double bi = (J11 * dri - J01 * dsi) * idet, gi = (-J10 * dri + J00 * dsi) * idet; // dN/dx, dN/dy
@@ -440,11 +448,8 @@ __device__ __forceinline__ void quad4_block_add_rec(const double *rec, int ia, i
             m10 += w * (mc.nu * gi * bj + mc.g * bi * gj);
             m11 += w * (gi * gj + mc.g * bi * bj);
         }
-        // ---- plate (SA:641-684)
+        // ---- plate
         {
-            const double J00 = 0.25 * ((x12 + x34) * s - x12 + x34), J01 = 0.25 * ((y12 + y34) * s - y12 + y34);
-            const double J10 = 0.25 * ((x12 + x34) * r - x23 + x41), J11 = 0.25 * ((y12 + y34) * r - y23 + y41);
-            const double det = J00 * J11 - J01 * J10, idet = 1.0 / det;
             const double Ji[4] = {J11 * idet, -J01 * idet, -J10 * idet, J00 * idet};
             // serendipity derivatives (SA:906-923): corner n, mid-side of side s (nodes 5..8)
             auto corner_x = [&](double rr, double ss) { return 0.25 * rr * (1.0 + s * ss) * (2.0 * r * rr + s * ss); };
@@ -456,10 +461,8 @@ __device__ __forceinline__ void quad4_block_add_rec(const double *rec, int ia, i
                 return sd == 0 ? -0.5 * (1.0 - r * r) : (sd == 1 ? -s * (1.0 + r) : (sd == 2 ? 0.5 * (1.0 - r * r) : -s * (1.0 - r)));
             };
             double Bi[3][3], Bj[3][3];
-            dkq_node_block(xa_i, ya_i, xb_i, yb_i, corner_x(ri, si), corner_e(ri, si), mid_x(ia), mid_e(ia), mid_x(ia_p),
-                           mid_e(ia_p), Ji, Bi);
-            dkq_node_block(xa_j, ya_j, xb_j, yb_j, corner_x(rj, sj), corner_e(rj, sj), mid_x(ib), mid_e(ib), mid_x(ib_p),
-                           mid_e(ib_p), Ji, Bj);
+            dkq_node_block(sa_i, sb_i, corner_x(ri, si), corner_e(ri, si), mid_x(ia), mid_e(ia), mid_x(ia_p), mid_e(ia_p), Ji, Bi);
+            dkq_node_block(sa_j, sb_j, corner_x(rj, sj), corner_e(rj, sj), mid_x(ib), mid_e(ib), mid_x(ib_p), mid_e(ib_p), Ji, Bj);
             const double w = det * mc.cp;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
