@@ -65,8 +65,6 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
     // m.stamps[wave][8]; never compiled into the product kernel
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int slot) {
-        if (kAblate & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (kAblate & 128) asm volatile("s_nop 0" ::: "memory");
         if (kAblate & 32) {
             unsigned long long tnow;
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
@@ -262,7 +260,8 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
 #pragma unroll
                         for (int i = 0; i < 6; i++) {
                             v2d vv; vv.x = blk[6 * i + 2 * jp]; vv.y = blk[6 * i + 2 * jp + 1];
-                            __builtin_nontemporal_store(vv, dst + (jp * 6 + i) * kSliceNodes);
+                            if (kAblate & 64) dst[(jp * 6 + i) * kSliceNodes] = vv; // lab: plain instead of non-temporal stores
+                            else __builtin_nontemporal_store(vv, dst + (jp * 6 + i) * kSliceNodes);
                         }
                 } else if (blk[0] == 1.2345e300) {
                     out[0] = make_double2(blk[1], blk[2]);

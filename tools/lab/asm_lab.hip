@@ -60,8 +60,7 @@ int main(int argc, char **argv)
     const int R = 5;
     printf("W2 full               : %.3f ms\n", run<2, 0>(m, mc, grid, R));
     printf("W3 full               : %.3f ms\n", run<3, 0>(m, mc, grid, R));
-    printf("W2 lgkmcnt(0) at stamps: %.3f ms\n", run<2, 64>(m, mc, grid, R));
-    printf("W2 compiler fence at stamps: %.3f ms\n", run<2, 128>(m, mc, grid, R));
+    printf("W2 plain stores       : %.3f ms\n", run<2, 64>(m, mc, grid, R));
     printf("W2 full again         : %.3f ms\n", run<2, 0>(m, mc, grid, R));
     printf("W2 no global stores   : %.3f ms\n", run<2, 1>(m, mc, grid, R));
     printf("W2 all lanes record 0 : %.3f ms\n", run<2, 2>(m, mc, grid, R));
