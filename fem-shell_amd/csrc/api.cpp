@@ -48,10 +48,11 @@ double bytes_spmv(const femshell_ctx *c)
     const Plan &p = c->plan;
     return 292.0 * (double)p.nnz_blocks + 4.0 * (p.n_own + 1) + 96.0 * p.n_own;
 }
-double bytes_update(const femshell_ctx *c) { return (7.0 * 48.0 + 288.0) * c->plan.n_own; }
+// (the inverse diagonal blocks are symmetric: 21 of their 36 words are stored and read)
+double bytes_update(const femshell_ctx *c) { return (7.0 * 48.0 + 168.0) * c->plan.n_own; }
 double bytes_direction(const femshell_ctx *c) { return 3.0 * 48.0 * c->plan.n_own; }
 // single-reduction recurrence: z, w, p, s, x, r read, p, s, x, r, z written, Minv read
-double bytes_update_single_reduction(const femshell_ctx *c) { return (11.0 * 48.0 + 288.0) * c->plan.n_own; }
+double bytes_update_single_reduction(const femshell_ctx *c) { return (11.0 * 48.0 + 168.0) * c->plan.n_own; }
 
 int check_status(femshell_ctx *c, const char *what)
 {
@@ -286,7 +287,7 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     FS_HIP(c->items.upload(p.items, st));
     const size_t nrow = (size_t)p.n_pad * 6, nrow_ext = (size_t)p.n_local_nodes() * 6;
     FS_HIP(c->vals.alloc((size_t)p.total_slots() * 36));
-    FS_HIP(c->minv.alloc((size_t)p.n_slices * 6 * kSliceRows));
+    FS_HIP(c->minv.alloc((size_t)p.n_slices * 21 * kSliceNodes)); // upper triangles of the inverse diagonal blocks
     FS_HIP(c->F.alloc(nrow));
     FS_HIP(c->x.alloc(nrow));
     FS_HIP(c->r.alloc(nrow));

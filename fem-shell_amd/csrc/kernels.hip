@@ -181,20 +181,22 @@ void launch_element_matrices(const DeviceMatrix &m, const MatConst &mc, int32_t 
 }
 
 // =====================================================================================
-// Block-Jacobi setup: invert the 6x6 diagonal block of every owned node (Gauss-Jordan, no
-// pivoting: the blocks are SPD) into the row-interleaved layout the CG update kernel streams.
+// Block-Jacobi setup: invert the 6x6 diagonal block of every owned node (Cholesky: the blocks are SPD)
+// into the packed layout the CG vector kernels stream.
 // =====================================================================================
+// minv layout: per slice 21 words (upper triangle of the symmetric 6x6 inverse, row-major) x 32 nodes, nodes fastest
+constexpr int kMinvWords = 21;
+__host__ __device__ __forceinline__ int minv_word(int i, int j) { return (i * (11 - i)) / 2 + j; } // i <= j
+
 __global__ void k_block_jacobi(DeviceMatrix m)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= m.n_pad) return;
     const int s = a / kSliceNodes, n = a % kSliceNodes;
-    double *mi = m.minv + (int64_t)s * 6 * kSliceRows + n * 6;
+    double *mi = m.minv + (int64_t)s * kMinvWords * kSliceNodes + n;
     if (a >= m.n_own) {
 #pragma unroll
-        for (int j = 0; j < 6; j++)
-#pragma unroll
-            for (int i = 0; i < 6; i++) mi[j * kSliceRows + i] = 0.0;
+        for (int e = 0; e < kMinvWords; e++) mi[e * kSliceNodes] = 0.0;
         return;
     }
     const double2 *src = reinterpret_cast<const double2 *>(m.vals + m.slice_base[s] * 36);
@@ -207,43 +209,62 @@ __global__ void k_block_jacobi(DeviceMatrix m)
             A[i][2 * jp] = v.x;
             A[i][2 * jp + 1] = v.y;
         }
-#pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-        for (int j = 0; j < 6; j++) B[i][j] = (i == j) ? 1.0 : 0.0;
+    // Cholesky A = L L^T (the blocks are SPD), then A^-1 = L^-T L^-1: symmetric by construction and backward
+    // stable without pivoting, which matters on sliver elements (block condition numbers around 1e9)
+    double L[6][6], Li[6][6];
     bool ok = true;
 #pragma unroll
     for (int c = 0; c < 6; c++) {
-        const double piv = A[c][c];
-        if (!(piv > 0.0)) ok = false;
-        const double d = 1.0 / piv;
+        double d = A[c][c];
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-            A[c][j] *= d;
-            B[c][j] *= d;
+        for (int k = 0; k < c; k++) d -= L[c][k] * L[c][k];
+        if (!(d > 0.0)) {
+            ok = false;
+            d = 1.0;
         }
+        const double lcc = sqrt(d), il = 1.0 / lcc;
+        L[c][c] = lcc;
 #pragma unroll
-        for (int r = 0; r < 6; r++) {
-            if (r == c) continue;
-            const double f = A[r][c];
+        for (int r = c + 1; r < 6; r++) {
+            double v = A[r][c];
 #pragma unroll
-            for (int j = 0; j < 6; j++) {
-                A[r][j] -= f * A[c][j];
-                B[r][j] -= f * B[c][j];
-            }
+            for (int k = 0; k < c; k++) v -= L[r][k] * L[c][k];
+            L[r][c] = v * il;
         }
     }
+    // Li = L^-1 (lower triangular) by forward substitution
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        Li[c][c] = 1.0 / L[c][c];
+#pragma unroll
+        for (int r = c + 1; r < 6; r++) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = c; k < r; k++) v -= L[r][k] * Li[k][c];
+            Li[r][c] = v / L[r][r];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j2 = i; j2 < 6; j2++) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = j2; k < 6; k++) v += Li[k][i] * Li[k][j2];
+            B[i][j2] = v;
+        }
     if (!ok) {
         atomicCAS(m.status, 0, -(a + 1));
 #pragma unroll
         for (int i = 0; i < 6; i++)
 #pragma unroll
-            for (int j = 0; j < 6; j++) B[i][j] = (i == j) ? 1.0 : 0.0;
+            for (int j2 = i; j2 < 6; j2++) B[i][j2] = (i == j2) ? 1.0 : 0.0;
     }
+    // the inverse of a symmetric block is symmetric: its upper triangle is stored (and applied), 21 words per node
 #pragma unroll
-    for (int j = 0; j < 6; j++)
+    for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int i = 0; i < 6; i++) mi[j * kSliceRows + i] = B[i][j];
+        for (int j = i; j < 6; j++) mi[minv_word(i, j) * kSliceNodes] = B[i][j];
 }
 
 void launch_block_jacobi(const DeviceMatrix &m, hipStream_t st)
@@ -396,10 +417,11 @@ struct MinvRow {
 };
 __device__ __forceinline__ MinvRow load_minv(const DeviceMatrix &m, int sl, int t)
 {
-    const double *mi = m.minv + (int64_t)sl * 6 * kSliceRows + t;
+    const int n = t / 6, i = t % 6;
+    const double *mi = m.minv + (int64_t)sl * kMinvWords * kSliceNodes + n;
     MinvRow r;
 #pragma unroll
-    for (int j = 0; j < 6; j++) r.a[j] = mi[j * kSliceRows];
+    for (int j = 0; j < 6; j++) r.a[j] = mi[minv_word(i < j ? i : j, i < j ? j : i) * kSliceNodes];
     return r;
 }
 __device__ __forceinline__ double apply_minv(const MinvRow &mr, int t, const double *rs)

@@ -40,7 +40,7 @@ struct DeviceMatrix {
     double *vals = nullptr;             // total_slots x 36, sliced layout
     const double *rhs_loads = nullptr;  // n_pad x 6 nodal loads and
     double *rhs_F = nullptr;            // the right-hand side k_assemble fills beside K (nullptr: K only)
-    double *minv = nullptr;             // n_slices x 6 x 192: inverse diagonal blocks
+    double *minv = nullptr;             // n_slices x 21 x 32: upper triangles of the inverse diagonal blocks
     unsigned long long *stamps = nullptr; // profiling builds of k_assemble only (tools/lab)
     int32_t *status = nullptr;          // device int: 0 ok, e+1 = first degenerate local element,
                                         // -(node+1) = singular diagonal block
