@@ -355,7 +355,11 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
         }
         const int64_t row = (int64_t)sl * kSliceRows + (t & 31) * 6 + (t >> 5);
         y[row] = acc;
-        if (partials != nullptr) dotv += acc * x[row];
+        if (partials != nullptr) {
+            // x[row] is in LDS already: slot 0 is the diagonal block, its column is the lane's own node
+            const double2 xw = xs[t >> 6]; // word (t / 32) / 2 of the node's six entries
+            dotv += acc * (((t >> 5) & 1) ? xw.y : xw.x);
+        }
     }
     if (partials != nullptr) {
         const double tot = block_sum(dotv, sh);
