@@ -560,3 +560,48 @@ def test_tiny_meshes():
         u0 = oracle.direct_solve(r0, c0, v0, F0)
         assert info["converged"] == 1
         assert np.linalg.norm(u.ravel() - u0) <= 1e-10 * np.linalg.norm(u0)
+
+
+def test_context_reuse_new_mesh_new_constraints():
+    """One context, used the way a long-running program would: a mesh, a solve, a different (larger, mixed) mesh on
+    the same context, a change of the Dirichlet set after assembly, a change of the loads only; every state must
+    equal what a fresh context computes."""
+    def fresh(m, nu, E, t, dmask, loads):
+        fs_ = pkg.FemShell(nu, E, t)
+        fs_.set_mesh(m.xyz, m.tri, m.quad)
+        fs_.set_dirichlet(dmask)
+        fs_.set_loads(loads)
+        u_, info_ = fs_.solve(rtol=1e-12, max_it=100000)
+        assert info_["converged"] == 1
+        return u_, fs_.export_bsr()
+
+    rng = np.random.default_rng(3)
+    a = meshes.structured(9, 7, 0, 0, 3, 2, kind="t", ul_lr=True, bcids=(0, -1, 1, -1), factor=2.0, loading=2)
+    b = meshes.structured(37, 41, 0, 0, 5, 6, kind="q", bcids=(1, -1, -1, 0), factor=1.0, loading=2)
+    fs = pkg.FemShell(0.3, 2.0e5, 0.05)
+    for m in (a, b, a):  # smaller -> larger -> smaller again: every device buffer is re-sized both ways
+        dmask, loads = m.dirichlet_mask(), m.loads
+        fs.set_mesh(m.xyz, m.tri, m.quad)
+        fs.set_dirichlet(dmask)
+        fs.set_loads(loads)
+        u, info = fs.solve(rtol=1e-12, max_it=100000)
+        u_ref, (r0, c0, v0, F0) = fresh(m, 0.3, 2.0e5, 0.05, dmask, loads)
+        assert info["converged"] == 1
+        np.testing.assert_array_equal(u, u_ref)  # same kernels, same data: bitwise
+        # new Dirichlet set on the assembled context (constraint words, K, F and the Jacobi blocks must follow)
+        dmask2 = dmask.copy()
+        dmask2[rng.integers(0, m.n_nodes, 4)] |= 0x15
+        fs.set_dirichlet(dmask2)
+        u2, _ = fs.solve(rtol=1e-12, max_it=100000)
+        u2_ref, (r2, c2, v2, F2) = fresh(m, 0.3, 2.0e5, 0.05, dmask2, loads)
+        np.testing.assert_array_equal(u2, u2_ref)
+        rg, cg, vg, Fg = fs.export_bsr()
+        np.testing.assert_array_equal(vg, v2)
+        np.testing.assert_array_equal(Fg, F2)
+        # new loads only: K is kept, the right-hand side is rebuilt
+        loads3 = rng.normal(size=loads.shape)
+        fs.set_loads(loads3)
+        u3, info3 = fs.solve(rtol=1e-12, max_it=100000)
+        u3_ref, _ = fresh(m, 0.3, 2.0e5, 0.05, dmask2, loads3)
+        assert info3["assemble_seconds"] == 0.0
+        np.testing.assert_array_equal(u3, u3_ref)
