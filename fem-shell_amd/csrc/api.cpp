@@ -56,9 +56,9 @@ double bytes_update_single_reduction(const femshell_ctx *c) { return (11.0 * 48.
 
 int check_status(femshell_ctx *c, const char *what)
 {
-    int32_t st = 0;
-    FS_HIP(hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(hipMemcpyAsync(c->status_host, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     FS_HIP(hipStreamSynchronize(c->stream));
+    const int32_t st = *c->status_host;
     if (st == 0) return FEMSHELL_OK;
     FS_HIP(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), c->stream));
     char buf[160];
@@ -198,11 +198,12 @@ int femshell_create(const femshell_config *cfg, femshell_ctx **out)
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = c->status.alloc(1);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->status_host), sizeof(int32_t), hipHostMallocDefault);
     if (e == hipSuccess) e = c->status.zero(c->stream);
     if (e == hipSuccess) e = c->scal.alloc(1);
     if (e == hipSuccess) e = c->scal.zero(c->stream);
     if (e != hipSuccess) {
-        delete c;
+        (void)femshell_destroy(c); // releases whatever was created
         return set_err(FEMSHELL_ERR_HIP, std::string("femshell_create: ") + hipGetErrorString(e));
     }
     const double nu = cfg->nu, E = cfg->E, t = cfg->thickness;
@@ -227,6 +228,7 @@ int femshell_destroy(femshell_ctx *c)
     if (c->ev_p_ready) (void)hipEventDestroy(c->ev_p_ready);
     if (c->ev_halo_done) (void)hipEventDestroy(c->ev_halo_done);
     if (c->halo_stream) (void)hipStreamDestroy(c->halo_stream);
+    if (c->status_host) (void)hipHostFree(c->status_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);

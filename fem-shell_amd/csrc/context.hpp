@@ -62,6 +62,7 @@ struct femshell_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int32_t *status_host = nullptr; // pinned landing place of the device status word
     // halo exchange beside the interior SpMV (multi-rank contexts): second stream + hand-off events
     hipStream_t halo_stream = nullptr;
     hipEvent_t ev_p_ready = nullptr, ev_halo_done = nullptr;
