@@ -217,7 +217,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "elements assembled/s + CG iters/s, 4M-tri shell",
+            "metric": "elements assembled/s + CG iters/s, 4M-tri shell, 1/2/4/8 MI355X",
             "value": n_elem * args.steps / t_asm,
             "unit": "elements/s",
             "cg_iters_per_s": info["iterations"] / t_cg,
