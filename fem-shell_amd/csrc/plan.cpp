@@ -240,8 +240,10 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     // ---- per-slice element lists and slice-relative 16-bit gather entries
     p.slice_elem_ptr.assign((size_t)p.n_slices + 1, 0);
     p.pairs16.resize(p.pairs.size());
+    p.slice_elems.reserve(p.pairs.size() / 4 + 1024);
+    p.slice_elem_nodes.reserve(p.pairs.size() + 4096);
     {
-        std::vector<int32_t> ids;
+        std::vector<int32_t> ids, placed;
         for (int32_t s = 0; s < p.n_slices; s++) {
             const int32_t q0 = p.pair_ptr[p.slice_base[s]], q1 = p.pair_ptr[p.slice_base[s + 1]];
             ids.clear();
@@ -261,11 +263,9 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                 const int32_t idx = lds_pos((int32_t)(std::lower_bound(ids.begin(), ids.end(), le) - ids.begin()));
                 p.pairs16[q] = (uint16_t)((idx << 4) | (p.pairs[q] & 15u));
             }
-            {
-                std::vector<int32_t> placed(ids.size());
-                for (size_t r = 0; r < ids.size(); r++) placed[lds_pos((int32_t)r)] = ids[r];
-                ids.swap(placed);
-            }
+            placed.resize(ids.size());
+            for (size_t r = 0; r < ids.size(); r++) placed[lds_pos((int32_t)r)] = ids[r];
+            ids.swap(placed);
             p.slice_elems.insert(p.slice_elems.end(), ids.begin(), ids.end());
             for (int32_t le : ids) {
                 if (le < p.n_ltri()) {
@@ -282,7 +282,16 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     // ---- assembly work items
     p.item_ptr.assign((size_t)p.n_slices + 1, 0);
     {
-        std::vector<Plan::Item> tmp;
+        std::vector<Plan::Item> tmp, sorted;
+        p.items.reserve((size_t)p.n_slices * 256 + 1024);
+        // stable order by decreasing number of contributions (0..kItemPairs): a bucket pass, no allocation
+        auto order_by_work = [&](std::vector<Plan::Item> &v, size_t begin) {
+            sorted.clear();
+            for (int np = kItemPairs; np >= 0; np--)
+                for (size_t i = begin; i < v.size(); i++)
+                    if ((int)(v[i].z >> 16) == np) sorted.push_back(v[i]);
+            std::copy(sorted.begin(), sorted.end(), v.begin() + begin);
+        };
         for (int32_t s = 0; s < p.n_slices; s++) {
             tmp.clear();
             int32_t stage = 0;
@@ -310,8 +319,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                 }
             if (tmp.size() <= 256) {
                 // one round: order by decreasing work so that the waves are uniform
-                std::stable_sort(tmp.begin(), tmp.end(),
-                                 [](const Plan::Item &a, const Plan::Item &b) { return (a.z >> 16) > (b.z >> 16); });
+                order_by_work(tmp, 0);
             } else {
                 // several rounds of 256 items: a slot's chunks must share a round (they meet in LDS),
                 // so fill rounds greedily with whole slots, then order each round by work
@@ -325,8 +333,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                         for (size_t c = 0; c < nch; c++) packed.push_back(tmp[i + c]);
                         i += nch;
                     }
-                    std::stable_sort(packed.begin() + round_begin, packed.end(),
-                                     [](const Plan::Item &a, const Plan::Item &b) { return (a.z >> 16) > (b.z >> 16); });
+                    order_by_work(packed, round_begin);
                     if (i < tmp.size()) {
                         Plan::Item pad{0xffffu, 0, 0, 0}; // inert item: slot 0xffff, chunk 0, 0 chunks
                         while (packed.size() - round_begin < 256) packed.push_back(pad);
