@@ -87,3 +87,14 @@ def test_classic_and_single_reduction_recurrences_agree_across_ranks(tmp_path):
     assert abs(int(a["iterations"]) - int(b["iterations"])) <= 3
     err = np.linalg.norm(a["u"] - b["u"]) / np.linalg.norm(b["u"])
     assert err < 1e-8, err
+
+
+def test_real_rccl_accepts_the_stream_usage_of_the_cg_driver():
+    """Real librccl, one rank talking to itself: grouped send/recv on a second stream behind an event, all-reduces
+    on the main stream, alternating on one communicator -- the pattern of cg_driver.cpp with the halo overlap on."""
+    probe_dir = os.path.join(ROOT, "tests", "helpers", "rccl_probe")
+    subprocess.check_call(["make", "-C", probe_dir, "-s"])
+    out = subprocess.run([os.path.join(probe_dir, "two_streams"), "300"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         timeout=120)
+    assert out.returncode == 0, out.stdout.decode(errors="replace")[-2000:]
+    assert b"two_streams ok" in out.stdout
