@@ -291,10 +291,14 @@ __device__ __forceinline__ void spmv_load(SpmvChunk<kChunk> &c, const double2 *_
 #pragma unroll
     for (int q = 0; q < kChunk; q++) {
         if (k0 + q < W) {
-            const double2 *vv = v + (size_t)(k0 + q) * 3 * kSliceRows;
-            c.a[q][0] = vv[0];
-            c.a[q][1] = vv[kSliceRows];
-            c.a[q][2] = vv[2 * kSliceRows];
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const v2d *vv = reinterpret_cast<const v2d *>(v + (size_t)(k0 + q) * 3 * kSliceRows);
+            // K is read once per launch: non-temporal loads leave the caches to x
+            const v2d w0 = __builtin_nontemporal_load(vv), w1 = __builtin_nontemporal_load(vv + kSliceRows),
+                      w2 = __builtin_nontemporal_load(vv + 2 * kSliceRows);
+            c.a[q][0] = make_double2(w0.x, w0.y);
+            c.a[q][1] = make_double2(w1.x, w1.y);
+            c.a[q][2] = make_double2(w2.x, w2.y);
         } else {
 #pragma unroll
             for (int t = 0; t < 3; t++) c.a[q][t] = make_double2(0.0, 0.0);
