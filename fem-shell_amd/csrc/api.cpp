@@ -327,9 +327,7 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     c->dm.max_stage_rows = p.max_stage_rows;
     {
         // LDS of k_assemble: element records + partial-sum staging
-        int32_t max_items = 0;
-        for (int32_t s = 0; s < p.n_slices; s++) max_items = std::max(max_items, p.item_ptr[s + 1] - p.item_ptr[s]);
-        const size_t lds = assemble_lds_layout(c->dm, p.max_slice_elems, p.max_stage_rows, max_items);
+        const size_t lds = assemble_lds_layout(c->dm, p.max_slice_elems, p.max_stage_rows, p.n_lquad() > 0);
         if (p.max_slice_width > 64) return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_set_mesh: a node has more than 63 neighbours");
         if (lds > 160 * 1024) // one workgroup per CU at most; well-numbered meshes need about 50 KB (three per CU)
             return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_set_mesh: a 32-node slice touches too many elements for the LDS staging");

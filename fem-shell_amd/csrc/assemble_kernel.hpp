@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
     extern __shared__ double lds[];
     double *lds_rec = lds + m.lds_rec_off;
     double *lds_stage = lds + m.lds_stage_off;
+    constexpr int kRec = kHasQuads ? kRecDoublesQuad : kRecDoubles; // doubles per element record in LDS
     const int tid = threadIdx.x;
     // element records are built by the lanes counted from the END of the workgroup (element i of the slice by lane
     // 255 - i): the diagonal slots' work items, three contributions each, sit in the first wave, which would
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         // ---- phase A: one record per element touching the slice
         for (int i = etid; i < ne; i += blockDim.x) {
             const int4 c = (i == etid) ? nd : m.slice_elem_nodes[e0 + i];
-            double rec[kRecDoubles];
+            double rec[kRec];
             bool ok = false;
             if (!kHasQuads || c.w < 0) {
                 double X[9];
@@ -158,10 +159,14 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                 }
                 if (kAblate & 8) {
 #pragma unroll
-                    for (int q = 0; q < kRecDoubles; q++) rec[q] = 1.0 + 0.01 * q + X[q % 9] * 1e-9;
+                    for (int q = 0; q < kRec; q++) rec[q] = 1.0 + 0.01 * q + X[q % 9] * 1e-9;
                     ok = true;
                 } else {
                     ok = tri3_record(X, mc, rec);
+                    if (kHasQuads) {
+#pragma unroll
+                        for (int q = kRecDoubles; q < kRec; q++) rec[q] = 0.0;
+                    }
                 }
             } else {
                 double X[12];
@@ -176,9 +181,9 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                 ok = quad4_record(X, mc, rec);
             }
             if (!ok) atomicCAS(m.status, 0, e0 + i + 1);
-            double2 *dst = reinterpret_cast<double2 *>(lds_rec + (size_t)i * kRecDoubles);
+            double2 *dst = reinterpret_cast<double2 *>(lds_rec + (size_t)i * kRec);
 #pragma unroll
-            for (int q = 0; q < kRecDoubles / 2; q++) dst[q] = make_double2(rec[2 * q], rec[2 * q + 1]);
+            for (int q = 0; q < kRec / 2; q++) dst[q] = make_double2(rec[2 * q], rec[2 * q + 1]);
         }
         stamp(0); // phase A (coordinate gather + record math + LDS writes)
         lds_barrier();
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
             for (int i = 0; i < 36; i++) blk[i] = 0.0;
             for (int q = 0; q < cnt; q++) {
                 const uint32_t pr = (q == 0) ? (item.y & 0xffffu) : (q == 1 ? (item.y >> 16) : (item.z & 0xffffu));
-                const double *rec = lds_rec + ((kAblate & 2) ? 0 : (size_t)(pr >> 4) * kRecDoubles);
+                const double *rec = lds_rec + ((kAblate & 2) ? 0 : (size_t)(pr >> 4) * kRec);
                 if (kAblate & 4) {
 #pragma unroll
                     for (int i = 0; i < 26; i++) blk[i] += rec[i];

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(128) void k_element_matrices(DeviceMatrix m, MatCon
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)count * nb) return;
     const int e = (int)(t / nb), pr = (int)(t % nb), ia = pr / nn, ib = pr % nn;
-    double rec[kRecDoubles];
+    double rec[kRecDoublesQuad];
     bool ok;
     if (!quads) {
         const int32_t *c = m.tri + 3 * (int64_t)(first + e);

@@ -48,12 +48,12 @@ struct DeviceMatrix {
 
 // LDS layout of k_assemble for a plan with at most max_slice_elems element records and max_stage_rows partial-sum
 // rows per slice: [records | partial sums].  Returns the dynamic LDS size in bytes.
-inline size_t assemble_lds_layout(DeviceMatrix &m, int32_t max_slice_elems, int32_t max_stage_rows, int32_t max_slice_items)
+inline size_t assemble_lds_layout(DeviceMatrix &m, int32_t max_slice_elems, int32_t max_stage_rows, bool has_quads)
 {
-    (void)max_slice_items;
+    const int rec = has_quads ? kRecDoublesQuad : kRecDoubles;
     m.lds_rec_off = 0;
-    m.lds_stage_off = max_slice_elems * kRecDoubles;
-    m.lds_bytes = (int32_t)(((size_t)max_slice_elems * kRecDoubles + (size_t)max_stage_rows * 36) * sizeof(double));
+    m.lds_stage_off = max_slice_elems * rec;
+    m.lds_bytes = (int32_t)(((size_t)max_slice_elems * rec + (size_t)max_stage_rows * 36) * sizeof(double));
     return (size_t)m.lds_bytes;
 }
 // Scalars of the CG recurrence, resident in HBM (no host round trip per iteration).

@@ -109,6 +109,10 @@ constexpr int kRecKind = 16;    // 1.0 = TRI3, 2.0 = QUAD4, 0.0 = degenerate
 // [17..22] QQ (symmetric: 00,01,02,11,12,22)  [23..31] QC (row-major 3x3)  [32..37] CC (symmetric)
 constexpr int kRecQQ = 17, kRecQC = 23, kRecCC = 32;
 constexpr int kQuadX = 18, kQuadY = 22; // QUAD4 records: local x and y of the four nodes
+// Records of meshes with quadrilaterals are 46 doubles (again 2*odd): a QUAD4 record also carries, per Gauss point g,
+// the inverse Jacobian (four numbers) and its determinant at [kQuadGp + 5 g ..]
+constexpr int kRecDoublesQuad = 46;
+constexpr int kQuadGp = 26;
 // index of entry (n,m) of a symmetric 3x3 table stored as 00,01,02,11,12,22
 __device__ __forceinline__ int sym3(int n, int m)
 {
@@ -310,11 +314,11 @@ __device__ __forceinline__ void tri3_block_add_rec(const double *rec, int ia, in
 // =========================================================================================
 
 // SA:342-375: frame from the mid-side points; local coordinates are T*X without translation.
-__device__ __forceinline__ bool quad4_record(const double X[12], const MatConst &mc, double rec[kRecDoubles])
+__device__ __forceinline__ bool quad4_record(const double X[12], const MatConst &mc, double rec[kRecDoublesQuad])
 {
     (void)mc;
 #pragma unroll
-    for (int i = 0; i < kRecDoubles; i++) rec[i] = 0.0;
+    for (int i = 0; i < kRecDoublesQuad; i++) rec[i] = 0.0;
     double ex[3], ey[3], ez[3], vr[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
@@ -357,6 +361,27 @@ __device__ __forceinline__ bool quad4_record(const double X[12], const MatConst 
 #pragma unroll
     for (int n = 0; n < 4; n++) a2 += rec[kQuadX + n] * rec[kQuadY + (n + 1) % 4] - rec[kQuadX + (n + 1) % 4] * rec[kQuadY + n];
     if (!(fabs(a2) > 0.0)) return false;
+    // Jacobian of the bilinear map at the four Gauss points (SA:482-487 order; SA:489-538 and SA:641-684 use the
+    // same four numbers), its inverse and determinant
+    {
+        const double *x = rec + kQuadX, *y = rec + kQuadY;
+        const double x12 = x[0] - x[1], y12 = y[0] - y[1], x23 = x[1] - x[2], y23 = y[1] - y[2];
+        const double x34 = x[2] - x[3], y34 = y[2] - y[3], x41 = x[3] - x[0], y41 = y[3] - y[0];
+        const double root = 0.57735026918962576451; // sqrt(1/3)
+#pragma unroll
+        for (int gp = 0; gp < 4; gp++) {
+            const double r = (gp & 2) ? -root : root, s = (gp & 1) ? -root : root;
+            const double J00 = 0.25 * ((x12 + x34) * s - x12 + x34), J01 = 0.25 * ((y12 + y34) * s - y12 + y34);
+            const double J10 = 0.25 * ((x12 + x34) * r - x23 + x41), J11 = 0.25 * ((y12 + y34) * r - y23 + y41);
+            const double det = J00 * J11 - J01 * J10, idet = 1.0 / det;
+            double *g = rec + kQuadGp + 5 * gp;
+            g[0] = J11 * idet;
+            g[1] = -J01 * idet;
+            g[2] = -J10 * idet;
+            g[3] = J00 * idet;
+            g[4] = det;
+        }
+    }
     rec[kRecKind] = 2.0;
     return true;
 }
@@ -403,12 +428,6 @@ __device__ __forceinline__ void dkq_node_block(const DkqSide &sa, const DkqSide 
 __device__ __forceinline__ void quad4_block_add_rec(const double *rec, int ia, int ib, const MatConst &mc,
                                                     double acc[36])
 {
-    double x[4], y[4];
-#pragma unroll
-    for (int n = 0; n < 4; n++) {
-        x[n] = rec[kQuadX + n];
-        y[n] = rec[kQuadY + n];
-    }
     // node data by dynamic index straight from the record (LDS or registers), no selects
     const int ia_p = (ia + 3) & 3, ia_n = (ia + 1) & 3, ib_p = (ib + 3) & 3, ib_n = (ib + 1) & 3;
     const double xi_ = rec[kQuadX + ia], yi_ = rec[kQuadY + ia], xj_ = rec[kQuadX + ib], yj_ = rec[kQuadY + ib];
@@ -420,8 +439,6 @@ __device__ __forceinline__ void quad4_block_add_rec(const double *rec, int ia, i
     // natural coordinates of the corner nodes: (-1,-1), (1,-1), (1,1), (-1,1)
     const double ri = (ia == 1 || ia == 2) ? 1.0 : -1.0, si = (ia >= 2) ? 1.0 : -1.0;
     const double rj = (ib == 1 || ib == 2) ? 1.0 : -1.0, sj = (ib >= 2) ? 1.0 : -1.0;
-    const double x12 = x[0] - x[1], y12 = y[0] - y[1], x23 = x[1] - x[2], y23 = y[1] - y[2];
-    const double x34 = x[2] - x[3], y34 = y[2] - y[3], x41 = x[3] - x[0], y41 = y[3] - y[0];
     const DkqSide sa_i = dkq_side(xa_i, ya_i), sb_i = dkq_side(xb_i, yb_i), sa_j = dkq_side(xa_j, ya_j),
                   sb_j = dkq_side(xb_j, yb_j);
 
@@ -431,17 +448,16 @@ __device__ __forceinline__ void quad4_block_add_rec(const double *rec, int ia, i
 #pragma unroll 1
     for (int gp = 0; gp < 4; gp++) {
         const double r = (gp & 2) ? -root : root, s = (gp & 1) ? -root : root; // SA:482-487 order
-        // the Jacobian of the bilinear map at this Gauss point serves the membrane (SA:489-538) and the plate
-        // (SA:641-684): both formulas of the reference give the same four numbers
-        const double J00 = 0.25 * ((x12 + x34) * s - x12 + x34), J01 = 0.25 * ((y12 + y34) * s - y12 + y34);
-        const double J10 = 0.25 * ((x12 + x34) * r - x23 + x41), J11 = 0.25 * ((y12 + y34) * r - y23 + y41);
-        const double det = J00 * J11 - J01 * J10, idet = 1.0 / det;
+        // inverse Jacobian and determinant of this Gauss point from the record
+        const double *gq = rec + kQuadGp + 5 * gp;
+        const double Ji[4] = {gq[0], gq[1], gq[2], gq[3]};
+        const double det = gq[4];
         // ---- membrane
         {
             const double dri = 0.25 * ri * (1.0 + si * s), dsi = 0.25 * si * (1.0 + ri * r);
             const double drj = 0.25 * rj * (1.0 + sj * s), dsj = 0.25 * sj * (1.0 + rj * r);
-            const double bi = (J11 * dri - J01 * dsi) * idet, gi = (-J10 * dri + J00 * dsi) * idet; // dN/dx, dN/dy
-            const double bj = (J11 * drj - J01 * dsj) * idet, gj = (-J10 * drj + J00 * dsj) * idet;
+            const double bi = Ji[0] * dri + Ji[1] * dsi, gi = Ji[2] * dri + Ji[3] * dsi; // dN/dx, dN/dy
+            const double bj = Ji[0] * drj + Ji[1] * dsj, gj = Ji[2] * drj + Ji[3] * dsj;
             const double w = det * mc.t * mc.cm;
             m00 += w * (bi * bj + mc.g * gi * gj);
             m01 += w * (mc.nu * bi * gj + mc.g * gi * bj);
@@ -450,7 +466,6 @@ __device__ __forceinline__ void quad4_block_add_rec(const double *rec, int ia, i
         }
         // ---- plate
         {
-            const double Ji[4] = {J11 * idet, -J01 * idet, -J10 * idet, J00 * idet};
             // serendipity derivatives (SA:906-923): corner n, mid-side of side s (nodes 5..8)
             auto corner_x = [&](double rr, double ss) { return 0.25 * rr * (1.0 + s * ss) * (2.0 * r * rr + s * ss); };
             auto corner_e = [&](double rr, double ss) { return 0.25 * ss * (1.0 + r * rr) * (2.0 * s * ss + r * rr); };

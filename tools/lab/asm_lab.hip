@@ -48,7 +48,8 @@ int main(int argc, char **argv)
     {
         int32_t max_items = 0;
         for (int32_t s = 0; s < p.n_slices; s++) max_items = std::max(max_items, p.item_ptr[s + 1] - p.item_ptr[s]);
-        assemble_lds_layout(m, p.max_slice_elems, p.max_stage_rows, max_items);
+        (void)max_items;
+        assemble_lds_layout(m, p.max_slice_elems, p.max_stage_rows, false);
     }
     std::vector<uint8_t> dm(p.n_local_nodes(), 0); m.dmask = up(dm);
     std::vector<uint32_t> fl(p.items.size(), 0u); m.item_flags = up(fl); // no Dirichlet nodes in the lab mesh
