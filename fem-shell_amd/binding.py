@@ -230,7 +230,8 @@ class FemShell:
 # ---- host-only plan inspection (include/femshell_plan.h); needs no GPU -----------------------
 
 PLAN_INFO = ["n_own", "n_pad", "n_ghost", "n_slices", "n_ltri", "n_lquad", "total_slots", "n_pairs",
-             "n_peers", "row_begin", "row_end", "nnz_blocks", "n_interior_slices"]
+             "n_peers", "row_begin", "row_end", "nnz_blocks", "n_interior_slices", "n_items",
+             "n_multi_round_slices", "max_slice_elems", "max_slice_width"]
 PLAN_ARRAYS = {
     "ghost_global": (0, np.int32), "tri_local": (1, np.int32), "tri_global_id": (2, np.int32),
     "quad_local": (3, np.int32), "quad_global_id": (4, np.int32), "slice_width": (5, np.int32),

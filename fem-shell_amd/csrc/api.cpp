@@ -289,6 +289,7 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     FS_HIP(c->items.upload(p.items, st));
     const size_t nrow = (size_t)p.n_pad * 6, nrow_ext = (size_t)p.n_local_nodes() * 6;
     FS_HIP(c->vals.alloc((size_t)p.total_slots() * 36));
+    FS_HIP(c->vals.zero(st)); // the padding slots of the ELL layout stay zero; assembly writes the real blocks only
     FS_HIP(c->minv.alloc((size_t)p.n_slices * 21 * kSliceNodes)); // upper triangles of the inverse diagonal blocks
     FS_HIP(c->F.alloc(nrow));
     FS_HIP(c->x.alloc(nrow));

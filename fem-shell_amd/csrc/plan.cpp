@@ -300,7 +300,8 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                 for (int n = 0; n < kSliceNodes; n++) {
                     const int64_t idx = Plan::slot_index(p.slice_base[s], k, n);
                     const int32_t q0 = p.pair_ptr[idx], cnt = p.pair_ptr[idx + 1] - q0;
-                    const int nchunks = std::max(1, (cnt + kItemPairs - 1) / kItemPairs);
+                    if (cnt == 0) continue; // padding slot: its zero block is written once, when K is allocated
+                    const int nchunks = (cnt + kItemPairs - 1) / kItemPairs;
                     if (nchunks > 255) return fail("a block slot has more than 765 contributions");
                     const int32_t stage0 = stage;
                     for (int c = 0; c < nchunks; c++) {

@@ -49,6 +49,12 @@ int femshell_plan_info(const femshell_plan *plan, int64_t *info)
     info[FEMSHELL_PLAN_ROW_END] = p.row_end;
     info[FEMSHELL_PLAN_NNZ_BLOCKS] = p.nnz_blocks;
     info[FEMSHELL_PLAN_N_INTERIOR_SLICES] = p.n_interior_slices;
+    info[FEMSHELL_PLAN_N_ITEMS] = (int64_t)p.items.size();
+    int64_t multi = 0;
+    for (int32_t s = 0; s < p.n_slices; s++) multi += (p.item_ptr[s + 1] - p.item_ptr[s]) > 256;
+    info[FEMSHELL_PLAN_N_MULTI_ROUND_SLICES] = multi;
+    info[FEMSHELL_PLAN_MAX_SLICE_ELEMS] = p.max_slice_elems;
+    info[FEMSHELL_PLAN_MAX_SLICE_WIDTH] = p.max_slice_width;
     return FEMSHELL_OK;
 }
 

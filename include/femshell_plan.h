@@ -27,6 +27,10 @@ enum {
     FEMSHELL_PLAN_N_LTRI, FEMSHELL_PLAN_N_LQUAD, FEMSHELL_PLAN_TOTAL_SLOTS, FEMSHELL_PLAN_N_PAIRS,
     FEMSHELL_PLAN_N_PEERS, FEMSHELL_PLAN_ROW_BEGIN, FEMSHELL_PLAN_ROW_END, FEMSHELL_PLAN_NNZ_BLOCKS,
     FEMSHELL_PLAN_N_INTERIOR_SLICES, /* slices that read no ghost column: multiplied while the halo is in flight */
+    FEMSHELL_PLAN_N_ITEMS,           /* assembly work items (<= 3 element contributions each) */
+    FEMSHELL_PLAN_N_MULTI_ROUND_SLICES, /* slices with more than 256 work items (several assembly rounds) */
+    FEMSHELL_PLAN_MAX_SLICE_ELEMS,   /* most elements any slice touches (LDS records) */
+    FEMSHELL_PLAN_MAX_SLICE_WIDTH,   /* widest slice (block slots per node row) */
     FEMSHELL_PLAN_INFO_COUNT
 };
 /* fills info[FEMSHELL_PLAN_INFO_COUNT] */
