@@ -21,7 +21,8 @@ SYMBOLS = [
     "femshell_get_solution", "femshell_residual_history", "femshell_element_matrices",
     "femshell_nnz_blocks", "femshell_export_bsr", "femshell_spmv", "femshell_row_begin",
     "femshell_row_end", "femshell_comm_unique_id", "femshell_comm_init", "femshell_time_kernel",
-    "femshell_sync",
+    "femshell_sync", "femshell_pc_defaults", "femshell_set_preconditioner", "femshell_amg_levels", "femshell_amg_level",
+    "femshell_amg_export",
 ]
 
 
@@ -39,7 +40,22 @@ class Config(C.Structure):
 class SolveInfo(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("rel_residual", C.c_double),
                 ("true_rel_residual", C.c_double), ("assemble_seconds", C.c_double), ("setup_seconds", C.c_double), ("solve_seconds", C.c_double),
-                ("bytes_per_iteration", C.c_double)]
+                ("bytes_per_iteration", C.c_double), ("pc_type", C.c_int32), ("amg_levels", C.c_int32),
+                ("pc_setup_seconds", C.c_double), ("operator_complexity", C.c_double)]
+
+
+class PcOptions(C.Structure):
+    _fields_ = [("type", C.c_int32), ("cycle", C.c_int32), ("smoother_degree", C.c_int32), ("coarse_degree", C.c_int32),
+                ("coarsest_nodes", C.c_int32), ("max_levels", C.c_int32), ("eig_ratio", C.c_double)]
+
+
+class AmgLevelInfo(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("n_coarse", C.c_int32), ("nnz_blocks", C.c_int64), ("p_blocks", C.c_int64),
+                ("lambda_max", C.c_double)]
+
+
+PC_BLOCK_JACOBI, PC_AMG = 0, 1
+CYCLE_V, CYCLE_K = 0, 1
 
 
 def library_path():
@@ -93,9 +109,17 @@ def load_library():
     L.femshell_comm_init.argtypes = [vp, bp]
     L.femshell_time_kernel.argtypes = [vp, C.c_int, C.c_int32, dp, dp]
     L.femshell_sync.argtypes = [vp]
+    L.femshell_pc_defaults.argtypes = [C.c_int32, C.POINTER(PcOptions)]
+    L.femshell_set_preconditioner.argtypes = [vp, C.POINTER(PcOptions)]
+    L.femshell_amg_levels.argtypes = [vp]
+    L.femshell_amg_levels.restype = C.c_int32
+    L.femshell_amg_level.argtypes = [vp, C.c_int32, C.POINTER(AmgLevelInfo)]
+    L.femshell_amg_export.argtypes = [vp, C.c_int32, C.c_int32, C.c_void_p]
+    L.femshell_amg_export.restype = C.c_int64
     for name in SYMBOLS:
         if name != "femshell_last_error" and not name.startswith("femshell_nnz") and \
-                not name.startswith("femshell_row") and name != "femshell_residual_history":
+                not name.startswith("femshell_row") and name != "femshell_residual_history" and \
+                name not in ("femshell_amg_levels", "femshell_amg_export"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -226,6 +250,44 @@ class FemShell:
     def sync(self):
         _check(self._L.femshell_sync(self._h))
 
+    def set_preconditioner(self, kind="amg", **options):
+        """kind: "jacobi" (6x6 block-Jacobi, the default) or "amg" (smoothed-aggregation multigrid);
+        options: cycle ("V"/"K"), smoother_degree, coarse_degree, coarsest_nodes, max_levels, eig_ratio."""
+        o = PcOptions()
+        _check(self._L.femshell_pc_defaults(PC_AMG if kind == "amg" else PC_BLOCK_JACOBI, C.byref(o)))
+        for k, v in options.items():
+            if k == "cycle":
+                v = CYCLE_K if str(v).upper() == "K" else CYCLE_V
+            if not hasattr(o, k):
+                raise TypeError("unknown preconditioner option " + k)
+            setattr(o, k, v)
+        _check(self._L.femshell_set_preconditioner(self._h, C.byref(o)))
+
+    def amg_levels(self):
+        """Per-level facts of the multigrid hierarchy of the last solve (empty with block-Jacobi)."""
+        out = []
+        for l in range(self._L.femshell_amg_levels(self._h)):
+            info = AmgLevelInfo()
+            _check(self._L.femshell_amg_level(self._h, l, C.byref(info)))
+            out.append({f[0]: getattr(info, f[0]) for f in AmgLevelInfo._fields_})
+        return out
+
+    def amg_export(self, level):
+        """Host copies of a level (small problems): dict with agg, A (rowptr, cols, vals), P (rowptr, cols, vals)."""
+        names = {"agg": (0, np.int32), "A_rowptr": (1, np.int64), "A_cols": (2, np.int32), "A_vals": (3, np.float64),
+                 "P_rowptr": (4, np.int64), "P_cols": (5, np.int32), "P_vals": (6, np.float64)}
+        out = {}
+        for name, (which, dt) in names.items():
+            n = self._L.femshell_amg_export(self._h, level, which, None)
+            if n < 0:
+                out[name] = None
+                continue
+            a = np.zeros(n, dtype=dt)
+            if n:
+                self._L.femshell_amg_export(self._h, level, which, a.ctypes.data_as(C.c_void_p))
+            out[name] = a.reshape(-1, 6, 6) if name.endswith("vals") else a
+        return out
+
 
 # ---- host-only plan inspection (include/femshell_plan.h); needs no GPU -----------------------
 
@@ -273,3 +335,84 @@ def build_plan(xyz, tri=None, quad=None, rank=0, world_size=1):
     finally:
         L.femshell_plan_destroy(h)
     return out
+
+
+# ---- host-only pieces of the multigrid setup (include/femshell_plan.h); need no GPU --------------------------
+
+COARSEN_ARRAYS = {"agg": (0, np.int32), "P_rowptr": (1, np.int64), "P_cols": (2, np.int32), "P_vals": (3, np.float64),
+                  "Ac_rowptr": (4, np.int64), "Ac_cols": (5, np.int32), "Ac_vals": (6, np.float64), "Bc": (7, np.float64)}
+
+
+def amg_host_rbm(xyz, dmask=None):
+    L = load_library()
+    L.femshell_amg_host_rbm.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_double)]
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    dm = None if dmask is None else np.ascontiguousarray(dmask, dtype=np.uint8)
+    B = np.zeros((len(xyz), 6, 6))
+    _check(L.femshell_amg_host_rbm(len(xyz), _d(xyz), _b(dm), _d(B)))
+    return B
+
+
+def amg_host_coarsen(rowptr, colidx, vals, B, lambda_max):
+    """One coarsening step of the library's host setup: dict with agg, P (BSR arrays), Ac (BSR arrays), Bc."""
+    L = load_library()
+    L.femshell_amg_host_coarsen.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                                            C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_void_p)]
+    L.femshell_amg_coarsening_destroy.argtypes = [C.c_void_p]
+    L.femshell_amg_coarsening_destroy.restype = None
+    L.femshell_amg_coarsening_array.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.femshell_amg_coarsening_array.restype = C.c_int64
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    h = C.c_void_p()
+    _check(L.femshell_amg_host_coarsen(len(rowptr) - 1, _i(rowptr), _i(colidx), _d(vals), _d(B), float(lambda_max), C.byref(h)))
+    try:
+        out = {}
+        for name, (which, dt) in COARSEN_ARRAYS.items():
+            n = L.femshell_amg_coarsening_array(h, which, None)
+            a = np.zeros(n, dtype=dt)
+            if n:
+                L.femshell_amg_coarsening_array(h, which, a.ctypes.data_as(C.c_void_p))
+            out[name] = a
+    finally:
+        L.femshell_amg_coarsening_destroy(h)
+    out["P_vals"] = out["P_vals"].reshape(-1, 6, 6)
+    out["Ac_vals"] = out["Ac_vals"].reshape(-1, 6, 6)
+    out["Bc"] = out["Bc"].reshape(-1, 6, 6)
+    return out
+
+
+def amg_host_dense_inverse(rowptr, colidx, vals):
+    L = load_library()
+    L.femshell_amg_host_dense_inverse.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                                                  C.POINTER(C.c_double)]
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    n = 6 * (len(rowptr) - 1)
+    inv = np.zeros((n, n))
+    _check(L.femshell_amg_host_dense_inverse(len(rowptr) - 1, _i(rowptr), _i(colidx), _d(vals), _d(inv)))
+    return inv
+
+
+def amg_host_pack(rowptr, colidx, vals, diag_first):
+    """Sliced block ELL image of a BSR matrix: (slice_width, slice_base, cols, ell_vals)."""
+    L = load_library()
+    L.femshell_amg_host_pack.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int32,
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.femshell_amg_host_pack.restype = C.c_int64
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    n = len(rowptr) - 1
+    total = L.femshell_amg_host_pack(n, _i(rowptr), _i(colidx), _d(vals), int(diag_first), None, None, None, None)
+    ns = (n + 31) // 32
+    sw = np.zeros(ns, dtype=np.int32)
+    sb = np.zeros(ns + 1, dtype=np.int64)
+    cols = np.zeros(total, dtype=np.int32)
+    ev = np.zeros(total * 36)
+    L.femshell_amg_host_pack(n, _i(rowptr), _i(colidx), _d(vals), int(diag_first), _i(sw),
+                             sb.ctypes.data_as(C.POINTER(C.c_int64)), _i(cols), _d(ev))
+    return sw, sb, cols, ev

@@ -1,0 +1,83 @@
+// amg.hpp -- smoothed-aggregation multigrid preconditioner of the CG solve (opt-in; the default stays the 6x6
+// block-Jacobi preconditioner whose iterates are the oracle's).
+//
+// Why it exists: the reference hands K u = F to PETSc's KSP with whatever -ksp_type/-pc_type the user passes
+// (fem-shell.cpp:130-138, doc/implementation.tex:68-72).  With point-block Jacobi the iteration count of the shell
+// systems grows with the element count (x3.7 per mesh doubling): about 1e6 iterations on the
+// 4M-triangle meshes of BASELINE.json.  The hierarchy below keeps it near 100.
+//
+// Method (Vanek, Mandel, Brezina 1996): every level is again a matrix of 6x6 node blocks, so the sliced block ELL
+// layout, k_spmv and the block-Jacobi kernels serve all levels.
+//   * near-null space B: the six rigid-body modes of the shell (rows of fixed dofs zeroed)
+//   * greedy distance-1 aggregation of the block graph, tentative prolongator by a QR factorisation of B per
+//     aggregate (coarse B = the R factors), one damped block-Jacobi smoothing step P = (I - 4/(3 lam) D^-1 A) P0
+//   * Galerkin operators A_c = P^T A P
+//   * smoother: Chebyshev polynomial in D^-1 A (D = 6x6 diagonal blocks) on [lam/ratio, lam], lam from a power
+//     iteration on the device; coarsest level: explicit dense inverse
+//   * cycles: V, or K (two flexible-CG steps per coarse level, Notay & Vassilevski 2008) -- the 4th-order bending
+//     part loses a factor of about 2.3 in iterations per level with V cycles, the K cycle keeps the two-grid rate
+// The setup's sparse algebra (this file, amg_setup.cpp) runs on the host once per matrix; the cycle runs on the
+// device (amg_kernels.hip, amg_solve.cpp).
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace femshell {
+
+// block CSR with 6x6 blocks (row-major inside a block), columns ascending within a row
+struct Bsr {
+    int32_t nr = 0, nc = 0; // block rows / block columns
+    std::vector<int64_t> ptr;
+    std::vector<int32_t> col;
+    std::vector<double> val;
+    int64_t nnzb() const { return (int64_t)col.size(); }
+};
+
+// runs f(begin, end) over [0,n) split into contiguous chunks on the host's hardware threads
+void parallel_chunks(int64_t n, const std::function<void(int64_t, int64_t)> &f, int64_t min_chunk = 256);
+int host_threads();
+
+// rigid-body modes: B[n][6 dofs][6 modes] about the centroid of xyz; rows of fixed dofs (dmask bit v) are zero
+void rigid_body_modes(int32_t n, const double *xyz, const uint8_t *dmask, std::vector<double> *B);
+
+// greedy distance-1 aggregation of the block graph of A; returns the number of aggregates
+int32_t aggregate_nodes(const Bsr &A, std::vector<int32_t> *agg);
+
+// tentative prolongator: per aggregate B_agg = Q R (modified Gram-Schmidt, two passes; dependent columns give a
+// zero column of Q and a zero diagonal of R).  Q[n][6][6] (row block of node n, column block agg[n]),
+// Bc[na][6][6] = R
+void tentative_prolongator(const std::vector<int32_t> &agg, int32_t na, const std::vector<double> &B,
+                           std::vector<double> *Q, std::vector<double> *Bc);
+
+// inverse of the 6x6 diagonal blocks (Cholesky; identity for blocks that are not positive definite)
+void block_diagonal_inverse(const Bsr &A, std::vector<double> *Dinv);
+
+void bsr_multiply(const Bsr &A, const Bsr &B, Bsr *C);  // C = A B
+void bsr_transpose(const Bsr &A, Bsr *T);
+
+// P = P0 - omega * Dinv * (A * P0), P0 given by (agg, Q)
+void smoothed_prolongator(const Bsr &A, const std::vector<double> &Dinv, const std::vector<int32_t> &agg, int32_t na,
+                          const std::vector<double> &Q, double omega, Bsr *P);
+
+// Ac = P^T A P (R = P^T is returned too); coarse dofs without any fine support (zero column of P) get a unit diagonal
+void galerkin_product(const Bsr &A, const Bsr &P, Bsr *R, Bsr *Ac);
+
+// dense inverse of a small SPD block matrix (coarsest level), n = 6*A.nr; false when A is not positive definite
+bool dense_inverse(const Bsr &A, std::vector<double> *inv);
+
+// sliced block ELL image of a BSR matrix in the device layout of plan.hpp (32 block rows per slice; with
+// diag_first the diagonal block sits in slot 0 as k_block_jacobi expects); padding slots hold zero blocks and
+// point at column pad_col
+struct SlicedEll {
+    int32_t n_rows = 0, n_pad = 0, n_slices = 0, max_width = 0;
+    std::vector<int32_t> slice_width;
+    std::vector<int64_t> slice_base;
+    std::vector<int32_t> cols;
+    std::vector<double> vals;
+};
+void pack_sliced_ell(const Bsr &A, bool diag_first, SlicedEll *out);
+
+} // namespace femshell

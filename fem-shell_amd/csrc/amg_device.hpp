@@ -1,0 +1,59 @@
+// amg_device.hpp -- the multigrid hierarchy in HBM (amg_solve.cpp) as the context sees it.
+#pragma once
+
+#include <memory>
+#include <vector>
+
+#include "amg.hpp"
+#include "amg_kernels.hpp"
+#include "context.hpp"
+
+namespace femshell {
+
+// one sliced block ELL operator of the hierarchy (level matrix, prolongation or restriction)
+struct AmgOperator {
+    DevBuf<int32_t> slice_width, cols;
+    DevBuf<int64_t> slice_base;
+    DevBuf<double> vals;
+    DeviceMatrix dm{};      // the view k_spmv / k_block_jacobi take
+    int64_t nnzb = 0;       // real blocks
+    int32_t n_cols_pad = 0; // padded block columns = nodes of the input vector
+};
+
+struct AmgLevel {
+    int32_t n = 0, n_pad = 0; // nodes (6 dofs each) / padded to whole slices
+    int64_t nnzb = 0;         // blocks of the level matrix
+    AmgOperator A;            // levels >= 1 (level 0 is the context's K)
+    AmgOperator P, R;         // to / from the next coarser level (absent on the coarsest)
+    DevBuf<double> minv;      // block-Jacobi inverse of A (levels >= 1)
+    double lam = 0.0;         // upper bound of the spectrum of D^-1 A used by the smoother
+    double inv_theta = 0.0;
+    std::vector<double> cheb_a, cheb_c; // d = a d + c D^-1 r of Chebyshev steps 1 .. degree-1
+    DevBuf<double> b, x;      // right-hand side and correction (levels >= 1; level 0 works on the CG's r and z)
+    DevBuf<double> r, d, q;   // residual, Chebyshev direction, operator product
+    DevBuf<double> c1, v1, r2, c2, v2; // K cycle (levels >= 1)
+    DevBuf<KcycScalars> ks;
+    DevBuf<double> kscratch;
+    // host copies for the inspection exports (small problems only)
+    Bsr hA, hP;
+    std::vector<int32_t> agg;
+};
+
+struct Amg {
+    femshell_pc_options opt{};
+    std::vector<std::unique_ptr<AmgLevel>> levels;
+    DevBuf<double> coarse_inv; // dense inverse of the coarsest operator
+    bool valid = false;
+    double setup_seconds = 0.0;
+};
+
+void amg_default_options(femshell_pc_options *o);
+int amg_setup(femshell_ctx *c);
+// z = M(r): one multigrid cycle on the context's stream (all launches are no-ops once gate->done != 0)
+int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate);
+int cg_amg(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it);
+double amg_bytes_per_iteration(const femshell_ctx *c);
+// K of a single-rank context as host BSR with ascending columns (api.cpp)
+int download_matrix(femshell_ctx *c, Bsr *A);
+
+} // namespace femshell

@@ -1,0 +1,333 @@
+// amg_kernels.hip -- gfx950 vector kernels of the multigrid preconditioner (amg.hpp) and of the flexible PCG
+// around it.  All of them are HBM streaming kernels with one lane per scalar row of a 32-node slice, like the
+// CG kernels of kernels.hip; the level operators, restrictions and prolongations are multiplied by k_spmv.
+#include "amg_kernels.hpp"
+
+#include "device_common.hpp"
+
+namespace femshell {
+
+// ---- Chebyshev smoother ------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(192) void k_cheb_start(DeviceMatrix m, const double *__restrict__ rin, double *__restrict__ d,
+                                                    double *x, double inv_theta, int accumulate, const CgScalars *gate)
+{
+    __shared__ double rs[kSliceRows];
+    if (gate != nullptr && gate->done != 0) return;
+    const int t = threadIdx.x;
+    for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
+        const int sl = w.s;
+        const int64_t row = (int64_t)sl * kSliceRows + t;
+        const MinvRow mr = load_minv(m, sl, t);
+        const double rv = rin[row];
+        const double xv = accumulate ? x[row] : 0.0;
+        __syncthreads();
+        rs[t] = rv;
+        __syncthreads();
+        const double dv = inv_theta * apply_minv(mr, t, rs);
+        d[row] = dv;
+        x[row] = xv + dv;
+    }
+}
+
+void launch_cheb_start(const DeviceMatrix &m, const double *rin, double *d, double *x, double inv_theta, bool accumulate,
+                       const CgScalars *gate, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_cheb_start, dim3(slice_grid(m)), dim3(192), 0, st, m, rin, d, x, inv_theta, accumulate ? 1 : 0, gate);
+}
+
+__global__ __launch_bounds__(192) void k_cheb_step(DeviceMatrix m, const double *rin, const double *__restrict__ q,
+                                                   double *rout, double *__restrict__ d, double *__restrict__ x, double a,
+                                                   double c, const CgScalars *gate)
+{
+    __shared__ double rs[kSliceRows];
+    if (gate != nullptr && gate->done != 0) return;
+    const int t = threadIdx.x;
+    for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
+        const int sl = w.s;
+        const int64_t row = (int64_t)sl * kSliceRows + t;
+        const MinvRow mr = load_minv(m, sl, t);
+        const double rn = rin[row] - q[row];
+        const double dv = d[row], xv = x[row];
+        rout[row] = rn;
+        __syncthreads();
+        rs[t] = rn;
+        __syncthreads();
+        const double dn = a * dv + c * apply_minv(mr, t, rs);
+        d[row] = dn;
+        x[row] = xv + dn;
+    }
+}
+
+void launch_cheb_step(const DeviceMatrix &m, const double *rin, const double *q, double *rout, double *d, double *x,
+                      double a, double c, const CgScalars *gate, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_cheb_step, dim3(slice_grid(m)), dim3(192), 0, st, m, rin, q, rout, d, x, a, c, gate);
+}
+
+// ---- power iteration ---------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(192) void k_minv_apply_norm(DeviceMatrix m, const double *__restrict__ q, double *__restrict__ z,
+                                                         double *__restrict__ partials)
+{
+    __shared__ double rs[kSliceRows];
+    __shared__ double sh[3];
+    const int t = threadIdx.x;
+    double acc = 0.0;
+    for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
+        const int sl = w.s;
+        const int64_t row = (int64_t)sl * kSliceRows + t;
+        const MinvRow mr = load_minv(m, sl, t);
+        const double qv = q[row];
+        __syncthreads();
+        rs[t] = qv;
+        __syncthreads();
+        const double zv = apply_minv(mr, t, rs);
+        z[row] = zv;
+        acc += zv * zv;
+    }
+    const double tot = block_sum(acc, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+void launch_minv_apply_norm(const DeviceMatrix &m, const double *q, double *z, double *partials, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_minv_apply_norm, dim3(slice_grid(m)), dim3(192), 0, st, m, q, z, partials);
+}
+
+__global__ __launch_bounds__(256) void k_fill_hash(double *x, int64_t n_real, int64_t n_total)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_total; i += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t h = (uint64_t)i * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull;
+        h ^= h >> 29;
+        h *= 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 32;
+        const double u = (double)(h >> 11) * (1.0 / 9007199254740992.0); // [0,1)
+        x[i] = i < n_real ? 2.0 * u - 1.0 : 0.0;
+    }
+}
+
+void launch_fill_hash(double *x, int64_t n_real, int64_t n_total, hipStream_t st)
+{
+    const int64_t blocks = (n_total + 255) / 256;
+    hipLaunchKernelGGL(k_fill_hash, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, x, n_real, n_total);
+}
+
+// ---- coarsest level ----------------------------------------------------------------------------------------
+
+// one wave per row of the dense inverse (rows are read with consecutive lanes on consecutive words)
+__global__ __launch_bounds__(256) void k_dense_gemv(const double *__restrict__ A, const double *__restrict__ b,
+                                                    double *__restrict__ y, int n, int n_pad6, const CgScalars *gate)
+{
+    if (gate != nullptr && gate->done != 0) return;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_pad6) return;
+    double acc = 0.0;
+    if (row < n) {
+        const double *a = A + (int64_t)row * n;
+        for (int j = lane; j < n; j += 64) acc += a[j] * b[j];
+        acc = wave_sum(acc);
+    }
+    if (lane == 0) y[row] = acc;
+}
+
+void launch_dense_gemv(const double *Ainv, const double *b, double *y, int32_t n, int32_t n_pad6, const CgScalars *gate,
+                       hipStream_t st)
+{
+    hipLaunchKernelGGL(k_dense_gemv, dim3((n_pad6 + 3) / 4), dim3(256), 0, st, Ainv, b, y, n, n_pad6, gate);
+}
+
+// ---- flexible PCG ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(192) void k_pcg_init(DeviceMatrix m, CgVectors v)
+{
+    __shared__ double sh[3];
+    const int t = threadIdx.x;
+    double d1 = 0.0;
+    for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
+        const int64_t row = (int64_t)w.s * kSliceRows + t;
+        const double bv = v.b[row];
+        v.x[row] = 0.0;
+        v.r[row] = bv;
+        d1 += bv * bv;
+    }
+    const double t1 = block_sum(d1, sh);
+    if (threadIdx.x == 0) v.partials[blockIdx.x] = t1;
+}
+
+void launch_pcg_init(const DeviceMatrix &m, const CgVectors &v, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pcg_init, dim3(slice_grid(m)), dim3(192), 0, st, m, v);
+}
+
+__global__ __launch_bounds__(192) void k_pcg_update(DeviceMatrix m, CgVectors v)
+{
+    __shared__ double sh[3];
+    if (v.s->done != 0) return;
+    const int t = threadIdx.x;
+    const double alpha = v.s->alpha;
+    double d1 = 0.0;
+    for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
+        const int64_t row = (int64_t)w.s * kSliceRows + t;
+        const double pv = v.p[row], qv = v.q[row], xv = v.x[row], rv = v.r[row];
+        v.x[row] = xv + alpha * pv;
+        const double rn = rv - alpha * qv;
+        v.r[row] = rn;
+        d1 += rn * rn;
+    }
+    const double t1 = block_sum(d1, sh);
+    if (threadIdx.x == 0) v.partials[blockIdx.x] = t1;
+}
+
+void launch_pcg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pcg_update, dim3(slice_grid(m)), dim3(192), 0, st, m, v);
+}
+
+__global__ __launch_bounds__(192) void k_pcg_dots(DeviceMatrix m, CgVectors v)
+{
+    __shared__ double sh[3];
+    if (v.s->done != 0) return;
+    const int G = gridDim.x, t = threadIdx.x;
+    double d0 = 0.0, d2 = 0.0;
+    for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
+        const int64_t row = (int64_t)w.s * kSliceRows + t;
+        const double zv = v.z[row];
+        d0 += v.r[row] * zv;
+        d2 += zv * v.q[row];
+    }
+    const double t0 = block_sum(d0, sh);
+    const double t2 = block_sum(d2, sh);
+    if (threadIdx.x == 0) {
+        v.partials[blockIdx.x] = t0;
+        v.partials[G + blockIdx.x] = t2;
+    }
+}
+
+void launch_pcg_dots(const DeviceMatrix &m, const CgVectors &v, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pcg_dots, dim3(slice_grid(m)), dim3(192), 0, st, m, v);
+}
+
+__global__ __launch_bounds__(256) void k_copy_gated(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t n2,
+                                                    const CgScalars *gate)
+{
+    if (gate != nullptr && gate->done != 0) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+void launch_copy(const double *src, double *dst, int64_t n, const CgScalars *gate, hipStream_t st)
+{
+    const int64_t n2 = n / 2, blocks = (n2 + 255) / 256; // vector lengths are multiples of 192
+    hipLaunchKernelGGL(k_copy_gated, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st,
+                       reinterpret_cast<const double2 *>(src), reinterpret_cast<double2 *>(dst), n2, gate);
+}
+
+// ---- K cycle -----------------------------------------------------------------------------------------------
+
+constexpr int kKcycGroups = 128; // stage-1 workgroups of a K-cycle dot product
+
+__global__ __launch_bounds__(256) void k_kcyc_dots(const double *__restrict__ a0, const double *__restrict__ b0,
+                                                   const double *__restrict__ a1, const double *__restrict__ b1,
+                                                   const double *__restrict__ a2, const double *__restrict__ b2, int64_t n,
+                                                   double *__restrict__ scratch, const CgScalars *gate)
+{
+    __shared__ double sh[4];
+    if (gate != nullptr && gate->done != 0) return;
+    // contiguous chunk per workgroup, fixed order: deterministic
+    const int64_t chunk = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        s0 += a0[i] * b0[i];
+        s1 += a1[i] * b1[i];
+        if (a2 != nullptr) s2 += a2[i] * b2[i];
+    }
+    const double t0 = block_sum(s0, sh);
+    const double t1 = block_sum(s1, sh);
+    const double t2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) {
+        scratch[blockIdx.x] = t0;
+        scratch[kKcycGroups + blockIdx.x] = t1;
+        scratch[2 * kKcycGroups + blockIdx.x] = t2;
+    }
+}
+
+__global__ __launch_bounds__(128) void k_kcyc_finish(int phase, int groups, const double *__restrict__ scratch, KcycScalars *ks,
+                                                     const CgScalars *gate)
+{
+    __shared__ double sh[4];
+    if (gate != nullptr && gate->done != 0) return;
+    double s[3];
+    for (int a = 0; a < 3; a++) {
+        const double part = (int)threadIdx.x < groups ? scratch[a * kKcycGroups + threadIdx.x] : 0.0;
+        s[a] = block_sum(part, sh);
+    }
+    if (threadIdx.x != 0) return;
+    if (phase == 1) {
+        const double rho1 = s[0], a1 = s[1];
+        ks->rho1 = rho1;
+        ks->a1 = a1;
+        ks->t = rho1 > 0.0 ? a1 / rho1 : 0.0;
+    } else {
+        const double g = s[0], b2 = s[1], a2 = s[2];
+        const double rho1 = ks->rho1, a1 = ks->a1;
+        double w1 = ks->t, w2 = 0.0;
+        if (rho1 > 0.0) {
+            const double rho2 = b2 - g * g / rho1;
+            if (rho2 > 0.0) {
+                w1 = a1 / rho1 - g * a2 / (rho1 * rho2);
+                w2 = a2 / rho2;
+            }
+        }
+        ks->w1 = w1;
+        ks->w2 = w2;
+    }
+}
+
+void launch_kcyc_dots(int phase, const double *a0, const double *b0, const double *a1, const double *b1, const double *a2,
+                      const double *b2, int64_t n6, KcycScalars *ks, double *scratch, const CgScalars *gate, hipStream_t st)
+{
+    int groups = (int)((n6 + 4095) / 4096);
+    if (groups > kKcycGroups) groups = kKcycGroups;
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL(k_kcyc_dots, dim3(groups), dim3(256), 0, st, a0, b0, a1, b1, a2, b2, n6, scratch, gate);
+    hipLaunchKernelGGL(k_kcyc_finish, dim3(1), dim3(128), 0, st, phase, groups, scratch, ks, gate);
+}
+
+__global__ __launch_bounds__(256) void k_kcyc_r2(const double *__restrict__ rc, const double *__restrict__ v1,
+                                                 double *__restrict__ r2, int64_t n, const KcycScalars *ks, const CgScalars *gate)
+{
+    if (gate != nullptr && gate->done != 0) return;
+    const double t = ks->t;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        r2[i] = rc[i] - t * v1[i];
+}
+
+void launch_kcyc_r2(const double *rc, const double *v1, double *r2, int64_t n6, const KcycScalars *ks, const CgScalars *gate,
+                    hipStream_t st)
+{
+    const int64_t blocks = (n6 + 255) / 256;
+    hipLaunchKernelGGL(k_kcyc_r2, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, rc, v1, r2, n6, ks, gate);
+}
+
+__global__ __launch_bounds__(256) void k_kcyc_combine(const double *__restrict__ c1, const double *__restrict__ c2,
+                                                      double *__restrict__ x, int64_t n, const KcycScalars *ks,
+                                                      const CgScalars *gate)
+{
+    if (gate != nullptr && gate->done != 0) return;
+    const double w1 = ks->w1, w2 = ks->w2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        x[i] = w1 * c1[i] + w2 * c2[i];
+}
+
+void launch_kcyc_combine(const double *c1, const double *c2, double *x, int64_t n6, const KcycScalars *ks,
+                         const CgScalars *gate, hipStream_t st)
+{
+    const int64_t blocks = (n6 + 255) / 256;
+    hipLaunchKernelGGL(k_kcyc_combine, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, c1, c2, x, n6, ks, gate);
+}
+
+} // namespace femshell

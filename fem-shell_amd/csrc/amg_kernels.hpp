@@ -1,0 +1,59 @@
+// amg_kernels.hpp -- launchers of the multigrid cycle's vector kernels (amg_kernels.hip).  The matrix products of
+// the cycle (level operators, restriction, prolongation) all run through k_spmv of kernels.hip: every operator of
+// the hierarchy is a sliced block ELL matrix of 6x6 blocks.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace femshell {
+
+// Chebyshev smoothing in D^-1 A (D = 6x6 diagonal blocks, m.minv):
+//   start: d = inv_theta * D^-1 rin;  x = d (zero initial guess) or x += d (accumulate)
+//   step:  r = rin - q (q = A d);  d = a d + c D^-1 r;  x += d        (rin may be r itself)
+// every kernel is a no-op once gate->done != 0 (gate may be null)
+void launch_cheb_start(const DeviceMatrix &m, const double *rin, double *d, double *x, double inv_theta, bool accumulate,
+                       const CgScalars *gate, hipStream_t st);
+void launch_cheb_step(const DeviceMatrix &m, const double *rin, const double *q, double *rout, double *d, double *x,
+                      double a, double c, const CgScalars *gate, hipStream_t st);
+
+// power iteration for lambda_max(D^-1 A): z = D^-1 q with the partial sums of z.z (one per workgroup of slice_grid(m))
+void launch_minv_apply_norm(const DeviceMatrix &m, const double *q, double *z, double *partials, hipStream_t st);
+// x[i] = deterministic pseudo-random value in (-1,1) for rows of real nodes, 0 for padding rows
+void launch_fill_hash(double *x, int64_t n_real, int64_t n_total, hipStream_t st);
+
+// coarsest level: y = Ainv b, Ainv dense n x n (row-major); rows [n, n_pad6) of y are set to zero
+void launch_dense_gemv(const double *Ainv, const double *b, double *y, int32_t n, int32_t n_pad6, const CgScalars *gate,
+                       hipStream_t st);
+
+// ---- outer flexible PCG with a general preconditioner z = M(r) --------------------------------------------
+// (G = slice_grid(m) partial sums per array; the scalar steps are the CG_PHASE_FLEX_* phases of k_cg_scalar)
+// x = 0, r = b, partial sums of b.b into partials[0 ...]
+void launch_pcg_init(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);
+// x += alpha p, r -= alpha q, partial sums of r.r into partials[0 ...]
+void launch_pcg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);
+// partial sums of r.z into partials[0 ...] and of z.q into partials[G ...]
+void launch_pcg_dots(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);
+void launch_copy(const double *src, double *dst, int64_t n, const CgScalars *gate, hipStream_t st);
+
+// ---- K cycle: two steps of flexible CG on the coarse problem of a level ------------------------------------
+// sums[k] = a_k . b_k for up to three pairs (single workgroup finishes; vectors of n6 entries), then the
+// coefficient step `phase` on the K-cycle scalars ks:
+//   phase 1 (after c1 = M rc, v1 = A c1):        sums = (c1.v1, c1.rc)        -> ks->rho1, ks->a1, ks->t = a1/rho1
+//   phase 2 (after c2 = M r2, v2 = A c2):        sums = (c2.v1, c2.v2, c2.r2) -> ks->w1, ks->w2 with x = w1 c1 + w2 c2
+struct KcycScalars {
+    double rho1, a1, t, w1, w2;
+    double pad[3];
+};
+void launch_kcyc_dots(int phase, const double *a0, const double *b0, const double *a1, const double *b1, const double *a2,
+                      const double *b2, int64_t n6, KcycScalars *ks, double *scratch, const CgScalars *gate, hipStream_t st);
+// out = in - ks->t * v
+void launch_kcyc_r2(const double *rc, const double *v1, double *r2, int64_t n6, const KcycScalars *ks, const CgScalars *gate,
+                    hipStream_t st);
+// x = ks->w1 c1 + ks->w2 c2
+void launch_kcyc_combine(const double *c1, const double *c2, double *x, int64_t n6, const KcycScalars *ks,
+                         const CgScalars *gate, hipStream_t st);
+
+} // namespace femshell

@@ -1,0 +1,508 @@
+// amg_setup.cpp -- host side of the smoothed-aggregation setup (see amg.hpp): sparse block algebra on BSR
+// matrices with 6x6 blocks, run once per matrix on the host's threads.  No device code here.
+#include "amg.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+#include "plan.hpp"
+
+namespace femshell {
+
+int host_threads()
+{
+    static const int n = [] {
+        const char *e = getenv("FEMSHELL_HOST_THREADS");
+        int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        if (t < 1) t = 1;
+        if (t > 64) t = 64;
+        return t;
+    }();
+    return n;
+}
+
+void parallel_chunks(int64_t n, const std::function<void(int64_t, int64_t)> &f, int64_t min_chunk)
+{
+    if (n <= 0) return;
+    int64_t nt = std::min<int64_t>(host_threads(), (n + min_chunk - 1) / min_chunk);
+    if (nt <= 1) {
+        f(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve((size_t)nt);
+    for (int64_t t = 0; t < nt; t++) {
+        const int64_t b = n * t / nt, e = n * (t + 1) / nt;
+        th.emplace_back([&f, b, e] { f(b, e); });
+    }
+    for (auto &t : th) t.join();
+}
+
+namespace {
+
+// c += a * b (6x6, row-major)
+inline void blk_mac(const double *a, const double *b, double *c)
+{
+    for (int i = 0; i < 6; i++)
+        for (int k = 0; k < 6; k++) {
+            const double aik = a[6 * i + k];
+            for (int j = 0; j < 6; j++) c[6 * i + j] += aik * b[6 * k + j];
+        }
+}
+
+// 6x6 SPD inverse by Cholesky; false when the block is not positive definite
+bool spd_inverse6(const double *A, double *inv)
+{
+    double L[6][6] = {}, Li[6][6] = {};
+    for (int c = 0; c < 6; c++) {
+        double d = A[6 * c + c];
+        for (int k = 0; k < c; k++) d -= L[c][k] * L[c][k];
+        if (!(d > 0.0)) return false;
+        const double lcc = std::sqrt(d);
+        L[c][c] = lcc;
+        for (int r = c + 1; r < 6; r++) {
+            double v = A[6 * r + c];
+            for (int k = 0; k < c; k++) v -= L[r][k] * L[c][k];
+            L[r][c] = v / lcc;
+        }
+    }
+    for (int c = 0; c < 6; c++) {
+        Li[c][c] = 1.0 / L[c][c];
+        for (int r = c + 1; r < 6; r++) {
+            double v = 0.0;
+            for (int k = c; k < r; k++) v -= L[r][k] * Li[k][c];
+            Li[r][c] = v / L[r][r];
+        }
+    }
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+            double v = 0.0;
+            for (int k = std::max(i, j); k < 6; k++) v += Li[k][i] * Li[k][j];
+            inv[6 * i + j] = v;
+        }
+    return true;
+}
+
+} // namespace
+
+void rigid_body_modes(int32_t n, const double *xyz, const uint8_t *dmask, std::vector<double> *Bout)
+{
+    std::vector<double> &B = *Bout;
+    B.assign((size_t)n * 36, 0.0);
+    double c[3] = {0, 0, 0};
+    for (int32_t a = 0; a < n; a++)
+        for (int d = 0; d < 3; d++) c[d] += xyz[3ll * a + d];
+    for (int d = 0; d < 3; d++) c[d] /= std::max(n, 1);
+    parallel_chunks(n, [&](int64_t b0, int64_t b1) {
+        for (int64_t a = b0; a < b1; a++) {
+            double *b = &B[(size_t)a * 36];
+            const double x = xyz[3 * a] - c[0], y = xyz[3 * a + 1] - c[1], z = xyz[3 * a + 2] - c[2];
+            for (int i = 0; i < 6; i++) b[6 * i + i] = 1.0;
+            // u = omega x r: rotation about x -> (0,-z,y), about y -> (z,0,-x), about z -> (-y,x,0)
+            b[6 * 1 + 3] = -z;
+            b[6 * 2 + 3] = y;
+            b[6 * 0 + 4] = z;
+            b[6 * 2 + 4] = -x;
+            b[6 * 0 + 5] = -y;
+            b[6 * 1 + 5] = x;
+            const uint8_t m = dmask ? dmask[a] : 0;
+            for (int v = 0; v < 6; v++)
+                if ((m >> v) & 1u)
+                    for (int j = 0; j < 6; j++) b[6 * v + j] = 0.0;
+        }
+    });
+}
+
+int32_t aggregate_nodes(const Bsr &A, std::vector<int32_t> *aggout)
+{
+    const int32_t n = A.nr;
+    std::vector<int32_t> agg((size_t)n, -1);
+    int32_t na = 0;
+    // pass 1: a node whose whole neighbourhood is free becomes the root of a new aggregate
+    for (int32_t i = 0; i < n; i++) {
+        if (agg[i] >= 0) continue;
+        const int64_t b = A.ptr[i], e = A.ptr[i + 1];
+        if (e - b <= 1) continue;
+        bool free_nb = true;
+        for (int64_t q = b; q < e && free_nb; q++) free_nb = agg[A.col[q]] < 0;
+        if (!free_nb) continue;
+        for (int64_t q = b; q < e; q++) agg[A.col[q]] = na;
+        na++;
+    }
+    // pass 2: leftovers join the aggregate of their first aggregated neighbour (state of pass 1)
+    std::vector<int32_t> agg2(agg);
+    for (int32_t i = 0; i < n; i++) {
+        if (agg[i] >= 0) continue;
+        for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++)
+            if (agg[A.col[q]] >= 0) {
+                agg2[i] = agg[A.col[q]];
+                break;
+            }
+    }
+    agg.swap(agg2);
+    // pass 3: what is still free forms aggregates of its own
+    for (int32_t i = 0; i < n; i++) {
+        if (agg[i] >= 0) continue;
+        for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++)
+            if (agg[A.col[q]] < 0) agg[A.col[q]] = na;
+        agg[i] = na;
+        na++;
+    }
+    aggout->swap(agg);
+    return na;
+}
+
+void tentative_prolongator(const std::vector<int32_t> &agg, int32_t na, const std::vector<double> &B,
+                           std::vector<double> *Qout, std::vector<double> *Bcout)
+{
+    const int32_t n = (int32_t)agg.size();
+    std::vector<double> &Q = *Qout, &Bc = *Bcout;
+    Q.assign((size_t)n * 36, 0.0);
+    Bc.assign((size_t)na * 36, 0.0);
+    // nodes grouped by aggregate, ascending node id inside
+    std::vector<int32_t> ptr((size_t)na + 1, 0), order((size_t)n);
+    for (int32_t i = 0; i < n; i++) ptr[agg[i] + 1]++;
+    for (int32_t a = 0; a < na; a++) ptr[a + 1] += ptr[a];
+    {
+        std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+        for (int32_t i = 0; i < n; i++) order[fill[agg[i]]++] = i;
+    }
+    parallel_chunks(na, [&](int64_t a0, int64_t a1) {
+        std::vector<double> M, v;
+        for (int64_t a = a0; a < a1; a++) {
+            const int32_t k = ptr[a + 1] - ptr[a], rows = 6 * k;
+            M.assign((size_t)rows * 6, 0.0); // column-major: M[j*rows + r]
+            for (int32_t t = 0; t < k; t++) {
+                const double *b = &B[(size_t)order[ptr[a] + t] * 36];
+                for (int d = 0; d < 6; d++)
+                    for (int m = 0; m < 6; m++) M[(size_t)m * rows + 6 * t + d] = b[6 * d + m];
+            }
+            double R[36] = {0};
+            v.resize(rows);
+            for (int j = 0; j < 6; j++) {
+                double *cj = &M[(size_t)j * rows];
+                double n0 = 0.0;
+                for (int r = 0; r < rows; r++) n0 += cj[r] * cj[r];
+                n0 = std::sqrt(n0);
+                for (int pass = 0; pass < 2; pass++)
+                    for (int i = 0; i < j; i++) {
+                        const double *qi = &M[(size_t)i * rows];
+                        double c = 0.0;
+                        for (int r = 0; r < rows; r++) c += qi[r] * cj[r];
+                        for (int r = 0; r < rows; r++) cj[r] -= c * qi[r];
+                        R[6 * i + j] += c;
+                    }
+                double nj = 0.0;
+                for (int r = 0; r < rows; r++) nj += cj[r] * cj[r];
+                nj = std::sqrt(nj);
+                if (n0 > 0.0 && nj > 1e-8 * n0) {
+                    R[6 * j + j] = nj;
+                    for (int r = 0; r < rows; r++) cj[r] /= nj;
+                } else {
+                    R[6 * j + j] = 0.0; // dependent column: no coarse dof here
+                    for (int r = 0; r < rows; r++) cj[r] = 0.0;
+                }
+            }
+            for (int32_t t = 0; t < k; t++) {
+                double *q = &Q[(size_t)order[ptr[a] + t] * 36];
+                for (int d = 0; d < 6; d++)
+                    for (int m = 0; m < 6; m++) q[6 * d + m] = M[(size_t)m * rows + 6 * t + d];
+            }
+            std::memcpy(&Bc[(size_t)a * 36], R, sizeof R);
+        }
+    }, 16);
+}
+
+void block_diagonal_inverse(const Bsr &A, std::vector<double> *Dout)
+{
+    std::vector<double> &D = *Dout;
+    D.assign((size_t)A.nr * 36, 0.0);
+    parallel_chunks(A.nr, [&](int64_t r0, int64_t r1) {
+        for (int64_t i = r0; i < r1; i++) {
+            double *inv = &D[(size_t)i * 36];
+            bool ok = false;
+            for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++)
+                if (A.col[q] == i) {
+                    ok = spd_inverse6(&A.val[(size_t)q * 36], inv);
+                    break;
+                }
+            if (!ok) {
+                std::fill(inv, inv + 36, 0.0);
+                for (int d = 0; d < 6; d++) inv[7 * d] = 1.0;
+            }
+        }
+    });
+}
+
+void bsr_multiply(const Bsr &A, const Bsr &B, Bsr *Cout)
+{
+    Bsr &C = *Cout;
+    C = Bsr();
+    C.nr = A.nr;
+    C.nc = B.nc;
+    const int64_t n = A.nr;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (n + 1023) / 1024));
+    struct Part {
+        int64_t r0 = 0, r1 = 0;
+        std::vector<int32_t> cnt, col;
+        std::vector<double> val;
+    };
+    std::vector<Part> parts((size_t)nt);
+    for (int t = 0; t < nt; t++) {
+        parts[t].r0 = n * t / nt;
+        parts[t].r1 = n * (t + 1) / nt;
+    }
+    auto work = [&](Part &p) {
+        std::vector<int32_t> marker((size_t)B.nc, -1), list;
+        std::vector<std::pair<int32_t, int32_t>> order;
+        p.cnt.reserve((size_t)(p.r1 - p.r0));
+        std::vector<double> acc;
+        for (int64_t i = p.r0; i < p.r1; i++) {
+            list.clear();
+            acc.clear();
+            for (int64_t qa = A.ptr[i]; qa < A.ptr[i + 1]; qa++) {
+                const int32_t k = A.col[qa];
+                const double *a = &A.val[(size_t)qa * 36];
+                for (int64_t qb = B.ptr[k]; qb < B.ptr[k + 1]; qb++) {
+                    const int32_t j = B.col[qb];
+                    int32_t pos = marker[j];
+                    if (pos < 0) {
+                        pos = (int32_t)list.size();
+                        marker[j] = pos;
+                        list.push_back(j);
+                        acc.resize(acc.size() + 36, 0.0);
+                    }
+                    blk_mac(a, &B.val[(size_t)qb * 36], &acc[(size_t)pos * 36]);
+                }
+            }
+            order.clear();
+            for (size_t s = 0; s < list.size(); s++) order.push_back({list[s], (int32_t)s});
+            std::sort(order.begin(), order.end());
+            for (auto &o : order) {
+                p.col.push_back(o.first);
+                p.val.insert(p.val.end(), acc.begin() + (size_t)o.second * 36, acc.begin() + (size_t)o.second * 36 + 36);
+                marker[o.first] = -1;
+            }
+            p.cnt.push_back((int32_t)list.size());
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) th.emplace_back([&, t] { work(parts[t]); });
+        work(parts[0]);
+        for (auto &t : th) t.join();
+    }
+    C.ptr.assign((size_t)n + 1, 0);
+    for (auto &p : parts)
+        for (int64_t i = p.r0; i < p.r1; i++) C.ptr[i + 1] = C.ptr[i] + p.cnt[i - p.r0];
+    C.col.resize((size_t)C.ptr[n]);
+    C.val.resize((size_t)C.ptr[n] * 36);
+    for (auto &p : parts) {
+        std::copy(p.col.begin(), p.col.end(), C.col.begin() + C.ptr[p.r0]);
+        std::copy(p.val.begin(), p.val.end(), C.val.begin() + C.ptr[p.r0] * 36);
+        std::vector<int32_t>().swap(p.col);
+        std::vector<double>().swap(p.val);
+    }
+}
+
+void bsr_transpose(const Bsr &A, Bsr *Tout)
+{
+    Bsr &T = *Tout;
+    T = Bsr();
+    T.nr = A.nc;
+    T.nc = A.nr;
+    T.ptr.assign((size_t)T.nr + 1, 0);
+    for (int32_t c : A.col) T.ptr[c + 1]++;
+    for (int32_t i = 0; i < T.nr; i++) T.ptr[i + 1] += T.ptr[i];
+    T.col.resize(A.col.size());
+    T.val.resize(A.val.size());
+    std::vector<int64_t> fill(T.ptr.begin(), T.ptr.end() - 1);
+    for (int32_t i = 0; i < A.nr; i++) // ascending rows -> ascending columns of the transpose
+        for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++) {
+            const int64_t d = fill[A.col[q]]++;
+            T.col[d] = i;
+            const double *s = &A.val[(size_t)q * 36];
+            double *t = &T.val[(size_t)d * 36];
+            for (int r = 0; r < 6; r++)
+                for (int c = 0; c < 6; c++) t[6 * c + r] = s[6 * r + c];
+        }
+}
+
+void smoothed_prolongator(const Bsr &A, const std::vector<double> &Dinv, const std::vector<int32_t> &agg, int32_t na,
+                          const std::vector<double> &Q, double omega, Bsr *Pout)
+{
+    Bsr P0;
+    P0.nr = A.nr;
+    P0.nc = na;
+    P0.ptr.resize((size_t)A.nr + 1);
+    for (int64_t i = 0; i <= A.nr; i++) P0.ptr[i] = i;
+    P0.col.assign(agg.begin(), agg.end());
+    P0.val = Q;
+    Bsr &P = *Pout;
+    bsr_multiply(A, P0, &P); // pattern of P = pattern of A P0 (it contains (i, agg[i]): A has its diagonal)
+    parallel_chunks(A.nr, [&](int64_t r0, int64_t r1) {
+        double t[36];
+        for (int64_t i = r0; i < r1; i++) {
+            const double *di = &Dinv[(size_t)i * 36];
+            for (int64_t q = P.ptr[i]; q < P.ptr[i + 1]; q++) {
+                double *v = &P.val[(size_t)q * 36];
+                std::fill(t, t + 36, 0.0);
+                blk_mac(di, v, t);
+                const bool own = P.col[q] == agg[i];
+                for (int e = 0; e < 36; e++) v[e] = (own ? Q[(size_t)i * 36 + e] : 0.0) - omega * t[e];
+            }
+        }
+    });
+}
+
+void galerkin_product(const Bsr &A, const Bsr &P, Bsr *R, Bsr *Ac)
+{
+    Bsr AP;
+    bsr_multiply(A, P, &AP);
+    bsr_transpose(P, R);
+    bsr_multiply(*R, AP, Ac);
+    // coarse dofs without fine support (zero column of P): unit diagonal keeps the level matrix SPD
+    for (int32_t i = 0; i < Ac->nr; i++)
+        for (int64_t q = Ac->ptr[i]; q < Ac->ptr[i + 1]; q++)
+            if (Ac->col[q] == i) {
+                double *d = &Ac->val[(size_t)q * 36];
+                for (int v = 0; v < 6; v++)
+                    if (d[7 * v] == 0.0) d[7 * v] = 1.0;
+            }
+}
+
+bool dense_inverse(const Bsr &A, std::vector<double> *invout)
+{
+    const int64_t n = 6ll * A.nr;
+    std::vector<double> L((size_t)(n * n), 0.0);
+    for (int32_t i = 0; i < A.nr; i++)
+        for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++) {
+            const int32_t j = A.col[q];
+            const double *v = &A.val[(size_t)q * 36];
+            for (int r = 0; r < 6; r++)
+                for (int c = 0; c < 6; c++) L[(size_t)(6 * i + r) * n + 6 * j + c] = v[6 * r + c];
+        }
+    // symmetrise (the Galerkin product is symmetric up to rounding), then Cholesky in the lower triangle
+    for (int64_t r = 0; r < n; r++)
+        for (int64_t c = 0; c < r; c++) L[r * n + c] = 0.5 * (L[r * n + c] + L[c * n + r]);
+    for (int64_t c = 0; c < n; c++) {
+        double d = L[c * n + c];
+        for (int64_t k = 0; k < c; k++) d -= L[c * n + k] * L[c * n + k];
+        if (!(d > 0.0)) return false;
+        const double lcc = std::sqrt(d);
+        L[c * n + c] = lcc;
+        parallel_chunks(n - c - 1, [&](int64_t b, int64_t e) {
+            for (int64_t r = c + 1 + b; r < c + 1 + e; r++) {
+                double v = L[r * n + c];
+                const double *lr = &L[r * n], *lc = &L[c * n];
+                for (int64_t k = 0; k < c; k++) v -= lr[k] * lc[k];
+                L[r * n + c] = v / lcc;
+            }
+        }, 64);
+    }
+    // Li = L^-1 column by column, then inv = Li^T Li
+    std::vector<double> Li((size_t)(n * n), 0.0);
+    parallel_chunks(n, [&](int64_t c0, int64_t c1) {
+        for (int64_t c = c0; c < c1; c++) {
+            Li[c * n + c] = 1.0 / L[c * n + c];
+            for (int64_t r = c + 1; r < n; r++) {
+                double v = 0.0;
+                const double *lr = &L[r * n];
+                for (int64_t k = c; k < r; k++) v -= lr[k] * Li[k * n + c];
+                Li[r * n + c] = v / lr[r];
+            }
+        }
+    }, 8);
+    std::vector<double> &inv = *invout;
+    inv.assign((size_t)(n * n), 0.0);
+    // rows of Li^T are columns of Li: inv(i,j) = sum_k Li(k,i) Li(k,j); use the transposed copy for locality
+    std::vector<double> LiT((size_t)(n * n));
+    for (int64_t r = 0; r < n; r++)
+        for (int64_t c = 0; c <= r; c++) LiT[c * n + r] = Li[r * n + c];
+    parallel_chunks(n, [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; i++)
+            for (int64_t j = 0; j <= i; j++) {
+                double v = 0.0;
+                const double *a = &LiT[i * n], *b = &LiT[j * n];
+                for (int64_t k = i; k < n; k++) v += a[k] * b[k];
+                inv[i * n + j] = v;
+                inv[j * n + i] = v;
+            }
+    }, 8);
+    return true;
+}
+
+void pack_sliced_ell(const Bsr &A, bool diag_first, SlicedEll *out)
+{
+    SlicedEll &S = *out;
+    S = SlicedEll();
+    S.n_rows = A.nr;
+    S.n_pad = (A.nr + kSliceNodes - 1) / kSliceNodes * kSliceNodes;
+    S.n_slices = S.n_pad / kSliceNodes;
+    S.slice_width.assign((size_t)S.n_slices, 1);
+    S.slice_base.assign((size_t)S.n_slices + 1, 0);
+    for (int32_t s = 0; s < S.n_slices; s++) {
+        int w = 1;
+        for (int n = 0; n < kSliceNodes; n++) {
+            const int32_t a = s * kSliceNodes + n;
+            if (a >= A.nr) continue;
+            int cnt = (int)(A.ptr[a + 1] - A.ptr[a]);
+            if (diag_first) { // slot 0 is reserved for the diagonal block even when the row has none
+                bool have = false;
+                for (int64_t q = A.ptr[a]; q < A.ptr[a + 1] && !have; q++) have = A.col[q] == a;
+                if (!have) cnt++;
+            }
+            w = std::max(w, cnt);
+        }
+        S.slice_width[s] = w;
+        S.max_width = std::max(S.max_width, w);
+        S.slice_base[s + 1] = S.slice_base[s] + (int64_t)w * kSliceNodes;
+    }
+    const int64_t total = S.slice_base[S.n_slices];
+    S.cols.assign((size_t)total, 0);
+    S.vals.assign((size_t)total * 36, 0.0);
+    parallel_chunks(S.n_slices, [&](int64_t s0, int64_t s1) {
+        for (int64_t s = s0; s < s1; s++) {
+            const int w = S.slice_width[s];
+            const int64_t base = S.slice_base[s];
+            double *dst = &S.vals[(size_t)base * 36];
+            for (int n = 0; n < kSliceNodes; n++) {
+                const int32_t a = (int32_t)s * kSliceNodes + n;
+                const int32_t pad_col = diag_first ? std::min(a, S.n_pad - 1) : 0;
+                int k = 0;
+                auto put = [&](int64_t q) {
+                    S.cols[(size_t)(base + (int64_t)k * kSliceNodes + n)] = A.col[q];
+                    const double *v = &A.val[(size_t)q * 36];
+                    for (int i = 0; i < 6; i++)
+                        for (int j = 0; j < 6; j++)
+                            dst[((((int64_t)k * 3 + j / 2) * 6 + i) * kSliceNodes + n) * 2 + (j & 1)] = v[6 * i + j];
+                    k++;
+                };
+                if (a < A.nr) {
+                    if (diag_first) {
+                        bool have = false;
+                        for (int64_t q = A.ptr[a]; q < A.ptr[a + 1]; q++)
+                            if (A.col[q] == a) {
+                                put(q);
+                                have = true;
+                            }
+                        if (!have) { // keep slot 0 for the (zero) diagonal block
+                            S.cols[(size_t)(base + n)] = a;
+                            k = 1;
+                        }
+                        for (int64_t q = A.ptr[a]; q < A.ptr[a + 1]; q++)
+                            if (A.col[q] != a) put(q);
+                    } else {
+                        for (int64_t q = A.ptr[a]; q < A.ptr[a + 1]; q++) put(q);
+                    }
+                }
+                for (; k < w; k++) S.cols[(size_t)(base + (int64_t)k * kSliceNodes + n)] = pad_col;
+            }
+        }
+    }, 8);
+}
+
+} // namespace femshell

@@ -1,0 +1,389 @@
+// amg_solve.cpp -- device side of the multigrid preconditioner (amg.hpp): the hierarchy in HBM, the V / K cycle
+// and the flexible PCG around it.  Replaces what `-pc_type gamg`-style options select inside PETSc's KSPSolve
+// behind equation_systems.solve() (fem-shell.cpp:138, doc/implementation.tex:68-72).
+#include "amg_device.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace femshell {
+
+namespace {
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int upload_operator(AmgOperator &op, const SlicedEll &S, int32_t n_cols_pad, int64_t nnzb, hipStream_t st)
+{
+    FS_HIP(op.slice_width.upload(S.slice_width, st));
+    FS_HIP(op.slice_base.upload(S.slice_base, st));
+    FS_HIP(op.cols.upload(S.cols, st));
+    FS_HIP(op.vals.upload(S.vals, st));
+    FS_HIP(hipStreamSynchronize(st));
+    op.nnzb = nnzb;
+    op.n_cols_pad = n_cols_pad;
+    op.dm = DeviceMatrix();
+    op.dm.n_own = S.n_rows;
+    op.dm.n_pad = S.n_pad;
+    op.dm.n_slices = S.n_slices;
+    op.dm.slice_width = op.slice_width.p;
+    op.dm.slice_base = op.slice_base.p;
+    op.dm.cols = op.cols.p;
+    op.dm.vals = op.vals.p;
+    op.dm.max_slice_width = S.max_width;
+    return FEMSHELL_OK;
+}
+
+// lambda_max(D^-1 A) of a level by power iteration on the device (x <- D^-1 A x, ratio of consecutive norms)
+int power_iteration(femshell_ctx *c, AmgLevel &L, const DeviceMatrix &A, int iterations, double *lam_out)
+{
+    hipStream_t st = c->stream;
+    const int G = slice_grid(A);
+    DevBuf<double> part;
+    FS_HIP(part.alloc((size_t)G));
+    std::vector<double> h((size_t)G);
+    double *x = L.d.p, *z = L.r.p;
+    launch_fill_hash(x, 6ll * L.n, 6ll * L.n_pad, st);
+    double prev = 0.0, lam = 1.0;
+    for (int it = 0; it < iterations; it++) {
+        launch_spmv(A, x, L.q.p, nullptr, nullptr, st);
+        launch_minv_apply_norm(A, L.q.p, z, part.p, st);
+        FS_HIP(hipMemcpyAsync(h.data(), part.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        FS_HIP(hipStreamSynchronize(st));
+        double s = 0.0;
+        for (double v : h) s += v;
+        const double nrm = std::sqrt(s);
+        if (!(nrm > 0.0) || !std::isfinite(nrm)) return set_err(FEMSHELL_ERR_BREAKDOWN, "multigrid setup: power iteration broke down");
+        if (it > 0) lam = nrm / prev;
+        prev = nrm;
+        std::swap(x, z);
+        if (nrm > 1e100) { // rescale (never reached with lambda ~ 2 and 30 steps; kept for safety)
+            return set_err(FEMSHELL_ERR_BREAKDOWN, "multigrid setup: power iteration overflow");
+        }
+    }
+    FS_HIP(hipGetLastError());
+    *lam_out = lam;
+    return FEMSHELL_OK;
+}
+
+int alloc_level_vectors(AmgLevel &L, bool top, bool kcycle, hipStream_t st)
+{
+    const size_t n6 = (size_t)L.n_pad * 6;
+    if (!top) {
+        FS_HIP(L.b.alloc(n6));
+        FS_HIP(L.x.alloc(n6));
+        FS_HIP(L.b.zero(st));
+        FS_HIP(L.x.zero(st));
+    }
+    FS_HIP(L.r.alloc(n6));
+    FS_HIP(L.d.alloc(n6));
+    FS_HIP(L.q.alloc(n6));
+    FS_HIP(L.r.zero(st));
+    FS_HIP(L.d.zero(st));
+    FS_HIP(L.q.zero(st));
+    if (!top && kcycle) {
+        FS_HIP(L.c1.alloc(n6));
+        FS_HIP(L.v1.alloc(n6));
+        FS_HIP(L.r2.alloc(n6));
+        FS_HIP(L.c2.alloc(n6));
+        FS_HIP(L.v2.alloc(n6));
+        FS_HIP(L.c1.zero(st));
+        FS_HIP(L.v1.zero(st));
+        FS_HIP(L.r2.zero(st));
+        FS_HIP(L.c2.zero(st));
+        FS_HIP(L.v2.zero(st));
+        FS_HIP(L.ks.alloc(1));
+        FS_HIP(L.ks.zero(st));
+        FS_HIP(L.kscratch.alloc(3 * 128));
+    }
+    return FEMSHELL_OK;
+}
+
+} // namespace
+
+void amg_default_options(femshell_pc_options *o)
+{
+    std::memset(o, 0, sizeof *o);
+    o->type = FEMSHELL_PC_AMG;
+    o->cycle = FEMSHELL_CYCLE_K;
+    o->smoother_degree = 2;
+    o->coarse_degree = 4;
+    o->coarsest_nodes = 200;
+    o->max_levels = 12;
+    o->eig_ratio = 30.0;
+}
+
+const DeviceMatrix &amg_level_matrix(const femshell_ctx *c, int l) { return l == 0 ? c->dm : c->amg->levels[l]->A.dm; }
+
+// Builds the hierarchy for the matrix currently in HBM.  Host: aggregation, prolongators, Galerkin products
+// (amg_setup.cpp); device: lambda_max of every level, block-Jacobi inverses of the coarse operators.
+int amg_setup(femshell_ctx *c)
+{
+    const double t0 = now_s();
+    hipStream_t st = c->stream;
+    const femshell_pc_options opt = c->pc;
+    const bool kcycle = opt.cycle == FEMSHELL_CYCLE_K;
+    c->amg.reset(new Amg());
+    Amg &H = *c->amg;
+    H.opt = opt;
+    const Plan &pl = c->plan;
+
+    Bsr A;
+    int rc = download_matrix(c, &A);
+    if (rc) return rc;
+    std::vector<double> B;
+    rigid_body_modes(pl.n_own, pl.xyz_local.data(), c->dmask_global.data() + pl.row_begin, &B);
+    const bool keep_host = A.nnzb() <= (int64_t)2000000; // inspection exports (tests) on small problems only
+
+    for (int l = 0;; l++) {
+        H.levels.emplace_back(new AmgLevel());
+        AmgLevel &L = *H.levels.back();
+        L.n = A.nr;
+        L.n_pad = (A.nr + kSliceNodes - 1) / kSliceNodes * kSliceNodes;
+        L.nnzb = A.nnzb();
+        if (l > 0) {
+            SlicedEll S;
+            pack_sliced_ell(A, true, &S);
+            rc = upload_operator(L.A, S, S.n_pad, A.nnzb(), st);
+            if (rc) return rc;
+            FS_HIP(L.minv.alloc((size_t)S.n_slices * 21 * kSliceNodes));
+            L.A.dm.minv = L.minv.p;
+            L.A.dm.status = c->status.p;
+            launch_block_jacobi(L.A.dm, st);
+            FS_HIP(hipGetLastError());
+            FS_HIP(hipMemcpyAsync(c->status_host, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            FS_HIP(hipStreamSynchronize(st));
+            if (*c->status_host != 0) {
+                FS_HIP(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), st));
+                return set_err(FEMSHELL_ERR_BREAKDOWN, "multigrid setup: a diagonal block of coarse level " + std::to_string(l) +
+                                                           " is not positive definite");
+            }
+        }
+        rc = alloc_level_vectors(L, l == 0, kcycle, st);
+        if (rc) return rc;
+        const DeviceMatrix &Adev = amg_level_matrix(c, l);
+        const bool coarsest = L.n <= opt.coarsest_nodes || l + 1 >= opt.max_levels;
+        if (coarsest) {
+            std::vector<double> inv;
+            if (L.n > 4096) return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: coarsest level too large for a dense inverse");
+            if (!dense_inverse(A, &inv))
+                return set_err(FEMSHELL_ERR_BREAKDOWN, "multigrid setup: coarsest operator is not positive definite");
+            FS_HIP(H.coarse_inv.upload(inv, st));
+            FS_HIP(hipStreamSynchronize(st));
+            if (keep_host) L.hA = std::move(A);
+            break;
+        }
+        double lam = 0.0;
+        rc = power_iteration(c, L, Adev, 30, &lam);
+        if (rc) return rc;
+        L.lam = 1.1 * lam; // the power iteration approaches from below
+        // coarsen
+        std::vector<int32_t> agg;
+        const int32_t na = aggregate_nodes(A, &agg);
+        std::vector<double> Q, Bc, Dinv;
+        tentative_prolongator(agg, na, B, &Q, &Bc);
+        block_diagonal_inverse(A, &Dinv);
+        Bsr P, R, Ac;
+        smoothed_prolongator(A, Dinv, agg, na, Q, (4.0 / 3.0) / L.lam, &P);
+        std::vector<double>().swap(Q);
+        std::vector<double>().swap(Dinv);
+        galerkin_product(A, P, &R, &Ac);
+        {
+            SlicedEll S;
+            const int32_t nc_pad = (na + kSliceNodes - 1) / kSliceNodes * kSliceNodes;
+            pack_sliced_ell(P, false, &S);
+            rc = upload_operator(L.P, S, nc_pad, P.nnzb(), st);
+            if (rc) return rc;
+            pack_sliced_ell(R, false, &S);
+            rc = upload_operator(L.R, S, L.n_pad, R.nnzb(), st);
+            if (rc) return rc;
+        }
+        if (keep_host) {
+            L.hA = std::move(A);
+            L.hP = std::move(P);
+            L.agg = std::move(agg);
+        }
+        A = std::move(Ac);
+        B.swap(Bc);
+    }
+    // Chebyshev coefficients per level
+    for (size_t l = 0; l + 1 < H.levels.size(); l++) {
+        AmgLevel &L = *H.levels[l];
+        const int deg = std::max(1, l == 0 ? opt.smoother_degree : opt.coarse_degree);
+        const double lmax = L.lam, lmin = L.lam / opt.eig_ratio;
+        const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+        L.inv_theta = 1.0 / theta;
+        L.cheb_a.clear();
+        L.cheb_c.clear();
+        double rho = 1.0 / sigma;
+        for (int k = 1; k < deg; k++) {
+            const double rho_new = 1.0 / (2.0 * sigma - rho);
+            L.cheb_a.push_back(rho_new * rho);
+            L.cheb_c.push_back(2.0 * rho_new / delta);
+            rho = rho_new;
+        }
+    }
+    FS_HIP(hipStreamSynchronize(st));
+    H.setup_seconds = now_s() - t0;
+    H.valid = true;
+    return FEMSHELL_OK;
+}
+
+namespace {
+
+struct Cycle {
+    femshell_ctx *c;
+    Amg &H;
+    const CgScalars *gate;
+    hipStream_t st;
+
+    void smooth(int l, const double *b, double *x, bool zero_guess)
+    {
+        AmgLevel &L = *H.levels[l];
+        const DeviceMatrix &A = amg_level_matrix(c, l);
+        const double *rcur = b;
+        if (!zero_guess) {
+            launch_spmv_axpy(A, x, L.r.p, b, -1.0, gate, st);
+            rcur = L.r.p;
+        }
+        launch_cheb_start(A, rcur, L.d.p, x, L.inv_theta, !zero_guess, gate, st);
+        for (size_t k = 0; k < L.cheb_a.size(); k++) {
+            launch_spmv(A, L.d.p, L.q.p, nullptr, gate, st);
+            launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st);
+            rcur = L.r.p;
+        }
+    }
+
+    // x = M_l(b): one cycle on level l
+    void cycle(int l, const double *b, double *x)
+    {
+        AmgLevel &L = *H.levels[l];
+        if ((size_t)l + 1 == H.levels.size()) {
+            launch_dense_gemv(H.coarse_inv.p, b, x, 6 * L.n, 6 * L.n_pad, gate, st);
+            return;
+        }
+        const DeviceMatrix &A = amg_level_matrix(c, l);
+        AmgLevel &N = *H.levels[l + 1];
+        smooth(l, b, x, true);
+        launch_spmv_axpy(A, x, L.r.p, b, -1.0, gate, st);       // r = b - A x
+        launch_spmv(L.R.dm, L.r.p, N.b.p, nullptr, gate, st);   // b_c = R r
+        const bool next_is_coarsest = (size_t)l + 2 == H.levels.size();
+        if (H.opt.cycle == FEMSHELL_CYCLE_K && !next_is_coarsest) kcycle(l + 1);
+        else cycle(l + 1, N.b.p, N.x.p);
+        launch_spmv_axpy(L.P.dm, N.x.p, x, x, 1.0, gate, st);   // x += P x_c
+        smooth(l, b, x, false);
+    }
+
+    // two steps of flexible CG on A_l x = b_l preconditioned by the cycle (Notay & Vassilevski's K cycle)
+    void kcycle(int l)
+    {
+        AmgLevel &L = *H.levels[l];
+        const DeviceMatrix &A = amg_level_matrix(c, l);
+        const int64_t n6 = 6ll * L.n_pad;
+        cycle(l, L.b.p, L.c1.p);
+        launch_spmv(A, L.c1.p, L.v1.p, nullptr, gate, st);
+        launch_kcyc_dots(1, L.c1.p, L.v1.p, L.c1.p, L.b.p, nullptr, nullptr, n6, L.ks.p, L.kscratch.p, gate, st);
+        launch_kcyc_r2(L.b.p, L.v1.p, L.r2.p, n6, L.ks.p, gate, st);
+        cycle(l, L.r2.p, L.c2.p);
+        launch_spmv(A, L.c2.p, L.v2.p, nullptr, gate, st);
+        launch_kcyc_dots(2, L.c2.p, L.v1.p, L.c2.p, L.v2.p, L.c2.p, L.r2.p, n6, L.ks.p, L.kscratch.p, gate, st);
+        launch_kcyc_combine(L.c1.p, L.c2.p, L.x.p, n6, L.ks.p, gate, st);
+    }
+};
+
+// host side of the stopping test
+struct AmgPoll {
+    int32_t next_check = 1, step = 1;
+    int operator()(femshell_ctx *c, const CgVectors &v, int32_t it, int32_t max_it, CgScalars *hs)
+    {
+        if (it + 1 != next_check || it + 1 >= max_it) return 0;
+        FS_HIP(hipMemcpyAsync(hs, v.s, sizeof *hs, hipMemcpyDeviceToHost, c->stream));
+        FS_HIP(hipStreamSynchronize(c->stream));
+        if (hs->done != 0) return 1;
+        if (step < 4) step *= 2;
+        next_check += step;
+        return 0;
+    }
+};
+
+} // namespace
+
+int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate)
+{
+    Cycle cy{c, *c->amg, gate, c->stream};
+    cy.cycle(0, r, z);
+    FS_HIP(hipGetLastError());
+    return FEMSHELL_OK;
+}
+
+// Flexible preconditioned CG (beta = z.(r - r_old) / r_old.z_old, so that the K cycle's slightly varying operator
+// does not break the recurrence); stopping rule and scalars as in cg_classic.
+int cg_amg(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it)
+{
+    const DeviceMatrix &m = c->dm;
+    hipStream_t st = c->stream;
+    const int64_t n6 = 6ll * m.n_pad;
+    launch_pcg_init(m, v, st);
+    int rc = scalar_step(c, v, 1, CG_PHASE_FLEX_INIT, rtol);
+    if (rc) return rc;
+    rc = amg_apply(c, v.r, v.z, v.s);
+    if (rc) return rc;
+    launch_pcg_dots(m, v, st);
+    rc = scalar_step(c, v, 1, CG_PHASE_FLEX_RZ0, rtol);
+    if (rc) return rc;
+    launch_copy(v.z, v.p, n6, v.s, st);
+    CgScalars hs{};
+    AmgPoll poll;
+    for (int32_t it = 0; it < max_it; it++) {
+        launch_spmv(m, v.p, v.q, v.partials, v.s, st);
+        rc = scalar_step(c, v, 1, CG_PHASE_ALPHA, rtol);
+        if (rc) return rc;
+        launch_pcg_update(m, v, st);
+        rc = scalar_step(c, v, 1, CG_PHASE_FLEX_CONV, rtol);
+        if (rc) return rc;
+        rc = amg_apply(c, v.r, v.z, v.s);
+        if (rc) return rc;
+        launch_pcg_dots(m, v, st);
+        rc = scalar_step(c, v, 2, CG_PHASE_FLEX_BETA, rtol);
+        if (rc) return rc;
+        launch_cg_direction(m, v, st);
+        rc = poll(c, v, it, max_it, &hs);
+        if (rc < 0) return rc;
+        if (rc == 1) break;
+    }
+    return FEMSHELL_OK;
+}
+
+// algorithmic HBM bytes of one preconditioned iteration: every operator product of the cycle streams its blocks
+// (292 B each) once, plus the vector passes
+double amg_bytes_per_iteration(const femshell_ctx *c)
+{
+    const Amg &H = *c->amg;
+    std::vector<double> visits(H.levels.size(), 0.0);
+    visits[0] = 1.0;
+    double bytes = 0.0;
+    for (size_t l = 0; l + 1 < H.levels.size(); l++) {
+        const AmgLevel &L = *H.levels[l];
+        const double deg = (double)L.cheb_a.size() + 1.0;
+        // pre: deg-1 products, residual: 1, post: deg products; K cycle adds one product per visit on levels >= 1
+        double a_products = 2.0 * deg;
+        const bool k_here = H.opt.cycle == FEMSHELL_CYCLE_K && l >= 1;
+        const double vec = 48.0 * L.n;
+        double per_visit = a_products * (292.0 * (double)L.nnzb + 2.0 * vec) + 292.0 * (double)(L.P.nnzb + L.R.nnzb) + 4.0 * vec +
+                           (2.0 * deg) * (5.0 * vec + 168.0 * L.n);
+        if (k_here) per_visit += 292.0 * (double)L.nnzb + 8.0 * vec;
+        bytes += visits[l] * per_visit;
+        const bool next_k = H.opt.cycle == FEMSHELL_CYCLE_K && l + 2 < H.levels.size();
+        visits[l + 1] = visits[l] * (next_k ? 2.0 : 1.0);
+    }
+    const AmgLevel &C = *H.levels.back();
+    bytes += visits.back() * 8.0 * 36.0 * (double)C.n * (double)C.n;
+    return bytes;
+}
+
+} // namespace femshell

@@ -1,6 +1,7 @@
 // api.cpp -- the C ABI of libfemshell (include/femshell.h): context, host<->HBM plumbing, measurement hooks.
 // The CG driver is cg_driver.cpp, the plan inspection entry points plan_api.cpp.  All arithmetic of the hot path
 // runs in the kernels of kernels.hip; there is no CPU fallback anywhere in this library.
+#include "amg_device.hpp"
 #include "context.hpp"
 
 #include <algorithm>
@@ -82,6 +83,31 @@ int check_status(femshell_ctx *c, const char *what)
     return set_err(FEMSHELL_ERR_BREAKDOWN, buf);
 }
 
+// Collective agreement on a rank-local outcome (multi-rank contexts): a degenerate element or a non-SPD diagonal
+// block exists on the owning rank only; without this the healthy ranks would walk on into the halo exchange and
+// the all-reduces of the CG loop and wait there forever.  Every rank calls this at the same points (after the
+// assembly and after the block-Jacobi setup); all of them leave with an error when any of them has one.
+int agree_status(femshell_ctx *c, int local_rc, const char *what)
+{
+    if (!c->comm.active()) return local_rc;
+    const std::string local_msg = last_err();
+    FS_HIP(c->agree.alloc(1));
+    *c->agree_host = local_rc ? 1.0 : 0.0;
+    FS_HIP(hipMemcpyAsync(c->agree.p, c->agree_host, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    std::string e;
+    if (!comm_allreduce_sum(c->comm, c->agree.p, 1, c->stream, &e)) return set_err(FEMSHELL_ERR_COMM, e);
+    FS_HIP(hipMemcpyAsync(c->agree_host, c->agree.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(hipStreamSynchronize(c->stream));
+    if (local_rc) return set_err(local_rc, local_msg);
+    if (*c->agree_host > 0.0) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "%s: failed on %d other rank(s) of the row partition (degenerate element or non-SPD block there)",
+                 what, (int)*c->agree_host);
+        return set_err(FEMSHELL_ERR_MESH, buf);
+    }
+    return FEMSHELL_OK;
+}
+
 // scatter the global per-node arrays into the rank-local numbering and upload
 int upload_node_data(femshell_ctx *c)
 {
@@ -113,7 +139,7 @@ int do_assemble(femshell_ctx *c)
     launch_assemble(c->dm, c->mc, c->stream); // K and F (k_rhs alone serves changes of the loads)
     FS_HIP(hipEventRecord(c->ev1, c->stream));
     FS_HIP(hipGetLastError());
-    rc = check_status(c, "femshell_assemble");
+    rc = agree_status(c, check_status(c, "femshell_assemble"), "femshell_assemble");
     if (rc) return rc;
     float ms = 0.f;
     FS_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -121,6 +147,7 @@ int do_assemble(femshell_ctx *c)
     c->matrix_valid = true;
     c->rhs_valid = true;
     c->jacobi_valid = false;
+    c->amg.reset(); // the multigrid hierarchy belongs to the previous K
     return FEMSHELL_OK;
 }
 
@@ -138,7 +165,7 @@ int do_jacobi(femshell_ctx *c)
     launch_block_jacobi(c->dm, c->stream);
     FS_HIP(hipEventRecord(c->ev1, c->stream));
     FS_HIP(hipGetLastError());
-    int rc = check_status(c, "block-Jacobi setup");
+    int rc = agree_status(c, check_status(c, "block-Jacobi setup"), "block-Jacobi setup");
     if (rc) return rc;
     float ms = 0.f;
     FS_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -150,6 +177,54 @@ int do_jacobi(femshell_ctx *c)
 } // namespace
 
 namespace femshell {
+
+int download_matrix(femshell_ctx *c, Bsr *Aout)
+{
+    const Plan &p = c->plan;
+    if (c->cfg.world_size != 1) return set_err(FEMSHELL_ERR_UNSUPPORTED, "matrix download: single-rank contexts only");
+    std::vector<double> h((size_t)p.total_slots() * 36);
+    FS_HIP(hipMemcpyAsync(h.data(), c->vals.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(hipStreamSynchronize(c->stream));
+    Bsr &A = *Aout;
+    A = Bsr();
+    A.nr = A.nc = p.n_own;
+    A.ptr.assign((size_t)p.n_own + 1, 0);
+    for (int32_t a = 0; a < p.n_own; a++) {
+        const int s = a / kSliceNodes, n = a % kSliceNodes;
+        int cnt = 0;
+        for (int k = 0; k < p.slice_width[s]; k++) {
+            const int64_t slot = Plan::slot_index(p.slice_base[s], k, n);
+            if (p.pair_ptr[slot + 1] > p.pair_ptr[slot]) cnt++;
+        }
+        A.ptr[a + 1] = A.ptr[a] + cnt;
+    }
+    A.col.resize((size_t)A.ptr[p.n_own]);
+    A.val.resize((size_t)A.ptr[p.n_own] * 36);
+    parallel_chunks(p.n_own, [&](int64_t a0, int64_t a1) {
+        std::vector<std::pair<int32_t, int>> order;
+        for (int64_t a = a0; a < a1; a++) {
+            const int s = (int)(a / kSliceNodes), n = (int)(a % kSliceNodes);
+            const int64_t base = p.slice_base[s];
+            order.clear();
+            for (int k = 0; k < p.slice_width[s]; k++) {
+                const int64_t slot = Plan::slot_index(base, k, n);
+                if (p.pair_ptr[slot + 1] > p.pair_ptr[slot]) order.push_back({p.cols[slot], k});
+            }
+            std::sort(order.begin(), order.end());
+            int64_t nb = A.ptr[a];
+            const double *src = h.data() + base * 36;
+            for (auto &ck : order) {
+                A.col[nb] = ck.first; // single rank: local id == global id
+                double *blk = &A.val[(size_t)nb * 36];
+                for (int i = 0; i < 6; i++)
+                    for (int j = 0; j < 6; j++)
+                        blk[6 * i + j] = src[((((int64_t)ck.second * 3 + j / 2) * 6 + i) * kSliceNodes + n) * 2 + (j & 1)];
+                nb++;
+            }
+        }
+    });
+    return FEMSHELL_OK;
+}
 
 CgVectors cg_vectors(femshell_ctx *c)
 {
@@ -199,6 +274,7 @@ int femshell_create(const femshell_config *cfg, femshell_ctx **out)
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = c->status.alloc(1);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->status_host), sizeof(int32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->agree_host), sizeof(double), hipHostMallocDefault);
     if (e == hipSuccess) e = c->status.zero(c->stream);
     if (e == hipSuccess) e = c->scal.alloc(1);
     if (e == hipSuccess) e = c->scal.zero(c->stream);
@@ -214,6 +290,11 @@ int femshell_create(const femshell_config *cfg, femshell_ctx **out)
     c->mc.t = t;
     c->mc.flags = cfg->flags;
     c->mc.pad = 0;
+    {
+        const char *e = getenv("FEMSHELL_PC");
+        const bool amg = e && (std::strcmp(e, "amg") == 0 || std::strcmp(e, "gamg") == 0) && cfg->world_size == 1;
+        (void)femshell_pc_defaults(amg ? FEMSHELL_PC_AMG : FEMSHELL_PC_BLOCK_JACOBI, &c->pc);
+    }
     *out = c;
     return FEMSHELL_OK;
 }
@@ -229,6 +310,7 @@ int femshell_destroy(femshell_ctx *c)
     if (c->ev_halo_done) (void)hipEventDestroy(c->ev_halo_done);
     if (c->halo_stream) (void)hipStreamDestroy(c->halo_stream);
     if (c->status_host) (void)hipHostFree(c->status_host);
+    if (c->agree_host) (void)hipHostFree(c->agree_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -423,6 +505,75 @@ int femshell_assemble(femshell_ctx *c)
     return do_assemble(c);
 }
 
+int femshell_pc_defaults(int32_t type, femshell_pc_options *out)
+{
+    if (!out) return set_err(FEMSHELL_ERR_INVALID, "femshell_pc_defaults: null argument");
+    if (type != FEMSHELL_PC_BLOCK_JACOBI && type != FEMSHELL_PC_AMG)
+        return set_err(FEMSHELL_ERR_INVALID, "femshell_pc_defaults: unknown preconditioner type");
+    amg_default_options(out);
+    out->type = type;
+    if (type == FEMSHELL_PC_AMG) {
+        const char *cy = getenv("FEMSHELL_AMG_CYCLE");
+        if (cy && (cy[0] == 'V' || cy[0] == 'v')) out->cycle = FEMSHELL_CYCLE_V;
+    }
+    return FEMSHELL_OK;
+}
+
+int femshell_set_preconditioner(femshell_ctx *c, const femshell_pc_options *opt)
+{
+    if (!c || !opt) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_preconditioner: null argument");
+    if (opt->type != FEMSHELL_PC_BLOCK_JACOBI && opt->type != FEMSHELL_PC_AMG)
+        return set_err(FEMSHELL_ERR_INVALID, "femshell_set_preconditioner: unknown preconditioner type");
+    if (opt->type == FEMSHELL_PC_AMG) {
+        if (c->cfg.world_size != 1)
+            return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_set_preconditioner: the multigrid preconditioner serves single-rank contexts only");
+        if ((opt->cycle != FEMSHELL_CYCLE_V && opt->cycle != FEMSHELL_CYCLE_K) || opt->smoother_degree < 1 || opt->smoother_degree > 16 ||
+            opt->coarse_degree < 1 || opt->coarse_degree > 16 || opt->coarsest_nodes < 1 || opt->coarsest_nodes > 680 ||
+            opt->max_levels < 2 || opt->max_levels > 32 || !(opt->eig_ratio > 1.0))
+            return set_err(FEMSHELL_ERR_INVALID, "femshell_set_preconditioner: option out of range");
+    }
+    c->pc = *opt;
+    c->amg.reset();
+    return FEMSHELL_OK;
+}
+
+int32_t femshell_amg_levels(femshell_ctx *c) { return (c && c->amg && c->amg->valid) ? (int32_t)c->amg->levels.size() : 0; }
+
+int femshell_amg_level(femshell_ctx *c, int32_t level, femshell_amg_level_info *info)
+{
+    if (!c || !info) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_level: null argument");
+    if (level < 0 || level >= femshell_amg_levels(c)) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_level: no such level");
+    const AmgLevel &L = *c->amg->levels[level];
+    const bool last = level + 1 == (int32_t)c->amg->levels.size();
+    info->n_nodes = L.n;
+    info->n_coarse = last ? 0 : c->amg->levels[level + 1]->n;
+    info->nnz_blocks = L.nnzb;
+    info->p_blocks = last ? 0 : L.P.nnzb;
+    info->lambda_max = L.lam;
+    return FEMSHELL_OK;
+}
+
+int64_t femshell_amg_export(femshell_ctx *c, int32_t level, int32_t which, void *out)
+{
+    if (!c || level < 0 || level >= femshell_amg_levels(c)) return -1;
+    const AmgLevel &L = *c->amg->levels[level];
+    auto give = [&](const void *src, size_t count, size_t elem) -> int64_t {
+        if (out && count) std::memcpy(out, src, count * elem);
+        return (int64_t)count;
+    };
+    const Bsr &M = (which >= FEMSHELL_AMG_P_ROWPTR) ? L.hP : L.hA;
+    switch (which) {
+    case FEMSHELL_AMG_AGGREGATES: return L.agg.empty() ? -1 : give(L.agg.data(), L.agg.size(), sizeof(int32_t));
+    case FEMSHELL_AMG_A_ROWPTR:
+    case FEMSHELL_AMG_P_ROWPTR: return M.ptr.empty() ? -1 : give(M.ptr.data(), M.ptr.size(), sizeof(int64_t));
+    case FEMSHELL_AMG_A_COLS:
+    case FEMSHELL_AMG_P_COLS: return M.ptr.empty() ? -1 : give(M.col.data(), M.col.size(), sizeof(int32_t));
+    case FEMSHELL_AMG_A_VALS:
+    case FEMSHELL_AMG_P_VALS: return M.ptr.empty() ? -1 : give(M.val.data(), M.val.size(), sizeof(double));
+    default: return -1;
+    }
+}
+
 int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, femshell_solve_info *info)
 {
     if (!c) return set_err(FEMSHELL_ERR_INVALID, "femshell_solve: null context");
@@ -445,6 +596,18 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
         if (rc) return rc;
         setup_s = c->last_setup_s;
     }
+    double pc_setup_s = 0.0;
+    const bool use_amg = c->pc.type == FEMSHELL_PC_AMG;
+    if (use_amg && (!c->amg || !c->amg->valid)) {
+        if (c->cfg.world_size != 1 || c->comm.active())
+            return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_solve: the multigrid preconditioner serves single-rank contexts only");
+        rc = amg_setup(c);
+        if (rc) {
+            c->amg.reset();
+            return rc;
+        }
+        pc_setup_s = c->amg->setup_seconds;
+    }
     hipStream_t st = c->stream;
     FS_HIP(c->hist.alloc((size_t)std::min<int64_t>(std::max(max_it, 1), 1 << 22))); // history of the first 4M iterations
     CgVectors v = cg_vectors(c);
@@ -454,8 +617,9 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
     // a previous solve leaves done = 1 behind; the reduction launch in front of an all-reduce carries no phase and
     // would skip its work on it (multi-rank re-solves, e.g. every coupling iteration)
     FS_HIP(c->scal.zero(st));
-    const bool single_reduction = use_single_reduction(c);
-    rc = single_reduction ? cg_single_reduction(c, v, rtol, max_it) : cg_classic(c, v, rtol, max_it);
+    const bool single_reduction = !use_amg && use_single_reduction(c);
+    rc = use_amg ? cg_amg(c, v, rtol, max_it)
+                 : single_reduction ? cg_single_reduction(c, v, rtol, max_it) : cg_classic(c, v, rtol, max_it);
     if (rc) return rc;
     CgScalars hs{};
     FS_HIP(hipMemcpyAsync(&hs, v.s, sizeof hs, hipMemcpyDeviceToHost, st));
@@ -497,8 +661,18 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
         info->assemble_seconds = asm_s;
         info->setup_seconds = setup_s;
         info->solve_seconds = 1e-3 * ms;
-        info->bytes_per_iteration = single_reduction ? bytes_spmv(c) + bytes_update_single_reduction(c)
-                                                     : bytes_spmv(c) + bytes_update(c) + bytes_direction(c);
+        info->bytes_per_iteration = use_amg ? bytes_spmv(c) + (6.0 + 5.0 + 3.0) * 48.0 * c->plan.n_own + amg_bytes_per_iteration(c)
+                                    : single_reduction ? bytes_spmv(c) + bytes_update_single_reduction(c)
+                                                       : bytes_spmv(c) + bytes_update(c) + bytes_direction(c);
+        info->pc_type = c->pc.type;
+        info->amg_levels = use_amg ? (int32_t)c->amg->levels.size() : 0;
+        info->pc_setup_seconds = pc_setup_s;
+        info->operator_complexity = 0.0;
+        if (use_amg) {
+            double tot = 0.0;
+            for (auto &L : c->amg->levels) tot += (double)L->nnzb;
+            info->operator_complexity = tot / (double)c->amg->levels[0]->nnzb;
+        }
     }
     if (hs.done < 0)
         return set_err(FEMSHELL_ERR_BREAKDOWN, "femshell_solve: CG breakdown, p.Ap <= 0 (matrix not positive definite)");
@@ -570,8 +744,6 @@ int femshell_export_bsr(femshell_ctx *c, int32_t *rowptr, int32_t *colidx, doubl
     int rc = select_device(c);
     if (rc) return rc;
     const Plan &p = c->plan;
-    std::vector<double> h((size_t)p.total_slots() * 36);
-    FS_HIP(hipMemcpyAsync(h.data(), c->vals.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (F) {
         if (!c->rhs_valid) {
             rc = do_rhs(c);
@@ -579,30 +751,12 @@ int femshell_export_bsr(femshell_ctx *c, int32_t *rowptr, int32_t *colidx, doubl
         }
         FS_HIP(hipMemcpyAsync(F, c->F.p, (size_t)p.n_own * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
-    FS_HIP(hipStreamSynchronize(c->stream));
-    int64_t nb = 0;
-    rowptr[0] = 0;
-    std::vector<std::pair<int32_t, int>> order;
-    for (int32_t a = 0; a < p.n_own; a++) {
-        const int s = a / kSliceNodes, n = a % kSliceNodes;
-        const int64_t base = p.slice_base[s];
-        order.clear();
-        for (int k = 0; k < p.slice_width[s]; k++) {
-            const int64_t slot = Plan::slot_index(base, k, n);
-            if (p.pair_ptr[slot + 1] > p.pair_ptr[slot]) order.push_back({p.cols[slot], k});
-        }
-        std::sort(order.begin(), order.end());
-        for (auto &ck : order) {
-            colidx[nb] = ck.first; // single rank: local id == global id
-            double *blk = vals + 36 * nb;
-            const double *src = h.data() + base * 36;
-            for (int i = 0; i < 6; i++)
-                for (int j = 0; j < 6; j++)
-                    blk[6 * i + j] = src[((((int64_t)ck.second * 3 + j / 2) * 6 + i) * kSliceNodes + n) * 2 + (j & 1)];
-            nb++;
-        }
-        rowptr[a + 1] = (int32_t)nb;
-    }
+    Bsr A;
+    rc = download_matrix(c, &A);
+    if (rc) return rc;
+    for (int32_t a = 0; a <= p.n_own; a++) rowptr[a] = (int32_t)A.ptr[a];
+    std::copy(A.col.begin(), A.col.end(), colidx);
+    std::copy(A.val.begin(), A.val.end(), vals);
     return FEMSHELL_OK;
 }
 

@@ -2,27 +2,11 @@
 // ablation harness tools/lab/asm_lab.hip).
 #pragma once
 
+#include "device_common.hpp"
 #include "kernels.hpp"
 #include "plan.hpp"
 
 namespace femshell {
-
-// Workgroup b belongs to XCD group x = b%8 and walks the slices x*per + j, j = b/8, b/8 + G/8, ...
-// of that group's contiguous eighth of the rows (per = ceil(S/8), G = gridDim.x).
-struct SliceWalk {
-    int per, first, last, step, s;
-    __device__ __forceinline__ SliceWalk(int n_slices)
-    {
-        per = (n_slices + 7) >> 3;
-        const int x = blockIdx.x & 7;
-        first = x * per;
-        last = min(first + per, n_slices);
-        step = gridDim.x >> 3;
-        s = first + (blockIdx.x >> 3);
-    }
-    __device__ __forceinline__ bool valid() const { return s < last; }
-    __device__ __forceinline__ void next() { s += step; }
-};
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding
 // global stores (s_waitcnt vmcnt(0)), which would expose the latency of the K stores of every output pass;

@@ -54,7 +54,7 @@ int spmv_with_halo(femshell_ctx *c, const CgVectors &v, double *xin, double *you
 int scalar_step(femshell_ctx *c, const CgVectors &v, int nsums, CgPhase phase, double rtol, int n_partials, int len3)
 {
     if (c->comm.active()) {
-        launch_cg_scalar(c->dm, v, true, nsums, CG_PHASE_NONE, rtol, c->stream, n_partials, len3);
+        launch_cg_scalar(c->dm, v, true, nsums, CG_PHASE_NONE, rtol, c->stream, n_partials, len3, (int)phase);
         std::string e;
         double *red = reinterpret_cast<double *>(reinterpret_cast<char *>(v.s) + offsetof(CgScalars, red));
         if (!comm_allreduce_sum(c->comm, red, nsums, c->stream, &e)) return set_err(FEMSHELL_ERR_COMM, e);

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -14,6 +15,8 @@
 #include "plan.hpp"
 
 namespace femshell {
+
+struct Amg; // multigrid hierarchy (amg_device.hpp)
 
 // records the message femshell_last_error() returns on the calling thread and passes `code` through
 int set_err(int code, const std::string &msg);
@@ -63,6 +66,8 @@ struct femshell_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int32_t *status_host = nullptr; // pinned landing place of the device status word
+    double *agree_host = nullptr;   // pinned word of the cross-rank agreement on a rank-local failure (api.cpp)
+    femshell::DevBuf<double> agree;
     // halo exchange beside the interior SpMV (multi-rank contexts): second stream + hand-off events
     hipStream_t halo_stream = nullptr;
     hipEvent_t ev_p_ready = nullptr, ev_halo_done = nullptr;
@@ -93,6 +98,9 @@ struct femshell_ctx {
     femshell::DeviceMatrix dm{};
     femshell::Comm comm;
     std::vector<int32_t> all_begin, all_end;
+
+    femshell_pc_options pc{};           // preconditioner of femshell_solve (block-Jacobi unless set otherwise)
+    std::shared_ptr<femshell::Amg> amg; // hierarchy of the multigrid preconditioner, rebuilt when K changes
 
     double last_assemble_s = 0.0, last_setup_s = 0.0;
     std::vector<double> hist_host;

@@ -10,6 +10,7 @@
 // by neighbouring slices.
 #include "kernels.hpp"
 #include "plan.hpp"
+#include "device_common.hpp"
 #include "assemble_kernel.hpp"
 
 #include <cstdlib>
@@ -36,27 +37,6 @@ int slice_grid(const DeviceMatrix &m)
     }();
     const int g = 8 * ((m.n_slices + 7) / 8);
     return g < cap ? g : cap;
-}
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// sum over the workgroup, valid in thread 0; sh must hold blockDim.x/64 doubles
-__device__ __forceinline__ double block_sum(double v, double *sh)
-{
-    v = wave_sum(v);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    if (lane == 0) sh[w] = v;
-    __syncthreads();
-    double t = 0.0;
-    if (threadIdx.x == 0)
-        for (int i = 0; i < nw; i++) t += sh[i];
-    __syncthreads();
-    return t;
 }
 
 void launch_assemble(const DeviceMatrix &m, const MatConst &mc, hipStream_t st)
@@ -184,10 +164,6 @@ void launch_element_matrices(const DeviceMatrix &m, const MatConst &mc, int32_t 
 // Block-Jacobi setup: invert the 6x6 diagonal block of every owned node (Cholesky: the blocks are SPD)
 // into the packed layout the CG vector kernels stream.
 // =====================================================================================
-// minv layout: per slice 21 words (upper triangle of the symmetric 6x6 inverse, row-major) x 32 nodes, nodes fastest
-constexpr int kMinvWords = 21;
-__host__ __device__ __forceinline__ int minv_word(int i, int j) { return (i * (11 - i)) / 2 + j; } // i <= j
-
 __global__ void k_block_jacobi(DeviceMatrix m)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -327,7 +303,8 @@ __device__ __forceinline__ double spmv_fma(const SpmvChunk<kChunk> &c, const dou
 template <int kChunk>
 __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__restrict__ x,
                                               double *__restrict__ y, double *__restrict__ partials,
-                                              const CgScalars *s, const int32_t *__restrict__ order, int count)
+                                              const CgScalars *s, const int32_t *__restrict__ order, int count,
+                                              const double *base_vec, double sign)
 {
     extern __shared__ double2 xs_all[]; // max_slice_width x 32 nodes x 3 words: x of the slice's block columns
     __shared__ double sh[3];
@@ -358,7 +335,8 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
             acc = spmv_fma<kChunk>(ch, xs, k0, W, acc);
         }
         const int64_t row = (int64_t)sl * kSliceRows + (t & 31) * 6 + (t >> 5);
-        y[row] = acc;
+        // base_vec: y = base + sign * K x (residual b - K x, prolongation x + P x_c); may alias y
+        y[row] = base_vec != nullptr ? base_vec[row] + sign * acc : acc;
         if (partials != nullptr) {
             // x[row] is in LDS already: slot 0 is the diagonal block, its column is the lane's own node
             const double2 xw = xs[t >> 6]; // word (t / 32) / 2 of the node's six entries
@@ -372,7 +350,8 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
 }
 
 static void spmv_dispatch(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
-                          const int32_t *order, int count, int grid, hipStream_t st)
+                          const int32_t *order, int count, int grid, hipStream_t st, const double *base_vec = nullptr,
+                          double sign = 1.0)
 {
     static const int chunk = [] {
         const char *e = getenv("FEMSHELL_SPMV_CHUNK"); // tuning knob: block slots loaded together
@@ -383,7 +362,7 @@ static void spmv_dispatch(const DeviceMatrix &m, const double *x, double *y, dou
     auto launch = [&](auto kernel) {
         if (lds > 64 * 1024) // beyond the default dynamic-LDS limit (slices wider than 42 blocks)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kernel, g, b, lds, st, m, x, y, partials, s, order, count);
+        hipLaunchKernelGGL(kernel, g, b, lds, st, m, x, y, partials, s, order, count, base_vec, sign);
     };
     switch (chunk) {
     case 1: launch(k_spmv<1>); break;
@@ -397,6 +376,12 @@ void launch_spmv(const DeviceMatrix &m, const double *x, double *y, double *part
                  hipStream_t st)
 {
     spmv_dispatch(m, x, y, partials, s, nullptr, m.n_slices, slice_grid(m), st);
+}
+
+void launch_spmv_axpy(const DeviceMatrix &m, const double *x, double *y, const double *base_vec, double sign,
+                      const CgScalars *s, hipStream_t st)
+{
+    spmv_dispatch(m, x, y, nullptr, s, nullptr, m.n_slices, slice_grid(m), st, base_vec, sign);
 }
 
 int span_grid(const DeviceMatrix &m, int count)
@@ -417,29 +402,6 @@ int launch_spmv_span(const DeviceMatrix &m, const double *x, double *y, double *
 // =====================================================================================
 // CG vector kernels (one lane per scalar row, one workgroup per slice)
 // =====================================================================================
-
-// z_row = sum_j Minv[row][j] * r[node*6+j].  The six Minv entries of the row are fetched before the
-// residual of the slice is exchanged through LDS, so their latency overlaps the barrier.
-struct MinvRow {
-    double a[6];
-};
-__device__ __forceinline__ MinvRow load_minv(const DeviceMatrix &m, int sl, int t)
-{
-    const int n = t / 6, i = t % 6;
-    const double *mi = m.minv + (int64_t)sl * kMinvWords * kSliceNodes + n;
-    MinvRow r;
-#pragma unroll
-    for (int j = 0; j < 6; j++) r.a[j] = mi[minv_word(i < j ? i : j, i < j ? j : i) * kSliceNodes];
-    return r;
-}
-__device__ __forceinline__ double apply_minv(const MinvRow &mr, int t, const double *rs)
-{
-    const int nb = (t / 6) * 6;
-    double z = 0.0;
-#pragma unroll
-    for (int j = 0; j < 6; j++) z += mr.a[j] * rs[nb + j];
-    return z;
-}
 
 __global__ __launch_bounds__(192) void k_cg_init(DeviceMatrix m, CgVectors v, int restart)
 {
@@ -692,6 +654,32 @@ __device__ __forceinline__ void cg_scalar_phase(const CgVectors &v, int phase, d
                 s->rz = rzn;
             }
         }
+    } else if (phase == CG_PHASE_FLEX_INIT) {
+        s->bb = s->red[0];
+        s->rr = s->red[0];
+        s->tol2 = rtol > 0.0 ? rtol * rtol * s->red[0] : 0.0;
+        s->alpha = 0.0;
+        s->beta = 0.0;
+        s->rz = 0.0;
+        s->iters = 0;
+        s->done = (s->red[0] == 0.0) ? 1 : 0;
+    } else if (phase == CG_PHASE_FLEX_RZ0) {
+        s->rz = s->red[0];
+        if (!(s->red[0] > 0.0)) s->done = -1; // the preconditioner is not positive definite
+    } else if (phase == CG_PHASE_FLEX_CONV) {
+        const double rr = s->red[0];
+        s->rr = rr;
+        const int it = s->iters + 1;
+        s->iters = it;
+        if (v.hist != nullptr && it <= v.hist_cap) v.hist[it - 1] = rr / s->bb;
+        if (rr <= s->tol2) s->done = 1;
+    } else if (phase == CG_PHASE_FLEX_BETA) {
+        const double rzn = s->red[0], zq = s->red[1];
+        if (!(rzn > 0.0)) s->done = -1;
+        else {
+            s->beta = -s->alpha * zq / s->rz;
+            s->rz = rzn;
+        }
     } else if (phase == CG_PHASE_BETA) {
         const double rzn = s->red[0], rr = s->red[1];
         s->rr = rr;
@@ -707,11 +695,14 @@ __device__ __forceinline__ void cg_scalar_phase(const CgVectors &v, int phase, d
 }
 
 __global__ __launch_bounds__(256) void k_cg_scalar(CgVectors v, int G, int do_reduce, int nsums, int phase,
-                                                   double rtol, int len3)
+                                                   double rtol, int len3, int gate_phase)
 {
     __shared__ double sh[4];
     CgScalars *s = v.s;
-    if (phase != CG_PHASE_INIT && phase != CG_PHASE_RESTART && phase != CG_PHASE_FUSED_INIT && s->done != 0)
+    // gate_phase: the phase this launch belongs to (a reduce-only launch in front of an all-reduce carries
+    // phase NONE but must not be skipped when it serves an INIT / RESTART step on a finished solve)
+    if (gate_phase != CG_PHASE_INIT && gate_phase != CG_PHASE_RESTART && gate_phase != CG_PHASE_FUSED_INIT &&
+        gate_phase != CG_PHASE_FLEX_INIT && s->done != 0)
         return; // same decision in every workgroup
     if (!do_reduce) {
         if (blockIdx.x == 0 && threadIdx.x == 0) cg_scalar_phase(v, phase, rtol);
@@ -756,11 +747,12 @@ __global__ __launch_bounds__(256) void k_cg_scalar(CgVectors v, int G, int do_re
 }
 
 void launch_cg_scalar(const DeviceMatrix &m, const CgVectors &v, bool reduce, int nsums, CgPhase phase,
-                      double rtol, hipStream_t st, int n_partials, int len3)
+                      double rtol, hipStream_t st, int n_partials, int len3, int gate_phase)
 {
     const int G = n_partials > 0 ? n_partials : slice_grid(m);
     const int groups = reduce ? (G >= 4096 ? kReduceGroups : 1) : 1;
-    hipLaunchKernelGGL(k_cg_scalar, dim3(groups), dim3(256), 0, st, v, G, reduce ? 1 : 0, nsums, (int)phase, rtol, len3);
+    hipLaunchKernelGGL(k_cg_scalar, dim3(groups), dim3(256), 0, st, v, G, reduce ? 1 : 0, nsums, (int)phase, rtol, len3,
+                       gate_phase < 0 ? (int)phase : gate_phase);
 }
 
 __global__ void k_pack(const double *p, const int32_t *nodes, int32_t count, double *buf)

@@ -88,7 +88,12 @@ struct CgVectors {
 
 enum CgPhase : int {
     CG_PHASE_NONE = 0, CG_PHASE_INIT = 1, CG_PHASE_ALPHA = 2, CG_PHASE_BETA = 3, CG_PHASE_RESTART = 4,
-    CG_PHASE_FUSED_INIT = 5, CG_PHASE_FUSED_STEP = 6 // single-reduction (Chronopoulos-Gear) recurrence
+    CG_PHASE_FUSED_INIT = 5, CG_PHASE_FUSED_STEP = 6, // single-reduction (Chronopoulos-Gear) recurrence
+    // flexible PCG around a general preconditioner (multigrid cycle, amg_solve.cpp):
+    CG_PHASE_FLEX_INIT = 7, // red[0] = b.b
+    CG_PHASE_FLEX_RZ0 = 8,  // red[0] = r.z of the initial residual
+    CG_PHASE_FLEX_CONV = 9, // red[0] = r.r after the update: iteration count, history, stopping test
+    CG_PHASE_FLEX_BETA = 10 // red[0] = r.z, red[1] = z.q: beta = z.(r - r_old) / rz_old = -alpha z.q / rz_old
 };
 
 int slice_grid(const DeviceMatrix &m); // workgroups of the per-slice kernels (multiple of 8, at most 2560)
@@ -105,6 +110,10 @@ void launch_element_matrices(const DeviceMatrix &m, const MatConst &mc, int32_t 
 // (s != nullptr: no-op once s->done != 0)
 void launch_spmv(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
                  hipStream_t st);
+// y = base_vec + sign * K x (base_vec may be y itself): residuals b - K x and prolongations x + P x_c of the
+// multigrid cycle; K may be rectangular (x indexed by the block columns, y and base_vec by the block rows)
+void launch_spmv_axpy(const DeviceMatrix &m, const double *x, double *y, const double *base_vec, double sign,
+                      const CgScalars *s, hipStream_t st);
 // the same over the slices order[begin, begin+count) only (interior / boundary halves of an overlapped
 // halo exchange); the partial sums go to partials[partial_offset ...]; returns the number written
 int launch_spmv_span(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
@@ -122,8 +131,10 @@ void launch_cg_direction(const DeviceMatrix &m, const CgVectors &v, hipStream_t 
 // scalar update of `phase` (rtol only used by CG_PHASE_INIT)
 // (n_partials > 0: length of each partial array, default slice_grid(m); nsums == 3: the third array, the SpMV's,
 // starts at 2 * n_partials and holds len3 entries)
+// gate_phase >= 0: the phase whose skip rule applies (the reduce-only launch in front of an all-reduce runs phase
+// NONE on behalf of another phase; INIT / RESTART steps must also run on a finished solve)
 void launch_cg_scalar(const DeviceMatrix &m, const CgVectors &v, bool reduce, int nsums, CgPhase phase,
-                      double rtol, hipStream_t st, int n_partials = 0, int len3 = 0);
+                      double rtol, hipStream_t st, int n_partials = 0, int len3 = 0, int gate_phase = -1);
 
 // Single-reduction preconditioned CG (Chronopoulos & Gear): one all-reduce of (r.z, r.r, z.Az) per iteration.
 //   init:   x = 0, r = b, z = M^-1 r, p = s = 0, partial sums of r.z and r.r

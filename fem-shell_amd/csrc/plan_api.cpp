@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 
+#include "amg.hpp"
 #include "context.hpp"
 
 using namespace femshell;
@@ -98,6 +99,103 @@ int64_t femshell_plan_array(const femshell_plan *plan, int which, void *out)
         return give(tmp);
     default: return -1;
     }
+}
+
+
+// ---- host-only pieces of the multigrid setup ---------------------------------------------------------------
+
+struct femshell_amg_coarsening {
+    std::vector<int32_t> agg;
+    Bsr P, Ac;
+    std::vector<double> Bc;
+};
+
+namespace {
+void to_bsr(int32_t n, const int32_t *rowptr, const int32_t *colidx, const double *vals, Bsr *A)
+{
+    A->nr = A->nc = n;
+    A->ptr.assign(rowptr, rowptr + n + 1);
+    A->col.assign(colidx, colidx + rowptr[n]);
+    A->val.assign(vals, vals + 36ll * rowptr[n]);
+}
+} // namespace
+
+int femshell_amg_host_rbm(int32_t n_nodes, const double *xyz, const uint8_t *dmask, double *B_out)
+{
+    if (n_nodes <= 0 || !xyz || !B_out) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_host_rbm: invalid argument");
+    std::vector<double> B;
+    rigid_body_modes(n_nodes, xyz, dmask, &B);
+    std::memcpy(B_out, B.data(), B.size() * sizeof(double));
+    return FEMSHELL_OK;
+}
+
+int femshell_amg_host_coarsen(int32_t n_nodes, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                              const double *B, double lambda_max, femshell_amg_coarsening **out)
+{
+    if (n_nodes <= 0 || !rowptr || !colidx || !vals || !B || !out || !(lambda_max > 0.0))
+        return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_host_coarsen: invalid argument");
+    Bsr A;
+    to_bsr(n_nodes, rowptr, colidx, vals, &A);
+    femshell_amg_coarsening *h = new femshell_amg_coarsening();
+    const int32_t na = aggregate_nodes(A, &h->agg);
+    std::vector<double> Bv(B, B + 36ll * n_nodes), Q, Dinv;
+    tentative_prolongator(h->agg, na, Bv, &Q, &h->Bc);
+    block_diagonal_inverse(A, &Dinv);
+    smoothed_prolongator(A, Dinv, h->agg, na, Q, (4.0 / 3.0) / lambda_max, &h->P);
+    Bsr R;
+    galerkin_product(A, h->P, &R, &h->Ac);
+    *out = h;
+    return FEMSHELL_OK;
+}
+
+void femshell_amg_coarsening_destroy(femshell_amg_coarsening *h) { delete h; }
+
+int64_t femshell_amg_coarsening_array(const femshell_amg_coarsening *h, int which, void *out)
+{
+    if (!h) return -1;
+    auto give = [&](const void *src, size_t count, size_t elem) -> int64_t {
+        if (out && count) std::memcpy(out, src, count * elem);
+        return (int64_t)count;
+    };
+    switch (which) {
+    case FEMSHELL_COARSEN_AGG: return give(h->agg.data(), h->agg.size(), sizeof(int32_t));
+    case FEMSHELL_COARSEN_P_ROWPTR: return give(h->P.ptr.data(), h->P.ptr.size(), sizeof(int64_t));
+    case FEMSHELL_COARSEN_P_COLS: return give(h->P.col.data(), h->P.col.size(), sizeof(int32_t));
+    case FEMSHELL_COARSEN_P_VALS: return give(h->P.val.data(), h->P.val.size(), sizeof(double));
+    case FEMSHELL_COARSEN_AC_ROWPTR: return give(h->Ac.ptr.data(), h->Ac.ptr.size(), sizeof(int64_t));
+    case FEMSHELL_COARSEN_AC_COLS: return give(h->Ac.col.data(), h->Ac.col.size(), sizeof(int32_t));
+    case FEMSHELL_COARSEN_AC_VALS: return give(h->Ac.val.data(), h->Ac.val.size(), sizeof(double));
+    case FEMSHELL_COARSEN_BC: return give(h->Bc.data(), h->Bc.size(), sizeof(double));
+    default: return -1;
+    }
+}
+
+int femshell_amg_host_dense_inverse(int32_t n_nodes, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                                    double *inv_out)
+{
+    if (n_nodes <= 0 || !rowptr || !colidx || !vals || !inv_out)
+        return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_host_dense_inverse: invalid argument");
+    Bsr A;
+    to_bsr(n_nodes, rowptr, colidx, vals, &A);
+    std::vector<double> inv;
+    if (!dense_inverse(A, &inv)) return set_err(FEMSHELL_ERR_BREAKDOWN, "femshell_amg_host_dense_inverse: matrix is not positive definite");
+    std::memcpy(inv_out, inv.data(), inv.size() * sizeof(double));
+    return FEMSHELL_OK;
+}
+
+int64_t femshell_amg_host_pack(int32_t n_rows, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                               int32_t diag_first, int32_t *slice_width, int64_t *slice_base, int32_t *cols, double *ell_vals)
+{
+    if (n_rows <= 0 || !rowptr || !colidx || !vals) return -1;
+    Bsr A;
+    to_bsr(n_rows, rowptr, colidx, vals, &A);
+    SlicedEll S;
+    pack_sliced_ell(A, diag_first != 0, &S);
+    if (slice_width) std::memcpy(slice_width, S.slice_width.data(), S.slice_width.size() * sizeof(int32_t));
+    if (slice_base) std::memcpy(slice_base, S.slice_base.data(), S.slice_base.size() * sizeof(int64_t));
+    if (cols) std::memcpy(cols, S.cols.data(), S.cols.size() * sizeof(int32_t));
+    if (ell_vals) std::memcpy(ell_vals, S.vals.data(), S.vals.size() * sizeof(double));
+    return S.slice_base.back();
 }
 
 } // extern "C"

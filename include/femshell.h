@@ -103,7 +103,54 @@ typedef struct femshell_solve_info {
     double setup_seconds;   /* block-Jacobi factorisation */
     double solve_seconds;   /* CG loop, device time */
     double bytes_per_iteration; /* algorithmic HBM bytes of one CG iteration on this rank */
+    int32_t pc_type;        /* femshell_pc_type the solve ran with */
+    int32_t amg_levels;     /* levels of the multigrid hierarchy (0 with block-Jacobi) */
+    double pc_setup_seconds;/* host + device time of the multigrid setup done inside this call (0 if reused) */
+    double operator_complexity; /* sum of the level matrices' blocks / blocks of K (0 with block-Jacobi) */
 } femshell_solve_info;
+
+/* ---- preconditioner ------------------------------------------------------------------
+ * replaces: the -ksp_type / -pc_type options the reference passes through to PETSc
+ * (doc/implementation.tex:68-72; equation_systems.parameters stay untouched, SA:130-133).
+ * The Krylov method is always CG (K is SPD).  FEMSHELL_PC_BLOCK_JACOBI (default) is the 6x6
+ * point-block Jacobi whose iterates the CPU oracle reproduces step by step; its iteration
+ * count grows with the element count.  FEMSHELL_PC_AMG is a smoothed-aggregation multigrid
+ * (rigid-body modes, Chebyshev/block-Jacobi smoothing, V or K cycle) around which the solve
+ * runs a flexible CG: the answer a user of `-pc_type gamg` expects, with iteration counts
+ * that stay near 100 up to the 4M-triangle meshes.  Single-rank contexts only for now.
+ * The environment variable FEMSHELL_PC=amg|jacobi sets the default of new contexts. */
+typedef enum femshell_pc_type { FEMSHELL_PC_BLOCK_JACOBI = 0, FEMSHELL_PC_AMG = 1 } femshell_pc_type;
+typedef enum femshell_cycle { FEMSHELL_CYCLE_V = 0, FEMSHELL_CYCLE_K = 1 } femshell_cycle;
+typedef struct femshell_pc_options {
+    int32_t type;            /* femshell_pc_type */
+    int32_t cycle;           /* femshell_cycle (default K: two flexible-CG steps per coarse level) */
+    int32_t smoother_degree; /* Chebyshev degree on the finest level (default 2) */
+    int32_t coarse_degree;   /* Chebyshev degree on the coarser levels (default 4) */
+    int32_t coarsest_nodes;  /* coarsening stops at this many nodes; dense inverse there (default 200) */
+    int32_t max_levels;      /* default 12 */
+    double eig_ratio;        /* the smoother targets [lambda_max/eig_ratio, lambda_max] of D^-1 A (default 30) */
+} femshell_pc_options;
+/* fills *out with the defaults of `type` */
+int femshell_pc_defaults(int32_t type, femshell_pc_options *out);
+/* takes effect at the next femshell_solve; the hierarchy is rebuilt whenever K changes */
+int femshell_set_preconditioner(femshell_ctx *ctx, const femshell_pc_options *opt);
+
+/* inspection of the multigrid hierarchy of the last solve (tests; host copies are kept for
+ * matrices of up to 2M blocks): level 0 is K itself */
+typedef struct femshell_amg_level_info {
+    int32_t n_nodes;        /* block rows of the level */
+    int32_t n_coarse;       /* aggregates = block rows of the next level (0 on the coarsest) */
+    int64_t nnz_blocks;     /* blocks of the level matrix */
+    int64_t p_blocks;       /* blocks of the prolongator to this level from the next (0 on the coarsest) */
+    double lambda_max;      /* upper end of the smoother's interval for D^-1 A */
+} femshell_amg_level_info;
+int32_t femshell_amg_levels(femshell_ctx *ctx);
+int femshell_amg_level(femshell_ctx *ctx, int32_t level, femshell_amg_level_info *info);
+enum { FEMSHELL_AMG_AGGREGATES = 0, /* int32 [n_nodes] */
+       FEMSHELL_AMG_A_ROWPTR, FEMSHELL_AMG_A_COLS, FEMSHELL_AMG_A_VALS,   /* int64 [n+1], int32 [nnzb], double [nnzb*36] */
+       FEMSHELL_AMG_P_ROWPTR, FEMSHELL_AMG_P_COLS, FEMSHELL_AMG_P_VALS };
+/* returns the element count of the array (-1: not available); copies it to out when out != NULL */
+int64_t femshell_amg_export(femshell_ctx *ctx, int32_t level, int32_t which, void *out);
 
 /* replaces: equation_systems.solve() -> PETSc KSPSolve (SA:138, PC:271) followed by
  * build_solution_vector (SA:141; PC:274-280 broadcast): 6x6-block-Jacobi preconditioned CG,

@@ -58,6 +58,33 @@ enum {
 /* returns the element count of the array; copies it to out when out != NULL */
 int64_t femshell_plan_array(const femshell_plan *plan, int which, void *out);
 
+/* ---- host-only pieces of the multigrid setup (csrc/amg.hpp), for CPU tests against the numpy restatement
+ * oracle/amg_oracle.py.  One coarsening step: aggregation, tentative prolongator from the near-null space B
+ * (n x 6 x 6: dof x mode), prolongator smoothing with omega = 4 / (3 lambda_max), Galerkin product. ---- */
+int femshell_amg_host_rbm(int32_t n_nodes, const double *xyz, const uint8_t *dmask, double *B_out);
+
+typedef struct femshell_amg_coarsening femshell_amg_coarsening;
+int femshell_amg_host_coarsen(int32_t n_nodes, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                              const double *B, double lambda_max, femshell_amg_coarsening **out);
+void femshell_amg_coarsening_destroy(femshell_amg_coarsening *h);
+enum {
+    FEMSHELL_COARSEN_AGG = 0,  /* int32 [n_nodes]                */
+    FEMSHELL_COARSEN_P_ROWPTR, /* int64 [n_nodes+1]              */
+    FEMSHELL_COARSEN_P_COLS,   /* int32                          */
+    FEMSHELL_COARSEN_P_VALS,   /* double [blocks*36]             */
+    FEMSHELL_COARSEN_AC_ROWPTR,/* int64 [n_coarse+1]             */
+    FEMSHELL_COARSEN_AC_COLS,
+    FEMSHELL_COARSEN_AC_VALS,
+    FEMSHELL_COARSEN_BC        /* double [n_coarse*36]: coarse near-null space */
+};
+int64_t femshell_amg_coarsening_array(const femshell_amg_coarsening *h, int which, void *out);
+/* dense inverse of a small SPD block matrix (coarsest level): inv_out (6n)^2 doubles */
+int femshell_amg_host_dense_inverse(int32_t n_nodes, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                                    double *inv_out);
+/* the sliced block ELL image the device kernels read, for layout tests: returns total slots; arrays may be NULL */
+int64_t femshell_amg_host_pack(int32_t n_rows, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                               int32_t diag_first, int32_t *slice_width, int64_t *slice_base, int32_t *cols, double *ell_vals);
+
 #ifdef __cplusplus
 }
 #endif

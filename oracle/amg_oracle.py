@@ -1,0 +1,275 @@
+"""CPU restatement (numpy/scipy) of the smoothed-aggregation multigrid preconditioner of libfemshell
+(fem-shell_amd/csrc/amg.hpp): TEST INFRASTRUCTURE ONLY -- imported by tests/ and tools/, never by the product.
+
+The reference delegates the solve to PETSc's KSP with user-chosen -ksp_type/-pc_type
+(/root/reference/src/fem-shell/fem-shell.cpp:130-138, doc/implementation.tex:68-72); there is no reference
+implementation of a multigrid method to restate.  What pins this path is therefore (a) the converged
+displacements, which are solver independent and are compared with the direct solve of the oracle-assembled K,
+and (b) this independent restatement of the published algorithm (Vanek, Mandel, Brezina, Computing 56, 1996;
+K cycle: Notay & Vassilevski, NLAA 15, 2008), against which the hierarchy the library builds is compared
+operator by operator.
+
+Conventions: matrices are scipy BSR with 6x6 blocks; B[n, dof, mode] is the near-null space.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+
+def rigid_body_modes(xyz, dmask):
+    xyz = np.asarray(xyz, dtype=np.float64).reshape(-1, 3)
+    n = len(xyz)
+    c = xyz - xyz.sum(axis=0) / n
+    B = np.zeros((n, 6, 6))
+    for i in range(6):
+        B[:, i, i] = 1.0
+    x, y, z = c[:, 0], c[:, 1], c[:, 2]
+    B[:, 1, 3], B[:, 2, 3] = -z, y   # rotation about x: u = (0,-z,y)
+    B[:, 0, 4], B[:, 2, 4] = z, -x   # about y: (z,0,-x)
+    B[:, 0, 5], B[:, 1, 5] = -y, x   # about z: (-y,x,0)
+    if dmask is not None:
+        dmask = np.asarray(dmask)
+        for v in range(6):
+            B[((dmask >> v) & 1) == 1, v, :] = 0.0
+    return B
+
+
+def aggregate(rowptr, colidx):
+    """Greedy distance-1 aggregation, three passes; returns (agg, n_aggregates)."""
+    n = len(rowptr) - 1
+    agg = -np.ones(n, dtype=np.int64)
+    na = 0
+    for i in range(n):
+        if agg[i] >= 0:
+            continue
+        nb = colidx[rowptr[i]:rowptr[i + 1]]
+        if len(nb) <= 1:
+            continue
+        if np.all(agg[nb] < 0):
+            agg[nb] = na
+            na += 1
+    agg2 = agg.copy()
+    for i in range(n):
+        if agg[i] >= 0:
+            continue
+        cand = agg[colidx[rowptr[i]:rowptr[i + 1]]]
+        cand = cand[cand >= 0]
+        if len(cand):
+            agg2[i] = cand[0]
+    agg = agg2
+    for i in range(n):
+        if agg[i] < 0:
+            nb = colidx[rowptr[i]:rowptr[i + 1]]
+            agg[nb[agg[nb] < 0]] = na
+            agg[i] = na
+            na += 1
+    return agg, na
+
+
+def tentative(agg, na, B):
+    """Per aggregate B_agg = Q R by modified Gram-Schmidt (two passes); dependent columns -> zero column of Q."""
+    n = len(agg)
+    order = np.argsort(agg, kind="stable")
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(agg, minlength=na))])
+    Q = np.zeros((n, 6, 6))
+    Bc = np.zeros((na, 6, 6))
+    for a in range(na):
+        idx = order[ptr[a]:ptr[a + 1]]
+        M = B[idx].reshape(-1, 6).copy()
+        R = np.zeros((6, 6))
+        for j in range(6):
+            n0 = np.linalg.norm(M[:, j])
+            for _ in range(2):
+                for i in range(j):
+                    c = M[:, i] @ M[:, j]
+                    M[:, j] -= c * M[:, i]
+                    R[i, j] += c
+            nj = np.linalg.norm(M[:, j])
+            if n0 > 0.0 and nj > 1e-8 * n0:
+                R[j, j] = nj
+                M[:, j] /= nj
+            else:
+                R[j, j] = 0.0
+                M[:, j] = 0.0
+        Q[idx] = M.reshape(-1, 6, 6)
+        Bc[a] = R
+    return Q, Bc
+
+
+def block_diag(A):
+    A = A.tobsr((6, 6))
+    A.sort_indices()
+    n = A.shape[0] // 6
+    D = np.zeros((n, 6, 6))
+    rows = np.repeat(np.arange(n), np.diff(A.indptr))
+    sel = A.indices == rows
+    D[rows[sel]] = A.data[sel]
+    return D
+
+
+def block_diag_inverse(A):
+    D = block_diag(A)
+    Dinv = np.zeros_like(D)
+    for i in range(len(D)):
+        try:
+            np.linalg.cholesky(D[i])
+            Dinv[i] = np.linalg.inv(D[i])
+        except np.linalg.LinAlgError:
+            Dinv[i] = np.eye(6)
+    return Dinv
+
+
+def bd_matrix(Dinv):
+    n = len(Dinv)
+    return sp.bsr_matrix((Dinv, np.arange(n, dtype=np.int32), np.arange(n + 1, dtype=np.int32)), shape=(6 * n, 6 * n))
+
+
+def coarsen(A, B, lam):
+    """One coarsening step with the upper spectral bound lam of D^-1 A: returns (agg, P, Ac, Bc)."""
+    A = A.tobsr((6, 6))
+    A.sort_indices()
+    n = A.shape[0] // 6
+    agg, na = aggregate(A.indptr, A.indices)
+    Q, Bc = tentative(agg, na, B)
+    P0 = sp.bsr_matrix((Q, agg.astype(np.int32), np.arange(n + 1, dtype=np.int32)), shape=(6 * n, 6 * na))
+    Dm = bd_matrix(block_diag_inverse(A))
+    P = (P0 - ((4.0 / 3.0) / lam) * (Dm @ (A @ P0))).tobsr((6, 6))
+    Ac = (P.T @ (A @ P)).tobsr((6, 6))
+    # coarse dofs without fine support: unit diagonal
+    d = Ac.diagonal()
+    if np.any(d == 0.0):
+        fix = sp.diags((d == 0.0).astype(np.float64))
+        Ac = (Ac + fix).tobsr((6, 6))
+    return agg, P, Ac, Bc
+
+
+def lambda_max(A, Dm, iterations=30):
+    """Power iteration for D^-1 A (the library does the same on the device with its own start vector)."""
+    x = np.random.default_rng(0).uniform(-1.0, 1.0, A.shape[0])
+    prev, lam = 0.0, 1.0
+    for it in range(iterations):
+        x = Dm @ (A @ x)
+        nrm = np.linalg.norm(x)
+        if it > 0:
+            lam = nrm / prev
+        prev = nrm
+    return lam
+
+
+class Level:
+    pass
+
+
+def setup(A, xyz, dmask, lams=None, coarsest_nodes=200, max_levels=12, eig_ratio=30.0, degree=2, coarse_degree=4):
+    """lams: upper bounds of the spectrum per level as the library reports them (femshell_amg_level); computed
+    here (1.1 x power iteration) when None."""
+    levels = []
+    B = rigid_body_modes(xyz, dmask)
+    A = A.tobsr((6, 6))
+    while True:
+        L = Level()
+        L.A = A
+        L.n = A.shape[0] // 6
+        L.Dm = bd_matrix(block_diag_inverse(A))
+        levels.append(L)
+        li = len(levels) - 1
+        if L.n <= coarsest_nodes or len(levels) >= max_levels:
+            L.dense_inv = np.linalg.inv(A.toarray())
+            break
+        L.lam = lams[li] if lams is not None else 1.1 * lambda_max(A, L.Dm)
+        L.agg, L.P, Ac, B = coarsen(A, B, L.lam)
+        L.R = L.P.T.tobsr((6, 6))
+        deg = degree if li == 0 else coarse_degree
+        lmax, lmin = L.lam, L.lam / eig_ratio
+        theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
+        sigma = theta / delta
+        L.inv_theta = 1.0 / theta
+        L.cheb = []
+        rho = 1.0 / sigma
+        for _ in range(1, deg):
+            rho_new = 1.0 / (2.0 * sigma - rho)
+            L.cheb.append((rho_new * rho, 2.0 * rho_new / delta))
+            rho = rho_new
+        A = Ac
+    return levels
+
+
+def smooth(L, b, x):
+    """Chebyshev smoothing in D^-1 A; x None = zero initial guess."""
+    if x is None:
+        r = b
+        x = np.zeros_like(b)
+    else:
+        r = b - L.A @ x
+    d = L.inv_theta * (L.Dm @ r)
+    x = x + d
+    for a, c in L.cheb:
+        r = r - L.A @ d
+        d = a * d + c * (L.Dm @ r)
+        x = x + d
+    return x
+
+
+def cycle(levels, li, b, kcycle):
+    L = levels[li]
+    if li == len(levels) - 1:
+        return L.dense_inv @ b
+    x = smooth(L, b, None)
+    bc = L.R @ (b - L.A @ x)
+    if kcycle and li + 2 < len(levels):
+        xc = kcycle_solve(levels, li + 1, bc)
+    else:
+        xc = cycle(levels, li + 1, bc, kcycle)
+    x = x + L.P @ xc
+    return smooth(L, b, x)
+
+
+def kcycle_solve(levels, li, rc):
+    """Two steps of flexible CG on A_li x = rc preconditioned by the cycle of level li."""
+    A = levels[li].A
+    c1 = cycle(levels, li, rc, True)
+    v1 = A @ c1
+    rho1, a1 = c1 @ v1, c1 @ rc
+    t = a1 / rho1 if rho1 > 0.0 else 0.0
+    r2 = rc - t * v1
+    c2 = cycle(levels, li, r2, True)
+    v2 = A @ c2
+    g, b2, a2 = c2 @ v1, c2 @ v2, c2 @ r2
+    w1, w2 = t, 0.0
+    if rho1 > 0.0:
+        rho2 = b2 - g * g / rho1
+        if rho2 > 0.0:
+            w1 = a1 / rho1 - g * a2 / (rho1 * rho2)
+            w2 = a2 / rho2
+    return w1 * c1 + w2 * c2
+
+
+def flexible_pcg(A, b, M, rtol=1e-10, max_it=1000):
+    """beta = z.(r - r_old) / r_old.z_old = -alpha z.q / rz_old; stops at ||r|| <= rtol ||b||."""
+    x = np.zeros_like(b)
+    r = b.copy()
+    bb = b @ b
+    hist = []
+    if bb == 0.0:
+        return x, hist
+    z = M(r)
+    rz = r @ z
+    p = z.copy()
+    for _ in range(max_it):
+        q = A @ p
+        alpha = rz / (p @ q)
+        x += alpha * p
+        r -= alpha * q
+        rr = r @ r
+        hist.append(np.sqrt(rr / bb))
+        if rr <= rtol * rtol * bb:
+            break
+        z = M(r)
+        rzn, zq = r @ z, z @ q
+        beta = -alpha * zq / rz
+        rz = rzn
+        p = z + beta * p
+    return x, hist
+
+
+def solve(A, b, levels, kcycle=True, rtol=1e-10, max_it=1000):
+    return flexible_pcg(A, b, lambda r: cycle(levels, 0, r, kcycle), rtol, max_it)

@@ -17,6 +17,12 @@ def build_problem(kind):
         m = meshes.structured(40, 56, 0, 0, 4, 5.6, kind="t", ul_lr=True, bcids=(0, 0, 1, -1), factor=3.0, loading=2)
         m.xyz[:, 2] = 0.2 * np.sin(1.1 * m.xyz[:, 0]) * np.cos(0.6 * m.xyz[:, 1])
         return m, (0.3, 2.0e5, 0.05)
+    if kind == "panel_bad":
+        # one zero-area triangle among the last rows: only the rank that owns it sees the failure locally
+        m, mat = build_problem("panel")
+        a, b, c = m.tri[-3]
+        m.xyz[c] = 0.5 * (m.xyz[a] + m.xyz[b])
+        return m, mat
     if kind == "cylinder":
         m = meshes.pinched_cylinder(48, 40)
         return m, m.material
@@ -45,6 +51,16 @@ def main():
     fs.set_mesh(m.xyz, m.tri, m.quad)
     fs.set_dirichlet(m.dirichlet_mask())
     fs.set_loads(m.loads)
+    if kind == "panel_bad":
+        # every rank must come back with an error (none may hang in a collective of the CG loop)
+        try:
+            fs.solve(rtol=1e-11, max_it=1000)
+            code, msg = 0, ""
+        except pkg.FemShellError as ex:
+            code, msg = ex.code, str(ex)
+        np.savez(out_file, code=code, msg=msg)
+        fs.close()
+        return
     u, info = fs.solve(rtol=1e-11, max_it=100000)
     b, e = fs.row_range()
     # a second solve on the same context with doubled loads (the coupled program re-solves every coupling iteration)

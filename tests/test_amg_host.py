@@ -1,0 +1,136 @@
+"""Host side of the multigrid setup (csrc/amg_setup.cpp) against the numpy restatement oracle/amg_oracle.py:
+aggregation, tentative prolongator, prolongator smoothing, Galerkin product, coarsest inverse, device layout.
+CPU only."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import amg_oracle
+from tests.helpers import meshes, oracle
+from tests.helpers.product import ensure_built
+
+
+def _binding():
+    import importlib
+
+    return importlib.import_module("fem-shell_amd.binding")
+
+
+def _problem(kind):
+    if kind == "panel":
+        m = meshes.structured(24, 20, 0, 0, 6, 5, kind="t", ul_lr=True, bcids=(0, 0, 1, -1), factor=300.0, loading=2)
+        mat = oracle.material(0.3, 1e7, 0.5)
+    elif kind == "roof":
+        m = meshes.scordelis_lo(18)
+        mat = oracle.material(*m.material)
+    elif kind == "quads":
+        m = meshes.structured(12, 12, 0, 0, 10, 10, kind="q", bcids=(1, 1, 1, 1), factor=1.0, loading=2)
+        mat = oracle.material(0.3, 10.92, 1.0)
+    dm = m.dirichlet_mask()
+    rp, ci, vals, F = oracle.assemble(m.xyz, m.tri, m.quad, mat, dm, m.loads)
+    return m, dm, rp, ci, vals, F
+
+
+def _bsr(rowptr, cols, vals, nc):
+    n = len(rowptr) - 1
+    return sp.bsr_matrix((vals, cols, rowptr), shape=(6 * n, 6 * nc))
+
+
+@pytest.mark.parametrize("kind", ["panel", "roof", "quads"])
+def test_one_coarsening_step_equals_the_restatement(kind):
+    ensure_built()
+    m, dm, rp, ci, vals, F = _problem(kind)
+    B = _binding().amg_host_rbm(m.xyz, dm)
+    B0 = amg_oracle.rigid_body_modes(m.xyz, dm)
+    np.testing.assert_allclose(B, B0, rtol=0, atol=1e-13 * np.abs(B0).max())
+    lam = 2.5
+    h = _binding().amg_host_coarsen(rp, ci, vals, B, lam)
+    A = _bsr(rp, ci, vals, m.n_nodes)
+    agg, P, Ac, Bc = amg_oracle.coarsen(A, B0, lam)
+    na = int(agg.max()) + 1
+    np.testing.assert_array_equal(h["agg"], agg)
+    assert len(h["Ac_rowptr"]) == na + 1
+    # every node has an aggregate, aggregates are connected neighbourhoods of ~7 nodes on these meshes
+    assert h["agg"].min() == 0 and 3.0 < m.n_nodes / na < 12.0
+    Pl = _bsr(h["P_rowptr"], h["P_cols"], h["P_vals"], na)
+    assert abs(Pl - P).max() <= 1e-12 * abs(P).max()
+    Acl = _bsr(h["Ac_rowptr"], h["Ac_cols"], h["Ac_vals"], na)
+    assert abs(Acl - Ac).max() <= 1e-12 * abs(Ac).max()
+    np.testing.assert_allclose(h["Bc"], Bc, rtol=0, atol=1e-11 * np.abs(Bc).max())
+    # the smoothed prolongator reproduces the near-null space where no Dirichlet row interferes: P Bc = B - omega D^-1 A B,
+    # and A B = 0 on rows whose whole neighbourhood is unconstrained -- except in the drilling rotation: the
+    # reference's drilling block (max/1000 on every node block, SA:1035-1052) is positive definite, it penalises
+    # theta_z itself, so a rigid rotation about the normal has a little energy there (flat meshes: row 5 only)
+    PB = (Pl @ sp.bsr_matrix((h["Bc"], np.arange(na, dtype=np.int32), np.arange(na + 1, dtype=np.int32)),
+                            shape=(6 * na, 6 * na))).toarray().reshape(m.n_nodes, 6, na, 6)
+    free = np.ones(m.n_nodes, dtype=bool)
+    for a in range(m.n_nodes):
+        nb = ci[rp[a]:rp[a + 1]]
+        nb2 = np.concatenate([ci[rp[b]:rp[b + 1]] for b in nb])
+        free[a] = not dm[nb2].any()
+    scale = np.abs(B0).max()
+    for a in (np.nonzero(free)[0][:50] if kind != "roof" else []):
+        got = PB[a].sum(axis=1)  # sum over aggregates of the block row of P Bc
+        assert np.abs(got - B0[a])[:5].max() <= 1e-8 * scale
+    # symmetric and positive definite coarse operator
+    Ad = Acl.toarray()
+    assert np.abs(Ad - Ad.T).max() <= 1e-12 * np.abs(Ad).max()
+    assert np.linalg.eigvalsh(0.5 * (Ad + Ad.T)).min() > 0.0
+
+
+def test_rank_deficient_aggregates_get_inert_coarse_dofs():
+    # a clamped strip: aggregates made of fully fixed nodes carry no near-null-space vector at all; their coarse
+    # dofs must come out as decoupled unit rows (the level matrix stays SPD)
+    ensure_built()
+    m = meshes.structured(6, 30, 0, 0, 1, 5, kind="t", ul_lr=True, bcids=(1, 1, 1, 1))
+    m.loads[:, 2] = 1.0
+    dm = m.dirichlet_mask()
+    dm[m.xyz[:, 1] < 1.01] = 0x3F  # clamp a whole region
+    mat = oracle.material(0.3, 1e5, 0.1)
+    rp, ci, vals, F = oracle.assemble(m.xyz, m.tri, m.quad, mat, dm, m.loads)
+    B = _binding().amg_host_rbm(m.xyz, dm)
+    h = _binding().amg_host_coarsen(rp, ci, vals, B, 2.5)
+    na = len(h["Ac_rowptr"]) - 1
+    Ad = _bsr(h["Ac_rowptr"], h["Ac_cols"], h["Ac_vals"], na).toarray()
+    inert = np.nonzero(np.abs(h["Bc"]).sum(axis=2).reshape(-1) == 0.0)[0]  # zero rows of the coarse near-null space
+    assert len(inert) >= 6
+    for k in inert:
+        assert Ad[k, k] == 1.0 and np.abs(Ad[k]).sum() == 1.0 and np.abs(Ad[:, k]).sum() == 1.0
+    assert np.linalg.eigvalsh(0.5 * (Ad + Ad.T)).min() > 0.0
+
+
+def test_dense_inverse_of_the_coarsest_operator():
+    ensure_built()
+    m, dm, rp, ci, vals, F = _problem("panel")
+    B = _binding().amg_host_rbm(m.xyz, dm)
+    h = _binding().amg_host_coarsen(rp, ci, vals, B, 2.5)
+    na = len(h["Ac_rowptr"]) - 1
+    inv = _binding().amg_host_dense_inverse(h["Ac_rowptr"].astype(np.int32), h["Ac_cols"], h["Ac_vals"])
+    Ad = _bsr(h["Ac_rowptr"], h["Ac_cols"], h["Ac_vals"], na).toarray()
+    assert np.abs(inv @ Ad - np.eye(6 * na)).max() < 1e-8
+    assert np.abs(inv - inv.T).max() == 0.0
+
+
+@pytest.mark.parametrize("diag_first", [True, False])
+def test_sliced_ell_image_of_a_level_operator(diag_first):
+    # the layout k_spmv reads: vals[base*36 + (((k*3 + j/2)*6 + i)*32 + n)*2 + j%2] for slot k of node n of a slice
+    ensure_built()
+    m, dm, rp, ci, vals, F = _problem("roof")
+    sw, sb, cols, ev = _binding().amg_host_pack(rp, ci, vals, diag_first)
+    n = m.n_nodes
+    assert len(sw) == (n + 31) // 32 and sb[-1] == len(cols)
+    x = np.random.default_rng(3).standard_normal((((n + 31) // 32) * 32, 6))
+    x[n:] = 0.0
+    y = np.zeros_like(x)
+    for s in range(len(sw)):
+        blk = ev[sb[s] * 36:sb[s + 1] * 36].reshape(sw[s], 3, 6, 32, 2)  # k, jp, i, n, jj
+        for k in range(sw[s]):
+            c = cols[sb[s] + k * 32: sb[s] + (k + 1) * 32]
+            xs = x[c].reshape(32, 3, 2)  # n, jp, jj
+            y[32 * s:32 * s + 32] += np.einsum("pind,npd->ni", blk[k], xs)
+            if diag_first and k == 0:
+                rows = np.arange(32 * s, 32 * s + 32)
+                assert np.array_equal(c[rows < n], rows[rows < n])
+    y0 = oracle.spmv(rp, ci, vals, x[:n].ravel()).reshape(n, 6)
+    assert np.abs(y[:n] - y0).max() <= 1e-13 * np.abs(y0).max()
+    assert np.abs(y[n:]).max() == 0.0

@@ -1,0 +1,126 @@
+"""Multigrid-preconditioned solves on the GPU (csrc/amg_*.{cpp,hip}) against the CPU oracle: converged
+displacements against the direct solve, the hierarchy against the numpy restatement oracle/amg_oracle.py,
+iteration counts against the restatement's flexible PCG."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import amg_oracle
+from tests.helpers import meshes, oracle
+from tests.helpers.product import ensure_built, pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(kind, n):
+    if kind == "panel":
+        m = meshes.structured(n, n, 0, 0, 10, 10, kind="t", ul_lr=True, bcids=(0, 0, 0, 0), factor=300.0, loading=2)
+        mat = (0.3, 1e7, 0.5)
+    elif kind == "roof":
+        m = meshes.scordelis_lo(n)
+        mat = m.material
+    elif kind == "cylinder":
+        m = meshes.pinched_cylinder(n, n)
+        mat = m.material
+    elif kind == "quads":
+        m = meshes.structured(n, n, 0, 0, 10, 10, kind="q", bcids=(1, 1, 1, 1), factor=300.0, loading=2)
+        mat = (0.3, 1e7, 0.5)
+    return m, mat
+
+
+def _context(m, mat):
+    ensure_built()
+    fs = pkg.FemShell(*mat, device=0)
+    fs.set_mesh(m.xyz, m.tri, m.quad)
+    fs.set_dirichlet(m.dirichlet_mask())
+    fs.set_loads(m.loads)
+    return fs
+
+
+def _bsr(rowptr, cols, vals, nc):
+    n = len(rowptr) - 1
+    return sp.bsr_matrix((vals, cols, rowptr), shape=(6 * n, 6 * nc))
+
+
+@pytest.mark.parametrize("kind,n", [("panel", 64), ("roof", 48), ("cylinder", 48), ("quads", 40)])
+def test_multigrid_solve_matches_the_direct_solve(kind, n):
+    m, mat = _make(kind, n)
+    fs = _context(m, mat)
+    fs.set_preconditioner("amg")
+    u, info = fs.solve(rtol=1e-12, max_it=500)
+    assert info["converged"] == 1 and info["pc_type"] == 1 and info["amg_levels"] >= 2
+    rg, cg, vg, Fg = fs.export_bsr()
+    # solver term: against the refined direct solve of the matrix the GPU assembled (north star: < 1e-10)
+    ug = oracle.refined_solve(rg, cg, vg, Fg)
+    err = np.linalg.norm(u.ravel() - ug) / np.linalg.norm(ug)
+    assert err < 1e-10, err
+    # block-Jacobi needs an order of magnitude more iterations on the same system
+    fs.set_preconditioner("jacobi")
+    u2, info2 = fs.solve(rtol=1e-12, max_it=200000)
+    assert info2["converged"] == 1 and info2["iterations"] > 8 * info["iterations"], (info["iterations"], info2["iterations"])
+    assert np.linalg.norm(u2.ravel() - ug) / np.linalg.norm(ug) < 2e-10
+    fs.close()
+
+
+@pytest.mark.parametrize("cycle", ["V", "K"])
+def test_hierarchy_and_iteration_counts_follow_the_restatement(cycle):
+    m, mat = _make("panel", 48)
+    fs = _context(m, mat)
+    fs.set_preconditioner("amg", cycle=cycle, coarsest_nodes=60)
+    u, info = fs.solve(rtol=1e-10, max_it=400)
+    assert info["converged"] == 1
+    lv = fs.amg_levels()
+    assert len(lv) >= 3 and lv[0]["n_nodes"] == m.n_nodes
+    rg, cg, vg, Fg = fs.export_bsr()
+    A = _bsr(rg, cg, vg, m.n_nodes)
+    # the restatement with the library's spectral bounds (its power iteration starts from another vector)
+    levels = amg_oracle.setup(A, m.xyz, m.dirichlet_mask(), lams=[l["lambda_max"] for l in lv], coarsest_nodes=60)
+    assert [L.n for L in levels] == [l["n_nodes"] for l in lv]
+    for li, L in enumerate(levels[:-1]):
+        ex = fs.amg_export(li)
+        np.testing.assert_array_equal(ex["agg"], L.agg)
+        P = _bsr(ex["P_rowptr"], ex["P_cols"], ex["P_vals"], lv[li]["n_coarse"])
+        assert abs(P - L.P).max() <= 1e-11 * abs(L.P).max()
+        Al = _bsr(ex["A_rowptr"], ex["A_cols"], ex["A_vals"], lv[li]["n_nodes"])
+        assert abs(Al - L.A).max() <= 1e-10 * abs(L.A).max()
+        # the library's bound is a bound: 1.1 x its power iteration against an independent estimate
+        assert 0.9 * lv[li]["lambda_max"] <= 1.1 * amg_oracle.lambda_max(L.A, L.Dm, 60) <= 1.25 * lv[li]["lambda_max"]
+    u0, hist = amg_oracle.solve(A, Fg, levels, kcycle=(cycle == "K"), rtol=1e-10, max_it=400)
+    assert abs(len(hist) - info["iterations"]) <= 2, (len(hist), info["iterations"])
+    h = fs.residual_history()
+    k = min(len(h), len(hist), 20)
+    np.testing.assert_allclose(h[:k], hist[:k], rtol=1e-5)
+    assert np.linalg.norm(u.ravel() - u0) / np.linalg.norm(u0) < 1e-8
+    fs.close()
+
+
+def test_hierarchy_is_reused_until_the_matrix_changes():
+    m, mat = _make("roof", 40)
+    fs = _context(m, mat)
+    fs.set_preconditioner("amg")
+    u1, i1 = fs.solve(rtol=1e-10, max_it=300)
+    assert i1["pc_setup_seconds"] > 0.0
+    fs.set_loads(2.0 * m.loads)
+    u2, i2 = fs.solve(rtol=1e-10, max_it=300)
+    assert i2["pc_setup_seconds"] == 0.0 and i2["converged"] == 1
+    assert np.linalg.norm(u2 - 2.0 * u1) <= 1e-8 * np.linalg.norm(u2)
+    # a new Dirichlet set changes K: the hierarchy is rebuilt
+    dm = m.dirichlet_mask()
+    dm[m.n_nodes // 2] = 0x3F
+    fs.set_dirichlet(dm)
+    u3, i3 = fs.solve(rtol=1e-10, max_it=300)
+    assert i3["pc_setup_seconds"] > 0.0 and i3["converged"] == 1
+    assert np.abs(u3[m.n_nodes // 2]).max() == 0.0
+    # bitwise reproducible
+    u4, i4 = fs.solve(rtol=1e-10, max_it=300)
+    assert np.array_equal(u3, u4) and i3["iterations"] == i4["iterations"]
+    fs.close()
+
+
+def test_multigrid_is_refused_on_multi_rank_contexts():
+    ensure_built()
+    fs = pkg.FemShell(0.3, 1.0, 1.0, device=0, rank=0, world_size=2)
+    with pytest.raises(pkg.FemShellError) as e:
+        fs.set_preconditioner("amg")
+    assert e.value.code == -7
+    fs.close()

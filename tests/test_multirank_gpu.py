@@ -58,9 +58,25 @@ def test_partitioned_solve_on_one_gpu_matches_single_rank(world, kind, tmp_path)
         # re-solve on the same context (state left by the first solve must not leak): linear in the loads
         assert r["converged2"] == 1 and abs(int(r["iterations2"]) - int(r["iterations"])) <= 3
         assert np.linalg.norm(r["u2"] - 2.0 * r["u"]) <= 1e-8 * np.linalg.norm(r["u2"])
+        # the explicit residual ||b - K u|| / ||b|| is a global quantity: every rank reports the same number and it
+        # is the single-rank one up to the rounding of two different CG runs (the reduction in front of the
+        # all-reduce once skipped its work on a finished solve and reported stale sums times sqrt(world))
+        assert float(r["true_res"]) == float(ranks[0]["true_res"])
+        assert 0.2 * float(single["true_res"]) <= float(r["true_res"]) <= 5.0 * float(single["true_res"]), (
+            float(r["true_res"]), float(single["true_res"]))
     assert covered.all()
     err = np.linalg.norm(ranks[0]["u"] - single["u"]) / np.linalg.norm(single["u"])
     assert err < 1e-8, err  # two CG runs with different summation order on an ill-conditioned system
+
+
+def test_rank_local_failure_is_reported_by_every_rank(tmp_path):
+    # a degenerate element exists on the rank that owns its rows only; the others must not walk on into the
+    # collectives of the CG loop (they would hang): all ranks agree on the outcome after the assembly
+    ranks = run_ranks(3, "panel_bad", tmp_path)
+    codes = [int(r["code"]) for r in ranks]
+    assert all(c == -4 for c in codes), codes  # FEMSHELL_ERR_MESH everywhere
+    assert any("degenerate" in str(r["msg"]) and "triangle" in str(r["msg"]) for r in ranks)
+    assert any("other rank" in str(r["msg"]) for r in ranks)
 
 
 def test_halo_overlap_and_single_stream_exchange_agree(tmp_path):

@@ -1,0 +1,41 @@
+"""Multigrid-preconditioned solve on a BASELINE-size mesh: iterations, time to solution, hierarchy facts.
+usage: amg_probe.py panel|roof|cylinder N [V|K] [rtol]"""
+import importlib
+import json
+import sys
+import time
+
+sys.path.insert(0, ".")
+from tests.helpers import meshes  # noqa: E402
+
+pkg = importlib.import_module("fem-shell_amd")
+kind, n = sys.argv[1], int(sys.argv[2])
+cycle = sys.argv[3] if len(sys.argv) > 3 else "K"
+rtol = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-10
+if kind == "panel":
+    m = meshes.structured(n, n, 0, 0, 10, 10, kind="t", ul_lr=True, bcids=(0, 0, 0, 0), factor=300.0, loading=2)
+    mat = (0.3, 1e7, 0.5)
+elif kind == "roof":
+    m = meshes.scordelis_lo(n)
+    mat = m.material
+else:
+    m = meshes.pinched_cylinder(n, n)
+    mat = m.material
+fs = pkg.FemShell(*mat, device=0)
+t0 = time.time()
+fs.set_mesh(m.xyz, m.tri, m.quad)
+fs.set_dirichlet(m.dirichlet_mask())
+fs.set_loads(m.loads)
+fs.assemble()
+print("mesh %s %d: %d tri, symbolic+assembly %.2fs" % (kind, n, len(m.tri), time.time() - t0), flush=True)
+fs.set_preconditioner("amg", cycle=cycle)
+t0 = time.time()
+u, info = fs.solve(rtol=rtol, max_it=3000, fetch=False)
+wall = time.time() - t0
+print(json.dumps({"wall_s": wall, **info}))
+for l in fs.amg_levels():
+    print("  ", l)
+u2, info2 = fs.solve(rtol=rtol, max_it=3000, fetch=False)
+print("second solve (hierarchy reused):", json.dumps(info2))
+h = fs.residual_history()
+print("residual history (every 10th):", " ".join("%.1e" % v for v in h[::10]))
