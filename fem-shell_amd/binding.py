@@ -22,7 +22,7 @@ SYMBOLS = [
     "femshell_nnz_blocks", "femshell_export_bsr", "femshell_spmv", "femshell_row_begin",
     "femshell_row_end", "femshell_comm_unique_id", "femshell_comm_init", "femshell_time_kernel",
     "femshell_sync", "femshell_pc_defaults", "femshell_set_preconditioner", "femshell_amg_levels", "femshell_amg_level",
-    "femshell_amg_export",
+    "femshell_amg_export", "femshell_residual",
 ]
 
 
@@ -46,7 +46,8 @@ class SolveInfo(C.Structure):
 
 class PcOptions(C.Structure):
     _fields_ = [("type", C.c_int32), ("cycle", C.c_int32), ("smoother_degree", C.c_int32), ("coarse_degree", C.c_int32),
-                ("coarsest_nodes", C.c_int32), ("max_levels", C.c_int32), ("eig_ratio", C.c_double)]
+                ("coarsest_nodes", C.c_int32), ("max_levels", C.c_int32), ("refine_passes", C.c_int32), ("reserved", C.c_int32),
+                ("eig_ratio", C.c_double)]
 
 
 class AmgLevelInfo(C.Structure):
@@ -101,6 +102,7 @@ def load_library():
     L.femshell_nnz_blocks.restype = C.c_int64
     L.femshell_export_bsr.argtypes = [vp, ip, ip, dp, dp]
     L.femshell_spmv.argtypes = [vp, dp, dp]
+    L.femshell_residual.argtypes = [vp, dp, dp]
     L.femshell_row_begin.argtypes = [vp]
     L.femshell_row_begin.restype = C.c_int32
     L.femshell_row_end.argtypes = [vp]
@@ -238,6 +240,13 @@ class FemShell:
         _check(self._L.femshell_spmv(self._h, _d(x), _d(y)))
         return y
 
+    def residual(self, x):
+        """F - K x with double-double products and row sums."""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        r = np.zeros_like(x)
+        _check(self._L.femshell_residual(self._h, _d(x), _d(r)))
+        return r
+
     def row_range(self):
         return int(self._L.femshell_row_begin(self._h)), int(self._L.femshell_row_end(self._h))
 
@@ -252,7 +261,7 @@ class FemShell:
 
     def set_preconditioner(self, kind="amg", **options):
         """kind: "jacobi" (6x6 block-Jacobi, the default) or "amg" (smoothed-aggregation multigrid);
-        options: cycle ("V"/"K"), smoother_degree, coarse_degree, coarsest_nodes, max_levels, eig_ratio."""
+        options: cycle ("V"/"K"), smoother_degree, coarse_degree, coarsest_nodes, max_levels, refine_passes, eig_ratio."""
         o = PcOptions()
         _check(self._L.femshell_pc_defaults(PC_AMG if kind == "amg" else PC_BLOCK_JACOBI, C.byref(o)))
         for k, v in options.items():

@@ -51,7 +51,9 @@ void amg_default_options(femshell_pc_options *o);
 int amg_setup(femshell_ctx *c);
 // z = M(r): one multigrid cycle on the context's stream (all launches are no-ops once gate->done != 0)
 int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate);
-int cg_amg(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it);
+// *true_rr_out: ||b - K x||^2 of the returned iterate when the residual replacement computed it, else -1
+// *rec_rr_out: recurrence ||r||^2 the stopping rule saw last
+int cg_amg(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it, double *true_rr_out, double *rec_rr_out);
 double amg_bytes_per_iteration(const femshell_ctx *c);
 // K of a single-rank context as host BSR with ascending columns (api.cpp)
 int download_matrix(femshell_ctx *c, Bsr *A);

@@ -185,6 +185,24 @@ void launch_pcg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st
     hipLaunchKernelGGL(k_pcg_update, dim3(slice_grid(m)), dim3(192), 0, st, m, v);
 }
 
+__global__ __launch_bounds__(192) void k_pcg_norm(DeviceMatrix m, CgVectors v)
+{
+    __shared__ double sh[3];
+    const int t = threadIdx.x;
+    double d1 = 0.0;
+    for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
+        const double rv = v.r[(int64_t)w.s * kSliceRows + t];
+        d1 += rv * rv;
+    }
+    const double t1 = block_sum(d1, sh);
+    if (threadIdx.x == 0) v.partials[blockIdx.x] = t1;
+}
+
+void launch_pcg_norm(const DeviceMatrix &m, const CgVectors &v, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pcg_norm, dim3(slice_grid(m)), dim3(192), 0, st, m, v);
+}
+
 __global__ __launch_bounds__(192) void k_pcg_dots(DeviceMatrix m, CgVectors v)
 {
     __shared__ double sh[3];
@@ -223,6 +241,24 @@ void launch_copy(const double *src, double *dst, int64_t n, const CgScalars *gat
     const int64_t n2 = n / 2, blocks = (n2 + 255) / 256; // vector lengths are multiples of 192
     hipLaunchKernelGGL(k_copy_gated, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st,
                        reinterpret_cast<const double2 *>(src), reinterpret_cast<double2 *>(dst), n2, gate);
+}
+
+__global__ __launch_bounds__(256) void k_add(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t n2)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+        const double2 a = src[i];
+        double2 d = dst[i];
+        d.x += a.x;
+        d.y += a.y;
+        dst[i] = d;
+    }
+}
+
+void launch_add(const double *src, double *dst, int64_t n, hipStream_t st)
+{
+    const int64_t n2 = n / 2, blocks = (n2 + 255) / 256;
+    hipLaunchKernelGGL(k_add, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st,
+                       reinterpret_cast<const double2 *>(src), reinterpret_cast<double2 *>(dst), n2);
 }
 
 // ---- K cycle -----------------------------------------------------------------------------------------------

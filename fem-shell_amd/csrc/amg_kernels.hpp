@@ -34,9 +34,12 @@ void launch_dense_gemv(const double *Ainv, const double *b, double *y, int32_t n
 void launch_pcg_init(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);
 // x += alpha p, r -= alpha q, partial sums of r.r into partials[0 ...]
 void launch_pcg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);
+// partial sums of r.r into partials[0 ...] (explicit residual of the residual replacement)
+void launch_pcg_norm(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);
 // partial sums of r.z into partials[0 ...] and of z.q into partials[G ...]
 void launch_pcg_dots(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);
 void launch_copy(const double *src, double *dst, int64_t n, const CgScalars *gate, hipStream_t st);
+void launch_add(const double *src, double *dst, int64_t n, hipStream_t st); // dst += src
 
 // ---- K cycle: two steps of flexible CG on the coarse problem of a level ------------------------------------
 // sums[k] = a_k . b_k for up to three pairs (single workgroup finishes; vectors of n6 entries), then the

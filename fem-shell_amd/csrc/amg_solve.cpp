@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 
@@ -115,6 +116,7 @@ void amg_default_options(femshell_pc_options *o)
     o->coarse_degree = 4;
     o->coarsest_nodes = 200;
     o->max_levels = 12;
+    o->refine_passes = 1;
     o->eig_ratio = 30.0;
 }
 
@@ -301,7 +303,7 @@ struct AmgPoll {
     int32_t next_check = 1, step = 1;
     int operator()(femshell_ctx *c, const CgVectors &v, int32_t it, int32_t max_it, CgScalars *hs)
     {
-        if (it + 1 != next_check || it + 1 >= max_it) return 0;
+        if (it + 1 != next_check && it + 1 < max_it) return 0;
         FS_HIP(hipMemcpyAsync(hs, v.s, sizeof *hs, hipMemcpyDeviceToHost, c->stream));
         FS_HIP(hipStreamSynchronize(c->stream));
         if (hs->done != 0) return 1;
@@ -323,38 +325,99 @@ int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate
 
 // Flexible preconditioned CG (beta = z.(r - r_old) / r_old.z_old, so that the K cycle's slightly varying operator
 // does not break the recurrence); stopping rule and scalars as in cg_classic.
-int cg_amg(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it)
+//
+// Iterative refinement: on the thin-shell systems ||K|| ||x|| exceeds ||b|| by seven to nine orders of magnitude.
+// Every product K p then carries rounding noise of eps ||K|| ||p||, part of which falls on the soft modes: the
+// displacement error against a direct solve stalls at 2e-10 on the 250k-triangle roof however far the recurrence
+// residual is driven.  After the recurrence has converged the residual of the iterate is therefore evaluated in
+// double-double (k_residual_dd; in plain FP64 it is noise itself, and restarting from it made the error worse:
+// 2e-10 -> 2e-9) and the correction equation K e = b - K x is solved by the same method from e = 0 in a vector of
+// its own -- there the noise scales with ||e||, not ||x|| -- and added once: x += e.  (Continuing the recurrence on
+// x itself does not help: every update x += alpha p rounds at eps ||x||.)  Measured on the roof: 2e-10 -> 2e-13
+// with one pass.  femshell_pc_options::refine_passes passes at most (default 1; 0 = off); the residual norm cannot
+// fall below eps ||K|| ||x|| (x is stored in FP64), so passes are counted, not tested.
+// *true_rr_out = ||b - K x||^2 (double-double) of the returned iterate.
+int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, double *true_rr_out, double *rec_rr_out)
 {
     const DeviceMatrix &m = c->dm;
     hipStream_t st = c->stream;
     const int64_t n6 = 6ll * m.n_pad;
-    launch_pcg_init(m, v, st);
-    int rc = scalar_step(c, v, 1, CG_PHASE_FLEX_INIT, rtol);
-    if (rc) return rc;
-    rc = amg_apply(c, v.r, v.z, v.s);
-    if (rc) return rc;
-    launch_pcg_dots(m, v, st);
-    rc = scalar_step(c, v, 1, CG_PHASE_FLEX_RZ0, rtol);
-    if (rc) return rc;
-    launch_copy(v.z, v.p, n6, v.s, st);
+    *true_rr_out = -1.0;
+    *rec_rr_out = -1.0;
+    const int refine = c->amg->opt.refine_passes;
+    CgVectors v = v0;
     CgScalars hs{};
-    AmgPoll poll;
-    for (int32_t it = 0; it < max_it; it++) {
-        launch_spmv(m, v.p, v.q, v.partials, v.s, st);
-        rc = scalar_step(c, v, 1, CG_PHASE_ALPHA, rtol);
-        if (rc) return rc;
-        launch_pcg_update(m, v, st);
-        rc = scalar_step(c, v, 1, CG_PHASE_FLEX_CONV, rtol);
-        if (rc) return rc;
+    int32_t it = 0;
+    for (int pass = 0;; pass++) {
+        int rc;
+        if (pass == 0) {
+            launch_pcg_init(m, v, st);
+            rc = scalar_step(c, v, 1, CG_PHASE_FLEX_INIT, rtol);
+            if (rc) return rc;
+        } else {
+            // correction equation: right-hand side = residual of the accumulated solution, evaluated in double-double
+            launch_residual_dd(m, c->xacc.p, v0.b, c->rres.p, st);
+            v.b = c->rres.p;
+            launch_pcg_init(m, v, st); // x = 0, r = rhs, partial sums of r.r
+            rc = scalar_step(c, v, 1, CG_PHASE_FLEX_RESTART, rtol);
+            if (rc) return rc;
+            FS_HIP(hipMemcpyAsync(&hs, v.s, sizeof hs, hipMemcpyDeviceToHost, st));
+            FS_HIP(hipStreamSynchronize(st));
+            *true_rr_out = hs.rr;
+            if (hs.done != 0 || pass > refine || it >= max_it) {
+                const int32_t one = 1; // the solve as a whole has converged
+                FS_HIP(hipMemcpyAsync(reinterpret_cast<char *>(v.s) + offsetof(CgScalars, done), &one, sizeof one, hipMemcpyHostToDevice, st));
+                launch_copy(c->xacc.p, v.x, n6, nullptr, st);
+                FS_HIP(hipStreamSynchronize(st));
+                return FEMSHELL_OK;
+            }
+        }
         rc = amg_apply(c, v.r, v.z, v.s);
         if (rc) return rc;
         launch_pcg_dots(m, v, st);
-        rc = scalar_step(c, v, 2, CG_PHASE_FLEX_BETA, rtol);
+        rc = scalar_step(c, v, 1, CG_PHASE_FLEX_RZ0, rtol);
         if (rc) return rc;
-        launch_cg_direction(m, v, st);
-        rc = poll(c, v, it, max_it, &hs);
-        if (rc < 0) return rc;
-        if (rc == 1) break;
+        launch_copy(v.z, v.p, n6, v.s, st);
+        AmgPoll poll;
+        poll.next_check = it + 1;
+        bool finished = false;
+        for (; it < max_it; it++) {
+            launch_spmv(m, v.p, v.q, v.partials, v.s, st);
+            rc = scalar_step(c, v, 1, CG_PHASE_ALPHA, rtol);
+            if (rc) return rc;
+            launch_pcg_update(m, v, st);
+            rc = scalar_step(c, v, 1, CG_PHASE_FLEX_CONV, rtol);
+            if (rc) return rc;
+            rc = amg_apply(c, v.r, v.z, v.s);
+            if (rc) return rc;
+            launch_pcg_dots(m, v, st);
+            rc = scalar_step(c, v, 2, CG_PHASE_FLEX_BETA, rtol);
+            if (rc) return rc;
+            launch_cg_direction(m, v, st);
+            rc = poll(c, v, it, max_it, &hs);
+            if (rc < 0) return rc;
+            if (rc == 1) {
+                finished = true;
+                break;
+            }
+        }
+        if (!finished) {
+            FS_HIP(hipMemcpyAsync(&hs, v.s, sizeof hs, hipMemcpyDeviceToHost, st));
+            FS_HIP(hipStreamSynchronize(st));
+        }
+        it = hs.iters;
+        *rec_rr_out = hs.rr; // what the stopping rule saw
+        if (pass > 0) {
+            // x += e; the context's x is the accumulated solution again
+            launch_add(v.x, c->xacc.p, n6, st);
+            launch_copy(c->xacc.p, v.x, n6, nullptr, st);
+        }
+        if (hs.done != 1 || rtol <= 0.0) return FEMSHELL_OK; // iteration limit or breakdown: no refinement
+        if (pass == 0) {
+            FS_HIP(c->xacc.alloc((size_t)n6));
+            FS_HIP(c->rres.alloc((size_t)n6));
+            launch_copy(v.x, c->xacc.p, n6, nullptr, st);
+        }
     }
     return FEMSHELL_OK;
 }

@@ -515,6 +515,8 @@ int femshell_pc_defaults(int32_t type, femshell_pc_options *out)
     if (type == FEMSHELL_PC_AMG) {
         const char *cy = getenv("FEMSHELL_AMG_CYCLE");
         if (cy && (cy[0] == 'V' || cy[0] == 'v')) out->cycle = FEMSHELL_CYCLE_V;
+        const char *rp = getenv("FEMSHELL_REFINE_PASSES");
+        if (rp && atoi(rp) >= 0 && atoi(rp) <= 4) out->refine_passes = atoi(rp);
     }
     return FEMSHELL_OK;
 }
@@ -529,7 +531,7 @@ int femshell_set_preconditioner(femshell_ctx *c, const femshell_pc_options *opt)
             return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_set_preconditioner: the multigrid preconditioner serves single-rank contexts only");
         if ((opt->cycle != FEMSHELL_CYCLE_V && opt->cycle != FEMSHELL_CYCLE_K) || opt->smoother_degree < 1 || opt->smoother_degree > 16 ||
             opt->coarse_degree < 1 || opt->coarse_degree > 16 || opt->coarsest_nodes < 1 || opt->coarsest_nodes > 680 ||
-            opt->max_levels < 2 || opt->max_levels > 32 || !(opt->eig_ratio > 1.0))
+            opt->max_levels < 2 || opt->max_levels > 32 || !(opt->eig_ratio > 1.0) || opt->refine_passes < 0 || opt->refine_passes > 4)
             return set_err(FEMSHELL_ERR_INVALID, "femshell_set_preconditioner: option out of range");
     }
     c->pc = *opt;
@@ -618,16 +620,19 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
     // would skip its work on it (multi-rank re-solves, e.g. every coupling iteration)
     FS_HIP(c->scal.zero(st));
     const bool single_reduction = !use_amg && use_single_reduction(c);
-    rc = use_amg ? cg_amg(c, v, rtol, max_it)
+    double amg_true_rr = -1.0, amg_rec_rr = -1.0;
+    rc = use_amg ? cg_amg(c, v, rtol, max_it, &amg_true_rr, &amg_rec_rr)
                  : single_reduction ? cg_single_reduction(c, v, rtol, max_it) : cg_classic(c, v, rtol, max_it);
     if (rc) return rc;
     CgScalars hs{};
     FS_HIP(hipMemcpyAsync(&hs, v.s, sizeof hs, hipMemcpyDeviceToHost, st));
     FS_HIP(hipStreamSynchronize(st));
     const bool recurrence_converged = hs.done == 1;
-    const double recurrence_rr = hs.rr;
+    const double recurrence_rr = (use_amg && amg_rec_rr >= 0.0) ? amg_rec_rr : hs.rr;
     double true_rel = -1.0;
-    if (recurrence_converged && rtol > 0.0 && hs.bb > 0.0) {
+    if (use_amg && amg_true_rr >= 0.0 && hs.bb > 0.0) {
+        true_rel = std::sqrt(amg_true_rr / hs.bb); // computed by the residual replacement of cg_amg
+    } else if (recurrence_converged && rtol > 0.0 && hs.bb > 0.0) {
         // explicit residual r = b - K x (reported, not enforced): q = K x through the SpMV kernel, whose
         // input vector carries the ghost entries; the CG state is dead at this point
         launch_copy_x_to_p(m, v, st);
@@ -776,6 +781,30 @@ int femshell_spmv(femshell_ctx *c, const double *x, double *y)
     launch_spmv(c->dm, dx.p, dy.p, nullptr, nullptr, c->stream);
     FS_HIP(hipGetLastError());
     FS_HIP(hipMemcpyAsync(y, dy.p, (size_t)p.n_own * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(hipStreamSynchronize(c->stream));
+    return FEMSHELL_OK;
+}
+
+int femshell_residual(femshell_ctx *c, const double *x, double *r)
+{
+    if (!c || !x || !r) return set_err(FEMSHELL_ERR_INVALID, "femshell_residual: null argument");
+    if (!c->matrix_valid) return set_err(FEMSHELL_ERR_INVALID, "femshell_residual: call femshell_assemble first");
+    if (c->cfg.world_size != 1) return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_residual: single-rank contexts only");
+    int rc = select_device(c);
+    if (rc) return rc;
+    if (!c->rhs_valid) {
+        rc = do_rhs(c);
+        if (rc) return rc;
+    }
+    const Plan &p = c->plan;
+    DevBuf<double> dx, dr;
+    FS_HIP(dx.alloc((size_t)p.n_local_nodes() * 6));
+    FS_HIP(dr.alloc((size_t)p.n_pad * 6));
+    FS_HIP(dx.zero(c->stream));
+    FS_HIP(hipMemcpyAsync(dx.p, x, (size_t)p.n_own * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    launch_residual_dd(c->dm, dx.p, c->F.p, dr.p, c->stream);
+    FS_HIP(hipGetLastError());
+    FS_HIP(hipMemcpyAsync(r, dr.p, (size_t)p.n_own * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     FS_HIP(hipStreamSynchronize(c->stream));
     return FEMSHELL_OK;
 }

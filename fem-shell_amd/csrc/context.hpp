@@ -88,6 +88,7 @@ struct femshell_ctx {
     femshell::DevBuf<uint8_t> dmask;
     // CG state
     femshell::DevBuf<double> x, r, z, p, q, sv, partials, hist, sendbuf, ufull;
+    femshell::DevBuf<double> xacc, rres; // iterative refinement of the multigrid-preconditioned solve: accumulated solution, residual
     femshell::DevBuf<femshell::CgScalars> scal;
     femshell::DevBuf<int32_t> send_nodes, spmv_order;
     std::vector<int32_t> send_offsets; // per peer, in nodes

@@ -349,6 +349,86 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
     }
 }
 
+// Residual r = b - K x with the products and the row sums carried in double-double (error-free TwoProduct by FMA,
+// TwoSum accumulation): on the thin-shell systems ||K|| ||x|| exceeds ||b|| by seven to nine orders of magnitude, so a
+// residual evaluated in plain FP64 is rounding noise at 1e-7 ||b|| and restarting CG from it makes the answer worse.
+// This kernel feeds the residual replacement of the multigrid-preconditioned solve (amg_solve.cpp).  Same data
+// movement as k_spmv (HBM-bound at 0.2 flop/B; the five-fold arithmetic stays far below the FP64 ridge).
+struct DD {
+    double hi, lo;
+};
+// (with the default -ffp-contract=fast the compiler fuses acc.hi + a*x and a*x - bb into FMAs -- HIP's __dmul_rn /
+// __dadd_rn are plain operators and `#pragma clang fp contract(off)` did not prevent it either; the product is
+// therefore issued through inline assembly -- and the error terms below, which assume
+// s = fl(acc.hi + fl(a x)), would be those of a different sum: measured, the "double-double" residual was then no
+// better than the FP64 one)
+__device__ __forceinline__ void dd_fma_acc(DD &acc, double a, double x)
+{
+    double p; // fl(a x) as an opaque instruction: neither pragmas nor the _rn intrinsics stop the backend from fusing
+    asm("v_mul_f64 %0, %1, %2" : "=v"(p) : "v"(a), "v"(x));
+    const double e = __fma_rn(a, x, -p);          // a*x = p + e exactly
+    const double s = __dadd_rn(acc.hi, p);
+    const double bb = __dsub_rn(s, acc.hi);
+    const double err = __dadd_rn(__dsub_rn(acc.hi, __dsub_rn(s, bb)), __dsub_rn(p, bb)); // acc.hi + p = s + err exactly
+    acc.hi = s;
+    acc.lo = __dadd_rn(acc.lo, __dadd_rn(err, e));
+}
+
+__global__ __launch_bounds__(192) void k_residual_dd(DeviceMatrix m, const double *__restrict__ x, const double *__restrict__ b,
+                                                     double *__restrict__ r)
+{
+    extern __shared__ double2 xs_all[];
+    const int t = threadIdx.x;
+    const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
+        const int sl = w.s;
+        const int64_t base = m.slice_base[sl];
+        const int W = m.slice_width[sl];
+        const double2 *v = reinterpret_cast<const double2 *>(m.vals + base * 36) + t;
+        __syncthreads();
+        for (int e = t; e < W * kSliceNodes; e += kSliceRows) {
+            const double2 *xv = x2 + 3 * (int64_t)m.cols[base + e];
+            xs_all[3 * e] = xv[0];
+            xs_all[3 * e + 1] = xv[1];
+            xs_all[3 * e + 2] = xv[2];
+        }
+        __syncthreads();
+        const double2 *xs = xs_all + 3 * (t & 31);
+        DD acc{0.0, 0.0};
+        for (int k0 = 0; k0 < W; k0 += 4) {
+            SpmvChunk<4> ch;
+            spmv_load<4>(ch, v, k0, W);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (k0 + q < W) {
+                    const double2 *xx = xs + (size_t)(k0 + q) * 3 * kSliceNodes;
+#pragma unroll
+                    for (int u = 0; u < 3; u++) {
+                        const double2 xw = xx[u];
+                        dd_fma_acc(acc, ch.a[q][u].x, xw.x);
+                        dd_fma_acc(acc, ch.a[q][u].y, xw.y);
+                    }
+                }
+            }
+        }
+        const int64_t row = (int64_t)sl * kSliceRows + (t & 31) * 6 + (t >> 5);
+        // r = b - (hi + lo), the difference b - hi taken exactly
+        const double bv = b[row];
+        const double s = __dsub_rn(bv, acc.hi);
+        const double bb = __dsub_rn(s, bv);
+        const double err = __dadd_rn(__dsub_rn(bv, __dsub_rn(s, bb)), __dsub_rn(-acc.hi, bb));
+        r[row] = __dadd_rn(s, __dsub_rn(err, acc.lo));
+    }
+}
+
+void launch_residual_dd(const DeviceMatrix &m, const double *x, const double *b, double *r, hipStream_t st)
+{
+    const size_t lds = (size_t)m.max_slice_width * kSliceNodes * 3 * sizeof(double2);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_residual_dd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_residual_dd, dim3(slice_grid(m)), dim3(192), lds, st, m, x, b, r);
+}
+
 static void spmv_dispatch(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
                           const int32_t *order, int count, int grid, hipStream_t st, const double *base_vec = nullptr,
                           double sign = 1.0)
@@ -663,6 +743,14 @@ __device__ __forceinline__ void cg_scalar_phase(const CgVectors &v, int phase, d
         s->rz = 0.0;
         s->iters = 0;
         s->done = (s->red[0] == 0.0) ? 1 : 0;
+    } else if (phase == CG_PHASE_FLEX_RESTART) {
+        // a refinement pass starts: red[0] = r.r of the new right-hand side; b.b, the tolerance (relative to the
+        // original right-hand side), the iteration count and the history carry on
+        s->rr = s->red[0];
+        s->alpha = 0.0;
+        s->beta = 0.0;
+        s->rz = 0.0;
+        s->done = (s->red[0] <= s->tol2) ? 1 : 0;
     } else if (phase == CG_PHASE_FLEX_RZ0) {
         s->rz = s->red[0];
         if (!(s->red[0] > 0.0)) s->done = -1; // the preconditioner is not positive definite
@@ -702,7 +790,7 @@ __global__ __launch_bounds__(256) void k_cg_scalar(CgVectors v, int G, int do_re
     // gate_phase: the phase this launch belongs to (a reduce-only launch in front of an all-reduce carries
     // phase NONE but must not be skipped when it serves an INIT / RESTART step on a finished solve)
     if (gate_phase != CG_PHASE_INIT && gate_phase != CG_PHASE_RESTART && gate_phase != CG_PHASE_FUSED_INIT &&
-        gate_phase != CG_PHASE_FLEX_INIT && s->done != 0)
+        gate_phase != CG_PHASE_FLEX_INIT && gate_phase != CG_PHASE_FLEX_RESTART && s->done != 0)
         return; // same decision in every workgroup
     if (!do_reduce) {
         if (blockIdx.x == 0 && threadIdx.x == 0) cg_scalar_phase(v, phase, rtol);

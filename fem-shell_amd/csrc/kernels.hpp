@@ -93,7 +93,9 @@ enum CgPhase : int {
     CG_PHASE_FLEX_INIT = 7, // red[0] = b.b
     CG_PHASE_FLEX_RZ0 = 8,  // red[0] = r.z of the initial residual
     CG_PHASE_FLEX_CONV = 9, // red[0] = r.r after the update: iteration count, history, stopping test
-    CG_PHASE_FLEX_BETA = 10 // red[0] = r.z, red[1] = z.q: beta = z.(r - r_old) / rz_old = -alpha z.q / rz_old
+    CG_PHASE_FLEX_BETA = 10, // red[0] = r.z, red[1] = z.q: beta = z.(r - r_old) / rz_old = -alpha z.q / rz_old
+    CG_PHASE_FLEX_RESTART = 11 // red[0] = r.r of the right-hand side of a refinement pass (the double-double residual
+                               // of the accumulated solution); tolerance, iteration count and history carry on
 };
 
 int slice_grid(const DeviceMatrix &m); // workgroups of the per-slice kernels (multiple of 8, at most 2560)
@@ -114,6 +116,8 @@ void launch_spmv(const DeviceMatrix &m, const double *x, double *y, double *part
 // multigrid cycle; K may be rectangular (x indexed by the block columns, y and base_vec by the block rows)
 void launch_spmv_axpy(const DeviceMatrix &m, const double *x, double *y, const double *base_vec, double sign,
                       const CgScalars *s, hipStream_t st);
+// r = b - K x with double-double products and row sums (accurate residual for the residual replacement; r != x)
+void launch_residual_dd(const DeviceMatrix &m, const double *x, const double *b, double *r, hipStream_t st);
 // the same over the slices order[begin, begin+count) only (interior / boundary halves of an overlapped
 // halo exchange); the partial sums go to partials[partial_offset ...]; returns the number written
 int launch_spmv_span(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,

@@ -128,6 +128,11 @@ typedef struct femshell_pc_options {
     int32_t coarse_degree;   /* Chebyshev degree on the coarser levels (default 4) */
     int32_t coarsest_nodes;  /* coarsening stops at this many nodes; dense inverse there (default 200) */
     int32_t max_levels;      /* default 12 */
+    int32_t refine_passes;   /* iterative refinement after convergence: the residual of the iterate is evaluated in
+                                double-double and the correction equation solved by the same method (default 1; 0 = off).
+                                Plain FP64 CG stalls at a displacement error of kappa*eps -- 2e-10 on the 250k-triangle
+                                roof -- one pass brings it to 1e-13 */
+    int32_t reserved;
     double eig_ratio;        /* the smoother targets [lambda_max/eig_ratio, lambda_max] of D^-1 A (default 30) */
 } femshell_pc_options;
 /* fills *out with the defaults of `type` */
@@ -180,6 +185,9 @@ int64_t femshell_nnz_blocks(femshell_ctx *ctx); /* number of 6x6 blocks of K on 
 int femshell_export_bsr(femshell_ctx *ctx, int32_t *rowptr, int32_t *colidx, double *vals, double *F);
 /* y = K x on the device */
 int femshell_spmv(femshell_ctx *ctx, const double *x, double *y);
+/* r = F - K x with products and row sums in double-double (the residual the iterative refinement of the
+ * multigrid-preconditioned solve restarts from); x[n_nodes][6] */
+int femshell_residual(femshell_ctx *ctx, const double *x, double *r);
 
 /* ---- row partition over several GPUs (one process per GPU, RCCL over xGMI) ---------- */
 

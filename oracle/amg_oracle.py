@@ -271,5 +271,26 @@ def flexible_pcg(A, b, M, rtol=1e-10, max_it=1000):
     return x, hist
 
 
-def solve(A, b, levels, kcycle=True, rtol=1e-10, max_it=1000):
-    return flexible_pcg(A, b, lambda r: cycle(levels, 0, r, kcycle), rtol, max_it)
+def residual_extended(A, b, x):
+    """b - A x with products and row sums in numpy longdouble (the library uses double-double on the device)."""
+    A = A.tocsr()
+    A.sort_indices()
+    ld = np.longdouble
+    return (b.astype(ld) - np.add.reduceat(A.data.astype(ld) * x.astype(ld)[A.indices], A.indptr[:-1])).astype(np.float64)
+
+
+def solve(A, b, levels, kcycle=True, rtol=1e-10, max_it=1000, refine_passes=0):
+    """Flexible PCG around the cycle, then `refine_passes` steps of iterative refinement: residual of the iterate in
+    extended precision, correction equation solved by the same method to the same absolute tolerance, x += e."""
+    M = lambda r: cycle(levels, 0, r, kcycle)  # noqa: E731
+    x, hist = flexible_pcg(A, b, M, rtol, max_it)
+    nb = np.linalg.norm(b)
+    for _ in range(refine_passes):
+        r = residual_extended(A, b, x)
+        nr = np.linalg.norm(r)
+        if nr <= rtol * nb:
+            break
+        e, h = flexible_pcg(A, r, M, rtol * nb / nr, max_it - len(hist))
+        hist = hist + [v * nr / nb for v in h]
+        x = x + e
+    return x, hist

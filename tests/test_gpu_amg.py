@@ -85,12 +85,66 @@ def test_hierarchy_and_iteration_counts_follow_the_restatement(cycle):
         assert abs(Al - L.A).max() <= 1e-10 * abs(L.A).max()
         # the library's bound is a bound: 1.1 x its power iteration against an independent estimate
         assert 0.9 * lv[li]["lambda_max"] <= 1.1 * amg_oracle.lambda_max(L.A, L.Dm, 60) <= 1.25 * lv[li]["lambda_max"]
-    u0, hist = amg_oracle.solve(A, Fg, levels, kcycle=(cycle == "K"), rtol=1e-10, max_it=400)
-    assert abs(len(hist) - info["iterations"]) <= 2, (len(hist), info["iterations"])
+    u0, hist = amg_oracle.solve(A, Fg, levels, kcycle=(cycle == "K"), rtol=1e-10, max_it=400, refine_passes=1)
+    assert abs(len(hist) - info["iterations"]) <= 3, (len(hist), info["iterations"])
     h = fs.residual_history()
     k = min(len(h), len(hist), 20)
     np.testing.assert_allclose(h[:k], hist[:k], rtol=1e-5)
-    assert np.linalg.norm(u.ravel() - u0) / np.linalg.norm(u0) < 1e-8
+    assert np.linalg.norm(u.ravel() - u0) / np.linalg.norm(u0) < 1e-11
+    fs.close()
+
+
+def test_double_double_residual_and_what_refinement_buys():
+    # thin roof: ||K|| ||x|| / ||b|| ~ 1e7.  The FP64 residual of a converged iterate is rounding noise, the
+    # double-double one is exact to 1e-12 ||b||; without refinement the displacement error stalls near kappa*eps,
+    # one pass takes it down by orders of magnitude
+    m, mat = _make("roof", 96)
+    fs = _context(m, mat)
+    fs.set_preconditioner("amg", refine_passes=0)
+    u0, i0 = fs.solve(rtol=1e-12, max_it=500)
+    rg, cg, vg, Fg = fs.export_bsr()
+    A = _bsr(rg, cg, vg, m.n_nodes)
+    r_ext = amg_oracle.residual_extended(A, Fg, u0.ravel())
+    r_dd = fs.residual(u0)
+    r_f64 = Fg - A @ u0.ravel()
+    nb = np.linalg.norm(Fg)
+    assert np.linalg.norm(r_dd - r_ext) <= 1e-11 * nb
+    assert np.linalg.norm(r_f64 - r_ext) >= 50 * np.linalg.norm(r_dd - r_ext)  # FP64 evaluation: noise
+    assert abs(i0["true_rel_residual"] - np.linalg.norm(r_ext) / nb) <= 1e-3 * i0["true_rel_residual"]
+    ug = oracle.refined_solve(rg, cg, vg, Fg)
+    e0 = np.linalg.norm(u0.ravel() - ug) / np.linalg.norm(ug)
+    fs.set_preconditioner("amg", refine_passes=1)
+    u1, i1 = fs.solve(rtol=1e-12, max_it=500)
+    e1 = np.linalg.norm(u1.ravel() - ug) / np.linalg.norm(ug)
+    assert i1["iterations"] > i0["iterations"] and e1 < 1e-12 and e1 < 0.05 * e0, (e0, e1)
+    fs.close()
+
+
+def test_config1_scordelis_lo_250k_converged_against_the_direct_solve():
+    """BASELINE.json configs[1] at full size: 354 x 354 squares = 250,632 tri3, 756,150 dofs, solved to rtol 1e-12.
+    Solver term: against the oracle's refined direct solve of the matrix the GPU assembled, < 1e-10 (north star).
+    Total: against the oracle's own assembly + direct solve; the two FP64 assemblies agree to 1e-14 and kappa carries
+    that to ~2e-8 in the displacements -- any two correct FP64 implementations differ by that."""
+    m, mat = _make("roof", 354)
+    assert len(m.tri) == 250632
+    fs = _context(m, mat)
+    fs.set_preconditioner("amg")
+    u, info = fs.solve(rtol=1e-12, max_it=1000)
+    assert info["converged"] == 1 and info["iterations"] < 400
+    assert info["solve_seconds"] < 5.0
+    rg, cg, vg, Fg = fs.export_bsr()
+    ug = oracle.refined_solve(rg, cg, vg, Fg, sweeps=4)
+    solver_err = np.linalg.norm(u.ravel() - ug) / np.linalg.norm(ug)
+    assert solver_err < 1e-10, solver_err
+    r0, c0, v0, F0 = oracle.assemble(m.xyz, m.tri, m.quad, oracle.material(*mat), m.dirichlet_mask(), m.loads)
+    assert np.abs(vg - v0).max() <= 1e-12 * np.abs(v0).max()
+    assert np.array_equal(Fg, F0)
+    u0 = oracle.refined_solve(r0, c0, v0, F0, sweeps=4)
+    total = np.linalg.norm(u.ravel() - u0) / np.linalg.norm(u0)
+    sensitivity = np.linalg.norm(ug - u0) / np.linalg.norm(u0)
+    assert total < 1e-6 and abs(total - sensitivity) < 1e-10, (total, sensitivity)
+    print("config1 250k roof: %d iterations, %.3f s, solver term %.2e, total %.2e (two assemblies: %.2e)"
+          % (info["iterations"], info["solve_seconds"], solver_err, total, sensitivity))
     fs.close()
 
 
