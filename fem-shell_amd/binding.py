@@ -22,7 +22,7 @@ SYMBOLS = [
     "femshell_nnz_blocks", "femshell_export_bsr", "femshell_spmv", "femshell_row_begin",
     "femshell_row_end", "femshell_comm_unique_id", "femshell_comm_init", "femshell_time_kernel",
     "femshell_sync", "femshell_pc_defaults", "femshell_set_preconditioner", "femshell_amg_levels", "femshell_amg_level",
-    "femshell_amg_export", "femshell_residual",
+    "femshell_amg_export", "femshell_residual", "femshell_comm_ranks",
 ]
 
 
@@ -109,6 +109,8 @@ def load_library():
     L.femshell_row_end.restype = C.c_int32
     L.femshell_comm_unique_id.argtypes = [bp]
     L.femshell_comm_init.argtypes = [vp, bp]
+    L.femshell_comm_ranks.argtypes = [vp]
+    L.femshell_comm_ranks.restype = C.c_int32
     L.femshell_time_kernel.argtypes = [vp, C.c_int, C.c_int32, dp, dp]
     L.femshell_sync.argtypes = [vp]
     L.femshell_pc_defaults.argtypes = [C.c_int32, C.POINTER(PcOptions)]
@@ -121,7 +123,7 @@ def load_library():
     for name in SYMBOLS:
         if name != "femshell_last_error" and not name.startswith("femshell_nnz") and \
                 not name.startswith("femshell_row") and name != "femshell_residual_history" and \
-                name not in ("femshell_amg_levels", "femshell_amg_export"):
+                name not in ("femshell_amg_levels", "femshell_amg_export", "femshell_comm_ranks"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -177,6 +179,9 @@ class FemShell:
         uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
         assert uid.size == 128
         _check(self._L.femshell_comm_init(self._h, _b(uid)))
+
+    def comm_ranks(self):
+        return int(self._L.femshell_comm_ranks(self._h))
 
     def set_mesh(self, xyz, tri=None, quad=None):
         xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)

@@ -112,8 +112,8 @@ void amg_default_options(femshell_pc_options *o)
     std::memset(o, 0, sizeof *o);
     o->type = FEMSHELL_PC_AMG;
     o->cycle = FEMSHELL_CYCLE_K;
-    o->smoother_degree = 2;
-    o->coarse_degree = 4;
+    o->smoother_degree = 3; // tools/amg_sweep.py on the 1M-triangle panel and the 250k roof: K cycle with degree 3
+    o->coarse_degree = 3;   // on every level is the fastest to 1e-10 (93 / 91 iterations)
     o->coarsest_nodes = 200;
     o->max_levels = 12;
     o->refine_passes = 1;

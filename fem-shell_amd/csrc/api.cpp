@@ -340,6 +340,8 @@ int femshell_comm_init(femshell_ctx *c, const uint8_t id[128])
     return FEMSHELL_OK;
 }
 
+int32_t femshell_comm_ranks(femshell_ctx *c) { return c ? comm_count(c->comm) : 0; }
+
 int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri,
                       int32_t n_quad, const int32_t *quad)
 {

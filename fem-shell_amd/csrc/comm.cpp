@@ -16,6 +16,7 @@ struct Api {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -54,6 +55,7 @@ bool load_api(std::string *err)
     FS_SYM(GetUniqueId)
     FS_SYM(CommInitRank)
     FS_SYM(CommDestroy)
+    FS_SYM(CommCount)
     FS_SYM(AllReduce)
     FS_SYM(Broadcast)
     FS_SYM(Send)
@@ -97,6 +99,13 @@ bool comm_init(Comm &c, const uint8_t id_bytes[128], int rank, int world, std::s
     c.rank = rank;
     c.world = world;
     return true;
+}
+
+int comm_count(const Comm &c)
+{
+    int n = 0;
+    if (!c.comm || !g_api.CommCount || g_api.CommCount(static_cast<ncclComm_t>(c.comm), &n) != ncclSuccess) return 0;
+    return n;
 }
 
 void comm_destroy(Comm &c)

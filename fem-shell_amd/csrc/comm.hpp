@@ -30,6 +30,7 @@ struct Comm {
 bool comm_unique_id(uint8_t id_out[128], std::string *err);
 bool comm_init(Comm &c, const uint8_t id[128], int rank, int world, std::string *err);
 void comm_destroy(Comm &c);
+int comm_count(const Comm &c); // ranks RCCL itself reports for the communicator (ncclCommCount); 0 without one
 
 // in-place sum of `count` doubles across ranks, stream-ordered
 bool comm_allreduce_sum(Comm &c, double *buf, int count, hipStream_t st, std::string *err);

@@ -124,8 +124,8 @@ typedef enum femshell_cycle { FEMSHELL_CYCLE_V = 0, FEMSHELL_CYCLE_K = 1 } femsh
 typedef struct femshell_pc_options {
     int32_t type;            /* femshell_pc_type */
     int32_t cycle;           /* femshell_cycle (default K: two flexible-CG steps per coarse level) */
-    int32_t smoother_degree; /* Chebyshev degree on the finest level (default 2) */
-    int32_t coarse_degree;   /* Chebyshev degree on the coarser levels (default 4) */
+    int32_t smoother_degree; /* Chebyshev degree on the finest level (default 3) */
+    int32_t coarse_degree;   /* Chebyshev degree on the coarser levels (default 3) */
     int32_t coarsest_nodes;  /* coarsening stops at this many nodes; dense inverse there (default 200) */
     int32_t max_levels;      /* default 12 */
     int32_t refine_passes;   /* iterative refinement after convergence: the residual of the iterate is evaluated in
@@ -198,6 +198,8 @@ int32_t femshell_row_end(femshell_ctx *ctx);   /* one past the last owned node r
  * replaces: LibMeshInit / init.comm() (SA:28, 35) */
 int femshell_comm_unique_id(uint8_t id_out[128]);
 int femshell_comm_init(femshell_ctx *ctx, const uint8_t id[128]);
+/* ranks RCCL reports for this context's communicator (ncclCommCount); 0 when the context has none */
+int32_t femshell_comm_ranks(femshell_ctx *ctx);
 
 /* ---- measurement ----------------------------------------------------------------- */
 

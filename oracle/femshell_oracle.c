@@ -15,6 +15,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <time.h>
 
 /* ---------------------------------------------------------------- small dense helpers */
@@ -193,17 +196,13 @@ static void p_curv(const poly *p, double L1, double L2, double out[3])
     out[2] = 2.0 * d12;
 }
 
-void fso_tri3_specht_B(const double C[3], double L1, double L2, const double dphi[6], double B[27])
+/* chi_1..chi_9 for the side ratios mu (SA:702-704) as polynomials */
+static void specht_chi(const double mu[3], poly chi[9])
 {
-    /* SA:702-704 */
-    const double mu[3] = {(C[0] - C[1]) / C[2], (C[2] - C[0]) / C[1], (C[1] - C[2]) / C[0]};
-
     poly L[3];
     L[0] = p_lin(0.0, 1.0, 0.0);
     L[1] = p_lin(0.0, 0.0, 1.0);
     L[2] = p_lin(1.0, -1.0, -1.0);
-
-    poly chi[9];
     for (int i = 0; i < 3; i++) chi[i] = L[i];
     chi[3] = p_mul(&L[0], &L[1]);
     chi[4] = p_mul(&L[1], &L[2]);
@@ -219,7 +218,12 @@ void fso_tri3_specht_B(const double C[3], double L1, double L2, const double dph
         poly bub = p_mul(&L123, &lin);
         chi[6 + i] = p_axpby(1.0, &lead, 0.5, &bub);
     }
+}
 
+/* rows of B~ from the curvature triples cc[n] of chi_1..chi_9 at one point: the shape functions are linear
+ * combinations of the chi (shellelements.tex:1107-1111), and so are their curvatures */
+static void specht_compose(const double cc[9][3], const double dphi[6], double B[27])
+{
     /* coordinate differences seen from node i: (x_ki, y_ki) and (x_ji, y_ji);
      * dphi rows are (12),(31),(23) */
     static const int row_ki[3] = {1, 0, 2};
@@ -228,23 +232,73 @@ void fso_tri3_specht_B(const double C[3], double L1, double L2, const double dph
         const int k = (i + 2) % 3;
         const double xki = dphi[2 * row_ki[i]], yki = dphi[2 * row_ki[i] + 1];
         const double xji = -dphi[2 * row_ji[i]], yji = -dphi[2 * row_ji[i] + 1];
-        poly d = p_axpby(1.0, &chi[6 + k], -1.0, &chi[3 + k]); /* chi_{k+6} - chi_{k+3} */
-        poly e = p_axpby(1.0, &chi[6 + i], -1.0, &chi[6 + k]);
-        poly w = p_axpby(1.0, &chi[i], -1.0, &chi[3 + i]);
-        w = p_axpby(1.0, &w, 1.0, &chi[3 + k]);
-        w = p_axpby(1.0, &w, 2.0, &e);
-        poly tx = p_axpby(-yki, &d, yji, &chi[6 + i]);
-        poly ty = p_axpby(xki, &d, -xji, &chi[6 + i]);
-        double cw[3], cx[3], cy[3];
-        p_curv(&w, L1, L2, cw);
-        p_curv(&tx, L1, L2, cx);
-        p_curv(&ty, L1, L2, cy);
         for (int r = 0; r < 3; r++) {
-            B[r * 9 + 3 * i + 0] = cw[r];
-            B[r * 9 + 3 * i + 1] = cx[r];
-            B[r * 9 + 3 * i + 2] = cy[r];
+            const double d = cc[6 + k][r] - cc[3 + k][r];           /* chi_{k+6} - chi_{k+3} */
+            const double e = cc[6 + i][r] - cc[6 + k][r];
+            const double w = cc[i][r] - cc[3 + i][r] + cc[3 + k][r] + 2.0 * e;
+            B[r * 9 + 3 * i + 0] = w;
+            B[r * 9 + 3 * i + 1] = -yki * d + yji * cc[6 + i][r];
+            B[r * 9 + 3 * i + 2] = xki * d - xji * cc[6 + i][r];
         }
     }
+}
+
+void fso_tri3_specht_B(const double C[3], double L1, double L2, const double dphi[6], double B[27])
+{
+    /* SA:702-704 */
+    const double mu[3] = {(C[0] - C[1]) / C[2], (C[2] - C[0]) / C[1], (C[1] - C[2]) / C[0]};
+    poly chi[9];
+    specht_chi(mu, chi);
+    double cc[9][3];
+    for (int n = 0; n < 9; n++) p_curv(&chi[n], L1, L2, cc[n]);
+    specht_compose(cc, dphi, B);
+}
+
+/* Tabulated form used by the assembly (the reference evaluates closed-form entries, SA:706-888; the device kernels
+ * use the same idea, csrc/specht_tables.h): at a fixed Gauss point the curvatures of chi_1..chi_6 are constants and
+ * those of chi_7..chi_9 are affine in one side ratio mu.  The tables are filled once from the polynomial machinery
+ * above (values at mu = 0 and mu = 1), so the derivation stays the single source; fso_tri3_specht_B remains the
+ * cross-check (tests/test_oracle_known_answers.py). */
+static const double kGauss[3][2] = {{1.0 / 6.0, 1.0 / 6.0}, {2.0 / 3.0, 1.0 / 6.0}, {1.0 / 6.0, 2.0 / 3.0}};
+static double g_chi0[3][9][3], g_chi1[3][3][3];
+static int g_tables_ready = 0;
+
+void fso_init_tables(void)
+{
+    if (g_tables_ready) return;
+    const double mu0[3] = {0.0, 0.0, 0.0}, mu1[3] = {1.0, 1.0, 1.0};
+    poly c0[9], c1[9];
+    specht_chi(mu0, c0);
+    specht_chi(mu1, c1);
+    for (int g = 0; g < 3; g++) {
+        for (int n = 0; n < 9; n++) p_curv(&c0[n], kGauss[g][0], kGauss[g][1], g_chi0[g][n]);
+        for (int i = 0; i < 3; i++) {
+            double t[3];
+            p_curv(&c1[6 + i], kGauss[g][0], kGauss[g][1], t);
+            for (int r = 0; r < 3; r++) g_chi1[g][i][r] = t[r] - g_chi0[g][6 + i][r];
+        }
+    }
+    g_tables_ready = 1;
+}
+
+static int g_specht_polynomial = 0;
+void fso_set_specht_polynomial(int on) { g_specht_polynomial = on; }
+
+static void specht_B_gauss(const double C[3], int g, const double dphi[6], double B[27])
+{
+    if (g_specht_polynomial || !g_tables_ready) {
+        fso_tri3_specht_B(C, kGauss[g][0], kGauss[g][1], dphi, B);
+        return;
+    }
+    const double mu[3] = {(C[0] - C[1]) / C[2], (C[2] - C[0]) / C[1], (C[1] - C[2]) / C[0]};
+    double cc[9][3];
+    for (int n = 0; n < 6; n++)
+        for (int r = 0; r < 3; r++) cc[n][r] = g_chi0[g][n][r];
+    for (int i = 0; i < 3; i++) {
+        const double m = mu[(i + 2) % 3];
+        for (int r = 0; r < 3; r++) cc[6 + i][r] = g_chi0[g][6 + i][r] + m * g_chi1[g][i][r];
+    }
+    specht_compose(cc, dphi, B);
 }
 
 /* ---------------------------------------------------------------- TRI3 plate (SA:555-603) */
@@ -252,8 +306,6 @@ void fso_tri3_specht_B(const double C[3], double L1, double L2, const double dph
 static void tri3_plate(const double dphi[6], double area, const double Dp[9], uint32_t flags,
                        double Ke_p[81])
 {
-    static const double qp[3][2] = {
-        {1.0 / 6.0, 1.0 / 6.0}, {2.0 / 3.0, 1.0 / 6.0}, {1.0 / 6.0, 2.0 / 3.0}};
     const double x31 = dphi[2], y31 = dphi[3], x23 = dphi[4], y23 = dphi[5];
     double C[3];
     for (int i = 0; i < 3; i++) C[i] = dphi[2 * i] * dphi[2 * i] + dphi[2 * i + 1] * dphi[2 * i + 1];
@@ -271,7 +323,7 @@ static void tri3_plate(const double dphi[6], double area, const double Dp[9], ui
     memset(Ke_p, 0, 81 * sizeof(double));
     for (int g = 0; g < 3; g++) {
         double B[27], YB[27], DYB[27], YtDYB[27], BtK[81];
-        fso_tri3_specht_B(C, qp[g][0], qp[g][1], dphi, B);
+        specht_B_gauss(C, g, dphi, B);
         mm(3, 3, 9, Y, B, YB);        /* Y B        */
         mm(3, 3, 9, Dp, YB, DYB);     /* Dp Y B     */
         mtm(3, 3, 9, Y, DYB, YtDYB);  /* Y^T Dp Y B */
@@ -380,6 +432,7 @@ int fso_element_tri3(const double xyz[9], const fso_material *mat, double Ke[324
 {
     double Dm[9], Dp[9], Kg[324];
     fso_material_matrices(mat, Dm, Dp);
+    fso_init_tables(); /* the same arithmetic as the global assembly */
     if (element_tri3_nm(xyz, mat, Dm, Dp, Kg, parts)) return -1;
     to_var_major(3, Kg, Ke);
     return 0;
@@ -646,16 +699,63 @@ static void constrain_element(int nodes, const int32_t *conn, const uint8_t *dir
 }
 
 static void scatter_element(int nodes, const int32_t *conn, const double *Kg, const int32_t *rowptr,
-                            const int32_t *colidx, double *vals)
+                            const int32_t *colidx, double *vals, int32_t n0, int32_t n1)
 {
     const int N = 6 * nodes;
-    for (int i = 0; i < nodes; i++)
+    for (int i = 0; i < nodes; i++) {
+        if (conn[i] < n0 || conn[i] >= n1) continue; /* rows of another thread's range */
         for (int j = 0; j < nodes; j++) {
             double *blk = vals + 36 * find_block(rowptr, colidx, conn[i], conn[j]);
             for (int a = 0; a < 6; a++)
                 for (int b = 0; b < 6; b++) blk[6 * a + b] += Kg[(6 * i + a) * N + 6 * j + b];
         }
+    }
 }
+
+/* rows [n0,n1) of K: every element touching such a node is computed, only its rows in the range are added
+ * (elements on a range boundary are computed by both neighbours: no write is shared between threads) */
+static int assemble_rows(int32_t n0, int32_t n1, const double *xyz, int32_t n_tri, const int32_t *tri, int32_t n_quad,
+                         const int32_t *quad, const fso_material *mat, const double *Dm, const double *Dp,
+                         const uint8_t *dirichlet, const int32_t *rowptr, const int32_t *colidx, double *vals)
+{
+    for (int32_t e = 0; e < n_tri; e++) {
+        const int32_t *c = tri + 3 * (int64_t)e;
+        int mine = 0;
+        for (int i = 0; i < 3; i++) mine |= (c[i] >= n0 && c[i] < n1);
+        if (!mine) continue;
+        double X[9], Kg[324];
+        for (int i = 0; i < 3; i++)
+            for (int d = 0; d < 3; d++) X[3 * i + d] = xyz[3 * (int64_t)c[i] + d];
+        if (element_tri3_nm(X, mat, Dm, Dp, Kg, NULL)) return -(e + 1);
+        constrain_element(3, c, dirichlet, Kg);
+        scatter_element(3, c, Kg, rowptr, colidx, vals, n0, n1);
+    }
+    for (int32_t e = 0; e < n_quad; e++) {
+        const int32_t *c = quad + 4 * (int64_t)e;
+        int mine = 0;
+        for (int i = 0; i < 4; i++) mine |= (c[i] >= n0 && c[i] < n1);
+        if (!mine) continue;
+        double X[12], Kg[576];
+        for (int i = 0; i < 4; i++)
+            for (int d = 0; d < 3; d++) X[3 * i + d] = xyz[3 * (int64_t)c[i] + d];
+        if (element_quad4_nm(X, mat, Dm, Dp, Kg, NULL, NULL)) return -(n_tri + e + 1);
+        constrain_element(4, c, dirichlet, Kg);
+        scatter_element(4, c, Kg, rowptr, colidx, vals, n0, n1);
+    }
+    return 0;
+}
+
+static int g_threads = 1;
+void fso_set_threads(int n)
+{
+    g_threads = n > 0 ? n : 1;
+#ifdef _OPENMP
+    omp_set_num_threads(g_threads);
+#else
+    g_threads = 1;
+#endif
+}
+int fso_threads(void) { return g_threads; }
 
 int fso_assemble_bsr(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri,
                      int32_t n_quad, const int32_t *quad, const fso_material *mat,
@@ -664,25 +764,26 @@ int fso_assemble_bsr(int32_t n_nodes, const double *xyz, int32_t n_tri, const in
 {
     double Dm[9], Dp[9];
     fso_material_matrices(mat, Dm, Dp);
-    memset(vals, 0, (size_t)rowptr[n_nodes] * 36 * sizeof(double));
-    for (int32_t e = 0; e < n_tri; e++) {
-        const int32_t *c = tri + 3 * e;
-        double X[9], Kg[324];
-        for (int i = 0; i < 3; i++)
-            for (int d = 0; d < 3; d++) X[3 * i + d] = xyz[3 * (int64_t)c[i] + d];
-        if (element_tri3_nm(X, mat, Dm, Dp, Kg, NULL)) return -(e + 1);
-        constrain_element(3, c, dirichlet, Kg);
-        scatter_element(3, c, Kg, rowptr, colidx, vals);
+    fso_init_tables();
+    const int nt = g_threads;
+    int rc = 0;
+    if (nt <= 1) {
+        memset(vals, 0, (size_t)rowptr[n_nodes] * 36 * sizeof(double));
+        rc = assemble_rows(0, n_nodes, xyz, n_tri, tri, n_quad, quad, mat, Dm, Dp, dirichlet, rowptr, colidx, vals);
+    } else {
+        /* one contiguous node range per thread (the MPI ranks of the reference own contiguous dof ranges too) */
+#pragma omp parallel for schedule(static, 1)
+        for (int t = 0; t < nt; t++) {
+            const int32_t n0 = (int32_t)((int64_t)n_nodes * t / nt), n1 = (int32_t)((int64_t)n_nodes * (t + 1) / nt);
+            memset(vals + 36 * (int64_t)rowptr[n0], 0, (size_t)(rowptr[n1] - rowptr[n0]) * 36 * sizeof(double));
+            const int r = assemble_rows(n0, n1, xyz, n_tri, tri, n_quad, quad, mat, Dm, Dp, dirichlet, rowptr, colidx, vals);
+            if (r) {
+#pragma omp critical
+                rc = r;
+            }
+        }
     }
-    for (int32_t e = 0; e < n_quad; e++) {
-        const int32_t *c = quad + 4 * e;
-        double X[12], Kg[576];
-        for (int i = 0; i < 4; i++)
-            for (int d = 0; d < 3; d++) X[3 * i + d] = xyz[3 * (int64_t)c[i] + d];
-        if (element_quad4_nm(X, mat, Dm, Dp, Kg, NULL, NULL)) return -(n_tri + e + 1);
-        constrain_element(4, c, dirichlet, Kg);
-        scatter_element(4, c, Kg, rowptr, colidx, vals);
-    }
+    if (rc) return rc;
     /* SA:1118-1153: each node's load enters once; fixed dofs get rhs 0 (SA:1227) */
     if (F)
         for (int32_t n = 0; n < n_nodes; n++)
@@ -698,6 +799,7 @@ int fso_assemble_bsr(int32_t n_nodes, const double *xyz, int32_t n_tri, const in
 void fso_bsr_spmv(int32_t n_nodes, const int32_t *rowptr, const int32_t *colidx, const double *vals,
                   const double *x, double *y)
 {
+#pragma omp parallel for schedule(static)
     for (int32_t a = 0; a < n_nodes; a++) {
         double acc[6] = {0, 0, 0, 0, 0, 0};
         for (int32_t q = rowptr[a]; q < rowptr[a + 1]; q++) {
@@ -746,6 +848,7 @@ static int inv6(double *A)
 static double dot(int64_t n, const double *a, const double *b)
 {
     double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
     for (int64_t i = 0; i < n; i++) s += a[i] * b[i];
     return s;
 }
@@ -790,6 +893,7 @@ int fso_pcg_block_jacobi(int32_t n_nodes, const int32_t *rowptr, const int32_t *
                 const double pq = dot(n, p, q);
                 if (!(pq > 0.0)) { res.converged = -1; break; }
                 const double alpha = rz / pq;
+#pragma omp parallel for schedule(static)
                 for (int64_t i = 0; i < n; i++) {
                     x[i] += alpha * p[i];
                     r[i] -= alpha * q[i];
@@ -799,6 +903,7 @@ int fso_pcg_block_jacobi(int32_t n_nodes, const int32_t *rowptr, const int32_t *
                 res.rel_residual = rel;
                 if (resid_hist) resid_hist[it - 1] = rel;
                 if (rel <= rtol) { res.converged = 1; break; }
+#pragma omp parallel for schedule(static)
                 for (int32_t a = 0; a < n_nodes; a++)
                     for (int i = 0; i < 6; i++) {
                         double s = 0.0;
@@ -809,6 +914,7 @@ int fso_pcg_block_jacobi(int32_t n_nodes, const int32_t *rowptr, const int32_t *
                 const double rz_new = dot(n, r, z);
                 const double beta = rz_new / rz;
                 rz = rz_new;
+#pragma omp parallel for schedule(static)
                 for (int64_t i = 0; i < n; i++) p[i] = z[i] + beta * p[i];
             }
         }

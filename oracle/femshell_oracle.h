@@ -100,6 +100,17 @@ int fso_pcg_block_jacobi(int32_t n_nodes, const int32_t *rowptr, const int32_t *
                          const double *vals, const double *b, double rtol, int32_t max_it,
                          double *x, double *resid_hist, fso_pcg_info *info);
 
+/* CPU-baseline controls (bench.py's cpu_baseline leg).  The library built by the default `make` target is serial
+ * (-O2 -ffp-contract=off: the checker of the tests); `make fast` builds libfemshell_oracle_fast.so from the same
+ * source with -O3 -march=native -fopenmp on the machine that runs it, where fso_set_threads(n) makes the assembly
+ * (contiguous node ranges per thread, like the reference's MPI ranks) and the PCG kernels run on n threads. */
+void fso_set_threads(int n);
+int fso_threads(void);
+/* Specht curvatures: tabulated per Gauss point (default; filled from the polynomial derivation) or rebuilt from
+ * the polynomials for every element and Gauss point (1: the cross-check of the tables, about 20x slower) */
+void fso_set_specht_polynomial(int on);
+void fso_init_tables(void);
+
 /* timing helper for bench.py's cpu_baseline leg: assemble element matrices of
  * the first n_sample triangles `repeat` times, return elements per second */
 double fso_time_assembly(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri,

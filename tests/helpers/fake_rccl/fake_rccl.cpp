@@ -165,6 +165,12 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
     return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count)
+{
+    *count = reinterpret_cast<const FakeComm *>(comm)->nranks;
+    return ncclSuccess;
+}
+
 const char *ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "fake rccl error"; }
 
 ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op,

@@ -54,14 +54,40 @@ def build():
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
 
 
+FAST_LIB_PATH = os.path.join(ORACLE_DIR, "libfemshell_oracle_fast.so")
 _lib = None
+_use_fast = False
+
+
+def use_fast_build(threads=1):
+    """Switch this process to the CPU-baseline build of the same source (`make -C oracle fast`: -O3 -march=native
+    -fopenmp, compiled on the machine that runs it) and set its thread count.  bench.py's cpu_baseline leg only."""
+    global _lib, _use_fast
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "fast"])
+    _use_fast = True
+    _lib = None
+    lib().fso_set_threads(int(threads))
+    return lib().fso_threads()
+
+
+def set_threads(n):
+    lib().fso_set_threads(int(n))
+    return lib().fso_threads()
+
+
+def set_specht_polynomial(on):
+    """True: rebuild the Specht curvatures from the polynomial derivation for every element (cross-check of the tables)."""
+    lib().fso_set_specht_polynomial(1 if on else 0)
 
 
 def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(FAST_LIB_PATH if _use_fast else LIB_PATH)
+        L.fso_set_threads.argtypes = [C.c_int]
+        L.fso_threads.restype = C.c_int
+        L.fso_set_specht_polynomial.argtypes = [C.c_int]
         dp = C.POINTER(C.c_double)
         ip = C.POINTER(C.c_int32)
         bp = C.POINTER(C.c_uint8)

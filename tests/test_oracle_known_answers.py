@@ -158,6 +158,24 @@ def test_non_isosceles_as_coded_Y(nx, ny, wc):
     assert u[centre, 2] == pytest.approx(wc, rel=2e-6)
 
 
+def test_tabulated_specht_curvatures_equal_the_polynomial_derivation():
+    # the assembly evaluates the Specht curvature matrix from per-Gauss-point tables (filled once from the polynomial
+    # derivation of thesis shellelements.tex:1023-1039, 1107-1111); rebuilding the polynomials for every element and
+    # Gauss point must give the same element matrices
+    rng = np.random.default_rng(11)
+    mat = oracle.material(0.27, 3.1e5, 0.07)
+    try:
+        for _ in range(200):
+            X = rng.standard_normal((3, 3)) * rng.uniform(0.1, 5.0)
+            oracle.set_specht_polynomial(False)
+            k_tab = oracle.element_tri3(X, mat)
+            oracle.set_specht_polynomial(True)
+            k_pol = oracle.element_tri3(X, mat)
+            assert np.abs(k_tab - k_pol).max() <= 2e-13 * np.abs(k_pol).max()
+    finally:
+        oracle.set_specht_polynomial(False)
+
+
 def test_committed_goldens_are_what_the_oracle_computes():
     """tests/golden/*.npz are oracle outputs (tools/gen_golden_elements.py, tools/gen_golden_solutions.py):
     a change of the oracle that moves them must be deliberate."""

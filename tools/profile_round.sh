@@ -1,15 +1,15 @@
 #!/bin/bash
-# Collects what profiles/ holds for a round, on the GPU box:  tools/profile_round.sh r01
+# Collects what profiles/ holds for a round, on the GPU box:  tools/profile_round.sh r02
 #   gpurun_out/<tag>_bench.json            bench.py default run (parity probe + CPU baseline included)
 #   gpurun_out/<tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of bench.py --profile
 #   gpurun_out/<tag>_pmc_hbm_traffic.json  FETCH_SIZE / WRITE_SIZE, one counter per pass (tools/pmc_summary.py)
 # Every profiler pass runs under its own timeout; no TA_* counters (they hang rocprofv3 on this pool).
 set -u
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-timeout 600 python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+timeout 900 python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o s -- python3 bench.py --steps 10 --warmup 2 --profile > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_stats.err
 cp $out/${tag}_stats/s_kernel_stats.csv $out/${tag}_kernel_stats.csv 2> /dev/null
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --profile > /dev/null 2> $out/${tag}_pmc_fetch.err
