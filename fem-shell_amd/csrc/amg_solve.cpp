@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstddef>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -112,8 +113,8 @@ void amg_default_options(femshell_pc_options *o)
     std::memset(o, 0, sizeof *o);
     o->type = FEMSHELL_PC_AMG;
     o->cycle = FEMSHELL_CYCLE_K;
-    o->smoother_degree = 3; // tools/amg_sweep.py on the 1M-triangle panel and the 250k roof: K cycle with degree 3
-    o->coarse_degree = 3;   // on every level is the fastest to 1e-10 (93 / 91 iterations)
+    o->smoother_degree = 2; // tools/amg_sweep.py: on the 1M-triangle panel and the 250k roof (launch-bound) degree 3 / 3 is
+    o->coarse_degree = 4;   // 8 % faster to 1e-10, on the 4M-triangle panel (HBM-bound) 2 / 4 wins: 1.72 s against 1.97 s
     o->coarsest_nodes = 200;
     o->max_levels = 12;
     o->refine_passes = 1;
@@ -135,9 +136,17 @@ int amg_setup(femshell_ctx *c)
     H.opt = opt;
     const Plan &pl = c->plan;
 
+    static const bool verbose = getenv("FEMSHELL_AMG_VERBOSE") && atoi(getenv("FEMSHELL_AMG_VERBOSE")) != 0;
+    double tl = now_s();
+    auto lap = [&](const char *what, int level) {
+        const double t = now_s();
+        if (verbose) fprintf(stderr, "[femshell amg setup] level %d %-28s %.3f s\n", level, what, t - tl);
+        tl = t;
+    };
     Bsr A;
     int rc = download_matrix(c, &A);
     if (rc) return rc;
+    lap("download K", 0);
     std::vector<double> B;
     rigid_body_modes(pl.n_own, pl.xyz_local.data(), c->dmask_global.data() + pl.row_begin, &B);
     const bool keep_host = A.nnzb() <= (int64_t)2000000; // inspection exports (tests) on small problems only
@@ -168,6 +177,7 @@ int amg_setup(femshell_ctx *c)
         }
         rc = alloc_level_vectors(L, l == 0, kcycle, st);
         if (rc) return rc;
+        lap("upload + block-Jacobi", l);
         const DeviceMatrix &Adev = amg_level_matrix(c, l);
         const bool coarsest = L.n <= opt.coarsest_nodes || l + 1 >= opt.max_levels;
         if (coarsest) {
@@ -184,17 +194,22 @@ int amg_setup(femshell_ctx *c)
         rc = power_iteration(c, L, Adev, 30, &lam);
         if (rc) return rc;
         L.lam = 1.1 * lam; // the power iteration approaches from below
+        lap("power iteration", l);
         // coarsen
         std::vector<int32_t> agg;
         const int32_t na = aggregate_nodes(A, &agg);
+        lap("aggregation", l);
         std::vector<double> Q, Bc, Dinv;
         tentative_prolongator(agg, na, B, &Q, &Bc);
         block_diagonal_inverse(A, &Dinv);
+        lap("tentative P, D^-1", l);
         Bsr P, R, Ac;
         smoothed_prolongator(A, Dinv, agg, na, Q, (4.0 / 3.0) / L.lam, &P);
         std::vector<double>().swap(Q);
         std::vector<double>().swap(Dinv);
+        lap("smoothed P", l);
         galerkin_product(A, P, &R, &Ac);
+        lap("Galerkin product", l);
         {
             SlicedEll S;
             const int32_t nc_pad = (na + kSliceNodes - 1) / kSliceNodes * kSliceNodes;
@@ -205,6 +220,7 @@ int amg_setup(femshell_ctx *c)
             rc = upload_operator(L.R, S, L.n_pad, R.nnzb(), st);
             if (rc) return rc;
         }
+        lap("pack + upload P, R", l);
         if (keep_host) {
             L.hA = std::move(A);
             L.hP = std::move(P);

@@ -181,13 +181,13 @@ namespace femshell {
 int download_matrix(femshell_ctx *c, Bsr *Aout)
 {
     const Plan &p = c->plan;
-    if (c->cfg.world_size != 1) return set_err(FEMSHELL_ERR_UNSUPPORTED, "matrix download: single-rank contexts only");
     std::vector<double> h((size_t)p.total_slots() * 36);
     FS_HIP(hipMemcpyAsync(h.data(), c->vals.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     FS_HIP(hipStreamSynchronize(c->stream));
     Bsr &A = *Aout;
     A = Bsr();
-    A.nr = A.nc = p.n_own;
+    A.nr = p.n_own;  // this rank's node rows [row_begin, row_end)
+    A.nc = p.n_nodes; // global column ids
     A.ptr.assign((size_t)p.n_own + 1, 0);
     for (int32_t a = 0; a < p.n_own; a++) {
         const int s = a / kSliceNodes, n = a % kSliceNodes;
@@ -208,13 +208,16 @@ int download_matrix(femshell_ctx *c, Bsr *Aout)
             order.clear();
             for (int k = 0; k < p.slice_width[s]; k++) {
                 const int64_t slot = Plan::slot_index(base, k, n);
-                if (p.pair_ptr[slot + 1] > p.pair_ptr[slot]) order.push_back({p.cols[slot], k});
+                if (p.pair_ptr[slot + 1] > p.pair_ptr[slot]) {
+                    const int32_t lc = p.cols[slot]; // local column: owned row or ghost
+                    order.push_back({lc < p.n_pad ? p.row_begin + lc : p.ghost_global[lc - p.n_pad], k});
+                }
             }
             std::sort(order.begin(), order.end());
             int64_t nb = A.ptr[a];
             const double *src = h.data() + base * 36;
             for (auto &ck : order) {
-                A.col[nb] = ck.first; // single rank: local id == global id
+                A.col[nb] = ck.first;
                 double *blk = &A.val[(size_t)nb * 36];
                 for (int i = 0; i < 6; i++)
                     for (int j = 0; j < 6; j++)
@@ -747,7 +750,6 @@ int femshell_export_bsr(femshell_ctx *c, int32_t *rowptr, int32_t *colidx, doubl
 {
     if (!c || !rowptr || !colidx || !vals) return set_err(FEMSHELL_ERR_INVALID, "femshell_export_bsr: null argument");
     if (!c->matrix_valid) return set_err(FEMSHELL_ERR_INVALID, "femshell_export_bsr: call femshell_assemble first");
-    if (c->cfg.world_size != 1) return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_export_bsr: single-rank contexts only");
     int rc = select_device(c);
     if (rc) return rc;
     const Plan &p = c->plan;

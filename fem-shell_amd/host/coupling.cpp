@@ -302,7 +302,7 @@ int fem_shell_precice_main(int argc, char **argv, std::ostream &out, std::ostrea
     const char *stepsv = arg_after(argc, argv, "-steps");
     out << "Read command-line arguments.......OK" << std::endl;
     try {
-        ShellMesh mesh = read_xda(p.in_filename);
+        ShellMesh mesh = read_mesh(p.in_filename);
         int dims = 2;
         const InProcessCoupling::Scheme scheme = scheme_from_xml(config, &dims);
         const char *fluid = arg_after(argc, argv, "-fluid"); // extension: "tower" (default) | "edge"

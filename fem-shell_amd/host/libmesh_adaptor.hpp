@@ -1,7 +1,9 @@
 // libmesh_adaptor.hpp -- the binding a fem-shell maintainer adds to run the hot path on
 // libfemshell from the ORIGINAL libMesh program.  It needs libMesh headers, which do not exist
-// in this image, so everything is inside FEMSHELL_HAVE_LIBMESH and is not compiled here; the
-// same C-ABI calls are exercised by shell_system.cpp and the tests.  See INTEGRATION.md.
+// in this image, so everything is inside FEMSHELL_HAVE_LIBMESH; the same C-ABI calls are
+// exercised by shell_system.cpp and the tests.  tests/test_host_tools.py compiles this header
+// (-fsyntax-only) against tests/helpers/libmesh_mock, a test-only stand-in for the handful of
+// libMesh declarations it touches -- a syntax check, NOT a reference build.  See INTEGRATION.md.
 //
 // Two hooks, matching the two drop-in boundaries of the reference:
 //   (1) femshell_assemble_elasticity: same signature as assemble_elasticity
@@ -41,6 +43,7 @@ struct Binding {
     femshell_ctx *ctx = nullptr;
     bool mesh_sent = false;
     bool compat_copy_back = true; // add K,F into libMesh's matrix/rhs after the device assembly
+    EquationSystems *es = nullptr; // set by the assembly callback; the solver hook maps node dofs through it
 };
 inline Binding &binding()
 {
@@ -68,6 +71,14 @@ inline void send_mesh(EquationSystems &es)
         cfg.rank = (int32_t)mesh.processor_id();
         cfg.world_size = (int32_t)mesh.n_processors();
         check(femshell_create(&cfg, &b.ctx));
+        if (cfg.world_size > 1) {
+            // mpirun -n N (Test G, run_examples.sh:47-48): one GPU per MPI rank; rank 0 creates the RCCL id, libMesh's
+            // communicator distributes it (replaces LibMeshInit's MPI setup for the device path, fem-shell.cpp:28, 35)
+            std::vector<uint8_t> id(128, 0);
+            if (cfg.rank == 0) check(femshell_comm_unique_id(id.data()));
+            mesh.comm().broadcast(id, 0);
+            check(femshell_comm_init(b.ctx, id.data()));
+        }
     }
     const dof_id_type n_nodes = mesh.n_nodes();
     std::vector<double> xyz(3 * n_nodes);
@@ -109,21 +120,24 @@ inline void femshell_assemble_elasticity(EquationSystems &es, const std::string 
     libmesh_assert_equal_to(system_name, "Elasticity");
     LinearImplicitSystem &system = es.get_system<LinearImplicitSystem>("Elasticity");
     Binding &b = binding();
+    b.es = &es;
     if (!b.mesh_sent) send_mesh(es);
     send_forces(es.get_mesh());
     check(femshell_assemble(b.ctx));
     if (!b.compat_copy_back) return; // K and F stay in HBM for FemShellLinearSolver
-    // compat mode: hand the assembled block rows to libMesh (ADD semantics, fem-shell.cpp:1230-1231)
+    // compat mode: hand the assembled block rows to libMesh (ADD semantics, fem-shell.cpp:1230-1231).  Every rank
+    // exports the node rows [row_begin, row_end) it assembled (global column ids); libMesh/PETSc route the entries to
+    // the owner of each dof when the matrix is closed, as they do for the reference's own add_matrix calls.
     const int64_t nb = femshell_nnz_blocks(b.ctx);
-    const int32_t n_nodes = (int32_t)es.get_mesh().n_nodes();
-    std::vector<int32_t> rowptr(n_nodes + 1), colidx(nb);
-    std::vector<double> vals(36 * nb), F(6 * (size_t)n_nodes);
+    const int32_t row0 = femshell_row_begin(b.ctx), n_rows = femshell_row_end(b.ctx) - row0;
+    std::vector<int32_t> rowptr(n_rows + 1), colidx(nb);
+    std::vector<double> vals(36 * nb), F(6 * (size_t)n_rows);
     check(femshell_export_bsr(b.ctx, rowptr.data(), colidx.data(), vals.data(), F.data()));
     auto dof = [&](int32_t node, unsigned var) { return es.get_mesh().node_ref(node).dof_number(system.number(), var, 0); };
     DenseMatrix<Number> blk(6, 6);
     std::vector<dof_id_type> rows(6), cols(6);
-    for (int32_t a = 0; a < n_nodes; a++) {
-        for (unsigned v = 0; v < 6; v++) rows[v] = dof(a, v);
+    for (int32_t a = 0; a < n_rows; a++) {
+        for (unsigned v = 0; v < 6; v++) rows[v] = dof(row0 + a, v);
         for (int32_t q = rowptr[a]; q < rowptr[a + 1]; q++) {
             for (unsigned v = 0; v < 6; v++) cols[v] = dof(colidx[q], v);
             for (int i = 0; i < 6; i++)
@@ -144,9 +158,16 @@ class FemShellLinearSolver : public LinearSolver<Number> {
                                         const double tol, const unsigned int m_its) override
     {
         femshell_solve_info info{};
-        std::vector<double> u(solution.size());
-        check(femshell_solve(binding().ctx, tol, (int32_t)m_its, u.data(), &info)); // node-major 6*node+var
-        for (numeric_index_type i = solution.first_local_index(); i < solution.last_local_index(); i++) solution.set(i, u[i]);
+        Binding &b = binding();
+        if (!b.es) libmesh_error_msg("FemShellLinearSolver: attach femshell_assemble_elasticity first");
+        const MeshBase &mesh = b.es->get_mesh();
+        const unsigned sys = b.es->get_system<LinearImplicitSystem>("Elasticity").number();
+        std::vector<double> u(6 * (size_t)mesh.n_nodes());
+        check(femshell_solve(b.ctx, tol, (int32_t)m_its, u.data(), &info)); // full vector on every rank, 6*node+var
+        // libMesh numbers dofs per processor and (by default) variable-major: go through dof_number(), like the
+        // reference does when it reads the solution back (fem-shell.cpp:163-169); each rank sets the dofs it owns
+        for (const Node *nd : mesh.local_node_ptr_range())
+            for (unsigned var = 0; var < 6; var++) solution.set(nd->dof_number(sys, var, 0), u[6 * (size_t)nd->id() + var]);
         solution.close();
         return {(unsigned)info.iterations, info.rel_residual};
     }

@@ -57,6 +57,10 @@ std::vector<uint8_t> ShellMesh::dirichlet_mask() const
         mask[(size_t)a] |= m;
         mask[(size_t)c] |= m;
     }
+    for (const auto &nb : node_bcs) {
+        if (nb.second == 0 || nb.second == 20) mask[(size_t)nb.first] |= 0x07;
+        else if (nb.second == 1 || nb.second == 21) mask[(size_t)nb.first] |= 0x3F;
+    }
     return mask;
 }
 
@@ -69,6 +73,8 @@ std::vector<int32_t> ShellMesh::nodes_with_ids(const std::vector<int32_t> &ids) 
             s.insert(nd[(size_t)b.side]);
             s.insert(nd[(size_t)(b.side + 1) % nd.size()]);
         }
+    for (const auto &nb : node_bcs)
+        if (std::find(ids.begin(), ids.end(), nb.second) != ids.end()) s.insert(nb.first);
     return std::vector<int32_t>(s.begin(), s.end());
 }
 
@@ -114,10 +120,109 @@ ShellMesh read_xda(const std::string &path)
         is >> bc.elem >> bc.side >> bc.id;
         if (!is) throw std::runtime_error(path + ": bad boundary line " + std::to_string(b));
         if (bc.elem < 0 || bc.elem >= n_elem) throw std::runtime_error(path + ": boundary element out of range");
+        if (bc.side < 0 || bc.side >= (int32_t)m.element_nodes(bc.elem).size())
+            throw std::runtime_error(path + ": boundary line " + std::to_string(b) + " names side " + std::to_string(bc.side) +
+                                     " of an element with " + std::to_string(m.element_nodes(bc.elem).size()) + " sides");
         m.bcs.push_back(bc);
     }
     m.loads.assign((size_t)n_nodes * 6, 0.0);
     return m;
+}
+
+ShellMesh read_msh(const std::string &path)
+{
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("cannot open " + path);
+    ShellMesh m;
+    std::vector<std::pair<long, int32_t>> id_map; // Gmsh node number -> index in file order
+    auto node_index = [&](long id) -> int32_t {
+        auto it = std::lower_bound(id_map.begin(), id_map.end(), std::make_pair(id, (int32_t)-1));
+        if (it == id_map.end() || it->first != id) throw std::runtime_error(path + ": element references unknown node " + std::to_string(id));
+        return it->second;
+    };
+    struct Low { int nn; int32_t n[2]; int32_t id; };
+    std::vector<Low> lows;
+    std::string tok;
+    bool have_nodes = false, have_elems = false;
+    while (in >> tok) {
+        if (tok == "$MeshFormat") {
+            double ver = 0; int type = 0, size = 0;
+            in >> ver >> type >> size;
+            if (!in || ver < 2.0 || ver >= 3.0 || type != 0) throw std::runtime_error(path + ": only Gmsh ASCII format 2.x is supported");
+        } else if (tok == "$Nodes") {
+            long n = 0;
+            in >> n;
+            for (long i = 0; i < n; i++) {
+                long id; double x, y, z;
+                in >> id >> x >> y >> z;
+                if (!in) throw std::runtime_error(path + ": bad node line " + std::to_string(i));
+                id_map.push_back({id, (int32_t)i});
+                m.xyz.insert(m.xyz.end(), {x, y, z});
+            }
+            std::sort(id_map.begin(), id_map.end());
+            have_nodes = true;
+        } else if (tok == "$Elements") {
+            if (!have_nodes) throw std::runtime_error(path + ": $Elements before $Nodes");
+            long n = 0;
+            in >> n;
+            for (long i = 0; i < n; i++) {
+                long idx; int type, ntags;
+                in >> idx >> type >> ntags;
+                if (!in || ntags < 2) throw std::runtime_error(path + ": element line " + std::to_string(i) + " needs at least two tags (libMesh's requirement)");
+                long phys = 0;
+                for (int t = 0; t < ntags; t++) { long v; in >> v; if (t == 0) phys = v; }
+                const int nn = type == 2 ? 3 : type == 3 ? 4 : type == 1 ? 2 : type == 15 ? 1 : -1;
+                if (nn < 0) throw std::runtime_error(path + ": unsupported Gmsh element type " + std::to_string(type) + " (points, lines, triangles and quadrangles only)");
+                long ids[4];
+                for (int k = 0; k < nn; k++) in >> ids[k];
+                if (!in) throw std::runtime_error(path + ": bad element line " + std::to_string(i));
+                if (nn == 3) {
+                    m.order.push_back({'t', m.n_tri()});
+                    for (int k = 0; k < 3; k++) m.tri.push_back(node_index(ids[k]));
+                } else if (nn == 4) {
+                    m.order.push_back({'q', m.n_quad()});
+                    for (int k = 0; k < 4; k++) m.quad.push_back(node_index(ids[k]));
+                } else {
+                    Low l{nn, {node_index(ids[0]), nn == 2 ? node_index(ids[1]) : -1}, (int32_t)phys};
+                    lows.push_back(l);
+                }
+            }
+            have_elems = true;
+        }
+    }
+    if (!have_nodes || !have_elems || m.order.empty()) throw std::runtime_error(path + ": no $Nodes / $Elements with triangles or quadrangles");
+    // lower-dimensional elements -> boundary conditions
+    const int32_t n_elem = (int32_t)m.order.size();
+    for (const Low &l : lows) {
+        if (l.nn == 1) {
+            m.node_bcs.push_back({l.n[0], l.id});
+            continue;
+        }
+        bool found = false;
+        for (int32_t e = 0; e < n_elem && !found; e++) {
+            const std::vector<int32_t> nd = m.element_nodes(e);
+            for (size_t s = 0; s < nd.size() && !found; s++) {
+                const int32_t a = nd[s], b = nd[(s + 1) % nd.size()];
+                if ((a == l.n[0] && b == l.n[1]) || (a == l.n[1] && b == l.n[0])) {
+                    m.bcs.push_back({e, (int32_t)s, l.id});
+                    found = true;
+                }
+            }
+        }
+        if (!found) throw std::runtime_error(path + ": a boundary line is not a side of any element");
+    }
+    m.loads.assign((size_t)m.n_nodes() * 6, 0.0);
+    return m;
+}
+
+ShellMesh read_mesh(const std::string &path)
+{
+    auto ends_with = [&](const char *ext) { const std::string e(ext); return path.size() >= e.size() && path.compare(path.size() - e.size(), e.size(), e) == 0; };
+    if (ends_with(".msh")) return read_msh(path);
+    if (ends_with(".xdr"))
+        throw std::runtime_error(path + ": binary XDR meshes need libMesh's XDR codec, which this program does not carry; "
+                                        "convert to ASCII XDA (libMesh meshtool) or Gmsh .msh");
+    return read_xda(path);
 }
 
 std::string force_file_name(const std::string &mesh_path)
@@ -148,11 +253,11 @@ std::vector<double> read_forces(const std::string &path, int32_t n_nodes)
     return out;
 }
 
-void write_xda(const ShellMesh &m, const std::string &path)
+void write_xda(const ShellMesh &m, const std::string &path, int precision)
 {
     std::ofstream os(path);
     if (!os) throw std::runtime_error("cannot write " + path);
-    os.precision(17);
+    os.precision(precision);
     const long n_elem = m.n_tri() + m.n_quad();
     os << "libMesh-0.7.0+\n";
     os << n_elem << "      # number of elements\n";
@@ -248,7 +353,7 @@ ShellMesh generate_structured(const MeshGenArgs &a)
 void write_meshgen_files(const MeshGenArgs &a, const std::string &name)
 {
     const ShellMesh m = generate_structured(a);
-    write_xda(m, name + ".xda");
+    write_xda(m, name + ".xda", a.precision);
     if (a.loading <= 0) return;
     std::ofstream os(name + "_f");
     if (!os) throw std::runtime_error("cannot write " + name + "_f");

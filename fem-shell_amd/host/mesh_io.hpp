@@ -30,6 +30,7 @@ struct ShellMesh {
     std::vector<int32_t> quad;    // n_quad x 4
     std::vector<std::pair<char, int32_t>> order; // file order: ('t'|'q', index into tri/quad)
     std::vector<SideBC> bcs;
+    std::vector<std::pair<int32_t, int32_t>> node_bcs; // (node, boundary id): Gmsh point elements (doc/implementation.tex:103-124)
     std::vector<double> loads;    // n_nodes x 6 (already scaled by the file's factor)
 
     int32_t n_nodes() const { return (int32_t)(xyz.size() / 3); }
@@ -45,13 +46,22 @@ struct ShellMesh {
 
 // Throw std::runtime_error with a message on malformed input.
 ShellMesh read_xda(const std::string &path);
+// Gmsh ASCII format 2.x as libMesh's importer treats it (doc/implementation.tex:103-124): triangles (type 2) and
+// quadrangles (type 3) are the mesh; lower-dimensional elements define boundary conditions through their first tag
+// (the physical entity): 2-node lines (type 1) flag the element side they coincide with, points (type 15) the node.
+ShellMesh read_msh(const std::string &path);
+// what mesh.read(in_filename) does for the formats the reference program documents (fem-shell.cpp:37, :203): *.xda and
+// *.msh are read; the binary *.xdr needs libMesh's XDR codec and is refused with a message that says so
+ShellMesh read_mesh(const std::string &path);
 // Reads "<n> <factor> n x 6"; rows missing at the end stay zero (the reference's stream
 // extraction leaves them zero, fem-shell.cpp:59-66).  Returns n_nodes x 6, scaled.
 std::vector<double> read_forces(const std::string &path, int32_t n_nodes);
 // "<mesh>.xda" -> "<mesh>_f" (fem-shell.cpp:45-50)
 std::string force_file_name(const std::string &mesh_path);
 
-void write_xda(const ShellMesh &m, const std::string &path);
+// precision: significant digits of the coordinates; the reference's meshGen prints through a default ostream
+// (6 digits, main_all.cpp:226-339), which is the default here so that the twin's files are byte-identical
+void write_xda(const ShellMesh &m, const std::string &path, int precision = 6);
 
 struct MeshGenArgs {
     char type = 't';         // 't' | 'q'
@@ -63,6 +73,7 @@ struct MeshGenArgs {
     bool ul_lr = true;
     char dead_axis = 'z';
     bool meshgen_quirk = true; // write/apply only n_nodes-1 force rows like the reference tool
+    int precision = 6;         // digits of the coordinates in the .xda file (FEMSHELL_MESHGEN_PRECISION=17 for round-trip exact files)
 };
 ShellMesh generate_structured(const MeshGenArgs &a);
 // writes "<name>.xda" and, if loading > 0, "<name>_f" in the reference tool's format

@@ -49,6 +49,7 @@ int main(int argc, char **argv)
     a.loading = std::atoi(argv[10]);
     a.ul_lr = std::atoi(argv[11]) == 1;
     a.dead_axis = argv[12][0];
+    if (const char *e = std::getenv("FEMSHELL_MESHGEN_PRECISION")) a.precision = std::atoi(e) > 0 ? std::atoi(e) : 6;
     try {
         femshell_host::write_meshgen_files(a, argv[13]);
     } catch (const std::exception &e) {

@@ -158,7 +158,7 @@ int fem_shell_main(int argc, char **argv, std::ostream &out, std::ostream &err)
         return -1;
     }
     try {
-        ShellMesh mesh = read_xda(p.in_filename);
+        ShellMesh mesh = read_mesh(p.in_filename);
         out << " Mesh Information:\n  n_nodes()=" << mesh.n_nodes() << "\n  n_elem()=" << mesh.n_tri() + mesh.n_quad()
             << "\n";
         // CONVENTION: force file = mesh file name without extension + "_f" (SA:42-50); a missing

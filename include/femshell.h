@@ -124,8 +124,8 @@ typedef enum femshell_cycle { FEMSHELL_CYCLE_V = 0, FEMSHELL_CYCLE_K = 1 } femsh
 typedef struct femshell_pc_options {
     int32_t type;            /* femshell_pc_type */
     int32_t cycle;           /* femshell_cycle (default K: two flexible-CG steps per coarse level) */
-    int32_t smoother_degree; /* Chebyshev degree on the finest level (default 3) */
-    int32_t coarse_degree;   /* Chebyshev degree on the coarser levels (default 3) */
+    int32_t smoother_degree; /* Chebyshev degree on the finest level (default 2) */
+    int32_t coarse_degree;   /* Chebyshev degree on the coarser levels (default 4) */
     int32_t coarsest_nodes;  /* coarsening stops at this many nodes; dense inverse there (default 200) */
     int32_t max_levels;      /* default 12 */
     int32_t refine_passes;   /* iterative refinement after convergence: the residual of the iterate is evaluated in
@@ -180,8 +180,10 @@ int32_t femshell_residual_history(femshell_ctx *ctx, double *hist, int32_t cap);
 int femshell_element_matrices(femshell_ctx *ctx, int32_t first, int32_t count, double *Ke_out);
 
 int64_t femshell_nnz_blocks(femshell_ctx *ctx); /* number of 6x6 blocks of K on this rank */
-/* K as block CSR with sorted columns (vals: nnzb x 36 row-major) and F (6*n_nodes), after
- * femshell_assemble -- what system.matrix / system.rhs hold after the callback (SA:1230-1231) */
+/* K as block CSR with sorted columns (vals: nnzb x 36 row-major) and F, after femshell_assemble -- what
+ * system.matrix / system.rhs hold after the callback (SA:1230-1231).  A rank exports the node rows
+ * [femshell_row_begin, femshell_row_end) it owns: rowptr has row_end - row_begin + 1 entries, colidx holds global
+ * node ids, F has 6 entries per owned row (one rank: the whole matrix). */
 int femshell_export_bsr(femshell_ctx *ctx, int32_t *rowptr, int32_t *colidx, double *vals, double *F);
 /* y = K x on the device */
 int femshell_spmv(femshell_ctx *ctx, const double *x, double *y);
