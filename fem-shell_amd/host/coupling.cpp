@@ -320,15 +320,20 @@ int fem_shell_precice_main(int argc, char **argv, std::ostream &out, std::ostrea
         if (ifn.empty()) throw std::runtime_error("mesh has no coupling interface (boundary ids 2, 20, 21)");
         out << "preCICE dimensions = " << dims << ", dead axis = " << deadAxis << ", coupling interface nodes = " << ifn.size()
             << std::endl; // PC:74-77
-        ShellSystem system(p);
+        // one process per GPU: the in-process coupling stand-in and its dummy fluid run replicated on every rank (they are
+        // deterministic and see the full solution vector, PC:274-280), the structure solve is row-partitioned
+        const Launch launch = Launch::from_environment();
+        ShellSystem system(p, launch);
         mesh.loads.assign((size_t)mesh.n_nodes() * 6, 0.0);
         system.set_mesh(mesh);
         const std::array<int, 2> ax = dead_axis_components(deadAxis == '0' ? 'z' : deadAxis);
         int32_t probe = ifn[0];
         for (int32_t n : ifn)
             if (mesh.xyz[3 * (size_t)n + ax[1]] > mesh.xyz[3 * (size_t)probe + ax[1]]) probe = n;
+        std::ostream quiet(nullptr); // ranks other than 0 compute the same coupling steps silently
         const CoupledRunLog log = run_coupled_structure(interface, system, mesh, deadAxis, deltaT, p.tol, p.max_it, probe,
-                                                        ax[0], stepsv ? std::atoi(stepsv) : -1, out, p.debug);
+                                                        ax[0], stepsv ? std::atoi(stepsv) : -1, launch.rank == 0 ? out : quiet, p.debug);
+        if (launch.rank != 0) return 0;
         out << "Coupled run: " << log.time_steps << " time steps, " << log.coupling_iterations << " coupling iterations, "
             << log.cg_iterations << " CG iterations, assembly " << log.assemble_seconds << " s, solves " << log.solve_seconds
             << " s" << std::endl;

@@ -1,10 +1,16 @@
 // shell_system.cpp -- see shell_system.hpp
 #include "shell_system.hpp"
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <iostream>
 #include <stdexcept>
+#include <thread>
+
+#include <unistd.h>
 
 namespace femshell_host {
 
@@ -86,6 +92,27 @@ bool read_parameters(int argc, char **argv, Parameters &p, std::ostream &out, st
     }
     if (const char *v = arg_after(argc, argv, "-tol")) p.tol = std::atof(v);
     if (const char *v = arg_after(argc, argv, "-max_it")) p.max_it = std::atoi(v);
+    // PETSc-style options the reference's users pass on the same command line (doc/implementation.tex:68-72)
+    if (const char *v = arg_after(argc, argv, "-ksp_rtol")) p.tol = std::atof(v);
+    if (const char *v = arg_after(argc, argv, "-ksp_max_it")) p.max_it = std::atoi(v);
+    if (const char *v = arg_after(argc, argv, "-ksp_type")) {
+        p.ksp_type = v;
+        if (p.ksp_type != "cg") {
+            err << "NOTE: -ksp_type " << p.ksp_type << " is not available: K is symmetric positive definite and the solve on the GPU"
+                << " is a conjugate-gradient method; using -ksp_type cg\n";
+            p.ksp_type = "cg";
+        }
+    }
+    if (const char *v = arg_after(argc, argv, "-pc_type")) {
+        p.pc_type = v;
+        static const char *known[] = {"jacobi", "bjacobi", "pbjacobi", "none", "gamg", "amg", "ml", "hypre", "mg"};
+        bool ok = false;
+        for (const char *k : known) ok = ok || p.pc_type == k;
+        if (!ok) {
+            err << "ERROR: -pc_type " << p.pc_type << " is not available (jacobi|bjacobi|pbjacobi -> 6x6 block-Jacobi, gamg|amg|ml|hypre|mg -> multigrid)\n";
+            failed = true;
+        }
+    }
 
     out << "Run program with parameters:"
         << " debug messages = " << (p.debug ? "true" : "false") << ", nu = " << p.nu << ", E = " << p.em
@@ -105,7 +132,66 @@ ShellSystem::ShellSystem(const Parameters &p, int device, int rank, int world_si
     cfg.device = device;
     cfg.rank = rank;
     cfg.world_size = world_size;
+    rank_ = rank;
     check(femshell_create(&cfg, &ctx_), "femshell_create");
+}
+
+Launch Launch::from_environment()
+{
+    auto env_int = [](std::initializer_list<const char *> names, int fallback) {
+        for (const char *n : names)
+            if (const char *v = std::getenv(n)) return std::atoi(v);
+        return fallback;
+    };
+    Launch l;
+    l.rank = env_int({"FEMSHELL_RANK", "RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK"}, 0);
+    l.world_size = env_int({"FEMSHELL_WORLD_SIZE", "WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE"}, 1);
+    l.device = env_int({"FEMSHELL_DEVICE", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK"}, -1);
+    if (const char *f = std::getenv("FEMSHELL_UID_FILE")) l.uid_file = f;
+    else {
+        const char *port = std::getenv("MASTER_PORT");
+        l.uid_file = "/tmp/femshell_uid_" + (port ? std::string(port) : std::to_string((long)getppid()));
+    }
+    if (l.world_size < 1 || l.rank < 0 || l.rank >= l.world_size) throw std::runtime_error("launch environment: invalid rank / world size");
+    return l;
+}
+
+ShellSystem::ShellSystem(const Parameters &p, const Launch &launch, unsigned flags)
+    : ShellSystem(p, launch.device, launch.rank, launch.world_size, flags)
+{
+    if (launch.world_size > 1) {
+        unsigned char id[128];
+        const std::string tmp = launch.uid_file + ".tmp";
+        if (launch.rank == 0) {
+            check(femshell_comm_unique_id(id), "femshell_comm_unique_id");
+            {
+                std::ofstream os(tmp, std::ios::binary);
+                os.write(reinterpret_cast<const char *>(id), 128);
+                if (!os) throw std::runtime_error("cannot write " + tmp);
+            }
+            if (std::rename(tmp.c_str(), launch.uid_file.c_str()) != 0) throw std::runtime_error("cannot publish " + launch.uid_file);
+        } else {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                std::ifstream is(launch.uid_file, std::ios::binary);
+                if (is && is.read(reinterpret_cast<char *>(id), 128) && is.gcount() == 128) break;
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+                    throw std::runtime_error("rank " + std::to_string(launch.rank) + ": no RCCL id in " + launch.uid_file + " after 120 s");
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            }
+        }
+        comm_init(id);
+        if (launch.rank == 0 && !std::getenv("FEMSHELL_KEEP_UID_FILE")) std::remove(launch.uid_file.c_str()); // every rank has joined
+    }
+    choose_preconditioner(p);
+}
+
+void ShellSystem::choose_preconditioner(const Parameters &p)
+{
+    const bool amg = p.pc_type == "gamg" || p.pc_type == "amg" || p.pc_type == "ml" || p.pc_type == "hypre" || p.pc_type == "mg";
+    femshell_pc_options o;
+    check(femshell_pc_defaults(amg ? FEMSHELL_PC_AMG : FEMSHELL_PC_BLOCK_JACOBI, &o), "femshell_pc_defaults");
+    check(femshell_set_preconditioner(ctx_, &o), "femshell_set_preconditioner");
 }
 
 ShellSystem::~ShellSystem() { femshell_destroy(ctx_); }
@@ -168,11 +254,16 @@ int fem_shell_main(int argc, char **argv, std::ostream &out, std::ostream &err)
         } catch (const std::exception &) {
             mesh.loads.assign((size_t)mesh.n_nodes() * 6, 0.0);
         }
-        ShellSystem system(p);
+        const Launch launch = Launch::from_environment();
+        ShellSystem system(p, launch);
         system.set_mesh(mesh);
         const SolveResult res = system.solve(p.tol, p.max_it);
         const std::vector<double> &sols = system.build_solution_vector();
-        out << "Linear solver: 6x6 block-Jacobi CG on MI355X, " << res.iterations << " iterations, ||r||/||b|| = "
+        if (launch.rank != 0) return res.converged ? 0 : 2; // every rank holds the solution (SA:141); rank 0 reports it
+        out << "Linear solver: " << (res.info.pc_type == FEMSHELL_PC_AMG ? "multigrid-preconditioned" : "6x6 block-Jacobi")
+            << " CG on MI355X";
+        if (launch.world_size > 1) out << " (" << launch.world_size << " ranks)";
+        out << ", " << res.iterations << " iterations, ||r||/||b|| = "
             << res.final_residual << (res.converged ? "" : " (NOT converged)") << std::endl;
         out << "Solution: u_vec = [";
         for (int32_t id = 0; id < mesh.n_nodes(); id++) {

@@ -39,8 +39,24 @@ struct Parameters {
     bool isOutfileSet = false;
     // extensions (not in the reference): solver controls that libMesh/PETSc take from
     // equation_systems.parameters / -ksp_* options
-    double tol = 1e-12;       // libMesh "linear solver tolerance" default (TOLERANCE^2)
-    int max_it = 100000;
+    double tol = 1e-12;       // libMesh "linear solver tolerance" default (TOLERANCE^2); also -ksp_rtol
+    int max_it = 100000;      // also -ksp_max_it
+    // the reference passes -ksp_type / -pc_type through to PETSc (doc/implementation.tex:68-72).  K is SPD and the
+    // library's Krylov method is CG: -ksp_type cg is accepted, anything else is reported and replaced by cg;
+    // -pc_type jacobi|bjacobi|pbjacobi|none -> 6x6 block-Jacobi, gamg|amg|ml|hypre|mg -> the multigrid preconditioner
+    std::string ksp_type = "cg";
+    std::string pc_type = "bjacobi";
+};
+
+// One process per GPU.  How a rank learns its place: FEMSHELL_RANK / FEMSHELL_WORLD_SIZE, else the
+// launcher's variables (torchrun: RANK / WORLD_SIZE / LOCAL_RANK; Open MPI: OMPI_COMM_WORLD_*; MPICH/Slurm: PMI_RANK /
+// PMI_SIZE), else a single rank.  The 128-byte RCCL id travels through a file: rank 0 writes FEMSHELL_UID_FILE
+// (default: /tmp/femshell_uid_<MASTER_PORT or parent pid>), the others wait for it -- the role MPI plays for the
+// reference (LibMeshInit, fem-shell.cpp:28).
+struct Launch {
+    int rank = 0, world_size = 1, device = -1;
+    std::string uid_file;
+    static Launch from_environment();
 };
 
 // Same flags, defaults, messages and return convention as SA:194-267.
@@ -61,7 +77,11 @@ class ShellSystem {
     ShellSystem(const ShellSystem &) = delete;
     ShellSystem &operator=(const ShellSystem &) = delete;
 
+    // the ShellSystem of this process as the launch environment describes it: context on the rank's GPU, RCCL id
+    // exchanged, preconditioner chosen from p.pc_type
+    ShellSystem(const Parameters &p, const Launch &launch, unsigned flags = FEMSHELL_REF_DEFAULT);
     void comm_init(const unsigned char id[128]);
+    int rank() const { return rank_; }
     // mesh + boundary ids + nodal forces (what main() sets up before init(), SA:35-125)
     void set_mesh(const ShellMesh &m);
     void set_forces(const std::vector<double> &f6); // n_nodes x 6, replaces the `forces` global
@@ -74,8 +94,9 @@ class ShellSystem {
     femshell_ctx *handle() { return ctx_; }
 
   private:
+    void choose_preconditioner(const Parameters &p);
     femshell_ctx *ctx_ = nullptr;
-    int n_nodes_ = 0;
+    int n_nodes_ = 0, rank_ = 0;
     std::vector<double> sols_;
 };
 
