@@ -91,19 +91,21 @@ int agree_status(femshell_ctx *c, int local_rc, const char *what)
 {
     if (!c->comm.active()) return local_rc;
     const std::string local_msg = last_err();
-    FS_HIP(c->agree.alloc(1));
-    *c->agree_host = local_rc ? 1.0 : 0.0;
-    FS_HIP(hipMemcpyAsync(c->agree.p, c->agree_host, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    FS_HIP(c->agree.alloc(2));
+    // [ranks with a mesh error, ranks with any other error]: the healthy ranks leave with the same class of error
+    c->agree_host[0] = local_rc == FEMSHELL_ERR_MESH ? 1.0 : 0.0;
+    c->agree_host[1] = (local_rc && local_rc != FEMSHELL_ERR_MESH) ? 1.0 : 0.0;
+    FS_HIP(hipMemcpyAsync(c->agree.p, c->agree_host, 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     std::string e;
-    if (!comm_allreduce_sum(c->comm, c->agree.p, 1, c->stream, &e)) return set_err(FEMSHELL_ERR_COMM, e);
-    FS_HIP(hipMemcpyAsync(c->agree_host, c->agree.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (!comm_allreduce_sum(c->comm, c->agree.p, 2, c->stream, &e)) return set_err(FEMSHELL_ERR_COMM, e);
+    FS_HIP(hipMemcpyAsync(c->agree_host, c->agree.p, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     FS_HIP(hipStreamSynchronize(c->stream));
     if (local_rc) return set_err(local_rc, local_msg);
-    if (*c->agree_host > 0.0) {
-        char buf[160];
-        snprintf(buf, sizeof buf, "%s: failed on %d other rank(s) of the row partition (degenerate element or non-SPD block there)",
-                 what, (int)*c->agree_host);
-        return set_err(FEMSHELL_ERR_MESH, buf);
+    if (c->agree_host[0] + c->agree_host[1] > 0.0) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "%s: failed on %d other rank(s) of the row partition (%s there)", what,
+                 (int)(c->agree_host[0] + c->agree_host[1]), c->agree_host[0] > 0.0 ? "degenerate element" : "non-SPD diagonal block");
+        return set_err(c->agree_host[0] > 0.0 ? FEMSHELL_ERR_MESH : FEMSHELL_ERR_BREAKDOWN, buf);
     }
     return FEMSHELL_OK;
 }
@@ -277,7 +279,7 @@ int femshell_create(const femshell_config *cfg, femshell_ctx **out)
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = c->status.alloc(1);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->status_host), sizeof(int32_t), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->agree_host), sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->agree_host), 2 * sizeof(double), hipHostMallocDefault);
     if (e == hipSuccess) e = c->status.zero(c->stream);
     if (e == hipSuccess) e = c->scal.alloc(1);
     if (e == hipSuccess) e = c->scal.zero(c->stream);

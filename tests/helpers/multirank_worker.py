@@ -21,7 +21,7 @@ def build_problem(kind):
         # one zero-area triangle among the last rows: only the rank that owns it sees the failure locally
         m, mat = build_problem("panel")
         a, b, c = m.tri[-3]
-        m.xyz[c] = 0.5 * (m.xyz[a] + m.xyz[b])
+        m.xyz[c] = m.xyz[b]  # coincident nodes: exactly zero area
         return m, mat
     if kind == "cylinder":
         m = meshes.pinched_cylinder(48, 40)

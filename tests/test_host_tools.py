@@ -293,8 +293,8 @@ def test_cli_with_the_multigrid_preconditioner(tools):
     b = subprocess.run(base + ["-pc_type", "bjacobi"], capture_output=True, text=True)
     assert b.returncode == 0 and "6x6 block-Jacobi CG" in b.stdout
     ub = parse_solution(b.stdout)
-    ita = int(re.search(r"(\\d+) iterations", a.stdout).group(1))
-    itb = int(re.search(r"(\\d+) iterations", b.stdout).group(1))
+    ita = int(re.search(r"(\d+) iterations", a.stdout).group(1))
+    itb = int(re.search(r"(\d+) iterations", b.stdout).group(1))
     assert itb > 10 * ita
     assert np.abs(ua - ub).max() <= 1e-9 * np.abs(ub).max()
 
@@ -349,7 +349,7 @@ def test_coupled_program_on_two_ranks(tools, coupled_tool, tmp_path):
     assert single.returncode == 0, single.stderr
     outs = _run_ranks(cmd, 2, tmp_path)
     assert [rc for rc, _, _ in outs] == [0, 0], outs
-    tips1 = [float(v) for v in re.findall(r"tip\\[\\d+\\] node \\d+ = (\\S+)", single.stdout)]
-    tips2 = [float(v) for v in re.findall(r"tip\\[\\d+\\] node \\d+ = (\\S+)", outs[0][1])]
+    tips1 = [float(v) for v in re.findall(r"tip\[\d+\] node \d+ = (\S+)", single.stdout)]
+    tips2 = [float(v) for v in re.findall(r"tip\[\d+\] node \d+ = (\S+)", outs[0][1])]
     assert len(tips1) == 3 and len(tips2) == 3 and "tip[" not in outs[1][1]
     np.testing.assert_allclose(tips2, tips1, rtol=1e-7)
