@@ -307,14 +307,14 @@ class FemShell:
 
 PLAN_INFO = ["n_own", "n_pad", "n_ghost", "n_slices", "n_ltri", "n_lquad", "total_slots", "n_pairs",
              "n_peers", "row_begin", "row_end", "nnz_blocks", "n_interior_slices", "n_items",
-             "n_multi_round_slices", "max_slice_elems", "max_slice_width"]
+             "n_multi_round_slices", "max_slice_elems", "max_slice_width", "symmetric", "stored_blocks"]
 PLAN_ARRAYS = {
     "ghost_global": (0, np.int32), "tri_local": (1, np.int32), "tri_global_id": (2, np.int32),
     "quad_local": (3, np.int32), "quad_global_id": (4, np.int32), "slice_width": (5, np.int32),
     "slice_base": (6, np.int64), "cols": (7, np.int32), "pair_ptr": (8, np.int32), "pairs": (9, np.uint32),
     "xyz_local": (10, np.float64), "peer_ranks": (11, np.int32), "peer_recv_offset": (12, np.int32),
     "peer_recv_count": (13, np.int32), "peer_send_ptr": (14, np.int32), "peer_send_nodes": (15, np.int32),
-    "spmv_order": (16, np.int32),
+    "spmv_order": (16, np.int32), "in_width": (17, np.int32), "in_base": (18, np.int64), "in_slots": (19, np.int32),
 }
 
 

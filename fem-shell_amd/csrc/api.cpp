@@ -41,13 +41,16 @@ int64_t real_blocks(const femshell_ctx *c) { return c->plan.nnz_blocks; }
 double bytes_assemble(const femshell_ctx *c)
 {
     const Plan &p = c->plan;
-    return 12.0 * p.n_ltri() + 16.0 * p.n_lquad() + 24.0 * (p.n_own + p.n_ghost) + 292.0 * (double)p.nnz_blocks +
+    // (symmetric storage: only the stored blocks are computed and written -- the algorithmic bytes of that layout)
+    return 12.0 * p.n_ltri() + 16.0 * p.n_lquad() + 24.0 * (p.n_own + p.n_ghost) + 292.0 * (double)p.stored_blocks +
            4.0 * (p.n_own + 1) + 48.0 * p.n_own;
 }
 double bytes_spmv(const femshell_ctx *c)
 {
     const Plan &p = c->plan;
-    return 292.0 * (double)p.nnz_blocks + 4.0 * (p.n_own + 1) + 96.0 * p.n_own;
+    // (symmetric storage: every stored block is streamed once; the 48-byte transposed products written and read
+    // beside them are overhead of the method, not algorithmic traffic)
+    return 292.0 * (double)p.stored_blocks + 4.0 * (p.n_own + 1) + 96.0 * p.n_own;
 }
 // (the inverse diagonal blocks are symmetric: 21 of their 36 words are stored and read)
 double bytes_update(const femshell_ctx *c) { return (7.0 * 48.0 + 168.0) * c->plan.n_own; }
@@ -188,9 +191,10 @@ int download_matrix(femshell_ctx *c, Bsr *Aout)
     FS_HIP(hipStreamSynchronize(c->stream));
     Bsr &A = *Aout;
     A = Bsr();
-    A.nr = p.n_own;  // this rank's node rows [row_begin, row_end)
+    A.nr = p.n_own;   // this rank's node rows [row_begin, row_end)
     A.nc = p.n_nodes; // global column ids
     A.ptr.assign((size_t)p.n_own + 1, 0);
+    auto global_col = [&](int32_t lc) { return lc < p.n_pad ? p.row_begin + lc : p.ghost_global[lc - p.n_pad]; };
     for (int32_t a = 0; a < p.n_own; a++) {
         const int s = a / kSliceNodes, n = a % kSliceNodes;
         int cnt = 0;
@@ -198,32 +202,41 @@ int download_matrix(femshell_ctx *c, Bsr *Aout)
             const int64_t slot = Plan::slot_index(p.slice_base[s], k, n);
             if (p.pair_ptr[slot + 1] > p.pair_ptr[slot]) cnt++;
         }
+        if (p.symmetric)
+            for (int k = 0; k < p.in_width[s]; k++)
+                if (p.in_slots[(size_t)(p.in_base[s] + (int64_t)k * kSliceNodes + n)] >= 0) cnt++;
         A.ptr[a + 1] = A.ptr[a] + cnt;
     }
     A.col.resize((size_t)A.ptr[p.n_own]);
     A.val.resize((size_t)A.ptr[p.n_own] * 36);
     parallel_chunks(p.n_own, [&](int64_t a0, int64_t a1) {
-        std::vector<std::pair<int32_t, int>> order;
+        struct Src { int32_t col; int64_t slot; bool transposed; };
+        std::vector<Src> order;
         for (int64_t a = a0; a < a1; a++) {
             const int s = (int)(a / kSliceNodes), n = (int)(a % kSliceNodes);
             const int64_t base = p.slice_base[s];
             order.clear();
             for (int k = 0; k < p.slice_width[s]; k++) {
                 const int64_t slot = Plan::slot_index(base, k, n);
-                if (p.pair_ptr[slot + 1] > p.pair_ptr[slot]) {
-                    const int32_t lc = p.cols[slot]; // local column: owned row or ghost
-                    order.push_back({lc < p.n_pad ? p.row_begin + lc : p.ghost_global[lc - p.n_pad], k});
-                }
+                if (p.pair_ptr[slot + 1] > p.pair_ptr[slot]) order.push_back({global_col(p.cols[slot]), slot, false});
             }
-            std::sort(order.begin(), order.end());
+            if (p.symmetric) // blocks stored with the lower-numbered row: K(a, src) = K(src, a)^T
+                for (int k = 0; k < p.in_width[s]; k++) {
+                    const size_t e = (size_t)(p.in_base[s] + (int64_t)k * kSliceNodes + n);
+                    if (p.in_slots[e] >= 0) order.push_back({p.row_begin + p.in_rows[e], (int64_t)p.in_slots[e], true});
+                }
+            std::sort(order.begin(), order.end(), [](const Src &x, const Src &y) { return x.col < y.col; });
             int64_t nb = A.ptr[a];
-            const double *src = h.data() + base * 36;
-            for (auto &ck : order) {
-                A.col[nb] = ck.first;
+            for (const Src &sc : order) {
+                A.col[nb] = sc.col;
                 double *blk = &A.val[(size_t)nb * 36];
+                const int ns = (int)(sc.slot % kSliceNodes);
+                const double *src = h.data() + (sc.slot - ns) * 36; // the (slice, k) group of 32 blocks
                 for (int i = 0; i < 6; i++)
-                    for (int j = 0; j < 6; j++)
-                        blk[6 * i + j] = src[((((int64_t)ck.second * 3 + j / 2) * 6 + i) * kSliceNodes + n) * 2 + (j & 1)];
+                    for (int j = 0; j < 6; j++) {
+                        const double v = src[(((int64_t)(j / 2) * 6 + i) * kSliceNodes + ns) * 2 + (j & 1)];
+                        if (sc.transposed) blk[6 * j + i] = v; else blk[6 * i + j] = v;
+                    }
                 nb++;
             }
         }
@@ -360,7 +373,7 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
         if (!std::isfinite(xyz[i])) return set_err(FEMSHELL_ERR_MESH, "femshell_set_mesh: non-finite coordinate");
     std::string e;
     c->have_mesh = false;
-    if (!build_plan(n_nodes, xyz, n_tri, tri, n_quad, quad, c->cfg.rank, c->cfg.world_size, &c->plan, &e))
+    if (!build_plan(n_nodes, xyz, n_tri, tri, n_quad, quad, c->cfg.rank, c->cfg.world_size, &c->plan, &e, default_symmetric_storage()))
         return set_err(FEMSHELL_ERR_MESH, "femshell_set_mesh: " + e);
     const Plan &p = c->plan;
     hipStream_t st = c->stream;
@@ -376,6 +389,16 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     FS_HIP(c->item_ptr.upload(p.item_ptr, st));
     FS_HIP(c->slice_desc.upload(p.slice_desc, st));
     FS_HIP(c->items.upload(p.items, st));
+    FS_HIP(c->in_width.upload(p.in_width, st));
+    FS_HIP(c->in_base.upload(p.in_base, st));
+    FS_HIP(c->in_slots.upload(p.in_slots, st));
+    FS_HIP(c->in_rows.upload(p.in_rows, st));
+    if (p.symmetric) {
+        FS_HIP(c->tbuf.alloc((size_t)p.total_slots() * 6)); // transposed products next to every slot
+        FS_HIP(c->tbuf.zero(st));
+    } else {
+        c->tbuf.release();
+    }
     const size_t nrow = (size_t)p.n_pad * 6, nrow_ext = (size_t)p.n_local_nodes() * 6;
     FS_HIP(c->vals.alloc((size_t)p.total_slots() * 36));
     FS_HIP(c->vals.zero(st)); // the padding slots of the ELL layout stay zero; assembly writes the real blocks only
@@ -423,6 +446,13 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
             return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_set_mesh: a 32-node slice touches too many elements for the LDS staging");
     }
     c->dm.vals = c->vals.p;
+    c->dm.symmetric = p.symmetric ? 1 : 0;
+    c->dm.max_in_width = p.max_in_width;
+    c->dm.in_width = c->in_width.p;
+    c->dm.in_base = c->in_base.p;
+    c->dm.in_slots = c->in_slots.p;
+    c->dm.in_rows = c->in_rows.p;
+    c->dm.tbuf = c->tbuf.p;
     c->dm.minv = c->minv.p;
     c->dm.status = c->status.p;
     FS_HIP(c->partials.alloc(4 * (size_t)slice_grid(c->dm))); // r.z | r.r | the SpMV's dot (up to 2 x grid when split)

@@ -46,6 +46,7 @@ int spmv_with_halo(femshell_ctx *c, const CgVectors &v, double *xin, double *you
     const int gi = launch_spmv_span(c->dm, xin, yout, partials, v.s, c->spmv_order.p, 0, ni, 0, st);
     FS_HIP(hipStreamWaitEvent(st, c->ev_halo_done, 0));
     const int gb = launch_spmv_span(c->dm, xin, yout, partials, v.s, c->spmv_order.p, ni, nb, gi, st);
+    if (c->dm.symmetric) launch_sym_gather(c->dm, yout, nullptr, 1.0, v.s, st); // all transposed products are in place
     *n_partials = gi + gb;
     return FEMSHELL_OK;
 }

@@ -40,6 +40,14 @@ struct DeviceMatrix {
     double *vals = nullptr;             // total_slots x 36, sliced layout
     const double *rhs_loads = nullptr;  // n_pad x 6 nodal loads and
     double *rhs_F = nullptr;            // the right-hand side k_assemble fills beside K (nullptr: K only)
+    // symmetric storage (plan.hpp): transposed products K_ac^T x_a next to every slot, collected per row
+    int32_t symmetric = 0;
+    int32_t max_in_width = 0;
+    const int32_t *in_width = nullptr;  // n_slices
+    const int64_t *in_base = nullptr;   // n_slices+1
+    const int32_t *in_slots = nullptr;  // per in-entry: slot index or -1
+    const int32_t *in_rows = nullptr;   // per in-entry: local row of that block
+    double *tbuf = nullptr;             // total_slots x 6: per (slice, slot k) [component j][node n]
     double *minv = nullptr;             // n_slices x 21 x 32: upper triangles of the inverse diagonal blocks
     unsigned long long *stamps = nullptr; // profiling builds of k_assemble only (tools/lab)
     int32_t *status = nullptr;          // device int: 0 ok, e+1 = first degenerate local element,
@@ -116,6 +124,9 @@ void launch_spmv(const DeviceMatrix &m, const double *x, double *y, double *part
 // multigrid cycle; K may be rectangular (x indexed by the block columns, y and base_vec by the block rows)
 void launch_spmv_axpy(const DeviceMatrix &m, const double *x, double *y, const double *base_vec, double sign,
                       const CgScalars *s, hipStream_t st);
+// symmetric storage only: second phase of a product whose first phase ran through launch_spmv_span (the transposed
+// products of all slices must be in place): y = base_vec + sign * (y + sum of the row's transposed products)
+void launch_sym_gather(const DeviceMatrix &m, double *y, const double *base_vec, double sign, const CgScalars *s, hipStream_t st);
 // r = b - K x with double-double products and row sums (accurate residual for the residual replacement; r != x)
 void launch_residual_dd(const DeviceMatrix &m, const double *x, const double *b, double *r, hipStream_t st);
 // the same over the slices order[begin, begin+count) only (interior / boundary halves of an overlapped

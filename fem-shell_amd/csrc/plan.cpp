@@ -2,6 +2,7 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace femshell {
@@ -25,8 +26,14 @@ static int owner_of(int32_t node, int32_t n_nodes, int world)
     return r;
 }
 
+bool default_symmetric_storage()
+{
+    const char *e = getenv("FEMSHELL_SYMMETRIC");
+    return !(e && atoi(e) == 0);
+}
+
 bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri, int32_t n_quad,
-                const int32_t *quad, int rank, int world, Plan *P, std::string *err)
+                const int32_t *quad, int rank, int world, Plan *P, std::string *err, bool symmetric)
 {
     auto fail = [&](const std::string &m) {
         if (err) *err = m;
@@ -58,6 +65,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     p.n_quad = n_quad;
     p.rank = rank;
     p.world = world;
+    p.symmetric = symmetric;
     partition_rows(n_nodes, world, rank, &p.row_begin, &p.row_end);
     const int32_t g0 = p.row_begin, g1 = p.row_end;
     p.n_own = g1 - g0;
@@ -129,11 +137,26 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     std::vector<uint32_t> tmp_pairs; // packed pair
     std::vector<int32_t> tmp_next;
     std::vector<int> order;
+    std::vector<int32_t> lower_seen;
+    int64_t lower_blocks = 0;
     for (int32_t a = 0; a < n_own; a++) {
         slots.clear();
         tmp_pairs.clear();
         tmp_next.clear();
         slots.push_back({g0 + a, -1, -1, 0});
+        if (symmetric) { // count the distinct lower owned neighbours (blocks of K that get no slot)
+            lower_seen.clear();
+            for (int64_t q = adj_ptr[a]; q < adj_ptr[a + 1]; q++) {
+                const uint32_t ge = adj[q] >> 2;
+                const bool is_tri = ge < (uint32_t)n_tri;
+                const int nn = is_tri ? 3 : 4;
+                const int32_t *c = is_tri ? tri + 3ll * ge : quad + 4ll * (ge - n_tri);
+                for (int ib = 0; ib < nn; ib++)
+                    if (c[ib] >= g0 && c[ib] < g0 + a && std::find(lower_seen.begin(), lower_seen.end(), c[ib]) == lower_seen.end())
+                        lower_seen.push_back(c[ib]);
+            }
+            lower_blocks += (int64_t)lower_seen.size();
+        }
         for (int64_t q = adj_ptr[a]; q < adj_ptr[a + 1]; q++) {
             const uint32_t ge = adj[q] >> 2, ia = adj[q] & 3u;
             const bool is_tri = ge < (uint32_t)n_tri;
@@ -142,6 +165,8 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             const uint32_t le = (uint32_t)elem_local[ge];
             for (int ib = 0; ib < nn; ib++) {
                 const int32_t b = c[ib];
+                if (symmetric && b >= g0 && b < g0 + a) continue; // owned column with a lower number than the row:
+                                                                   // the block of row b acts here through its transpose
                 size_t s = 0;
                 for (; s < slots.size(); s++)
                     if (slots[s].col == b) break;
@@ -165,7 +190,8 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         node_slot_ptr[a + 1] = (int32_t)slot_col.size();
         if (slot_pairs.size() > 0x7fffff00ull) return fail("gather list exceeds 2^31 entries");
     }
-    p.nnz_blocks = (int64_t)slot_col.size();
+    p.stored_blocks = (int64_t)slot_col.size();
+    p.nnz_blocks = p.stored_blocks + lower_blocks;
 
     // ---- ghosts: referenced columns outside the owned range, ascending
     {
@@ -213,6 +239,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     }
     const int64_t total = p.slice_base[p.n_slices];
     if (total * 36 >= (1ll << 40)) return fail("matrix too large");
+    if (symmetric && total >= (1ll << 31)) return fail("matrix too large for symmetric storage (slot indices are 32-bit)");
     p.cols.resize((size_t)total);
     p.pair_ptr.resize((size_t)total + 1);
     p.pairs.clear();
@@ -236,6 +263,44 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             }
     }
     p.pair_ptr[total] = (int32_t)p.pairs.size();
+
+    // ---- symmetric storage: which stored blocks act on a row through their transpose
+    p.in_width.assign(p.n_slices, 0);
+    p.in_base.assign((size_t)p.n_slices + 1, 0);
+    if (symmetric) {
+        std::vector<int32_t> cnt((size_t)p.n_pad, 0);
+        for (int64_t idx = 0; idx < total; idx++) {
+            if (p.pair_ptr[idx + 1] == p.pair_ptr[idx]) continue; // padding slot
+            const int32_t c = p.cols[idx];
+            if (c < n_own) cnt[c]++; // counts the diagonal slots too; corrected below
+        }
+        for (int32_t a = 0; a < n_own; a++) cnt[a]--; // own diagonal
+        for (int32_t s2 = 0; s2 < p.n_slices; s2++) {
+            int w = 0;
+            for (int n = 0; n < kSliceNodes; n++) w = std::max(w, cnt[(size_t)s2 * kSliceNodes + n]);
+            p.in_width[s2] = w;
+            p.max_in_width = std::max(p.max_in_width, w);
+            p.in_base[s2 + 1] = p.in_base[s2] + (int64_t)w * kSliceNodes;
+        }
+        p.in_slots.assign((size_t)p.in_base[p.n_slices], -1);
+        p.in_rows.assign((size_t)p.in_base[p.n_slices], 0);
+        std::fill(cnt.begin(), cnt.end(), 0);
+        // ascending slot index = ascending slice of the source row; inside a slice slots run slot-major, which is a
+        // fixed order too: the sums of the gather phase are reproducible
+        for (int64_t idx = 0; idx < total; idx++) {
+            if (p.pair_ptr[idx + 1] == p.pair_ptr[idx]) continue;
+            const int32_t c = p.cols[idx];
+            if (c >= n_own) continue;
+            // source row of the slot
+            const int32_t s2 = (int32_t)(std::upper_bound(p.slice_base.begin(), p.slice_base.end(), idx) - p.slice_base.begin()) - 1;
+            const int32_t a = s2 * kSliceNodes + (int32_t)((idx - p.slice_base[s2]) % kSliceNodes);
+            if (a == c) continue;
+            const int32_t sc = c / kSliceNodes, nc = c % kSliceNodes;
+            p.in_slots[(size_t)(p.in_base[sc] + (int64_t)cnt[c] * kSliceNodes + nc)] = (int32_t)idx;
+            p.in_rows[(size_t)(p.in_base[sc] + (int64_t)cnt[c] * kSliceNodes + nc)] = a;
+            cnt[c]++;
+        }
+    }
 
     // ---- per-slice element lists and slice-relative 16-bit gather entries
     p.slice_elem_ptr.assign((size_t)p.n_slices + 1, 0);

@@ -80,7 +80,20 @@ struct Plan {
     std::vector<Item> items;
     int32_t max_stage_rows = 0;    // staging rows (36 doubles each) a slice needs at most
     int32_t max_slice_width = 0;
-    int64_t nnz_blocks = 0;            // real (non-padding) blocks
+    int64_t nnz_blocks = 0;            // blocks of the owned rows of K (what femshell_export_bsr returns)
+    // Symmetric storage (default; FEMSHELL_SYMMETRIC=0 stores every block): K = K^T, so of an off-diagonal pair
+    // (a,c), (c,a) with both nodes owned only the block of the lower-numbered row is assembled, stored and streamed;
+    // the other one acts through its transpose.  Blocks whose column is a ghost node stay (the owner of the
+    // column has its own copy and nobody applies a transpose across ranks).  The SpMV kernel writes the products
+    // K_ac^T x_a next to the block's slot (6 doubles) and the rows they belong to collect them through `in_slots`:
+    // per slice in_width[s] entries per node row, each the slot index of a stored block (a, this row) or -1.
+    bool symmetric = false;
+    int64_t stored_blocks = 0;         // blocks that have a slot (== nnz_blocks without symmetric storage)
+    std::vector<int32_t> in_width;     // n_slices
+    std::vector<int64_t> in_base;      // n_slices+1, in entries
+    std::vector<int32_t> in_slots;     // entry (in_base[s] + k*32 + n): slot index, -1 = none
+    std::vector<int32_t> in_rows;      // same shape: the local row a of that block (its x entries multiply the transpose)
+    int32_t max_in_width = 0;
     std::vector<HaloPeer> peers;
     // slices in SpMV order: the first n_interior_slices read no ghost column (they overlap the halo exchange)
     std::vector<int32_t> spmv_order;
@@ -100,6 +113,8 @@ void partition_rows(int32_t n_nodes, int world, int rank, int32_t *begin, int32_
 // Builds the plan.  Returns false and sets err on invalid input (index out of range,
 // repeated node in an element, too many elements).
 bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri, int32_t n_quad,
-                const int32_t *quad, int rank, int world, Plan *plan, std::string *err);
+                const int32_t *quad, int rank, int world, Plan *plan, std::string *err, bool symmetric = false);
+// the library's default storage: symmetric unless FEMSHELL_SYMMETRIC=0
+bool default_symmetric_storage();
 
 } // namespace femshell

@@ -23,7 +23,7 @@ int femshell_plan_create(int32_t n_nodes, const double *xyz, int32_t n_tri, cons
     *out = nullptr;
     femshell_plan *pl = new femshell_plan();
     std::string e;
-    if (!build_plan(n_nodes, xyz, n_tri, tri, n_quad, quad, rank, world_size, &pl->p, &e)) {
+    if (!build_plan(n_nodes, xyz, n_tri, tri, n_quad, quad, rank, world_size, &pl->p, &e, default_symmetric_storage())) {
         delete pl;
         return set_err(FEMSHELL_ERR_MESH, "femshell_plan_create: " + e);
     }
@@ -56,6 +56,8 @@ int femshell_plan_info(const femshell_plan *plan, int64_t *info)
     info[FEMSHELL_PLAN_N_MULTI_ROUND_SLICES] = multi;
     info[FEMSHELL_PLAN_MAX_SLICE_ELEMS] = p.max_slice_elems;
     info[FEMSHELL_PLAN_MAX_SLICE_WIDTH] = p.max_slice_width;
+    info[FEMSHELL_PLAN_SYMMETRIC] = p.symmetric ? 1 : 0;
+    info[FEMSHELL_PLAN_STORED_BLOCKS] = p.stored_blocks;
     return FEMSHELL_OK;
 }
 
@@ -81,6 +83,9 @@ int64_t femshell_plan_array(const femshell_plan *plan, int which, void *out)
     case FEMSHELL_PLAN_PAIRS: return give(p.pairs);
     case FEMSHELL_PLAN_XYZ_LOCAL: return give(p.xyz_local);
     case FEMSHELL_PLAN_SPMV_ORDER: return give(p.spmv_order);
+    case FEMSHELL_PLAN_IN_WIDTH: return give(p.in_width);
+    case FEMSHELL_PLAN_IN_BASE: return give(p.in_base);
+    case FEMSHELL_PLAN_IN_SLOTS: return give(p.in_slots);
     case FEMSHELL_PLAN_PEER_RANKS:
         for (auto &h : p.peers) tmp.push_back(h.rank);
         return give(tmp);

@@ -31,6 +31,9 @@ enum {
     FEMSHELL_PLAN_N_MULTI_ROUND_SLICES, /* slices with more than 256 work items (several assembly rounds) */
     FEMSHELL_PLAN_MAX_SLICE_ELEMS,   /* most elements any slice touches (LDS records) */
     FEMSHELL_PLAN_MAX_SLICE_WIDTH,   /* widest slice (block slots per node row) */
+    FEMSHELL_PLAN_SYMMETRIC,         /* 1: symmetric storage -- of an off-diagonal pair of owned nodes only the block of
+                                        the lower-numbered row has a slot (FEMSHELL_SYMMETRIC=0 turns it off) */
+    FEMSHELL_PLAN_STORED_BLOCKS,     /* blocks that have a slot (NNZ_BLOCKS counts the blocks of the owned rows of K) */
     FEMSHELL_PLAN_INFO_COUNT
 };
 /* fills info[FEMSHELL_PLAN_INFO_COUNT] */
@@ -53,7 +56,10 @@ enum {
     FEMSHELL_PLAN_PEER_RECV_COUNT,  /* int32 [n_peers]                                             */
     FEMSHELL_PLAN_PEER_SEND_PTR,    /* int32 [n_peers+1]     offsets into PEER_SEND_NODES          */
     FEMSHELL_PLAN_PEER_SEND_NODES,  /* int32 [sum]           owned local nodes sent to each peer   */
-    FEMSHELL_PLAN_SPMV_ORDER        /* int32 [n_slices]      interior slices first, then boundary  */
+    FEMSHELL_PLAN_SPMV_ORDER,       /* int32 [n_slices]      interior slices first, then boundary  */
+    FEMSHELL_PLAN_IN_WIDTH,         /* int32 [n_slices]      symmetric storage: transposed blocks per row  */
+    FEMSHELL_PLAN_IN_BASE,          /* int64 [n_slices+1]                                          */
+    FEMSHELL_PLAN_IN_SLOTS          /* int32 [in_base.back()] slot index of a block (a, this row) or -1 */
 };
 /* returns the element count of the array; copies it to out when out != NULL */
 int64_t femshell_plan_array(const femshell_plan *plan, int which, void *out);
