@@ -906,12 +906,15 @@ int femshell_time_kernel(femshell_ctx *c, femshell_kernel which, int32_t reps, d
             return set_err(FEMSHELL_ERR_INVALID, "femshell_time_kernel: unknown kernel");
         double sum_ms = 0.0;
         for (int32_t i = 0; i < reps; i++) {
+            // (as cg_classic runs them: with symmetric storage the SpMV is its first phase and the update kernel
+            // collects the transposed products)
             if (which == FEMSHELL_KERNEL_SPMV) FS_HIP(hipEventRecord(c->ev0, st));
-            launch_spmv(c->dm, v.p, v.q, v.partials, v.s, st);
+            if (c->dm.symmetric) launch_spmv_direct(c->dm, v.p, v.q, v.partials, v.s, st);
+            else launch_spmv(c->dm, v.p, v.q, v.partials, v.s, st);
             if (which == FEMSHELL_KERNEL_SPMV) FS_HIP(hipEventRecord(c->ev1, st));
             launch_cg_scalar(c->dm, v, true, 1, CG_PHASE_ALPHA, 0.0, st);
             if (which == FEMSHELL_KERNEL_CG_UPDATE) FS_HIP(hipEventRecord(c->ev0, st));
-            launch_cg_update(c->dm, v, st);
+            launch_cg_update(c->dm, v, st, c->dm.symmetric != 0);
             if (which == FEMSHELL_KERNEL_CG_UPDATE) FS_HIP(hipEventRecord(c->ev1, st));
             launch_cg_scalar(c->dm, v, true, 2, CG_PHASE_BETA, 0.0, st);
             if (which == FEMSHELL_KERNEL_CG_DIRECTION) FS_HIP(hipEventRecord(c->ev0, st));

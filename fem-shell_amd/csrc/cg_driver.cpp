@@ -26,14 +26,18 @@ int halo_exchange(femshell_ctx *c, double *p, hipStream_t st)
 // columns only; the slices with ghost columns follow once the halo has landed.  Returns the number of
 // partial sums written through *n_partials (0 = slice_grid).
 // (xin: input vector with ghost space, yout = K xin, partial sums of xin.yout from partials[0] on)
-int spmv_with_halo(femshell_ctx *c, const CgVectors &v, double *xin, double *yout, double *partials, int *n_partials)
+// (defer_gather: symmetric storage, the caller's next kernel collects the transposed products -- k_cg_update<true>)
+int spmv_with_halo(femshell_ctx *c, const CgVectors &v, double *xin, double *yout, double *partials, int *n_partials,
+                   bool defer_gather = false)
 {
     hipStream_t st = c->stream;
     *n_partials = 0;
+    defer_gather = defer_gather && c->dm.symmetric;
     if (!c->halo_overlap) {
         int rc = halo_exchange(c, xin, st);
         if (rc) return rc;
-        launch_spmv(c->dm, xin, yout, partials, v.s, st);
+        if (defer_gather) launch_spmv_direct(c->dm, xin, yout, partials, v.s, st);
+        else launch_spmv(c->dm, xin, yout, partials, v.s, st);
         return FEMSHELL_OK;
     }
     const Plan &pl = c->plan;
@@ -46,7 +50,7 @@ int spmv_with_halo(femshell_ctx *c, const CgVectors &v, double *xin, double *you
     const int gi = launch_spmv_span(c->dm, xin, yout, partials, v.s, c->spmv_order.p, 0, ni, 0, st);
     FS_HIP(hipStreamWaitEvent(st, c->ev_halo_done, 0));
     const int gb = launch_spmv_span(c->dm, xin, yout, partials, v.s, c->spmv_order.p, ni, nb, gi, st);
-    if (c->dm.symmetric) launch_sym_gather(c->dm, yout, nullptr, 1.0, v.s, st); // all transposed products are in place
+    if (c->dm.symmetric && !defer_gather) launch_sym_gather(c->dm, yout, nullptr, 1.0, v.s, st); // all transposed products are in place
     *n_partials = gi + gb;
     return FEMSHELL_OK;
 }
@@ -95,11 +99,11 @@ int cg_classic(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it)
     DonePoll poll;
     for (int32_t it = 0; it < max_it; it++) {
         int n_partials = 0;
-        rc = spmv_with_halo(c, v, v.p, v.q, v.partials, &n_partials);
+        rc = spmv_with_halo(c, v, v.p, v.q, v.partials, &n_partials, true);
         if (rc) return rc;
         rc = scalar_step(c, v, 1, CG_PHASE_ALPHA, rtol, n_partials);
         if (rc) return rc;
-        launch_cg_update(m, v, st);
+        launch_cg_update(m, v, st, m.symmetric != 0);
         rc = scalar_step(c, v, 2, CG_PHASE_BETA, rtol);
         if (rc) return rc;
         launch_cg_direction(m, v, st);

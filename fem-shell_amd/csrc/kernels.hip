@@ -720,6 +720,9 @@ void launch_copy_x_to_p(const DeviceMatrix &m, const CgVectors &v, hipStream_t s
 }
 
 // x += alpha p ; r -= alpha q ; z = M^-1 r ; partial sums of r.z and r.r
+// (gather: symmetric storage, q holds the direct part of K p only; the row adds the transposed products of its
+// in-list here instead of in a k_sym_gather pass of its own -- one read and one write of q and a launch less)
+template <bool kGather>
 __global__ __launch_bounds__(192) void k_cg_update(DeviceMatrix m, CgVectors v)
 {
     __shared__ double rs[kSliceRows];
@@ -732,7 +735,16 @@ __global__ __launch_bounds__(192) void k_cg_update(DeviceMatrix m, CgVectors v)
         const int sl = w.s;
         const int64_t row = (int64_t)sl * kSliceRows + t;
         const MinvRow mr = load_minv(m, sl, t);
-        const double pv = v.p[row], qv = v.q[row], xv = v.x[row], rv = v.r[row];
+        const double pv = v.p[row], xv = v.x[row], rv = v.r[row];
+        double qv = v.q[row];
+        if (kGather) {
+            const int Wi = m.in_width[sl], n = t / 6, j = t % 6;
+            const int64_t ib = m.in_base[sl];
+            for (int k = 0; k < Wi; k++) {
+                const int32_t slot = m.in_slots[ib + (int64_t)k * kSliceNodes + n];
+                if (slot >= 0) qv += m.tbuf[(int64_t)slot * 6 + j];
+            }
+        }
         v.x[row] = xv + alpha * pv;
         const double rn = rv - alpha * qv;
         v.r[row] = rn;
@@ -752,9 +764,15 @@ __global__ __launch_bounds__(192) void k_cg_update(DeviceMatrix m, CgVectors v)
     }
 }
 
-void launch_cg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st)
+void launch_cg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st, bool gather)
 {
-    hipLaunchKernelGGL(k_cg_update, dim3(slice_grid(m)), dim3(192), 0, st, m, v);
+    if (gather) hipLaunchKernelGGL(k_cg_update<true>, dim3(slice_grid(m)), dim3(192), 0, st, m, v);
+    else hipLaunchKernelGGL(k_cg_update<false>, dim3(slice_grid(m)), dim3(192), 0, st, m, v);
+}
+
+void launch_spmv_direct(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s, hipStream_t st)
+{
+    spmv_sym_phase1(m, x, y, partials, s, nullptr, m.n_slices, slice_grid(m), st);
 }
 
 // ---- single-reduction recurrence (multi-rank solves): see kernels.hpp

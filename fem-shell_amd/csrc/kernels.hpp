@@ -140,7 +140,11 @@ int launch_spmv_span(const DeviceMatrix &m, const double *x, double *y, double *
 void launch_cg_init(const DeviceMatrix &m, const CgVectors &v, bool restart, hipStream_t st);
 // p[owned rows] = x (to run q = K x through the SpMV kernel, whose input carries the ghost entries)
 void launch_copy_x_to_p(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);
-void launch_cg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);    // x,r,z + partial r.z, r.r
+// x,r,z + partial r.z, r.r.  gather (symmetric storage): v.q holds the direct part of K p only (launch_spmv_direct or
+// spans without launch_sym_gather); the kernel adds the transposed products of each row's in-list itself
+void launch_cg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st, bool gather = false);
+// symmetric storage: first phase of y = K x only (direct part of y, transposed products into m.tbuf, fused x.Kx sums)
+void launch_spmv_direct(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s, hipStream_t st);
 void launch_cg_direction(const DeviceMatrix &m, const CgVectors &v, hipStream_t st); // p = z + beta p
 // single-workgroup scalar step: optional reduction of `nsums` partial arrays into s->red, then the
 // scalar update of `phase` (rtol only used by CG_PHASE_INIT)

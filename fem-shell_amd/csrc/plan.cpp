@@ -345,6 +345,12 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     }
 
     // ---- assembly work items
+    // contributions per item (FEMSHELL_ITEM_PAIRS overrides): 3 fills the four waves of a full-storage slice evenly (256
+    // items); with symmetric storage a structured slice has 32 diagonal slots of 6 and 96 off-diagonal slots of 2
+    // contributions, and items of 2 (192 equal items, three full waves while the fourth builds records) were measured
+    // against items of 3 (160 items): 0.904 vs 0.875 ms -- fewer items and partial-sum rows win, 3 stays
+    static const int item_pairs_env = getenv("FEMSHELL_ITEM_PAIRS") ? atoi(getenv("FEMSHELL_ITEM_PAIRS")) : 0;
+    const int item_pairs = (item_pairs_env >= 1 && item_pairs_env <= kItemPairs) ? item_pairs_env : kItemPairs;
     p.item_ptr.assign((size_t)p.n_slices + 1, 0);
     {
         std::vector<Plan::Item> tmp, sorted;
@@ -366,11 +372,11 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                     const int64_t idx = Plan::slot_index(p.slice_base[s], k, n);
                     const int32_t q0 = p.pair_ptr[idx], cnt = p.pair_ptr[idx + 1] - q0;
                     if (cnt == 0) continue; // padding slot: its zero block is written once, when K is allocated
-                    const int nchunks = (cnt + kItemPairs - 1) / kItemPairs;
+                    const int nchunks = (cnt + item_pairs - 1) / item_pairs;
                     if (nchunks > 255) return fail("a block slot has more than 765 contributions");
                     const int32_t stage0 = stage;
                     for (int c = 0; c < nchunks; c++) {
-                        const int32_t b = q0 + c * kItemPairs, e = std::min(q0 + cnt, b + kItemPairs);
+                        const int32_t b = q0 + c * item_pairs, e = std::min(q0 + cnt, b + item_pairs);
                         const int np = std::max(0, e - b);
                         uint32_t pr[3] = {0, 0, 0};
                         for (int q = 0; q < np; q++) pr[q] = p.pairs16[b + q];

@@ -37,7 +37,7 @@ int main(int argc, char **argv)
     std::vector<int32_t> tri; tri.reserve(6 * (size_t)nx * nx);
     for (int j = 0; j < nx; j++) for (int i = 0; i < nx; i++) { int n = i + j * (nx + 1), up_ = nx + 1; tri.insert(tri.end(), {n, n + 1, n + up_, n + 1, n + up_ + 1, n + up_}); }
     Plan p; std::string err;
-    if (!build_plan(nn, xyz.data(), (int)tri.size() / 3, tri.data(), 0, nullptr, 0, 1, &p, &err)) { printf("plan: %s\n", err.c_str()); return 1; }
+    if (!build_plan(nn, xyz.data(), (int)tri.size() / 3, tri.data(), 0, nullptr, 0, 1, &p, &err, default_symmetric_storage())) { printf("plan: %s\n", err.c_str()); return 1; }
     DeviceMatrix m;
     m.n_own = p.n_own; m.n_pad = p.n_pad; m.n_ghost = p.n_ghost; m.n_slices = p.n_slices; m.n_ltri = p.n_ltri(); m.n_lquad = 0;
     m.xyz = up(p.xyz_local); m.tri = up(p.tri_local); m.slice_width = up(p.slice_width); m.slice_base = up(p.slice_base);

@@ -15,6 +15,12 @@ cp $out/${tag}_stats/s_kernel_stats.csv $out/${tag}_kernel_stats.csv 2> /dev/nul
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --profile > /dev/null 2> $out/${tag}_pmc_fetch.err
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -o w -- python3 bench.py --steps 3 --warmup 1 --profile > /dev/null 2> $out/${tag}_pmc_write.err
 python3 tools/pmc_summary.py $out/${tag}_pmc_fetch/f_counter_collection.csv $out/${tag}_pmc_write/w_counter_collection.csv $out/${tag}_pmc_hbm_traffic.json
+# FP64 work of the kernels (the assembly kernel is VALU-bound with symmetric storage): instruction counters, one pass each
+for cnt in SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $cnt --output-format csv -d $out/${tag}_pmc_$cnt -o c -- python3 bench.py --steps 3 --warmup 1 --profile > /dev/null 2> $out/${tag}_pmc_$cnt.err
+done
+python3 tools/pmc_flops.py $out/${tag}_pmc_SQ_INSTS_VALU_FMA_F64/c_counter_collection.csv $out/${tag}_pmc_SQ_INSTS_VALU_MUL_F64/c_counter_collection.csv $out/${tag}_pmc_SQ_INSTS_VALU_ADD_F64/c_counter_collection.csv $out/${tag}_pmc_fp64.json
+rm -rf $out/${tag}_pmc_SQ_INSTS_VALU_FMA_F64 $out/${tag}_pmc_SQ_INSTS_VALU_MUL_F64 $out/${tag}_pmc_SQ_INSTS_VALU_ADD_F64
 # keep the merged-back directory small: the raw counter tables are large
 rm -rf $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_stats
 tail -1 $out/${tag}_bench.json
