@@ -221,6 +221,8 @@ def main():
     ap.add_argument("--nx", type=int, default=None, help="squares per side (default 1414 -> 3,998,792 tri3; roof: 354)")
     ap.add_argument("--workload", default="panel", choices=["panel", "cylinder", "roof"])
     ap.add_argument("--cg-iters", type=int, default=50, help="CG iterations per step in the CG phase")
+    ap.add_argument("--jacobi-probe-iters", type=int, default=5000,
+                    help="untimed block-Jacobi run whose residual history goes into time_to_solution.block_jacobi_alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-parity", action="store_true", help="skip the 250k-element converged parity (two CPU direct solves)")
     ap.add_argument("--profile", action="store_true",
@@ -310,6 +312,10 @@ def main():
     barrier()
     t_cg = max_over_ranks(time.perf_counter() - t0)
     jacobi_hist = fs.residual_history()
+    if world == 1 and not args.profile and args.jacobi_probe_iters > n_it:
+        # where block-Jacobi alone stands on this system after a few thousand iterations (time_to_solution)
+        fs.solve(rtol=0.0, max_it=args.jacobi_probe_iters, fetch=False)
+        jacobi_hist = fs.residual_history()
 
     # ---- per-kernel durations with HIP events on the library's stream
     reps = max(5, args.steps)
@@ -336,12 +342,27 @@ def main():
                 traffic["_source"] = "profiles/" + cands[-1]
             else:
                 traffic_note = "stale: profiles/%s was taken with other kernel sources" % cands[-1]
+    # FP64 work per launch from the committed instruction-counter passes (tools/pmc_flops.py), same rule
+    fp64 = {}
+    if world == 1 and args.workload == "panel" and args.nx == 1414:
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_fp64.json"))
+        if cands and traffic.get("_source"):
+            with open(os.path.join(ROOT, "profiles", cands[-1])) as f:
+                for kname, v in json.load(f).items():
+                    fp64[kname.split("::")[-1].split("<")[0]] = v["flops_per_launch"]
 
     def roof(ms, nbytes, kernel=None):
         gbs = nbytes / (ms * 1e-3) / 1e9
-        return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": traffic.get(kernel), "traffic_from_committed_profile": traffic.get("_source") if kernel in traffic else traffic_note,
-                "ms_per_launch": ms, "algorithmic_bytes_per_launch": nbytes}
+        out = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+               "traffic": traffic.get(kernel), "traffic_from_committed_profile": traffic.get("_source") if kernel in traffic else traffic_note,
+               "ms_per_launch": ms, "algorithmic_bytes_per_launch": nbytes}
+        if kernel in traffic:
+            out["traffic_gb_per_s"] = traffic[kernel] / (ms * 1e-3) / 1e9
+        if kernel in fp64:  # FP64 vector peak 78.6 TFLOP/s (MI355X_MICROARCH.md)
+            out["fp64_gflop_per_launch"] = fp64[kernel] / 1e9
+            out["fp64_tflops"] = fp64[kernel] / (ms * 1e-3) / 1e12
+            out["fp64_frac_of_78.6_tflops"] = out["fp64_tflops"] / 78.6
+        return out
 
     tts = None
     if world == 1 and not args.profile:
@@ -365,6 +386,8 @@ def main():
         if tts["block_jacobi_alone"] and "extrapolated_iterations_to_1e-10" in tts["block_jacobi_alone"]:
             tts["block_jacobi_alone"]["extrapolated_seconds"] = tts["block_jacobi_alone"]["extrapolated_iterations_to_1e-10"] * t_cg / max(info["iterations"], 1)
 
+    symmetric = os.environ.get("FEMSHELL_SYMMETRIC", "1") != "0"
+    spmv_kernel = "k_spmv_sym" if symmetric else "k_spmv"
     if rank == 0:
         out = {
             "metric": "elements assembled/s + CG iters/s, 4M-tri shell, 1/2/4/8 MI355X",
@@ -385,8 +408,10 @@ def main():
                                    % (args.nx, args.nx, n_elem, n_nodes, 6 * n_nodes),
                        "parallelism": "row-partition x%d" % world, "cg_iters_per_step": args.cg_iters,
                        "preconditioner": "6x6 block-Jacobi", "symbolic_setup_s": setup_s,
+                       "matrix_storage": "symmetric (diagonal + blocks of the lower-numbered row)" if symmetric else "full",
                        "rccl_ranks_seen": rccl_ranks},
-            "roofline": dict(roof(spmv_ms, spmv_bytes, "k_spmv"), kernel="k_spmv (q = K p, fused p.q)"),
+            "roofline": dict(roof(spmv_ms, spmv_bytes, spmv_kernel), kernel=spmv_kernel + " (q = K p, fused p.q" +
+                             ("; symmetric storage: first phase, the update kernel collects the transposed products)" if symmetric else ")")),
             "roofline_assembly": dict(roof(asm_ms, asm_bytes, "k_assemble"), kernel="k_assemble"),
             "roofline_cg_update": dict(roof(upd_ms, upd_bytes, "k_cg_update"), kernel="k_cg_update"),
             "roofline_cg_direction": dict(roof(dir_ms, dir_bytes, "k_cg_direction"), kernel="k_cg_direction"),
