@@ -413,9 +413,9 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
                     u[2 * jp] += kw.x * xa[i];
                     u[2 * jp + 1] += kw.y * xa[i];
                 }
-            // the transpose acts on row c when c is another owned row (stored blocks have c > a there; ghost
-            // columns belong to another rank, padding slots point at the own row)
-            if (k > 0 && c > a && c < m.n_pad) {
+            // the transpose acts on row c when c is another owned row (ghost columns belong to another rank,
+            // padding slots point at the own row)
+            if (k > 0 && c != a && c < m.n_pad) {
                 double2 *t = tb + ((size_t)k * kSliceNodes + n) * 3;
                 t[0] = make_double2(u[0], u[1]);
                 t[1] = make_double2(u[2], u[3]);

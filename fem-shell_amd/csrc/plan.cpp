@@ -137,26 +137,113 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     std::vector<uint32_t> tmp_pairs; // packed pair
     std::vector<int32_t> tmp_next;
     std::vector<int> order;
-    std::vector<int32_t> lower_seen;
+    // ---- symmetric storage: which row of an owned pair (a,c) holds the block.  Any choice works -- the SpMV applies
+    // every stored off-diagonal block to both rows -- so it is made to balance the rows: the ELL width of a slice is the
+    // largest slot count of its 32 rows.  Start: the lower-numbered row keeps the block (on a structured grid every
+    // interior row then holds exactly its three higher neighbours and nothing below moves); then local repair: a row
+    // above the mean hands a block to a neighbour that is at least two below it, directly or through one
+    // intermediate row, until nothing moves.  Planar triangulations admit 3 per inner node (Schnyder); the repair gets unstructured Delaunay
+    // meshes to width 4-5 where "lower row keeps" gives 6-7 and full storage 10-11.
+    std::vector<int64_t> nb_ptr;
+    std::vector<int32_t> nb;      // owned neighbours (local ids), ascending per row
+    std::vector<uint8_t> nb_mine; // 1: the block (row, nb) is stored with this row
     int64_t lower_blocks = 0;
+    if (symmetric) {
+        nb_ptr.assign((size_t)n_own + 1, 0);
+        std::vector<int32_t> tmp;
+        std::vector<int32_t> cnt((size_t)n_own, 0); // blocks a row stores besides its diagonal (ghost columns included)
+        for (int pass = 0; pass < 2; pass++) {
+            for (int32_t a = 0; a < n_own; a++) {
+                tmp.clear();
+                int ghosts = 0;
+                for (int64_t q = adj_ptr[a]; q < adj_ptr[a + 1]; q++) {
+                    const uint32_t ge = adj[q] >> 2;
+                    const bool is_tri = ge < (uint32_t)n_tri;
+                    const int nn = is_tri ? 3 : 4;
+                    const int32_t *c = is_tri ? tri + 3ll * ge : quad + 4ll * (ge - n_tri);
+                    for (int ib = 0; ib < nn; ib++) {
+                        const int32_t b = c[ib];
+                        if (b == g0 + a) continue;
+                        if (b >= g0 && b < g1) tmp.push_back(b - g0);
+                        else tmp.push_back(n_own + (b < g0 ? b : b - n_own)); // ghost marker (distinct per global id)
+                    }
+                }
+                std::sort(tmp.begin(), tmp.end());
+                tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                int owned = 0;
+                for (int32_t v : tmp) (v < n_own ? owned : ghosts)++;
+                if (pass == 0) {
+                    nb_ptr[a + 1] = nb_ptr[a] + owned;
+                    cnt[a] = ghosts;
+                } else {
+                    int64_t w = nb_ptr[a];
+                    for (int32_t v : tmp)
+                        if (v < n_own) nb[w++] = v;
+                }
+            }
+            if (pass == 0) nb.resize((size_t)nb_ptr[n_own]);
+        }
+        nb_mine.assign(nb.size(), 0);
+        auto index_of = [&](int32_t row, int32_t col) -> int64_t {
+            return std::lower_bound(nb.begin() + nb_ptr[row], nb.begin() + nb_ptr[row + 1], col) - nb.begin();
+        };
+        for (int32_t a = 0; a < n_own; a++) // start: the lower-numbered row keeps the block
+            for (int64_t q = nb_ptr[a]; q < nb_ptr[a + 1]; q++)
+                if (nb[q] > a) {
+                    nb_mine[q] = 1;
+                    cnt[a]++;
+                }
+        // local repair towards the mean
+        const int target = (int)((nb.size() / 2 + (size_t)n_own - 1) / (size_t)std::max(n_own, 1));
+        auto give = [&](int32_t from, int64_t q_from) { // the block (from, nb[q_from]) moves to the other row
+            const int32_t to = nb[q_from];
+            nb_mine[q_from] = 0;
+            nb_mine[index_of(to, from)] = 1;
+            cnt[from]--;
+            cnt[to]++;
+        };
+        for (int sweep = 0; sweep < 32; sweep++) {
+            int64_t moved = 0;
+            for (int32_t a = 0; a < n_own; a++) {
+                while (cnt[a] > target) {
+                    bool done = false;
+                    for (int64_t q = nb_ptr[a]; q < nb_ptr[a + 1] && !done; q++)
+                        if (nb_mine[q] && cnt[nb[q]] + 2 <= cnt[a]) {
+                            give(a, q);
+                            done = true;
+                        }
+                    for (int64_t q = nb_ptr[a]; q < nb_ptr[a + 1] && !done; q++) {
+                        if (!nb_mine[q]) continue;
+                        const int32_t c = nb[q];
+                        if (cnt[c] + 1 > cnt[a]) continue; // c would rise above a
+                        for (int64_t r = nb_ptr[c]; r < nb_ptr[c + 1] && !done; r++)
+                            if (nb_mine[r] && nb[r] != a && cnt[nb[r]] + 2 <= cnt[a]) {
+                                give(c, r);
+                                give(a, q);
+                                done = true;
+                            }
+                    }
+                    if (!done) break;
+                    moved++;
+                }
+            }
+            if (!moved) break;
+        }
+        for (int32_t a = 0; a < n_own; a++)
+            for (int64_t q = nb_ptr[a]; q < nb_ptr[a + 1]; q++)
+                if (!nb_mine[q]) lower_blocks++; // blocks of K without a slot in this row
+    }
+    auto stored_here = [&](int32_t a, int32_t b_global) { // symmetric storage: does row a hold the block (a, b)?
+        if (b_global < g0 || b_global >= g1) return true; // ghost column
+        const int32_t c = b_global - g0;
+        const int64_t q = std::lower_bound(nb.begin() + nb_ptr[a], nb.begin() + nb_ptr[a + 1], c) - nb.begin();
+        return nb_mine[q] != 0;
+    };
     for (int32_t a = 0; a < n_own; a++) {
         slots.clear();
         tmp_pairs.clear();
         tmp_next.clear();
         slots.push_back({g0 + a, -1, -1, 0});
-        if (symmetric) { // count the distinct lower owned neighbours (blocks of K that get no slot)
-            lower_seen.clear();
-            for (int64_t q = adj_ptr[a]; q < adj_ptr[a + 1]; q++) {
-                const uint32_t ge = adj[q] >> 2;
-                const bool is_tri = ge < (uint32_t)n_tri;
-                const int nn = is_tri ? 3 : 4;
-                const int32_t *c = is_tri ? tri + 3ll * ge : quad + 4ll * (ge - n_tri);
-                for (int ib = 0; ib < nn; ib++)
-                    if (c[ib] >= g0 && c[ib] < g0 + a && std::find(lower_seen.begin(), lower_seen.end(), c[ib]) == lower_seen.end())
-                        lower_seen.push_back(c[ib]);
-            }
-            lower_blocks += (int64_t)lower_seen.size();
-        }
         for (int64_t q = adj_ptr[a]; q < adj_ptr[a + 1]; q++) {
             const uint32_t ge = adj[q] >> 2, ia = adj[q] & 3u;
             const bool is_tri = ge < (uint32_t)n_tri;
@@ -165,8 +252,8 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             const uint32_t le = (uint32_t)elem_local[ge];
             for (int ib = 0; ib < nn; ib++) {
                 const int32_t b = c[ib];
-                if (symmetric && b >= g0 && b < g0 + a) continue; // owned column with a lower number than the row:
-                                                                   // the block of row b acts here through its transpose
+                if (symmetric && b != g0 + a && !stored_here(a, b)) continue; // the block lives with row b and acts here
+                                                                               // through its transpose
                 size_t s = 0;
                 for (; s < slots.size(); s++)
                     if (slots[s].col == b) break;

@@ -82,8 +82,9 @@ struct Plan {
     int32_t max_slice_width = 0;
     int64_t nnz_blocks = 0;            // blocks of the owned rows of K (what femshell_export_bsr returns)
     // Symmetric storage (default; FEMSHELL_SYMMETRIC=0 stores every block): K = K^T, so of an off-diagonal pair
-    // (a,c), (c,a) with both nodes owned only the block of the lower-numbered row is assembled, stored and streamed;
-    // the other one acts through its transpose.  Blocks whose column is a ghost node stay (the owner of the
+    // (a,c), (c,a) with both nodes owned only one block is assembled, stored and streamed -- with the row that has
+    // fewer blocks (plan.cpp: balanced orientation; on structured grids the lower-numbered row) -- and the other
+    // one acts through its transpose.  Blocks whose column is a ghost node stay (the owner of the
     // column has its own copy and nobody applies a transpose across ranks).  The SpMV kernel writes the products
     // K_ac^T x_a next to the block's slot (6 doubles) and the rows they belong to collect them through `in_slots`:
     // per slice in_width[s] entries per node row, each the slot index of a stored block (a, this row) or -1.

@@ -52,12 +52,11 @@ def assemble_from_plan(plan, mat, oracle, dmask_local=None):
                                 blk[i, i] = float(p1 - p0)
                 out[slot] = (row, col, blk)
     if plan.get("symmetric"):
-        # symmetric storage: of a pair of owned nodes only the block of the lower row has a slot; the other one is
+        # symmetric storage: of a pair of owned nodes only one row holds the block; the other one is
         # its transpose (keys beyond the slot range)
         nxt = int(plan["slice_base"][-1])
         for slot, (row, col, blk) in list(out.items()):
             if col != row and col < plan["n_own"]:
-                assert col > row
                 out[nxt] = (col, row, blk.T.copy())
                 nxt += 1
     return out
