@@ -22,17 +22,29 @@
 
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace femshell {
+
+// allocator that leaves doubles uninitialised on resize: the gigabyte-sized value arrays of the setup are written
+// in full by parallel loops; a serial zero fill first would cost as much as the loop itself
+template <class T> struct default_init_allocator : std::allocator<T> {
+    template <class U> struct rebind { using other = default_init_allocator<U>; };
+    using std::allocator<T>::allocator;
+    template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... Args> void construct(U *p, Args &&...args) { ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...); }
+};
+using ValueArray = std::vector<double, default_init_allocator<double>>;
 
 // block CSR with 6x6 blocks (row-major inside a block), columns ascending within a row
 struct Bsr {
     int32_t nr = 0, nc = 0; // block rows / block columns
     std::vector<int64_t> ptr;
     std::vector<int32_t> col;
-    std::vector<double> val;
+    ValueArray val;
     int64_t nnzb() const { return (int64_t)col.size(); }
 };
 
@@ -76,7 +88,7 @@ struct SlicedEll {
     std::vector<int32_t> slice_width;
     std::vector<int64_t> slice_base;
     std::vector<int32_t> cols;
-    std::vector<double> vals;
+    ValueArray vals;
 };
 void pack_sliced_ell(const Bsr &A, bool diag_first, SlicedEll *out);
 

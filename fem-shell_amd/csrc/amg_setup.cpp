@@ -244,68 +244,58 @@ void bsr_multiply(const Bsr &A, const Bsr &B, Bsr *Cout)
     C.nr = A.nr;
     C.nc = B.nc;
     const int64_t n = A.nr;
-    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (n + 1023) / 1024));
-    struct Part {
-        int64_t r0 = 0, r1 = 0;
-        std::vector<int32_t> cnt, col;
-        std::vector<double> val;
-    };
-    std::vector<Part> parts((size_t)nt);
-    for (int t = 0; t < nt; t++) {
-        parts[t].r0 = n * t / nt;
-        parts[t].r1 = n * (t + 1) / nt;
-    }
-    auto work = [&](Part &p) {
+    // pass 1 (symbolic): distinct columns per row; pass 2 (numeric) writes every row straight into its place --
+    // both parallel over row chunks, nothing gigabyte-sized is touched by one thread alone
+    std::vector<int32_t> cnt((size_t)n, 0);
+    parallel_chunks(n, [&](int64_t r0, int64_t r1) {
+        std::vector<int32_t> marker((size_t)B.nc, -1);
+        for (int64_t i = r0; i < r1; i++) {
+            int32_t c = 0;
+            for (int64_t qa = A.ptr[i]; qa < A.ptr[i + 1]; qa++) {
+                const int32_t k = A.col[qa];
+                for (int64_t qb = B.ptr[k]; qb < B.ptr[k + 1]; qb++)
+                    if (marker[B.col[qb]] != (int32_t)i) {
+                        marker[B.col[qb]] = (int32_t)i;
+                        c++;
+                    }
+            }
+            cnt[i] = c;
+        }
+    }, 1024);
+    C.ptr.assign((size_t)n + 1, 0);
+    for (int64_t i = 0; i < n; i++) C.ptr[i + 1] = C.ptr[i] + cnt[i];
+    C.col.resize((size_t)C.ptr[n]);
+    C.val.resize((size_t)C.ptr[n] * 36);
+    parallel_chunks(n, [&](int64_t r0, int64_t r1) {
         std::vector<int32_t> marker((size_t)B.nc, -1), list;
-        std::vector<std::pair<int32_t, int32_t>> order;
-        p.cnt.reserve((size_t)(p.r1 - p.r0));
-        std::vector<double> acc;
-        for (int64_t i = p.r0; i < p.r1; i++) {
+        std::vector<int32_t> rank;
+        for (int64_t i = r0; i < r1; i++) {
             list.clear();
-            acc.clear();
+            for (int64_t qa = A.ptr[i]; qa < A.ptr[i + 1]; qa++) {
+                const int32_t k = A.col[qa];
+                for (int64_t qb = B.ptr[k]; qb < B.ptr[k + 1]; qb++)
+                    if (marker[B.col[qb]] < 0) {
+                        marker[B.col[qb]] = 0;
+                        list.push_back(B.col[qb]);
+                    }
+            }
+            std::sort(list.begin(), list.end());
+            const int64_t base = C.ptr[i];
+            for (size_t s2 = 0; s2 < list.size(); s2++) {
+                marker[list[s2]] = (int32_t)s2 + 1; // position + 1 in the row
+                C.col[(size_t)base + s2] = list[s2];
+            }
+            double *out = &C.val[(size_t)base * 36];
+            std::fill(out, out + list.size() * 36, 0.0);
             for (int64_t qa = A.ptr[i]; qa < A.ptr[i + 1]; qa++) {
                 const int32_t k = A.col[qa];
                 const double *a = &A.val[(size_t)qa * 36];
-                for (int64_t qb = B.ptr[k]; qb < B.ptr[k + 1]; qb++) {
-                    const int32_t j = B.col[qb];
-                    int32_t pos = marker[j];
-                    if (pos < 0) {
-                        pos = (int32_t)list.size();
-                        marker[j] = pos;
-                        list.push_back(j);
-                        acc.resize(acc.size() + 36, 0.0);
-                    }
-                    blk_mac(a, &B.val[(size_t)qb * 36], &acc[(size_t)pos * 36]);
-                }
+                for (int64_t qb = B.ptr[k]; qb < B.ptr[k + 1]; qb++)
+                    blk_mac(a, &B.val[(size_t)qb * 36], out + (size_t)(marker[B.col[qb]] - 1) * 36);
             }
-            order.clear();
-            for (size_t s = 0; s < list.size(); s++) order.push_back({list[s], (int32_t)s});
-            std::sort(order.begin(), order.end());
-            for (auto &o : order) {
-                p.col.push_back(o.first);
-                p.val.insert(p.val.end(), acc.begin() + (size_t)o.second * 36, acc.begin() + (size_t)o.second * 36 + 36);
-                marker[o.first] = -1;
-            }
-            p.cnt.push_back((int32_t)list.size());
+            for (int32_t j : list) marker[j] = -1;
         }
-    };
-    {
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; t++) th.emplace_back([&, t] { work(parts[t]); });
-        work(parts[0]);
-        for (auto &t : th) t.join();
-    }
-    C.ptr.assign((size_t)n + 1, 0);
-    for (auto &p : parts)
-        for (int64_t i = p.r0; i < p.r1; i++) C.ptr[i + 1] = C.ptr[i] + p.cnt[i - p.r0];
-    C.col.resize((size_t)C.ptr[n]);
-    C.val.resize((size_t)C.ptr[n] * 36);
-    for (auto &p : parts) {
-        std::copy(p.col.begin(), p.col.end(), C.col.begin() + C.ptr[p.r0]);
-        std::copy(p.val.begin(), p.val.end(), C.val.begin() + C.ptr[p.r0] * 36);
-        std::vector<int32_t>().swap(p.col);
-        std::vector<double>().swap(p.val);
-    }
+    }, 1024);
 }
 
 void bsr_transpose(const Bsr &A, Bsr *Tout)
@@ -319,16 +309,24 @@ void bsr_transpose(const Bsr &A, Bsr *Tout)
     for (int32_t i = 0; i < T.nr; i++) T.ptr[i + 1] += T.ptr[i];
     T.col.resize(A.col.size());
     T.val.resize(A.val.size());
-    std::vector<int64_t> fill(T.ptr.begin(), T.ptr.end() - 1);
-    for (int32_t i = 0; i < A.nr; i++) // ascending rows -> ascending columns of the transpose
-        for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++) {
-            const int64_t d = fill[A.col[q]]++;
-            T.col[d] = i;
-            const double *s = &A.val[(size_t)q * 36];
+    std::vector<int64_t> src(A.col.size()); // block of A that lands in each block of T
+    {
+        std::vector<int64_t> fill(T.ptr.begin(), T.ptr.end() - 1);
+        for (int32_t i = 0; i < A.nr; i++) // ascending rows -> ascending columns of the transpose
+            for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++) {
+                const int64_t d = fill[A.col[q]]++;
+                T.col[(size_t)d] = i;
+                src[(size_t)d] = q;
+            }
+    }
+    parallel_chunks((int64_t)src.size(), [&](int64_t d0, int64_t d1) {
+        for (int64_t d = d0; d < d1; d++) {
+            const double *s2 = &A.val[(size_t)src[(size_t)d] * 36];
             double *t = &T.val[(size_t)d * 36];
             for (int r = 0; r < 6; r++)
-                for (int c = 0; c < 6; c++) t[6 * c + r] = s[6 * r + c];
+                for (int c = 0; c < 6; c++) t[6 * c + r] = s2[6 * r + c];
         }
+    }, 4096);
 }
 
 void smoothed_prolongator(const Bsr &A, const std::vector<double> &Dinv, const std::vector<int32_t> &agg, int32_t na,
@@ -340,7 +338,7 @@ void smoothed_prolongator(const Bsr &A, const std::vector<double> &Dinv, const s
     P0.ptr.resize((size_t)A.nr + 1);
     for (int64_t i = 0; i <= A.nr; i++) P0.ptr[i] = i;
     P0.col.assign(agg.begin(), agg.end());
-    P0.val = Q;
+    P0.val.assign(Q.begin(), Q.end());
     Bsr &P = *Pout;
     bsr_multiply(A, P0, &P); // pattern of P = pattern of A P0 (it contains (i, agg[i]): A has its diagonal)
     parallel_chunks(A.nr, [&](int64_t r0, int64_t r1) {
@@ -463,12 +461,13 @@ void pack_sliced_ell(const Bsr &A, bool diag_first, SlicedEll *out)
     }
     const int64_t total = S.slice_base[S.n_slices];
     S.cols.assign((size_t)total, 0);
-    S.vals.assign((size_t)total * 36, 0.0);
+    S.vals.resize((size_t)total * 36);
     parallel_chunks(S.n_slices, [&](int64_t s0, int64_t s1) {
         for (int64_t s = s0; s < s1; s++) {
             const int w = S.slice_width[s];
             const int64_t base = S.slice_base[s];
             double *dst = &S.vals[(size_t)base * 36];
+            std::fill(dst, dst + (size_t)w * kSliceNodes * 36, 0.0); // padding slots stay zero
             for (int n = 0; n < kSliceNodes; n++) {
                 const int32_t a = (int32_t)s * kSliceNodes + n;
                 const int32_t pad_col = diag_first ? std::min(a, S.n_pad - 1) : 0;

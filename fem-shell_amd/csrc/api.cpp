@@ -186,8 +186,15 @@ namespace femshell {
 int download_matrix(femshell_ctx *c, Bsr *Aout)
 {
     const Plan &p = c->plan;
-    std::vector<double> h((size_t)p.total_slots() * 36);
-    FS_HIP(hipMemcpyAsync(h.data(), c->vals.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    // pinned landing buffer: a pageable std::vector would be zero-filled first and copied at a fraction of the PCIe rate
+    struct Pinned {
+        double *p = nullptr;
+        ~Pinned() { if (p) (void)hipHostFree(p); }
+        double *data() const { return p; }
+    } h;
+    const size_t h_size = (size_t)p.total_slots() * 36;
+    FS_HIP(hipHostMalloc(reinterpret_cast<void **>(&h.p), h_size * sizeof(double), hipHostMallocDefault));
+    FS_HIP(hipMemcpyAsync(h.data(), c->vals.p, h_size * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     FS_HIP(hipStreamSynchronize(c->stream));
     Bsr &A = *Aout;
     A = Bsr();

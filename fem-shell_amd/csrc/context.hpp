@@ -48,7 +48,7 @@ template <class T> struct DevBuf {
         if (e == hipSuccess) n = count;
         return e;
     }
-    hipError_t upload(const std::vector<T> &h, hipStream_t st)
+    template <class Vec> hipError_t upload(const Vec &h, hipStream_t st) // any contiguous container of T
     {
         hipError_t e = alloc(h.size());
         if (e != hipSuccess || h.empty()) return e;
