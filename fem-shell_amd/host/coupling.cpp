@@ -1,6 +1,12 @@
 // coupling.cpp -- see coupling.hpp
 #include "coupling.hpp"
 
+#ifdef FEMSHELL_HAVE_PRECICE
+// build with -DFEMSHELL_HAVE_PRECICE -lprecice: the coupled program then talks to the real coupling library (pre-1.0
+// SolverInterface API, the one the reference uses, PC:15, 50-52); -inprocess keeps the built-in stand-in
+#include "precice/SolverInterface.hpp"
+#endif
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -313,8 +319,15 @@ int fem_shell_precice_main(int argc, char **argv, std::ostream &out, std::ostrea
             dummy = DummyFluid::left_edge(dims, probe_cs.grid);
         }
         InProcessCoupling interface(dummy, scheme);
-        out << "preCICE configured... (in-process stand-in, " << dims << "D, " << scheme.max_time / scheme.timestep
-            << " time steps)" << std::endl;
+#ifdef FEMSHELL_HAVE_PRECICE
+        bool in_process = false; // built against preCICE: the real library unless -inprocess is given
+        for (int i = 1; i < argc; i++) in_process = in_process || std::string(argv[i]) == "-inprocess";
+#else
+        const bool in_process = true;
+#endif
+        if (in_process)
+            out << "preCICE configured... (in-process stand-in, " << dims << "D, " << scheme.max_time / scheme.timestep
+                << " time steps)" << std::endl;
         // probe: the highest interface node, displacement along the first live axis
         const std::vector<int32_t> ifn = mesh.nodes_with_ids({2, 20, 21});
         if (ifn.empty()) throw std::runtime_error("mesh has no coupling interface (boundary ids 2, 20, 21)");
@@ -331,8 +344,19 @@ int fem_shell_precice_main(int argc, char **argv, std::ostream &out, std::ostrea
         for (int32_t n : ifn)
             if (mesh.xyz[3 * (size_t)n + ax[1]] > mesh.xyz[3 * (size_t)probe + ax[1]]) probe = n;
         std::ostream quiet(nullptr); // ranks other than 0 compute the same coupling steps silently
-        const CoupledRunLog log = run_coupled_structure(interface, system, mesh, deadAxis, deltaT, p.tol, p.max_it, probe,
-                                                        ax[0], stepsv ? std::atoi(stepsv) : -1, launch.rank == 0 ? out : quiet, p.debug);
+        CoupledRunLog log;
+#ifdef FEMSHELL_HAVE_PRECICE
+        if (!in_process) {
+            // the reference's participant: a real coupling library and a real fluid solver on the other side (PC:50-52);
+            // every rank joins with its rank / size like global_processor_id() / global_n_processors() there
+            precice::SolverInterface real("STRUCTURE", config, launch.rank, launch.world_size);
+            out << "preCICE configured..." << std::endl;
+            log = run_coupled_structure(real, system, mesh, deadAxis, deltaT, p.tol, p.max_it, probe, ax[0],
+                                        stepsv ? std::atoi(stepsv) : -1, launch.rank == 0 ? out : quiet, p.debug);
+        } else
+#endif
+            log = run_coupled_structure(interface, system, mesh, deadAxis, deltaT, p.tol, p.max_it, probe, ax[0],
+                                        stepsv ? std::atoi(stepsv) : -1, launch.rank == 0 ? out : quiet, p.debug);
         if (launch.rank != 0) return 0;
         out << "Coupled run: " << log.time_steps << " time steps, " << log.coupling_iterations << " coupling iterations, "
             << log.cg_iterations << " CG iterations, assembly " << log.assemble_seconds << " s, solves " << log.solve_seconds

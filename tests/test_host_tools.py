@@ -98,6 +98,15 @@ def test_libmesh_adaptor_compiles_against_the_test_only_mock(tmp_path):
                            "-I" + HOST, "-I" + os.path.join(ROOT, "tests", "helpers", "libmesh_mock"), str(tu)])
 
 
+def test_coupled_program_compiles_against_a_precice_declaration():
+    # -DFEMSHELL_HAVE_PRECICE instantiates run_coupled_structure<precice::SolverInterface> (the reference's participant,
+    # fem-shell_precice.cpp:50-52); preCICE is absent here, so tests/helpers/precice_mock declares the pre-1.0
+    # SolverInterface methods the adapter calls.  Syntax check only, nothing is linked.
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-DFEMSHELL_HAVE_PRECICE",
+                           "-I" + os.path.join(ROOT, "include"), "-I" + HOST, "-I" + os.path.join(ROOT, "tests", "helpers", "precice_mock"),
+                           os.path.join(HOST, "coupling.cpp")])
+
+
 def test_cli_usage_and_missing_arguments(tools):
     fem, _ = tools
     r = subprocess.run([fem], capture_output=True, text=True)
