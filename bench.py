@@ -387,11 +387,15 @@ def main():
         fs.sync()
         wall = time.perf_counter() - t0
         _, ib = fs.solve(rtol=1e-10, max_it=3000, fetch=False)  # hierarchy reused (the coupled program re-solves)
+        fs.set_preconditioner("amg", refine_passes=0)            # same hierarchy, no refinement pass
+        _, ic = fs.solve(rtol=1e-10, max_it=3000, fetch=False)
         tts = {"preconditioner": "smoothed-aggregation multigrid (rigid-body modes, Chebyshev/block-Jacobi smoothing, K cycle), "
                                  "flexible CG, 1 refinement pass with a double-double residual",
                "rtol": 1e-10, "iterations": ia["iterations"], "converged": ia["converged"],
                "solve_seconds": ia["solve_seconds"], "pc_setup_seconds": ia["pc_setup_seconds"], "wall_seconds_first_solve": wall,
                "solve_seconds_hierarchy_reused": ib["solve_seconds"], "levels": ia["amg_levels"],
+               "without_refinement_pass": {"iterations": ic["iterations"], "solve_seconds": ic["solve_seconds"],
+                                           "note": "recurrence residual 1e-10 reached; the displacement error then stalls at kappa*eps (DESIGN section 5)"},
                "operator_complexity": ia["operator_complexity"], "true_rel_residual_double_double": ia["true_rel_residual"],
                "algorithmic_gb_per_iteration": ia["bytes_per_iteration"] / 1e9,
                "achieved_gb_per_s": ia["bytes_per_iteration"] * ia["iterations"] / ia["solve_seconds"] / 1e9,

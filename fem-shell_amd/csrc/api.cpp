@@ -578,8 +578,14 @@ int femshell_set_preconditioner(femshell_ctx *c, const femshell_pc_options *opt)
             opt->max_levels < 2 || opt->max_levels > 32 || !(opt->eig_ratio > 1.0) || opt->refine_passes < 0 || opt->refine_passes > 4)
             return set_err(FEMSHELL_ERR_INVALID, "femshell_set_preconditioner: option out of range");
     }
+    // the hierarchy does not depend on the refinement passes: keep it when nothing else changes
+    femshell_pc_options a = c->pc, b = *opt;
+    a.refine_passes = b.refine_passes = 0;
+    a.reserved = b.reserved = 0;
+    const bool same_hierarchy = std::memcmp(&a, &b, sizeof a) == 0;
     c->pc = *opt;
-    c->amg.reset();
+    if (same_hierarchy && c->amg && c->amg->valid) c->amg->opt = *opt;
+    else c->amg.reset();
     return FEMSHELL_OK;
 }
 
@@ -885,6 +891,7 @@ int femshell_time_kernel(femshell_ctx *c, femshell_kernel which, int32_t reps, d
         FS_HIP(c->bp.alloc(nrow_ext));
         FS_HIP(c->bpart.alloc(2 * (size_t)slice_grid(c->dm)));
         FS_HIP(c->bscal.alloc(1));
+        FS_HIP(c->bscal.zero(st)); // the reduction's ticket counter must start at 0 (recycled memory is not)
         v.x = c->bx.p; v.r = c->br.p; v.z = c->bz.p; v.p = c->bp.p; v.q = c->bq.p;
         v.b = c->F.p; v.partials = c->bpart.p; v.s = c->bscal.p; v.hist = nullptr; v.hist_cap = 0;
         FS_HIP(c->bp.zero(st));
