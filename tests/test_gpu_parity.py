@@ -605,3 +605,53 @@ def test_context_reuse_new_mesh_new_constraints():
         u3_ref, _ = fresh(m, 0.3, 2.0e5, 0.05, dmask2, loads3)
         assert info3["assemble_seconds"] == 0.0
         np.testing.assert_array_equal(u3, u3_ref)
+
+
+# ------------------------------------------------------------------ symmetric storage against full storage
+
+def test_symmetric_storage_equals_full_storage(monkeypatch):
+    """K is stored as diagonal + one block per pair of owned nodes (default) or in full (FEMSHELL_SYMMETRIC=0, the
+    round-1 layout): same matrix up to the 1e-16 by which the reference's two independently summed blocks of a pair
+    differ, same products to 1e-13, same solve; products and solves are bitwise reproducible in both layouts."""
+    m = curved_mesh(41, 33)
+    rng = np.random.default_rng(11)
+    x = rng.normal(size=6 * m.n_nodes)
+    out = {}
+    for sym in ("1", "0"):
+        monkeypatch.setenv("FEMSHELL_SYMMETRIC", sym)
+        fs = make_ctx(m, 0.3, 7.0e4, 0.05)
+        fs.assemble()
+        r, c, v, F = fs.export_bsr()
+        y1, y2 = fs.spmv(x), fs.spmv(x)
+        assert np.array_equal(y1, y2)
+        u1, i1 = fs.solve(rtol=1e-11, max_it=50000)
+        u2, i2 = fs.solve(rtol=1e-11, max_it=50000)
+        assert np.array_equal(u1, u2) and i1["iterations"] == i2["iterations"] and i1["converged"] == 1
+        out[sym] = (r, c, v, F, y1, u1, i1, fs.residual(u1))
+        fs.close()
+    monkeypatch.delenv("FEMSHELL_SYMMETRIC")
+    (r1, c1, v1, F1, y1, u1, i1, res1), (r0, c0, v0, F0, y0, u0, i0, res0) = out["1"], out["0"]
+    np.testing.assert_array_equal(r1, r0)
+    np.testing.assert_array_equal(c1, c0)
+    np.testing.assert_array_equal(F1, F0)
+    assert np.abs(v1 - v0).max() <= 1e-14 * np.abs(v0).max()
+    # exactly symmetric outside the diagonal blocks with symmetric storage (a diagonal block is a sum of element blocks
+    # that are symmetric to rounding only, like the reference's)
+    K1 = oracle.to_scipy(r1, c1, v1)
+    D = (K1 - K1.T).tocoo()
+    off = (D.row // 6) != (D.col // 6)
+    assert np.abs(D.data[off]).max(initial=0.0) == 0.0
+    assert np.abs(D.data).max(initial=0.0) <= 1e-14 * abs(K1).max()
+    assert np.linalg.norm(y1 - y0) <= 1e-13 * np.linalg.norm(y0)
+    assert abs(i1["iterations"] - i0["iterations"]) <= max(3, 0.02 * i0["iterations"])
+    assert np.linalg.norm(u1 - u0) <= 1e-8 * np.linalg.norm(u0)
+    # the double-double residuals of the two layouts agree far below the FP64 noise of either
+    assert np.linalg.norm(res1 - oracle_residual(r1, c1, v1, F1, u1)) <= 1e-11 * np.linalg.norm(F1)
+    assert np.linalg.norm(res0 - oracle_residual(r0, c0, v0, F0, u0)) <= 1e-11 * np.linalg.norm(F0)
+
+
+def oracle_residual(r, c, v, F, u):
+    K = oracle.to_scipy(r, c, v)
+    K.sort_indices()
+    ld = np.longdouble
+    return (F.astype(ld) - np.add.reduceat(K.data.astype(ld) * u.ravel().astype(ld)[K.indices], K.indptr[:-1])).astype(np.float64)
