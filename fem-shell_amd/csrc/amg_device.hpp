@@ -24,6 +24,7 @@ struct AmgLevel {
     int32_t n = 0, n_pad = 0; // nodes (6 dofs each) / padded to whole slices
     int64_t nnzb = 0;         // blocks of the level matrix
     AmgOperator A;            // levels >= 1 (level 0 is the context's K)
+    bool A_on_device = false; // the level matrix was computed in HBM (amg_device_setup.cpp), nothing to upload
     AmgOperator P, R;         // to / from the next coarser level (absent on the coarsest)
     DevBuf<double> minv;      // block-Jacobi inverse of A (levels >= 1)
     double lam = 0.0;         // upper bound of the spectrum of D^-1 A used by the smoother
@@ -57,5 +58,8 @@ int cg_amg(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it, dou
 double amg_bytes_per_iteration(const femshell_ctx *c);
 // K of a single-rank context as host BSR with ascending columns (api.cpp)
 int download_matrix(femshell_ctx *c, Bsr *A);
+// first coarsening step with the numerics on the device (amg_device_setup.cpp)
+int amg_device_coarsen(femshell_ctx *c, AmgLevel &L, AmgLevel &next, const std::vector<double> &B, double lam, bool keep_host,
+                       Bsr *Ac_host, std::vector<double> *Bc_out, const std::function<void(const char *)> &lap);
 
 } // namespace femshell

@@ -1,0 +1,406 @@
+// amg_device_setup.cpp -- first coarsening step of the multigrid setup with the numerics on the device.
+//
+// The finest level dominates the setup: K has 14M blocks on the 4M-triangle meshes, and the host path (amg_setup.cpp)
+// first has to bring it over PCIe and mirror it.  Here the host only does integer work on the block graph the plan
+// already holds -- aggregation, the patterns of P, A P, R = P^T and A_c = P^T A P, and the index lists that tell every
+// block of a result which blocks feed it -- and the device computes the values from K where it lies (amg_kernels.hip:
+// k_amg_prolongator, k_amg_ap, k_amg_restriction, k_amg_galerkin), directly in the sliced block ELL layout the cycle
+// multiplies with.  Only the coarse operator (a ninth of the rows) travels back for the remaining levels, which stay on
+// the host.  FEMSHELL_AMG_SETUP=host keeps everything on the host (the path tests compare this one with).
+#include "amg_device.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <thread>
+
+namespace femshell {
+
+namespace {
+
+// rows as sorted lists -> sliced ELL pattern (32 rows per slice, `count` real entries per row, padding columns 0;
+// diag_first: the entry equal to the row index is moved to slot 0)
+struct EllPattern {
+    int32_t n_rows = 0, n_pad = 0, n_slices = 0, max_width = 0;
+    std::vector<int32_t> slice_width;
+    std::vector<int64_t> slice_base;
+    std::vector<int32_t> cols;
+    std::vector<uint8_t> count;
+    int64_t nnzb = 0;
+    int64_t total() const { return slice_base.empty() ? 0 : slice_base.back(); }
+};
+
+bool pack_pattern(int32_t n_rows, const std::vector<int64_t> &ptr, const std::vector<int32_t> &col, bool diag_first, EllPattern *out)
+{
+    EllPattern &E = *out;
+    E = EllPattern();
+    E.n_rows = n_rows;
+    E.n_pad = (n_rows + kSliceNodes - 1) / kSliceNodes * kSliceNodes;
+    E.n_slices = E.n_pad / kSliceNodes;
+    E.slice_width.assign((size_t)E.n_slices, 1);
+    E.slice_base.assign((size_t)E.n_slices + 1, 0);
+    E.count.assign((size_t)E.n_pad, 0);
+    for (int32_t s = 0; s < E.n_slices; s++) {
+        int w = 1;
+        for (int n = 0; n < kSliceNodes; n++) {
+            const int32_t a = s * kSliceNodes + n;
+            if (a >= n_rows) continue;
+            const int64_t c = ptr[a + 1] - ptr[a];
+            if (c > 255) return false;
+            E.count[a] = (uint8_t)c;
+            w = std::max<int>(w, (int)c);
+        }
+        E.slice_width[s] = w;
+        E.max_width = std::max(E.max_width, w);
+        E.slice_base[s + 1] = E.slice_base[s] + (int64_t)w * kSliceNodes;
+    }
+    E.nnzb = ptr[n_rows];
+    E.cols.assign((size_t)E.total(), 0);
+    parallel_chunks(E.n_slices, [&](int64_t s0, int64_t s1) {
+        for (int64_t s = s0; s < s1; s++)
+            for (int n = 0; n < kSliceNodes; n++) {
+                const int32_t a = (int32_t)s * kSliceNodes + n;
+                if (a >= n_rows) continue;
+                int k = 0;
+                if (diag_first) {
+                    E.cols[(size_t)(E.slice_base[s] + n)] = a;
+                    k = 1;
+                }
+                for (int64_t q = ptr[a]; q < ptr[a + 1]; q++) {
+                    if (diag_first && col[q] == a) continue;
+                    E.cols[(size_t)(E.slice_base[s] + (int64_t)k * kSliceNodes + n)] = col[q];
+                    k++;
+                }
+            }
+    }, 64);
+    return true;
+}
+
+struct DevPattern {
+    DevBuf<int32_t> slice_width, cols;
+    DevBuf<int64_t> slice_base;
+    DevBuf<uint8_t> count;
+};
+
+int upload_pattern(const EllPattern &E, DevPattern &D, double *vals, EllView *view, hipStream_t st)
+{
+    FS_HIP(D.slice_width.upload(E.slice_width, st));
+    FS_HIP(D.slice_base.upload(E.slice_base, st));
+    FS_HIP(D.cols.upload(E.cols, st));
+    FS_HIP(D.count.upload(E.count, st));
+    view->n_rows = E.n_rows;
+    view->n_slices = E.n_slices;
+    view->slice_width = D.slice_width.p;
+    view->slice_base = D.slice_base.p;
+    view->cols = D.cols.p;
+    view->count = D.count.p;
+    view->vals = vals;
+    view->total = E.total();
+    return FEMSHELL_OK;
+}
+
+// the pattern's device arrays become the operator's own (the cycle multiplies with them)
+void adopt(AmgOperator &op, const EllPattern &E, DevPattern &D, DevBuf<double> &vals, int32_t n_cols_pad)
+{
+    std::swap(op.slice_width.p, D.slice_width.p);
+    std::swap(op.slice_width.n, D.slice_width.n);
+    std::swap(op.slice_base.p, D.slice_base.p);
+    std::swap(op.slice_base.n, D.slice_base.n);
+    std::swap(op.cols.p, D.cols.p);
+    std::swap(op.cols.n, D.cols.n);
+    std::swap(op.vals.p, vals.p);
+    std::swap(op.vals.n, vals.n);
+    op.nnzb = E.nnzb;
+    op.n_cols_pad = n_cols_pad;
+    op.dm = DeviceMatrix();
+    op.dm.n_own = E.n_rows;
+    op.dm.n_pad = E.n_pad;
+    op.dm.n_slices = E.n_slices;
+    op.dm.slice_width = op.slice_width.p;
+    op.dm.slice_base = op.slice_base.p;
+    op.dm.cols = op.cols.p;
+    op.dm.vals = op.vals.p;
+    op.dm.max_slice_width = E.max_width;
+}
+
+// host BSR (ascending columns) from a pattern and the ELL values brought back from the device
+void ell_to_bsr(const EllPattern &E, const double *vals, int32_t n_cols, Bsr *out)
+{
+    Bsr &A = *out;
+    A = Bsr();
+    A.nr = E.n_rows;
+    A.nc = n_cols;
+    A.ptr.assign((size_t)E.n_rows + 1, 0);
+    for (int32_t a = 0; a < E.n_rows; a++) A.ptr[a + 1] = A.ptr[a] + E.count[a];
+    A.col.resize((size_t)A.ptr[E.n_rows]);
+    A.val.resize((size_t)A.ptr[E.n_rows] * 36);
+    parallel_chunks(E.n_rows, [&](int64_t a0, int64_t a1) {
+        std::vector<std::pair<int32_t, int>> order;
+        for (int64_t a = a0; a < a1; a++) {
+            const int s = (int)(a / kSliceNodes), n = (int)(a % kSliceNodes);
+            order.clear();
+            for (int k = 0; k < E.count[a]; k++) order.push_back({E.cols[(size_t)(E.slice_base[s] + (int64_t)k * kSliceNodes + n)], k});
+            std::sort(order.begin(), order.end());
+            int64_t nb = A.ptr[a];
+            for (auto &ck : order) {
+                A.col[(size_t)nb] = ck.first;
+                const double *src = vals + (E.slice_base[s] + (int64_t)ck.second * kSliceNodes) * 36;
+                double *blk = &A.val[(size_t)nb * 36];
+                for (int i = 0; i < 6; i++)
+                    for (int j = 0; j < 6; j++) blk[6 * i + j] = src[((int64_t)((j / 2) * 6 + i) * kSliceNodes + n) * 2 + (j & 1)];
+                nb++;
+            }
+        }
+    });
+}
+
+int download_vals(const DevBuf<double> &d, std::vector<double, default_init_allocator<double>> *h, hipStream_t st)
+{
+    h->resize(d.n);
+    FS_HIP(hipMemcpyAsync(h->data(), d.p, d.n * sizeof(double), hipMemcpyDeviceToHost, st));
+    FS_HIP(hipStreamSynchronize(st));
+    return FEMSHELL_OK;
+}
+
+} // namespace
+
+// the block graph of the context's K as a pattern-only BSR with ascending columns (what download_matrix would give)
+void graph_of_plan(const Plan &p, Bsr *G)
+{
+    Bsr &A = *G;
+    A = Bsr();
+    A.nr = A.nc = p.n_own;
+    A.ptr.assign((size_t)p.n_own + 1, 0);
+    auto count_row = [&](int32_t a) {
+        const int s = a / kSliceNodes, n = a % kSliceNodes;
+        int cnt = 0;
+        for (int k = 0; k < p.slice_width[s]; k++) {
+            const int64_t slot = Plan::slot_index(p.slice_base[s], k, n);
+            if (k == 0 || p.cols[slot] != a) cnt++;
+        }
+        if (p.symmetric)
+            for (int k = 0; k < p.in_width[s]; k++)
+                if (p.in_slots[(size_t)(p.in_base[s] + (int64_t)k * kSliceNodes + n)] >= 0) cnt++;
+        return cnt;
+    };
+    for (int32_t a = 0; a < p.n_own; a++) A.ptr[a + 1] = A.ptr[a] + count_row(a);
+    A.col.resize((size_t)A.ptr[p.n_own]);
+    parallel_chunks(p.n_own, [&](int64_t a0, int64_t a1) {
+        for (int64_t a = a0; a < a1; a++) {
+            const int s = (int)(a / kSliceNodes), n = (int)(a % kSliceNodes);
+            int64_t w = A.ptr[a];
+            for (int k = 0; k < p.slice_width[s]; k++) {
+                const int64_t slot = Plan::slot_index(p.slice_base[s], k, n);
+                if (k == 0 || p.cols[slot] != a) A.col[(size_t)w++] = p.cols[slot];
+            }
+            if (p.symmetric)
+                for (int k = 0; k < p.in_width[s]; k++) {
+                    const size_t e = (size_t)(p.in_base[s] + (int64_t)k * kSliceNodes + n);
+                    if (p.in_slots[e] >= 0) A.col[(size_t)w++] = p.in_rows[e];
+                }
+            std::sort(A.col.begin() + A.ptr[a], A.col.begin() + A.ptr[a + 1]);
+        }
+    });
+}
+
+// One coarsening step of level 0 on the device.  In: the context's K (c->dm, block-Jacobi inverse valid), the near-null
+// space B of the fine nodes, the spectral bound lam.  Out: L.P, L.R (operators of the cycle), next.A (the coarse level
+// matrix in HBM, diagonal slot first), Ac_host (its host copy for the remaining levels), Bc, and for small problems the
+// host copies the inspection exports want.
+int amg_device_coarsen(femshell_ctx *c, AmgLevel &L, AmgLevel &next, const std::vector<double> &B, double lam, bool keep_host,
+                       Bsr *Ac_host, std::vector<double> *Bc_out, const std::function<void(const char *)> &lap)
+{
+    const Plan &p = c->plan;
+    hipStream_t st = c->stream;
+    const int32_t n = p.n_own;
+    if (c->cfg.world_size != 1) return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: single-rank contexts only");
+    // ---- aggregation and tentative prolongator on the graph
+    Bsr G;
+    graph_of_plan(p, &G);
+    std::vector<int32_t> agg;
+    const int32_t na = aggregate_nodes(G, &agg);
+    lap("graph + aggregation");
+    std::vector<double> Q;
+    tentative_prolongator(agg, na, B, &Q, Bc_out);
+    lap("tentative P");
+
+    // ---- patterns
+    // P: per fine row the sorted distinct aggregates of its neighbours (the row itself included)
+    std::vector<int64_t> pptr((size_t)n + 1, 0);
+    std::vector<int32_t> pcol;
+    {
+        std::vector<uint8_t> cnt((size_t)n, 0);
+        std::vector<int32_t> tmp_all((size_t)G.ptr[n]); // upper bound storage: distinct aggregates per row, compacted below
+        parallel_chunks(n, [&](int64_t a0, int64_t a1) {
+            for (int64_t a = a0; a < a1; a++) {
+                int32_t *t = &tmp_all[(size_t)G.ptr[a]];
+                int m = 0;
+                for (int64_t q = G.ptr[a]; q < G.ptr[a + 1]; q++) t[m++] = agg[G.col[q]];
+                std::sort(t, t + m);
+                m = (int)(std::unique(t, t + m) - t);
+                cnt[a] = (uint8_t)std::min(m, 255);
+            }
+        });
+        for (int32_t a = 0; a < n; a++) pptr[a + 1] = pptr[a] + cnt[a];
+        pcol.resize((size_t)pptr[n]);
+        parallel_chunks(n, [&](int64_t a0, int64_t a1) {
+            for (int64_t a = a0; a < a1; a++) std::copy_n(&tmp_all[(size_t)G.ptr[a]], cnt[a], &pcol[(size_t)pptr[a]]);
+        });
+    }
+    auto p_index = [&](int32_t row, int32_t J) -> int {
+        const int32_t *b = &pcol[(size_t)pptr[row]], *e = &pcol[(size_t)pptr[row + 1]];
+        return (int)(std::lower_bound(b, e, J) - b);
+    };
+    // which slot of P's row every block of K feeds (own slots and in-list entries, in the order the kernels walk them)
+    std::vector<uint8_t> pmap_own((size_t)p.total_slots(), 0), pmap_in(p.in_slots.size(), 0);
+    parallel_chunks(n, [&](int64_t a0, int64_t a1) {
+        for (int64_t a = a0; a < a1; a++) {
+            const int s = (int)(a / kSliceNodes), nn = (int)(a % kSliceNodes);
+            for (int k = 0; k < p.slice_width[s]; k++) {
+                const int64_t slot = Plan::slot_index(p.slice_base[s], k, nn);
+                const int32_t cc = p.cols[slot];
+                if (k == 0 || cc != a) pmap_own[(size_t)slot] = (uint8_t)p_index((int32_t)a, agg[cc]);
+            }
+            if (p.symmetric)
+                for (int k = 0; k < p.in_width[s]; k++) {
+                    const size_t e = (size_t)(p.in_base[s] + (int64_t)k * kSliceNodes + nn);
+                    if (p.in_slots[e] >= 0) pmap_in[e] = (uint8_t)p_index((int32_t)a, agg[p.in_rows[e]]);
+                }
+        }
+    });
+    // A P: per fine row the union of the P rows of its neighbours
+    std::vector<int64_t> aptr((size_t)n + 1, 0);
+    std::vector<int32_t> acol;
+    {
+        std::vector<std::vector<int32_t>> parts; // per chunk, concatenated afterwards
+        std::vector<int32_t> cnt((size_t)n, 0);
+        const int nchunks = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (n + 4095) / 4096));
+        parts.resize((size_t)nchunks);
+        std::vector<std::thread> th;
+        auto work = [&](int t) {
+            const int64_t a0 = (int64_t)n * t / nchunks, a1 = (int64_t)n * (t + 1) / nchunks;
+            std::vector<int32_t> tmp;
+            for (int64_t a = a0; a < a1; a++) {
+                tmp.clear();
+                for (int64_t q = G.ptr[a]; q < G.ptr[a + 1]; q++) {
+                    const int32_t j = G.col[q];
+                    tmp.insert(tmp.end(), pcol.begin() + pptr[j], pcol.begin() + pptr[j + 1]);
+                }
+                std::sort(tmp.begin(), tmp.end());
+                tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                cnt[a] = (int32_t)tmp.size();
+                parts[(size_t)t].insert(parts[(size_t)t].end(), tmp.begin(), tmp.end());
+            }
+        };
+        for (int t = 1; t < nchunks; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &t : th) t.join();
+        for (int32_t a = 0; a < n; a++) aptr[a + 1] = aptr[a] + cnt[a];
+        acol.resize((size_t)aptr[n]);
+        for (int t = 0; t < nchunks; t++) {
+            const int64_t a0 = (int64_t)n * t / nchunks;
+            std::copy(parts[(size_t)t].begin(), parts[(size_t)t].end(), acol.begin() + aptr[a0]);
+        }
+    }
+    // R = P^T as lists: per aggregate the fine rows (ascending) and the slot of the aggregate in their P row
+    std::vector<int64_t> rptr((size_t)na + 1, 0);
+    std::vector<int32_t> rrow((size_t)pptr[n]);
+    std::vector<uint8_t> rk((size_t)pptr[n]);
+    {
+        for (int64_t q = 0; q < pptr[n]; q++) rptr[(size_t)pcol[(size_t)q] + 1]++;
+        for (int32_t I = 0; I < na; I++) rptr[I + 1] += rptr[I];
+        std::vector<int64_t> fill(rptr.begin(), rptr.end() - 1);
+        for (int32_t a = 0; a < n; a++)
+            for (int64_t q = pptr[a]; q < pptr[a + 1]; q++) {
+                const int64_t d = fill[(size_t)pcol[(size_t)q]]++;
+                rrow[(size_t)d] = a;
+                rk[(size_t)d] = (uint8_t)(q - pptr[a]);
+            }
+    }
+    // A_c: per aggregate the union of the A P rows of its fine rows
+    std::vector<int64_t> cptr((size_t)na + 1, 0);
+    std::vector<int32_t> ccol;
+    {
+        std::vector<std::vector<int32_t>> rows((size_t)na);
+        parallel_chunks(na, [&](int64_t I0, int64_t I1) {
+            std::vector<int32_t> tmp;
+            for (int64_t I = I0; I < I1; I++) {
+                tmp.clear();
+                for (int64_t q = rptr[I]; q < rptr[I + 1]; q++) {
+                    const int32_t i = rrow[(size_t)q];
+                    tmp.insert(tmp.end(), acol.begin() + aptr[i], acol.begin() + aptr[i + 1]);
+                }
+                std::sort(tmp.begin(), tmp.end());
+                tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                rows[(size_t)I] = tmp;
+            }
+        }, 64);
+        for (int32_t I = 0; I < na; I++) cptr[I + 1] = cptr[I] + (int64_t)rows[(size_t)I].size();
+        ccol.resize((size_t)cptr[na]);
+        for (int32_t I = 0; I < na; I++) std::copy(rows[(size_t)I].begin(), rows[(size_t)I].end(), ccol.begin() + cptr[I]);
+    }
+    EllPattern eP, eAP, eR, eAc;
+    if (!pack_pattern(n, pptr, pcol, false, &eP) || !pack_pattern(n, aptr, acol, false, &eAP) ||
+        !pack_pattern(na, cptr, ccol, true, &eAc))
+        return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: a row of an intermediate operator has more than 255 blocks");
+    {
+        std::vector<int32_t> rcol(rrow); // R's columns are the fine rows, already ascending per aggregate
+        if (!pack_pattern(na, rptr, rcol, false, &eR))
+            return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: an aggregate is seen by more than 255 fine rows");
+    }
+    lap("patterns of P, AP, R, Ac");
+
+    // ---- values on the device
+    DevBuf<int32_t> d_agg, d_rrow;
+    DevBuf<double> d_Q, vP, vAP, vR, vAc;
+    DevBuf<uint8_t> d_pmap_own, d_pmap_in, d_rk;
+    DevBuf<int64_t> d_rptr;
+    DevPattern dP, dAP, dR, dAc;
+    FS_HIP(d_agg.upload(agg, st));
+    FS_HIP(d_Q.upload(Q, st));
+    FS_HIP(d_pmap_own.upload(pmap_own, st));
+    FS_HIP(d_pmap_in.upload(pmap_in, st));
+    FS_HIP(d_rptr.upload(rptr, st));
+    FS_HIP(d_rrow.upload(rrow, st));
+    FS_HIP(d_rk.upload(rk, st));
+    FS_HIP(vP.alloc((size_t)eP.total() * 36));
+    FS_HIP(vAP.alloc((size_t)eAP.total() * 36));
+    FS_HIP(vR.alloc((size_t)eR.total() * 36));
+    FS_HIP(vAc.alloc((size_t)eAc.total() * 36));
+    EllView wP, wAP, wR, wAc;
+    int rc = upload_pattern(eP, dP, vP.p, &wP, st);
+    if (!rc) rc = upload_pattern(eAP, dAP, vAP.p, &wAP, st);
+    if (!rc) rc = upload_pattern(eR, dR, vR.p, &wR, st);
+    if (!rc) rc = upload_pattern(eAc, dAc, vAc.p, &wAc, st);
+    if (rc) return rc;
+    FS_HIP(hipStreamSynchronize(st)); // the host vectors above go out of scope at the end of this function only, but be safe
+    lap("uploads");
+    launch_amg_prolongator(c->dm, d_agg.p, d_Q.p, (4.0 / 3.0) / lam, d_pmap_own.p, d_pmap_in.p, wP, st);
+    launch_amg_ap(c->dm, wP, wAP, st);
+    launch_amg_restriction(wP, d_rptr.p, d_rrow.p, d_rk.p, wR, st);
+    launch_amg_galerkin(wP, wAP, d_rptr.p, d_rrow.p, d_rk.p, wAc, st);
+    FS_HIP(hipGetLastError());
+    FS_HIP(hipStreamSynchronize(st));
+    lap("P, AP, R, Ac on the device");
+
+    // ---- the coarse operator goes back for the remaining levels; small problems keep P for the inspection exports
+    {
+        ValueArray h;
+        rc = download_vals(vAc, &h, st);
+        if (rc) return rc;
+        ell_to_bsr(eAc, h.data(), na, Ac_host);
+        if (keep_host) {
+            rc = download_vals(vP, &h, st);
+            if (rc) return rc;
+            ell_to_bsr(eP, h.data(), na, &L.hP);
+            L.agg = agg;
+        }
+    }
+    const int32_t nc_pad = eAc.n_pad;
+    adopt(L.P, eP, dP, vP, nc_pad);
+    adopt(L.R, eR, dR, vR, eP.n_pad);
+    adopt(next.A, eAc, dAc, vAc, nc_pad);
+    lap("download of the coarse operator");
+    return FEMSHELL_OK;
+}
+
+} // namespace femshell

@@ -367,3 +367,243 @@ void launch_kcyc_combine(const double *c1, const double *c2, double *x, int64_t 
 }
 
 } // namespace femshell
+
+// =====================================================================================================================
+// Multigrid setup on the device (amg_kernels.hpp): one lane per block of the result, gathers over the plan's lists
+// =====================================================================================================================
+namespace femshell {
+
+namespace {
+
+// element (i, j) of the block in slot `slot` of a sliced block ELL value array (slice bases are multiples of 32)
+__device__ __forceinline__ int64_t ell_index(int64_t slot, int i, int j)
+{
+    const int n = (int)(slot & 31);
+    return (slot - n) * 36 + ((int64_t)((j >> 1) * 6 + i) * kSliceNodes + n) * 2 + (j & 1);
+}
+__device__ __forceinline__ void ell_load(const double *vals, int64_t slot, double b[36], bool transposed)
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const double v = vals[ell_index(slot, i, j)];
+            if (transposed) b[6 * j + i] = v;
+            else b[6 * i + j] = v;
+        }
+}
+__device__ __forceinline__ void ell_store(double *vals, int64_t slot, const double b[36])
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) vals[ell_index(slot, i, j)] = b[6 * i + j];
+}
+// c += a * b (row-major 6x6), a^T * b with ta
+__device__ __forceinline__ void blk_mac(const double a[36], const double b[36], double c[36], bool ta)
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const double aik = ta ? a[6 * k + i] : a[6 * i + k];
+#pragma unroll
+            for (int j = 0; j < 6; j++) c[6 * i + j] += aik * b[6 * k + j];
+        }
+}
+// slot k of row (sl, n) of an ELL matrix
+__device__ __forceinline__ int64_t ell_slot(const EllView &M, int sl, int k, int n) { return M.slice_base[sl] + (int64_t)k * kSliceNodes + n; }
+
+// the neighbours of row a of K in a fixed order: its own slots (padding skipped), then its in-list (symmetric storage)
+template <class F> __device__ __forceinline__ void for_each_neighbour(const DeviceMatrix &A, int a, F f)
+{
+    const int sl = a / kSliceNodes, n = a % kSliceNodes;
+    const int64_t base = A.slice_base[sl];
+    const int W = A.slice_width[sl];
+    for (int k = 0; k < W; k++) {
+        const int64_t slot = base + (int64_t)k * kSliceNodes + n;
+        const int c = (k == 0) ? a : A.cols[slot];
+        if (k > 0 && c == a) continue; // padding slot
+        f(c, slot, false, slot);
+    }
+    if (A.symmetric) {
+        const int Wi = A.in_width[sl];
+        const int64_t ib = A.in_base[sl];
+        for (int k = 0; k < Wi; k++) {
+            const int64_t e = ib + (int64_t)k * kSliceNodes + n;
+            const int32_t slot = A.in_slots[e];
+            if (slot >= 0) f(A.in_rows[e], (int64_t)slot, true, e);
+        }
+    }
+}
+
+} // namespace
+
+__device__ __forceinline__ int ell_slice_of(const EllView &M, int64_t t)
+{
+    int lo = 0, hi = M.n_slices - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (M.slice_base[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+// slot of column J in row r of M, -1 if absent
+__device__ __forceinline__ int64_t ell_find(const EllView &M, int r, int J)
+{
+    const int sl = r / kSliceNodes, n = r % kSliceNodes;
+    const int cnt = M.count[r];
+    for (int k = 0; k < cnt; k++) {
+        const int64_t slot = M.slice_base[sl] + (int64_t)k * kSliceNodes + n;
+        if (M.cols[slot] == J) return slot;
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(128) void k_amg_prolongator(DeviceMatrix A, const int32_t *__restrict__ agg, const double *__restrict__ Q,
+                                                         double omega, const uint8_t *__restrict__ pmap_own,
+                                                         const uint8_t *__restrict__ pmap_in, EllView P)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.total) return;
+    // thread t <-> slot t of P
+    const int sl = ell_slice_of(P, t); // slices have different widths: bisection over slice_base
+    const int64_t off = t - P.slice_base[sl];
+    const int kP = (int)(off / kSliceNodes), n = (int)(off % kSliceNodes);
+    const int a = sl * kSliceNodes + n;
+    double out[36];
+#pragma unroll
+    for (int e = 0; e < 36; e++) out[e] = 0.0;
+    if (a < P.n_rows && kP < P.count[a]) {
+        const int J = P.cols[t];
+        double acc[36];
+#pragma unroll
+        for (int e = 0; e < 36; e++) acc[e] = 0.0;
+        for_each_neighbour(A, a, [&](int c, int64_t slot, bool transposed, int64_t map_index) {
+            const uint8_t target = transposed ? pmap_in[map_index] : pmap_own[map_index];
+            if (target != kP) return;
+            double blk[36], q[36];
+            ell_load(A.vals, slot, blk, transposed);
+#pragma unroll
+            for (int e = 0; e < 36; e++) q[e] = Q[(int64_t)c * 36 + e];
+            blk_mac(blk, q, acc, false);
+        });
+        // D^-1 from the packed upper triangle of the inverse diagonal block
+        double dinv[36];
+        const double *mi = A.minv + (int64_t)(a / kSliceNodes) * kMinvWords * kSliceNodes + (a % kSliceNodes);
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j < 6; j++) dinv[6 * i + j] = mi[minv_word(i < j ? i : j, i < j ? j : i) * kSliceNodes];
+        double sm[36];
+#pragma unroll
+        for (int e = 0; e < 36; e++) sm[e] = 0.0;
+        blk_mac(dinv, acc, sm, false);
+        const bool own = J == agg[a];
+#pragma unroll
+        for (int e = 0; e < 36; e++) out[e] = (own ? Q[(int64_t)a * 36 + e] : 0.0) - omega * sm[e];
+    }
+    ell_store(P.vals, t, out);
+}
+
+__global__ __launch_bounds__(128) void k_amg_ap(DeviceMatrix A, EllView P, EllView AP)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= AP.total) return;
+    const int sl = ell_slice_of(AP, t);
+    const int64_t off = t - AP.slice_base[sl];
+    const int kA = (int)(off / kSliceNodes), n = (int)(off % kSliceNodes);
+    const int a = sl * kSliceNodes + n;
+    double acc[36];
+#pragma unroll
+    for (int e = 0; e < 36; e++) acc[e] = 0.0;
+    if (a < AP.n_rows && kA < AP.count[a]) {
+        const int J = AP.cols[t];
+        for_each_neighbour(A, a, [&](int c, int64_t slot, bool transposed, int64_t) {
+            const int64_t ps = ell_find(P, c, J);
+            if (ps < 0) return;
+            double blk[36], pb[36];
+            ell_load(A.vals, slot, blk, transposed);
+            ell_load(P.vals, ps, pb, false);
+            blk_mac(blk, pb, acc, false);
+        });
+    }
+    ell_store(AP.vals, t, acc);
+}
+
+__global__ __launch_bounds__(128) void k_amg_restriction(EllView P, const int64_t *__restrict__ rptr, const int32_t *__restrict__ rrow,
+                                                         const uint8_t *__restrict__ rk, EllView R)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= R.total) return;
+    const int sl = ell_slice_of(R, t);
+    const int64_t off = t - R.slice_base[sl];
+    const int kR = (int)(off / kSliceNodes), n = (int)(off % kSliceNodes);
+    const int I = sl * kSliceNodes + n;
+    double out[36];
+#pragma unroll
+    for (int e = 0; e < 36; e++) out[e] = 0.0;
+    if (I < R.n_rows && kR < (int)(rptr[I + 1] - rptr[I])) {
+        const int64_t q = rptr[I] + kR;
+        const int i = rrow[q];
+        ell_load(P.vals, ell_slot(P, i / kSliceNodes, rk[q], i % kSliceNodes), out, true);
+    }
+    ell_store(R.vals, t, out);
+}
+
+__global__ __launch_bounds__(128) void k_amg_galerkin(EllView P, EllView AP, const int64_t *__restrict__ rptr,
+                                                      const int32_t *__restrict__ rrow, const uint8_t *__restrict__ rk, EllView Ac)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Ac.total) return;
+    const int sl = ell_slice_of(Ac, t);
+    const int64_t off = t - Ac.slice_base[sl];
+    const int kC = (int)(off / kSliceNodes), n = (int)(off % kSliceNodes);
+    const int I = sl * kSliceNodes + n;
+    double acc[36];
+#pragma unroll
+    for (int e = 0; e < 36; e++) acc[e] = 0.0;
+    if (I < Ac.n_rows && kC < Ac.count[I]) {
+        const int J = Ac.cols[t];
+        for (int64_t q = rptr[I]; q < rptr[I + 1]; q++) {
+            const int i = rrow[q];
+            const int64_t as = ell_find(AP, i, J);
+            if (as < 0) continue;
+            double pb[36], ab[36];
+            ell_load(P.vals, ell_slot(P, i / kSliceNodes, rk[q], i % kSliceNodes), pb, false);
+            ell_load(AP.vals, as, ab, false);
+            blk_mac(pb, ab, acc, true); // P_iI^T (A P)_iJ
+        }
+        if (J == I) // coarse dofs without fine support (zero column of P): unit diagonal keeps the level matrix SPD
+#pragma unroll
+            for (int v = 0; v < 6; v++)
+                if (acc[7 * v] == 0.0) acc[7 * v] = 1.0;
+    }
+    ell_store(Ac.vals, t, acc);
+}
+
+void launch_amg_prolongator(const DeviceMatrix &A, const int32_t *agg, const double *Q, double omega, const uint8_t *pmap_own,
+                            const uint8_t *pmap_in, const EllView &P, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_amg_prolongator, dim3((unsigned)((P.total + 127) / 128)), dim3(128), 0, st, A, agg, Q, omega, pmap_own,
+                       pmap_in, P);
+}
+
+void launch_amg_ap(const DeviceMatrix &A, const EllView &P, const EllView &AP, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_amg_ap, dim3((unsigned)((AP.total + 127) / 128)), dim3(128), 0, st, A, P, AP);
+}
+
+void launch_amg_restriction(const EllView &P, const int64_t *rptr, const int32_t *rrow, const uint8_t *rk, const EllView &R,
+                            hipStream_t st)
+{
+    hipLaunchKernelGGL(k_amg_restriction, dim3((unsigned)((R.total + 127) / 128)), dim3(128), 0, st, P, rptr, rrow, rk, R);
+}
+
+void launch_amg_galerkin(const EllView &P, const EllView &AP, const int64_t *rptr, const int32_t *rrow, const uint8_t *rk,
+                         const EllView &Ac, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_amg_galerkin, dim3((unsigned)((Ac.total + 127) / 128)), dim3(128), 0, st, P, AP, rptr, rrow, rk, Ac);
+}
+
+} // namespace femshell

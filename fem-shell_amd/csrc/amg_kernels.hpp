@@ -60,3 +60,31 @@ void launch_kcyc_combine(const double *c1, const double *c2, double *x, int64_t 
                          const CgScalars *gate, hipStream_t st);
 
 } // namespace femshell
+
+namespace femshell {
+
+// ---- multigrid setup on the device (level 0): numeric values of the smoothed prolongator, A P, R = P^T and the
+// Galerkin operator P^T A P, on patterns the host computed from the block graph (amg_device_setup.cpp).  All operators are
+// sliced block ELL; `count` gives the real entries of a row (the rest of its slots is padding with zero values).
+struct EllView {
+    int32_t n_rows = 0, n_slices = 0;
+    const int32_t *slice_width = nullptr;
+    const int64_t *slice_base = nullptr;
+    const int32_t *cols = nullptr;
+    const uint8_t *count = nullptr; // real entries per row
+    double *vals = nullptr;
+    int64_t total = 0;              // slots (= slice_base[n_slices])
+};
+// P = P0 - omega D^-1 A P0: P0 has the block Q[i] in column agg[i]; pmap_own / pmap_in give, for every slot of A and every
+// entry of its in-lists, the slot of P's row the product feeds
+void launch_amg_prolongator(const DeviceMatrix &A, const int32_t *agg, const double *Q, double omega, const uint8_t *pmap_own,
+                            const uint8_t *pmap_in, const EllView &P, hipStream_t st);
+void launch_amg_ap(const DeviceMatrix &A, const EllView &P, const EllView &AP, hipStream_t st);
+// R (rows = aggregates) from P: entry q of row I is the transposed block (rrow[q], slot rk[q]) of P
+void launch_amg_restriction(const EllView &P, const int64_t *rptr, const int32_t *rrow, const uint8_t *rk, const EllView &R,
+                            hipStream_t st);
+// Ac = P^T (A P); diagonal slot first; coarse dofs without fine support get a unit diagonal
+void launch_amg_galerkin(const EllView &P, const EllView &AP, const int64_t *rptr, const int32_t *rrow, const uint8_t *rk,
+                         const EllView &Ac, hipStream_t st);
+
+} // namespace femshell

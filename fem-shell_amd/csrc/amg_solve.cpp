@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 namespace femshell {
 
@@ -143,26 +144,59 @@ int amg_setup(femshell_ctx *c)
         if (verbose) fprintf(stderr, "[femshell amg setup] level %d %-28s %.3f s\n", level, what, t - tl);
         tl = t;
     };
+    // the first coarsening step runs its numerics on the device unless FEMSHELL_AMG_SETUP=host (amg_device_setup.cpp)
+    static const bool host_only = getenv("FEMSHELL_AMG_SETUP") && std::string(getenv("FEMSHELL_AMG_SETUP")) == "host";
+    const bool keep_host = pl.nnz_blocks <= (int64_t)2000000; // inspection exports (tests) on small problems only
     Bsr A;
-    int rc = download_matrix(c, &A);
-    if (rc) return rc;
-    lap("download K", 0);
     std::vector<double> B;
     rigid_body_modes(pl.n_own, pl.xyz_local.data(), c->dmask_global.data() + pl.row_begin, &B);
-    const bool keep_host = A.nnzb() <= (int64_t)2000000; // inspection exports (tests) on small problems only
-
-    for (int l = 0;; l++) {
+    int rc = FEMSHELL_OK;
+    int first_level = 0;
+    if (!host_only && pl.n_own > opt.coarsest_nodes && opt.max_levels > 1) {
         H.levels.emplace_back(new AmgLevel());
-        AmgLevel &L = *H.levels.back();
+        AmgLevel &L0 = *H.levels.back();
+        L0.n = pl.n_own;
+        L0.n_pad = pl.n_pad;
+        L0.nnzb = pl.nnz_blocks;
+        rc = alloc_level_vectors(L0, true, kcycle, st);
+        if (rc) return rc;
+        double lam = 0.0;
+        rc = power_iteration(c, L0, c->dm, 30, &lam);
+        if (rc) return rc;
+        L0.lam = 1.1 * lam;
+        lap("power iteration", 0);
+        H.levels.emplace_back(new AmgLevel());
+        AmgLevel &L1 = *H.levels.back();
+        std::vector<double> Bc;
+        rc = amg_device_coarsen(c, L0, L1, B, L0.lam, keep_host, &A, &Bc, [&](const char *what) { lap(what, 0); });
+        if (rc) return rc;
+        L1.A_on_device = true;
+        if (keep_host) {
+            rc = download_matrix(c, &L0.hA);
+            if (rc) return rc;
+        }
+        B.swap(Bc);
+        first_level = 1;
+    } else {
+        rc = download_matrix(c, &A);
+        if (rc) return rc;
+        lap("download K", 0);
+    }
+
+    for (int l = first_level;; l++) {
+        if ((int)H.levels.size() <= l) H.levels.emplace_back(new AmgLevel());
+        AmgLevel &L = *H.levels[l];
         L.n = A.nr;
         L.n_pad = (A.nr + kSliceNodes - 1) / kSliceNodes * kSliceNodes;
         L.nnzb = A.nnzb();
         if (l > 0) {
-            SlicedEll S;
-            pack_sliced_ell(A, true, &S);
-            rc = upload_operator(L.A, S, S.n_pad, A.nnzb(), st);
-            if (rc) return rc;
-            FS_HIP(L.minv.alloc((size_t)S.n_slices * 21 * kSliceNodes));
+            if (!L.A_on_device) {
+                SlicedEll S;
+                pack_sliced_ell(A, true, &S);
+                rc = upload_operator(L.A, S, S.n_pad, A.nnzb(), st);
+                if (rc) return rc;
+            }
+            FS_HIP(L.minv.alloc((size_t)L.A.dm.n_slices * 21 * kSliceNodes));
             L.A.dm.minv = L.minv.p;
             L.A.dm.status = c->status.p;
             launch_block_jacobi(L.A.dm, st);
