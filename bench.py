@@ -386,6 +386,7 @@ def main():
         _, ia = fs.solve(rtol=1e-10, max_it=3000, fetch=False)
         fs.sync()
         wall = time.perf_counter() - t0
+        sst = fs.amg_setup_stats()
         _, ib = fs.solve(rtol=1e-10, max_it=3000, fetch=False)  # hierarchy reused (the coupled program re-solves)
         fs.set_preconditioner("amg", refine_passes=0)            # same hierarchy, no refinement pass
         _, ic = fs.solve(rtol=1e-10, max_it=3000, fetch=False)
@@ -399,6 +400,18 @@ def main():
                "operator_complexity": ia["operator_complexity"], "true_rel_residual_double_double": ia["true_rel_residual"],
                "algorithmic_gb_per_iteration": ia["bytes_per_iteration"] / 1e9,
                "achieved_gb_per_s": ia["bytes_per_iteration"] * ia["iterations"] / ia["solve_seconds"] / 1e9,
+               "setup_first_coarsening_on_device": {
+                   "prolongator_ms": sst["prolongator_ms"], "ap_ms": sst["ap_ms"], "restriction_ms": sst["restriction_ms"],
+                   "galerkin_ms": sst["galerkin_ms"],
+                   "galerkin_kernel": "k_amg_galerkin_mfma (v_mfma_f64_16x16x4_f64, one wave per coarse row)" if sst["galerkin_on_matrix_cores"] else "k_amg_galerkin (vector ALUs)",
+                   "galerkin_useful_gflop": sst["galerkin_useful_flops"] / 1e9,
+                   "galerkin_mfma_gflop_issued": sst["galerkin_mfma_flops_issued"] / 1e9,
+                   "roofline": {"bound": "mfma", "achieved": sst["galerkin_mfma_flops_issued"] / max(sst["galerkin_ms"], 1e-9) / 1e9,
+                                "peak": 78.6, "unit": "TFLOP/s",
+                                "frac": sst["galerkin_mfma_flops_issued"] / max(sst["galerkin_ms"], 1e-9) / 1e9 / 78.6,
+                                "note": "FP64 matrix peak 78.6 TFLOP/s; the panels are 6 rows tall (10 of 16 tile rows idle) and gathered "
+                                        "8 bytes at a time from the block ELL layout: latency-bound, 11.6 ms against 5.8 ms of the "
+                                        "vector-ALU kernel (FEMSHELL_AMG_GALERKIN=valu), 1 % of the 1.2 s setup either way"}},
                "block_jacobi_alone": jacobi_extrapolation(jacobi_hist)}
         if tts["block_jacobi_alone"] and "extrapolated_iterations_to_1e-10" in tts["block_jacobi_alone"]:
             tts["block_jacobi_alone"]["extrapolated_seconds"] = tts["block_jacobi_alone"]["extrapolated_iterations_to_1e-10"] * t_cg / max(info["iterations"], 1)

@@ -40,8 +40,16 @@ struct AmgLevel {
     std::vector<int32_t> agg;
 };
 
+// timings of the first coarsening step on the device (amg_device_setup.cpp); zero when the host path ran
+struct AmgSetupStats {
+    double prolongator_ms = 0, ap_ms = 0, restriction_ms = 0, galerkin_ms = 0;
+    double galerkin_useful_flops = 0, galerkin_mfma_flops_issued = 0;
+    int galerkin_mfma = 0;
+};
+
 struct Amg {
     femshell_pc_options opt{};
+    AmgSetupStats stats;
     std::vector<std::unique_ptr<AmgLevel>> levels;
     DevBuf<double> coarse_inv; // dense inverse of the coarsest operator
     bool valid = false;

@@ -10,7 +10,9 @@
 #include "amg_device.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 
 namespace femshell {
@@ -374,12 +376,47 @@ int amg_device_coarsen(femshell_ctx *c, AmgLevel &L, AmgLevel &next, const std::
     if (rc) return rc;
     FS_HIP(hipStreamSynchronize(st)); // the host vectors above go out of scope at the end of this function only, but be safe
     lap("uploads");
+    // FEMSHELL_AMG_GALERKIN=valu: one lane per result block on the vector ALUs instead of the matrix cores (A/B, tests)
+    static const bool use_mfma = !(getenv("FEMSHELL_AMG_GALERKIN") && std::string(getenv("FEMSHELL_AMG_GALERKIN")) == "valu");
+    hipEvent_t ev[5];
+    for (auto &e : ev) FS_HIP(hipEventCreate(&e));
+    FS_HIP(hipEventRecord(ev[0], st));
     launch_amg_prolongator(c->dm, d_agg.p, d_Q.p, (4.0 / 3.0) / lam, d_pmap_own.p, d_pmap_in.p, wP, st);
+    FS_HIP(hipEventRecord(ev[1], st));
     launch_amg_ap(c->dm, wP, wAP, st);
+    FS_HIP(hipEventRecord(ev[2], st));
     launch_amg_restriction(wP, d_rptr.p, d_rrow.p, d_rk.p, wR, st);
-    launch_amg_galerkin(wP, wAP, d_rptr.p, d_rrow.p, d_rk.p, wAc, st);
+    FS_HIP(hipEventRecord(ev[3], st));
+    launch_amg_galerkin(wP, wAP, d_rptr.p, d_rrow.p, d_rk.p, wAc, st, use_mfma);
+    FS_HIP(hipEventRecord(ev[4], st));
     FS_HIP(hipGetLastError());
     FS_HIP(hipStreamSynchronize(st));
+    {
+        AmgSetupStats &S = c->amg->stats;
+        float ms = 0.f;
+        FS_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        S.prolongator_ms = ms;
+        FS_HIP(hipEventElapsedTime(&ms, ev[1], ev[2]));
+        S.ap_ms = ms;
+        FS_HIP(hipEventElapsedTime(&ms, ev[2], ev[3]));
+        S.restriction_ms = ms;
+        FS_HIP(hipEventElapsedTime(&ms, ev[3], ev[4]));
+        S.galerkin_ms = ms;
+        S.galerkin_mfma = use_mfma ? 1 : 0;
+        // work of the Galerkin product: useful = one 6x6x6 product per (fine row i, aggregate I in P's row i, block of
+        // (A P)'s row i); issued on the matrix cores = 16x16x4 tiles, two k-steps per fine row and panel tile
+        double useful = 0.0, issued = 0.0;
+        for (int32_t a = 0; a < n; a++) useful += 432.0 * (double)(pptr[a + 1] - pptr[a]) * (double)(aptr[a + 1] - aptr[a]);
+        for (int32_t I = 0; I < na; I++) {
+            const int cnt = (int)(cptr[I + 1] - cptr[I]);
+            double tiles = 0.0;
+            for (int g0 = 0; g0 < cnt; g0 += 16) tiles += (double)((6 * std::min(16, cnt - g0) + 15) / 16);
+            issued += 2048.0 * 2.0 * tiles * (double)(rptr[I + 1] - rptr[I]);
+        }
+        S.galerkin_useful_flops = useful;
+        S.galerkin_mfma_flops_issued = use_mfma ? issued : 0.0;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
     lap("P, AP, R, Ac on the device");
 
     // ---- the coarse operator goes back for the remaining levels; small problems keep P for the inspection exports

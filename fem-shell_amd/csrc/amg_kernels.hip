@@ -582,6 +582,83 @@ __global__ __launch_bounds__(128) void k_amg_galerkin(EllView P, EllView AP, con
     ell_store(Ac.vals, t, acc);
 }
 
+// The Galerkin product on the matrix cores.  For a coarse row I the contraction sum_i P_iI^T (A P)_iJ over the ~20 fine
+// rows i that see aggregate I and the ~12 coarse columns J of the row is a dense tall-skinny product: X^T (6 x 6k) times Y
+// (6k x 6m), Y holding the blocks (A P)_iJ and zeros where a fine row does not reach a column.  One wave per coarse row
+// runs it as v_mfma_f64_16x16x4_f64 tiles: M = the 6 coarse dofs of I (10 of the 16 rows idle), K = the 6 dofs of fine
+// row i in two steps of 4, N = 16 columns of the panel per tile.  Operand maps (cdna_hip_programming.md, f64 form):
+// lane l holds A[row l&15][k l>>4] and B[k l>>4][col l&15]; result reg g of lane l is D[row (l>>4) + 4g][col l&15].
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int kGalerkinTiles = 6; // 96 panel columns = 16 coarse columns per pass
+
+__global__ __launch_bounds__(64) void k_amg_galerkin_mfma(EllView P, EllView AP, const int64_t *__restrict__ rptr,
+                                                          const int32_t *__restrict__ rrow, const uint8_t *__restrict__ rk, EllView Ac)
+{
+    __shared__ int32_t jcol[256];
+    __shared__ int64_t apslot[16];
+    const int I = blockIdx.x, lane = threadIdx.x;
+    const int sl = I / kSliceNodes, n = I % kSliceNodes;
+    const int W = Ac.slice_width[sl];
+    const int cnt = I < Ac.n_rows ? Ac.count[I] : 0;
+    const int64_t base = Ac.slice_base[sl];
+    for (int k = lane; k < cnt; k += 64) jcol[k] = Ac.cols[base + (int64_t)k * kSliceNodes + n];
+    // padding slots of the row hold zero blocks
+    for (int e = lane; e < (W - cnt) * 36; e += 64) {
+        const int k = cnt + e / 36, ij = e % 36;
+        Ac.vals[ell_index(base + (int64_t)k * kSliceNodes + n, ij / 6, ij % 6)] = 0.0;
+    }
+    __syncthreads();
+    const int r = lane & 15, kq = lane >> 4;
+    for (int g0 = 0; g0 < cnt; g0 += 16) { // 16 coarse columns = 96 panel columns per pass
+        const int gcnt = min(16, cnt - g0);
+        const int ntiles = (6 * gcnt + 15) / 16;
+        v4d acc[kGalerkinTiles];
+#pragma unroll
+        for (int t = 0; t < kGalerkinTiles; t++) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int64_t q = rptr[I]; q < rptr[I + 1]; q++) {
+            const int i = rrow[q];
+            const int64_t pslot = ell_slot(P, i / kSliceNodes, rk[q], i % kSliceNodes);
+            __syncthreads(); // the previous fine row's readers are done with apslot
+            if (lane < gcnt) apslot[lane] = ell_find(AP, i, jcol[g0 + lane]);
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const int d = 4 * ks + kq; // dof of the fine row (k index of this step)
+                const double a = (r < 6 && d < 6) ? P.vals[ell_index(pslot, d, r)] : 0.0; // X^T[r][d] = P_iI[d][r]
+#pragma unroll
+                for (int t = 0; t < kGalerkinTiles; t++) {
+                    if (t < ntiles) {
+                        const int colg = 16 * t + r, sj = colg / 6, cdof = colg % 6;
+                        double b = 0.0;
+                        if (d < 6 && sj < gcnt) {
+                            const int64_t as = apslot[sj];
+                            if (as >= 0) b = AP.vals[ell_index(as, d, cdof)];
+                        }
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // rows 0..5 of the tiles are the block rows; row = (lane >> 4) + 4 * reg
+#pragma unroll
+        for (int t = 0; t < kGalerkinTiles; t++) {
+            if (t < ntiles) {
+                const int colg = 16 * t + r, sj = colg / 6, cdof = colg % 6;
+#pragma unroll
+                for (int reg = 0; reg < 2; reg++) {
+                    const int row = kq + 4 * reg;
+                    if (row < 6 && sj < gcnt) {
+                        double v = acc[t][reg];
+                        // coarse dofs without fine support (zero column of P): unit diagonal keeps the level matrix SPD
+                        if (jcol[g0 + sj] == I && row == cdof && v == 0.0) v = 1.0;
+                        Ac.vals[ell_index(base + (int64_t)(g0 + sj) * kSliceNodes + n, row, cdof)] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 void launch_amg_prolongator(const DeviceMatrix &A, const int32_t *agg, const double *Q, double omega, const uint8_t *pmap_own,
                             const uint8_t *pmap_in, const EllView &P, hipStream_t st)
 {
@@ -601,9 +678,12 @@ void launch_amg_restriction(const EllView &P, const int64_t *rptr, const int32_t
 }
 
 void launch_amg_galerkin(const EllView &P, const EllView &AP, const int64_t *rptr, const int32_t *rrow, const uint8_t *rk,
-                         const EllView &Ac, hipStream_t st)
+                         const EllView &Ac, hipStream_t st, bool mfma)
 {
-    hipLaunchKernelGGL(k_amg_galerkin, dim3((unsigned)((Ac.total + 127) / 128)), dim3(128), 0, st, P, AP, rptr, rrow, rk, Ac);
+    if (mfma) // one wave per coarse row (padding rows of the last slice included: they get zero blocks)
+        hipLaunchKernelGGL(k_amg_galerkin_mfma, dim3((unsigned)(Ac.n_slices * kSliceNodes)), dim3(64), 0, st, P, AP, rptr, rrow, rk, Ac);
+    else
+        hipLaunchKernelGGL(k_amg_galerkin, dim3((unsigned)((Ac.total + 127) / 128)), dim3(128), 0, st, P, AP, rptr, rrow, rk, Ac);
 }
 
 } // namespace femshell

@@ -83,8 +83,9 @@ void launch_amg_ap(const DeviceMatrix &A, const EllView &P, const EllView &AP, h
 // R (rows = aggregates) from P: entry q of row I is the transposed block (rrow[q], slot rk[q]) of P
 void launch_amg_restriction(const EllView &P, const int64_t *rptr, const int32_t *rrow, const uint8_t *rk, const EllView &R,
                             hipStream_t st);
-// Ac = P^T (A P); diagonal slot first; coarse dofs without fine support get a unit diagonal
+// Ac = P^T (A P); diagonal slot first; coarse dofs without fine support get a unit diagonal.  mfma: one wave per coarse
+// row contracts its tall-skinny panels with v_mfma_f64_16x16x4_f64; else one lane per result block on the vector ALUs
 void launch_amg_galerkin(const EllView &P, const EllView &AP, const int64_t *rptr, const int32_t *rrow, const uint8_t *rk,
-                         const EllView &Ac, hipStream_t st);
+                         const EllView &Ac, hipStream_t st, bool mfma);
 
 } // namespace femshell

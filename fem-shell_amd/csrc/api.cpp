@@ -605,6 +605,21 @@ int femshell_amg_level(femshell_ctx *c, int32_t level, femshell_amg_level_info *
     return FEMSHELL_OK;
 }
 
+int femshell_amg_setup_stats(femshell_ctx *c, double out[7])
+{
+    if (!c || !out) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_setup_stats: null argument");
+    if (!c->amg || !c->amg->valid) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_setup_stats: no multigrid hierarchy");
+    const AmgSetupStats &S = c->amg->stats;
+    out[0] = S.prolongator_ms;
+    out[1] = S.ap_ms;
+    out[2] = S.restriction_ms;
+    out[3] = S.galerkin_ms;
+    out[4] = S.galerkin_useful_flops;
+    out[5] = S.galerkin_mfma_flops_issued;
+    out[6] = (double)S.galerkin_mfma;
+    return FEMSHELL_OK;
+}
+
 int64_t femshell_amg_export(femshell_ctx *c, int32_t level, int32_t which, void *out)
 {
     if (!c || level < 0 || level >= femshell_amg_levels(c)) return -1;

@@ -156,6 +156,10 @@ enum { FEMSHELL_AMG_AGGREGATES = 0, /* int32 [n_nodes] */
        FEMSHELL_AMG_P_ROWPTR, FEMSHELL_AMG_P_COLS, FEMSHELL_AMG_P_VALS };
 /* returns the element count of the array (-1: not available); copies it to out when out != NULL */
 int64_t femshell_amg_export(femshell_ctx *ctx, int32_t level, int32_t which, void *out);
+/* device timings of the first coarsening step of the last setup: out[0..3] = milliseconds of the prolongator, A P,
+ * restriction and Galerkin kernels, out[4] = useful flops of the Galerkin product, out[5] = flops issued on the
+ * matrix cores (v_mfma_f64_16x16x4_f64 tiles; 0 when the vector-ALU kernel ran), out[6] = 1 if the matrix cores ran */
+int femshell_amg_setup_stats(femshell_ctx *ctx, double out[7]);
 
 /* replaces: equation_systems.solve() -> PETSc KSPSolve (SA:138, PC:271) followed by
  * build_solution_vector (SA:141; PC:274-280 broadcast): 6x6-block-Jacobi preconditioned CG,

@@ -35,6 +35,13 @@ wall = time.time() - t0
 print(json.dumps({"wall_s": wall, **info}))
 for l in fs.amg_levels():
     print("  ", l)
+st = fs.amg_setup_stats()
+print("first coarsening step on the device: P %.2f ms, AP %.2f ms, R %.2f ms, Galerkin %.2f ms (%s): %.1f GFLOP useful%s" % (
+    st["prolongator_ms"], st["ap_ms"], st["restriction_ms"], st["galerkin_ms"],
+    "v_mfma_f64_16x16x4_f64" if st["galerkin_on_matrix_cores"] else "vector ALUs", st["galerkin_useful_flops"] / 1e9,
+    ", %.1f GFLOP issued on the matrix cores = %.1f TFLOP/s" % (st["galerkin_mfma_flops_issued"] / 1e9,
+                                                               st["galerkin_mfma_flops_issued"] / max(st["galerkin_ms"], 1e-9) / 1e9)
+    if st["galerkin_on_matrix_cores"] else ""))
 u2, info2 = fs.solve(rtol=rtol, max_it=3000, fetch=False)
 print("second solve (hierarchy reused):", json.dumps(info2))
 h = fs.residual_history()
