@@ -438,3 +438,27 @@ def amg_host_pack(rowptr, colidx, vals, diag_first):
     L.femshell_amg_host_pack(n, _i(rowptr), _i(colidx), _d(vals), int(diag_first), _i(sw),
                              sb.ctypes.data_as(C.POINTER(C.c_int64)), _i(cols), _d(ev))
     return sw, sb, cols, ev
+
+
+def amg_host_pack_sym(rowptr, colidx, vals):
+    """Symmetric-storage image of a square BSR matrix: dict of the ELL arrays and the in-lists."""
+    L = load_library()
+    i32, i64, dbl = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double)
+    L.femshell_amg_host_pack_sym.argtypes = [C.c_int32, i32, i32, dbl, i32, i64, i32, dbl, i32, i64, i32, i32, i64]
+    L.femshell_amg_host_pack_sym.restype = C.c_int64
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    n = len(rowptr) - 1
+    in_total = C.c_int64()
+    total = L.femshell_amg_host_pack_sym(n, _i(rowptr), _i(colidx), _d(vals), None, None, None, None, None, None, None, None,
+                                         C.byref(in_total))
+    ns = (n + 31) // 32
+    out = {"slice_width": np.zeros(ns, np.int32), "slice_base": np.zeros(ns + 1, np.int64), "cols": np.zeros(total, np.int32),
+           "vals": np.zeros(total * 36), "in_width": np.zeros(ns, np.int32), "in_base": np.zeros(ns + 1, np.int64),
+           "in_slots": np.zeros(in_total.value, np.int32), "in_rows": np.zeros(in_total.value, np.int32)}
+    p64 = lambda a: a.ctypes.data_as(i64)  # noqa: E731
+    L.femshell_amg_host_pack_sym(n, _i(rowptr), _i(colidx), _d(vals), _i(out["slice_width"]), p64(out["slice_base"]),
+                                 _i(out["cols"]), _d(out["vals"]), _i(out["in_width"]), p64(out["in_base"]),
+                                 _i(out["in_slots"]), _i(out["in_rows"]), C.byref(in_total))
+    return out

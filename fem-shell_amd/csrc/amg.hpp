@@ -16,7 +16,10 @@
 //     iteration on the device; coarsest level: explicit dense inverse
 //   * cycles: V, or K (two flexible-CG steps per coarse level, Notay & Vassilevski 2008) -- the 4th-order bending
 //     part loses a factor of about 2.3 in iterations per level with V cycles, the K cycle keeps the two-grid rate
-// The setup's sparse algebra (this file, amg_setup.cpp) runs on the host once per matrix; the cycle runs on the
+// Setup: the first coarsening step computes its numbers on the device from K where it lies (amg_device_setup.cpp: the
+// host does the integer work on the block graph, kernels fill P, A P, R and the Galerkin operator -- the latter on the
+// matrix cores); the remaining, nine times smaller levels use the host algebra of this file (amg_setup.cpp), which also
+// serves FEMSHELL_AMG_SETUP=host.  Level operators are stored like K: diagonal + upper blocks.  The cycle runs on the
 // device (amg_kernels.hip, amg_solve.cpp).
 #pragma once
 
@@ -91,5 +94,21 @@ struct SlicedEll {
     ValueArray vals;
 };
 void pack_sliced_ell(const Bsr &A, bool diag_first, SlicedEll *out);
+
+// symmetric storage of a square operator with a symmetric pattern (coarse level matrices): the diagonal block in slot
+// 0 and the blocks (a, c) with c > a; the in-lists tell row c which stored blocks (a, c) act on it through their
+// transpose (plan.hpp describes the layout; k_spmv_sym / k_sym_gather multiply with it)
+struct SlicedEllSym : SlicedEll {
+    int32_t max_in_width = 0;
+    std::vector<int32_t> in_width;
+    std::vector<int64_t> in_base;
+    std::vector<int32_t> in_slots, in_rows;
+};
+void pack_sliced_ell_sym(const Bsr &A, SlicedEllSym *out);
+// in-lists of a diagonal-first upper pattern given as ELL arrays (rows kept their blocks (a, c >= a) only)
+void build_in_lists(int32_t n_rows, const std::vector<int32_t> &slice_width, const std::vector<int64_t> &slice_base,
+                    const std::vector<int32_t> &cols, const std::vector<uint8_t> &count, SlicedEllSym *out);
+// A += strict upper part transposed (A holds the diagonal and upper blocks of a symmetric matrix): full BSR
+void mirror_upper(Bsr *A);
 
 } // namespace femshell

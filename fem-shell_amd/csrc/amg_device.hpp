@@ -15,7 +15,11 @@ struct AmgOperator {
     DevBuf<int32_t> slice_width, cols;
     DevBuf<int64_t> slice_base;
     DevBuf<double> vals;
-    DeviceMatrix dm{};      // the view k_spmv / k_block_jacobi take
+    // symmetric storage (square level operators): in-lists and the transposed products beside the slots
+    DevBuf<int32_t> in_width, in_slots, in_rows;
+    DevBuf<int64_t> in_base;
+    DevBuf<double> tbuf;
+    DeviceMatrix dm{};      // the view k_spmv / k_spmv_sym / k_block_jacobi take
     int64_t nnzb = 0;       // real blocks
     int32_t n_cols_pad = 0; // padded block columns = nodes of the input vector
 };
@@ -57,6 +61,11 @@ struct Amg {
 };
 
 void amg_default_options(femshell_pc_options *o);
+// symmetric storage of the coarse level operators (FEMSHELL_AMG_COARSE_SYM=1; default: full storage, measured faster --
+// the coarse products are launch- and latency-bound, and the lane-per-node kernel has a sixth of the lanes)
+bool coarse_symmetric_storage();
+// in-lists of a symmetric-storage operator into HBM and into op.dm (the slot arrays of op are in place already)
+int attach_in_lists(AmgOperator &op, const SlicedEllSym &S, int64_t total_slots, hipStream_t st);
 int amg_setup(femshell_ctx *c);
 // z = M(r): one multigrid cycle on the context's stream (all launches are no-ops once gate->done != 0)
 int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate);

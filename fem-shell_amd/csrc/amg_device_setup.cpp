@@ -318,7 +318,9 @@ int amg_device_coarsen(femshell_ctx *c, AmgLevel &L, AmgLevel &next, const std::
                 rk[(size_t)d] = (uint8_t)(q - pptr[a]);
             }
     }
-    // A_c: per aggregate the union of the A P rows of its fine rows
+    // A_c: per aggregate the union of the A P rows of its fine rows (symmetric storage: columns >= the row only; the
+    // coarse operator is symmetric, the cycle applies the stored blocks to both rows)
+    const bool sym_coarse = coarse_symmetric_storage();
     std::vector<int64_t> cptr((size_t)na + 1, 0);
     std::vector<int32_t> ccol;
     {
@@ -333,6 +335,7 @@ int amg_device_coarsen(femshell_ctx *c, AmgLevel &L, AmgLevel &next, const std::
                 }
                 std::sort(tmp.begin(), tmp.end());
                 tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                if (sym_coarse) tmp.erase(tmp.begin(), std::lower_bound(tmp.begin(), tmp.end(), (int32_t)I)); // diagonal and upper blocks
                 rows[(size_t)I] = tmp;
             }
         }, 64);
@@ -425,6 +428,7 @@ int amg_device_coarsen(femshell_ctx *c, AmgLevel &L, AmgLevel &next, const std::
         rc = download_vals(vAc, &h, st);
         if (rc) return rc;
         ell_to_bsr(eAc, h.data(), na, Ac_host);
+        if (sym_coarse) mirror_upper(Ac_host); // the host algorithms of the next levels take the full matrix
         if (keep_host) {
             rc = download_vals(vP, &h, st);
             if (rc) return rc;
@@ -436,6 +440,12 @@ int amg_device_coarsen(femshell_ctx *c, AmgLevel &L, AmgLevel &next, const std::
     adopt(L.P, eP, dP, vP, nc_pad);
     adopt(L.R, eR, dR, vR, eP.n_pad);
     adopt(next.A, eAc, dAc, vAc, nc_pad);
+    if (sym_coarse) {
+        SlicedEllSym S;
+        build_in_lists(na, eAc.slice_width, eAc.slice_base, eAc.cols, eAc.count, &S);
+        rc = attach_in_lists(next.A, S, eAc.total(), st);
+        if (rc) return rc;
+    }
     lap("download of the coarse operator");
     return FEMSHELL_OK;
 }

@@ -36,6 +36,9 @@ void launch_cheb_start(const DeviceMatrix &m, const double *rin, double *d, doub
     hipLaunchKernelGGL(k_cheb_start, dim3(slice_grid(m)), dim3(192), 0, st, m, rin, d, x, inv_theta, accumulate ? 1 : 0, gate);
 }
 
+// (kGather: symmetric storage, q holds the direct part of A d only -- launch_spmv_direct -- and the row adds the
+// transposed products of its in-list here, as k_cg_update<true> does for the CG iteration)
+template <bool kGather>
 __global__ __launch_bounds__(192) void k_cheb_step(DeviceMatrix m, const double *rin, const double *__restrict__ q,
                                                    double *rout, double *__restrict__ d, double *__restrict__ x, double a,
                                                    double c, const CgScalars *gate)
@@ -47,7 +50,16 @@ __global__ __launch_bounds__(192) void k_cheb_step(DeviceMatrix m, const double 
         const int sl = w.s;
         const int64_t row = (int64_t)sl * kSliceRows + t;
         const MinvRow mr = load_minv(m, sl, t);
-        const double rn = rin[row] - q[row];
+        double qv = q[row];
+        if (kGather) {
+            const int Wi = m.in_width[sl], n = t / 6, j = t % 6;
+            const int64_t ib = m.in_base[sl];
+            for (int k = 0; k < Wi; k++) {
+                const int32_t slot = m.in_slots[ib + (int64_t)k * kSliceNodes + n];
+                if (slot >= 0) qv += m.tbuf[(int64_t)slot * 6 + j];
+            }
+        }
+        const double rn = rin[row] - qv;
         const double dv = d[row], xv = x[row];
         rout[row] = rn;
         __syncthreads();
@@ -60,9 +72,10 @@ __global__ __launch_bounds__(192) void k_cheb_step(DeviceMatrix m, const double 
 }
 
 void launch_cheb_step(const DeviceMatrix &m, const double *rin, const double *q, double *rout, double *d, double *x,
-                      double a, double c, const CgScalars *gate, hipStream_t st)
+                      double a, double c, const CgScalars *gate, hipStream_t st, bool gather)
 {
-    hipLaunchKernelGGL(k_cheb_step, dim3(slice_grid(m)), dim3(192), 0, st, m, rin, q, rout, d, x, a, c, gate);
+    if (gather) hipLaunchKernelGGL(k_cheb_step<true>, dim3(slice_grid(m)), dim3(192), 0, st, m, rin, q, rout, d, x, a, c, gate);
+    else hipLaunchKernelGGL(k_cheb_step<false>, dim3(slice_grid(m)), dim3(192), 0, st, m, rin, q, rout, d, x, a, c, gate);
 }
 
 // ---- power iteration ---------------------------------------------------------------------------------------

@@ -16,8 +16,9 @@ namespace femshell {
 // every kernel is a no-op once gate->done != 0 (gate may be null)
 void launch_cheb_start(const DeviceMatrix &m, const double *rin, double *d, double *x, double inv_theta, bool accumulate,
                        const CgScalars *gate, hipStream_t st);
+// (gather: symmetric storage, q is the direct part of A d from launch_spmv_direct; the kernel collects the transposed products)
 void launch_cheb_step(const DeviceMatrix &m, const double *rin, const double *q, double *rout, double *d, double *x,
-                      double a, double c, const CgScalars *gate, hipStream_t st);
+                      double a, double c, const CgScalars *gate, hipStream_t st, bool gather = false);
 
 // power iteration for lambda_max(D^-1 A): z = D^-1 q with the partial sums of z.z (one per workgroup of slice_grid(m))
 void launch_minv_apply_norm(const DeviceMatrix &m, const double *q, double *z, double *partials, hipStream_t st);

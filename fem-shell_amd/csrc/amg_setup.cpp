@@ -520,4 +520,111 @@ void pack_sliced_ell(const Bsr &A, bool diag_first, SlicedEll *out)
     }, 8);
 }
 
+void build_in_lists(int32_t n_rows, const std::vector<int32_t> &slice_width, const std::vector<int64_t> &slice_base,
+                    const std::vector<int32_t> &cols, const std::vector<uint8_t> &count, SlicedEllSym *out)
+{
+    SlicedEllSym &S = *out;
+    const int32_t n_slices = (int32_t)slice_width.size();
+    const int32_t n_pad = n_slices * kSliceNodes;
+    std::vector<int32_t> cnt((size_t)n_pad, 0);
+    auto for_each_offdiag = [&](const std::function<void(int32_t a, int32_t c, int64_t slot)> &f) {
+        for (int32_t s = 0; s < n_slices; s++)
+            for (int k = 1; k < slice_width[s]; k++)
+                for (int n = 0; n < kSliceNodes; n++) {
+                    const int32_t a = s * kSliceNodes + n;
+                    if (a >= n_rows || k >= count[a]) continue;
+                    const int64_t slot = slice_base[s] + (int64_t)k * kSliceNodes + n;
+                    f(a, cols[(size_t)slot], slot);
+                }
+    };
+    for_each_offdiag([&](int32_t, int32_t c, int64_t) { cnt[c]++; });
+    S.in_width.assign((size_t)n_slices, 0);
+    S.in_base.assign((size_t)n_slices + 1, 0);
+    S.max_in_width = 0;
+    for (int32_t s = 0; s < n_slices; s++) {
+        int w = 0;
+        for (int n = 0; n < kSliceNodes; n++) w = std::max(w, cnt[(size_t)s * kSliceNodes + n]);
+        S.in_width[s] = w;
+        S.max_in_width = std::max(S.max_in_width, w);
+        S.in_base[s + 1] = S.in_base[s] + (int64_t)w * kSliceNodes;
+    }
+    S.in_slots.assign((size_t)S.in_base[n_slices], -1);
+    S.in_rows.assign((size_t)S.in_base[n_slices], 0);
+    std::fill(cnt.begin(), cnt.end(), 0);
+    for_each_offdiag([&](int32_t a, int32_t c, int64_t slot) { // ascending slot index: a fixed order of the sums
+        const size_t e = (size_t)(S.in_base[c / kSliceNodes] + (int64_t)cnt[c] * kSliceNodes + c % kSliceNodes);
+        S.in_slots[e] = (int32_t)slot;
+        S.in_rows[e] = a;
+        cnt[c]++;
+    });
+}
+
+void pack_sliced_ell_sym(const Bsr &A, SlicedEllSym *out)
+{
+    // the upper part as a matrix of its own, packed diagonal first
+    Bsr U;
+    U.nr = A.nr;
+    U.nc = A.nc;
+    U.ptr.assign((size_t)A.nr + 1, 0);
+    for (int32_t a = 0; a < A.nr; a++) {
+        int64_t c = 0;
+        for (int64_t q = A.ptr[a]; q < A.ptr[a + 1]; q++) c += A.col[q] >= a;
+        U.ptr[a + 1] = U.ptr[a] + c;
+    }
+    U.col.resize((size_t)U.ptr[A.nr]);
+    U.val.resize((size_t)U.ptr[A.nr] * 36);
+    parallel_chunks(A.nr, [&](int64_t a0, int64_t a1) {
+        for (int64_t a = a0; a < a1; a++) {
+            int64_t w = U.ptr[a];
+            for (int64_t q = A.ptr[a]; q < A.ptr[a + 1]; q++)
+                if (A.col[q] >= a) {
+                    U.col[(size_t)w] = A.col[q];
+                    std::memcpy(&U.val[(size_t)w * 36], &A.val[(size_t)q * 36], 36 * sizeof(double));
+                    w++;
+                }
+        }
+    });
+    SlicedEll base;
+    pack_sliced_ell(U, true, &base);
+    static_cast<SlicedEll &>(*out) = std::move(base);
+    std::vector<uint8_t> count((size_t)out->n_pad, 0);
+    for (int32_t a = 0; a < A.nr; a++) count[a] = (uint8_t)std::min<int64_t>(255, U.ptr[a + 1] - U.ptr[a]);
+    build_in_lists(A.nr, out->slice_width, out->slice_base, out->cols, count, out);
+}
+
+void mirror_upper(Bsr *Aio)
+{
+    Bsr T;
+    bsr_transpose(*Aio, &T);
+    Bsr &U = *Aio;
+    Bsr F;
+    F.nr = U.nr;
+    F.nc = U.nc;
+    F.ptr.assign((size_t)U.nr + 1, 0);
+    for (int32_t a = 0; a < U.nr; a++) {
+        int64_t lower = 0;
+        for (int64_t q = T.ptr[a]; q < T.ptr[a + 1]; q++) lower += T.col[q] < a; // (c, a) stored with c < a
+        F.ptr[a + 1] = F.ptr[a] + lower + (U.ptr[a + 1] - U.ptr[a]);
+    }
+    F.col.resize((size_t)F.ptr[U.nr]);
+    F.val.resize((size_t)F.ptr[U.nr] * 36);
+    parallel_chunks(U.nr, [&](int64_t a0, int64_t a1) {
+        for (int64_t a = a0; a < a1; a++) {
+            int64_t w = F.ptr[a];
+            for (int64_t q = T.ptr[a]; q < T.ptr[a + 1]; q++) // ascending lower columns (transpose rows are ascending)
+                if (T.col[q] < a) {
+                    F.col[(size_t)w] = T.col[q];
+                    std::memcpy(&F.val[(size_t)w * 36], &T.val[(size_t)q * 36], 36 * sizeof(double));
+                    w++;
+                }
+            for (int64_t q = U.ptr[a]; q < U.ptr[a + 1]; q++) {
+                F.col[(size_t)w] = U.col[q];
+                std::memcpy(&F.val[(size_t)w * 36], &U.val[(size_t)q * 36], 36 * sizeof(double));
+                w++;
+            }
+        }
+    });
+    *Aio = std::move(F);
+}
+
 } // namespace femshell

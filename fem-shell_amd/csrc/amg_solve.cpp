@@ -42,6 +42,29 @@ int upload_operator(AmgOperator &op, const SlicedEll &S, int32_t n_cols_pad, int
     return FEMSHELL_OK;
 }
 
+} // namespace
+
+int attach_in_lists(AmgOperator &op, const SlicedEllSym &S, int64_t total_slots, hipStream_t st)
+{
+    FS_HIP(op.in_width.upload(S.in_width, st));
+    FS_HIP(op.in_base.upload(S.in_base, st));
+    FS_HIP(op.in_slots.upload(S.in_slots, st));
+    FS_HIP(op.in_rows.upload(S.in_rows, st));
+    FS_HIP(op.tbuf.alloc((size_t)total_slots * 6));
+    FS_HIP(op.tbuf.zero(st));
+    FS_HIP(hipStreamSynchronize(st));
+    op.dm.symmetric = 1;
+    op.dm.max_in_width = S.max_in_width;
+    op.dm.in_width = op.in_width.p;
+    op.dm.in_base = op.in_base.p;
+    op.dm.in_slots = op.in_slots.p;
+    op.dm.in_rows = op.in_rows.p;
+    op.dm.tbuf = op.tbuf.p;
+    return FEMSHELL_OK;
+}
+
+namespace {
+
 // lambda_max(D^-1 A) of a level by power iteration on the device (x <- D^-1 A x, ratio of consecutive norms)
 int power_iteration(femshell_ctx *c, AmgLevel &L, const DeviceMatrix &A, int iterations, double *lam_out)
 {
@@ -108,6 +131,12 @@ int alloc_level_vectors(AmgLevel &L, bool top, bool kcycle, hipStream_t st)
 }
 
 } // namespace
+
+bool coarse_symmetric_storage()
+{
+    const char *e = getenv("FEMSHELL_AMG_COARSE_SYM");
+    return e && atoi(e) != 0 && default_symmetric_storage();
+}
 
 void amg_default_options(femshell_pc_options *o)
 {
@@ -191,9 +220,17 @@ int amg_setup(femshell_ctx *c)
         L.nnzb = A.nnzb();
         if (l > 0) {
             if (!L.A_on_device) {
-                SlicedEll S;
-                pack_sliced_ell(A, true, &S);
-                rc = upload_operator(L.A, S, S.n_pad, A.nnzb(), st);
+                // the level operators are symmetric: diagonal and upper blocks only, like K (FEMSHELL_SYMMETRIC=0: full)
+                if (coarse_symmetric_storage()) {
+                    SlicedEllSym S;
+                    pack_sliced_ell_sym(A, &S);
+                    rc = upload_operator(L.A, S, S.n_pad, (A.nnzb() + A.nr) / 2, st); // stored: diagonal + one block per pair
+                    if (!rc) rc = attach_in_lists(L.A, S, S.slice_base.back(), st);
+                } else {
+                    SlicedEll S;
+                    pack_sliced_ell(A, true, &S);
+                    rc = upload_operator(L.A, S, S.n_pad, A.nnzb(), st);
+                }
                 if (rc) return rc;
             }
             FS_HIP(L.minv.alloc((size_t)L.A.dm.n_slices * 21 * kSliceNodes));
@@ -305,8 +342,13 @@ struct Cycle {
         }
         launch_cheb_start(A, rcur, L.d.p, x, L.inv_theta, !zero_guess, gate, st);
         for (size_t k = 0; k < L.cheb_a.size(); k++) {
-            launch_spmv(A, L.d.p, L.q.p, nullptr, gate, st);
-            launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st);
+            if (A.symmetric) { // first phase of the product; the step kernel collects the transposed products
+                launch_spmv_direct(A, L.d.p, L.q.p, nullptr, gate, st);
+                launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, true);
+            } else {
+                launch_spmv(A, L.d.p, L.q.p, nullptr, gate, st);
+                launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st);
+            }
             rcur = L.r.p;
         }
     }
@@ -487,9 +529,11 @@ double amg_bytes_per_iteration(const femshell_ctx *c)
         double a_products = 2.0 * deg;
         const bool k_here = H.opt.cycle == FEMSHELL_CYCLE_K && l >= 1;
         const double vec = 48.0 * L.n;
-        double per_visit = a_products * (292.0 * (double)L.nnzb + 2.0 * vec) + 292.0 * (double)(L.P.nnzb + L.R.nnzb) + 4.0 * vec +
+        // blocks a product of the level operator streams (symmetric storage: the stored ones)
+        const double blocks = l == 0 ? (double)c->plan.stored_blocks : (double)L.A.nnzb;
+        double per_visit = a_products * (292.0 * blocks + 2.0 * vec) + 292.0 * (double)(L.P.nnzb + L.R.nnzb) + 4.0 * vec +
                            (2.0 * deg) * (5.0 * vec + 168.0 * L.n);
-        if (k_here) per_visit += 292.0 * (double)L.nnzb + 8.0 * vec;
+        if (k_here) per_visit += 292.0 * blocks + 8.0 * vec;
         bytes += visits[l] * per_visit;
         const bool next_k = H.opt.cycle == FEMSHELL_CYCLE_K && l + 2 < H.levels.size();
         visits[l + 1] = visits[l] * (next_k ? 2.0 : 1.0);

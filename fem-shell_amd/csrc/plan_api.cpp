@@ -203,4 +203,25 @@ int64_t femshell_amg_host_pack(int32_t n_rows, const int32_t *rowptr, const int3
     return S.slice_base.back();
 }
 
+int64_t femshell_amg_host_pack_sym(int32_t n_rows, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                                   int32_t *slice_width, int64_t *slice_base, int32_t *cols, double *ell_vals,
+                                   int32_t *in_width, int64_t *in_base, int32_t *in_slots, int32_t *in_rows, int64_t *in_total)
+{
+    if (n_rows <= 0 || !rowptr || !colidx || !vals) return -1;
+    Bsr A;
+    to_bsr(n_rows, rowptr, colidx, vals, &A);
+    SlicedEllSym S;
+    pack_sliced_ell_sym(A, &S);
+    if (slice_width) std::memcpy(slice_width, S.slice_width.data(), S.slice_width.size() * sizeof(int32_t));
+    if (slice_base) std::memcpy(slice_base, S.slice_base.data(), S.slice_base.size() * sizeof(int64_t));
+    if (cols) std::memcpy(cols, S.cols.data(), S.cols.size() * sizeof(int32_t));
+    if (ell_vals) std::memcpy(ell_vals, S.vals.data(), S.vals.size() * sizeof(double));
+    if (in_width) std::memcpy(in_width, S.in_width.data(), S.in_width.size() * sizeof(int32_t));
+    if (in_base) std::memcpy(in_base, S.in_base.data(), S.in_base.size() * sizeof(int64_t));
+    if (in_slots) std::memcpy(in_slots, S.in_slots.data(), S.in_slots.size() * sizeof(int32_t));
+    if (in_rows) std::memcpy(in_rows, S.in_rows.data(), S.in_rows.size() * sizeof(int32_t));
+    if (in_total) *in_total = (int64_t)S.in_slots.size();
+    return S.slice_base.back();
+}
+
 } // extern "C"

@@ -91,6 +91,13 @@ int femshell_amg_host_dense_inverse(int32_t n_nodes, const int32_t *rowptr, cons
 int64_t femshell_amg_host_pack(int32_t n_rows, const int32_t *rowptr, const int32_t *colidx, const double *vals,
                                int32_t diag_first, int32_t *slice_width, int64_t *slice_base, int32_t *cols, double *ell_vals);
 
+/* symmetric storage of a square operator (coarse multigrid levels): diagonal + upper blocks in the sliced ELL arrays and
+ * the in-lists of the transposed products; returns the total slots, *in_total receives the in-list entries; arrays may
+ * be NULL for a sizing call */
+int64_t femshell_amg_host_pack_sym(int32_t n_rows, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                                   int32_t *slice_width, int64_t *slice_base, int32_t *cols, double *ell_vals,
+                                   int32_t *in_width, int64_t *in_base, int32_t *in_slots, int32_t *in_rows, int64_t *in_total);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,3 +134,56 @@ def test_sliced_ell_image_of_a_level_operator(diag_first):
     y0 = oracle.spmv(rp, ci, vals, x[:n].ravel()).reshape(n, 6)
     assert np.abs(y[:n] - y0).max() <= 1e-13 * np.abs(y0).max()
     assert np.abs(y[n:]).max() == 0.0
+
+
+def test_symmetric_storage_image_of_a_coarse_operator():
+    """Coarse level operators are stored like K: diagonal + upper blocks, and per row the list of stored blocks that act on
+    it through their transpose.  Numpy model of the two phases of k_spmv_sym / k_sym_gather on the packed arrays against
+    the full product."""
+    ensure_built()
+    m, dm, rp, ci, vals, F = _problem("panel")
+    B = _binding().amg_host_rbm(m.xyz, dm)
+    h = _binding().amg_host_coarsen(rp, ci, vals, B, 2.5)
+    na = len(h["Ac_rowptr"]) - 1
+    Ac = _bsr(h["Ac_rowptr"], h["Ac_cols"], h["Ac_vals"], na)
+    S = _binding().amg_host_pack_sym(h["Ac_rowptr"].astype(np.int32), h["Ac_cols"], h["Ac_vals"])
+    n_pad = len(S["slice_width"]) * 32
+    x = np.zeros((n_pad, 6))
+    x[:na] = np.random.default_rng(2).standard_normal((na, 6))
+    y = np.zeros_like(x)
+    T = np.zeros((len(S["cols"]), 6))
+    stored = 0
+    for s in range(len(S["slice_width"])):
+        w, base = int(S["slice_width"][s]), int(S["slice_base"][s])
+        blk = S["vals"][base * 36:(base + w * 32) * 36].reshape(w, 3, 6, 32, 2)  # k, jp, i, n, jj
+        for k in range(w):
+            for n in range(32):
+                a = 32 * s + n
+                c = int(S["cols"][base + k * 32 + n])
+                Kb = blk[k, :, :, n, :].transpose(1, 0, 2).reshape(6, 6)  # [i][j = 2 jp + jj]
+                if k == 0:
+                    assert c == min(a, n_pad - 1)
+                elif c == a:
+                    assert not Kb.any()  # padding slot
+                    continue
+                else:
+                    assert c > a
+                    T[base + k * 32 + n] = Kb.T @ x[a]
+                    stored += 1
+                y[a] += Kb @ x[c]
+    for s in range(len(S["in_width"])):
+        for k in range(int(S["in_width"][s])):
+            for n in range(32):
+                e = int(S["in_base"][s]) + k * 32 + n
+                if S["in_slots"][e] >= 0:
+                    assert S["in_rows"][e] < 32 * s + n
+                    y[32 * s + n] += T[S["in_slots"][e]]
+    # the packed image is exactly symmetric (upper blocks mirrored): compare with the symmetrised operator
+    Ad = Ac.toarray()
+    blockmask = np.kron(np.triu(np.ones((na, na)), 1), np.ones((6, 6)))
+    diagmask = np.kron(np.eye(na), np.ones((6, 6)))
+    Asym = Ad * diagmask + Ad * blockmask + (Ad * blockmask).T
+    y0 = Asym @ x[:na].ravel()
+    assert np.abs(y[:na].ravel() - y0).max() <= 1e-12 * np.abs(y0).max()
+    assert stored == (Ac.tobsr((6, 6)).nnz // 36 - na) // 2
+    assert np.abs(Asym - Ad).max() <= 1e-10 * np.abs(Ad).max()  # the Galerkin operator is symmetric to rounding
