@@ -20,9 +20,12 @@ from .binding import (  # noqa: F401
     REF_DEFAULT,
     REF_DRILL_MAX,
     REF_Y21,
+    REORDER_MORTON,
+    REORDER_RCM,
     build_library,
     comm_unique_id,
     library_path,
     load_library,
     build_plan,
+    reorder_host,
 )

@@ -12,6 +12,8 @@ REF_Y21 = 0x1
 REF_DRILL_MAX = 0x2
 REASSEMBLE_EACH_SOLVE = 0x4
 REF_DEFAULT = REF_Y21 | REF_DRILL_MAX
+REORDER_MORTON = 0x10
+REORDER_RCM = 0x20
 
 KERNEL_ASSEMBLE, KERNEL_SPMV, KERNEL_CG_UPDATE, KERNEL_CG_DIRECTION = 0, 1, 2, 3
 
@@ -462,3 +464,20 @@ def amg_host_pack_sym(rowptr, colidx, vals):
                                  _i(out["cols"]), _d(out["vals"]), _i(out["in_width"]), p64(out["in_base"]),
                                  _i(out["in_slots"]), _i(out["in_rows"]), C.byref(in_total))
     return out
+
+
+def reorder_host(kind, xyz, tri=None, quad=None):
+    """perm[new index] = caller's node id of the library's optional renumbering ("morton" or "rcm")."""
+    L = load_library()
+    i32, dbl = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    L.femshell_reorder_host.argtypes = [C.c_int32, C.c_int32, dbl, C.c_int32, i32, C.c_int32, i32, i32]
+    L.femshell_reorder_host.restype = C.c_int
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    tri = np.zeros((0, 3), np.int32) if tri is None else np.ascontiguousarray(tri, dtype=np.int32)
+    quad = np.zeros((0, 4), np.int32) if quad is None else np.ascontiguousarray(quad, dtype=np.int32)
+    perm = np.zeros(len(xyz), np.int32)
+    rc = L.femshell_reorder_host({"morton": 0, "rcm": 1}[kind], len(xyz), _d(xyz), len(tri), _i(tri) if len(tri) else None,
+                                 len(quad), _i(quad) if len(quad) else None, _i(perm))
+    if rc:
+        raise FemShellError(-1, "femshell_reorder_host: invalid mesh")
+    return perm

@@ -3,6 +3,7 @@
 // runs in the kernels of kernels.hip; there is no CPU fallback anywhere in this library.
 #include "amg_device.hpp"
 #include "context.hpp"
+#include "reorder.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -81,8 +82,11 @@ int check_status(femshell_ctx *c, const char *what)
             snprintf(buf, sizeof buf, "%s: element %d failed", what, le);
         return set_err(FEMSHELL_ERR_MESH, buf);
     }
-    snprintf(buf, sizeof buf, "%s: diagonal block of node %d is not positive definite", what,
-             c->plan.row_begin + (-st - 1));
+    {
+        const int32_t node = c->plan.row_begin + (-st - 1);
+        snprintf(buf, sizeof buf, "%s: diagonal block of node %d is not positive definite", what,
+                 (!c->perm.empty() && node >= 0 && node < (int32_t)c->perm.size()) ? c->perm[node] : node);
+    }
     return set_err(FEMSHELL_ERR_BREAKDOWN, buf);
 }
 
@@ -313,6 +317,11 @@ int femshell_create(const femshell_config *cfg, femshell_ctx **out)
     c->mc.nu = nu;
     c->mc.g = (1.0 - nu) / 2.0;
     c->mc.t = t;
+    if (!(c->cfg.flags & (FEMSHELL_REORDER_MORTON | FEMSHELL_REORDER_RCM)))
+        if (const char *e = getenv("FEMSHELL_REORDER")) {
+            if (std::strcmp(e, "morton") == 0) c->cfg.flags |= FEMSHELL_REORDER_MORTON;
+            else if (std::strcmp(e, "rcm") == 0) c->cfg.flags |= FEMSHELL_REORDER_RCM;
+        }
     c->mc.flags = cfg->flags;
     c->mc.pad = 0;
     {
@@ -380,6 +389,30 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
         if (!std::isfinite(xyz[i])) return set_err(FEMSHELL_ERR_MESH, "femshell_set_mesh: non-finite coordinate");
     std::string e;
     c->have_mesh = false;
+    c->perm.clear();
+    c->iperm.clear();
+    std::vector<double> xyz_r;
+    std::vector<int32_t> tri_r, quad_r;
+    if ((c->cfg.flags & (FEMSHELL_REORDER_MORTON | FEMSHELL_REORDER_RCM)) && c->cfg.world_size == 1 && n_nodes > 0) {
+        for (int64_t q = 0; q < 3ll * n_tri; q++)
+            if (tri[q] < 0 || tri[q] >= n_nodes) return set_err(FEMSHELL_ERR_MESH, "femshell_set_mesh: triangle " + std::to_string(q / 3) + " references a node out of range");
+        for (int64_t q = 0; q < 4ll * n_quad; q++)
+            if (quad[q] < 0 || quad[q] >= n_nodes) return set_err(FEMSHELL_ERR_MESH, "femshell_set_mesh: quad " + std::to_string(q / 4) + " references a node out of range");
+        if (c->cfg.flags & FEMSHELL_REORDER_RCM) rcm_order(n_nodes, n_tri, tri, n_quad, quad, &c->perm);
+        else morton_order(n_nodes, xyz, &c->perm);
+        c->iperm.assign((size_t)n_nodes, 0);
+        for (int32_t i = 0; i < n_nodes; i++) c->iperm[c->perm[i]] = i;
+        xyz_r.resize((size_t)n_nodes * 3);
+        for (int32_t i = 0; i < n_nodes; i++)
+            for (int d = 0; d < 3; d++) xyz_r[3ull * i + d] = xyz[3ull * c->perm[i] + d];
+        tri_r.resize((size_t)n_tri * 3);
+        for (int64_t q = 0; q < 3ll * n_tri; q++) tri_r[(size_t)q] = c->iperm[tri[q]];
+        quad_r.resize((size_t)n_quad * 4);
+        for (int64_t q = 0; q < 4ll * n_quad; q++) quad_r[(size_t)q] = c->iperm[quad[q]];
+        xyz = xyz_r.data();
+        tri = tri_r.data();
+        quad = quad_r.data();
+    }
     if (!build_plan(n_nodes, xyz, n_tri, tri, n_quad, quad, c->cfg.rank, c->cfg.world_size, &c->plan, &e, default_symmetric_storage()))
         return set_err(FEMSHELL_ERR_MESH, "femshell_set_mesh: " + e);
     const Plan &p = c->plan;
@@ -508,7 +541,7 @@ int femshell_set_dirichlet(femshell_ctx *c, int32_t n, const int32_t *node_ids, 
         const int32_t a = node_ids ? node_ids[i] : i;
         if (a < 0 || a >= nn) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_dirichlet: node id out of range");
         if (mask6[i] & ~0x3Fu) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_dirichlet: mask has bits above dof 5");
-        m[a] |= mask6[i];
+        m[c->iperm.empty() ? a : c->iperm[a]] |= mask6[i];
     }
     int rc = select_device(c);
     if (rc) return rc;
@@ -531,7 +564,7 @@ int femshell_set_loads(femshell_ctx *c, int32_t n, const int32_t *node_ids, cons
         if (a < 0 || a >= nn) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_loads: node id out of range");
         for (int v = 0; v < 6; v++) {
             if (!std::isfinite(f6[6ll * i + v])) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_loads: non-finite load");
-            l[6ull * a + v] = f6[6ll * i + v];
+            l[6ull * (c->iperm.empty() ? a : c->iperm[a]) + v] = f6[6ll * i + v];
         }
     }
     int rc = select_device(c);
@@ -758,8 +791,15 @@ int femshell_get_solution(femshell_ctx *c, double *u_out)
     if (rc) return rc;
     const Plan &p = c->plan;
     if (!c->comm.active()) {
-        FS_HIP(hipMemcpyAsync(u_out, c->x.p, (size_t)p.n_own * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (c->perm.empty()) {
+            FS_HIP(hipMemcpyAsync(u_out, c->x.p, (size_t)p.n_own * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            FS_HIP(hipStreamSynchronize(c->stream));
+            return FEMSHELL_OK;
+        }
+        std::vector<double> h((size_t)p.n_own * 6); // internal numbering -> the caller's
+        FS_HIP(hipMemcpyAsync(h.data(), c->x.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         FS_HIP(hipStreamSynchronize(c->stream));
+        for (int32_t i = 0; i < p.n_own; i++) std::memcpy(u_out + 6ull * c->perm[i], &h[6ull * i], 6 * sizeof(double));
         return FEMSHELL_OK;
     }
     FS_HIP(c->ufull.alloc((size_t)p.n_nodes * 6));
@@ -823,9 +863,37 @@ int femshell_export_bsr(femshell_ctx *c, int32_t *rowptr, int32_t *colidx, doubl
     Bsr A;
     rc = download_matrix(c, &A);
     if (rc) return rc;
-    for (int32_t a = 0; a <= p.n_own; a++) rowptr[a] = (int32_t)A.ptr[a];
-    std::copy(A.col.begin(), A.col.end(), colidx);
-    std::copy(A.val.begin(), A.val.end(), vals);
+    if (c->perm.empty()) {
+        for (int32_t a = 0; a <= p.n_own; a++) rowptr[a] = (int32_t)A.ptr[a];
+        std::copy(A.col.begin(), A.col.end(), colidx);
+        std::copy(A.val.begin(), A.val.end(), vals);
+        return FEMSHELL_OK;
+    }
+    // internal numbering -> the caller's: rows in the caller's order, columns ascending in the caller's ids
+    if (F) {
+        std::vector<double> Fi(F, F + (size_t)p.n_own * 6);
+        for (int32_t i = 0; i < p.n_own; i++) std::memcpy(F + 6ull * c->perm[i], &Fi[6ull * i], 6 * sizeof(double));
+    }
+    rowptr[0] = 0;
+    for (int32_t u = 0; u < p.n_own; u++) {
+        const int32_t i = c->iperm[u];
+        rowptr[u + 1] = rowptr[u] + (int32_t)(A.ptr[i + 1] - A.ptr[i]);
+    }
+    parallel_chunks(p.n_own, [&](int64_t u0, int64_t u1) {
+        std::vector<std::pair<int32_t, int64_t>> order;
+        for (int64_t u = u0; u < u1; u++) {
+            const int32_t i = c->iperm[(size_t)u];
+            order.clear();
+            for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++) order.push_back({c->perm[A.col[(size_t)q]], q});
+            std::sort(order.begin(), order.end());
+            int64_t w = rowptr[u];
+            for (auto &o : order) {
+                colidx[w] = o.first;
+                std::memcpy(vals + 36 * w, &A.val[(size_t)o.second * 36], 36 * sizeof(double));
+                w++;
+            }
+        }
+    });
     return FEMSHELL_OK;
 }
 
@@ -841,11 +909,18 @@ int femshell_spmv(femshell_ctx *c, const double *x, double *y)
     FS_HIP(dx.alloc((size_t)p.n_local_nodes() * 6));
     FS_HIP(dy.alloc((size_t)p.n_pad * 6));
     FS_HIP(dx.zero(c->stream));
-    FS_HIP(hipMemcpyAsync(dx.p, x, (size_t)p.n_own * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    std::vector<double> xi, yi; // internal numbering when the library renumbered the nodes
+    if (!c->perm.empty()) {
+        xi.resize((size_t)p.n_own * 6);
+        yi.resize((size_t)p.n_own * 6);
+        for (int32_t i = 0; i < p.n_own; i++) std::memcpy(&xi[6ull * i], x + 6ull * c->perm[i], 6 * sizeof(double));
+    }
+    FS_HIP(hipMemcpyAsync(dx.p, xi.empty() ? x : xi.data(), (size_t)p.n_own * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     launch_spmv(c->dm, dx.p, dy.p, nullptr, nullptr, c->stream);
     FS_HIP(hipGetLastError());
-    FS_HIP(hipMemcpyAsync(y, dy.p, (size_t)p.n_own * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(hipMemcpyAsync(yi.empty() ? y : yi.data(), dy.p, (size_t)p.n_own * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     FS_HIP(hipStreamSynchronize(c->stream));
+    for (int32_t i = 0; i < p.n_own && !yi.empty(); i++) std::memcpy(y + 6ull * c->perm[i], &yi[6ull * i], 6 * sizeof(double));
     return FEMSHELL_OK;
 }
 
@@ -865,11 +940,18 @@ int femshell_residual(femshell_ctx *c, const double *x, double *r)
     FS_HIP(dx.alloc((size_t)p.n_local_nodes() * 6));
     FS_HIP(dr.alloc((size_t)p.n_pad * 6));
     FS_HIP(dx.zero(c->stream));
-    FS_HIP(hipMemcpyAsync(dx.p, x, (size_t)p.n_own * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    std::vector<double> xi, ri;
+    if (!c->perm.empty()) {
+        xi.resize((size_t)p.n_own * 6);
+        ri.resize((size_t)p.n_own * 6);
+        for (int32_t i = 0; i < p.n_own; i++) std::memcpy(&xi[6ull * i], x + 6ull * c->perm[i], 6 * sizeof(double));
+    }
+    FS_HIP(hipMemcpyAsync(dx.p, xi.empty() ? x : xi.data(), (size_t)p.n_own * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     launch_residual_dd(c->dm, dx.p, c->F.p, dr.p, c->stream);
     FS_HIP(hipGetLastError());
-    FS_HIP(hipMemcpyAsync(r, dr.p, (size_t)p.n_own * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(hipMemcpyAsync(ri.empty() ? r : ri.data(), dr.p, (size_t)p.n_own * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     FS_HIP(hipStreamSynchronize(c->stream));
+    for (int32_t i = 0; i < p.n_own && !ri.empty(); i++) std::memcpy(r + 6ull * c->perm[i], &ri[6ull * i], 6 * sizeof(double));
     return FEMSHELL_OK;
 }
 

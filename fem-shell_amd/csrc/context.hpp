@@ -22,11 +22,20 @@ struct Amg; // multigrid hierarchy (amg_device.hpp)
 int set_err(int code, const std::string &msg);
 const std::string &last_err();
 
+inline const char *fs_basename(const char *path)
+{
+    const char *b = path;
+    for (const char *q = path; *q; q++)
+        if (*q == '/') b = q + 1;
+    return b;
+}
+
 #define FS_HIP(call)                                                                                   \
     do {                                                                                               \
         hipError_t e_ = (call);                                                                        \
         if (e_ != hipSuccess)                                                                          \
-            return set_err(FEMSHELL_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));       \
+            return set_err(FEMSHELL_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_) +      \
+                                                 " (" + fs_basename(__FILE__) + ":" + std::to_string(__LINE__) + ")"); \
     } while (0)
 
 template <class T> struct DevBuf {
@@ -76,6 +85,9 @@ struct femshell_ctx {
     femshell::Plan plan;
     bool have_mesh = false, matrix_valid = false, rhs_valid = false, jacobi_valid = false, have_solution = false;
 
+    // optional renumbering (reorder.cpp): internal node i is the caller's node perm[i]; iperm is the inverse; both empty
+    // when the caller's numbering is kept.  dmask_global / loads_global and everything below are in internal numbering.
+    std::vector<int32_t> perm, iperm;
     std::vector<uint8_t> dmask_global;  // n_nodes
     std::vector<double> loads_global;   // n_nodes*6
 

@@ -304,44 +304,50 @@ template <int kChunk>
 __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__restrict__ x,
                                               double *__restrict__ y, double *__restrict__ partials,
                                               const CgScalars *s, const int32_t *__restrict__ order, int count,
-                                              const double *base_vec, double sign)
+                                              const double *base_vec, double sign, int panel)
 {
-    extern __shared__ double2 xs_all[]; // max_slice_width x 32 nodes x 3 words: x of the slice's block columns
+    extern __shared__ double2 xs_all[]; // panel slots x 32 nodes x 3 words: x of the slice's block columns
     __shared__ double sh[3];
     if (s != nullptr && s->done != 0) return;
     const int t = threadIdx.x;
     const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    const double2 *xs = xs_all + 3 * (t & 31);
     double dotv = 0.0;
     for (SliceWalk w(count); w.valid(); w.next()) {
         const int sl = order != nullptr ? order[w.s] : w.s;
         const int64_t base = m.slice_base[sl];
         const int W = m.slice_width[sl];
-        const double2 *v = reinterpret_cast<const double2 *>(m.vals + base * 36) + t;
-        SpmvChunk<kChunk> ch;
-        spmv_load<kChunk>(ch, v, 0, W);
-        __syncthreads(); // the previous slice's readers are done with xs_all
-        for (int e = t; e < W * kSliceNodes; e += kSliceRows) {
-            const double2 *xv = x2 + 3 * (int64_t)m.cols[base + e];
-            const double2 x0 = xv[0], x1 = xv[1], x2w = xv[2];
-            xs_all[3 * e] = x0;
-            xs_all[3 * e + 1] = x1;
-            xs_all[3 * e + 2] = x2w;
-        }
-        __syncthreads();
-        const double2 *xs = xs_all + 3 * (t & 31);
-        double acc = spmv_fma<kChunk>(ch, xs, 0, W, 0.0);
-        for (int k0 = kChunk; k0 < W; k0 += kChunk) {
-            spmv_load<kChunk>(ch, v, k0, W);
-            acc = spmv_fma<kChunk>(ch, xs, k0, W, acc);
+        double acc = 0.0;
+        double2 xw = make_double2(0.0, 0.0);
+        // slices wider than the LDS panel (restriction operators of coarse multigrid levels: a coarse node collects
+        // from every fine node its basis function touches) go through it in several passes
+        for (int p0 = 0; p0 == 0 || p0 < W; p0 += panel) {
+            const int Wp = W - p0 < panel ? W - p0 : panel;
+            const double2 *v = reinterpret_cast<const double2 *>(m.vals + base * 36) + (size_t)p0 * 3 * kSliceRows + t;
+            const int32_t *cols = m.cols + base + (int64_t)p0 * kSliceNodes;
+            SpmvChunk<kChunk> ch;
+            spmv_load<kChunk>(ch, v, 0, Wp);
+            __syncthreads(); // the previous panel's readers are done with xs_all
+            for (int e = t; e < Wp * kSliceNodes; e += kSliceRows) {
+                const double2 *xv = x2 + 3 * (int64_t)cols[e];
+                const double2 x0 = xv[0], x1 = xv[1], x2w = xv[2];
+                xs_all[3 * e] = x0;
+                xs_all[3 * e + 1] = x1;
+                xs_all[3 * e + 2] = x2w;
+            }
+            __syncthreads();
+            acc = spmv_fma<kChunk>(ch, xs, 0, Wp, acc);
+            for (int k0 = kChunk; k0 < Wp; k0 += kChunk) {
+                spmv_load<kChunk>(ch, v, k0, Wp);
+                acc = spmv_fma<kChunk>(ch, xs, k0, Wp, acc);
+            }
+            // x[row] is in LDS during the first panel: slot 0 is the diagonal block, its column is the lane's own node
+            if (p0 == 0 && partials != nullptr) xw = xs[t >> 6]; // word (t / 32) / 2 of the node's six entries
         }
         const int64_t row = (int64_t)sl * kSliceRows + (t & 31) * 6 + (t >> 5);
         // base_vec: y = base + sign * K x (residual b - K x, prolongation x + P x_c); may alias y
         y[row] = base_vec != nullptr ? base_vec[row] + sign * acc : acc;
-        if (partials != nullptr) {
-            // x[row] is in LDS already: slot 0 is the diagonal block, its column is the lane's own node
-            const double2 xw = xs[t >> 6]; // word (t / 32) / 2 of the node's six entries
-            dotv += acc * (((t >> 5) & 1) ? xw.y : xw.x);
-        }
+        if (partials != nullptr) dotv += acc * (((t >> 5) & 1) ? xw.y : xw.x);
     }
     if (partials != nullptr) {
         const double tot = block_sum(dotv, sh);
@@ -602,6 +608,8 @@ void launch_residual_dd(const DeviceMatrix &m, const double *x, const double *b,
     hipLaunchKernelGGL(k_residual_dd, dim3(slice_grid(m)), dim3(192), lds, st, m, x, b, r);
 }
 
+constexpr int kSpmvPanel = 64; // block slots of x staged in LDS at a time by k_spmv
+
 static void spmv_dispatch(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
                           const int32_t *order, int count, int grid, hipStream_t st, const double *base_vec = nullptr,
                           double sign = 1.0)
@@ -611,11 +619,13 @@ static void spmv_dispatch(const DeviceMatrix &m, const double *x, double *y, dou
         return e ? atoi(e) : 8;
     }();
     const dim3 g(grid), b(192);
-    const size_t lds = (size_t)m.max_slice_width * kSliceNodes * 3 * sizeof(double2); // x of the block columns
+    // x of the block columns, at most kSpmvPanel slots at a time (96 KiB of the CU's 160)
+    const int panel = m.max_slice_width < kSpmvPanel ? (m.max_slice_width > 0 ? m.max_slice_width : 1) : kSpmvPanel;
+    const size_t lds = (size_t)panel * kSliceNodes * 3 * sizeof(double2);
     auto launch = [&](auto kernel) {
         if (lds > 64 * 1024) // beyond the default dynamic-LDS limit (slices wider than 42 blocks)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kernel, g, b, lds, st, m, x, y, partials, s, order, count, base_vec, sign);
+        hipLaunchKernelGGL(kernel, g, b, lds, st, m, x, y, partials, s, order, count, base_vec, sign, panel);
     };
     switch (chunk) {
     case 1: launch(k_spmv<1>); break;

@@ -7,6 +7,7 @@
 
 #include "amg.hpp"
 #include "context.hpp"
+#include "reorder.hpp"
 
 using namespace femshell;
 
@@ -222,6 +223,21 @@ int64_t femshell_amg_host_pack_sym(int32_t n_rows, const int32_t *rowptr, const 
     if (in_rows) std::memcpy(in_rows, S.in_rows.data(), S.in_rows.size() * sizeof(int32_t));
     if (in_total) *in_total = (int64_t)S.in_slots.size();
     return S.slice_base.back();
+}
+
+int femshell_reorder_host(int32_t kind, int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri,
+                          int32_t n_quad, const int32_t *quad, int32_t *perm_out)
+{
+    if (n_nodes <= 0 || !xyz || !perm_out || (n_tri > 0 && !tri) || (n_quad > 0 && !quad)) return -1;
+    for (int64_t q = 0; q < 3ll * n_tri; q++)
+        if (tri[q] < 0 || tri[q] >= n_nodes) return -1;
+    for (int64_t q = 0; q < 4ll * n_quad; q++)
+        if (quad[q] < 0 || quad[q] >= n_nodes) return -1;
+    std::vector<int32_t> perm;
+    if (kind == 1) rcm_order(n_nodes, n_tri, tri, n_quad, quad, &perm);
+    else morton_order(n_nodes, xyz, &perm);
+    std::memcpy(perm_out, perm.data(), perm.size() * sizeof(int32_t));
+    return 0;
 }
 
 } // extern "C"

@@ -49,6 +49,13 @@ typedef enum femshell_status {
 #define FEMSHELL_REF_DRILL_MAX  0x2u /* SA:1035-1052: drilling stiffness max(..)/1000 on every node block */
 #define FEMSHELL_REASSEMBLE_EACH_SOLVE 0x4u /* PC:271: rebuild K on every solve (the reference does; K is constant) */
 #define FEMSHELL_REF_DEFAULT    (FEMSHELL_REF_Y21 | FEMSHELL_REF_DRILL_MAX)
+/* node renumbering inside the library (single-rank contexts): rows are stored along a Morton curve through the mesh /
+ * in reverse Cuthill-McKee order, so that the x entries a 32-node slice gathers are close together whatever the caller's
+ * numbering is.  libMesh renumbers for locality by default; the reference switches it off only because its force file is
+ * indexed by the original ids (SA:36).  Every node-indexed argument of this ABI keeps the caller's numbering.
+ * FEMSHELL_REORDER=morton|rcm in the environment sets the flag for contexts created without one. */
+#define FEMSHELL_REORDER_MORTON 0x10u
+#define FEMSHELL_REORDER_RCM    0x20u
 
 typedef struct femshell_config {
     double nu;          /* Poisson's ratio  -nu (SA:217) */

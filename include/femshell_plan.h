@@ -91,6 +91,11 @@ int femshell_amg_host_dense_inverse(int32_t n_nodes, const int32_t *rowptr, cons
 int64_t femshell_amg_host_pack(int32_t n_rows, const int32_t *rowptr, const int32_t *colidx, const double *vals,
                                int32_t diag_first, int32_t *slice_width, int64_t *slice_base, int32_t *cols, double *ell_vals);
 
+/* the node ordering FEMSHELL_REORDER_MORTON (kind 0) / FEMSHELL_REORDER_RCM (kind 1) would use inside femshell_set_mesh:
+ * perm_out[new index] = caller's node id (csrc/reorder.cpp) */
+int femshell_reorder_host(int32_t kind, int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri,
+                          int32_t n_quad, const int32_t *quad, int32_t *perm_out);
+
 /* symmetric storage of a square operator (coarse multigrid levels): diagonal + upper blocks in the sliced ELL arrays and
  * the in-lists of the transposed products; returns the total slots, *in_total receives the in-list entries; arrays may
  * be NULL for a sizing call */

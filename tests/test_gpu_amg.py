@@ -209,3 +209,26 @@ def test_multigrid_is_refused_on_multi_rank_contexts():
         fs.set_preconditioner("amg")
     assert e.value.code == -7
     fs.close()
+
+
+def test_restriction_rows_wider_than_the_lds_panel():
+    """On this Delaunay mesh (slivers on the hull, Morton numbering) a coarse node of level 1 collects from 162 fine
+    nodes: k_spmv stages the x entries of at most 64 block columns in LDS at a time and goes through wider slices in
+    several passes (the launch used to fail with 'invalid argument' beyond 106 columns = 160 KiB)."""
+    from tests.test_gpu_parity import delaunay_shell
+    xyz, tri = delaunay_shell(2500, 5)
+    n = len(xyz)
+    rng = np.random.default_rng(3)
+    fs = pkg.FemShell(0.3, 7.0e4, 0.03, flags=pkg.REF_DEFAULT | pkg.REORDER_MORTON)
+    fs.set_mesh(xyz, tri)
+    fixed = np.flatnonzero(xyz[:, 0] < 0.2).astype(np.int32)
+    fs.set_dirichlet(np.full(len(fixed), 0x3F, np.uint8), node_ids=fixed)
+    fs.set_loads(rng.normal(size=(n, 6)))
+    fs.set_preconditioner("amg")
+    u, info = fs.solve(rtol=1e-8, max_it=4000)
+    assert info["converged"] == 1 and info["amg_levels"] >= 3
+    lv = fs.amg_levels()
+    assert lv[1]["n_nodes"] < 400
+    r, c, v, F = fs.export_bsr()
+    u_ref = oracle.refined_solve(r, c, v, F)
+    assert np.linalg.norm(u.ravel() - u_ref) <= 1e-4 * np.linalg.norm(u_ref)  # kappa ~ 1e13 on this mesh

@@ -475,18 +475,25 @@ def test_config3_pinched_cylinder_scaled():
 
 # ------------------------------------------------------------------ unstructured meshes (irregular valence)
 
-def delaunay_shell(n_pts, seed):
+def delaunay_shell(n_pts, seed, jittered=False):
     """Random Delaunay triangulation of a curved patch, node numbering shuffled: valences 3..10+, so slices
     are wide and ragged, gather lists are uneven and many slices need several assembly rounds."""
     from scipy.spatial import Delaunay
 
     rng = np.random.default_rng(seed)
-    uv = rng.uniform(0.0, 1.0, size=(n_pts, 2))
+    if jittered:  # a grid with every interior point moved by up to 0.35 spacings: irregular valence, no slivers
+        side = int(np.sqrt(n_pts))
+        g = np.stack(np.meshgrid(np.arange(side), np.arange(side), indexing="ij"), axis=-1).reshape(-1, 2).astype(np.float64)
+        inner = np.all((g > 0) & (g < side - 1), axis=1)[:, None]  # the boundary stays straight: no hull slivers
+        uv = (g + inner * rng.uniform(-0.35, 0.35, size=g.shape)) / (side - 1)
+        n_pts = len(uv)
+    else:
+        uv = rng.uniform(0.0, 1.0, size=(n_pts, 2))
     tri = Delaunay(uv).simplices.astype(np.int32)
     # drop slivers on the hull (nearly collinear points)
     p, q, r = uv[tri[:, 0]], uv[tri[:, 1]], uv[tri[:, 2]]
     area = 0.5 * np.abs((q[:, 0] - p[:, 0]) * (r[:, 1] - p[:, 1]) - (q[:, 1] - p[:, 1]) * (r[:, 0] - p[:, 0]))
-    tri = tri[area > 1e-7]
+    tri = tri[area > (0.05 * area.mean() if jittered else 1e-7)]
     used = np.unique(tri)
     remap = -np.ones(n_pts, dtype=np.int64)
     remap[used] = rng.permutation(len(used))
@@ -655,3 +662,58 @@ def oracle_residual(r, c, v, F, u):
     K.sort_indices()
     ld = np.longdouble
     return (F.astype(ld) - np.add.reduceat(K.data.astype(ld) * u.ravel().astype(ld)[K.indices], K.indptr[:-1])).astype(np.float64)
+
+
+@pytest.mark.parametrize("flag", ["REORDER_MORTON", "REORDER_RCM"])
+def test_internal_renumbering_is_invisible_at_the_boundary(flag):
+    """FEMSHELL_REORDER_MORTON / _RCM renumber the nodes inside the library only (csrc/reorder.cpp): on a Delaunay mesh
+    with shuffled numbering every node-indexed argument and result keeps the caller's ids -- the exported matrix, right
+    hand side, products, residuals, element matrices and the solution equal those of a context without the flag (and
+    the oracle's), sparse Dirichlet / load lists included; both preconditioners."""
+    xyz, tri = delaunay_shell(2500, 5, jittered=True)
+    n = len(xyz)
+    rng = np.random.default_rng(3)
+    fixed = np.flatnonzero(xyz[:, 0] < 0.2).astype(np.int32)
+    loaded = rng.choice(n, 40, replace=False).astype(np.int32)
+    f6 = rng.normal(size=(40, 6))
+    x = rng.normal(size=6 * n)
+    res = {}
+    for name, flags in (("plain", pkg.REF_DEFAULT), ("reordered", pkg.REF_DEFAULT | getattr(pkg, flag))):
+        fs = pkg.FemShell(0.3, 7.0e4, 0.03, flags=flags)
+        fs.set_mesh(xyz, tri)
+        fs.set_dirichlet(np.full(len(fixed), 0x3F, np.uint8), node_ids=fixed)
+        fs.set_loads(f6, node_ids=loaded)
+        fs.assemble()
+        r, c, v, F = fs.export_bsr()
+        y = fs.spmv(x)
+        ke = fs.element_matrices(0, 50)
+        fs.set_preconditioner("amg")
+        u_amg, i_amg = fs.solve(rtol=1e-12, max_it=500)
+        assert i_amg["converged"] == 1
+        rr = fs.residual(u_amg)
+        fs.set_preconditioner("block_jacobi")
+        _, i_bj = fs.solve(rtol=0.0, max_it=60, fetch=False)
+        res[name] = (r, c, v, F, y, ke, u_amg, rr, fs.residual_history())
+        fs.close()
+    (r0, c0, v0, F0, y0, ke0, u0, rr0, h0), (r1, c1, v1, F1, y1, ke1, u1, rr1, h1) = res["plain"], res["reordered"]
+    np.testing.assert_array_equal(r1, r0)
+    np.testing.assert_array_equal(c1, c0)
+    np.testing.assert_array_equal(F1, F0)
+    np.testing.assert_array_equal(ke1, ke0)
+    assert np.abs(v1 - v0).max() <= 1e-13 * np.abs(v0).max()   # same element sums in another order
+    assert np.linalg.norm(y1 - y0) <= 1e-13 * np.linalg.norm(y0)
+    np.testing.assert_allclose(h1[:20], h0[:20], rtol=1e-6)     # same block-Jacobi CG, iteration by iteration
+    dmask = np.zeros(n, np.uint8)
+    dmask[fixed] = 0x3F
+    loads = np.zeros((n, 6))
+    loads[loaded] = f6
+    ro, co, vo, Fo = oracle.assemble(xyz, tri, np.zeros((0, 4), np.int32), oracle.material(0.3, 7.0e4, 0.03), dmask, loads)
+    np.testing.assert_array_equal(r1, ro)
+    np.testing.assert_array_equal(c1, co)
+    np.testing.assert_array_equal(F1, Fo)
+    assert np.abs(v1 - vo).max() <= 1e-12 * np.abs(vo).max()
+    # both solutions solve their own (rounding-different) matrices to the refinement floor; they agree to kappa * eps
+    assert np.linalg.norm(rr1) <= 1e-10 * np.linalg.norm(F1)
+    assert np.linalg.norm(rr1 - oracle_residual(r1, c1, v1, F1, u1)) <= 1e-11 * np.linalg.norm(F1)
+    assert np.linalg.norm(u1 - u0) <= 1e-6 * np.linalg.norm(u0)
+    assert np.all(u1[fixed] == 0.0)
