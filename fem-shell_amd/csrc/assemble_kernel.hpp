@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
     // 255 - i): the diagonal slots' work items, three contributions each, sit in the first wave, which would
     // otherwise also carry 64 of the 130 records of a structured slice; the last waves have two contributions per
     // lane and start the next slice's records while the first wave still finishes its blocks
-    const int etid = (int)blockDim.x - 1 - tid;
+    constexpr int kThreads = 256; // the launch's workgroup size (blockDim.x would be a scalar load per use)
+    const int etid = kThreads - 1 - tid;
 
     // profiling build (kAblate & 32): s_memtime stamps at the phase boundaries, summed per wave and written to
     // m.stamps[wave][8]; never compiled into the product kernel
@@ -75,7 +76,11 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         X[6] = pc[0]; X[7] = pc[1]; X[8] = pc[2];
     };
     // The bookkeeping of a slice (element range, item range, slot base, width) is one 32-byte descriptor, fetched
-    // with scalar loads three slices ahead, so that no phase waits for a scalar round trip either.
+    // three slices ahead.  The compiler reads it with a vector load (the kernel stores to memory it cannot tell
+    // apart) and would move it to scalar registers at once -- a full memory round trip in every wave and slice, behind
+    // the K stores of the previous slice because vmcnt retires in order.  So the words of the newest descriptor stay in
+    // vector registers (desc_a, desc_b) and are moved to scalar registers at the top of the next slice, where the
+    // wave waits for its prefetched coordinates anyway.
     struct Desc {
         int e0, ne, i0, ni;
         int64_t base;
@@ -91,7 +96,28 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         }
         return d;
     };
-    Desc d0 = load_desc(w.s), d1 = load_desc(w.s + w.step), d2 = load_desc(w.s + 2 * w.step);
+    int4 desc_a = make_int4(0, 0, 0, 0), desc_b = make_int4(0, 0, 0, 0);
+    auto fetch_desc = [&](int s_) {
+        desc_a = make_int4(0, 0, 0, 0);
+        desc_b = make_int4(0, 0, 0, 0);
+        if (s_ < w.last) {
+            desc_a = m.slice_desc[2 * s_];
+            desc_b = m.slice_desc[2 * s_ + 1];
+        }
+    };
+    auto decode_desc = [&]() {
+        Desc d;
+        d.e0 = __builtin_amdgcn_readfirstlane(desc_a.x);
+        d.ne = __builtin_amdgcn_readfirstlane(desc_a.y);
+        d.i0 = __builtin_amdgcn_readfirstlane(desc_a.z);
+        d.ni = __builtin_amdgcn_readfirstlane(desc_a.w);
+        d.base = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(desc_b.y) << 32) |
+                           (uint32_t)__builtin_amdgcn_readfirstlane(desc_b.x));
+        d.W = __builtin_amdgcn_readfirstlane(desc_b.z);
+        return d;
+    };
+    Desc d0 = load_desc(w.s), d1 = load_desc(w.s + w.step), d2 = d1;
+    fetch_desc(w.s + 2 * w.step);
     int e0 = d0.e0, ne = d0.ne;
     int4 nd = make_int4(0, 0, 0, -1);
     if (etid < ne) nd = m.slice_elem_nodes[e0 + etid];
@@ -123,13 +149,15 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         const int i0 = d0.i0, ni = d0.ni;
         uint4 item = item_pre; // fetched during the previous slice's block math
         uint32_t flags = flags_pre;
+        d2 = decode_desc(); // slice s+2, fetched during the previous slice
 
         if (m.rhs_F != nullptr && tid < kSliceRows) {
             const bool fixed = (rhs_mask >> (tid % 6)) & 1u;
             m.rhs_F[(int64_t)s * kSliceRows + tid] = (fixed || s * kSliceNodes + tid / 6 >= m.n_own) ? 0.0 : rhs_pre;
         }
+        stamp(5); // top of the slice: wait for the prefetched operands, right-hand side rows, descriptor decode
         // ---- phase A: one record per element touching the slice
-        for (int i = etid; i < ne; i += blockDim.x) {
+        for (int i = etid; i < ne; i += kThreads) {
             const int4 c = (i == etid) ? nd : m.slice_elem_nodes[e0 + i];
             double rec[kRec];
             bool ok = false;
@@ -176,7 +204,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         // ids of slice s+2, descriptor of slice s+3
         uint4 item_next = make_uint4(0, 0, 0, 0);
         uint32_t flags_next = 0u;
-        const Desc d3 = load_desc(s + 3 * w.step);
+        fetch_desc(s + 3 * w.step);
         fetch_rhs(s + w.step);
         e0 = d1.e0;
         ne = d1.ne;
@@ -188,12 +216,13 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         }
         if (etid < d2.ne) nd_n = m.slice_elem_nodes[d2.e0 + etid];
 
+        stamp(6); // issue of the prefetches
         // ---- phase B: one lane per work item (at most kItemPairs element contributions), in rounds of 256
         //      items; the lane that owns a block slot stores its finished block straight to K: in the layout of
         //      plan.hpp the lanes of a slot (consecutive nodes) write consecutive 16-byte words with every store
         double2 *out = reinterpret_cast<double2 *>(m.vals + base * 36);
-        const bool multi = ni > (int)blockDim.x; // several rounds
-        for (int r0 = 0; r0 < ni; r0 += blockDim.x) {
+        const bool multi = ni > kThreads; // several rounds
+        for (int r0 = 0; r0 < ni; r0 += kThreads) {
             const int it = r0 + tid;
             const bool live = it < ni;
             if (r0 > 0) {
@@ -288,7 +317,6 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
         flags_pre = flags_next;
         d0 = d1;
         d1 = d2;
-        d2 = d3;
     }
     if (kAblate & 32) {
         if ((tid & 63) == 0) {

@@ -10,3 +10,8 @@ for _ in range(3):
     fs.assemble()
 ms, by = fs.time_kernel(pkg.KERNEL_ASSEMBLE, 5)
 print("ASM: %.3f ms  %.1f GB/s  %.1f Melem/s" % (ms, by/ms/1e6, len(m.tri)/ms/1e3))
+ms_s, by_s = fs.time_kernel(pkg.KERNEL_SPMV, 20)
+print("SPMV: %.4f ms %.0f GB/s" % (ms_s, by_s / ms_s / 1e6))
+if os.environ.get("CG", "1") == "1":
+    _, info = fs.solve(rtol=0.0, max_it=300, fetch=False)
+    print("CG: %.4f ms/iter" % (1e3 * info["solve_seconds"] / info["iterations"]))

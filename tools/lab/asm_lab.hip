@@ -79,20 +79,20 @@ int main(int argc, char **argv)
         std::vector<unsigned long long> h((size_t)grid * 4 * 8);
         CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
         const char *names[8] = {"phase A (record math + LDS)", "barrier after A", "block math + single-item stores", "staging + barrier",
-                                "reduction + diagonal stores", "(unused)", "(unused)", "(unused)"};
+                                "reduction + diagonal stores", "top of slice (operand wait, rhs)", "prefetch issue", "(unused)"};
         double tot[8] = {0}; double all = 0;
         for (size_t w_ = 0; w_ < (size_t)grid * 4; w_++) for (int q = 0; q < 8; q++) { tot[q] += (double)h[w_ * 8 + q]; all += (double)h[w_ * 8 + q]; }
         unsigned long long clk[2]; CK(hipMemcpy(clk, st + (size_t)grid * 32, 16, hipMemcpyDeviceToHost));
         printf("in-kernel clock: %llu shader cycles per %llu ticks of 100 MHz -> %.3f GHz\n", clk[0], clk[1], 0.1 * (double)clk[0] / (double)clk[1]);
         printf("%s: %.3f ms per launch; share of wave cycles per phase:\n", title, ms);
-        for (int q = 0; q < 5; q++) printf("  %-32s %5.1f %%   (%.0f cycles per wave per slice)\n", names[q], 100.0 * tot[q] / all, tot[q] / ((double)p.n_slices * 4));
+        for (int q = 0; q < 7; q++) printf("  %-32s %5.1f %%   (%.0f cycles per wave per slice)\n", names[q], 100.0 * tot[q] / all, tot[q] / ((double)p.n_slices * 4));
         // the waves of a workgroup do different work (first wave: diagonal items; last waves: element records)
         for (int wv = 0; wv < 4; wv++) {
             double tw[8] = {0}; double allw = 0;
             for (size_t b_ = 0; b_ < (size_t)grid; b_++) for (int q = 0; q < 8; q++) { tw[q] += (double)h[(b_ * 4 + wv) * 8 + q]; allw += (double)h[(b_ * 4 + wv) * 8 + q]; }
             printf("  wave %d: cycles per slice:", wv);
-            for (int q = 0; q < 5; q++) printf(" %6.0f", tw[q] / (double)p.n_slices);
-            printf("  (A, barrier, block, staging+barrier, reduce)  total %.0f\n", allw / (double)p.n_slices);
+            for (int q = 0; q < 7; q++) printf(" %6.0f", tw[q] / (double)p.n_slices);
+            printf("  (A, barrier, block, staging+barrier, reduce, top, prefetch)  total %.0f\n", allw / (double)p.n_slices);
         }
     };
     stamps(std::integral_constant<int, 32>(), "stamped build");
