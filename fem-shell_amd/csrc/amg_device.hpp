@@ -61,9 +61,8 @@ struct Amg {
 };
 
 void amg_default_options(femshell_pc_options *o);
-// symmetric storage of the coarse level operators (FEMSHELL_AMG_COARSE_SYM=1; default: full storage, measured faster --
-// the coarse products are launch- and latency-bound, and the lane-per-node kernel has a sixth of the lanes)
-bool coarse_symmetric_storage();
+// symmetric storage of a coarse level operator of n_nodes nodes (large levels only, see amg_solve.cpp)
+bool coarse_symmetric_storage(int32_t n_nodes);
 // in-lists of a symmetric-storage operator into HBM and into op.dm (the slot arrays of op are in place already)
 int attach_in_lists(AmgOperator &op, const SlicedEllSym &S, int64_t total_slots, hipStream_t st);
 int amg_setup(femshell_ctx *c);

@@ -320,7 +320,7 @@ int amg_device_coarsen(femshell_ctx *c, AmgLevel &L, AmgLevel &next, const std::
     }
     // A_c: per aggregate the union of the A P rows of its fine rows (symmetric storage: columns >= the row only; the
     // coarse operator is symmetric, the cycle applies the stored blocks to both rows)
-    const bool sym_coarse = coarse_symmetric_storage();
+    const bool sym_coarse = coarse_symmetric_storage(na);
     std::vector<int64_t> cptr((size_t)na + 1, 0);
     std::vector<int32_t> ccol;
     {

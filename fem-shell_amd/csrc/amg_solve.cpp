@@ -132,10 +132,17 @@ int alloc_level_vectors(AmgLevel &L, bool top, bool kcycle, hipStream_t st)
 
 } // namespace
 
-bool coarse_symmetric_storage()
+bool coarse_symmetric_storage(int32_t n_nodes)
 {
-    const char *e = getenv("FEMSHELL_AMG_COARSE_SYM");
-    return e && atoi(e) != 0 && default_symmetric_storage();
+    // levels of at least 100,000 nodes (FEMSHELL_AMG_COARSE_SYM overrides; 1 = all levels, 0 = none) are stored like K,
+    // diagonal + upper blocks: their products are HBM-bound (4M-triangle panel, level 1 of 222k nodes: 1.63 s against
+    // 1.71 s per solve); the smaller levels are launch- and latency-bound, where the two-phase product loses (all
+    // levels symmetric: 1.80 s)
+    static const long min_nodes = [] {
+        const char *e = getenv("FEMSHELL_AMG_COARSE_SYM");
+        return e ? atol(e) : 100000l;
+    }();
+    return min_nodes > 0 && n_nodes >= min_nodes && default_symmetric_storage();
 }
 
 void amg_default_options(femshell_pc_options *o)
@@ -221,7 +228,7 @@ int amg_setup(femshell_ctx *c)
         if (l > 0) {
             if (!L.A_on_device) {
                 // the level operators are symmetric: diagonal and upper blocks only, like K (FEMSHELL_SYMMETRIC=0: full)
-                if (coarse_symmetric_storage()) {
+                if (coarse_symmetric_storage(A.nr)) {
                     SlicedEllSym S;
                     pack_sliced_ell_sym(A, &S);
                     rc = upload_operator(L.A, S, S.n_pad, (A.nnzb() + A.nr) / 2, st); // stored: diagonal + one block per pair
