@@ -236,17 +236,29 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
             const int slot_in_slice = (int)(item.x & 0xffffu), chunk = (int)((item.x >> 16) & 0xffu),
                       nchunks = (int)(item.x >> 24);
             const int cnt = (int)(item.z >> 16);
+            // slot 0 of a node row is its diagonal block: all contributions are K_e(ia, ia), symmetric, and the lane
+            // keeps the upper triangle only (tri3_diag_add_rec; blk[0..20] in sym6 order).  Items are ordered by work, so
+            // the diagonal items of a slice fill whole waves.
+            const bool sym_item = !kHasQuads && !(kAblate & 4) && slot_in_slice < kSliceNodes;
             double blk[36];
 #pragma unroll
             for (int i = 0; i < 36; i++) blk[i] = 0.0;
-            for (int q = 0; q < cnt; q++) {
-                const uint32_t pr = (q == 0) ? (item.y & 0xffffu) : (q == 1 ? (item.y >> 16) : (item.z & 0xffffu));
-                const double *rec = lds_rec + ((kAblate & 2) ? 0 : (size_t)(pr >> 4) * kRec);
-                if (kAblate & 4) {
+            if (sym_item) {
+                for (int q = 0; q < cnt; q++) {
+                    const uint32_t pr = (q == 0) ? (item.y & 0xffffu) : (q == 1 ? (item.y >> 16) : (item.z & 0xffffu));
+                    const double *rec = lds_rec + ((kAblate & 2) ? 0 : (size_t)(pr >> 4) * kRec);
+                    tri3_diag_add_rec(rec, (int)(pr & 3u), mc, blk);
+                }
+            } else {
+                for (int q = 0; q < cnt; q++) {
+                    const uint32_t pr = (q == 0) ? (item.y & 0xffffu) : (q == 1 ? (item.y >> 16) : (item.z & 0xffffu));
+                    const double *rec = lds_rec + ((kAblate & 2) ? 0 : (size_t)(pr >> 4) * kRec);
+                    if (kAblate & 4) {
 #pragma unroll
-                    for (int i = 0; i < 26; i++) blk[i] += rec[i];
-                } else {
-                    block_add_rec<kHasQuads>(rec, (int)((pr >> 2) & 3u), (int)(pr & 3u), mc, blk);
+                        for (int i = 0; i < 26; i++) blk[i] += rec[i];
+                    } else {
+                        block_add_rec<kHasQuads>(rec, (int)((pr >> 2) & 3u), (int)(pr & 3u), mc, blk);
+                    }
                 }
             }
             const bool owner = live && chunk == 0 && nchunks > 0; // nchunks == 0: padding item
@@ -257,7 +269,38 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
             const int valence = (int)((flags >> 12) & 255u);
             const bool diag_slot = (flags >> 20) & 1u;
             // constraints (libMesh constrain_element_matrix_and_vector semantics) and the 18 stores of a finished block
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            // the same for a diagonal block held as its upper triangle: row and column masks coincide
+            auto finish_sym_block = [&]() {
+                if (mrow) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++)
+#pragma unroll
+                        for (int j = i; j < 6; j++)
+                            if (((mrow >> i) & 1u) | ((mrow >> j) & 1u)) blk[sym6(i, j)] = (i == j) ? (double)valence : 0.0;
+                }
+                if (!(kAblate & 1)) {
+                    v2d *dst = reinterpret_cast<v2d *>(out) + (slot_in_slice & 31);
+#pragma unroll
+                    for (int jp = 0; jp < 3; jp++)
+#pragma unroll
+                        for (int i = 0; i < 6; i++) {
+                            const int j0 = 2 * jp, j1 = 2 * jp + 1;
+                            v2d vv;
+                            vv.x = blk[i <= j0 ? sym6(i, j0) : sym6(j0, i)];
+                            vv.y = blk[i <= j1 ? sym6(i, j1) : sym6(j1, i)];
+                            if (kAblate & 64) dst[(jp * 6 + i) * kSliceNodes] = vv;
+                            else __builtin_nontemporal_store(vv, dst + (jp * 6 + i) * kSliceNodes);
+                        }
+                } else if (blk[0] == 1.2345e300) {
+                    out[0] = make_double2(blk[1], blk[2]);
+                }
+            };
             auto finish_block = [&]() {
+                if (sym_item) {
+                    finish_sym_block();
+                    return;
+                }
                 if (mrow | mcol) {
 #pragma unroll
                     for (int i = 0; i < 6; i++)
@@ -271,7 +314,6 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                     }
                 }
                 if (!(kAblate & 1)) {
-                    typedef double v2d __attribute__((ext_vector_type(2)));
                     v2d *dst = reinterpret_cast<v2d *>(out) + (size_t)(slot_in_slice >> 5) * 3 * kSliceRows + (slot_in_slice & 31);
 #pragma unroll
                     for (int jp = 0; jp < 3; jp++)
@@ -292,7 +334,11 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
             if (live && chunk > 0) {
                 double2 *st = reinterpret_cast<double2 *>(lds_stage + (size_t)item.w * 36);
 #pragma unroll
-                for (int i = 0; i < 18; i++) st[i] = make_double2(blk[2 * i], blk[2 * i + 1]);
+                for (int i = 0; i < 11; i++) st[i] = make_double2(blk[2 * i], blk[2 * i + 1]);
+                if (!sym_item) {
+#pragma unroll
+                    for (int i = 11; i < 18; i++) st[i] = make_double2(blk[2 * i], blk[2 * i + 1]);
+                }
             }
             lds_barrier();
             stamp(3); // staging write + barrier
@@ -302,10 +348,18 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                 for (int c = 1; c < nchunks; c++) {
                     const double2 *st = reinterpret_cast<const double2 *>(lds_stage + (size_t)(item.w + c - 1) * 36);
 #pragma unroll
-                    for (int i = 0; i < 18; i++) {
+                    for (int i = 0; i < 11; i++) {
                         const double2 v = st[i];
                         blk[2 * i] += v.x;
                         blk[2 * i + 1] += v.y;
+                    }
+                    if (!sym_item) {
+#pragma unroll
+                        for (int i = 11; i < 18; i++) {
+                            const double2 v = st[i];
+                            blk[2 * i] += v.x;
+                            blk[2 * i + 1] += v.y;
+                        }
                     }
                 }
                 finish_block();
