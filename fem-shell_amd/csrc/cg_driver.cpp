@@ -56,16 +56,20 @@ int spmv_with_halo(femshell_ctx *c, const CgVectors &v, double *xin, double *you
 }
 
 // (len3: length of the third partial array when nsums == 3)
-int scalar_step(femshell_ctx *c, const CgVectors &v, int nsums, CgPhase phase, double rtol, int n_partials, int len3)
+// (phase NONE: the sums are reduced -- and all-reduced -- into red[] and no scalar step is taken: the caller's next
+//  kernel does it; gate_phase then names the step the sums belong to)
+int scalar_step(femshell_ctx *c, const CgVectors &v, int nsums, CgPhase phase, double rtol, int n_partials, int len3,
+                int gate_phase)
 {
+    const int gate = gate_phase >= 0 ? gate_phase : (int)phase;
     if (c->comm.active()) {
-        launch_cg_scalar(c->dm, v, true, nsums, CG_PHASE_NONE, rtol, c->stream, n_partials, len3, (int)phase);
+        launch_cg_scalar(c->dm, v, true, nsums, CG_PHASE_NONE, rtol, c->stream, n_partials, len3, gate);
         std::string e;
         double *red = reinterpret_cast<double *>(reinterpret_cast<char *>(v.s) + offsetof(CgScalars, red));
         if (!comm_allreduce_sum(c->comm, red, nsums, c->stream, &e)) return set_err(FEMSHELL_ERR_COMM, e);
-        launch_cg_scalar(c->dm, v, false, nsums, phase, rtol, c->stream);
+        if (phase != CG_PHASE_NONE) launch_cg_scalar(c->dm, v, false, nsums, phase, rtol, c->stream);
     } else {
-        launch_cg_scalar(c->dm, v, true, nsums, phase, rtol, c->stream, n_partials, len3);
+        launch_cg_scalar(c->dm, v, true, nsums, phase, rtol, c->stream, n_partials, len3, gate);
     }
     return FEMSHELL_OK;
 }
@@ -123,24 +127,41 @@ int cg_single_reduction(femshell_ctx *c, const CgVectors &v, double rtol, int32_
     hipStream_t st = c->stream;
     const int G = slice_grid(m);
     double *spmv_partials = v.partials + 2 * (size_t)G; // third partial array
+    // FEMSHELL_CG_FOLD=0: the unfolded sequence (k_sym_gather pass, scalar step as a launch of its own) for A/B runs
+    const char *fold_env = getenv("FEMSHELL_CG_FOLD");
+    const bool fold = !(fold_env && atoi(fold_env) == 0);
+    const bool gather = fold && m.symmetric != 0; // the update kernel collects the transposed products of w = A z
     launch_cgcg_init(m, v, st);
     int len3 = 0;
-    int rc = spmv_with_halo(c, v, v.z, v.q, spmv_partials, &len3);
+    int rc = spmv_with_halo(c, v, v.z, v.q, spmv_partials, &len3, gather);
     if (rc) return rc;
     rc = scalar_step(c, v, 3, CG_PHASE_FUSED_INIT, rtol, G, len3 > 0 ? len3 : G);
     if (rc) return rc;
     CgScalars hs{};
     DonePoll poll;
+    // One iteration on the main stream: update (with the scalar step of the previous iteration and the collection of
+    // the transposed products folded in), interior product, boundary product, reduction of the partial sums, all-reduce
+    // of three doubles -- four kernels and one collective; pack and send/recv run beside the interior product.
+    bool open_step = false; // an all-reduce whose scalar step has not been taken yet
     for (int32_t it = 0; it < max_it; it++) {
-        launch_cgcg_update(m, v, st);
-        rc = spmv_with_halo(c, v, v.z, v.q, spmv_partials, &len3);
+        launch_cgcg_update(m, v, st, fold && it > 0 ? (int)((it - 1) & 1) : -1, gather);
+        rc = spmv_with_halo(c, v, v.z, v.q, spmv_partials, &len3, gather);
         if (rc) return rc;
-        rc = scalar_step(c, v, 3, CG_PHASE_FUSED_STEP, rtol, G, len3 > 0 ? len3 : G);
+        if (fold) {
+            rc = scalar_step(c, v, 3, CG_PHASE_NONE, rtol, G, len3 > 0 ? len3 : G, (int)CG_PHASE_FUSED_STEP);
+            open_step = true;
+        } else {
+            rc = scalar_step(c, v, 3, CG_PHASE_FUSED_STEP, rtol, G, len3 > 0 ? len3 : G);
+        }
         if (rc) return rc;
         rc = poll(c, v, it, max_it, &hs);
         if (rc < 0) return rc;
-        if (rc == 1) break;
+        if (rc == 1) {
+            open_step = false; // done was set by the step inside an update kernel; the sums reduced since belong to no-ops
+            break;
+        }
     }
+    if (open_step) launch_cg_scalar(m, v, false, 3, CG_PHASE_FUSED_STEP, rtol, st); // closes the last iteration
     return FEMSHELL_OK;
 }
 

@@ -132,6 +132,7 @@ int cg_classic(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it)
 int cg_single_reduction(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it);
 bool use_single_reduction(const femshell_ctx *c);
 // reduction of the partial sums [+ all-reduce on contexts with a communicator] + scalar step
-int scalar_step(femshell_ctx *c, const CgVectors &v, int nsums, CgPhase phase, double rtol, int n_partials = 0, int len3 = 0);
+int scalar_step(femshell_ctx *c, const CgVectors &v, int nsums, CgPhase phase, double rtol, int n_partials = 0, int len3 = 0,
+                int gate_phase = -1);
 
 } // namespace femshell

@@ -822,19 +822,66 @@ void launch_cgcg_init(const DeviceMatrix &m, const CgVectors &v, hipStream_t st)
     hipLaunchKernelGGL(k_cgcg_init, dim3(slice_grid(m)), dim3(192), 0, st, m, v);
 }
 
-__global__ __launch_bounds__(192) void k_cgcg_update(DeviceMatrix m, CgVectors v)
+// (kGather: as in k_cg_update.  step >= 0: the scalar step of the previous iteration is done here, by every workgroup
+// for itself and published by workgroup 0 -- a launch less between the all-reduce and the next product; the arithmetic
+// is that of cg_scalar_phase(CG_PHASE_FUSED_STEP))
+template <bool kGather>
+__global__ __launch_bounds__(192) void k_cgcg_update(DeviceMatrix m, CgVectors v, int step)
 {
     __shared__ double rs[kSliceRows];
     __shared__ double sh[3];
-    if (v.s->done != 0) return;
+    CgScalars *s = v.s;
+    if (s->done != 0) return; // set by an earlier launch: the same in every workgroup
     const int G = gridDim.x, t = threadIdx.x;
-    const double alpha = v.s->alpha, beta = v.s->beta;
+    double alpha, beta;
+    if (step >= 0) {
+        const int par = step & 1;
+        const double rz_old = s->ring_rz[par], alpha_old = s->ring_alpha[par];
+        const double rzn = s->red[0], rr = s->red[1], zaz = s->red[2];
+        int done = 0;
+        alpha = 0.0;
+        beta = 0.0;
+        if (rr <= s->tol2) done = 1;
+        else {
+            beta = rzn / rz_old;
+            const double denom = zaz - beta * rzn / alpha_old;
+            if (!(denom > 0.0)) done = -1;
+            else alpha = rzn / denom;
+        }
+        if (blockIdx.x == 0 && t == 0) {
+            s->rr = rr;
+            const int it = s->iters + 1;
+            s->iters = it;
+            if (v.hist != nullptr && it <= v.hist_cap) v.hist[it - 1] = rr / s->bb;
+            if (done == 0) {
+                s->beta = beta;
+                s->alpha = alpha;
+                s->rz = rzn;
+                s->ring_rz[par ^ 1] = rzn;
+                s->ring_alpha[par ^ 1] = alpha;
+            }
+            s->done = done; // read by the later launches only: this one has taken its decision from red[]
+        }
+        if (done != 0) return;
+    } else {
+        alpha = s->alpha;
+        beta = s->beta;
+    }
     double d0 = 0.0, d1 = 0.0;
     for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
         const int sl = w.s;
         const int64_t row = (int64_t)sl * kSliceRows + t;
         const MinvRow mr = load_minv(m, sl, t);
-        const double uv = v.z[row], wv = v.q[row], pv = v.p[row], sv = v.sv[row], xv = v.x[row], rv = v.r[row];
+        const double uv = v.z[row], pv = v.p[row], sv = v.sv[row], xv = v.x[row], rv = v.r[row];
+        double wv = v.q[row];
+        if (kGather) {
+            const int Wi = m.in_width[sl], n = t / 6, j = t % 6;
+            const int64_t ib = m.in_base[sl];
+            for (int k = 0; k < Wi; k++) {
+                const int32_t slot = m.in_slots[ib + (int64_t)k * kSliceNodes + n];
+                if (slot >= 0) wv += m.tbuf[(int64_t)slot * 6 + j];
+            }
+        }
         const double pn = uv + beta * pv, sn = wv + beta * sv;
         v.p[row] = pn;
         v.sv[row] = sn;
@@ -857,9 +904,10 @@ __global__ __launch_bounds__(192) void k_cgcg_update(DeviceMatrix m, CgVectors v
     }
 }
 
-void launch_cgcg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st)
+void launch_cgcg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st, int step, bool gather)
 {
-    hipLaunchKernelGGL(k_cgcg_update, dim3(slice_grid(m)), dim3(192), 0, st, m, v);
+    if (gather) hipLaunchKernelGGL(k_cgcg_update<true>, dim3(slice_grid(m)), dim3(192), 0, st, m, v, step);
+    else hipLaunchKernelGGL(k_cgcg_update<false>, dim3(slice_grid(m)), dim3(192), 0, st, m, v, step);
 }
 
 // p = z + beta p over the owned (padded) rows, 16 bytes per lane
@@ -931,6 +979,8 @@ __device__ __forceinline__ void cg_scalar_phase(const CgVectors &v, int phase, d
             if (!(s->red[2] > 0.0)) s->done = -1;
             else s->alpha = s->red[0] / s->red[2];
         }
+        s->ring_rz[0] = s->rz;
+        s->ring_alpha[0] = s->alpha;
     } else if (phase == CG_PHASE_FUSED_STEP) {
         // red = (r.z, r.r, z.Az) of the new residual: beta = rz'/rz, alpha = rz' / (z.Az - beta rz'/alpha)
         const double rzn = s->red[0], rr = s->red[1], zaz = s->red[2];

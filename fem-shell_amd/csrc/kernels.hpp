@@ -78,6 +78,10 @@ struct CgScalars {
     uint32_t ticket;     // arrival counter of the two-stage reduction (0 between launches)
     uint32_t pad;
     double stage[3][64]; // stage-1 sums of the reduction workgroups
+    // single-reduction recurrence with the scalar step folded into the update kernel (k_cgcg_update): every workgroup
+    // derives alpha / beta from red[] and the previous (r.z, alpha); those are read from ring[parity] while workgroup 0
+    // writes ring[parity ^ 1] and the fields above
+    double ring_rz[2], ring_alpha[2];
 };
 
 struct CgVectors {
@@ -160,7 +164,10 @@ void launch_cg_scalar(const DeviceMatrix &m, const CgVectors &v, bool reduce, in
 //   update: p = z + beta p, s = w + beta s, x += alpha p, r -= alpha s, z = M^-1 r, partial sums of r.z and r.r
 // with w = A z (v.q) from the SpMV kernel, whose fused dot is z.w
 void launch_cgcg_init(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);
-void launch_cgcg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);
+// step >= 0: the kernel first performs the scalar step that closes the previous iteration (red[] holds its global sums;
+// reads ring[step & 1], writes ring[(step & 1) ^ 1]); gather: q holds the direct part of a symmetric product only, the
+// rows add the transposed products of their in-lists
+void launch_cgcg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st, int step = -1, bool gather = false);
 
 // halo: gather owned entries of p into a contiguous send buffer
 void launch_pack(const double *p, const int32_t *send_nodes, int32_t count, double *sendbuf, hipStream_t st);

@@ -311,6 +311,27 @@ def test_single_reduction_recurrence_matches_classic_and_oracle(monkeypatch):
     assert info2["iterations"] == 37 and info2["converged"] == 0
 
 
+def test_folded_single_reduction_iteration_is_bitwise_the_unfolded_one(monkeypatch):
+    # multi-rank iteration: the scalar step and the collection of the transposed products are folded into the update
+    # kernel (four kernels + one all-reduce per iteration); FEMSHELL_CG_FOLD=0 keeps them as launches of their own
+    m = curved_mesh(30, 22)
+    fs = make_ctx(m, 0.3, 7.0e4, 0.05)
+    monkeypatch.setenv("FEMSHELL_CG_SINGLE_REDUCTION", "1")
+    out = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("FEMSHELL_CG_FOLD", fold)
+        u, info = fs.solve(rtol=1e-11, max_it=40000)
+        uf, infof = fs.solve(rtol=0.0, max_it=53)
+        out[fold] = (u, info, fs.residual_history(), uf, infof)
+    monkeypatch.delenv("FEMSHELL_CG_FOLD")
+    monkeypatch.delenv("FEMSHELL_CG_SINGLE_REDUCTION")
+    (u1, i1, h1, uf1, if1), (u0, i0, h0, uf0, if0) = out["1"], out["0"]
+    assert i1["converged"] == 1 and i0["converged"] == 1 and i1["iterations"] == i0["iterations"]
+    assert if1["iterations"] == 53 and if0["iterations"] == 53
+    assert np.array_equal(u1, u0) and np.array_equal(uf1, uf0) and np.array_equal(h1, h0)
+    assert 0 <= i1["true_rel_residual"] < 1e-9
+
+
 def test_fixed_iteration_mode_and_resolve_with_new_loads():
     m = curved_mesh(24, 18)
     fs = make_ctx(m, 0.3, 7.0e4, 0.05)
