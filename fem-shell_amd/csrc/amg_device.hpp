@@ -51,6 +51,13 @@ struct AmgSetupStats {
     int galerkin_mfma = 0;
 };
 
+// Level 0 of a row-partitioned context (see amg_solve.cpp): work vectors in the rank's numbering (x0, d0 with ghost
+// space: they are inputs of the halo product) and two fine-level vectors in global numbering for the transfer operators
+struct AmgDist {
+    DevBuf<double> x0, r0, d0, q0;
+    DevBuf<double> gfine, gcorr;
+};
+
 struct Amg {
     femshell_pc_options opt{};
     AmgSetupStats stats;
@@ -58,6 +65,7 @@ struct Amg {
     DevBuf<double> coarse_inv; // dense inverse of the coarsest operator
     bool valid = false;
     double setup_seconds = 0.0;
+    std::shared_ptr<AmgDist> dist; // row-partitioned contexts only
 };
 
 void amg_default_options(femshell_pc_options *o);
@@ -66,6 +74,9 @@ bool coarse_symmetric_storage(int32_t n_nodes);
 // in-lists of a symmetric-storage operator into HBM and into op.dm (the slot arrays of op are in place already)
 int attach_in_lists(AmgOperator &op, const SlicedEllSym &S, int64_t total_slots, hipStream_t st);
 int amg_setup(femshell_ctx *c);
+// contexts with a communicator: c->amg_shadow holds the whole K and has run amg_setup; shares its hierarchy with c and
+// allocates the level-0 vectors of the rank
+int amg_attach_shadow(femshell_ctx *c);
 // z = M(r): one multigrid cycle on the context's stream (all launches are no-ops once gate->done != 0)
 int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate);
 // *true_rr_out: ||b - K x||^2 of the returned iterate when the residual replacement computed it, else -1

@@ -274,6 +274,21 @@ void launch_add(const double *src, double *dst, int64_t n, hipStream_t st)
                        reinterpret_cast<const double2 *>(src), reinterpret_cast<double2 *>(dst), n2);
 }
 
+__global__ __launch_bounds__(256) void k_sub(const double2 *__restrict__ a, const double2 *__restrict__ b, double2 *__restrict__ out, int64_t n2)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+        const double2 x = a[i], y = b[i];
+        out[i] = make_double2(x.x - y.x, x.y - y.y);
+    }
+}
+
+void launch_sub(const double *a, const double *b, double *out, int64_t n, hipStream_t st)
+{
+    const int64_t n2 = n / 2, blocks = (n2 + 255) / 256;
+    hipLaunchKernelGGL(k_sub, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st,
+                       reinterpret_cast<const double2 *>(a), reinterpret_cast<const double2 *>(b), reinterpret_cast<double2 *>(out), n2);
+}
+
 // ---- K cycle -----------------------------------------------------------------------------------------------
 
 constexpr int kKcycGroups = 128; // stage-1 workgroups of a K-cycle dot product

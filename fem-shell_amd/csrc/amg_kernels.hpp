@@ -41,6 +41,7 @@ void launch_pcg_norm(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);
 void launch_pcg_dots(const DeviceMatrix &m, const CgVectors &v, hipStream_t st);
 void launch_copy(const double *src, double *dst, int64_t n, const CgScalars *gate, hipStream_t st);
 void launch_add(const double *src, double *dst, int64_t n, hipStream_t st); // dst += src
+void launch_sub(const double *a, const double *b, double *out, int64_t n, hipStream_t st); // out = a - b
 
 // ---- K cycle: two steps of flexible CG on the coarse problem of a level ------------------------------------
 // sums[k] = a_k . b_k for up to three pairs (single workgroup finishes; vectors of n6 entries), then the

@@ -330,6 +330,47 @@ int amg_setup(femshell_ctx *c)
     return FEMSHELL_OK;
 }
 
+// ---- multigrid on row-partitioned contexts -------------------------------------------------------------------------
+// The hierarchy is the single-rank one, held by every rank: the context's shadow (api.cpp) assembles the whole K on the
+// rank's own GPU (a millisecond) and runs amg_setup on it, so all ranks compute the same levels from the same numbers and
+// the preconditioner -- hence the iteration count -- is the one of a single-rank solve.  Level 0 is the only level that
+// is split: its smoother runs on the rank's rows of the partitioned K (halo product), the transfer operators of the
+// shadow act on fine vectors in global numbering that are zero outside the rank's rows, and one all-reduce sums the
+// restricted residuals; the coarse levels (a ninth of the rows and below) run replicated, without communication.
+// What this costs: the coarse part of the cycle is not divided by the rank count (it is what bounds the speed-up), one
+// all-reduce of a level-1 vector per cycle, and HBM for the whole K and the hierarchy on every GPU (5 GB of 288 for
+// the 4M-triangle meshes).  Aggregates across the row partition with distributed coarse operators are what would lift
+// that bound.
+int amg_attach_shadow(femshell_ctx *c)
+{
+    femshell_ctx *sh = c->amg_shadow;
+    if (!sh || !sh->amg || !sh->amg->valid) return set_err(FEMSHELL_ERR_INVALID, "multigrid setup: no hierarchy on the shadow context");
+    if (sh->amg->levels.size() < 2)
+        return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid on a row-partitioned context needs at least two levels");
+    c->amg = sh->amg; // one hierarchy, two owners
+    Amg &H = *c->amg;
+    H.dist.reset(new AmgDist());
+    AmgDist &D = *H.dist;
+    const Plan &p = c->plan;
+    hipStream_t st = c->stream;
+    const size_t n6 = (size_t)p.n_pad * 6, n6g = (size_t)(p.n_pad + p.n_ghost) * 6;
+    FS_HIP(D.x0.alloc(n6g));
+    FS_HIP(D.d0.alloc(n6g));
+    FS_HIP(D.r0.alloc(n6));
+    FS_HIP(D.q0.alloc(n6));
+    FS_HIP(D.x0.zero(st));
+    FS_HIP(D.d0.zero(st));
+    FS_HIP(D.r0.zero(st));
+    FS_HIP(D.q0.zero(st));
+    const size_t g6 = (size_t)H.levels[0]->n_pad * 6; // fine vectors in global numbering
+    FS_HIP(D.gfine.alloc(g6));
+    FS_HIP(D.gcorr.alloc(g6));
+    FS_HIP(D.gfine.zero(st)); // stays zero outside the rank's rows
+    FS_HIP(D.gcorr.zero(st));
+    FS_HIP(hipStreamSynchronize(st));
+    return FEMSHELL_OK;
+}
+
 namespace {
 
 struct Cycle {
@@ -397,6 +438,82 @@ struct Cycle {
     }
 };
 
+// level 0 of a row-partitioned context (amg_attach_shadow); everything below level 0 is `coarse`, the shadow's cycle
+struct DistCycle {
+    femshell_ctx *c;
+    Amg &H;
+    const CgScalars *gate;
+    hipStream_t st;
+    int rc = FEMSHELL_OK;
+
+    // y = K x, halo exchange beside the interior slices (symmetric storage: the direct part; the consumer collects the
+    // transposed products)
+    void product(double *x, double *y, bool defer)
+    {
+        if (rc) return;
+        CgVectors vv;
+        vv.s = const_cast<CgScalars *>(gate);
+        int np = 0;
+        rc = spmv_with_halo(c, vv, x, y, nullptr, &np, defer);
+    }
+    // r0 = b - K x
+    void residual(const double *b, double *x)
+    {
+        AmgDist &D = *H.dist;
+        const DeviceMatrix &A = c->dm;
+        if (A.symmetric) {
+            product(x, D.r0.p, true);
+            launch_sym_gather(A, D.r0.p, b, -1.0, gate, st);
+        } else {
+            product(x, D.q0.p, false);
+            launch_sub(b, D.q0.p, D.r0.p, 6ll * A.n_pad, st);
+        }
+    }
+    void smooth(const double *b, double *x, bool zero_guess)
+    {
+        AmgLevel &L = *H.levels[0];
+        AmgDist &D = *H.dist;
+        const DeviceMatrix &A = c->dm;
+        const double *rcur = b;
+        if (!zero_guess) {
+            residual(b, x);
+            rcur = D.r0.p;
+        }
+        launch_cheb_start(A, rcur, D.d0.p, x, L.inv_theta, !zero_guess, gate, st);
+        for (size_t k = 0; k < L.cheb_a.size(); k++) {
+            product(D.d0.p, D.q0.p, A.symmetric != 0);
+            launch_cheb_step(A, rcur, D.q0.p, D.r0.p, D.d0.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, A.symmetric != 0);
+            rcur = D.r0.p;
+        }
+    }
+    int cycle(const double *b, double *z)
+    {
+        AmgLevel &L = *H.levels[0], &N = *H.levels[1];
+        AmgDist &D = *H.dist;
+        const Plan &p = c->plan;
+        const int64_t own6 = 6ll * p.n_own, off = 6ll * p.row_begin;
+        double *x = D.x0.p;
+        smooth(b, x, true);
+        residual(b, x);
+        // restriction: the rank's rows of the residual in a global fine vector, the shadow's R, sum over the ranks
+        launch_copy(D.r0.p, D.gfine.p + off, own6, gate, st);
+        launch_spmv(L.R.dm, D.gfine.p, N.b.p, nullptr, gate, st);
+        if (rc) return rc;
+        std::string e;
+        if (!comm_allreduce_sum(c->comm, N.b.p, (int)(6ll * N.n_pad), st, &e)) return set_err(FEMSHELL_ERR_COMM, e);
+        Cycle coarse{c->amg_shadow, H, gate, st};
+        const bool next_is_coarsest = H.levels.size() == 2;
+        if (H.opt.cycle == FEMSHELL_CYCLE_K && !next_is_coarsest) coarse.kcycle(1);
+        else coarse.cycle(1, N.b.p, N.x.p);
+        // prolongation: the shadow's P into a global fine vector, the rank's rows of it onto x
+        launch_spmv(L.P.dm, N.x.p, D.gcorr.p, nullptr, gate, st);
+        launch_add(D.gcorr.p + off, x, own6, st);
+        smooth(b, x, false);
+        launch_copy(x, z, 6ll * p.n_pad, gate, st);
+        return rc;
+    }
+};
+
 // host side of the stopping test
 struct AmgPoll {
     int32_t next_check = 1, step = 1;
@@ -416,6 +533,13 @@ struct AmgPoll {
 
 int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate)
 {
+    if (c->amg->dist) {
+        DistCycle dc{c, *c->amg, gate, c->stream};
+        const int rc = dc.cycle(r, z);
+        if (rc) return rc;
+        FS_HIP(hipGetLastError());
+        return FEMSHELL_OK;
+    }
     Cycle cy{c, *c->amg, gate, c->stream};
     cy.cycle(0, r, z);
     FS_HIP(hipGetLastError());
@@ -455,6 +579,8 @@ int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, do
             if (rc) return rc;
         } else {
             // correction equation: right-hand side = residual of the accumulated solution, evaluated in double-double
+            rc = halo_exchange(c, c->xacc.p, st); // no-op without a communicator
+            if (rc) return rc;
             launch_residual_dd(m, c->xacc.p, v0.b, c->rres.p, st);
             v.b = c->rres.p;
             launch_pcg_init(m, v, st); // x = 0, r = rhs, partial sums of r.r
@@ -481,8 +607,11 @@ int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, do
         poll.next_check = it + 1;
         bool finished = false;
         for (; it < max_it; it++) {
-            launch_spmv(m, v.p, v.q, v.partials, v.s, st);
-            rc = scalar_step(c, v, 1, CG_PHASE_ALPHA, rtol);
+            int n_partials = 0;
+            if (c->comm.active()) rc = spmv_with_halo(c, v, v.p, v.q, v.partials, &n_partials, false);
+            else launch_spmv(m, v.p, v.q, v.partials, v.s, st);
+            if (rc) return rc;
+            rc = scalar_step(c, v, 1, CG_PHASE_ALPHA, rtol, n_partials);
             if (rc) return rc;
             launch_pcg_update(m, v, st);
             rc = scalar_step(c, v, 1, CG_PHASE_FLEX_CONV, rtol);
@@ -513,7 +642,8 @@ int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, do
         }
         if (hs.done != 1 || rtol <= 0.0) return FEMSHELL_OK; // iteration limit or breakdown: no refinement
         if (pass == 0) {
-            FS_HIP(c->xacc.alloc((size_t)n6));
+            FS_HIP(c->xacc.alloc((size_t)n6 + 6 * (size_t)m.n_ghost)); // ghost space: input of the double-double residual
+            FS_HIP(c->xacc.zero(st));
             FS_HIP(c->rres.alloc((size_t)n6));
             launch_copy(v.x, c->xacc.p, n6, nullptr, st);
         }

@@ -6,6 +6,7 @@
 #include "reorder.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -183,6 +184,47 @@ int do_jacobi(femshell_ctx *c)
     return FEMSHELL_OK;
 }
 
+double wall_s()
+{
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+// Multigrid on a context with a communicator (amg_solve.cpp, "multigrid on row-partitioned contexts"): a single-rank
+// context on the same device gets the whole mesh and the Dirichlet set, assembles K, and builds the hierarchy this
+// context then shares.
+int amg_setup_through_shadow(femshell_ctx *c)
+{
+    if (c->mesh_xyz.empty()) return set_err(FEMSHELL_ERR_INVALID, "multigrid setup: the context holds no copy of the mesh");
+    if (c->amg_shadow) {
+        (void)femshell_destroy(c->amg_shadow);
+        c->amg_shadow = nullptr;
+    }
+    femshell_config cfg = c->cfg;
+    cfg.rank = 0;
+    cfg.world_size = 1;
+    cfg.device = c->device;
+    cfg.flags &= ~(uint32_t)(FEMSHELL_REORDER_MORTON | FEMSHELL_REORDER_RCM); // the copy of the mesh is in internal numbering
+    femshell_ctx *sh = nullptr;
+    int rc = femshell_create(&cfg, &sh);
+    if (rc) return rc;
+    c->amg_shadow = sh;
+    sh->cfg.flags = cfg.flags; // (femshell_create reads FEMSHELL_REORDER from the environment)
+    sh->mc = c->mc;
+    const int32_t nn = (int32_t)(c->mesh_xyz.size() / 3);
+    rc = femshell_set_mesh(sh, nn, c->mesh_xyz.data(), (int32_t)(c->mesh_tri.size() / 3), c->mesh_tri.data(),
+                           (int32_t)(c->mesh_quad.size() / 4), c->mesh_quad.data());
+    if (!rc) rc = femshell_set_dirichlet(sh, nn, nullptr, c->dmask_global.data());
+    if (!rc) rc = do_assemble(sh);
+    if (!rc) rc = do_jacobi(sh);
+    if (rc) return rc;
+    sh->pc = c->pc;
+    rc = amg_setup(sh);
+    if (rc) return rc;
+    FS_HIP(hipStreamSynchronize(sh->stream));
+    return amg_attach_shadow(c);
+}
+
 } // namespace
 
 namespace femshell {
@@ -326,7 +368,7 @@ int femshell_create(const femshell_config *cfg, femshell_ctx **out)
     c->mc.pad = 0;
     {
         const char *e = getenv("FEMSHELL_PC");
-        const bool amg = e && (std::strcmp(e, "amg") == 0 || std::strcmp(e, "gamg") == 0) && cfg->world_size == 1;
+        const bool amg = e && (std::strcmp(e, "amg") == 0 || std::strcmp(e, "gamg") == 0);
         (void)femshell_pc_defaults(amg ? FEMSHELL_PC_AMG : FEMSHELL_PC_BLOCK_JACOBI, &c->pc);
     }
     *out = c;
@@ -338,6 +380,9 @@ int femshell_destroy(femshell_ctx *c)
     if (!c) return FEMSHELL_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->amg.reset();
+    if (c->amg_shadow) (void)femshell_destroy(c->amg_shadow);
+    c->amg_shadow = nullptr;
     comm_destroy(c->comm);
     if (c->halo_stream) (void)hipStreamSynchronize(c->halo_stream);
     if (c->ev_p_ready) (void)hipEventDestroy(c->ev_p_ready);
@@ -415,6 +460,15 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     }
     if (!build_plan(n_nodes, xyz, n_tri, tri, n_quad, quad, c->cfg.rank, c->cfg.world_size, &c->plan, &e, default_symmetric_storage()))
         return set_err(FEMSHELL_ERR_MESH, "femshell_set_mesh: " + e);
+    if (c->amg_shadow) { // belongs to the previous mesh
+        (void)femshell_destroy(c->amg_shadow);
+        c->amg_shadow = nullptr;
+    }
+    if (c->comm.active()) { // the multigrid preconditioner of a row-partitioned context builds its hierarchy from the whole mesh
+        c->mesh_xyz.assign(xyz, xyz + 3ll * n_nodes);
+        c->mesh_tri.assign(tri, tri + 3ll * n_tri);
+        c->mesh_quad.assign(quad, quad + 4ll * n_quad);
+    }
     const Plan &p = c->plan;
     hipStream_t st = c->stream;
     FS_HIP(c->xyz.upload(p.xyz_local, st));
@@ -604,8 +658,6 @@ int femshell_set_preconditioner(femshell_ctx *c, const femshell_pc_options *opt)
     if (opt->type != FEMSHELL_PC_BLOCK_JACOBI && opt->type != FEMSHELL_PC_AMG)
         return set_err(FEMSHELL_ERR_INVALID, "femshell_set_preconditioner: unknown preconditioner type");
     if (opt->type == FEMSHELL_PC_AMG) {
-        if (c->cfg.world_size != 1)
-            return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_set_preconditioner: the multigrid preconditioner serves single-rank contexts only");
         if ((opt->cycle != FEMSHELL_CYCLE_V && opt->cycle != FEMSHELL_CYCLE_K) || opt->smoother_degree < 1 || opt->smoother_degree > 16 ||
             opt->coarse_degree < 1 || opt->coarse_degree > 16 || opt->coarsest_nodes < 1 || opt->coarsest_nodes > 680 ||
             opt->max_levels < 2 || opt->max_levels > 32 || !(opt->eig_ratio > 1.0) || opt->refine_passes < 0 || opt->refine_passes > 4)
@@ -699,14 +751,22 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
     double pc_setup_s = 0.0;
     const bool use_amg = c->pc.type == FEMSHELL_PC_AMG;
     if (use_amg && (!c->amg || !c->amg->valid)) {
-        if (c->cfg.world_size != 1 || c->comm.active())
-            return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_solve: the multigrid preconditioner serves single-rank contexts only");
-        rc = amg_setup(c);
-        if (rc) {
-            c->amg.reset();
-            return rc;
+        if (c->comm.active()) {
+            const double t0 = wall_s();
+            rc = agree_status(c, amg_setup_through_shadow(c), "multigrid setup");
+            if (rc) {
+                c->amg.reset();
+                return rc;
+            }
+            pc_setup_s = wall_s() - t0;
+        } else {
+            rc = amg_setup(c);
+            if (rc) {
+                c->amg.reset();
+                return rc;
+            }
+            pc_setup_s = c->amg->setup_seconds;
         }
-        pc_setup_s = c->amg->setup_seconds;
     }
     hipStream_t st = c->stream;
     FS_HIP(c->hist.alloc((size_t)std::min<int64_t>(std::max(max_it, 1), 1 << 22))); // history of the first 4M iterations

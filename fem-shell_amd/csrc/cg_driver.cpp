@@ -28,7 +28,7 @@ int halo_exchange(femshell_ctx *c, double *p, hipStream_t st)
 // (xin: input vector with ghost space, yout = K xin, partial sums of xin.yout from partials[0] on)
 // (defer_gather: symmetric storage, the caller's next kernel collects the transposed products -- k_cg_update<true>)
 int spmv_with_halo(femshell_ctx *c, const CgVectors &v, double *xin, double *yout, double *partials, int *n_partials,
-                   bool defer_gather = false)
+                   bool defer_gather)
 {
     hipStream_t st = c->stream;
     *n_partials = 0;

@@ -116,6 +116,12 @@ struct femshell_ctx {
 
     femshell_pc_options pc{};           // preconditioner of femshell_solve (block-Jacobi unless set otherwise)
     std::shared_ptr<femshell::Amg> amg; // hierarchy of the multigrid preconditioner, rebuilt when K changes
+    // contexts with a communicator: the mesh as it was handed over (internal numbering), and a single-rank context on
+    // the same device that assembles the whole K and owns the hierarchy all ranks hold a copy of (amg_solve.cpp,
+    // "multigrid on row-partitioned contexts")
+    std::vector<double> mesh_xyz;
+    std::vector<int32_t> mesh_tri, mesh_quad;
+    femshell_ctx *amg_shadow = nullptr;
 
     double last_assemble_s = 0.0, last_setup_s = 0.0;
     std::vector<double> hist_host;
@@ -127,6 +133,11 @@ namespace femshell {
 CgVectors cg_vectors(femshell_ctx *c);
 // pack + grouped send/recv of the ghost entries of vec (owned | padding | ghosts) on stream st
 int halo_exchange(femshell_ctx *c, double *vec, hipStream_t st);
+// yout = K xin with the halo exchange beside the interior slices (xin carries ghost space); partial sums of xin.yout when
+// partials != nullptr (*n_partials of them, 0 = slice_grid); defer_gather: symmetric storage, the caller's next kernel
+// collects the transposed products
+int spmv_with_halo(femshell_ctx *c, const CgVectors &v, double *xin, double *yout, double *partials, int *n_partials,
+                   bool defer_gather = false);
 // the two recurrences (cg_driver.cpp); the CG state is left in the context's vectors and scalars
 int cg_classic(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it);
 int cg_single_reduction(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it);

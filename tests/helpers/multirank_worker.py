@@ -51,6 +51,9 @@ def main():
     fs.set_mesh(m.xyz, m.tri, m.quad)
     fs.set_dirichlet(m.dirichlet_mask())
     fs.set_loads(m.loads)
+    pc = os.environ.get("FEMSHELL_TEST_PC", "")
+    if pc == "amg":
+        fs.set_preconditioner("amg", coarsest_nodes=60)
     if kind == "panel_bad":
         # every rank must come back with an error (none may hang in a collective of the CG loop)
         try:
@@ -67,7 +70,8 @@ def main():
     fs.set_loads(2.0 * m.loads)
     u2, info2 = fs.solve(rtol=1e-11, max_it=100000)
     np.savez(out_file, u=u, iterations=info["iterations"], converged=info["converged"], begin=b, end=e,
-             true_res=info["true_rel_residual"], u2=u2, converged2=info2["converged"], iterations2=info2["iterations"])
+             true_res=info["true_rel_residual"], u2=u2, converged2=info2["converged"], iterations2=info2["iterations"],
+             levels=info["amg_levels"])
     fs.close()
 
 

@@ -202,15 +202,6 @@ def test_hierarchy_is_reused_until_the_matrix_changes():
     fs.close()
 
 
-def test_multigrid_is_refused_on_multi_rank_contexts():
-    ensure_built()
-    fs = pkg.FemShell(0.3, 1.0, 1.0, device=0, rank=0, world_size=2)
-    with pytest.raises(pkg.FemShellError) as e:
-        fs.set_preconditioner("amg")
-    assert e.value.code == -7
-    fs.close()
-
-
 def test_restriction_rows_wider_than_the_lds_panel():
     """On this Delaunay mesh (slivers on the hull, Morton numbering) a coarse node of level 1 collects from 162 fine
     nodes: k_spmv stages the x entries of at most 64 block columns in LDS at a time and goes through wider slices in
@@ -232,3 +223,30 @@ def test_restriction_rows_wider_than_the_lds_panel():
     r, c, v, F = fs.export_bsr()
     u_ref = oracle.refined_solve(r, c, v, F)
     assert np.linalg.norm(u.ravel() - u_ref) <= 1e-4 * np.linalg.norm(u_ref)  # kappa ~ 1e13 on this mesh
+
+
+def test_multigrid_through_a_one_rank_rccl_communicator(monkeypatch):
+    # the row-partitioned multigrid path (shadow context, halo product in the smoother, all-reduce of the restricted
+    # residual) with the real librccl, on the one GPU a test box has: same iterations and solution as without a communicator
+    m = meshes.structured(40, 36, 0, 0, 10, 9, kind="t", ul_lr=True, bcids=(0, 0, 0, 0), factor=300.0, loading=2)
+    m.xyz[:, 2] = 0.4 * np.sin(0.5 * m.xyz[:, 0]) * np.cos(0.4 * m.xyz[:, 1])
+    ref = pkg.FemShell(0.3, 1e7, 0.1)
+    ref.set_mesh(m.xyz, m.tri)
+    ref.set_dirichlet(m.dirichlet_mask())
+    ref.set_loads(m.loads)
+    ref.set_preconditioner("amg", coarsest_nodes=60)
+    u0, i0 = ref.solve(rtol=1e-11, max_it=2000)
+    monkeypatch.setenv("FEMSHELL_FORCE_COMM", "1")
+    fs = pkg.FemShell(0.3, 1e7, 0.1, rank=0, world_size=1)
+    fs.comm_init(pkg.comm_unique_id())
+    monkeypatch.delenv("FEMSHELL_FORCE_COMM")
+    fs.set_mesh(m.xyz, m.tri)
+    fs.set_dirichlet(m.dirichlet_mask())
+    fs.set_loads(m.loads)
+    fs.set_preconditioner("amg", coarsest_nodes=60)
+    u1, i1 = fs.solve(rtol=1e-11, max_it=2000)
+    assert i0["converged"] == 1 and i1["converged"] == 1 and i1["amg_levels"] == i0["amg_levels"] >= 2
+    assert abs(i1["iterations"] - i0["iterations"]) <= 2
+    assert np.linalg.norm(u1 - u0) <= 1e-10 * np.linalg.norm(u0)
+    u2, i2 = fs.solve(rtol=1e-11, max_it=2000)  # hierarchy reused
+    assert i2["pc_setup_seconds"] == 0.0 and np.array_equal(u2, u1)

@@ -16,11 +16,13 @@ FAKE_DIR = os.path.join(ROOT, "tests", "helpers", "fake_rccl")
 WORKER = os.path.join(ROOT, "tests", "helpers", "multirank_worker.py")
 
 
-def run_ranks(world, kind, tmp_path, overlap=True, single_reduction=None):
+def run_ranks(world, kind, tmp_path, overlap=True, single_reduction=None, pc=None):
     ensure_built()
     subprocess.check_call(["make", "-C", FAKE_DIR, "-s"])
     env = dict(os.environ, FEMSHELL_RCCL_LIB=os.path.join(FAKE_DIR, "libfake_rccl.so"),
                FEMSHELL_HALO_OVERLAP="1" if overlap else "0")
+    if pc is not None:
+        env["FEMSHELL_TEST_PC"] = pc
     if single_reduction is not None:  # default: multi-rank solves use the single-reduction recurrence
         env["FEMSHELL_CG_SINGLE_REDUCTION"] = "1" if single_reduction else "0"
     uid = str(tmp_path / ("uid_%d_%s.npy" % (world, kind)))
@@ -67,6 +69,36 @@ def test_partitioned_solve_on_one_gpu_matches_single_rank(world, kind, tmp_path)
     assert covered.all()
     err = np.linalg.norm(ranks[0]["u"] - single["u"]) / np.linalg.norm(single["u"])
     assert err < 1e-8, err  # two CG runs with different summation order on an ill-conditioned system
+
+
+@pytest.mark.parametrize("world,kind", [(2, "panel"), (3, "cylinder")])
+def test_multigrid_on_a_row_partitioned_context_is_the_single_rank_preconditioner(world, kind, tmp_path):
+    # every rank holds the single-rank hierarchy (built by its shadow context from the whole K); level 0 is smoothed on
+    # the rank's rows with the halo product, the restricted residuals are summed by an all-reduce: the same
+    # preconditioner as on one rank, so the same iteration count and the same solution
+    (tmp_path / "one").mkdir()
+    (tmp_path / "many").mkdir()
+    (tmp_path / "jac").mkdir()
+    single = run_ranks(1, kind, tmp_path / "one", pc="amg")[0]
+    ranks = run_ranks(world, kind, tmp_path / "many", pc="amg")
+    jacobi = run_ranks(1, kind, tmp_path / "jac")[0]
+    assert single["converged"] == 1 and int(single["levels"]) >= 2
+    assert int(single["iterations"]) * 5 < int(jacobi["iterations"])  # what the preconditioner is for
+    covered = np.zeros(single["u"].shape[0], dtype=bool)
+    for r in ranks:
+        assert r["converged"] == 1 and int(r["levels"]) == int(single["levels"])
+        assert abs(int(r["iterations"]) - int(single["iterations"])) <= 2, (int(r["iterations"]), int(single["iterations"]))
+        assert int(r["iterations"]) == int(ranks[0]["iterations"])
+        covered[int(r["begin"]):int(r["end"])] = True
+        np.testing.assert_array_equal(r["u"], ranks[0]["u"])
+        assert r["converged2"] == 1
+        assert np.linalg.norm(r["u2"] - 2.0 * r["u"]) <= 1e-9 * np.linalg.norm(r["u2"])
+        assert float(r["true_res"]) == float(ranks[0]["true_res"])
+    assert covered.all()
+    err = np.linalg.norm(ranks[0]["u"] - single["u"]) / np.linalg.norm(single["u"])
+    assert err < 1e-10, err  # both went through the refinement pass with the double-double residual
+    errj = np.linalg.norm(ranks[0]["u"] - jacobi["u"]) / np.linalg.norm(jacobi["u"])
+    assert errj < 1e-8, errj
 
 
 def test_rank_local_failure_is_reported_by_every_rank(tmp_path):
