@@ -149,3 +149,26 @@ def test_real_rccl_accepts_the_stream_usage_of_the_cg_driver():
                          timeout=120)
     assert out.returncode == 0, out.stdout.decode(errors="replace")[-2000:]
     assert b"two_streams ok" in out.stdout
+
+
+def test_bench_runs_row_partitioned_under_the_launcher_the_driver_uses(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` on the one GPU of the test box (both ranks on
+    device 0, fake transport): the N > 1 path of bench.py -- gloo control plane, unique id broadcast, barriers, max over
+    ranks, the multigrid time-to-solution through the shadow contexts -- prints one JSON line from rank 0."""
+    import json
+    ensure_built()
+    subprocess.check_call(["make", "-C", FAKE_DIR, "-s"])
+    env = dict(os.environ, FEMSHELL_RCCL_LIB=os.path.join(FAKE_DIR, "libfake_rccl.so"), FEMSHELL_BENCH_SAME_DEVICE="1",
+               MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nx", "96",
+           "--cg-iters", "5", "--jacobi-probe-iters", "0", "--no-cpu-baseline", "--no-full-parity"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
+    assert out.returncode == 0, out.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks_seen"] == 2 and d["value"] > 0 and d["cg_iters_per_s"] > 0
+    assert d["scaling"] == "strong" and d["config"]["parallelism"] == "row-partition x2"
+    tts = d["time_to_solution"]
+    assert tts["converged"] == 1 and tts["levels"] >= 2 and tts["iterations"] < 200
