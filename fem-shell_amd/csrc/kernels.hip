@@ -750,7 +750,18 @@ __global__ __launch_bounds__(192) void k_cg_update(DeviceMatrix m, CgVectors v)
         if (kGather) {
             const int Wi = m.in_width[sl], n = t / 6, j = t % 6;
             const int64_t ib = m.in_base[sl];
-            for (int k = 0; k < Wi; k++) {
+            // the slot indices of the first entries together, then their products together: one entry at a time is two
+            // dependent memory round trips per entry (same order of the additions either way)
+            int32_t slot4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) slot4[k] = (k < Wi) ? m.in_slots[ib + (int64_t)k * kSliceNodes + n] : -1;
+            double t4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) t4[k] = (slot4[k] >= 0) ? m.tbuf[(int64_t)slot4[k] * 6 + j] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (slot4[k] >= 0) qv += t4[k];
+            for (int k = 4; k < Wi; k++) {
                 const int32_t slot = m.in_slots[ib + (int64_t)k * kSliceNodes + n];
                 if (slot >= 0) qv += m.tbuf[(int64_t)slot * 6 + j];
             }
