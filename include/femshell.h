@@ -124,7 +124,9 @@ typedef struct femshell_solve_info {
  * count grows with the element count.  FEMSHELL_PC_AMG is a smoothed-aggregation multigrid
  * (rigid-body modes, Chebyshev/block-Jacobi smoothing, V or K cycle) around which the solve
  * runs a flexible CG: the answer a user of `-pc_type gamg` expects, with iteration counts
- * that stay near 100 up to the 4M-triangle meshes.  Single-rank contexts only for now.
+ * that stay near 100 up to the 4M-triangle meshes.  On row-partitioned contexts every rank
+ * holds the single-rank hierarchy (built on its own GPU from the whole K) and smooths its own
+ * rows: same iteration counts as on one rank, one all-reduce of a coarse vector per cycle.
  * The environment variable FEMSHELL_PC=amg|jacobi sets the default of new contexts. */
 typedef enum femshell_pc_type { FEMSHELL_PC_BLOCK_JACOBI = 0, FEMSHELL_PC_AMG = 1 } femshell_pc_type;
 typedef enum femshell_cycle { FEMSHELL_CYCLE_V = 0, FEMSHELL_CYCLE_K = 1 } femshell_cycle;
