@@ -56,7 +56,13 @@ void parallel_chunks(int64_t n, const std::function<void(int64_t, int64_t)> &f, 
 int host_threads();
 
 // rigid-body modes: B[n][6 dofs][6 modes] about the centroid of xyz; rows of fixed dofs (dmask bit v) are zero
-void rigid_body_modes(int32_t n, const double *xyz, const uint8_t *dmask, std::vector<double> *B);
+// normals (optional, n x 3 unit vectors or zeros): the rotational parts of the three rotation modes are projected onto
+// the tangent plane of each node (see amg_setup.cpp)
+void rigid_body_modes(int32_t n, const double *xyz, const uint8_t *dmask, std::vector<double> *B, const double *normals = nullptr);
+// area-weighted unit normals of the nodes [0, n) from the elements of a mesh in the same numbering (tri: 3 ids, quad: 4 ids
+// per element; nodes >= n are neighbours whose coordinates are in xyz too)
+void node_normals(int32_t n, const double *xyz, int64_t n_tri, const int32_t *tri, int64_t n_quad, const int32_t *quad,
+                  std::vector<double> *normals);
 
 // greedy distance-1 aggregation of the block graph of A; returns the number of aggregates
 int32_t aggregate_nodes(const Bsr &A, std::vector<int32_t> *agg);

@@ -185,7 +185,14 @@ int amg_setup(femshell_ctx *c)
     const bool keep_host = pl.nnz_blocks <= (int64_t)2000000; // inspection exports (tests) on small problems only
     Bsr A;
     std::vector<double> B;
-    rigid_body_modes(pl.n_own, pl.xyz_local.data(), c->dmask_global.data() + pl.row_begin, &B);
+    {
+        // FEMSHELL_AMG_PLAIN_RBM=1: the six plain rigid-body modes (A/B runs)
+        static const bool plain = getenv("FEMSHELL_AMG_PLAIN_RBM") && atoi(getenv("FEMSHELL_AMG_PLAIN_RBM")) != 0;
+        std::vector<double> normals;
+        if (!plain)
+            node_normals(pl.n_own, pl.xyz_local.data(), pl.n_ltri(), pl.tri_local.data(), pl.n_lquad(), pl.quad_local.data(), &normals);
+        rigid_body_modes(pl.n_own, pl.xyz_local.data(), c->dmask_global.data() + pl.row_begin, &B, plain ? nullptr : normals.data());
+    }
     int rc = FEMSHELL_OK;
     int first_level = 0;
     if (!host_only && pl.n_own > opt.coarsest_nodes && opt.max_levels > 1) {

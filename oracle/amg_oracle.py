@@ -15,7 +15,29 @@ import numpy as np
 import scipy.sparse as sp
 
 
-def rigid_body_modes(xyz, dmask):
+def node_normals(xyz, tri=None, quad=None):
+    """Area-weighted unit normals of the nodes (csrc/amg_setup.cpp: node_normals)."""
+    xyz = np.asarray(xyz, dtype=np.float64).reshape(-1, 3)
+    N = np.zeros_like(xyz)
+    if tri is not None and len(tri):
+        t = np.asarray(tri).reshape(-1, 3)
+        w = np.cross(xyz[t[:, 1]] - xyz[t[:, 0]], xyz[t[:, 2]] - xyz[t[:, 0]])
+        for i in range(3):
+            np.add.at(N, t[:, i], w)
+    if quad is not None and len(quad):
+        q = np.asarray(quad).reshape(-1, 4)
+        w = np.cross(xyz[q[:, 1]] - xyz[q[:, 0]], xyz[q[:, 2]] - xyz[q[:, 0]]) + np.cross(xyz[q[:, 2]] - xyz[q[:, 0]], xyz[q[:, 3]] - xyz[q[:, 0]])
+        for i in range(4):
+            np.add.at(N, q[:, i], w)
+    ln = np.linalg.norm(N, axis=1)
+    ok = ln > 0
+    N[ok] /= ln[ok, None]
+    return N
+
+
+def rigid_body_modes(xyz, dmask, normals=None):
+    """normals: the rotational part of the rotation modes is projected onto the tangent plane of each node (the drilling
+    stiffness penalises the rotation about the normal without coupling it to the in-plane displacements)."""
     xyz = np.asarray(xyz, dtype=np.float64).reshape(-1, 3)
     n = len(xyz)
     c = xyz - xyz.sum(axis=0) / n
@@ -26,6 +48,8 @@ def rigid_body_modes(xyz, dmask):
     B[:, 1, 3], B[:, 2, 3] = -z, y   # rotation about x: u = (0,-z,y)
     B[:, 0, 4], B[:, 2, 4] = z, -x   # about y: (z,0,-x)
     B[:, 0, 5], B[:, 1, 5] = -y, x   # about z: (-y,x,0)
+    if normals is not None:
+        B[:, 3:6, 3:6] -= normals[:, :, None] * normals[:, None, :]
     if dmask is not None:
         dmask = np.asarray(dmask)
         for v in range(6):
@@ -159,11 +183,13 @@ class Level:
     pass
 
 
-def setup(A, xyz, dmask, lams=None, coarsest_nodes=200, max_levels=12, eig_ratio=30.0, degree=2, coarse_degree=4):
+def setup(A, xyz, dmask, lams=None, coarsest_nodes=200, max_levels=12, eig_ratio=30.0, degree=2, coarse_degree=4,
+          tri=None, quad=None):
     """lams: upper bounds of the spectrum per level as the library reports them (femshell_amg_level); computed
-    here (1.1 x power iteration) when None."""
+    here (1.1 x power iteration) when None.  tri / quad: connectivity for the node normals of rigid_body_modes."""
     levels = []
-    B = rigid_body_modes(xyz, dmask)
+    normals = node_normals(xyz, tri, quad) if (tri is not None or quad is not None) else None
+    B = rigid_body_modes(xyz, dmask, normals)
     A = A.tobsr((6, 6))
     while True:
         L = Level()

@@ -74,7 +74,8 @@ def test_hierarchy_and_iteration_counts_follow_the_restatement(cycle):
     rg, cg, vg, Fg = fs.export_bsr()
     A = _bsr(rg, cg, vg, m.n_nodes)
     # the restatement with the library's spectral bounds (its power iteration starts from another vector)
-    levels = amg_oracle.setup(A, m.xyz, m.dirichlet_mask(), lams=[l["lambda_max"] for l in lv], coarsest_nodes=60)
+    levels = amg_oracle.setup(A, m.xyz, m.dirichlet_mask(), lams=[l["lambda_max"] for l in lv], coarsest_nodes=60,
+                              tri=m.tri, quad=m.quad)
     assert [L.n for L in levels] == [l["n_nodes"] for l in lv]
     for li, L in enumerate(levels[:-1]):
         ex = fs.amg_export(li)
@@ -250,3 +251,31 @@ def test_multigrid_through_a_one_rank_rccl_communicator(monkeypatch):
     assert np.linalg.norm(u1 - u0) <= 1e-10 * np.linalg.norm(u0)
     u2, i2 = fs.solve(rtol=1e-11, max_it=2000)  # hierarchy reused
     assert i2["pc_setup_seconds"] == 0.0 and np.array_equal(u2, u1)
+
+
+def test_flap_loaded_in_its_plane_converges_like_the_plates():
+    # the coupled example's structure: a 0.1 x 1 flap in the x-z plane, bottom edge clamped, forces along x (in its plane).
+    # The soft modes there are rigid rotations with NO nodal rotation about the normal (the drilling stiffness is an
+    # uncoupled penalty): with the plain rigid-body modes as near-null space this took 715 iterations at this size
+    nx, nz = 50, 100
+    m = meshes.structured(nx, nz, 0, 0, 0.1, 1.0, kind="t", ul_lr=True, bcids=(2, 20, 2, 2), factor=1.0, loading=0, dead_axis="y")
+    loads = np.zeros((m.n_nodes, 6))
+    loads[np.abs(m.xyz[:, 0]) < 1e-12, 0] = 1.0
+    fs = pkg.FemShell(0.3, 1e6, 0.1)
+    fs.set_mesh(m.xyz, m.tri)
+    fs.set_dirichlet(m.dirichlet_mask())
+    fs.set_loads(loads)
+    fs.set_preconditioner("amg")
+    u, info = fs.solve(rtol=1e-11, max_it=2000)
+    assert info["converged"] == 1 and info["amg_levels"] >= 3
+    assert info["iterations"] < 120, info["iterations"]
+    mat = oracle.material(0.3, 1e6, 0.1)
+    r0, c0, v0, F0 = oracle.assemble(m.xyz, m.tri, m.quad, mat, m.dirichlet_mask(), loads)
+    rg, cg, vg, Fg = fs.export_bsr()
+    ud = oracle.refined_solve(rg, cg, vg, Fg)
+    assert np.linalg.norm(u.ravel() - ud) <= 1e-10 * np.linalg.norm(ud)
+    # the numpy restatement builds the same near-null space (tangent-plane projection with the node normals)
+    N = amg_oracle.node_normals(m.xyz, m.tri)
+    assert np.allclose(np.abs(N[:, 1]), 1.0) and np.allclose(N[:, [0, 2]], 0.0)
+    B = amg_oracle.rigid_body_modes(m.xyz, None, N)
+    assert np.allclose(B[:, 4, 4], 0.0) and np.allclose(B[:, 3, 3], 1.0) and np.allclose(B[:, 5, 5], 1.0)
