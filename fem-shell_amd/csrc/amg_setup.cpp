@@ -165,13 +165,52 @@ void rigid_body_modes(int32_t n, const double *xyz, const uint8_t *dmask, std::v
     });
 }
 
+// Order in which the greedy aggregation visits the nodes.  The passes below sweep the nodes in sequence, which gives
+// compact aggregates when the numbering itself sweeps the mesh (structured grids, Morton / Cuthill-McKee numberings) and
+// ragged ones when it does not: on a 500k-triangle Delaunay mesh with shuffled numbering the solve took 287 iterations
+// against 209 with a Cuthill-McKee numbering.  When the numbering is scattered (mean index distance of neighbours beyond
+// 8 sqrt(n)) the nodes are therefore visited in breadth-first order of the graph (components from their lowest node,
+// neighbours in column order); otherwise in index order.  Empty result = index order.
+void aggregation_order(const Bsr &A, std::vector<int32_t> *order)
+{
+    const int32_t n = A.nr;
+    order->clear();
+    if (n < 64) return;
+    double dist = 0.0;
+    for (int32_t i = 0; i < n; i++)
+        for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++) dist += std::fabs((double)A.col[q] - (double)i);
+    const int64_t edges = A.ptr[n];
+    if (edges == 0 || dist / (double)edges <= 8.0 * std::sqrt((double)n)) return;
+    order->reserve((size_t)n);
+    std::vector<char> seen((size_t)n, 0);
+    for (int32_t s0 = 0; s0 < n; s0++) {
+        if (seen[s0]) continue;
+        seen[s0] = 1;
+        size_t head = order->size();
+        order->push_back(s0);
+        while (head < order->size()) {
+            const int32_t i = (*order)[head++];
+            for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++) {
+                const int32_t j = A.col[q];
+                if (!seen[j]) {
+                    seen[j] = 1;
+                    order->push_back(j);
+                }
+            }
+        }
+    }
+}
+
 int32_t aggregate_nodes(const Bsr &A, std::vector<int32_t> *aggout)
 {
     const int32_t n = A.nr;
     std::vector<int32_t> agg((size_t)n, -1);
     int32_t na = 0;
+    std::vector<int32_t> order;
+    aggregation_order(A, &order);
     // pass 1: a node whose whole neighbourhood is free becomes the root of a new aggregate
-    for (int32_t i = 0; i < n; i++) {
+    for (int32_t v = 0; v < n; v++) {
+        const int32_t i = order.empty() ? v : order[(size_t)v];
         if (agg[i] >= 0) continue;
         const int64_t b = A.ptr[i], e = A.ptr[i + 1];
         if (e - b <= 1) continue;
@@ -183,7 +222,7 @@ int32_t aggregate_nodes(const Bsr &A, std::vector<int32_t> *aggout)
     }
     // pass 2: leftovers join the aggregate of their first aggregated neighbour (state of pass 1)
     std::vector<int32_t> agg2(agg);
-    for (int32_t i = 0; i < n; i++) {
+    for (int32_t i = 0; i < n; i++) { // (independent of the order: reads the state of pass 1 only)
         if (agg[i] >= 0) continue;
         for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++)
             if (agg[A.col[q]] >= 0) {
@@ -193,7 +232,8 @@ int32_t aggregate_nodes(const Bsr &A, std::vector<int32_t> *aggout)
     }
     agg.swap(agg2);
     // pass 3: what is still free forms aggregates of its own
-    for (int32_t i = 0; i < n; i++) {
+    for (int32_t v = 0; v < n; v++) {
+        const int32_t i = order.empty() ? v : order[(size_t)v];
         if (agg[i] >= 0) continue;
         for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++)
             if (agg[A.col[q]] < 0) agg[A.col[q]] = na;

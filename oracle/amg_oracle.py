@@ -57,12 +57,41 @@ def rigid_body_modes(xyz, dmask, normals=None):
     return B
 
 
+def aggregation_order(rowptr, colidx):
+    """Index order, or breadth-first order of the graph when the numbering is scattered (csrc/amg_setup.cpp)."""
+    n = len(rowptr) - 1
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    colidx = np.asarray(colidx, dtype=np.int64)
+    if n < 64 or rowptr[n] == 0:
+        return range(n)
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    if np.abs(colidx - rows).sum() / rowptr[n] <= 8.0 * np.sqrt(n):
+        return range(n)
+    seen = np.zeros(n, dtype=bool)
+    order = []
+    for s0 in range(n):
+        if seen[s0]:
+            continue
+        seen[s0] = True
+        order.append(s0)
+        head = len(order) - 1
+        while head < len(order):
+            i = order[head]
+            head += 1
+            for j in colidx[rowptr[i]:rowptr[i + 1]]:
+                if not seen[j]:
+                    seen[j] = True
+                    order.append(int(j))
+    return order
+
+
 def aggregate(rowptr, colidx):
     """Greedy distance-1 aggregation, three passes; returns (agg, n_aggregates)."""
     n = len(rowptr) - 1
     agg = -np.ones(n, dtype=np.int64)
     na = 0
-    for i in range(n):
+    order = aggregation_order(rowptr, colidx)
+    for i in order:
         if agg[i] >= 0:
             continue
         nb = colidx[rowptr[i]:rowptr[i + 1]]
@@ -80,7 +109,7 @@ def aggregate(rowptr, colidx):
         if len(cand):
             agg2[i] = cand[0]
     agg = agg2
-    for i in range(n):
+    for i in order:
         if agg[i] < 0:
             nb = colidx[rowptr[i]:rowptr[i + 1]]
             agg[nb[agg[nb] < 0]] = na
