@@ -284,6 +284,26 @@ def main():
         dist.broadcast(uid, src=0)
         fs.comm_init(uid.numpy())
     rccl_ranks = fs.comm_ranks()
+
+    # the boxes of the pool differ by about 10 % on bandwidth-bound kernels: a streaming copy of 2 x 1 GiB on this box,
+    # so that the roofline fractions of different runs can be compared
+    def device_copy_rate():
+        n = 1 << 27  # doubles
+        a = torch.empty(n, dtype=torch.float64, device="cuda")
+        b = torch.ones(n, dtype=torch.float64, device="cuda")
+        for _ in range(3):
+            a.copy_(b)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            a.copy_(b)
+        e1.record()
+        torch.cuda.synchronize()
+        rate = 10 * 2 * n * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
+        torch.cuda.empty_cache()
+        return rate
+    copy_gbs = device_copy_rate()
     t0 = time.perf_counter()
     fs.set_mesh(m.xyz, m.tri)
     setup_s = time.perf_counter() - t0
@@ -441,7 +461,7 @@ def main():
                        "parallelism": "row-partition x%d" % world, "cg_iters_per_step": args.cg_iters,
                        "preconditioner": "6x6 block-Jacobi", "symbolic_setup_s": setup_s,
                        "matrix_storage": "symmetric (diagonal + blocks of the lower-numbered row)" if symmetric else "full",
-                       "rccl_ranks_seen": rccl_ranks},
+                       "rccl_ranks_seen": rccl_ranks, "box_streaming_copy_gb_per_s": copy_gbs},
             "roofline": dict(roof(spmv_ms, spmv_bytes, spmv_kernel), kernel=spmv_kernel + " (q = K p, fused p.q" +
                              ("; symmetric storage: first phase, the update kernel collects the transposed products)" if symmetric else ")")),
             "roofline_assembly": dict(roof(asm_ms, asm_bytes, "k_assemble"), kernel="k_assemble"),
