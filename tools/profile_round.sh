@@ -24,3 +24,6 @@ rm -rf $out/${tag}_pmc_SQ_INSTS_VALU_FMA_F64 $out/${tag}_pmc_SQ_INSTS_VALU_MUL_F
 # keep the merged-back directory small: the raw counter tables are large
 rm -rf $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_stats
 tail -1 $out/${tag}_bench.json
+# the other two BASELINE workloads at full size (no CPU baseline, no direct-solve parity: those are in the panel run)
+timeout 400 python3 bench.py --workload cylinder --no-cpu-baseline --no-full-parity > $out/${tag}_bench_cylinder.json 2> $out/${tag}_bench_cylinder.err
+timeout 400 python3 bench.py --workload roof --no-cpu-baseline --no-full-parity --jacobi-probe-iters 0 > $out/${tag}_bench_roof.json 2> $out/${tag}_bench_roof.err
