@@ -573,7 +573,10 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     }
     c->all_begin.resize(p.world);
     c->all_end.resize(p.world);
-    for (int r = 0; r < p.world; r++) partition_rows(n_nodes, p.world, r, &c->all_begin[r], &c->all_end[r]);
+    for (int r = 0; r < p.world; r++) {
+        c->all_begin[r] = p.part_bounds[(size_t)r];
+        c->all_end[r] = p.part_bounds[(size_t)r + 1];
+    }
     c->dmask_global.assign((size_t)n_nodes, 0);
     c->loads_global.assign((size_t)n_nodes * 6, 0.0);
     rc = upload_node_data(c);

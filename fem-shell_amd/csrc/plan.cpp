@@ -15,15 +15,40 @@ void partition_rows(int32_t n_nodes, int world, int rank, int32_t *begin, int32_
     *end = (int32_t)std::min<int64_t>(s1 * kSliceNodes, n_nodes);
 }
 
-static int owner_of(int32_t node, int32_t n_nodes, int world)
+void partition_bounds(int32_t n_nodes, int32_t n_tri, const int32_t *tri, int32_t n_quad, const int32_t *quad, int world,
+                      std::vector<int32_t> *bounds)
 {
+    bounds->assign((size_t)world + 1, n_nodes);
+    (*bounds)[0] = 0;
+    if (world <= 1) return;
     const int64_t slices = ((int64_t)n_nodes + kSliceNodes - 1) / kSliceNodes;
-    const int64_t s = node / kSliceNodes;
-    // smallest r with slices*(r+1)/world > s
-    int r = (int)((s * world) / slices);
-    while (r + 1 < world && slices * (r + 1) / world <= s) r++;
-    while (r > 0 && slices * r / world > s) r--;
-    return r;
+    std::vector<int64_t> wsum((size_t)slices + 1, 0); // weight of slice s at wsum[s + 1], prefix sums below
+    auto count = [&](const int32_t *conn, int64_t n) {
+        for (int64_t q = 0; q < n; q++)
+            if (conn[q] >= 0 && conn[q] < n_nodes) wsum[(size_t)(conn[q] / kSliceNodes) + 1]++;
+    };
+    count(tri, 3ll * n_tri);
+    count(quad, 4ll * n_quad);
+    for (int64_t s = 0; s < slices; s++) {
+        const int64_t nodes_in = std::min<int64_t>(kSliceNodes, (int64_t)n_nodes - s * kSliceNodes);
+        wsum[(size_t)s + 1] += nodes_in + wsum[(size_t)s];
+    }
+    const int64_t total = wsum[(size_t)slices];
+    int64_t s = 0;
+    for (int r = 1; r < world; r++) {
+        const int64_t want = total * r / world;
+        while (s < slices && wsum[(size_t)s] < want) s++;
+        // never an empty rank while slices remain for the ranks behind
+        s = std::max<int64_t>(s, std::min<int64_t>(r, slices));
+        s = std::min<int64_t>(s, std::max<int64_t>(slices - (world - r), (*bounds)[(size_t)r - 1] / kSliceNodes));
+        (*bounds)[(size_t)r] = (int32_t)std::min<int64_t>(s * kSliceNodes, n_nodes);
+    }
+}
+
+static int owner_of(int32_t node, const std::vector<int32_t> &bounds)
+{
+    // the rank r with bounds[r] <= node < bounds[r + 1] (empty ranges skipped by upper_bound)
+    return (int)(std::upper_bound(bounds.begin(), bounds.end(), node) - bounds.begin()) - 1;
 }
 
 bool default_symmetric_storage()
@@ -66,7 +91,9 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     p.rank = rank;
     p.world = world;
     p.symmetric = symmetric;
-    partition_rows(n_nodes, world, rank, &p.row_begin, &p.row_end);
+    partition_bounds(n_nodes, n_tri, tri, n_quad, quad, world, &p.part_bounds);
+    p.row_begin = p.part_bounds[(size_t)rank];
+    p.row_end = p.part_bounds[(size_t)rank + 1];
     const int32_t g0 = p.row_begin, g1 = p.row_end;
     p.n_own = g1 - g0;
     p.n_pad = (p.n_own + kSliceNodes - 1) / kSliceNodes * kSliceNodes;
@@ -523,11 +550,11 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         // receive side: ghosts grouped by owner (ghost_global is ascending, ranges are contiguous)
         std::vector<HaloPeer> peers;
         for (int32_t q = 0; q < p.n_ghost;) {
-            const int r = owner_of(p.ghost_global[q], n_nodes, world);
+            const int r = owner_of(p.ghost_global[q], p.part_bounds);
             HaloPeer hp;
             hp.rank = r;
             hp.recv_offset = q;
-            while (q < p.n_ghost && owner_of(p.ghost_global[q], n_nodes, world) == r) q++;
+            while (q < p.n_ghost && owner_of(p.ghost_global[q], p.part_bounds) == r) q++;
             hp.recv_count = q - hp.recv_offset;
             peers.push_back(hp);
         }
@@ -538,7 +565,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             for (int32_t q = node_slot_ptr[a] + 1; q < node_slot_ptr[a + 1]; q++) {
                 const int32_t c = slot_col[q];
                 if (c >= g0 && c < g1) continue;
-                const int r = owner_of(c, n_nodes, world);
+                const int r = owner_of(c, p.part_bounds);
                 if (r != last && (send[r].empty() || send[r].back() != a)) send[r].push_back(a);
                 last = r;
             }

@@ -41,6 +41,7 @@ struct Plan {
     int32_t n_nodes = 0, n_tri = 0, n_quad = 0;
     int rank = 0, world = 1;
     int32_t row_begin = 0, row_end = 0; // owned global node range
+    std::vector<int32_t> part_bounds;   // world + 1 row boundaries of the partition (partition_bounds)
     // local numbering: owned [0,n_own), padding [n_own,n_pad), ghosts [n_pad, n_pad+n_ghost)
     int32_t n_own = 0, n_pad = 0, n_ghost = 0;
     std::vector<int32_t> ghost_global;  // ascending global ids
@@ -110,6 +111,11 @@ struct Plan {
 
 // owned node range of `rank` when n_nodes rows are split over `world` ranks
 void partition_rows(int32_t n_nodes, int world, int rank, int32_t *begin, int32_t *end);
+// Row boundaries of the `world` ranks, in whole slices of 32 nodes: contiguous ranges of the caller's numbering with equal
+// shares of the element incidences (valence + 1 per node: blocks of K per row, contributions to assemble).  On a regular
+// grid this is the equal split of partition_rows; on meshes with varying valence it balances work instead of rows.
+void partition_bounds(int32_t n_nodes, int32_t n_tri, const int32_t *tri, int32_t n_quad, const int32_t *quad, int world,
+                      std::vector<int32_t> *bounds);
 
 // Builds the plan.  Returns false and sets err on invalid input (index out of range,
 // repeated node in an element, too many elements).
