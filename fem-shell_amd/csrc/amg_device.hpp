@@ -55,7 +55,12 @@ struct AmgSetupStats {
 // space: they are inputs of the halo product) and two fine-level vectors in global numbering for the transfer operators
 struct AmgDist {
     DevBuf<double> x0, r0, d0, q0;
-    DevBuf<double> gfine, gcorr;
+    DevBuf<double> gfine;
+    // the rank's part of the shadow's level-0 transfer operators, as views of whole slices of their block ELL arrays:
+    // the rows of P of the rank's nodes; the rows of R (coarse nodes) between the lowest and the highest aggregate that
+    // the rank's nodes and their neighbours belong to -- all others get nothing from this rank's residual
+    DeviceMatrix Pown{}, Rsub{};
+    int32_t coarse_slice0 = 0;
 };
 
 struct Amg {

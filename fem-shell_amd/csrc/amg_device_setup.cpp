@@ -433,8 +433,8 @@ int amg_device_coarsen(femshell_ctx *c, AmgLevel &L, AmgLevel &next, const std::
             rc = download_vals(vP, &h, st);
             if (rc) return rc;
             ell_to_bsr(eP, h.data(), na, &L.hP);
-            L.agg = agg;
         }
+        L.agg = agg; // (row-partitioned contexts look up which coarse rows their nodes reach)
     }
     const int32_t nc_pad = eAc.n_pad;
     adopt(L.P, eP, dP, vP, nc_pad);

@@ -311,8 +311,8 @@ int amg_setup(femshell_ctx *c)
         if (keep_host) {
             L.hA = std::move(A);
             L.hP = std::move(P);
-            L.agg = std::move(agg);
         }
+        if (keep_host || l == 0) L.agg = std::move(agg);
         A = std::move(Ac);
         B.swap(Bc);
     }
@@ -371,12 +371,40 @@ int amg_attach_shadow(femshell_ctx *c)
     FS_HIP(D.d0.zero(st));
     FS_HIP(D.r0.zero(st));
     FS_HIP(D.q0.zero(st));
-    const size_t g6 = (size_t)H.levels[0]->n_pad * 6; // fine vectors in global numbering
+    const size_t g6 = (size_t)H.levels[0]->n_pad * 6; // a fine vector in global numbering
     FS_HIP(D.gfine.alloc(g6));
-    FS_HIP(D.gcorr.alloc(g6));
     FS_HIP(D.gfine.zero(st)); // stays zero outside the rank's rows
-    FS_HIP(D.gcorr.zero(st));
     FS_HIP(hipStreamSynchronize(st));
+    // the rank's views of the transfer operators (whole slices; row ranges of the partition are slice-aligned)
+    AmgLevel &L0 = *H.levels[0], &L1 = *H.levels[1];
+    if (p.row_begin % kSliceNodes != 0 || (int64_t)L0.agg.size() != (int64_t)L0.n)
+        return set_err(FEMSHELL_ERR_INVALID, "multigrid setup: the shadow hierarchy does not match the row partition");
+    const int32_t s0 = p.row_begin / kSliceNodes;
+    D.Pown = L0.P.dm;
+    D.Pown.slice_width = L0.P.dm.slice_width + s0;
+    D.Pown.slice_base = L0.P.dm.slice_base + s0;
+    D.Pown.n_slices = p.n_slices;
+    D.Pown.n_own = p.n_own;
+    D.Pown.n_pad = p.n_pad;
+    int32_t lo = L1.n, hi = -1;
+    auto see = [&](int32_t node) {
+        const int32_t I = L0.agg[(size_t)node];
+        lo = std::min(lo, I);
+        hi = std::max(hi, I);
+    };
+    for (int32_t a = p.row_begin; a < p.row_end; a++) see(a);
+    for (int32_t g : p.ghost_global) see(g);
+    if (hi < lo) {
+        lo = 0;
+        hi = 0;
+    }
+    const int32_t c0 = lo / kSliceNodes, c1 = hi / kSliceNodes + 1;
+    D.coarse_slice0 = c0;
+    D.Rsub = L0.R.dm;
+    D.Rsub.slice_width = L0.R.dm.slice_width + c0;
+    D.Rsub.slice_base = L0.R.dm.slice_base + c0;
+    D.Rsub.n_slices = c1 - c0;
+    D.Rsub.n_own = D.Rsub.n_pad = (c1 - c0) * kSliceNodes;
     return FEMSHELL_OK;
 }
 
@@ -497,16 +525,18 @@ struct DistCycle {
     }
     int cycle(const double *b, double *z)
     {
-        AmgLevel &L = *H.levels[0], &N = *H.levels[1];
+        AmgLevel &N = *H.levels[1];
         AmgDist &D = *H.dist;
         const Plan &p = c->plan;
         const int64_t own6 = 6ll * p.n_own, off = 6ll * p.row_begin;
         double *x = D.x0.p;
         smooth(b, x, true);
         residual(b, x);
-        // restriction: the rank's rows of the residual in a global fine vector, the shadow's R, sum over the ranks
+        // restriction: the rank's rows of the residual in a global fine vector, the coarse rows of the shadow's R that
+        // these rows reach, sum over the ranks
         launch_copy(D.r0.p, D.gfine.p + off, own6, gate, st);
-        launch_spmv(L.R.dm, D.gfine.p, N.b.p, nullptr, gate, st);
+        if (hipMemsetAsync(N.b.p, 0, N.b.n * sizeof(double), st) != hipSuccess) return set_err(FEMSHELL_ERR_HIP, "hipMemsetAsync");
+        launch_spmv(D.Rsub, D.gfine.p, N.b.p + 6ll * kSliceNodes * D.coarse_slice0, nullptr, gate, st);
         if (rc) return rc;
         std::string e;
         if (!comm_allreduce_sum(c->comm, N.b.p, (int)(6ll * N.n_pad), st, &e)) return set_err(FEMSHELL_ERR_COMM, e);
@@ -514,9 +544,8 @@ struct DistCycle {
         const bool next_is_coarsest = H.levels.size() == 2;
         if (H.opt.cycle == FEMSHELL_CYCLE_K && !next_is_coarsest) coarse.kcycle(1);
         else coarse.cycle(1, N.b.p, N.x.p);
-        // prolongation: the shadow's P into a global fine vector, the rank's rows of it onto x
-        launch_spmv(L.P.dm, N.x.p, D.gcorr.p, nullptr, gate, st);
-        launch_add(D.gcorr.p + off, x, own6, st);
+        // prolongation: the rank's rows of the shadow's P
+        launch_spmv_axpy(D.Pown, N.x.p, x, x, 1.0, gate, st);
         smooth(b, x, false);
         launch_copy(x, z, 6ll * p.n_pad, gate, st);
         return rc;
