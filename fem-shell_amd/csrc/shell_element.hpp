@@ -399,17 +399,19 @@ __device__ __forceinline__ bool quad4_record(const double X[12], const MatConst 
         ex[d] = mJ - mL;
         vr[d] = mK - mI;
     }
+    // no early returns (they left part of the record array in scratch memory, see tri3_frame): a degenerate quad gets
+    // zero scale factors and kind 0, which block_add_rec treats as an all-zero triangle record
     const double lx2 = ex[0] * ex[0] + ex[1] * ex[1] + ex[2] * ex[2];
-    if (!(lx2 > 0.0)) return false;
-    const double ilx = 1.0 / sqrt(lx2);
+    bool ok = lx2 > 0.0;
+    const double ilx = ok ? 1.0 / sqrt(lx2) : 0.0;
 #pragma unroll
     for (int d = 0; d < 3; d++) ex[d] *= ilx;
     ez[0] = ex[1] * vr[2] - ex[2] * vr[1];
     ez[1] = ex[2] * vr[0] - ex[0] * vr[2];
     ez[2] = ex[0] * vr[1] - ex[1] * vr[0];
     const double lz2 = ez[0] * ez[0] + ez[1] * ez[1] + ez[2] * ez[2];
-    if (!(lz2 > 0.0)) return false;
-    const double ilz = 1.0 / sqrt(lz2);
+    ok = ok && lz2 > 0.0;
+    const double ilz = ok ? 1.0 / sqrt(lz2) : 0.0;
 #pragma unroll
     for (int d = 0; d < 3; d++) ez[d] *= ilz;
     ey[0] = ez[1] * ex[2] - ez[2] * ex[1];
@@ -430,7 +432,7 @@ __device__ __forceinline__ bool quad4_record(const double X[12], const MatConst 
     double a2 = 0.0;
 #pragma unroll
     for (int n = 0; n < 4; n++) a2 += rec[kQuadX + n] * rec[kQuadY + (n + 1) % 4] - rec[kQuadX + (n + 1) % 4] * rec[kQuadY + n];
-    if (!(fabs(a2) > 0.0)) return false;
+    ok = ok && fabs(a2) > 0.0;
     // Jacobian of the bilinear map at the four Gauss points (SA:482-487 order; SA:489-538 and SA:641-684 use the
     // same four numbers), its inverse and determinant
     {
@@ -443,7 +445,7 @@ __device__ __forceinline__ bool quad4_record(const double X[12], const MatConst 
             const double r = (gp & 2) ? -root : root, s = (gp & 1) ? -root : root;
             const double J00 = 0.25 * ((x12 + x34) * s - x12 + x34), J01 = 0.25 * ((y12 + y34) * s - y12 + y34);
             const double J10 = 0.25 * ((x12 + x34) * r - x23 + x41), J11 = 0.25 * ((y12 + y34) * r - y23 + y41);
-            const double det = J00 * J11 - J01 * J10, idet = 1.0 / det;
+            const double det = J00 * J11 - J01 * J10, idet = (ok && det != 0.0) ? 1.0 / det : 0.0;
             double *g = rec + kQuadGp + 5 * gp;
             g[0] = J11 * idet;
             g[1] = -J01 * idet;
@@ -452,8 +454,12 @@ __device__ __forceinline__ bool quad4_record(const double X[12], const MatConst 
             g[4] = det;
         }
     }
-    rec[kRecKind] = 2.0;
-    return true;
+    rec[kRecKind] = ok ? 2.0 : 0.0;
+    if (!ok) {
+#pragma unroll
+        for (int i = 0; i < kRecDoublesQuad; i++) rec[i] = 0.0; // (selects, no branch: the values above may be Inf / NaN)
+    }
+    return ok;
 }
 
 // DKQ side coefficients (SA:613-621) of one element side with difference vector (x, y): they do not depend on
