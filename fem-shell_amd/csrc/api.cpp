@@ -196,25 +196,26 @@ double wall_s()
 int amg_setup_through_shadow(femshell_ctx *c)
 {
     if (c->mesh_xyz.empty()) return set_err(FEMSHELL_ERR_INVALID, "multigrid setup: the context holds no copy of the mesh");
-    if (c->amg_shadow) {
-        (void)femshell_destroy(c->amg_shadow);
-        c->amg_shadow = nullptr;
-    }
-    femshell_config cfg = c->cfg;
-    cfg.rank = 0;
-    cfg.world_size = 1;
-    cfg.device = c->device;
-    cfg.flags &= ~(uint32_t)(FEMSHELL_REORDER_MORTON | FEMSHELL_REORDER_RCM); // the copy of the mesh is in internal numbering
-    femshell_ctx *sh = nullptr;
-    int rc = femshell_create(&cfg, &sh);
-    if (rc) return rc;
-    c->amg_shadow = sh;
-    sh->cfg.flags = cfg.flags; // (femshell_create reads FEMSHELL_REORDER from the environment)
-    sh->mc = c->mc;
     const int32_t nn = (int32_t)(c->mesh_xyz.size() / 3);
-    rc = femshell_set_mesh(sh, nn, c->mesh_xyz.data(), (int32_t)(c->mesh_tri.size() / 3), c->mesh_tri.data(),
-                           (int32_t)(c->mesh_quad.size() / 4), c->mesh_quad.data());
-    if (!rc) rc = femshell_set_dirichlet(sh, nn, nullptr, c->dmask_global.data());
+    femshell_ctx *sh = c->amg_shadow; // kept while the mesh stays (femshell_set_mesh drops it): only K is assembled again
+    int rc = FEMSHELL_OK;
+    if (!sh) {
+        femshell_config cfg = c->cfg;
+        cfg.rank = 0;
+        cfg.world_size = 1;
+        cfg.device = c->device;
+        cfg.flags &= ~(uint32_t)(FEMSHELL_REORDER_MORTON | FEMSHELL_REORDER_RCM); // the copy of the mesh is in internal numbering
+        rc = femshell_create(&cfg, &sh);
+        if (rc) return rc;
+        c->amg_shadow = sh;
+        sh->cfg.flags = cfg.flags; // (femshell_create reads FEMSHELL_REORDER from the environment)
+        rc = femshell_set_mesh(sh, nn, c->mesh_xyz.data(), (int32_t)(c->mesh_tri.size() / 3), c->mesh_tri.data(),
+                               (int32_t)(c->mesh_quad.size() / 4), c->mesh_quad.data());
+        if (rc) return rc;
+    }
+    sh->mc = c->mc;
+    sh->amg.reset();
+    rc = femshell_set_dirichlet(sh, nn, nullptr, c->dmask_global.data());
     if (!rc) rc = do_assemble(sh);
     if (!rc) rc = do_jacobi(sh);
     if (rc) return rc;

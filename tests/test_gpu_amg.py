@@ -251,6 +251,15 @@ def test_multigrid_through_a_one_rank_rccl_communicator(monkeypatch):
     assert np.linalg.norm(u1 - u0) <= 1e-10 * np.linalg.norm(u0)
     u2, i2 = fs.solve(rtol=1e-11, max_it=2000)  # hierarchy reused
     assert i2["pc_setup_seconds"] == 0.0 and np.array_equal(u2, u1)
+    # K changes (another Dirichlet set): the shadow context stays, only its K and the hierarchy are built again
+    dm2 = m.dirichlet_mask().copy()
+    dm2[m.n_nodes // 2] |= 0x3F
+    for ctx in (fs, ref):
+        ctx.set_dirichlet(dm2)
+    u3, i3 = fs.solve(rtol=1e-11, max_it=2000)
+    u3r, i3r = ref.solve(rtol=1e-11, max_it=2000)
+    assert i3["converged"] == 1 and i3["pc_setup_seconds"] > 0.0 and abs(i3["iterations"] - i3r["iterations"]) <= 2
+    assert np.linalg.norm(u3 - u3r) <= 1e-10 * np.linalg.norm(u3r) and np.linalg.norm(u3 - u1) > 1e-6 * np.linalg.norm(u1)
 
 
 def test_flap_loaded_in_its_plane_converges_like_the_plates():
