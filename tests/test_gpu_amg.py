@@ -288,3 +288,35 @@ def test_flap_loaded_in_its_plane_converges_like_the_plates():
     assert np.allclose(np.abs(N[:, 1]), 1.0) and np.allclose(N[:, [0, 2]], 0.0)
     B = amg_oracle.rigid_body_modes(m.xyz, None, N)
     assert np.allclose(B[:, 4, 4], 0.0) and np.allclose(B[:, 3, 3], 1.0) and np.allclose(B[:, 5, 5], 1.0)
+
+
+@pytest.mark.parametrize("case", ["inplane", "folded", "strip"])
+def test_multigrid_on_other_load_cases_and_shapes(case):
+    # beyond the bending-dominated BASELINE configs (tools/amg_robustness_probe.py): a panel loaded in its plane, a plate
+    # folded by 90 degrees (the drilling rotation of one half is a bending rotation of the other), a thin cantilever strip
+    if case == "strip":
+        m = meshes.structured(128, 8, 0, 0, 16.0, 1.0, kind="t", ul_lr=True, bcids=(-1, -1, 1, -1), factor=300.0, loading=2)
+        mat, bound = (0.3, 1e7, 0.01), 150
+        xyz, loads = m.xyz, m.loads
+    else:
+        m = meshes.structured(64, 64, 0, 0, 10, 10, kind="t", ul_lr=True, bcids=(0, 0, 0, 0) if case == "inplane" else (-1, -1, 1, -1),
+                              factor=300.0, loading=2)
+        mat, bound = (0.3, 1e7, 0.5), 120
+        xyz, loads = m.xyz.copy(), np.zeros_like(m.loads)
+        if case == "inplane":
+            loads[:, 0] = 1.0
+        else:
+            right = m.xyz[:, 0] > 5.0
+            xyz[right, 0] = 5.0
+            xyz[right, 2] = m.xyz[right, 0] - 5.0
+            loads[:, 2] = 1.0
+    fs = pkg.FemShell(*mat)
+    fs.set_mesh(xyz, m.tri)
+    fs.set_dirichlet(m.dirichlet_mask())
+    fs.set_loads(loads)
+    fs.set_preconditioner("amg", coarsest_nodes=100)
+    u, info = fs.solve(rtol=1e-11, max_it=1000)
+    assert info["converged"] == 1 and info["amg_levels"] >= 2 and info["iterations"] < bound, info["iterations"]
+    rg, cg, vg, Fg = fs.export_bsr()
+    ud = oracle.refined_solve(rg, cg, vg, Fg)
+    assert np.linalg.norm(u.ravel() - ud) <= 2e-10 * np.linalg.norm(ud)
