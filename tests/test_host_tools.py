@@ -362,3 +362,11 @@ def test_coupled_program_on_two_ranks(tools, coupled_tool, tmp_path):
     tips2 = [float(v) for v in re.findall(r"tip\[\d+\] node \d+ = (\S+)", outs[0][1])]
     assert len(tips1) == 3 and len(tips2) == 3 and "tip[" not in outs[1][1]
     np.testing.assert_allclose(tips2, tips1, rtol=1e-7)
+    # the same with the multigrid preconditioner: every rank builds the single-rank hierarchy through its shadow context
+    # (K and the hierarchy once for all coupling iterations), same tip displacements
+    outs_mg = _run_ranks(cmd + ["-pc_type", "gamg"], 2, tmp_path)
+    assert [rc for rc, _, _ in outs_mg] == [0, 0], outs_mg
+    tips3 = [float(v) for v in re.findall(r"tip\[\d+\] node \d+ = (\S+)", outs_mg[0][1])]
+    np.testing.assert_allclose(tips3, tips1, rtol=1e-7)
+    its = lambda out: int(re.search(r"(\d+) CG iterations", out).group(1))
+    assert its(outs_mg[0][1]) * 3 < its(outs[0][1])
