@@ -672,7 +672,8 @@ int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, do
             FS_HIP(hipStreamSynchronize(st));
         }
         it = hs.iters;
-        *rec_rr_out = hs.rr; // what the stopping rule saw
+        if (pass == 0) *rec_rr_out = hs.rr; // what the stopping rule of the solve saw (a refinement pass stops earlier, see
+                                            // CG_PHASE_FLEX_RESTART)
         if (pass > 0) {
             // x += e; the context's x is the accumulated solution again
             launch_add(v.x, c->xacc.p, n6, st);

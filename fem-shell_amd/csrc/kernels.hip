@@ -955,6 +955,8 @@ void launch_cg_direction(const DeviceMatrix &m, const CgVectors &v, hipStream_t 
 // does not change the result: the final sum runs over the stage-1 sums in a fixed tree.
 constexpr int kReduceGroups = 64;
 
+constexpr double kRefineDrop = 1.0e-4; // residual reduction asked of a refinement pass (relative to its right-hand side)
+
 __device__ __forceinline__ void cg_scalar_phase(const CgVectors &v, int phase, double rtol)
 {
     CgScalars *s = v.s;
@@ -1026,7 +1028,12 @@ __device__ __forceinline__ void cg_scalar_phase(const CgVectors &v, int phase, d
         s->alpha = 0.0;
         s->beta = 0.0;
         s->rz = 0.0;
-        s->done = (s->red[0] <= s->tol2) ? 1 : 0;
+        const double tol2_solve = rtol > 0.0 ? rtol * rtol * s->bb : 0.0; // the tolerance of the solve as a whole
+        s->done = (s->red[0] <= tol2_solve) ? 1 : 0;
+        // the correction equation needs four digits, not the full tolerance again: its solution is added to an iterate
+        // whose error it reduces by that factor (2e-10 -> 1e-13 and below on the shell systems), and every further
+        // digit costs iterations of the whole method
+        s->tol2 = fmax(tol2_solve, kRefineDrop * kRefineDrop * s->red[0]);
     } else if (phase == CG_PHASE_FLEX_RZ0) {
         s->rz = s->red[0];
         if (!(s->red[0] > 0.0)) s->done = -1; // the preconditioner is not positive definite

@@ -336,7 +336,8 @@ def residual_extended(A, b, x):
 
 def solve(A, b, levels, kcycle=True, rtol=1e-10, max_it=1000, refine_passes=0):
     """Flexible PCG around the cycle, then `refine_passes` steps of iterative refinement: residual of the iterate in
-    extended precision, correction equation solved by the same method to the same absolute tolerance, x += e."""
+    extended precision, correction equation solved by the same method until its residual has dropped by 1e-4 (or to the
+    tolerance of the solve, whichever comes first), x += e."""
     M = lambda r: cycle(levels, 0, r, kcycle)  # noqa: E731
     x, hist = flexible_pcg(A, b, M, rtol, max_it)
     nb = np.linalg.norm(b)
@@ -345,7 +346,8 @@ def solve(A, b, levels, kcycle=True, rtol=1e-10, max_it=1000, refine_passes=0):
         nr = np.linalg.norm(r)
         if nr <= rtol * nb:
             break
-        e, h = flexible_pcg(A, r, M, rtol * nb / nr, max_it - len(hist))
+        # the correction needs four digits, not the full tolerance again (csrc/kernels.hip: kRefineDrop)
+        e, h = flexible_pcg(A, r, M, max(rtol * nb / nr, 1.0e-4), max_it - len(hist))
         hist = hist + [v * nr / nb for v in h]
         x = x + e
     return x, hist
