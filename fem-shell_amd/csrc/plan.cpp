@@ -3,9 +3,38 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
+#include <thread>
 
 namespace femshell {
+
+// host threads of the symbolic phase (FEMSHELL_HOST_THREADS, at most 64): contiguous chunks of [0, n), one per thread
+static int plan_threads()
+{
+    static const int n = [] {
+        const char *e = getenv("FEMSHELL_HOST_THREADS");
+        int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        return t < 1 ? 1 : (t > 64 ? 64 : t);
+    }();
+    return n;
+}
+template <class F> static void plan_parallel(int64_t n, int64_t min_chunk, F f) // f(thread, begin, end)
+{
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(plan_threads(), n / std::max<int64_t>(min_chunk, 1)));
+    if (nt <= 1) {
+        f(0, (int64_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back([&f, t, n, nt] { f(t, n * t / nt, n * (t + 1) / nt); });
+    for (auto &t : th) t.join();
+}
+static int plan_chunks(int64_t n, int64_t min_chunk)
+{
+    return (int)std::max<int64_t>(1, std::min<int64_t>(plan_threads(), n / std::max<int64_t>(min_chunk, 1)));
+}
 
 void partition_rows(int32_t n_nodes, int world, int rank, int32_t *begin, int32_t *end)
 {
@@ -83,6 +112,15 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                 if (c[i] == c[j]) return fail("quad " + std::to_string(e) + " repeats a node");
     }
 
+    // FEMSHELL_PLAN_VERBOSE=1: wall time of the phases below on stderr
+    static const bool verbose = getenv("FEMSHELL_PLAN_VERBOSE") && atoi(getenv("FEMSHELL_PLAN_VERBOSE")) != 0;
+    auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!verbose) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[femshell plan] %-44s %.3f s\n", what, std::chrono::duration<double>(t - t_lap).count());
+        t_lap = t;
+    };
     Plan &p = *P;
     p = Plan();
     p.n_nodes = n_nodes;
@@ -99,6 +137,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     p.n_pad = (p.n_own + kSliceNodes - 1) / kSliceNodes * kSliceNodes;
     p.n_slices = p.n_pad / kSliceNodes;
 
+    lap("up to: node - element adjacency for the owned n");
     // ---- node -> element adjacency for the owned nodes; entries (element << 2 | index in element),
     //      element = combined id (triangles first), ascending per node
     const int32_t n_own = p.n_own;
@@ -130,6 +169,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             }
     }
 
+    lap("up to: local elements every element touching an");
     // ---- local elements: every element touching an owned node
     std::vector<int32_t> elem_local((size_t)n_tri + n_quad, -1);
     for (uint32_t v : adj) elem_local[v >> 2] = 0;
@@ -145,6 +185,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             p.quad_global_id.push_back(e);
         }
 
+    lap("up to: per owned node block slots slot 0  diago");
     // ---- per owned node: block slots (slot 0 = diagonal, then ascending global column) and
     //      the gather list of every slot
     struct Slot {
@@ -157,13 +198,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     std::vector<int32_t> slot_col;                         // global ids, per node contiguous
     std::vector<int32_t> slot_pair_ptr(1, 0);              // per slot
     std::vector<uint32_t> slot_pairs;
-    slot_col.reserve((size_t)n_own * 8);
-    slot_pair_ptr.reserve((size_t)n_own * 8 + 1);
-    slot_pairs.reserve((size_t)adj.size() * 3);
-    std::vector<Slot> slots;
-    std::vector<uint32_t> tmp_pairs; // packed pair
-    std::vector<int32_t> tmp_next;
-    std::vector<int> order;
+    lap("up to: symmetric storage which row of an owned");
     // ---- symmetric storage: which row of an owned pair (a,c) holds the block.  Any choice works -- the SpMV applies
     // every stored off-diagonal block to both rows -- so it is made to balance the rows: the ELL width of a slice is the
     // largest slot count of its 32 rows.  Start: the lower-numbered row keeps the block (on a structured grid every
@@ -177,12 +212,21 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     int64_t lower_blocks = 0;
     if (symmetric) {
         nb_ptr.assign((size_t)n_own + 1, 0);
-        std::vector<int32_t> tmp;
-        std::vector<int32_t> cnt((size_t)n_own, 0); // blocks a row stores besides its diagonal (ghost columns included)
-        for (int pass = 0; pass < 2; pass++) {
-            for (int32_t a = 0; a < n_own; a++) {
-                tmp.clear();
-                int ghosts = 0;
+        std::vector<int32_t> cnt_ghost((size_t)n_own, 0);
+        // one parallel pass: the sorted distinct neighbours of every row land in a scratch array at an upper-bound offset
+        // (three or four entries per adjacent element), counts are taken, a second parallel pass compacts the owned ones
+        std::vector<int64_t> ub((size_t)n_own + 1, 0);
+        for (int32_t a = 0; a < n_own; a++) {
+            int64_t m = 0;
+            for (int64_t q = adj_ptr[a]; q < adj_ptr[a + 1]; q++) m += ((adj[q] >> 2) < (uint32_t)n_tri) ? 2 : 3;
+            ub[(size_t)a + 1] = ub[(size_t)a] + m;
+        }
+        std::vector<int32_t> scratch((size_t)ub[(size_t)n_own]);
+        std::vector<int32_t> n_distinct((size_t)n_own, 0);
+        plan_parallel(n_own, 4096, [&](int, int64_t a0, int64_t a1) {
+            for (int64_t a = a0; a < a1; a++) {
+                int32_t *t = scratch.data() + ub[(size_t)a];
+                int m = 0;
                 for (int64_t q = adj_ptr[a]; q < adj_ptr[a + 1]; q++) {
                     const uint32_t ge = adj[q] >> 2;
                     const bool is_tri = ge < (uint32_t)n_tri;
@@ -190,36 +234,39 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                     const int32_t *c = is_tri ? tri + 3ll * ge : quad + 4ll * (ge - n_tri);
                     for (int ib = 0; ib < nn; ib++) {
                         const int32_t b = c[ib];
-                        if (b == g0 + a) continue;
-                        if (b >= g0 && b < g1) tmp.push_back(b - g0);
-                        else tmp.push_back(n_own + (b < g0 ? b : b - n_own)); // ghost marker (distinct per global id)
+                        if (b == g0 + (int32_t)a) continue;
+                        if (b >= g0 && b < g1) t[m++] = b - g0;
+                        else t[m++] = n_own + (b < g0 ? b : b - n_own); // ghost marker (distinct per global id)
                     }
                 }
-                std::sort(tmp.begin(), tmp.end());
-                tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                std::sort(t, t + m);
+                m = (int)(std::unique(t, t + m) - t);
                 int owned = 0;
-                for (int32_t v : tmp) (v < n_own ? owned : ghosts)++;
-                if (pass == 0) {
-                    nb_ptr[a + 1] = nb_ptr[a] + owned;
-                    cnt[a] = ghosts;
-                } else {
-                    int64_t w = nb_ptr[a];
-                    for (int32_t v : tmp)
-                        if (v < n_own) nb[w++] = v;
-                }
+                for (int k = 0; k < m; k++) owned += t[k] < n_own ? 1 : 0;
+                n_distinct[(size_t)a] = owned; // (owned entries sort in front of the ghost markers)
+                cnt_ghost[(size_t)a] = m - owned;
             }
-            if (pass == 0) nb.resize((size_t)nb_ptr[n_own]);
-        }
+        });
+        for (int32_t a = 0; a < n_own; a++) nb_ptr[(size_t)a + 1] = nb_ptr[(size_t)a] + n_distinct[(size_t)a];
+        nb.resize((size_t)nb_ptr[n_own]);
+        plan_parallel(n_own, 4096, [&](int, int64_t a0, int64_t a1) {
+            for (int64_t a = a0; a < a1; a++)
+                std::copy_n(scratch.data() + ub[(size_t)a], n_distinct[(size_t)a], nb.data() + nb_ptr[(size_t)a]);
+        });
+        std::vector<int32_t>().swap(scratch);
+        std::vector<int32_t> cnt(cnt_ghost); // blocks a row stores besides its diagonal (ghost columns included)
         nb_mine.assign(nb.size(), 0);
         auto index_of = [&](int32_t row, int32_t col) -> int64_t {
             return std::lower_bound(nb.begin() + nb_ptr[row], nb.begin() + nb_ptr[row + 1], col) - nb.begin();
         };
-        for (int32_t a = 0; a < n_own; a++) // start: the lower-numbered row keeps the block
-            for (int64_t q = nb_ptr[a]; q < nb_ptr[a + 1]; q++)
-                if (nb[q] > a) {
-                    nb_mine[q] = 1;
-                    cnt[a]++;
-                }
+        plan_parallel(n_own, 4096, [&](int, int64_t a0, int64_t a1) { // start: the lower-numbered row keeps the block
+            for (int64_t a = a0; a < a1; a++)
+                for (int64_t q = nb_ptr[a]; q < nb_ptr[a + 1]; q++)
+                    if (nb[q] > a) {
+                        nb_mine[q] = 1;
+                        cnt[a]++;
+                    }
+        });
         // local repair towards the mean
         const int target = (int)((nb.size() / 2 + (size_t)n_own - 1) / (size_t)std::max(n_own, 1));
         auto give = [&](int32_t from, int64_t q_from) { // the block (from, nb[q_from]) moves to the other row
@@ -256,9 +303,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             }
             if (!moved) break;
         }
-        for (int32_t a = 0; a < n_own; a++)
-            for (int64_t q = nb_ptr[a]; q < nb_ptr[a + 1]; q++)
-                if (!nb_mine[q]) lower_blocks++; // blocks of K without a slot in this row
+        for (size_t q = 0; q < nb_mine.size(); q++) lower_blocks += nb_mine[q] ? 0 : 1; // blocks of K without a slot in their row
     }
     auto stored_here = [&](int32_t a, int32_t b_global) { // symmetric storage: does row a hold the block (a, b)?
         if (b_global < g0 || b_global >= g1) return true; // ghost column
@@ -266,47 +311,85 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         const int64_t q = std::lower_bound(nb.begin() + nb_ptr[a], nb.begin() + nb_ptr[a + 1], c) - nb.begin();
         return nb_mine[q] != 0;
     };
-    for (int32_t a = 0; a < n_own; a++) {
-        slots.clear();
-        tmp_pairs.clear();
-        tmp_next.clear();
-        slots.push_back({g0 + a, -1, -1, 0});
-        for (int64_t q = adj_ptr[a]; q < adj_ptr[a + 1]; q++) {
-            const uint32_t ge = adj[q] >> 2, ia = adj[q] & 3u;
-            const bool is_tri = ge < (uint32_t)n_tri;
-            const int nn = is_tri ? 3 : 4;
-            const int32_t *c = is_tri ? tri + 3ll * ge : quad + 4ll * (ge - n_tri);
-            const uint32_t le = (uint32_t)elem_local[ge];
-            for (int ib = 0; ib < nn; ib++) {
-                const int32_t b = c[ib];
-                if (symmetric && b != g0 + a && !stored_here(a, b)) continue; // the block lives with row b and acts here
-                                                                               // through its transpose
-                size_t s = 0;
-                for (; s < slots.size(); s++)
-                    if (slots[s].col == b) break;
-                if (s == slots.size()) slots.push_back({b, -1, -1, 0});
-                const int32_t id = (int32_t)tmp_pairs.size();
-                tmp_pairs.push_back((le << 4) | (ia << 2) | (uint32_t)ib);
-                tmp_next.push_back(-1);
-                if (slots[s].first < 0) slots[s].first = id; else tmp_next[slots[s].last] = id;
-                slots[s].last = id;
-                slots[s].count++;
+    {
+        // chunks of rows on the host threads, each into lists of its own (slot_pair_ptr relative to the chunk), joined in
+        // row order afterwards
+        const int nchunks_r = plan_chunks(n_own, 4096);
+        std::vector<std::vector<int32_t>> part_col((size_t)nchunks_r), part_ptr((size_t)nchunks_r);
+        std::vector<std::vector<uint32_t>> part_pairs((size_t)nchunks_r);
+        plan_parallel(n_own, 4096, [&](int t, int64_t a0, int64_t a1) {
+            std::vector<Slot> slots;
+            std::vector<uint32_t> tmp_pairs; // packed pair
+            std::vector<int32_t> tmp_next;
+            std::vector<int> order;
+            std::vector<int32_t> &pc = part_col[(size_t)t], &pp = part_ptr[(size_t)t];
+            std::vector<uint32_t> &pairs_t = part_pairs[(size_t)t];
+            pc.reserve((size_t)(a1 - a0) * 8);
+            pp.reserve((size_t)(a1 - a0) * 8);
+            pairs_t.reserve((size_t)(adj_ptr[a1] - adj_ptr[a0]) * 3);
+            for (int64_t a = a0; a < a1; a++) {
+                slots.clear();
+                tmp_pairs.clear();
+                tmp_next.clear();
+                slots.push_back({g0 + (int32_t)a, -1, -1, 0});
+                for (int64_t q = adj_ptr[a]; q < adj_ptr[a + 1]; q++) {
+                    const uint32_t ge = adj[q] >> 2, ia = adj[q] & 3u;
+                    const bool is_tri = ge < (uint32_t)n_tri;
+                    const int nn = is_tri ? 3 : 4;
+                    const int32_t *c = is_tri ? tri + 3ll * ge : quad + 4ll * (ge - n_tri);
+                    const uint32_t le = (uint32_t)elem_local[ge];
+                    for (int ib = 0; ib < nn; ib++) {
+                        const int32_t b = c[ib];
+                        if (symmetric && b != g0 + (int32_t)a && !stored_here((int32_t)a, b)) continue; // the block lives with row b
+                                                                                                       // and acts here through its transpose
+                        size_t s = 0;
+                        for (; s < slots.size(); s++)
+                            if (slots[s].col == b) break;
+                        if (s == slots.size()) slots.push_back({b, -1, -1, 0});
+                        const int32_t id = (int32_t)tmp_pairs.size();
+                        tmp_pairs.push_back((le << 4) | (ia << 2) | (uint32_t)ib);
+                        tmp_next.push_back(-1);
+                        if (slots[s].first < 0) slots[s].first = id; else tmp_next[slots[s].last] = id;
+                        slots[s].last = id;
+                        slots[s].count++;
+                    }
+                }
+                order.resize(slots.size());
+                for (size_t s = 0; s < slots.size(); s++) order[s] = (int)s;
+                std::sort(order.begin() + 1, order.end(), [&](int x, int y) { return slots[x].col < slots[y].col; });
+                for (int s : order) {
+                    pc.push_back(slots[s].col);
+                    for (int32_t id = slots[s].first; id >= 0; id = tmp_next[id]) pairs_t.push_back(tmp_pairs[id]);
+                    pp.push_back((int32_t)pairs_t.size()); // end of the slot's pairs, relative to the chunk
+                }
+                node_slot_ptr[(size_t)a + 1] = (int32_t)slots.size(); // count; prefix sums below
             }
+        });
+        size_t n_slots = 0, n_pairs = 0;
+        for (int t = 0; t < nchunks_r; t++) {
+            n_slots += part_col[(size_t)t].size();
+            n_pairs += part_pairs[(size_t)t].size();
         }
-        order.resize(slots.size());
-        for (size_t s = 0; s < slots.size(); s++) order[s] = (int)s;
-        std::sort(order.begin() + 1, order.end(), [&](int x, int y) { return slots[x].col < slots[y].col; });
-        for (int s : order) {
-            slot_col.push_back(slots[s].col);
-            for (int32_t id = slots[s].first; id >= 0; id = tmp_next[id]) slot_pairs.push_back(tmp_pairs[id]);
-            slot_pair_ptr.push_back((int32_t)slot_pairs.size());
+        if (n_pairs > 0x7fffff00ull || n_slots > 0x7fffff00ull) return fail("gather list exceeds 2^31 entries");
+        for (int32_t a = 0; a < n_own; a++) node_slot_ptr[(size_t)a + 1] += node_slot_ptr[(size_t)a];
+        slot_col.resize(n_slots);
+        slot_pair_ptr.resize(n_slots + 1);
+        slot_pairs.resize(n_pairs);
+        size_t so = 0, po = 0;
+        for (int t = 0; t < nchunks_r; t++) {
+            std::copy(part_col[(size_t)t].begin(), part_col[(size_t)t].end(), slot_col.begin() + so);
+            for (size_t k = 0; k < part_ptr[(size_t)t].size(); k++) slot_pair_ptr[so + k + 1] = (int32_t)(po + (size_t)part_ptr[(size_t)t][k]);
+            std::copy(part_pairs[(size_t)t].begin(), part_pairs[(size_t)t].end(), slot_pairs.begin() + po);
+            so += part_col[(size_t)t].size();
+            po += part_pairs[(size_t)t].size();
+            std::vector<int32_t>().swap(part_col[(size_t)t]);
+            std::vector<uint32_t>().swap(part_pairs[(size_t)t]);
         }
-        node_slot_ptr[a + 1] = (int32_t)slot_col.size();
-        if (slot_pairs.size() > 0x7fffff00ull) return fail("gather list exceeds 2^31 entries");
     }
     p.stored_blocks = (int64_t)slot_col.size();
     p.nnz_blocks = p.stored_blocks + lower_blocks;
 
+    lap("up to: ghosts referenced columns outside the ow");
     // ---- ghosts: referenced columns outside the owned range, ascending
     {
         std::vector<int32_t> g;
@@ -323,6 +406,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         return p.n_pad + (int32_t)(it - p.ghost_global.begin());
     };
 
+    lap("up to: local copies of connectivity and coordin");
     // ---- local copies of connectivity and coordinates
     p.tri_local.resize((size_t)n_ltri * 3);
     for (int32_t le = 0; le < n_ltri; le++)
@@ -338,6 +422,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     for (int32_t q = 0; q < p.n_ghost; q++)
         for (int d = 0; d < 3; d++) p.xyz_local[3ll * (p.n_pad + q) + d] = xyz[3ll * p.ghost_global[q] + d];
 
+    lap("up to: pack into slices");
     // ---- pack into slices
     p.slice_width.assign(p.n_slices, 1);
     p.slice_base.assign((size_t)p.n_slices + 1, 0);
@@ -378,6 +463,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     }
     p.pair_ptr[total] = (int32_t)p.pairs.size();
 
+    lap("up to: symmetric storage which stored blocks ac");
     // ---- symmetric storage: which stored blocks act on a row through their transpose
     p.in_width.assign(p.n_slices, 0);
     p.in_base.assign((size_t)p.n_slices + 1, 0);
@@ -401,63 +487,86 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         std::fill(cnt.begin(), cnt.end(), 0);
         // ascending slot index = ascending slice of the source row; inside a slice slots run slot-major, which is a
         // fixed order too: the sums of the gather phase are reproducible
-        for (int64_t idx = 0; idx < total; idx++) {
-            if (p.pair_ptr[idx + 1] == p.pair_ptr[idx]) continue;
-            const int32_t c = p.cols[idx];
-            if (c >= n_own) continue;
-            // source row of the slot
-            const int32_t s2 = (int32_t)(std::upper_bound(p.slice_base.begin(), p.slice_base.end(), idx) - p.slice_base.begin()) - 1;
-            const int32_t a = s2 * kSliceNodes + (int32_t)((idx - p.slice_base[s2]) % kSliceNodes);
-            if (a == c) continue;
-            const int32_t sc = c / kSliceNodes, nc = c % kSliceNodes;
-            p.in_slots[(size_t)(p.in_base[sc] + (int64_t)cnt[c] * kSliceNodes + nc)] = (int32_t)idx;
-            p.in_rows[(size_t)(p.in_base[sc] + (int64_t)cnt[c] * kSliceNodes + nc)] = a;
-            cnt[c]++;
-        }
+        for (int32_t s2 = 0; s2 < p.n_slices; s2++) // (ascending idx: slices, then slots of a slice, then its nodes)
+            for (int64_t idx = p.slice_base[s2]; idx < p.slice_base[s2 + 1]; idx++) {
+                if (p.pair_ptr[idx + 1] == p.pair_ptr[idx]) continue;
+                const int32_t c = p.cols[idx];
+                if (c >= n_own) continue;
+                const int32_t a = s2 * kSliceNodes + (int32_t)((idx - p.slice_base[s2]) % kSliceNodes); // source row of the slot
+                if (a == c) continue;
+                const int32_t sc = c / kSliceNodes, nc = c % kSliceNodes;
+                p.in_slots[(size_t)(p.in_base[sc] + (int64_t)cnt[c] * kSliceNodes + nc)] = (int32_t)idx;
+                p.in_rows[(size_t)(p.in_base[sc] + (int64_t)cnt[c] * kSliceNodes + nc)] = a;
+                cnt[c]++;
+            }
     }
 
-    // ---- per-slice element lists and slice-relative 16-bit gather entries
+    lap("up to: per-slice element lists and slice-relati");
+    // ---- per-slice element lists and slice-relative 16-bit gather entries (chunks of slices on the host threads, each
+    //      into lists of its own that are joined in slice order afterwards)
     p.slice_elem_ptr.assign((size_t)p.n_slices + 1, 0);
     p.pairs16.resize(p.pairs.size());
-    p.slice_elems.reserve(p.pairs.size() / 4 + 1024);
-    p.slice_elem_nodes.reserve(p.pairs.size() + 4096);
     {
-        std::vector<int32_t> ids, placed;
-        for (int32_t s = 0; s < p.n_slices; s++) {
-            const int32_t q0 = p.pair_ptr[p.slice_base[s]], q1 = p.pair_ptr[p.slice_base[s + 1]];
-            ids.clear();
-            for (int32_t q = q0; q < q1; q++) ids.push_back((int32_t)(p.pairs[q] >> 4));
-            std::sort(ids.begin(), ids.end());
-            ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
-            if (ids.size() > 4095) return fail("more than 4095 elements touch one 32-node slice");
-            p.max_slice_elems = std::max<int32_t>(p.max_slice_elems, (int32_t)ids.size());
-            // LDS position of the records: even-ranked elements first, then the odd-ranked ones.  Neighbouring
-            // lanes (neighbouring node rows) gather from neighbouring cells; mesh generators emit the two
-            // triangles of a cell back to back, so in ascending order those records are two apart and a
-            // wave's LDS reads fall on half of the banks; de-interleaved they are adjacent.
-            const int32_t n_even = ((int32_t)ids.size() + 1) / 2;
-            auto lds_pos = [&](int32_t rank) { return (rank & 1) ? n_even + (rank >> 1) : (rank >> 1); };
-            for (int32_t q = q0; q < q1; q++) {
-                const int32_t le = (int32_t)(p.pairs[q] >> 4);
-                const int32_t idx = lds_pos((int32_t)(std::lower_bound(ids.begin(), ids.end(), le) - ids.begin()));
-                p.pairs16[q] = (uint16_t)((idx << 4) | (p.pairs[q] & 15u));
-            }
-            placed.resize(ids.size());
-            for (size_t r = 0; r < ids.size(); r++) placed[lds_pos((int32_t)r)] = ids[r];
-            ids.swap(placed);
-            p.slice_elems.insert(p.slice_elems.end(), ids.begin(), ids.end());
-            for (int32_t le : ids) {
-                if (le < p.n_ltri()) {
-                    for (int i = 0; i < 3; i++) p.slice_elem_nodes.push_back(p.tri_local[3ll * le + i]);
-                    p.slice_elem_nodes.push_back(-1);
-                } else {
-                    for (int i = 0; i < 4; i++) p.slice_elem_nodes.push_back(p.quad_local[4ll * (le - p.n_ltri()) + i]);
+        const int nchunks = plan_chunks(p.n_slices, 256);
+        std::vector<std::vector<int32_t>> part_elems((size_t)nchunks), part_nodes((size_t)nchunks);
+        std::vector<int32_t> part_max((size_t)nchunks, 0), part_bad((size_t)nchunks, 0);
+        plan_parallel(p.n_slices, 256, [&](int t, int64_t s0, int64_t s1) {
+            std::vector<int32_t> ids, placed;
+            std::vector<int32_t> &elems = part_elems[(size_t)t], &nodes = part_nodes[(size_t)t];
+            elems.reserve((size_t)(s1 - s0) * 136);
+            nodes.reserve((size_t)(s1 - s0) * 136 * 4);
+            for (int64_t s = s0; s < s1; s++) {
+                const int32_t q0 = p.pair_ptr[p.slice_base[s]], q1 = p.pair_ptr[p.slice_base[s + 1]];
+                ids.clear();
+                for (int32_t q = q0; q < q1; q++) ids.push_back((int32_t)(p.pairs[q] >> 4));
+                std::sort(ids.begin(), ids.end());
+                ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+                if (ids.size() > 4095) {
+                    part_bad[(size_t)t] = 1;
+                    return;
                 }
+                part_max[(size_t)t] = std::max<int32_t>(part_max[(size_t)t], (int32_t)ids.size());
+                // LDS position of the records: even-ranked elements first, then the odd-ranked ones.  Neighbouring
+                // lanes (neighbouring node rows) gather from neighbouring cells; mesh generators emit the two
+                // triangles of a cell back to back, so in ascending order those records are two apart and a
+                // wave's LDS reads fall on half of the banks; de-interleaved they are adjacent.
+                const int32_t n_even = ((int32_t)ids.size() + 1) / 2;
+                auto lds_pos = [&](int32_t rank) { return (rank & 1) ? n_even + (rank >> 1) : (rank >> 1); };
+                for (int32_t q = q0; q < q1; q++) {
+                    const int32_t le = (int32_t)(p.pairs[q] >> 4);
+                    const int32_t idx = lds_pos((int32_t)(std::lower_bound(ids.begin(), ids.end(), le) - ids.begin()));
+                    p.pairs16[q] = (uint16_t)((idx << 4) | (p.pairs[q] & 15u));
+                }
+                placed.resize(ids.size());
+                for (size_t r = 0; r < ids.size(); r++) placed[lds_pos((int32_t)r)] = ids[r];
+                elems.insert(elems.end(), placed.begin(), placed.end());
+                for (int32_t le : placed) {
+                    if (le < p.n_ltri()) {
+                        for (int i = 0; i < 3; i++) nodes.push_back(p.tri_local[3ll * le + i]);
+                        nodes.push_back(-1);
+                    } else {
+                        for (int i = 0; i < 4; i++) nodes.push_back(p.quad_local[4ll * (le - p.n_ltri()) + i]);
+                    }
+                }
+                p.slice_elem_ptr[(size_t)s + 1] = (int32_t)placed.size(); // count; prefix sums below
             }
-            p.slice_elem_ptr[s + 1] = (int32_t)p.slice_elems.size();
+        });
+        for (int t = 0; t < nchunks; t++) {
+            if (part_bad[(size_t)t]) return fail("more than 4095 elements touch one 32-node slice");
+            p.max_slice_elems = std::max(p.max_slice_elems, part_max[(size_t)t]);
+        }
+        for (int32_t s = 0; s < p.n_slices; s++) p.slice_elem_ptr[(size_t)s + 1] += p.slice_elem_ptr[(size_t)s];
+        p.slice_elems.resize((size_t)p.slice_elem_ptr[(size_t)p.n_slices]);
+        p.slice_elem_nodes.resize(4 * p.slice_elems.size());
+        size_t off = 0;
+        for (int t = 0; t < nchunks; t++) { // chunks are contiguous slice ranges in thread order
+            std::copy(part_elems[(size_t)t].begin(), part_elems[(size_t)t].end(), p.slice_elems.begin() + off);
+            std::copy(part_nodes[(size_t)t].begin(), part_nodes[(size_t)t].end(), p.slice_elem_nodes.begin() + 4 * off);
+            off += part_elems[(size_t)t].size();
         }
     }
 
+    lap("up to: assembly work items");
     // ---- assembly work items
     // contributions per item (FEMSHELL_ITEM_PAIRS overrides): 3 fills the four waves of a full-storage slice evenly (256
     // items); with symmetric storage a structured slice has 32 diagonal slots of 6 and 96 off-diagonal slots of 2
@@ -467,71 +576,97 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     const int item_pairs = (item_pairs_env >= 1 && item_pairs_env <= kItemPairs) ? item_pairs_env : kItemPairs;
     p.item_ptr.assign((size_t)p.n_slices + 1, 0);
     {
-        std::vector<Plan::Item> tmp, sorted;
-        p.items.reserve((size_t)p.n_slices * 256 + 1024);
-        // stable order by decreasing number of contributions (0..kItemPairs): a bucket pass, no allocation
-        auto order_by_work = [&](std::vector<Plan::Item> &v, size_t begin) {
-            sorted.clear();
-            for (int np = kItemPairs; np >= 0; np--)
-                for (size_t i = begin; i < v.size(); i++)
-                    if ((int)(v[i].z >> 16) == np) sorted.push_back(v[i]);
-            std::copy(sorted.begin(), sorted.end(), v.begin() + begin);
-        };
-        for (int32_t s = 0; s < p.n_slices; s++) {
-            tmp.clear();
-            int32_t stage = 0;
-            const int w = p.slice_width[s];
-            for (int k = 0; k < w; k++)
-                for (int n = 0; n < kSliceNodes; n++) {
-                    const int64_t idx = Plan::slot_index(p.slice_base[s], k, n);
-                    const int32_t q0 = p.pair_ptr[idx], cnt = p.pair_ptr[idx + 1] - q0;
-                    if (cnt == 0) continue; // padding slot: its zero block is written once, when K is allocated
-                    const int nchunks = (cnt + item_pairs - 1) / item_pairs;
-                    if (nchunks > 255) return fail("a block slot has more than 765 contributions");
-                    const int32_t stage0 = stage;
-                    for (int c = 0; c < nchunks; c++) {
-                        const int32_t b = q0 + c * item_pairs, e = std::min(q0 + cnt, b + item_pairs);
-                        const int np = std::max(0, e - b);
-                        uint32_t pr[3] = {0, 0, 0};
-                        for (int q = 0; q < np; q++) pr[q] = p.pairs16[b + q];
-                        Plan::Item it;
-                        it.x = (uint32_t)(k * kSliceNodes + n) | ((uint32_t)c << 16) | ((uint32_t)nchunks << 24);
-                        it.y = pr[0] | (pr[1] << 16);
-                        it.z = pr[2] | ((uint32_t)np << 16);
-                        it.w = (uint32_t)(c == 0 ? stage0 : stage0 + c - 1);
-                        tmp.push_back(it);
+        // chunks of slices on the host threads, each into an item list of its own, joined in slice order afterwards
+        const int nchunks_t = plan_chunks(p.n_slices, 256);
+        std::vector<std::vector<Plan::Item>> part_items((size_t)nchunks_t);
+        std::vector<int32_t> part_stage((size_t)nchunks_t, 0), part_bad((size_t)nchunks_t, 0);
+        plan_parallel(p.n_slices, 256, [&](int t, int64_t s0, int64_t s1) {
+            std::vector<Plan::Item> tmp, sorted, packed;
+            std::vector<Plan::Item> &out = part_items[(size_t)t];
+            out.reserve((size_t)(s1 - s0) * 168);
+            // stable order by decreasing number of contributions (0..kItemPairs): a bucket pass, no allocation
+            auto order_by_work = [&](std::vector<Plan::Item> &v, size_t begin) {
+                sorted.clear();
+                for (int np = kItemPairs; np >= 0; np--)
+                    for (size_t i = begin; i < v.size(); i++)
+                        if ((int)(v[i].z >> 16) == np) sorted.push_back(v[i]);
+                std::copy(sorted.begin(), sorted.end(), v.begin() + begin);
+            };
+            for (int64_t s = s0; s < s1; s++) {
+                tmp.clear();
+                int32_t stage = 0;
+                const int w = p.slice_width[s];
+                for (int k = 0; k < w; k++)
+                    for (int n = 0; n < kSliceNodes; n++) {
+                        const int64_t idx = Plan::slot_index(p.slice_base[s], k, n);
+                        const int32_t q0 = p.pair_ptr[idx], cnt = p.pair_ptr[idx + 1] - q0;
+                        if (cnt == 0) continue; // padding slot: its zero block is written once, when K is allocated
+                        const int nchunks = (cnt + item_pairs - 1) / item_pairs;
+                        if (nchunks > 255) {
+                            part_bad[(size_t)t] = 1;
+                            return;
+                        }
+                        const int32_t stage0 = stage;
+                        for (int c = 0; c < nchunks; c++) {
+                            const int32_t b = q0 + c * item_pairs, e = std::min(q0 + cnt, b + item_pairs);
+                            const int np = std::max(0, e - b);
+                            uint32_t pr[3] = {0, 0, 0};
+                            for (int q = 0; q < np; q++) pr[q] = p.pairs16[b + q];
+                            Plan::Item it;
+                            it.x = (uint32_t)(k * kSliceNodes + n) | ((uint32_t)c << 16) | ((uint32_t)nchunks << 24);
+                            it.y = pr[0] | (pr[1] << 16);
+                            it.z = pr[2] | ((uint32_t)np << 16);
+                            it.w = (uint32_t)(c == 0 ? stage0 : stage0 + c - 1);
+                            tmp.push_back(it);
+                        }
+                        stage += nchunks - 1;
                     }
-                    stage += nchunks - 1;
-                }
-            if (tmp.size() <= 256) {
-                // one round: order by decreasing work so that the waves are uniform
-                order_by_work(tmp, 0);
-            } else {
-                // several rounds of 256 items: a slot's chunks must share a round (they meet in LDS),
-                // so fill rounds greedily with whole slots, then order each round by work
-                std::vector<Plan::Item> packed;
-                size_t i = 0;
-                while (i < tmp.size()) {
-                    const size_t round_begin = packed.size();
+                if (tmp.size() <= 256) {
+                    // one round: order by decreasing work so that the waves are uniform
+                    order_by_work(tmp, 0);
+                } else {
+                    // several rounds of 256 items: a slot's chunks must share a round (they meet in LDS),
+                    // so fill rounds greedily with whole slots, then order each round by work
+                    packed.clear();
+                    size_t i = 0;
                     while (i < tmp.size()) {
-                        const size_t nch = tmp[i].x >> 24;
-                        if (packed.size() - round_begin + nch > 256) break;
-                        for (size_t c = 0; c < nch; c++) packed.push_back(tmp[i + c]);
-                        i += nch;
+                        const size_t round_begin = packed.size();
+                        while (i < tmp.size()) {
+                            const size_t nch = tmp[i].x >> 24;
+                            if (packed.size() - round_begin + nch > 256) break;
+                            for (size_t c = 0; c < nch; c++) packed.push_back(tmp[i + c]);
+                            i += nch;
+                        }
+                        order_by_work(packed, round_begin);
+                        if (i < tmp.size()) {
+                            Plan::Item pad{0xffffu, 0, 0, 0}; // inert item: slot 0xffff, chunk 0, 0 chunks
+                            while (packed.size() - round_begin < 256) packed.push_back(pad);
+                        }
                     }
-                    order_by_work(packed, round_begin);
-                    if (i < tmp.size()) {
-                        Plan::Item pad{0xffffu, 0, 0, 0}; // inert item: slot 0xffff, chunk 0, 0 chunks
-                        while (packed.size() - round_begin < 256) packed.push_back(pad);
-                    }
+                    tmp.swap(packed);
                 }
-                tmp.swap(packed);
+                part_stage[(size_t)t] = std::max(part_stage[(size_t)t], stage);
+                out.insert(out.end(), tmp.begin(), tmp.end());
+                p.item_ptr[(size_t)s + 1] = (int32_t)tmp.size(); // count; prefix sums below
             }
-            p.max_stage_rows = std::max(p.max_stage_rows, stage);
-            p.items.insert(p.items.end(), tmp.begin(), tmp.end());
-            p.item_ptr[s + 1] = (int32_t)p.items.size();
+        });
+        size_t total_items = 0;
+        for (int t = 0; t < nchunks_t; t++) {
+            if (part_bad[(size_t)t]) return fail("a block slot has more than 765 contributions");
+            p.max_stage_rows = std::max(p.max_stage_rows, part_stage[(size_t)t]);
+            total_items += part_items[(size_t)t].size();
+        }
+        if (total_items > (size_t)0x7fffffff) return fail("more than 2^31 assembly work items on one rank");
+        for (int32_t s = 0; s < p.n_slices; s++) p.item_ptr[(size_t)s + 1] += p.item_ptr[(size_t)s];
+        p.items.resize(total_items);
+        size_t off = 0;
+        for (int t = 0; t < nchunks_t; t++) {
+            std::copy(part_items[(size_t)t].begin(), part_items[(size_t)t].end(), p.items.begin() + off);
+            off += part_items[(size_t)t].size();
+            std::vector<Plan::Item>().swap(part_items[(size_t)t]);
         }
     }
+    lap("up to: per-slice descriptors of the assembly ke");
     // ---- per-slice descriptors of the assembly kernel
     p.slice_desc.assign((size_t)p.n_slices * 8, 0);
     for (int32_t s = 0; s < p.n_slices; s++) {
@@ -545,6 +680,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         d[6] = p.slice_width[s];
     }
 
+    lap("up to: halo exchange lists");
     // ---- halo exchange lists
     if (world > 1) {
         // receive side: ghosts grouped by owner (ghost_global is ascending, ranges are contiguous)
@@ -597,6 +733,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         p.n_interior_slices = (int32_t)p.spmv_order.size();
         p.spmv_order.insert(p.spmv_order.end(), boundary.begin(), boundary.end());
     }
+    lap("up to: end");
     return true;
 }
 
