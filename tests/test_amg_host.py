@@ -26,6 +26,20 @@ def _problem(kind):
     elif kind == "quads":
         m = meshes.structured(12, 12, 0, 0, 10, 10, kind="q", bcids=(1, 1, 1, 1), factor=1.0, loading=2)
         mat = oracle.material(0.3, 10.92, 1.0)
+    elif kind == "shuffled":
+        # the panel with its nodes numbered at random: the aggregation then visits the nodes in breadth-first order of the
+        # graph (csrc/amg_setup.cpp: aggregation_order), in the library and in the restatement alike
+        m = meshes.structured(48, 40, 0, 0, 6, 5, kind="t", ul_lr=True, bcids=(0, 0, 1, -1), factor=300.0, loading=2)
+        perm = np.random.default_rng(5).permutation(m.n_nodes)  # new id of old node i
+        inv = np.argsort(perm)
+        m.xyz = m.xyz[inv]
+        m.loads = m.loads[inv]
+        m.tri = perm[m.tri].astype(np.int32)
+        mat = oracle.material(0.3, 1e7, 0.5)
+        dm_old = meshes.structured(48, 40, 0, 0, 6, 5, kind="t", ul_lr=True, bcids=(0, 0, 1, -1), factor=300.0, loading=2).dirichlet_mask()
+        dm = dm_old[inv]
+        rp, ci, vals, F = oracle.assemble(m.xyz, m.tri, m.quad, mat, dm, m.loads)
+        return m, dm, rp, ci, vals, F
     dm = m.dirichlet_mask()
     rp, ci, vals, F = oracle.assemble(m.xyz, m.tri, m.quad, mat, dm, m.loads)
     return m, dm, rp, ci, vals, F
@@ -36,7 +50,28 @@ def _bsr(rowptr, cols, vals, nc):
     return sp.bsr_matrix((vals, cols, rowptr), shape=(6 * n, 6 * nc))
 
 
-@pytest.mark.parametrize("kind", ["panel", "roof", "quads"])
+def test_aggregation_order_and_node_normals_of_the_restatement():
+    m = meshes.structured(24, 20, 0, 0, 6, 5, kind="t", ul_lr=True)
+    _, _, rp, ci, _, _ = _problem("panel")
+    assert list(amg_oracle.aggregation_order(rp, ci)) == list(range(m.n_nodes))  # a sweeping numbering is kept
+    ms, _, rps, cis, _, _ = _problem("shuffled")
+    order = list(amg_oracle.aggregation_order(rps, cis))
+    assert sorted(order) == list(range(ms.n_nodes)) and order != list(range(ms.n_nodes)) and order[0] == 0
+    pos = np.empty(ms.n_nodes, dtype=np.int64)
+    pos[order] = np.arange(ms.n_nodes)
+    # breadth first: every node but the first has a neighbour that comes before it
+    for i in order[1:]:
+        assert pos[cis[rps[i]:rps[i + 1]]].min() < pos[i]
+    roof = meshes.scordelis_lo(12)
+    N = amg_oracle.node_normals(roof.xyz, roof.tri)
+    assert np.allclose(np.linalg.norm(N, axis=1), 1.0)
+    radial = roof.xyz.copy()
+    radial[:, 1] = 0.0  # the roof is a cylinder about the y axis through the origin of x and z (meshes.scordelis_lo)
+    cosang = np.abs(np.sum(N * radial, axis=1)) / np.linalg.norm(radial, axis=1)
+    assert cosang.min() > 0.99
+
+
+@pytest.mark.parametrize("kind", ["panel", "roof", "quads", "shuffled"])
 def test_one_coarsening_step_equals_the_restatement(kind):
     ensure_built()
     m, dm, rp, ci, vals, F = _problem(kind)
