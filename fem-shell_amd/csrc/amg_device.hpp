@@ -24,11 +24,27 @@ struct AmgOperator {
     int32_t n_cols_pad = 0; // padded block columns = nodes of the input vector
 };
 
+// Host copy of the PATTERN of a level operator that lives in HBM in sliced block ELL (values stay on the device): what the
+// integer work of a device coarsening step needs.  Level 0 takes it from the plan, coarser levels from the pattern the
+// previous step built for its Galerkin product.
+struct HostEllPattern {
+    int32_t n = 0;                     // rows (nodes)
+    bool symmetric = false;            // diagonal + upper blocks stored, in-lists below
+    std::vector<int32_t> slice_width;
+    std::vector<int64_t> slice_base;
+    std::vector<int32_t> cols;
+    std::vector<uint8_t> count;        // real entries per row (slots 0 .. count-1)
+    std::vector<int32_t> in_width, in_slots, in_rows;
+    std::vector<int64_t> in_base;
+    bool empty() const { return slice_base.empty(); }
+};
+
 struct AmgLevel {
     int32_t n = 0, n_pad = 0; // nodes (6 dofs each) / padded to whole slices
     int64_t nnzb = 0;         // blocks of the level matrix
     AmgOperator A;            // levels >= 1 (level 0 is the context's K)
     bool A_on_device = false; // the level matrix was computed in HBM (amg_device_setup.cpp), nothing to upload
+    HostEllPattern pattern;   // ... and then this is the host copy of its pattern (for a further step on the device)
     AmgOperator P, R;         // to / from the next coarser level (absent on the coarsest)
     DevBuf<double> minv;      // block-Jacobi inverse of A (levels >= 1)
     double lam = 0.0;         // upper bound of the spectrum of D^-1 A used by the smoother
@@ -91,7 +107,12 @@ double amg_bytes_per_iteration(const femshell_ctx *c);
 // K of a single-rank context as host BSR with ascending columns (api.cpp)
 int download_matrix(femshell_ctx *c, Bsr *A);
 // first coarsening step with the numerics on the device (amg_device_setup.cpp)
-int amg_device_coarsen(femshell_ctx *c, AmgLevel &L, AmgLevel &next, const std::vector<double> &B, double lam, bool keep_host,
+// (A: the level operator in HBM, block-Jacobi inverse valid; pat: host copy of its pattern; want_host(coarse nodes): bring
+//  the coarse operator back as a host matrix -- needed when the next step runs on the host or the level is the coarsest)
+int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &A, const HostEllPattern &pat, AmgLevel &L, AmgLevel &next,
+                       const std::vector<double> &B, double lam, bool keep_host, const std::function<bool(int32_t)> &want_host,
                        Bsr *Ac_host, std::vector<double> *Bc_out, const std::function<void(const char *)> &lap);
+// the pattern of the context's K (level 0) from the plan
+void pattern_of_plan(const Plan &p, HostEllPattern *out);
 
 } // namespace femshell

@@ -165,59 +165,88 @@ int download_vals(const DevBuf<double> &d, std::vector<double, default_init_allo
 
 } // namespace
 
-// the block graph of the context's K as a pattern-only BSR with ascending columns (what download_matrix would give)
-void graph_of_plan(const Plan &p, Bsr *G)
+// the pattern of the context's K: the plan's slot arrays (padding slots of a row repeat the row's own index; multi-rank
+// contexts never get here -- their hierarchy is built by the shadow context)
+void pattern_of_plan(const Plan &p, HostEllPattern *out)
 {
-    Bsr &A = *G;
-    A = Bsr();
-    A.nr = A.nc = p.n_own;
-    A.ptr.assign((size_t)p.n_own + 1, 0);
-    auto count_row = [&](int32_t a) {
-        const int s = a / kSliceNodes, n = a % kSliceNodes;
-        int cnt = 0;
-        for (int k = 0; k < p.slice_width[s]; k++) {
-            const int64_t slot = Plan::slot_index(p.slice_base[s], k, n);
-            if (k == 0 || p.cols[slot] != a) cnt++;
-        }
-        if (p.symmetric)
-            for (int k = 0; k < p.in_width[s]; k++)
-                if (p.in_slots[(size_t)(p.in_base[s] + (int64_t)k * kSliceNodes + n)] >= 0) cnt++;
-        return cnt;
-    };
-    for (int32_t a = 0; a < p.n_own; a++) A.ptr[a + 1] = A.ptr[a] + count_row(a);
-    A.col.resize((size_t)A.ptr[p.n_own]);
+    HostEllPattern &H = *out;
+    H = HostEllPattern();
+    H.n = p.n_own;
+    H.symmetric = p.symmetric;
+    H.slice_width = p.slice_width;
+    H.slice_base = p.slice_base;
+    H.cols = p.cols;
+    H.count.assign((size_t)p.n_pad, 0);
     parallel_chunks(p.n_own, [&](int64_t a0, int64_t a1) {
         for (int64_t a = a0; a < a1; a++) {
             const int s = (int)(a / kSliceNodes), n = (int)(a % kSliceNodes);
-            int64_t w = A.ptr[a];
+            int cnt = 0;
             for (int k = 0; k < p.slice_width[s]; k++) {
                 const int64_t slot = Plan::slot_index(p.slice_base[s], k, n);
-                if (k == 0 || p.cols[slot] != a) A.col[(size_t)w++] = p.cols[slot];
+                if (k == 0 || p.cols[slot] != a) cnt = k + 1; // real slots come first (ascending columns, padding behind)
             }
-            if (p.symmetric)
-                for (int k = 0; k < p.in_width[s]; k++) {
-                    const size_t e = (size_t)(p.in_base[s] + (int64_t)k * kSliceNodes + n);
-                    if (p.in_slots[e] >= 0) A.col[(size_t)w++] = p.in_rows[e];
+            H.count[(size_t)a] = (uint8_t)cnt;
+        }
+    });
+    if (p.symmetric) {
+        H.in_width = p.in_width;
+        H.in_base = p.in_base;
+        H.in_slots = p.in_slots;
+        H.in_rows = p.in_rows;
+    }
+}
+
+namespace {
+
+// the block graph of a level operator as a pattern-only BSR with ascending columns (both directions of a symmetric one)
+void graph_of_pattern(const HostEllPattern &H, Bsr *G)
+{
+    Bsr &A = *G;
+    A = Bsr();
+    const int32_t n = H.n;
+    A.nr = A.nc = n;
+    A.ptr.assign((size_t)n + 1, 0);
+    auto count_row = [&](int32_t a) {
+        const int s = a / kSliceNodes, nn = a % kSliceNodes;
+        int cnt = H.count[(size_t)a];
+        if (H.symmetric)
+            for (int k = 0; k < H.in_width[s]; k++)
+                if (H.in_slots[(size_t)(H.in_base[s] + (int64_t)k * kSliceNodes + nn)] >= 0) cnt++;
+        return cnt;
+    };
+    for (int32_t a = 0; a < n; a++) A.ptr[a + 1] = A.ptr[a] + count_row(a);
+    A.col.resize((size_t)A.ptr[n]);
+    parallel_chunks(n, [&](int64_t a0, int64_t a1) {
+        for (int64_t a = a0; a < a1; a++) {
+            const int s = (int)(a / kSliceNodes), nn = (int)(a % kSliceNodes);
+            int64_t w = A.ptr[a];
+            for (int k = 0; k < H.count[(size_t)a]; k++) A.col[(size_t)w++] = H.cols[(size_t)(H.slice_base[s] + (int64_t)k * kSliceNodes + nn)];
+            if (H.symmetric)
+                for (int k = 0; k < H.in_width[s]; k++) {
+                    const size_t e = (size_t)(H.in_base[s] + (int64_t)k * kSliceNodes + nn);
+                    if (H.in_slots[e] >= 0) A.col[(size_t)w++] = H.in_rows[e];
                 }
             std::sort(A.col.begin() + A.ptr[a], A.col.begin() + A.ptr[a + 1]);
         }
     });
 }
 
+} // namespace
+
 // One coarsening step of level 0 on the device.  In: the context's K (c->dm, block-Jacobi inverse valid), the near-null
 // space B of the fine nodes, the spectral bound lam.  Out: L.P, L.R (operators of the cycle), next.A (the coarse level
 // matrix in HBM, diagonal slot first), Ac_host (its host copy for the remaining levels), Bc, and for small problems the
 // host copies the inspection exports want.
-int amg_device_coarsen(femshell_ctx *c, AmgLevel &L, AmgLevel &next, const std::vector<double> &B, double lam, bool keep_host,
+int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllPattern &pat, AmgLevel &L, AmgLevel &next,
+                       const std::vector<double> &B, double lam, bool keep_host, const std::function<bool(int32_t)> &want_host,
                        Bsr *Ac_host, std::vector<double> *Bc_out, const std::function<void(const char *)> &lap)
 {
-    const Plan &p = c->plan;
     hipStream_t st = c->stream;
-    const int32_t n = p.n_own;
+    const int32_t n = pat.n;
     if (c->cfg.world_size != 1) return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: single-rank contexts only");
     // ---- aggregation and tentative prolongator on the graph
     Bsr G;
-    graph_of_plan(p, &G);
+    graph_of_pattern(pat, &G);
     std::vector<int32_t> agg;
     const int32_t na = aggregate_nodes(G, &agg);
     lap("graph + aggregation");
@@ -253,19 +282,18 @@ int amg_device_coarsen(femshell_ctx *c, AmgLevel &L, AmgLevel &next, const std::
         return (int)(std::lower_bound(b, e, J) - b);
     };
     // which slot of P's row every block of K feeds (own slots and in-list entries, in the order the kernels walk them)
-    std::vector<uint8_t> pmap_own((size_t)p.total_slots(), 0), pmap_in(p.in_slots.size(), 0);
+    std::vector<uint8_t> pmap_own((size_t)pat.slice_base.back(), 0), pmap_in(pat.in_slots.size(), 0);
     parallel_chunks(n, [&](int64_t a0, int64_t a1) {
         for (int64_t a = a0; a < a1; a++) {
             const int s = (int)(a / kSliceNodes), nn = (int)(a % kSliceNodes);
-            for (int k = 0; k < p.slice_width[s]; k++) {
-                const int64_t slot = Plan::slot_index(p.slice_base[s], k, nn);
-                const int32_t cc = p.cols[slot];
-                if (k == 0 || cc != a) pmap_own[(size_t)slot] = (uint8_t)p_index((int32_t)a, agg[cc]);
+            for (int k = 0; k < pat.count[(size_t)a]; k++) {
+                const int64_t slot = pat.slice_base[s] + (int64_t)k * kSliceNodes + nn;
+                pmap_own[(size_t)slot] = (uint8_t)p_index((int32_t)a, agg[pat.cols[(size_t)slot]]);
             }
-            if (p.symmetric)
-                for (int k = 0; k < p.in_width[s]; k++) {
-                    const size_t e = (size_t)(p.in_base[s] + (int64_t)k * kSliceNodes + nn);
-                    if (p.in_slots[e] >= 0) pmap_in[e] = (uint8_t)p_index((int32_t)a, agg[p.in_rows[e]]);
+            if (pat.symmetric)
+                for (int k = 0; k < pat.in_width[s]; k++) {
+                    const size_t e = (size_t)(pat.in_base[s] + (int64_t)k * kSliceNodes + nn);
+                    if (pat.in_slots[e] >= 0) pmap_in[e] = (uint8_t)p_index((int32_t)a, agg[pat.in_rows[e]]);
                 }
         }
     });
@@ -384,9 +412,9 @@ int amg_device_coarsen(femshell_ctx *c, AmgLevel &L, AmgLevel &next, const std::
     hipEvent_t ev[5];
     for (auto &e : ev) FS_HIP(hipEventCreate(&e));
     FS_HIP(hipEventRecord(ev[0], st));
-    launch_amg_prolongator(c->dm, d_agg.p, d_Q.p, (4.0 / 3.0) / lam, d_pmap_own.p, d_pmap_in.p, wP, st);
+    launch_amg_prolongator(Adev, d_agg.p, d_Q.p, (4.0 / 3.0) / lam, d_pmap_own.p, d_pmap_in.p, wP, st);
     FS_HIP(hipEventRecord(ev[1], st));
-    launch_amg_ap(c->dm, wP, wAP, st);
+    launch_amg_ap(Adev, wP, wAP, st);
     FS_HIP(hipEventRecord(ev[2], st));
     launch_amg_restriction(wP, d_rptr.p, d_rrow.p, d_rk.p, wR, st);
     FS_HIP(hipEventRecord(ev[3], st));
@@ -394,7 +422,7 @@ int amg_device_coarsen(femshell_ctx *c, AmgLevel &L, AmgLevel &next, const std::
     FS_HIP(hipEventRecord(ev[4], st));
     FS_HIP(hipGetLastError());
     FS_HIP(hipStreamSynchronize(st));
-    {
+    if (!c->amg->levels.empty() && &L == c->amg->levels[0].get()) { // the statistics describe the step that matters: level 0
         AmgSetupStats &S = c->amg->stats;
         float ms = 0.f;
         FS_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
@@ -425,10 +453,13 @@ int amg_device_coarsen(femshell_ctx *c, AmgLevel &L, AmgLevel &next, const std::
     // ---- the coarse operator goes back for the remaining levels; small problems keep P for the inspection exports
     {
         ValueArray h;
-        rc = download_vals(vAc, &h, st);
-        if (rc) return rc;
-        ell_to_bsr(eAc, h.data(), na, Ac_host);
-        if (sym_coarse) mirror_upper(Ac_host); // the host algorithms of the next levels take the full matrix
+        *Ac_host = Bsr();
+        if (want_host(na) || keep_host) {
+            rc = download_vals(vAc, &h, st);
+            if (rc) return rc;
+            ell_to_bsr(eAc, h.data(), na, Ac_host);
+            if (sym_coarse) mirror_upper(Ac_host); // the host algorithms of the next levels take the full matrix
+        }
         if (keep_host) {
             rc = download_vals(vP, &h, st);
             if (rc) return rc;
@@ -440,12 +471,23 @@ int amg_device_coarsen(femshell_ctx *c, AmgLevel &L, AmgLevel &next, const std::
     adopt(L.P, eP, dP, vP, nc_pad);
     adopt(L.R, eR, dR, vR, eP.n_pad);
     adopt(next.A, eAc, dAc, vAc, nc_pad);
+    next.pattern = HostEllPattern();
+    next.pattern.n = na;
+    next.pattern.symmetric = sym_coarse;
     if (sym_coarse) {
         SlicedEllSym S;
         build_in_lists(na, eAc.slice_width, eAc.slice_base, eAc.cols, eAc.count, &S);
         rc = attach_in_lists(next.A, S, eAc.total(), st);
         if (rc) return rc;
+        next.pattern.in_width.swap(S.in_width);
+        next.pattern.in_base.swap(S.in_base);
+        next.pattern.in_slots.swap(S.in_slots);
+        next.pattern.in_rows.swap(S.in_rows);
     }
+    next.pattern.slice_width.swap(eAc.slice_width);
+    next.pattern.slice_base.swap(eAc.slice_base);
+    next.pattern.cols.swap(eAc.cols);
+    next.pattern.count.swap(eAc.count);
     lap("download of the coarse operator");
     return FEMSHELL_OK;
 }

@@ -195,6 +195,18 @@ int amg_setup(femshell_ctx *c)
             node_normals(pl.n_own, pl.xyz_local.data(), pl.n_ltri(), pl.tri_local.data(), pl.n_lquad(), pl.quad_local.data(), &normals);
         rigid_body_modes(pl.n_own, pl.xyz_local.data(), c->dmask_global.data() + pl.row_begin, &B, plain ? nullptr : normals.data());
     }
+    // Levels of more than device_min nodes are coarsened with the numerics on the device (amg_device_setup.cpp): their
+    // operator is in HBM already and only its pattern is needed on the host.  The coarse operator of such a step comes
+    // back as a host matrix only when the next step runs on the host (a small level, the coarsest one, the last allowed).
+    const char *dmin_env = getenv("FEMSHELL_AMG_DEVICE_MIN"); // nodes; levels at or below it are coarsened on the host
+    const int32_t device_min = dmin_env ? (int32_t)atol(dmin_env) : (int32_t)20000;
+    auto device_step = [&](int l, int32_t n_nodes) { // does level l take a device step?
+        return !host_only && n_nodes > std::max(device_min, opt.coarsest_nodes) && l + 2 < opt.max_levels;
+    };
+    // (decided by amg_device_coarsen for the level it creates: it knows the coarse size only after the aggregation)
+    auto want_host_matrix = [&](int next_level) {
+        return std::function<bool(int32_t)>([&, next_level](int32_t na) { return !device_step(next_level, na); });
+    };
     int rc = FEMSHELL_OK;
     int first_level = 0;
     if (!host_only && pl.n_own > opt.coarsest_nodes && opt.max_levels > 1) {
@@ -213,8 +225,11 @@ int amg_setup(femshell_ctx *c)
         H.levels.emplace_back(new AmgLevel());
         AmgLevel &L1 = *H.levels.back();
         std::vector<double> Bc;
-        rc = amg_device_coarsen(c, L0, L1, B, L0.lam, keep_host, &A, &Bc, [&](const char *what) { lap(what, 0); });
+        pattern_of_plan(pl, &L0.pattern);
+        rc = amg_device_coarsen(c, c->dm, L0.pattern, L0, L1, B, L0.lam, keep_host, want_host_matrix(1), &A, &Bc,
+                                [&](const char *what) { lap(what, 0); });
         if (rc) return rc;
+        L0.pattern = HostEllPattern(); // (the plan holds it)
         L1.A_on_device = true;
         if (keep_host) {
             rc = download_matrix(c, &L0.hA);
@@ -231,9 +246,17 @@ int amg_setup(femshell_ctx *c)
     for (int l = first_level;; l++) {
         if ((int)H.levels.size() <= l) H.levels.emplace_back(new AmgLevel());
         AmgLevel &L = *H.levels[l];
-        L.n = A.nr;
-        L.n_pad = (A.nr + kSliceNodes - 1) / kSliceNodes * kSliceNodes;
-        L.nnzb = A.nnzb();
+        const bool have_host = A.nr > 0 || !L.A_on_device; // the level's operator as a host matrix (else: in HBM + pattern)
+        if (have_host) {
+            L.n = A.nr;
+            L.nnzb = A.nnzb();
+        } else {
+            L.n = L.pattern.n;
+            int64_t stored = 0;
+            for (int32_t a = 0; a < L.n; a++) stored += L.pattern.count[(size_t)a];
+            L.nnzb = L.pattern.symmetric ? 2 * stored - L.n : stored;
+        }
+        L.n_pad = (L.n + kSliceNodes - 1) / kSliceNodes * kSliceNodes;
         if (l > 0) {
             if (!L.A_on_device) {
                 // the level operators are symmetric: diagonal and upper blocks only, like K (FEMSHELL_SYMMETRIC=0: full)
@@ -270,6 +293,7 @@ int amg_setup(femshell_ctx *c)
         if (coarsest) {
             std::vector<double> inv;
             if (L.n > 4096) return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: coarsest level too large for a dense inverse");
+            if (!have_host) return set_err(FEMSHELL_ERR_INVALID, "multigrid setup: the coarsest operator was not brought to the host");
             if (!dense_inverse(A, &inv))
                 return set_err(FEMSHELL_ERR_BREAKDOWN, "multigrid setup: coarsest operator is not positive definite");
             FS_HIP(H.coarse_inv.upload(inv, st));
@@ -283,6 +307,23 @@ int amg_setup(femshell_ctx *c)
         L.lam = 1.1 * lam; // the power iteration approaches from below
         lap("power iteration", l);
         // coarsen
+        if (L.A_on_device && !L.pattern.empty() && device_step(l, L.n)) {
+            // on the device: the operator is in HBM, its pattern on the host (amg_device_setup.cpp)
+            if ((int)H.levels.size() <= l + 1) H.levels.emplace_back(new AmgLevel());
+            AmgLevel &N = *H.levels[(size_t)l + 1];
+            std::vector<double> Bc;
+            Bsr Anext;
+            rc = amg_device_coarsen(c, L.A.dm, L.pattern, L, N, B, L.lam, keep_host, want_host_matrix(l + 1), &Anext, &Bc,
+                                    [&](const char *what) { lap(what, l); });
+            if (rc) return rc;
+            N.A_on_device = true;
+            if (keep_host && have_host) L.hA = std::move(A);
+            L.pattern = HostEllPattern();
+            A = std::move(Anext);
+            B.swap(Bc);
+            continue;
+        }
+        if (!have_host) return set_err(FEMSHELL_ERR_INVALID, "multigrid setup: level operator neither on the host nor coarsened on the device");
         std::vector<int32_t> agg;
         const int32_t na = aggregate_nodes(A, &agg);
         lap("aggregation", l);
