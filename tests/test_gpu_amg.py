@@ -95,6 +95,13 @@ def test_hierarchy_and_iteration_counts_follow_the_restatement(cycle):
     fs.close()
 
 
+def test_every_level_coarsened_on_the_device_follows_the_restatement_too(monkeypatch):
+    # levels above FEMSHELL_AMG_DEVICE_MIN nodes (20,000 by default: the test meshes never get there below level 0) take
+    # their coarsening step with the numerics on the device; forced down to 100-node levels here
+    monkeypatch.setenv("FEMSHELL_AMG_DEVICE_MIN", "100")
+    test_hierarchy_and_iteration_counts_follow_the_restatement("K")
+
+
 def test_double_double_residual_and_what_refinement_buys():
     # thin roof: ||K|| ||x|| / ||b|| ~ 1e7.  The FP64 residual of a converged iterate is rounding noise, the
     # double-double one is exact to 1e-12 ||b||; without refinement the displacement error stalls near kappa*eps,
