@@ -451,6 +451,13 @@ int amg_attach_shadow(femshell_ctx *c)
 
 namespace {
 
+// FEMSHELL_AMG_FUSED_CHEB=0: product and Chebyshev step of the full-storage levels as two launches (A/B runs)
+bool fused_cheb()
+{
+    const char *e = getenv("FEMSHELL_AMG_FUSED_CHEB");
+    return !(e && atoi(e) == 0);
+}
+
 struct Cycle {
     femshell_ctx *c;
     Amg &H;
@@ -467,10 +474,14 @@ struct Cycle {
             rcur = L.r.p;
         }
         launch_cheb_start(A, rcur, L.d.p, x, L.inv_theta, !zero_guess, gate, st);
+        double *d_cur = L.d.p, *d_next = L.q.p; // full-storage levels: the direction alternates between the two vectors
         for (size_t k = 0; k < L.cheb_a.size(); k++) {
             if (A.symmetric) { // first phase of the product; the step kernel collects the transposed products
                 launch_spmv_direct(A, L.d.p, L.q.p, nullptr, gate, st);
                 launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, true);
+            } else if (fused_cheb()) { // product and step in one launch (the small levels are bound by launch latency)
+                launch_spmv_cheb(A, d_cur, rcur, L.r.p, d_next, x, L.cheb_a[k], L.cheb_c[k], gate, st);
+                std::swap(d_cur, d_next);
             } else {
                 launch_spmv(A, L.d.p, L.q.p, nullptr, gate, st);
                 launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st);

@@ -300,14 +300,22 @@ __device__ __forceinline__ double spmv_fma(const SpmvChunk<kChunk> &c, const dou
     return acc;
 }
 
+// (cheb: the epilogue of launch_spmv_cheb -- y is r_out, base_vec r_in with sign -1, x the direction d_in)
+struct ChebEpilogue {
+    double *d_out = nullptr; // nullptr: plain product
+    double *xsol = nullptr;
+    double a = 0.0, c = 0.0;
+};
+
 template <int kChunk>
 __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__restrict__ x,
                                               double *__restrict__ y, double *__restrict__ partials,
                                               const CgScalars *s, const int32_t *__restrict__ order, int count,
-                                              const double *base_vec, double sign, int panel)
+                                              const double *base_vec, double sign, int panel, ChebEpilogue cheb)
 {
     extern __shared__ double2 xs_all[]; // panel slots x 32 nodes x 3 words: x of the slice's block columns
     __shared__ double sh[3];
+    __shared__ double rs[kSliceRows]; // Chebyshev epilogue: the slice's new residual, node-major
     if (s != nullptr && s->done != 0) return;
     const int t = threadIdx.x;
     const double2 *x2 = reinterpret_cast<const double2 *>(x);
@@ -346,7 +354,27 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
         }
         const int64_t row = (int64_t)sl * kSliceRows + (t & 31) * 6 + (t >> 5);
         // base_vec: y = base + sign * K x (residual b - K x, prolongation x + P x_c); may alias y
-        y[row] = base_vec != nullptr ? base_vec[row] + sign * acc : acc;
+        const double yv = base_vec != nullptr ? base_vec[row] + sign * acc : acc;
+        y[row] = yv;
+        if (cheb.d_out != nullptr) {
+            // d_out = a d_in + c D^-1 r_out on the lane's row; the six residual entries of its node sit in six lanes of
+            // three waves (lane = node + 32 dof): exchanged through LDS
+            const int n = t & 31, i = t >> 5;
+            const double *mi = m.minv + (int64_t)sl * kMinvWords * kSliceNodes + n;
+            double mrow[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) mrow[j] = mi[minv_word(i < j ? i : j, i < j ? j : i) * kSliceNodes];
+            const double dv = x[row], xv = cheb.xsol[row];
+            __syncthreads();
+            rs[n * 6 + i] = yv;
+            __syncthreads();
+            double z = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) z += mrow[j] * rs[n * 6 + j];
+            const double dn = cheb.a * dv + cheb.c * z;
+            cheb.d_out[row] = dn;
+            cheb.xsol[row] = xv + dn;
+        }
         if (partials != nullptr) dotv += acc * (((t >> 5) & 1) ? xw.y : xw.x);
     }
     if (partials != nullptr) {
@@ -612,7 +640,7 @@ constexpr int kSpmvPanel = 64; // block slots of x staged in LDS at a time by k_
 
 static void spmv_dispatch(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
                           const int32_t *order, int count, int grid, hipStream_t st, const double *base_vec = nullptr,
-                          double sign = 1.0)
+                          double sign = 1.0, ChebEpilogue cheb = ChebEpilogue())
 {
     static const int chunk = [] {
         const char *e = getenv("FEMSHELL_SPMV_CHUNK"); // tuning knob: block slots loaded together
@@ -625,7 +653,7 @@ static void spmv_dispatch(const DeviceMatrix &m, const double *x, double *y, dou
     auto launch = [&](auto kernel) {
         if (lds > 64 * 1024) // beyond the default dynamic-LDS limit (slices wider than 42 blocks)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kernel, g, b, lds, st, m, x, y, partials, s, order, count, base_vec, sign, panel);
+        hipLaunchKernelGGL(kernel, g, b, lds, st, m, x, y, partials, s, order, count, base_vec, sign, panel, cheb);
     };
     switch (chunk) {
     case 1: launch(k_spmv<1>); break;
@@ -644,6 +672,17 @@ void launch_spmv(const DeviceMatrix &m, const double *x, double *y, double *part
         return;
     }
     spmv_dispatch(m, x, y, partials, s, nullptr, m.n_slices, slice_grid(m), st);
+}
+
+void launch_spmv_cheb(const DeviceMatrix &m, const double *d_in, const double *r_in, double *r_out, double *d_out, double *x,
+                      double a, double c, const CgScalars *s, hipStream_t st)
+{
+    ChebEpilogue e;
+    e.d_out = d_out;
+    e.xsol = x;
+    e.a = a;
+    e.c = c;
+    spmv_dispatch(m, d_in, r_out, nullptr, s, nullptr, m.n_slices, slice_grid(m), st, r_in, -1.0, e);
 }
 
 void launch_spmv_axpy(const DeviceMatrix &m, const double *x, double *y, const double *base_vec, double sign,

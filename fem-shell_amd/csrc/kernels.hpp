@@ -126,6 +126,11 @@ void launch_spmv(const DeviceMatrix &m, const double *x, double *y, double *part
                  hipStream_t st);
 // y = base_vec + sign * K x (base_vec may be y itself): residuals b - K x and prolongations x + P x_c of the
 // multigrid cycle; K may be rectangular (x indexed by the block columns, y and base_vec by the block rows)
+// One Chebyshev step of the smoother in D^-1 A on a full-storage operator, fused with its product (multigrid levels that
+// are bound by the latency between launches): r_out = r_in - A d_in; d_out = a d_in + c D^-1 r_out; x += d_out.
+// d_out must not be d_in (other workgroups still read d_in); r_out may be r_in.
+void launch_spmv_cheb(const DeviceMatrix &m, const double *d_in, const double *r_in, double *r_out, double *d_out, double *x,
+                      double a, double c, const CgScalars *s, hipStream_t st);
 void launch_spmv_axpy(const DeviceMatrix &m, const double *x, double *y, const double *base_vec, double sign,
                       const CgScalars *s, hipStream_t st);
 // symmetric storage only: second phase of a product whose first phase ran through launch_spmv_span (the transposed
