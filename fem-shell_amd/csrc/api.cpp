@@ -52,7 +52,8 @@ double bytes_spmv(const femshell_ctx *c)
     const Plan &p = c->plan;
     // (symmetric storage: every stored block is streamed once; the 48-byte transposed products written and read
     // beside them are overhead of the method, not algorithmic traffic)
-    return 292.0 * (double)p.stored_blocks + 4.0 * (p.n_own + 1) + 96.0 * p.n_own;
+    // ... and of a diagonal block the 12 words (192 bytes) that hold its upper triangle
+    return 292.0 * (double)p.stored_blocks - (p.symmetric ? 96.0 * p.n_own : 0.0) + 4.0 * (p.n_own + 1) + 96.0 * p.n_own;
 }
 // (the inverse diagonal blocks are symmetric: 21 of their 36 words are stored and read)
 double bytes_update(const femshell_ctx *c) { return (7.0 * 48.0 + 168.0) * c->plan.n_own; }

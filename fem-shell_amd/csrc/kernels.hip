@@ -419,18 +419,34 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
         for (int i = 0; i < 6; i++) ya[i] = 0.0;
         const double2 *v = reinterpret_cast<const double2 *>(m.vals + base * 36) + n;
         double2 *tb = reinterpret_cast<double2 *>(m.tbuf + base * 6);
-        for (int k = 0; k < W; k++) {
-            const int c = (k == 0) ? a : m.cols[base + (int64_t)k * kSliceNodes + n];
-            typedef double v2d __attribute__((ext_vector_type(2)));
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        if (W > 0) {
+            // slot 0 is the diagonal block K_aa, which is symmetric: only the 12 of its 18 words that hold the upper
+            // triangle are read (each word is 512 contiguous bytes of the slice, so the other six never leave HBM);
+            // element (i, j) below the diagonal is taken from (j, i).  Same order of the sum over j as in the loop
+            // below, so a block whose halves mirror each other exactly (k_assemble's do) gives the same bits.
+            const v2d *vv = reinterpret_cast<const v2d *>(v);
+            v2d wd[18];
+#pragma unroll
+            for (int e = 0; e < 18; e++)
+                if (2 * (e / 6) + 1 >= e % 6) wd[e] = __builtin_nontemporal_load(vv + e * kSliceNodes);
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const int r = j >= i ? i : j, cl = j >= i ? j : i; // (r, cl): the element of the upper triangle
+                    const v2d kw = wd[(cl >> 1) * 6 + r];
+                    ya[i] += ((cl & 1) ? kw.y : kw.x) * xa[j];
+                }
+        }
+        for (int k = 1; k < W; k++) {
+            const int c = m.cols[base + (int64_t)k * kSliceNodes + n];
             const v2d *vv = reinterpret_cast<const v2d *>(v + (size_t)k * 18 * kSliceNodes);
             v2d wd[18];
 #pragma unroll
             for (int e = 0; e < 18; e++) wd[e] = __builtin_nontemporal_load(vv + e * kSliceNodes); // word (jp = e/6, i = e%6)
             double xc[6];
-            if (k == 0) {
-#pragma unroll
-                for (int i = 0; i < 6; i++) xc[i] = xa[i];
-            } else {
+            {
                 const double2 c0 = x2[3 * (int64_t)c], c1 = x2[3 * (int64_t)c + 1], c2 = x2[3 * (int64_t)c + 2];
                 xc[0] = c0.x; xc[1] = c0.y; xc[2] = c1.x; xc[3] = c1.y; xc[4] = c2.x; xc[5] = c2.y;
             }
@@ -449,7 +465,7 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
                 }
             // the transpose acts on row c when c is another owned row (ghost columns belong to another rank,
             // padding slots point at the own row)
-            if (k > 0 && c != a && c < m.n_pad) {
+            if (c != a && c < m.n_pad) {
                 double2 *t = tb + ((size_t)k * kSliceNodes + n) * 3;
                 t[0] = make_double2(u[0], u[1]);
                 t[1] = make_double2(u[2], u[3]);
