@@ -59,6 +59,9 @@ int host_threads();
 // normals (optional, n x 3 unit vectors or zeros): the rotational parts of the three rotation modes are projected onto
 // the tangent plane of each node (see amg_setup.cpp)
 void rigid_body_modes(int32_t n, const double *xyz, const uint8_t *dmask, std::vector<double> *B, const double *normals = nullptr);
+// the point the rotation modes turn about: the mean of the node coordinates (the device generates the modes of the finest
+// level from it, amg_kernels.hip near_null_row)
+void mesh_centre(int32_t n, const double *xyz, double c[3]);
 // area-weighted unit normals of the nodes [0, n) from the elements of a mesh in the same numbering (tri: 3 ids, quad: 4 ids
 // per element; nodes >= n are neighbours whose coordinates are in xyz too)
 void node_normals(int32_t n, const double *xyz, int64_t n_tri, const int32_t *tri, int64_t n_quad, const int32_t *quad,

@@ -109,9 +109,13 @@ int download_matrix(femshell_ctx *c, Bsr *A);
 // first coarsening step with the numerics on the device (amg_device_setup.cpp)
 // (A: the level operator in HBM, block-Jacobi inverse valid; pat: host copy of its pattern; want_host(coarse nodes): bring
 //  the coarse operator back as a host matrix -- needed when the next step runs on the host or the level is the coarsest)
+// (B: the level's near-null space in HBM -- generated from the mesh on level 0, the previous step's Bc_dev below; the
+//  tentative prolongator is factorised there.  Bc_dev: the coarse level's near-null space in HBM; Bc_out: its host copy,
+//  filled under the same condition as Ac_host)
 int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &A, const HostEllPattern &pat, AmgLevel &L, AmgLevel &next,
-                       const std::vector<double> &B, double lam, bool keep_host, const std::function<bool(int32_t)> &want_host,
-                       Bsr *Ac_host, std::vector<double> *Bc_out, const std::function<void(const char *)> &lap);
+                       const NearNullSrc &B, double lam, bool keep_host, const std::function<bool(int32_t)> &want_host,
+                       Bsr *Ac_host, std::vector<double> *Bc_out, DevBuf<double> *Bc_dev,
+                       const std::function<void(const char *)> &lap);
 // the pattern of the context's K (level 0) from the plan
 void pattern_of_plan(const Plan &p, HostEllPattern *out);
 

@@ -238,8 +238,9 @@ void graph_of_pattern(const HostEllPattern &H, Bsr *G)
 // matrix in HBM, diagonal slot first), Ac_host (its host copy for the remaining levels), Bc, and for small problems the
 // host copies the inspection exports want.
 int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllPattern &pat, AmgLevel &L, AmgLevel &next,
-                       const std::vector<double> &B, double lam, bool keep_host, const std::function<bool(int32_t)> &want_host,
-                       Bsr *Ac_host, std::vector<double> *Bc_out, const std::function<void(const char *)> &lap)
+                       const NearNullSrc &B, double lam, bool keep_host, const std::function<bool(int32_t)> &want_host,
+                       Bsr *Ac_host, std::vector<double> *Bc_out, DevBuf<double> *Bc_dev,
+                       const std::function<void(const char *)> &lap)
 {
     hipStream_t st = c->stream;
     const int32_t n = pat.n;
@@ -250,8 +251,37 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     std::vector<int32_t> agg;
     const int32_t na = aggregate_nodes(G, &agg);
     lap("graph + aggregation");
-    std::vector<double> Q;
-    tentative_prolongator(agg, na, B, &Q, Bc_out);
+    // tentative prolongator on the device: QR of every aggregate's rows of B, one wave each (k_amg_tentative_qr); the host
+    // only groups the nodes by aggregate
+    DevBuf<double> d_Q;
+    {
+        std::vector<int32_t> gptr((size_t)na + 1, 0), order((size_t)n);
+        for (int32_t i = 0; i < n; i++) gptr[(size_t)agg[i] + 1]++;
+        int32_t largest = 0;
+        for (int32_t I = 0; I < na; I++) {
+            largest = std::max(largest, gptr[(size_t)I + 1]);
+            gptr[(size_t)I + 1] += gptr[I];
+        }
+        {
+            std::vector<int32_t> fill(gptr.begin(), gptr.end() - 1);
+            for (int32_t i = 0; i < n; i++) order[(size_t)fill[agg[i]]++] = i;
+        }
+        DevBuf<int32_t> d_gptr, d_order;
+        FS_HIP(d_gptr.upload(gptr, st));
+        FS_HIP(d_order.upload(order, st));
+        FS_HIP(d_Q.alloc((size_t)n * 36));
+        FS_HIP(Bc_dev->alloc((size_t)na * 36));
+        // FEMSHELL_AMG_QR=memory: every aggregate takes the path of the large ones (rows in Q instead of registers; tests)
+        const bool in_memory = getenv("FEMSHELL_AMG_QR") && std::string(getenv("FEMSHELL_AMG_QR")) == "memory";
+        launch_amg_tentative_qr(B, d_gptr.p, d_order.p, na, largest, d_Q.p, Bc_dev->p, in_memory, st);
+        FS_HIP(hipGetLastError());
+        Bc_out->clear();
+        if (want_host(na) || keep_host) {
+            Bc_out->resize((size_t)na * 36);
+            FS_HIP(hipMemcpyAsync(Bc_out->data(), Bc_dev->p, Bc_out->size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        }
+        FS_HIP(hipStreamSynchronize(st)); // gptr / order go out of scope
+    }
     lap("tentative P");
 
     // ---- patterns
@@ -384,12 +414,11 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
 
     // ---- values on the device
     DevBuf<int32_t> d_agg, d_rrow;
-    DevBuf<double> d_Q, vP, vAP, vR, vAc;
+    DevBuf<double> vP, vAP, vR, vAc;
     DevBuf<uint8_t> d_pmap_own, d_pmap_in, d_rk;
     DevBuf<int64_t> d_rptr;
     DevPattern dP, dAP, dR, dAc;
     FS_HIP(d_agg.upload(agg, st));
-    FS_HIP(d_Q.upload(Q, st));
     FS_HIP(d_pmap_own.upload(pmap_own, st));
     FS_HIP(d_pmap_in.upload(pmap_in, st));
     FS_HIP(d_rptr.upload(rptr, st));

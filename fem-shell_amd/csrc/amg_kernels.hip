@@ -687,6 +687,161 @@ __global__ __launch_bounds__(64) void k_amg_galerkin_mfma(EllView P, EllView AP,
     }
 }
 
+// ---- tentative prolongator
+// row d of the 6x6 near-null block of `node`
+__device__ __forceinline__ void near_null_row(const NearNullSrc &S, int32_t node, int d, double out[6])
+{
+    if (S.B != nullptr) {
+        const double2 *b = reinterpret_cast<const double2 *>(S.B + (int64_t)node * 36 + 6 * d);
+        const double2 b0 = b[0], b1 = b[1], b2 = b[2];
+        out[0] = b0.x; out[1] = b0.y; out[2] = b1.x; out[3] = b1.y; out[4] = b2.x; out[5] = b2.y;
+        return;
+    }
+#pragma unroll
+    for (int m = 0; m < 6; m++) out[m] = (m == d) ? 1.0 : 0.0;
+    if (d < 3) {
+        // u = omega x r: rotation about x -> (0,-z,y), about y -> (z,0,-x), about z -> (-y,x,0)
+        const double x = S.xyz[3ll * node] - S.cx, y = S.xyz[3ll * node + 1] - S.cy, z = S.xyz[3ll * node + 2] - S.cz;
+        out[3] = d == 1 ? -z : (d == 2 ? y : 0.0);
+        out[4] = d == 0 ? z : (d == 2 ? -x : 0.0);
+        out[5] = d == 0 ? -y : (d == 1 ? x : 0.0);
+    } else if (S.normals != nullptr) {
+        const double *nv = S.normals + 3ll * node;
+        const double ni = nv[d - 3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) out[3 + j] -= ni * nv[j];
+    }
+    if (S.dmask != nullptr && ((S.dmask[node] >> d) & 1u)) {
+#pragma unroll
+        for (int m = 0; m < 6; m++) out[m] = 0.0;
+    }
+}
+
+__device__ __forceinline__ double wave_sum_all(double v) // the sum of the wave in every lane (lane 0's association order)
+{
+    v = wave_sum(v);
+    return __shfl(v, 0, 64);
+}
+
+constexpr int kQrRowsPerLane = 4; // rows of an aggregate held in registers: 256 rows = 42 nodes; larger ones work in memory
+
+// kInMemory = false: every lane keeps up to kQrRowsPerLane rows of the aggregate's 6k x 6 matrix in registers.
+// kInMemory = true (aggregates of more than 42 nodes, or all with FEMSHELL_AMG_QR=memory): the rows live in Q itself.
+template <bool kInMemory>
+__global__ __launch_bounds__(64) void k_amg_tentative_qr(NearNullSrc S, const int32_t *__restrict__ aptr,
+                                                         const int32_t *__restrict__ order, int32_t na, double *__restrict__ Q,
+                                                         double *__restrict__ Bc, int all)
+{
+    const int lane = threadIdx.x;
+    for (int32_t a = blockIdx.x; a < na; a += gridDim.x) {
+        const int32_t p0 = aptr[a];
+        const int rows = 6 * (aptr[a + 1] - p0);
+        const bool big = rows > 64 * kQrRowsPerLane || all != 0;
+        if (big != kInMemory) continue; // (uniform per wave) the other instantiation takes this aggregate
+        double R[36];
+#pragma unroll
+        for (int e = 0; e < 36; e++) R[e] = 0.0;
+        if (!kInMemory) {
+            double m[kQrRowsPerLane][6];
+            int64_t dst[kQrRowsPerLane];
+#pragma unroll
+            for (int q = 0; q < kQrRowsPerLane; q++) {
+                const int r = lane + 64 * q;
+                dst[q] = -1;
+#pragma unroll
+                for (int j = 0; j < 6; j++) m[q][j] = 0.0;
+                if (r < rows) {
+                    const int32_t node = order[p0 + r / 6];
+                    near_null_row(S, node, r % 6, m[q]);
+                    dst[q] = (int64_t)node * 36 + 6 * (r % 6);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < kQrRowsPerLane; q++) s += m[q][j] * m[q][j];
+                const double n0 = sqrt(wave_sum_all(s));
+#pragma unroll
+                for (int pass = 0; pass < 2; pass++)
+#pragma unroll
+                    for (int i = 0; i < j; i++) {
+                        double cpart = 0.0;
+#pragma unroll
+                        for (int q = 0; q < kQrRowsPerLane; q++) cpart += m[q][i] * m[q][j];
+                        const double cc = wave_sum_all(cpart);
+#pragma unroll
+                        for (int q = 0; q < kQrRowsPerLane; q++) m[q][j] -= cc * m[q][i];
+                        R[6 * i + j] += cc;
+                    }
+                s = 0.0;
+#pragma unroll
+                for (int q = 0; q < kQrRowsPerLane; q++) s += m[q][j] * m[q][j];
+                const double nj = sqrt(wave_sum_all(s));
+                const bool keep = n0 > 0.0 && nj > 1e-8 * n0; // else: dependent column, no coarse dof here
+                R[6 * j + j] = keep ? nj : 0.0;
+#pragma unroll
+                for (int q = 0; q < kQrRowsPerLane; q++) m[q][j] = keep ? m[q][j] / nj : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < kQrRowsPerLane; q++)
+                if (dst[q] >= 0) {
+                    double2 *o = reinterpret_cast<double2 *>(Q + dst[q]);
+                    o[0] = make_double2(m[q][0], m[q][1]);
+                    o[1] = make_double2(m[q][2], m[q][3]);
+                    o[2] = make_double2(m[q][4], m[q][5]);
+                }
+        } else {
+            // rows in Q (global memory, L2-resident for one aggregate); only this wave touches them
+            for (int r = lane; r < rows; r += 64) {
+                const int32_t node = order[p0 + r / 6];
+                double v[6];
+                near_null_row(S, node, r % 6, v);
+                double *o = Q + (int64_t)node * 36 + 6 * (r % 6);
+#pragma unroll
+                for (int j = 0; j < 6; j++) o[j] = v[j];
+            }
+            auto row_ptr = [&](int r) { return Q + (int64_t)order[p0 + r / 6] * 36 + 6 * (r % 6); };
+            for (int j = 0; j < 6; j++) {
+                double s = 0.0;
+                for (int r = lane; r < rows; r += 64) { const double v = row_ptr(r)[j]; s += v * v; }
+                const double n0 = sqrt(wave_sum_all(s));
+                for (int pass = 0; pass < 2; pass++)
+                    for (int i = 0; i < j; i++) {
+                        double cpart = 0.0;
+                        for (int r = lane; r < rows; r += 64) { const double *o = row_ptr(r); cpart += o[i] * o[j]; }
+                        const double cc = wave_sum_all(cpart);
+                        for (int r = lane; r < rows; r += 64) { double *o = row_ptr(r); o[j] -= cc * o[i]; }
+                        R[6 * i + j] += cc;
+                    }
+                s = 0.0;
+                for (int r = lane; r < rows; r += 64) { const double v = row_ptr(r)[j]; s += v * v; }
+                const double nj = sqrt(wave_sum_all(s));
+                const bool keep = n0 > 0.0 && nj > 1e-8 * n0;
+                R[6 * j + j] = keep ? nj : 0.0;
+                for (int r = lane; r < rows; r += 64) { double *o = row_ptr(r); o[j] = keep ? o[j] / nj : 0.0; }
+            }
+        }
+        if (lane == 0) {
+            double *o = Bc + (int64_t)a * 36;
+#pragma unroll
+            for (int e = 0; e < 36; e++) o[e] = R[e];
+        }
+    }
+}
+
+void launch_amg_tentative_qr(const NearNullSrc &B, const int32_t *aptr, const int32_t *order, int32_t na, int32_t largest,
+                             double *Q, double *Bc, bool rows_in_memory, hipStream_t st)
+{
+    if (na <= 0) return;
+    const unsigned grid = (unsigned)std::min<int64_t>(na, 1 << 20);
+    const int all = rows_in_memory ? 1 : 0;
+    if (!rows_in_memory)
+        hipLaunchKernelGGL(k_amg_tentative_qr<false>, dim3(grid), dim3(64), 0, st, B, aptr, order, na, Q, Bc, all);
+    if (rows_in_memory || 6 * largest > 64 * kQrRowsPerLane)
+        hipLaunchKernelGGL(k_amg_tentative_qr<true>, dim3(grid), dim3(64), 0, st, B, aptr, order, na, Q, Bc, all);
+}
+
 void launch_amg_prolongator(const DeviceMatrix &A, const int32_t *agg, const double *Q, double omega, const uint8_t *pmap_own,
                             const uint8_t *pmap_in, const EllView &P, hipStream_t st)
 {

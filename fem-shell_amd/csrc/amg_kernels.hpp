@@ -77,6 +77,23 @@ struct EllView {
     double *vals = nullptr;
     int64_t total = 0;              // slots (= slice_base[n_slices])
 };
+// Near-null space of a level as the tentative prolongator reads it: n x 36 stored rows (B[36 a + 6 d + m]: dof d of node a
+// in mode m -- the R factors of the previous coarsening step), or, on the finest level, generated from the mesh in HBM
+// (amg_setup.cpp rigid_body_modes: rigid-body modes about `centre`, rotations projected onto the tangent plane of the
+// node when normals != nullptr, constrained dofs zero).
+struct NearNullSrc {
+    const double *B = nullptr;
+    const double *xyz = nullptr, *normals = nullptr;
+    const uint8_t *dmask = nullptr;
+    double cx = 0.0, cy = 0.0, cz = 0.0;
+};
+// Tentative prolongator: per aggregate the thin QR factorisation of its rows of the near-null space (modified Gram-Schmidt,
+// two passes, dependent columns dropped -- the algorithm of tentative_prolongator in amg_setup.cpp).  The nodes of
+// aggregate I are order[aptr[I] .. aptr[I+1]) (ascending); Q (n x 36) gets the orthonormal rows, Bc (na x 36) the R
+// factors = the near-null space of the coarse level.  One wave per aggregate; `largest` = nodes of the largest aggregate
+// (beyond 42 nodes the rows are kept in Q instead of registers; rows_in_memory: all of them, for tests).
+void launch_amg_tentative_qr(const NearNullSrc &B, const int32_t *aptr, const int32_t *order, int32_t na, int32_t largest,
+                             double *Q, double *Bc, bool rows_in_memory, hipStream_t st);
 // P = P0 - omega D^-1 A P0: P0 has the block Q[i] in column agg[i]; pmap_own / pmap_in give, for every slot of A and every
 // entry of its in-lists, the slot of P's row the product feeds
 void launch_amg_prolongator(const DeviceMatrix &A, const int32_t *agg, const double *Q, double omega, const uint8_t *pmap_own,

@@ -132,14 +132,20 @@ void node_normals(int32_t n, const double *xyz, int64_t n_tri, const int32_t *tr
 // soft mode looks like, so the rotational part of the rotation modes is projected onto the tangent plane of each node:
 // theta = omega - (omega . n) n.  With the plain modes the multigrid needed 715 iterations on a 10k-triangle flap loaded in
 // its own plane (the coupled example), and the coarsest operators of the 250k-triangle flap lost definiteness.
+void mesh_centre(int32_t n, const double *xyz, double c[3])
+{
+    c[0] = c[1] = c[2] = 0.0;
+    for (int32_t a = 0; a < n; a++)
+        for (int d = 0; d < 3; d++) c[d] += xyz[3ll * a + d];
+    for (int d = 0; d < 3; d++) c[d] /= std::max(n, 1);
+}
+
 void rigid_body_modes(int32_t n, const double *xyz, const uint8_t *dmask, std::vector<double> *Bout, const double *normals)
 {
     std::vector<double> &B = *Bout;
     B.assign((size_t)n * 36, 0.0);
-    double c[3] = {0, 0, 0};
-    for (int32_t a = 0; a < n; a++)
-        for (int d = 0; d < 3; d++) c[d] += xyz[3ll * a + d];
-    for (int d = 0; d < 3; d++) c[d] /= std::max(n, 1);
+    double c[3];
+    mesh_centre(n, xyz, c);
     parallel_chunks(n, [&](int64_t b0, int64_t b1) {
         for (int64_t a = b0; a < b1; a++) {
             double *b = &B[(size_t)a * 36];

@@ -186,15 +186,13 @@ int amg_setup(femshell_ctx *c)
     static const bool host_only = getenv("FEMSHELL_AMG_SETUP") && std::string(getenv("FEMSHELL_AMG_SETUP")) == "host";
     const bool keep_host = pl.nnz_blocks <= (int64_t)2000000; // inspection exports (tests) on small problems only
     Bsr A;
-    std::vector<double> B;
-    {
-        // FEMSHELL_AMG_PLAIN_RBM=1: the six plain rigid-body modes (A/B runs)
-        static const bool plain = getenv("FEMSHELL_AMG_PLAIN_RBM") && atoi(getenv("FEMSHELL_AMG_PLAIN_RBM")) != 0;
-        std::vector<double> normals;
-        if (!plain)
-            node_normals(pl.n_own, pl.xyz_local.data(), pl.n_ltri(), pl.tri_local.data(), pl.n_lquad(), pl.quad_local.data(), &normals);
-        rigid_body_modes(pl.n_own, pl.xyz_local.data(), c->dmask_global.data() + pl.row_begin, &B, plain ? nullptr : normals.data());
-    }
+    std::vector<double> B;  // near-null space of the current level on the host (levels coarsened on the host) ...
+    DevBuf<double> Bdev;    // ... and in HBM (levels coarsened on the device, from the second one on)
+    // FEMSHELL_AMG_PLAIN_RBM=1: the six plain rigid-body modes (A/B runs)
+    static const bool plain = getenv("FEMSHELL_AMG_PLAIN_RBM") && atoi(getenv("FEMSHELL_AMG_PLAIN_RBM")) != 0;
+    std::vector<double> normals;
+    if (!plain)
+        node_normals(pl.n_own, pl.xyz_local.data(), pl.n_ltri(), pl.tri_local.data(), pl.n_lquad(), pl.quad_local.data(), &normals);
     // Levels of more than device_min nodes are coarsened with the numerics on the device (amg_device_setup.cpp): their
     // operator is in HBM already and only its pattern is needed on the host.  The coarse operator of such a step comes
     // back as a host matrix only when the next step runs on the host (a small level, the coarsest one, the last allowed).
@@ -226,8 +224,24 @@ int amg_setup(femshell_ctx *c)
         AmgLevel &L1 = *H.levels.back();
         std::vector<double> Bc;
         pattern_of_plan(pl, &L0.pattern);
-        rc = amg_device_coarsen(c, c->dm, L0.pattern, L0, L1, B, L0.lam, keep_host, want_host_matrix(1), &A, &Bc,
-                                [&](const char *what) { lap(what, 0); });
+        {
+            // the near-null space of the finest level is generated from the mesh in HBM (never stored: n x 36 doubles)
+            NearNullSrc src;
+            DevBuf<double> d_normals;
+            src.xyz = c->xyz.p;
+            src.dmask = c->dmask.p;
+            if (!plain) {
+                FS_HIP(d_normals.upload(normals, st));
+                src.normals = d_normals.p;
+            }
+            double ctr[3];
+            mesh_centre(pl.n_own, pl.xyz_local.data(), ctr);
+            src.cx = ctr[0];
+            src.cy = ctr[1];
+            src.cz = ctr[2];
+            rc = amg_device_coarsen(c, c->dm, L0.pattern, L0, L1, src, L0.lam, keep_host, want_host_matrix(1), &A, &Bc, &Bdev,
+                                    [&](const char *what) { lap(what, 0); });
+        }
         if (rc) return rc;
         L0.pattern = HostEllPattern(); // (the plan holds it)
         L1.A_on_device = true;
@@ -240,8 +254,10 @@ int amg_setup(femshell_ctx *c)
     } else {
         rc = download_matrix(c, &A);
         if (rc) return rc;
+        rigid_body_modes(pl.n_own, pl.xyz_local.data(), c->dmask_global.data() + pl.row_begin, &B, plain ? nullptr : normals.data());
         lap("download K", 0);
     }
+    normals = std::vector<double>();
 
     for (int l = first_level;; l++) {
         if ((int)H.levels.size() <= l) H.levels.emplace_back(new AmgLevel());
@@ -312,10 +328,18 @@ int amg_setup(femshell_ctx *c)
             if ((int)H.levels.size() <= l + 1) H.levels.emplace_back(new AmgLevel());
             AmgLevel &N = *H.levels[(size_t)l + 1];
             std::vector<double> Bc;
+            DevBuf<double> Bnext;
             Bsr Anext;
-            rc = amg_device_coarsen(c, L.A.dm, L.pattern, L, N, B, L.lam, keep_host, want_host_matrix(l + 1), &Anext, &Bc,
+            NearNullSrc src;
+            if (Bdev.p == nullptr) { // (the level came from a host step)
+                FS_HIP(Bdev.upload(B, st));
+            }
+            src.B = Bdev.p;
+            rc = amg_device_coarsen(c, L.A.dm, L.pattern, L, N, src, L.lam, keep_host, want_host_matrix(l + 1), &Anext, &Bc, &Bnext,
                                     [&](const char *what) { lap(what, l); });
             if (rc) return rc;
+            std::swap(Bdev.p, Bnext.p);
+            std::swap(Bdev.n, Bnext.n);
             N.A_on_device = true;
             if (keep_host && have_host) L.hA = std::move(A);
             L.pattern = HostEllPattern();
@@ -356,6 +380,7 @@ int amg_setup(femshell_ctx *c)
         if (keep_host || l == 0) L.agg = std::move(agg);
         A = std::move(Ac);
         B.swap(Bc);
+        Bdev.release();
     }
     // Chebyshev coefficients per level
     for (size_t l = 0; l + 1 < H.levels.size(); l++) {

@@ -102,6 +102,14 @@ def test_every_level_coarsened_on_the_device_follows_the_restatement_too(monkeyp
     test_hierarchy_and_iteration_counts_follow_the_restatement("K")
 
 
+def test_tentative_prolongator_with_the_rows_in_memory(monkeypatch):
+    # aggregates of more than 42 nodes keep the rows of their QR factorisation in HBM instead of registers; no test mesh
+    # has one, so the knob sends every aggregate down that path
+    monkeypatch.setenv("FEMSHELL_AMG_QR", "memory")
+    monkeypatch.setenv("FEMSHELL_AMG_DEVICE_MIN", "100")
+    test_hierarchy_and_iteration_counts_follow_the_restatement("K")
+
+
 def test_double_double_residual_and_what_refinement_buys():
     # thin roof: ||K|| ||x|| / ||b|| ~ 1e7.  The FP64 residual of a converged iterate is rounding noise, the
     # double-double one is exact to 1e-12 ||b||; without refinement the displacement error stalls near kappa*eps,
