@@ -55,7 +55,7 @@ __global__ __launch_bounds__(192) void k_cheb_step(DeviceMatrix m, const double 
             const int Wi = m.in_width[sl], n = t / 6, j = t % 6;
             const int64_t ib = m.in_base[sl];
             for (int k = 0; k < Wi; k++) {
-                const int32_t slot = m.in_slots[ib + (int64_t)k * kSliceNodes + n];
+                const int32_t slot = m.gat_slots[ib + (int64_t)k * kSliceNodes + n];
                 if (slot >= 0) qv += m.tbuf[(int64_t)slot * 6 + j];
             }
         }

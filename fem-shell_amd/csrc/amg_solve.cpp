@@ -59,6 +59,7 @@ int attach_in_lists(AmgOperator &op, const SlicedEllSym &S, int64_t total_slots,
     op.dm.in_base = op.in_base.p;
     op.dm.in_slots = op.in_slots.p;
     op.dm.in_rows = op.in_rows.p;
+    op.dm.gat_slots = op.in_slots.p; // (level operators: every transposed product through tbuf)
     op.dm.tbuf = op.tbuf.p;
     return FEMSHELL_OK;
 }

@@ -489,6 +489,9 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     FS_HIP(c->in_base.upload(p.in_base, st));
     FS_HIP(c->in_slots.upload(p.in_slots, st));
     FS_HIP(c->in_rows.upload(p.in_rows, st));
+    FS_HIP(c->gat_slots.upload(p.gat_slots, st));
+    FS_HIP(c->loc_index.upload(p.loc_index, st));
+    FS_HIP(c->loc_list.upload(p.loc_list, st));
     if (p.symmetric) {
         FS_HIP(c->tbuf.alloc((size_t)p.total_slots() * 6)); // transposed products next to every slot
         FS_HIP(c->tbuf.zero(st));
@@ -548,6 +551,12 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
     c->dm.in_base = c->in_base.p;
     c->dm.in_slots = c->in_slots.p;
     c->dm.in_rows = c->in_rows.p;
+    // FEMSHELL_SPMV_LOCAL=0: every transposed product through HBM (A/B runs)
+    const bool local_products = p.symmetric && p.max_loc > 0 && !(getenv("FEMSHELL_SPMV_LOCAL") && atoi(getenv("FEMSHELL_SPMV_LOCAL")) == 0);
+    c->dm.gat_slots = local_products ? c->gat_slots.p : c->in_slots.p;
+    c->dm.loc_index = local_products ? c->loc_index.p : nullptr;
+    c->dm.loc_list = local_products ? c->loc_list.p : nullptr;
+    c->dm.max_loc = local_products ? p.max_loc : 0;
     c->dm.tbuf = c->tbuf.p;
     c->dm.minv = c->minv.p;
     c->dm.status = c->status.p;

@@ -95,6 +95,8 @@ struct femshell_ctx {
     femshell::DevBuf<int32_t> tri, quad, slice_width, cols, pair_ptr, status;
     femshell::DevBuf<int64_t> slice_base, in_base;
     femshell::DevBuf<int32_t> in_width, in_slots, in_rows; // symmetric storage: per-row lists of transposed blocks
+    femshell::DevBuf<int32_t> gat_slots;                    // ... without the blocks whose product stays inside the slice
+    femshell::DevBuf<uint8_t> loc_index, loc_list;
     femshell::DevBuf<double> tbuf;                          // ... and their products K_ac^T x_a (6 doubles per slot)
     femshell::DevBuf<int32_t> slice_elem_ptr, slice_elem_nodes, item_ptr, slice_desc;
     femshell::DevBuf<femshell::Plan::Item> items;

@@ -402,6 +402,9 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
     const int lane = threadIdx.x, half = lane >> 5, n = lane & 31;
     const double2 *x2 = reinterpret_cast<const double2 *>(x);
     double dotv = 0.0;
+    extern __shared__ double2 lds_products[]; // [half][max_loc][3]: transposed products that stay inside a slice
+    const bool has_local = m.loc_index != nullptr;
+    double2 *lu = lds_products + (size_t)half * m.max_loc * 3;
     const int n_pairs = (count + 1) >> 1;
     for (SliceWalk w(n_pairs); w.valid(); w.next()) {
         const int q = 2 * w.s + half;
@@ -419,6 +422,7 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
         for (int i = 0; i < 6; i++) ya[i] = 0.0;
         const double2 *v = reinterpret_cast<const double2 *>(m.vals + base * 36) + n;
         double2 *tb = reinterpret_cast<double2 *>(m.tbuf + base * 6);
+        const uint8_t *li = has_local ? m.loc_index + base + n : nullptr;
         typedef double v2d __attribute__((ext_vector_type(2)));
         if (W > 0) {
             // slot 0 is the diagonal block K_aa, which is symmetric: only the 12 of its 18 words that hold the upper
@@ -466,7 +470,9 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
             // the transpose acts on row c when c is another owned row (ghost columns belong to another rank,
             // padding slots point at the own row)
             if (c != a && c < m.n_pad) {
-                double2 *t = tb + ((size_t)k * kSliceNodes + n) * 3;
+                const int local = has_local ? (int)li[(size_t)k * kSliceNodes] : 255;
+                // (row c is a row of this slice: the product waits in LDS for the end of the slice, else next to the slot)
+                double2 *t = local != 255 ? lu + local * 3 : tb + ((size_t)k * kSliceNodes + n) * 3;
                 t[0] = make_double2(u[0], u[1]);
                 t[1] = make_double2(u[2], u[3]);
                 t[2] = make_double2(u[4], u[5]);
@@ -474,13 +480,27 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
                     dotv += xc[0] * u[0] + xc[1] * u[1] + xc[2] * u[2] + xc[3] * u[3] + xc[4] * u[4] + xc[5] * u[5];
             }
         }
+        if (live && partials != nullptr) // (before the in-slice products join: x_c.u counted them above)
+            dotv += xa[0] * ya[0] + xa[1] * ya[1] + xa[2] * ya[2] + xa[3] * ya[3] + xa[4] * ya[4] + xa[5] * ya[5];
+        if (has_local) {
+            // the transposed products of this slice's own rows, in the order of the in-list
+            __syncthreads(); // (one wave per workgroup)
+            const int Wi = live ? m.in_width[sl] : 0;
+            const uint8_t *ll = m.loc_list + m.in_base[sl] + n;
+            for (int k = 0; k < Wi; k++) {
+                const int idx = ll[(size_t)k * kSliceNodes];
+                if (idx != 255) {
+                    const double2 t0 = lu[idx * 3], t1 = lu[idx * 3 + 1], t2 = lu[idx * 3 + 2];
+                    ya[0] += t0.x; ya[1] += t0.y; ya[2] += t1.x; ya[3] += t1.y; ya[4] += t2.x; ya[5] += t2.y;
+                }
+            }
+            __syncthreads(); // the next slice overwrites the products
+        }
         if (live) {
             double2 *yo = reinterpret_cast<double2 *>(y) + 3 * (int64_t)a;
             yo[0] = make_double2(ya[0], ya[1]);
             yo[1] = make_double2(ya[2], ya[3]);
             yo[2] = make_double2(ya[4], ya[5]);
-            if (partials != nullptr)
-                dotv += xa[0] * ya[0] + xa[1] * ya[1] + xa[2] * ya[2] + xa[3] * ya[3] + xa[4] * ya[4] + xa[5] * ya[5];
         }
     }
     if (partials != nullptr) {
@@ -501,7 +521,7 @@ __global__ __launch_bounds__(192) void k_sym_gather(DeviceMatrix m, double *y, c
         const int64_t row = (int64_t)sl * kSliceRows + t;
         double acc = y[row];
         for (int k = 0; k < Wi; k++) {
-            const int32_t slot = m.in_slots[ib + (int64_t)k * kSliceNodes + n];
+            const int32_t slot = m.gat_slots[ib + (int64_t)k * kSliceNodes + n];
             if (slot >= 0) acc += m.tbuf[(int64_t)slot * 6 + j];
         }
         y[row] = base_vec != nullptr ? base_vec[row] + sign * acc : acc;
@@ -511,7 +531,8 @@ __global__ __launch_bounds__(192) void k_sym_gather(DeviceMatrix m, double *y, c
 static void spmv_sym_phase1(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
                             const int32_t *order, int count, int grid, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_spmv_sym, dim3(grid), dim3(64), 0, st, m, x, y, partials, s, order, count);
+    const size_t lds = m.loc_index != nullptr ? (size_t)2 * m.max_loc * 48 : 0;
+    hipLaunchKernelGGL(k_spmv_sym, dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
 }
 
 void launch_sym_gather(const DeviceMatrix &m, double *y, const double *base_vec, double sign, const CgScalars *s, hipStream_t st)
@@ -809,7 +830,7 @@ __global__ __launch_bounds__(192) void k_cg_update(DeviceMatrix m, CgVectors v)
             // dependent memory round trips per entry (same order of the additions either way)
             int32_t slot4[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) slot4[k] = (k < Wi) ? m.in_slots[ib + (int64_t)k * kSliceNodes + n] : -1;
+            for (int k = 0; k < 4; k++) slot4[k] = (k < Wi) ? m.gat_slots[ib + (int64_t)k * kSliceNodes + n] : -1;
             double t4[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) t4[k] = (slot4[k] >= 0) ? m.tbuf[(int64_t)slot4[k] * 6 + j] : 0.0;
@@ -817,7 +838,7 @@ __global__ __launch_bounds__(192) void k_cg_update(DeviceMatrix m, CgVectors v)
             for (int k = 0; k < 4; k++)
                 if (slot4[k] >= 0) qv += t4[k];
             for (int k = 4; k < Wi; k++) {
-                const int32_t slot = m.in_slots[ib + (int64_t)k * kSliceNodes + n];
+                const int32_t slot = m.gat_slots[ib + (int64_t)k * kSliceNodes + n];
                 if (slot >= 0) qv += m.tbuf[(int64_t)slot * 6 + j];
             }
         }
@@ -944,7 +965,7 @@ __global__ __launch_bounds__(192) void k_cgcg_update(DeviceMatrix m, CgVectors v
             const int Wi = m.in_width[sl], n = t / 6, j = t % 6;
             const int64_t ib = m.in_base[sl];
             for (int k = 0; k < Wi; k++) {
-                const int32_t slot = m.in_slots[ib + (int64_t)k * kSliceNodes + n];
+                const int32_t slot = m.gat_slots[ib + (int64_t)k * kSliceNodes + n];
                 if (slot >= 0) wv += m.tbuf[(int64_t)slot * 6 + j];
             }
         }

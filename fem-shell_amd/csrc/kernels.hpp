@@ -47,6 +47,11 @@ struct DeviceMatrix {
     const int64_t *in_base = nullptr;   // n_slices+1
     const int32_t *in_slots = nullptr;  // per in-entry: slot index or -1
     const int32_t *in_rows = nullptr;   // per in-entry: local row of that block
+    // products that stay inside a slice go through LDS in k_spmv_sym (plan.hpp); loc_index == nullptr: all through tbuf
+    const int32_t *gat_slots = nullptr; // in_slots without the in-slice entries: what the collecting kernels walk
+    const uint8_t *loc_index = nullptr; // per slot
+    const uint8_t *loc_list = nullptr;  // per in-entry
+    int32_t max_loc = 0;
     double *tbuf = nullptr;             // total_slots x 6: per (slice, slot k) [component j][node n]
     double *minv = nullptr;             // n_slices x 21 x 32: upper triangles of the inverse diagonal blocks
     unsigned long long *stamps = nullptr; // profiling builds of k_assemble only (tools/lab)

@@ -254,6 +254,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                 std::copy_n(scratch.data() + ub[(size_t)a], n_distinct[(size_t)a], nb.data() + nb_ptr[(size_t)a]);
         });
         std::vector<int32_t>().swap(scratch);
+        lap("up to:   neighbour lists");
         std::vector<int32_t> cnt(cnt_ghost); // blocks a row stores besides its diagonal (ghost columns included)
         nb_mine.assign(nb.size(), 0);
         auto index_of = [&](int32_t row, int32_t col) -> int64_t {
@@ -304,6 +305,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             if (!moved) break;
         }
         for (size_t q = 0; q < nb_mine.size(); q++) lower_blocks += nb_mine[q] ? 0 : 1; // blocks of K without a slot in their row
+        lap("up to:   orientation of the stored blocks");
     }
     auto stored_here = [&](int32_t a, int32_t b_global) { // symmetric storage: does row a hold the block (a, b)?
         if (b_global < g0 || b_global >= g1) return true; // ghost column
@@ -371,6 +373,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             n_pairs += part_pairs[(size_t)t].size();
         }
         if (n_pairs > 0x7fffff00ull || n_slots > 0x7fffff00ull) return fail("gather list exceeds 2^31 entries");
+        lap("up to:   slots and pairs per row (chunks)");
         for (int32_t a = 0; a < n_own; a++) node_slot_ptr[(size_t)a + 1] += node_slot_ptr[(size_t)a];
         slot_col.resize(n_slots);
         slot_pair_ptr.resize(n_slots + 1);
@@ -499,6 +502,30 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                 p.in_rows[(size_t)(p.in_base[sc] + (int64_t)cnt[c] * kSliceNodes + nc)] = a;
                 cnt[c]++;
             }
+        // Transposed products that stay inside a slice: a stored block (a, c) whose column c is a row of the same slice
+        // hands u = K_ac^T x_a to row c through LDS inside the SpMV kernel instead of through HBM (48 bytes written by
+        // the SpMV, read again by the kernel that collects the products).  loc_index: per slot, the position of its u
+        // among the slice's in-slice blocks (255: the product leaves the slice); loc_list: per in-list entry the same
+        // position (255: collect it from HBM); gat_slots: the in-list without the in-slice entries.
+        p.loc_index.assign((size_t)total, 255);
+        p.loc_list.assign(p.in_slots.size(), 255);
+        p.gat_slots = p.in_slots;
+        std::vector<int32_t> per_slice((size_t)p.n_slices, 0);
+        plan_parallel(p.n_slices, 256, [&](int, int64_t s0, int64_t s1) {
+            for (int64_t s2 = s0; s2 < s1; s2++) {
+                int m = 0;
+                for (int64_t e = p.in_base[s2]; e < p.in_base[s2 + 1]; e++) { // (k, n) order of the in-list
+                    const int32_t slot = p.in_slots[(size_t)e];
+                    if (slot < 0 || slot < p.slice_base[s2] || slot >= p.slice_base[s2 + 1] || m >= 255) continue;
+                    p.loc_index[(size_t)slot] = (uint8_t)m;
+                    p.loc_list[(size_t)e] = (uint8_t)m;
+                    p.gat_slots[(size_t)e] = -1;
+                    m++;
+                }
+                per_slice[(size_t)s2] = m;
+            }
+        });
+        for (int32_t s2 = 0; s2 < p.n_slices; s2++) p.max_loc = std::max(p.max_loc, per_slice[(size_t)s2]);
     }
 
     lap("up to: per-slice element lists and slice-relati");

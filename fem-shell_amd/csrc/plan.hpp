@@ -96,6 +96,11 @@ struct Plan {
     std::vector<int32_t> in_slots;     // entry (in_base[s] + k*32 + n): slot index, -1 = none
     std::vector<int32_t> in_rows;      // same shape: the local row a of that block (its x entries multiply the transpose)
     int32_t max_in_width = 0;
+    // transposed products that stay inside a slice go through LDS (plan.cpp): per slot / per in-list entry the position
+    // among the slice's in-slice blocks (255 = none), the in-list without those entries, and the largest count of a slice
+    std::vector<uint8_t> loc_index, loc_list;
+    std::vector<int32_t> gat_slots;
+    int32_t max_loc = 0;
     std::vector<HaloPeer> peers;
     // slices in SpMV order: the first n_interior_slices read no ghost column (they overlap the halo exchange)
     std::vector<int32_t> spmv_order;
