@@ -9,12 +9,15 @@ tag=${1:-r02}
 out=gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-timeout 900 python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o s -- python3 bench.py --steps 10 --warmup 2 --profile > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_stats.err
 cp $out/${tag}_stats/s_kernel_stats.csv $out/${tag}_kernel_stats.csv 2> /dev/null
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --profile > /dev/null 2> $out/${tag}_pmc_fetch.err
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -o w -- python3 bench.py --steps 3 --warmup 1 --profile > /dev/null 2> $out/${tag}_pmc_write.err
 python3 tools/pmc_summary.py $out/${tag}_pmc_fetch/f_counter_collection.csv $out/${tag}_pmc_write/w_counter_collection.csv $out/${tag}_pmc_hbm_traffic.json
+# the default bench run comes after the counter passes and sees their summary (bench.py attaches `traffic` only from a
+# profile taken with the same kernel sources; on the box the copy under profiles/ is scratch -- commit it from gpurun_out/)
+cp $out/${tag}_pmc_hbm_traffic.json profiles/${tag}_pmc_hbm_traffic.json 2> /dev/null
+timeout 900 python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 # FP64 work of the kernels (the assembly kernel is VALU-bound with symmetric storage): instruction counters, one pass each
 for cnt in SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64; do
   timeout 300 rocprofv3 --kernel-trace --pmc $cnt --output-format csv -d $out/${tag}_pmc_$cnt -o c -- python3 bench.py --steps 3 --warmup 1 --profile > /dev/null 2> $out/${tag}_pmc_$cnt.err
