@@ -1,10 +1,10 @@
 """Per-kernel times of the CG iteration on the 4M-triangle panel through femshell_time_kernel (HIP events on the library's
-stream), several repetitions in one process:  python tools/cg_kernels_probe.py"""
+stream), several repetitions in one process:  python tools/cg_kernels_probe.py [nx]"""
 import importlib, sys
 sys.path.insert(0, ".")
 from bench import panel_mesh
 pkg = importlib.import_module("fem-shell_amd")
-m = panel_mesh(1414)
+m = panel_mesh(int(sys.argv[1]) if len(sys.argv) > 1 else 1414)
 fs = pkg.FemShell(0.3, 1e7, 0.5)
 fs.set_mesh(m.xyz, m.tri); fs.set_dirichlet(m.dirichlet_mask()); fs.set_loads(m.loads)
 for _ in range(20):
