@@ -84,6 +84,7 @@ struct Amg {
     AmgSetupStats stats;
     std::vector<std::unique_ptr<AmgLevel>> levels;
     DevBuf<double> coarse_inv; // dense inverse of the coarsest operator
+    DevBuf<float> K32;         // K in single precision for the smoothing products of level 0 (FEMSHELL_AMG_SMOOTH_F32)
     bool valid = false;
     double setup_seconds = 0.0;
     std::shared_ptr<AmgDist> dist; // row-partitioned contexts only

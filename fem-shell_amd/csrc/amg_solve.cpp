@@ -400,6 +400,18 @@ int amg_setup(femshell_ctx *c)
             rho = rho_new;
         }
     }
+    {
+        // FEMSHELL_AMG_SMOOTH_F32=1 (experimental): the Chebyshev products of level 0 stream a single-precision copy of K
+        // (residuals, the Krylov product and the coarse operators stay FP64)
+        const char *e = getenv("FEMSHELL_AMG_SMOOTH_F32");
+        H.K32.release();
+        if (e && atoi(e) != 0 && c->dm.symmetric && !H.levels.empty() && H.levels.size() > 1) {
+            const int64_t nv = (int64_t)pl.total_slots() * 36;
+            FS_HIP(H.K32.alloc((size_t)nv));
+            launch_to_f32(c->dm.vals, H.K32.p, nv, st);
+            FS_HIP(hipGetLastError());
+        }
+    }
     FS_HIP(hipStreamSynchronize(st));
     H.setup_seconds = now_s() - t0;
     H.valid = true;
@@ -503,7 +515,13 @@ struct Cycle {
         double *d_cur = L.d.p, *d_next = L.q.p; // full-storage levels: the direction alternates between the two vectors
         for (size_t k = 0; k < L.cheb_a.size(); k++) {
             if (A.symmetric) { // first phase of the product; the step kernel collects the transposed products
-                launch_spmv_direct(A, L.d.p, L.q.p, nullptr, gate, st);
+                if (l == 0 && H.K32.p != nullptr) {
+                    DeviceMatrix A32 = A;
+                    A32.vals32 = H.K32.p;
+                    launch_spmv_direct(A32, L.d.p, L.q.p, nullptr, gate, st, true);
+                } else {
+                    launch_spmv_direct(A, L.d.p, L.q.p, nullptr, gate, st);
+                }
                 launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, true);
             } else if (fused_cheb()) { // product and step in one launch (the small levels are bound by launch latency)
                 launch_spmv_cheb(A, d_cur, rcur, L.r.p, d_next, x, L.cheb_a[k], L.cheb_c[k], gate, st);

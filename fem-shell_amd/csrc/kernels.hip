@@ -394,6 +394,22 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
 // The fused dot x.Kx of CG needs no second phase: x.Kx = sum_a x_a.(direct part of y_a) + sum over stored
 // off-diagonal blocks of x_c.u.
 // =====================================================================================
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <bool kF32> __device__ __forceinline__ v2d load_word(const double2 *v, const float2 *v32, size_t off)
+{
+    if (kF32) {
+        const v2f w = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(v32) + off);
+        v2d r;
+        r.x = (double)w.x;
+        r.y = (double)w.y;
+        return r;
+    }
+    return __builtin_nontemporal_load(reinterpret_cast<const v2d *>(v) + off);
+}
+
+// kF32: the blocks come from m.vals32 (single precision, same layout), the arithmetic stays FP64
+template <bool kF32>
 __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *__restrict__ x, double *__restrict__ y,
                                                  double *__restrict__ partials, const CgScalars *s,
                                                  const int32_t *__restrict__ order, int count)
@@ -421,19 +437,18 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
 #pragma unroll
         for (int i = 0; i < 6; i++) ya[i] = 0.0;
         const double2 *v = reinterpret_cast<const double2 *>(m.vals + base * 36) + n;
+        const float2 *v32 = kF32 ? reinterpret_cast<const float2 *>(m.vals32 + base * 36) + n : nullptr;
         double2 *tb = reinterpret_cast<double2 *>(m.tbuf + base * 6);
         const uint8_t *li = has_local ? m.loc_index + base + n : nullptr;
-        typedef double v2d __attribute__((ext_vector_type(2)));
         if (W > 0) {
             // slot 0 is the diagonal block K_aa, which is symmetric: only the 12 of its 18 words that hold the upper
             // triangle are read (each word is 512 contiguous bytes of the slice, so the other six never leave HBM);
             // element (i, j) below the diagonal is taken from (j, i).  Same order of the sum over j as in the loop
             // below, so a block whose halves mirror each other exactly (k_assemble's do) gives the same bits.
-            const v2d *vv = reinterpret_cast<const v2d *>(v);
             v2d wd[18];
 #pragma unroll
             for (int e = 0; e < 18; e++)
-                if (2 * (e / 6) + 1 >= e % 6) wd[e] = __builtin_nontemporal_load(vv + e * kSliceNodes);
+                if (2 * (e / 6) + 1 >= e % 6) wd[e] = load_word<kF32>(v, v32, e * kSliceNodes);
 #pragma unroll
             for (int i = 0; i < 6; i++)
 #pragma unroll
@@ -445,10 +460,9 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
         }
         for (int k = 1; k < W; k++) {
             const int c = m.cols[base + (int64_t)k * kSliceNodes + n];
-            const v2d *vv = reinterpret_cast<const v2d *>(v + (size_t)k * 18 * kSliceNodes);
             v2d wd[18];
 #pragma unroll
-            for (int e = 0; e < 18; e++) wd[e] = __builtin_nontemporal_load(vv + e * kSliceNodes); // word (jp = e/6, i = e%6)
+            for (int e = 0; e < 18; e++) wd[e] = load_word<kF32>(v, v32, ((size_t)k * 18 + e) * kSliceNodes); // word (jp = e/6, i = e%6)
             double xc[6];
             {
                 const double2 c0 = x2[3 * (int64_t)c], c1 = x2[3 * (int64_t)c + 1], c2 = x2[3 * (int64_t)c + 2];
@@ -529,10 +543,23 @@ __global__ __launch_bounds__(192) void k_sym_gather(DeviceMatrix m, double *y, c
 }
 
 static void spmv_sym_phase1(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
-                            const int32_t *order, int count, int grid, hipStream_t st)
+                            const int32_t *order, int count, int grid, hipStream_t st, bool f32 = false)
 {
     const size_t lds = m.loc_index != nullptr ? (size_t)2 * m.max_loc * 48 : 0;
-    hipLaunchKernelGGL(k_spmv_sym, dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
+    if (f32 && m.vals32 != nullptr)
+        hipLaunchKernelGGL(k_spmv_sym<true>, dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
+    else
+        hipLaunchKernelGGL(k_spmv_sym<false>, dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
+}
+
+__global__ __launch_bounds__(256) void k_to_f32(const double *__restrict__ src, float *__restrict__ dst, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = (float)src[i];
+}
+
+void launch_to_f32(const double *src, float *dst, int64_t n, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_to_f32, dim3(4096), dim3(256), 0, st, src, dst, n);
 }
 
 void launch_sym_gather(const DeviceMatrix &m, double *y, const double *base_vec, double sign, const CgScalars *s, hipStream_t st)
@@ -867,9 +894,10 @@ void launch_cg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st,
     else hipLaunchKernelGGL(k_cg_update<false>, dim3(slice_grid(m)), dim3(192), 0, st, m, v);
 }
 
-void launch_spmv_direct(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s, hipStream_t st)
+void launch_spmv_direct(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s, hipStream_t st,
+                        bool single_precision_values)
 {
-    spmv_sym_phase1(m, x, y, partials, s, nullptr, m.n_slices, slice_grid(m), st);
+    spmv_sym_phase1(m, x, y, partials, s, nullptr, m.n_slices, slice_grid(m), st, single_precision_values);
 }
 
 // ---- single-reduction recurrence (multi-rank solves): see kernels.hpp

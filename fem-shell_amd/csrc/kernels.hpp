@@ -38,6 +38,7 @@ struct DeviceMatrix {
     int32_t lds_rec_off = 0, lds_stage_off = 0; // offsets in doubles
     const uint8_t *dmask = nullptr;     // per local node (owned, padding, ghosts)
     double *vals = nullptr;             // total_slots x 36, sliced layout
+    const float *vals32 = nullptr;      // the same in single precision (smoothing products of the multigrid cycle only)
     const double *rhs_loads = nullptr;  // n_pad x 6 nodal loads and
     double *rhs_F = nullptr;            // the right-hand side k_assemble fills beside K (nullptr: K only)
     // symmetric storage (plan.hpp): transposed products K_ac^T x_a next to every slot, collected per row
@@ -158,7 +159,10 @@ void launch_copy_x_to_p(const DeviceMatrix &m, const CgVectors &v, hipStream_t s
 // spans without launch_sym_gather); the kernel adds the transposed products of each row's in-list itself
 void launch_cg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st, bool gather = false);
 // symmetric storage: first phase of y = K x only (direct part of y, transposed products into m.tbuf, fused x.Kx sums)
-void launch_spmv_direct(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s, hipStream_t st);
+void launch_spmv_direct(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s, hipStream_t st,
+                        bool single_precision_values = false);
+// dst = (float)src
+void launch_to_f32(const double *src, float *dst, int64_t n, hipStream_t st);
 void launch_cg_direction(const DeviceMatrix &m, const CgVectors &v, hipStream_t st); // p = z + beta p
 // single-workgroup scalar step: optional reduction of `nsums` partial arrays into s->red, then the
 // scalar update of `phase` (rtol only used by CG_PHASE_INIT)
