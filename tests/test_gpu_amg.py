@@ -102,6 +102,24 @@ def test_every_level_coarsened_on_the_device_follows_the_restatement_too(monkeyp
     test_hierarchy_and_iteration_counts_follow_the_restatement("K")
 
 
+def test_single_precision_smoothing_products_leave_the_solution_alone(monkeypatch):
+    # FEMSHELL_AMG_SMOOTH_F32=1 (off by default): the Chebyshev products of level 0 read a float copy of K; the solve is
+    # flexible CG on the FP64 operator, so the answer is the same and the iteration count moves by a few at most
+    m, mat = _make("roof", 48)
+    fs = _context(m, mat)
+    fs.set_preconditioner("amg")
+    u, info = fs.solve(rtol=1e-12, max_it=500)
+    fs.close()
+    monkeypatch.setenv("FEMSHELL_AMG_SMOOTH_F32", "1")
+    fs = _context(m, mat)
+    fs.set_preconditioner("amg")
+    u32, info32 = fs.solve(rtol=1e-12, max_it=500)
+    assert info32["converged"] == 1 and abs(info32["iterations"] - info["iterations"]) <= 3, (info["iterations"], info32["iterations"])
+    assert not np.array_equal(u32, u)  # (the knob did something)
+    assert np.linalg.norm(u32 - u) / np.linalg.norm(u) < 1e-10
+    fs.close()
+
+
 def test_tentative_prolongator_with_the_rows_in_memory(monkeypatch):
     # aggregates of more than 42 nodes keep the rows of their QR factorisation in HBM instead of registers; no test mesh
     # has one, so the knob sends every aggregate down that path
