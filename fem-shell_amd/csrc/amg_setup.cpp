@@ -17,7 +17,7 @@ int host_threads()
 {
     static const int n = [] {
         const char *e = getenv("FEMSHELL_HOST_THREADS");
-        int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        int t = e ? atoi(e) : available_cpus();
         if (t < 1) t = 1;
         if (t > 64) t = 64;
         return t;

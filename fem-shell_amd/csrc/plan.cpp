@@ -1,6 +1,8 @@
 // plan.cpp -- host-side symbolic phase (see plan.hpp).
 #include "plan.hpp"
 
+#include <sched.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <chrono>
@@ -10,12 +12,24 @@
 
 namespace femshell {
 
+int available_cpus()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+        const int m = CPU_COUNT(&set);
+        if (m > 0 && (n < 1 || m < n)) n = m;
+    }
+    return n < 1 ? 1 : n;
+}
+
 // host threads of the symbolic phase (FEMSHELL_HOST_THREADS, at most 64): contiguous chunks of [0, n), one per thread
 static int plan_threads()
 {
     static const int n = [] {
         const char *e = getenv("FEMSHELL_HOST_THREADS");
-        int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        int t = e ? atoi(e) : available_cpus();
         return t < 1 ? 1 : (t > 64 ? 64 : t);
     }();
     return n;

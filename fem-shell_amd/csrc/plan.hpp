@@ -114,6 +114,10 @@ struct Plan {
     static inline int64_t slot_index(int64_t base, int k, int n) { return base + (int64_t)k * kSliceNodes + n; }
 };
 
+// CPUs this process may run on (its affinity mask; a pinned or cpuset-confined rank does not start a thread per core of
+// the machine), at least 1
+int available_cpus();
+
 // owned node range of `rank` when n_nodes rows are split over `world` ranks
 void partition_rows(int32_t n_nodes, int world, int rank, int32_t *begin, int32_t *end);
 // Row boundaries of the `world` ranks, in whole slices of 32 nodes: contiguous ranges of the caller's numbering with equal
