@@ -325,6 +325,7 @@ PLAN_ARRAYS = {
     "xyz_local": (10, np.float64), "peer_ranks": (11, np.int32), "peer_recv_offset": (12, np.int32),
     "peer_recv_count": (13, np.int32), "peer_send_ptr": (14, np.int32), "peer_send_nodes": (15, np.int32),
     "spmv_order": (16, np.int32), "in_width": (17, np.int32), "in_base": (18, np.int64), "in_slots": (19, np.int32),
+    "gat_slots": (20, np.int32), "loc_list": (21, np.uint8), "loc_index": (22, np.uint8),
 }
 
 

@@ -485,13 +485,17 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     p.in_width.assign(p.n_slices, 0);
     p.in_base.assign((size_t)p.n_slices + 1, 0);
     if (symmetric) {
+        // per row c: the neighbours a whose row holds the block of the pair (nb_mine == 0 on c's side), in ascending slot
+        // index of that block = ascending slice of the source row, then slot-major inside the slice -- a fixed order, so
+        // the sums of the gather phase are reproducible.  Rows in parallel; the slot of (a, c) is found in a's sorted list.
         std::vector<int32_t> cnt((size_t)p.n_pad, 0);
-        for (int64_t idx = 0; idx < total; idx++) {
-            if (p.pair_ptr[idx + 1] == p.pair_ptr[idx]) continue; // padding slot
-            const int32_t c = p.cols[idx];
-            if (c < n_own) cnt[c]++; // counts the diagonal slots too; corrected below
-        }
-        for (int32_t a = 0; a < n_own; a++) cnt[a]--; // own diagonal
+        plan_parallel(n_own, 4096, [&](int, int64_t c0, int64_t c1) {
+            for (int64_t c = c0; c < c1; c++) {
+                int m = 0;
+                for (int64_t q = nb_ptr[(size_t)c]; q < nb_ptr[(size_t)c + 1]; q++) m += nb_mine[(size_t)q] ? 0 : 1;
+                cnt[(size_t)c] = m;
+            }
+        });
         for (int32_t s2 = 0; s2 < p.n_slices; s2++) {
             int w = 0;
             for (int n = 0; n < kSliceNodes; n++) w = std::max(w, cnt[(size_t)s2 * kSliceNodes + n]);
@@ -501,21 +505,27 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         }
         p.in_slots.assign((size_t)p.in_base[p.n_slices], -1);
         p.in_rows.assign((size_t)p.in_base[p.n_slices], 0);
-        std::fill(cnt.begin(), cnt.end(), 0);
-        // ascending slot index = ascending slice of the source row; inside a slice slots run slot-major, which is a
-        // fixed order too: the sums of the gather phase are reproducible
-        for (int32_t s2 = 0; s2 < p.n_slices; s2++) // (ascending idx: slices, then slots of a slice, then its nodes)
-            for (int64_t idx = p.slice_base[s2]; idx < p.slice_base[s2 + 1]; idx++) {
-                if (p.pair_ptr[idx + 1] == p.pair_ptr[idx]) continue;
-                const int32_t c = p.cols[idx];
-                if (c >= n_own) continue;
-                const int32_t a = s2 * kSliceNodes + (int32_t)((idx - p.slice_base[s2]) % kSliceNodes); // source row of the slot
-                if (a == c) continue;
-                const int32_t sc = c / kSliceNodes, nc = c % kSliceNodes;
-                p.in_slots[(size_t)(p.in_base[sc] + (int64_t)cnt[c] * kSliceNodes + nc)] = (int32_t)idx;
-                p.in_rows[(size_t)(p.in_base[sc] + (int64_t)cnt[c] * kSliceNodes + nc)] = a;
-                cnt[c]++;
+        plan_parallel(n_own, 4096, [&](int, int64_t c0, int64_t c1) {
+            std::vector<std::pair<int64_t, int32_t>> src; // (slot index, source row)
+            for (int64_t c = c0; c < c1; c++) {
+                src.clear();
+                for (int64_t q = nb_ptr[(size_t)c]; q < nb_ptr[(size_t)c + 1]; q++) {
+                    if (nb_mine[(size_t)q]) continue;
+                    const int32_t a = nb[(size_t)q];
+                    // row a's slots: the diagonal, then ascending global columns
+                    const int32_t *b = slot_col.data() + node_slot_ptr[(size_t)a] + 1, *e = slot_col.data() + node_slot_ptr[(size_t)a + 1];
+                    const int k = 1 + (int)(std::lower_bound(b, e, g0 + (int32_t)c) - b);
+                    src.emplace_back(Plan::slot_index(p.slice_base[a / kSliceNodes], k, a % kSliceNodes), a);
+                }
+                std::sort(src.begin(), src.end());
+                const int32_t sc = (int32_t)(c / kSliceNodes), nc = (int32_t)(c % kSliceNodes);
+                for (size_t j = 0; j < src.size(); j++) {
+                    const size_t d = (size_t)(p.in_base[sc] + (int64_t)j * kSliceNodes + nc);
+                    p.in_slots[d] = (int32_t)src[j].first;
+                    p.in_rows[d] = src[j].second;
+                }
             }
+        });
         // Transposed products that stay inside a slice: a stored block (a, c) whose column c is a row of the same slice
         // hands u = K_ac^T x_a to row c through LDS inside the SpMV kernel instead of through HBM (48 bytes written by
         // the SpMV, read again by the kernel that collects the products).  loc_index: per slot, the position of its u

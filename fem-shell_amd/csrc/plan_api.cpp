@@ -87,6 +87,9 @@ int64_t femshell_plan_array(const femshell_plan *plan, int which, void *out)
     case FEMSHELL_PLAN_IN_WIDTH: return give(p.in_width);
     case FEMSHELL_PLAN_IN_BASE: return give(p.in_base);
     case FEMSHELL_PLAN_IN_SLOTS: return give(p.in_slots);
+    case FEMSHELL_PLAN_GAT_SLOTS: return give(p.gat_slots);
+    case FEMSHELL_PLAN_LOC_LIST: return give(p.loc_list);
+    case FEMSHELL_PLAN_LOC_INDEX: return give(p.loc_index);
     case FEMSHELL_PLAN_PEER_RANKS:
         for (auto &h : p.peers) tmp.push_back(h.rank);
         return give(tmp);

@@ -59,7 +59,11 @@ enum {
     FEMSHELL_PLAN_SPMV_ORDER,       /* int32 [n_slices]      interior slices first, then boundary  */
     FEMSHELL_PLAN_IN_WIDTH,         /* int32 [n_slices]      symmetric storage: transposed blocks per row  */
     FEMSHELL_PLAN_IN_BASE,          /* int64 [n_slices+1]                                          */
-    FEMSHELL_PLAN_IN_SLOTS          /* int32 [in_base.back()] slot index of a block (a, this row) or -1 */
+    FEMSHELL_PLAN_IN_SLOTS,         /* int32 [in_base.back()] slot index of a block (a, this row) or -1 */
+    /* transposed products that stay inside a slice go through LDS in the SpMV kernel (csrc/plan.hpp): */
+    FEMSHELL_PLAN_GAT_SLOTS,        /* int32 [in_base.back()] IN_SLOTS without the blocks of the row's own slice (-1 there) */
+    FEMSHELL_PLAN_LOC_LIST,         /* uint8 [in_base.back()] position of the block among its slice's in-slice blocks, 255 = none */
+    FEMSHELL_PLAN_LOC_INDEX         /* uint8 [total_slots]    the same position per slot, 255 = the product leaves the slice */
 };
 /* returns the element count of the array; copies it to out when out != NULL */
 int64_t femshell_plan_array(const femshell_plan *plan, int which, void *out);

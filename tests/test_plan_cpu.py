@@ -249,3 +249,31 @@ def test_optional_renumbering_is_a_permutation_that_narrows_the_slices(kind):
     assert sorted(pq.tolist()) == list(range(q.n_nodes))
     with pytest.raises(pkg.FemShellError):
         pkg.reorder_host(kind, q.xyz, np.array([[0, 1, q.n_nodes]], np.int32))
+
+
+def test_products_that_stay_inside_a_slice():
+    """Symmetric storage: a stored block (a, c) with c in a's own slice hands K_ac^T x_a to row c through LDS.  Every
+    in-list entry is served exactly one way -- from LDS (loc_list) or from HBM (gat_slots) -- and the slot and the entry
+    agree on the LDS position; positions of a slice are 0..m-1 without gaps."""
+    for m in (meshes.structured(40, 40, 0, 0, 1, 1, kind="t", ul_lr=True), meshes.structured(19, 23, 0, 0, 1, 1, kind="q")):
+        p = pkg.build_plan(m.xyz, m.tri, m.quad)
+        assert p["symmetric"] == 1
+        ins, gat, ll, li, sb, ib = p["in_slots"], p["gat_slots"], p["loc_list"], p["loc_index"], p["slice_base"], p["in_base"]
+        assert len(gat) == len(ins) == len(ll) and len(li) == p["total_slots"]
+        n_local = 0
+        for s in range(p["n_slices"]):
+            e = np.arange(ib[s], ib[s + 1])
+            slot = ins[e]
+            inside = (slot >= sb[s]) & (slot < sb[s + 1])
+            assert np.all(slot[~inside] == gat[e][~inside]) and np.all(ll[e][~inside] == 255)
+            assert np.all(gat[e][inside] == -1)
+            pos = ll[e][inside]
+            assert sorted(pos.tolist()) == list(range(len(pos)))            # one LDS position each, no gaps
+            assert np.all(li[slot[inside]] == pos)                          # the producer writes where the consumer reads
+            n_local += len(pos)
+            own = li[sb[s]:sb[s + 1]]
+            assert np.count_nonzero(own != 255) == len(pos)                 # no slot writes to LDS without a reader
+        assert n_local > 0
+        # row-major grid: the block towards the previous node of the row is the one that stays in the slice
+        if len(m.tri):
+            assert 0.25 < n_local / np.count_nonzero(ins >= 0) < 0.40
