@@ -1,7 +1,7 @@
 """Randomised matrix parity sweep on the GPU (one-off stress run, slower than the test suite):
 random Delaunay and structured meshes, tri / quad / mixed, random Dirichlet sets and behaviour flags, sorted and
 shuffled node numbering; the assembled K and F must equal the oracle's (1e-12 relative to max |K|), and after a
-change of the Dirichlet set on the same context as well.   python tools/stress_parity.py [cases] [seed]"""
+change of the Dirichlet set on the same context as well; the product K x against the oracle's on the same matrix.   python tools/stress_parity.py [cases] [seed]"""
 import importlib, sys
 import numpy as np
 sys.path.insert(0, '.')
@@ -11,6 +11,7 @@ pkg = importlib.import_module("fem-shell_amd")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 worst = 0.0
+worst_spmv = 0.0
 for case in range(cases):
     kind = rng.choice(["delaunay", "tri", "quad", "mixed"])
     if kind == "delaunay":
@@ -50,6 +51,14 @@ for case in range(cases):
         worst = max(worst, err)
         assert err <= 1e-12, (case, kind, err)
         assert np.array_equal(Fg, F0), (case, kind)
+        # the product with the assembled matrix (symmetric storage: diagonal triangles, transposed products through LDS
+        # and through HBM) against the oracle's product with the oracle's matrix
+        xv = rng.normal(size=6 * n)
+        yg = np.asarray(fs.spmv(xv)).ravel()
+        y0 = oracle.spmv(r0, c0, v0, xv)
+        serr = np.abs(yg - y0).max() / (np.abs(v0).max() * np.abs(xv).max())
+        worst_spmv = max(worst_spmv, serr)
+        assert serr <= 1e-12, (case, kind, serr)
     fs.close()
     print("case %3d %-9s nodes %6d tri %6d quad %5d flags %d  ok" % (case, kind, n, len(tri), len(quad), flags), flush=True)
-print("all %d cases equal to the oracle; worst relative difference %.2e" % (cases, worst))
+print("all %d cases equal to the oracle; worst relative difference %.2e (matrix), %.2e (product, relative to max|K| max|x|)" % (cases, worst, worst_spmv))
