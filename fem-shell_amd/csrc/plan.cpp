@@ -392,16 +392,21 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         slot_col.resize(n_slots);
         slot_pair_ptr.resize(n_slots + 1);
         slot_pairs.resize(n_pairs);
-        size_t so = 0, po = 0;
+        std::vector<size_t> so_of((size_t)nchunks_r + 1, 0), po_of((size_t)nchunks_r + 1, 0);
         for (int t = 0; t < nchunks_r; t++) {
-            std::copy(part_col[(size_t)t].begin(), part_col[(size_t)t].end(), slot_col.begin() + so);
-            for (size_t k = 0; k < part_ptr[(size_t)t].size(); k++) slot_pair_ptr[so + k + 1] = (int32_t)(po + (size_t)part_ptr[(size_t)t][k]);
-            std::copy(part_pairs[(size_t)t].begin(), part_pairs[(size_t)t].end(), slot_pairs.begin() + po);
-            so += part_col[(size_t)t].size();
-            po += part_pairs[(size_t)t].size();
-            std::vector<int32_t>().swap(part_col[(size_t)t]);
-            std::vector<uint32_t>().swap(part_pairs[(size_t)t]);
+            so_of[(size_t)t + 1] = so_of[(size_t)t] + part_col[(size_t)t].size();
+            po_of[(size_t)t + 1] = po_of[(size_t)t] + part_pairs[(size_t)t].size();
         }
+        plan_parallel(nchunks_r, 1, [&](int, int64_t t0, int64_t t1) { // every chunk's lists to their place, chunks in parallel
+            for (int64_t t = t0; t < t1; t++) {
+                const size_t so = so_of[(size_t)t], po = po_of[(size_t)t];
+                std::copy(part_col[(size_t)t].begin(), part_col[(size_t)t].end(), slot_col.begin() + so);
+                for (size_t k = 0; k < part_ptr[(size_t)t].size(); k++) slot_pair_ptr[so + k + 1] = (int32_t)(po + (size_t)part_ptr[(size_t)t][k]);
+                std::copy(part_pairs[(size_t)t].begin(), part_pairs[(size_t)t].end(), slot_pairs.begin() + po);
+                std::vector<int32_t>().swap(part_col[(size_t)t]);
+                std::vector<uint32_t>().swap(part_pairs[(size_t)t]);
+            }
+        });
     }
     p.stored_blocks = (int64_t)slot_col.size();
     p.nnz_blocks = p.stored_blocks + lower_blocks;
@@ -458,25 +463,44 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     if (symmetric && total >= (1ll << 31)) return fail("matrix too large for symmetric storage (slot indices are 32-bit)");
     p.cols.resize((size_t)total);
     p.pair_ptr.resize((size_t)total + 1);
-    p.pairs.clear();
-    p.pairs.reserve(slot_pairs.size());
-    // slot order inside a slice is (k, n); the gather list follows the same order
-    for (int32_t s = 0; s < p.n_slices; s++) {
-        const int w = p.slice_width[s];
-        for (int k = 0; k < w; k++)
-            for (int n = 0; n < kSliceNodes; n++) {
-                const int64_t idx = Plan::slot_index(p.slice_base[s], k, n);
-                const int32_t a = s * kSliceNodes + n;
-                p.pair_ptr[idx] = (int32_t)p.pairs.size();
-                if (a < n_own && k < node_slot_ptr[a + 1] - node_slot_ptr[a]) {
-                    const int32_t q = node_slot_ptr[a] + k;
-                    p.cols[idx] = to_local(slot_col[q]);
-                    p.pairs.insert(p.pairs.end(), slot_pairs.begin() + slot_pair_ptr[q],
-                                   slot_pairs.begin() + slot_pair_ptr[q + 1]);
-                } else {
-                    p.cols[idx] = std::min(a, p.n_pad - 1); // padding slot: zero block on the own row
+    // slot order inside a slice is (k, n); the gather list follows the same order.  Slices on the host threads: the
+    // gather entries of a slice first counted, then copied to the offset the counts of the slices before it give
+    {
+        std::vector<int64_t> slice_pairs((size_t)p.n_slices + 1, 0);
+        auto real_slot = [&](int32_t a, int k) { return a < n_own && k < node_slot_ptr[a + 1] - node_slot_ptr[a]; };
+        plan_parallel(p.n_slices, 256, [&](int, int64_t s0, int64_t s1) {
+            for (int64_t s = s0; s < s1; s++) {
+                int64_t m = 0;
+                for (int n = 0; n < kSliceNodes; n++) {
+                    const int32_t a = (int32_t)s * kSliceNodes + n;
+                    if (a < n_own) m += slot_pair_ptr[(size_t)node_slot_ptr[a + 1]] - slot_pair_ptr[(size_t)node_slot_ptr[a]];
                 }
+                slice_pairs[(size_t)s + 1] = m;
             }
+        });
+        for (int32_t s = 0; s < p.n_slices; s++) slice_pairs[(size_t)s + 1] += slice_pairs[(size_t)s];
+        p.pairs.resize((size_t)slice_pairs[(size_t)p.n_slices]);
+        plan_parallel(p.n_slices, 256, [&](int, int64_t s0, int64_t s1) {
+            for (int64_t s = s0; s < s1; s++) {
+                const int w = p.slice_width[(size_t)s];
+                int64_t at = slice_pairs[(size_t)s];
+                for (int k = 0; k < w; k++)
+                    for (int n = 0; n < kSliceNodes; n++) {
+                        const int64_t idx = Plan::slot_index(p.slice_base[(size_t)s], k, n);
+                        const int32_t a = (int32_t)s * kSliceNodes + n;
+                        p.pair_ptr[(size_t)idx] = (int32_t)at;
+                        if (real_slot(a, k)) {
+                            const int32_t q = node_slot_ptr[a] + k;
+                            p.cols[(size_t)idx] = to_local(slot_col[(size_t)q]);
+                            const int32_t b = slot_pair_ptr[(size_t)q], e = slot_pair_ptr[(size_t)q + 1];
+                            std::copy(slot_pairs.begin() + b, slot_pairs.begin() + e, p.pairs.begin() + at);
+                            at += e - b;
+                        } else {
+                            p.cols[(size_t)idx] = std::min(a, p.n_pad - 1); // padding slot: zero block on the own row
+                        }
+                    }
+            }
+        });
     }
     p.pair_ptr[total] = (int32_t)p.pairs.size();
 
