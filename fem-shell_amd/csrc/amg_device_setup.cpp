@@ -1,12 +1,15 @@
-// amg_device_setup.cpp -- first coarsening step of the multigrid setup with the numerics on the device.
+// amg_device_setup.cpp -- coarsening steps of the multigrid setup with the numerics on the device (every level above
+// FEMSHELL_AMG_DEVICE_MIN nodes, amg_solve.cpp).
 //
 // The finest level dominates the setup: K has 14M blocks on the 4M-triangle meshes, and the host path (amg_setup.cpp)
-// first has to bring it over PCIe and mirror it.  Here the host only does integer work on the block graph the plan
-// already holds -- aggregation, the patterns of P, A P, R = P^T and A_c = P^T A P, and the index lists that tell every
-// block of a result which blocks feed it -- and the device computes the values from K where it lies (amg_kernels.hip:
-// k_amg_prolongator, k_amg_ap, k_amg_restriction, k_amg_galerkin), directly in the sliced block ELL layout the cycle
-// multiplies with.  Only the coarse operator (a ninth of the rows) travels back for the remaining levels, which stay on
-// the host.  FEMSHELL_AMG_SETUP=host keeps everything on the host (the path tests compare this one with).
+// first has to bring it over PCIe and mirror it.  Here the host only does integer work on the block graph the plan (or
+// the previous step) already holds -- aggregation, the grouping of the nodes by aggregate, the patterns of P, A P,
+// R = P^T and A_c = P^T A P, and the index lists that tell every block of a result which blocks feed it -- and the device
+// computes the values from the operator where it lies (amg_kernels.hip: k_amg_tentative_qr, k_amg_prolongator, k_amg_ap,
+// k_amg_restriction, k_amg_galerkin), directly in the sliced block ELL layout the cycle multiplies with.  The near-null
+// space never exists as a host array: generated from the mesh on the finest level, the R factors of the previous step
+// below.  A coarse operator travels back only when the next step runs on the host.  FEMSHELL_AMG_SETUP=host keeps
+// everything on the host (the path tests compare this one with).
 #include "amg_device.hpp"
 
 #include <algorithm>
@@ -245,7 +248,7 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     hipStream_t st = c->stream;
     const int32_t n = pat.n;
     if (c->cfg.world_size != 1) return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: single-rank contexts only");
-    // ---- aggregation and tentative prolongator on the graph
+    // ---- aggregation on the graph
     Bsr G;
     graph_of_pattern(pat, &G);
     std::vector<int32_t> agg;

@@ -390,7 +390,9 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
 // bytes).  With a lane per node both products are lane-local: no reduction across lanes or waves.  Phase 2
 // (k_sym_gather), one lane per scalar row: y_c += sum of the u of the blocks (a, c), in the fixed order of the plan's
 // in-lists -- deterministic, no atomics.  Traffic on the 4M-triangle panel: 2.31 GB of blocks + 0.29 GB of u written
-// and read once, against 4.03 GB of blocks with full storage.
+// and read once, against 4.03 GB of blocks with full storage.  Two refinements: of the symmetric diagonal block only the
+// words of the upper triangle are read (2.12 GB of blocks), and a product whose row c lies in the lane's own slice waits
+// in LDS for the end of the slice instead of going through HBM (plan.hpp loc_index / loc_list: 0.19 GB of u).
 // The fused dot x.Kx of CG needs no second phase: x.Kx = sum_a x_a.(direct part of y_a) + sum over stored
 // off-diagonal blocks of x_c.u.
 // =====================================================================================

@@ -126,14 +126,17 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                 if (c[i] == c[j]) return fail("quad " + std::to_string(e) + " repeats a node");
     }
 
-    // FEMSHELL_PLAN_VERBOSE=1: wall time of the phases below on stderr
+    // FEMSHELL_PLAN_VERBOSE=1: wall time of the phases below on stderr.  lap(name) opens the phase `name` and prints the
+    // time of the one it closes.
     static const bool verbose = getenv("FEMSHELL_PLAN_VERBOSE") && atoi(getenv("FEMSHELL_PLAN_VERBOSE")) != 0;
     auto t_lap = std::chrono::steady_clock::now();
+    const char *open_phase = "input checks";
     auto lap = [&](const char *what) {
         if (!verbose) return;
         const auto t = std::chrono::steady_clock::now();
-        fprintf(stderr, "[femshell plan] %-44s %.3f s\n", what, std::chrono::duration<double>(t - t_lap).count());
+        fprintf(stderr, "[femshell plan] %-44s %.3f s\n", open_phase, std::chrono::duration<double>(t - t_lap).count());
         t_lap = t;
+        open_phase = what;
     };
     Plan &p = *P;
     p = Plan();
@@ -151,7 +154,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     p.n_pad = (p.n_own + kSliceNodes - 1) / kSliceNodes * kSliceNodes;
     p.n_slices = p.n_pad / kSliceNodes;
 
-    lap("up to: node - element adjacency for the owned n");
+    lap("node - element adjacency");
     // ---- node -> element adjacency for the owned nodes; entries (element << 2 | index in element),
     //      element = combined id (triangles first), ascending per node
     const int32_t n_own = p.n_own;
@@ -183,7 +186,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             }
     }
 
-    lap("up to: local elements every element touching an");
+    lap("local elements");
     // ---- local elements: every element touching an owned node
     std::vector<int32_t> elem_local((size_t)n_tri + n_quad, -1);
     for (uint32_t v : adj) elem_local[v >> 2] = 0;
@@ -199,7 +202,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             p.quad_global_id.push_back(e);
         }
 
-    lap("up to: per owned node block slots slot 0  diago");
+    lap("slot structures");
     // ---- per owned node: block slots (slot 0 = diagonal, then ascending global column) and
     //      the gather list of every slot
     struct Slot {
@@ -212,7 +215,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     std::vector<int32_t> slot_col;                         // global ids, per node contiguous
     std::vector<int32_t> slot_pair_ptr(1, 0);              // per slot
     std::vector<uint32_t> slot_pairs;
-    lap("up to: symmetric storage which row of an owned");
+    lap("symmetric storage: neighbour lists");
     // ---- symmetric storage: which row of an owned pair (a,c) holds the block.  Any choice works -- the SpMV applies
     // every stored off-diagonal block to both rows -- so it is made to balance the rows: the ELL width of a slice is the
     // largest slot count of its 32 rows.  Start: the lower-numbered row keeps the block (on a structured grid every
@@ -268,7 +271,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                 std::copy_n(scratch.data() + ub[(size_t)a], n_distinct[(size_t)a], nb.data() + nb_ptr[(size_t)a]);
         });
         std::vector<int32_t>().swap(scratch);
-        lap("up to:   neighbour lists");
+        lap("symmetric storage: which row holds a block");
         std::vector<int32_t> cnt(cnt_ghost); // blocks a row stores besides its diagonal (ghost columns included)
         nb_mine.assign(nb.size(), 0);
         auto index_of = [&](int32_t row, int32_t col) -> int64_t {
@@ -319,7 +322,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             if (!moved) break;
         }
         for (size_t q = 0; q < nb_mine.size(); q++) lower_blocks += nb_mine[q] ? 0 : 1; // blocks of K without a slot in their row
-        lap("up to:   orientation of the stored blocks");
+        lap("slots and gather pairs per row");
     }
     auto stored_here = [&](int32_t a, int32_t b_global) { // symmetric storage: does row a hold the block (a, b)?
         if (b_global < g0 || b_global >= g1) return true; // ghost column
@@ -387,7 +390,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             n_pairs += part_pairs[(size_t)t].size();
         }
         if (n_pairs > 0x7fffff00ull || n_slots > 0x7fffff00ull) return fail("gather list exceeds 2^31 entries");
-        lap("up to:   slots and pairs per row (chunks)");
+        lap("join of the per-thread lists");
         for (int32_t a = 0; a < n_own; a++) node_slot_ptr[(size_t)a + 1] += node_slot_ptr[(size_t)a];
         slot_col.resize(n_slots);
         slot_pair_ptr.resize(n_slots + 1);
@@ -411,7 +414,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     p.stored_blocks = (int64_t)slot_col.size();
     p.nnz_blocks = p.stored_blocks + lower_blocks;
 
-    lap("up to: ghosts referenced columns outside the ow");
+    lap("ghost columns");
     // ---- ghosts: referenced columns outside the owned range, ascending
     {
         std::vector<int32_t> g;
@@ -428,7 +431,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         return p.n_pad + (int32_t)(it - p.ghost_global.begin());
     };
 
-    lap("up to: local copies of connectivity and coordin");
+    lap("local connectivity and coordinates");
     // ---- local copies of connectivity and coordinates
     p.tri_local.resize((size_t)n_ltri * 3);
     for (int32_t le = 0; le < n_ltri; le++)
@@ -444,7 +447,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     for (int32_t q = 0; q < p.n_ghost; q++)
         for (int d = 0; d < 3; d++) p.xyz_local[3ll * (p.n_pad + q) + d] = xyz[3ll * p.ghost_global[q] + d];
 
-    lap("up to: pack into slices");
+    lap("pack into slices");
     // ---- pack into slices
     p.slice_width.assign(p.n_slices, 1);
     p.slice_base.assign((size_t)p.n_slices + 1, 0);
@@ -504,7 +507,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     }
     p.pair_ptr[total] = (int32_t)p.pairs.size();
 
-    lap("up to: symmetric storage which stored blocks ac");
+    lap("in-lists and in-slice products");
     // ---- symmetric storage: which stored blocks act on a row through their transpose
     p.in_width.assign(p.n_slices, 0);
     p.in_base.assign((size_t)p.n_slices + 1, 0);
@@ -576,7 +579,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         for (int32_t s2 = 0; s2 < p.n_slices; s2++) p.max_loc = std::max(p.max_loc, per_slice[(size_t)s2]);
     }
 
-    lap("up to: per-slice element lists and slice-relati");
+    lap("per-slice element lists");
     // ---- per-slice element lists and slice-relative 16-bit gather entries (chunks of slices on the host threads, each
     //      into lists of its own that are joined in slice order afterwards)
     p.slice_elem_ptr.assign((size_t)p.n_slices + 1, 0);
@@ -641,7 +644,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         }
     }
 
-    lap("up to: assembly work items");
+    lap("assembly work items");
     // ---- assembly work items
     // contributions per item (FEMSHELL_ITEM_PAIRS overrides): 3 fills the four waves of a full-storage slice evenly (256
     // items); with symmetric storage a structured slice has 32 diagonal slots of 6 and 96 off-diagonal slots of 2
@@ -741,7 +744,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             std::vector<Plan::Item>().swap(part_items[(size_t)t]);
         }
     }
-    lap("up to: per-slice descriptors of the assembly ke");
+    lap("slice descriptors");
     // ---- per-slice descriptors of the assembly kernel
     p.slice_desc.assign((size_t)p.n_slices * 8, 0);
     for (int32_t s = 0; s < p.n_slices; s++) {
@@ -755,7 +758,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         d[6] = p.slice_width[s];
     }
 
-    lap("up to: halo exchange lists");
+    lap("halo exchange lists");
     // ---- halo exchange lists
     if (world > 1) {
         // receive side: ghosts grouped by owner (ghost_global is ascending, ranges are contiguous)
@@ -808,7 +811,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         p.n_interior_slices = (int32_t)p.spmv_order.size();
         p.spmv_order.insert(p.spmv_order.end(), boundary.begin(), boundary.end());
     }
-    lap("up to: end");
+    lap("done");
     return true;
 }
 
