@@ -114,7 +114,8 @@ constexpr int kRecQQ = 17, kRecQC = 23, kRecCC = 32;
 constexpr int kQuadX = 18, kQuadY = 22; // QUAD4 records: local x and y of the four nodes
 // Records of meshes with quadrilaterals are 46 doubles (again 2*odd): a QUAD4 record also carries, per Gauss point g,
 // the inverse Jacobian (four numbers) and its determinant at [kQuadGp + 5 g ..]
-constexpr int kRecDoublesQuad = 46;
+constexpr int kRecDoublesQuad = 66;
+constexpr int kQuadSide = 46; // DKQ coefficients (a, b, c, d, e) of the four sides, side s = node s -> node s+1
 constexpr int kQuadGp = 26;
 // index of entry (n,m) of a symmetric 3x3 table stored as 00,01,02,11,12,22
 __device__ __forceinline__ int sym3(int n, int m)
@@ -383,6 +384,23 @@ __device__ __forceinline__ void tri3_diag_add_rec(const double *rec, int ia, con
 // Record: [0..8] ex,ey,ez  [kRecKind] = 2.0 if valid  [kQuadX..+3] local x of the 4 nodes  [kQuadY..+3] local y.
 // =========================================================================================
 
+// DKQ side coefficients (SA:613-621) of one element side with difference vector (x, y): they do not depend on
+// the Gauss point, so a block computes them once per side it needs
+struct DkqSide {
+    double a, b, c, d, e;
+};
+__device__ __forceinline__ DkqSide dkq_side(double x, double y)
+{
+    const double l = 1.0 / (x * x + y * y);
+    DkqSide s;
+    s.a = -x * l;
+    s.b = 0.75 * x * y * l;
+    s.c = (0.25 * x * x - 0.5 * y * y) * l;
+    s.d = -y * l;
+    s.e = (0.25 * y * y - 0.5 * x * x) * l;
+    return s;
+}
+
 // SA:342-375: frame from the mid-side points; local coordinates are T*X without translation.
 __device__ __forceinline__ bool quad4_record(const double X[12], const MatConst &mc, double rec[kRecDoublesQuad])
 {
@@ -454,29 +472,26 @@ __device__ __forceinline__ bool quad4_record(const double X[12], const MatConst 
             g[4] = det;
         }
     }
+    // side coefficients of the plate part (they do not depend on the Gauss point nor on the block): side s from node s
+    // to node s+1, differences as in SA:413-424
+#pragma unroll
+    for (int sd = 0; sd < 4; sd++) {
+        const double dx = rec[kQuadX + sd] - rec[kQuadX + (sd + 1) % 4], dy = rec[kQuadY + sd] - rec[kQuadY + (sd + 1) % 4];
+        const double l2 = dx * dx + dy * dy;
+        const double l = (ok && l2 > 0.0) ? 1.0 / l2 : 0.0;
+        double *q = rec + kQuadSide + 5 * sd;
+        q[0] = -dx * l;
+        q[1] = 0.75 * dx * dy * l;
+        q[2] = (0.25 * dx * dx - 0.5 * dy * dy) * l;
+        q[3] = -dy * l;
+        q[4] = (0.25 * dy * dy - 0.5 * dx * dx) * l;
+    }
     rec[kRecKind] = ok ? 2.0 : 0.0;
     if (!ok) {
 #pragma unroll
         for (int i = 0; i < kRecDoublesQuad; i++) rec[i] = 0.0; // (selects, no branch: the values above may be Inf / NaN)
     }
     return ok;
-}
-
-// DKQ side coefficients (SA:613-621) of one element side with difference vector (x, y): they do not depend on
-// the Gauss point, so a block computes them once per side it needs
-struct DkqSide {
-    double a, b, c, d, e;
-};
-__device__ __forceinline__ DkqSide dkq_side(double x, double y)
-{
-    const double l = 1.0 / (x * x + y * y);
-    DkqSide s;
-    s.a = -x * l;
-    s.b = 0.75 * x * y * l;
-    s.c = (0.25 * x * x - 0.5 * y * y) * l;
-    s.d = -y * l;
-    s.e = (0.25 * y * y - 0.5 * x * x) * l;
-    return s;
 }
 
 // DKQ curvature columns of node n at one Gauss point: B[r][c], r = (kxx, kyy, kxy), c = (w, tx, ty).
@@ -505,23 +520,22 @@ __device__ __forceinline__ void quad4_block_add_rec(const double *rec, int ia, i
                                                     double acc[36])
 {
     // node data by dynamic index straight from the record (LDS or registers), no selects
-    const int ia_p = (ia + 3) & 3, ia_n = (ia + 1) & 3, ib_p = (ib + 3) & 3, ib_n = (ib + 1) & 3;
-    const double xi_ = rec[kQuadX + ia], yi_ = rec[kQuadY + ia], xj_ = rec[kQuadX + ib], yj_ = rec[kQuadY + ib];
-    // side differences (SA:413-424): side s = node s - node s+1
-    const double xa_i = xi_ - rec[kQuadX + ia_n], ya_i = yi_ - rec[kQuadY + ia_n];   // side sa = ia
-    const double xb_i = rec[kQuadX + ia_p] - xi_, yb_i = rec[kQuadY + ia_p] - yi_;   // side sb = ia-1
-    const double xa_j = xj_ - rec[kQuadX + ib_n], ya_j = yj_ - rec[kQuadY + ib_n];
-    const double xb_j = rec[kQuadX + ib_p] - xj_, yb_j = rec[kQuadY + ib_p] - yj_;
+    const int ia_p = (ia + 3) & 3, ib_p = (ib + 3) & 3; // side s runs from node s to node s+1: a node sees sides s and s-1
     // natural coordinates of the corner nodes: (-1,-1), (1,-1), (1,1), (-1,1)
     const double ri = (ia == 1 || ia == 2) ? 1.0 : -1.0, si = (ia >= 2) ? 1.0 : -1.0;
     const double rj = (ib == 1 || ib == 2) ? 1.0 : -1.0, sj = (ib >= 2) ? 1.0 : -1.0;
-    const DkqSide sa_i = dkq_side(xa_i, ya_i), sb_i = dkq_side(xb_i, yb_i), sa_j = dkq_side(xa_j, ya_j),
-                  sb_j = dkq_side(xb_j, yb_j);
+    auto side = [&](int sd) {
+        const double *q = rec + kQuadSide + 5 * sd;
+        DkqSide r;
+        r.a = q[0]; r.b = q[1]; r.c = q[2]; r.d = q[3]; r.e = q[4];
+        return r;
+    };
+    const DkqSide sa_i = side(ia), sb_i = side(ia_p), sa_j = side(ib), sb_j = side(ib_p);
 
     double m00 = 0.0, m01 = 0.0, m10 = 0.0, m11 = 0.0;
     double p[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     const double root = 0.57735026918962576451; // sqrt(1/3)
-#pragma unroll 1
+#pragma unroll 1 // (unrolled by two the kernel spills 356 bytes per lane and takes 1.87 ms instead of 1.14 per million quads)
     for (int gp = 0; gp < 4; gp++) {
         const double r = (gp & 2) ? -root : root, s = (gp & 1) ? -root : root; // SA:482-487 order
         // inverse Jacobian and determinant of this Gauss point from the record
@@ -553,7 +567,14 @@ __device__ __forceinline__ void quad4_block_add_rec(const double *rec, int ia, i
             };
             double Bi[3][3], Bj[3][3];
             dkq_node_block(sa_i, sb_i, corner_x(ri, si), corner_e(ri, si), mid_x(ia), mid_e(ia), mid_x(ia_p), mid_e(ia_p), Ji, Bi);
-            dkq_node_block(sa_j, sb_j, corner_x(rj, sj), corner_e(rj, sj), mid_x(ib), mid_e(ib), mid_x(ib_p), mid_e(ib_p), Ji, Bj);
+            if (ia != ib) { // (the work items of the diagonal slots sit together in the first wave: it skips this as a whole)
+                dkq_node_block(sa_j, sb_j, corner_x(rj, sj), corner_e(rj, sj), mid_x(ib), mid_e(ib), mid_x(ib_p), mid_e(ib_p), Ji, Bj);
+            } else {
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) Bj[a][c] = Bi[a][c];
+            }
             const double w = det * mc.cp;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
