@@ -681,6 +681,45 @@ def test_symmetric_storage_equals_full_storage(monkeypatch):
     assert np.linalg.norm(res0 - oracle_residual(r0, c0, v0, F0, u0)) <= 1e-11 * np.linalg.norm(F0)
 
 
+def test_products_kept_in_the_slice_equal_the_products_through_hbm(monkeypatch):
+    """A stored block (a, c) with c in a's own slice hands K_ac^T x_a to row c through LDS (default) or, with
+    FEMSHELL_SPMV_LOCAL=0, through HBM like every other transposed product: the same product to rounding (the sums of a
+    row take another order), both equal to the oracle's, each reproducible bit by bit, and the same solve."""
+    cases = [curved_mesh(41, 33), meshes.structured(37, 29, 0, 0, 3, 2, kind="q", bcids=(0, 0, 1, -1), factor=3.0, loading=2)]
+    xyz, tri = delaunay_shell(2500, 7)
+    for m in cases + [None]:
+        if m is None:
+            n, X, T, Q = len(xyz), xyz, tri, np.zeros((0, 4), np.int32)
+            dm = np.zeros(n, dtype=np.uint8); dm[X[:, 0] < 0.2] = 0x3F
+            ld = np.zeros((n, 6)); ld[:, 2] = 1.0
+        else:
+            n, X, T, Q, dm, ld = m.n_nodes, m.xyz, m.tri, m.quad, m.dirichlet_mask(), m.loads
+        x = np.random.default_rng(2).normal(size=6 * n)
+        out = {}
+        for loc in ("1", "0"):
+            monkeypatch.setenv("FEMSHELL_SPMV_LOCAL", loc)
+            fs = pkg.FemShell(0.3, 7.0e4, 0.05)
+            fs.set_mesh(X, T, Q); fs.set_dirichlet(dm); fs.set_loads(ld); fs.assemble()
+            y1, y2 = fs.spmv(x), fs.spmv(x)
+            assert np.array_equal(y1, y2)
+            u, its = None, 0
+            if m is cases[0]:  # (the solve on the triangle mesh only: block-Jacobi CG is slow on the other two)
+                u, info = fs.solve(rtol=1e-11, max_it=100000)
+                assert info["converged"] == 1
+                its = info["iterations"]
+            r, c, v, F = fs.export_bsr()
+            out[loc] = (y1, u, its)
+            fs.close()
+        monkeypatch.delenv("FEMSHELL_SPMV_LOCAL")
+        y0 = oracle.spmv(r, c, v, x)
+        scale = np.abs(v).max() * np.abs(x).max()
+        assert np.abs(out["1"][0] - y0).max() <= 1e-13 * scale and np.abs(out["0"][0] - y0).max() <= 1e-13 * scale
+        assert not np.array_equal(out["1"][0], out["0"][0]) or len(T) == 0  # (the knob did something)
+        if m is cases[0]:
+            assert abs(out["1"][2] - out["0"][2]) <= max(3, 0.02 * out["0"][2])
+            assert np.linalg.norm(out["1"][1] - out["0"][1]) <= 1e-8 * np.linalg.norm(out["0"][1])
+
+
 def oracle_residual(r, c, v, F, u):
     K = oracle.to_scipy(r, c, v)
     K.sort_indices()
