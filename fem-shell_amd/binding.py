@@ -43,7 +43,9 @@ class SolveInfo(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("rel_residual", C.c_double),
                 ("true_rel_residual", C.c_double), ("assemble_seconds", C.c_double), ("setup_seconds", C.c_double), ("solve_seconds", C.c_double),
                 ("bytes_per_iteration", C.c_double), ("pc_type", C.c_int32), ("amg_levels", C.c_int32),
-                ("pc_setup_seconds", C.c_double), ("operator_complexity", C.c_double)]
+                ("pc_setup_seconds", C.c_double), ("operator_complexity", C.c_double),
+                ("refine_passes_done", C.c_int32), ("reserved0", C.c_int32), ("refine_correction_rel", C.c_double),
+                ("refine_residual_reduction", C.c_double), ("error_estimate", C.c_double)]
 
 
 class PcOptions(C.Structure):
@@ -81,6 +83,14 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    host_only = os.environ.get("FEMSHELL_HOST_LIBRARY")
+    if host_only:
+        # sanitizer builds of the host-side code only (`make -C fem-shell_amd/csrc san`, tools/run_sanitizers.sh): they
+        # export include/femshell_plan.h and femshell_last_error, nothing that touches a GPU
+        L = C.CDLL(host_only)
+        L.femshell_last_error.restype = C.c_char_p
+        _lib = L
+        return L
     path = library_path()
     if not os.path.exists(path):
         raise FemShellError(-2, "libfemshell.so is missing: build it with `make -C fem-shell_amd/csrc` "

@@ -106,7 +106,7 @@ int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate
 int cg_amg(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it, double *true_rr_out, double *rec_rr_out);
 double amg_bytes_per_iteration(const femshell_ctx *c);
 // K of a single-rank context as host BSR with ascending columns (api.cpp)
-int download_matrix(femshell_ctx *c, Bsr *A);
+int download_matrix(femshell_ctx *c, Bsr *A, int32_t *col_out = nullptr, double *val_out = nullptr);
 // first coarsening step with the numerics on the device (amg_device_setup.cpp)
 // (A: the level operator in HBM, block-Jacobi inverse valid; pat: host copy of its pattern; want_host(coarse nodes): bring
 //  the coarse operator back as a host matrix -- needed when the next step runs on the host or the level is the coarsest)

@@ -370,6 +370,16 @@ __global__ __launch_bounds__(256) void k_kcyc_r2(const double *__restrict__ rc, 
         r2[i] = rc[i] - t * v1[i];
 }
 
+int launch_two_dots(const double *a0, const double *b0, const double *a1, const double *b1, int64_t n, double *scratch, hipStream_t st)
+{
+    int groups = (int)((n + 4095) / 4096);
+    if (groups > kKcycGroups) groups = kKcycGroups;
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL(k_kcyc_dots, dim3(groups), dim3(256), 0, st, a0, b0, a1, b1, (const double *)nullptr, (const double *)nullptr, n,
+                       scratch, (const CgScalars *)nullptr);
+    return groups;
+}
+
 void launch_kcyc_r2(const double *rc, const double *v1, double *r2, int64_t n6, const KcycScalars *ks, const CgScalars *gate,
                     hipStream_t st)
 {

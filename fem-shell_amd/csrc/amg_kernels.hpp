@@ -54,6 +54,9 @@ struct KcycScalars {
 };
 void launch_kcyc_dots(int phase, const double *a0, const double *b0, const double *a1, const double *b1, const double *a2,
                       const double *b2, int64_t n6, KcycScalars *ks, double *scratch, const CgScalars *gate, hipStream_t st);
+// stage 1 of two dot products a0.b0 and a1.b1 over n entries: scratch[g] and scratch[128 + g] for g < the returned group
+// count (<= 128) hold the partial sums, in a fixed order (error estimate of the refinement passes: the host adds them)
+int launch_two_dots(const double *a0, const double *b0, const double *a1, const double *b1, int64_t n, double *scratch, hipStream_t st);
 // out = in - ks->t * v
 void launch_kcyc_r2(const double *rc, const double *v1, double *r2, int64_t n6, const KcycScalars *ks, const CgScalars *gate,
                     hipStream_t st);

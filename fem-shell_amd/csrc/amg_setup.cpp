@@ -13,17 +13,7 @@
 
 namespace femshell {
 
-int host_threads()
-{
-    static const int n = [] {
-        const char *e = getenv("FEMSHELL_HOST_THREADS");
-        int t = e ? atoi(e) : available_cpus();
-        if (t < 1) t = 1;
-        if (t > 64) t = 64;
-        return t;
-    }();
-    return n;
-}
+int host_threads() { return host_thread_count(); }
 
 void parallel_chunks(int64_t n, const std::function<void(int64_t, int64_t)> &f, int64_t min_chunk)
 {

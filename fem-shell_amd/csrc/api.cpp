@@ -4,6 +4,7 @@
 #include "amg_device.hpp"
 #include "context.hpp"
 #include "reorder.hpp"
+#include "trace.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -142,6 +143,7 @@ int upload_node_data(femshell_ctx *c)
 int do_assemble(femshell_ctx *c)
 {
     if (!c->have_mesh) return set_err(FEMSHELL_ERR_INVALID, "femshell_assemble: no mesh set");
+    TraceRange trace("femshell_assemble");
     int rc = select_device(c);
     if (rc) return rc;
     FS_HIP(hipEventRecord(c->ev0, c->stream));
@@ -172,6 +174,7 @@ int do_rhs(femshell_ctx *c)
 
 int do_jacobi(femshell_ctx *c)
 {
+    TraceRange trace("femshell block-Jacobi setup");
     FS_HIP(hipEventRecord(c->ev0, c->stream));
     launch_block_jacobi(c->dm, c->stream);
     FS_HIP(hipEventRecord(c->ev1, c->stream));
@@ -201,6 +204,17 @@ int amg_setup_through_shadow(femshell_ctx *c)
     femshell_ctx *sh = c->amg_shadow; // kept while the mesh stays (femshell_set_mesh drops it): only K is assembled again
     int rc = FEMSHELL_OK;
     if (!sh) {
+        // the whole K, its plan and the hierarchy on this GPU: 1.3 KB per triangle measured on the 4M-triangle meshes
+        // (5.2 GB); a mesh that was partitioned because it does not fit one GPU cannot take this path
+        size_t free_b = 0, total_b = 0;
+        FS_HIP(hipMemGetInfo(&free_b, &total_b));
+        const double need = 1.6e3 * ((double)c->mesh_tri.size() / 3.0 + 1.4 * (double)c->mesh_quad.size() / 4.0);
+        if (need > (double)free_b) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "multigrid on a row-partitioned context keeps the whole K and its hierarchy on every GPU: about %.1f GB "
+                     "for this mesh, %.1f GB free on device %d; use -pc_type bjacobi or fewer, larger partitions", need / 1e9, (double)free_b / 1e9, c->device);
+            return set_err(FEMSHELL_ERR_UNSUPPORTED, buf);
+        }
         femshell_config cfg = c->cfg;
         cfg.rank = 0;
         cfg.world_size = 1;
@@ -231,7 +245,9 @@ int amg_setup_through_shadow(femshell_ctx *c)
 
 namespace femshell {
 
-int download_matrix(femshell_ctx *c, Bsr *Aout)
+// (col_out / val_out != nullptr: columns and values go straight into the caller's arrays -- femshell_export_bsr at the
+//  4M-triangle sizes, where a second 4 GB copy of the blocks is not welcome -- and A keeps the row pointers only)
+int download_matrix(femshell_ctx *c, Bsr *Aout, int32_t *col_out, double *val_out)
 {
     const Plan &p = c->plan;
     // pinned landing buffer: a pageable std::vector would be zero-filled first and copied at a fraction of the PCIe rate
@@ -262,8 +278,12 @@ int download_matrix(femshell_ctx *c, Bsr *Aout)
                 if (p.in_slots[(size_t)(p.in_base[s] + (int64_t)k * kSliceNodes + n)] >= 0) cnt++;
         A.ptr[a + 1] = A.ptr[a] + cnt;
     }
-    A.col.resize((size_t)A.ptr[p.n_own]);
-    A.val.resize((size_t)A.ptr[p.n_own] * 36);
+    if (!col_out) {
+        A.col.resize((size_t)A.ptr[p.n_own]);
+        A.val.resize((size_t)A.ptr[p.n_own] * 36);
+        col_out = A.col.data();
+        val_out = A.val.data();
+    }
     parallel_chunks(p.n_own, [&](int64_t a0, int64_t a1) {
         struct Src { int32_t col; int64_t slot; bool transposed; };
         std::vector<Src> order;
@@ -283,8 +303,8 @@ int download_matrix(femshell_ctx *c, Bsr *Aout)
             std::sort(order.begin(), order.end(), [](const Src &x, const Src &y) { return x.col < y.col; });
             int64_t nb = A.ptr[a];
             for (const Src &sc : order) {
-                A.col[nb] = sc.col;
-                double *blk = &A.val[(size_t)nb * 36];
+                col_out[nb] = sc.col;
+                double *blk = val_out + (size_t)nb * 36;
                 const int ns = (int)(sc.slot % kSliceNodes);
                 const double *src = h.data() + (sc.slot - ns) * 36; // the (slice, k) group of 32 blocks
                 for (int i = 0; i < 6; i++)
@@ -368,6 +388,13 @@ int femshell_create(const femshell_config *cfg, femshell_ctx **out)
         }
     c->mc.flags = cfg->flags;
     c->mc.pad = 0;
+    if (cfg->world_size > 1) {
+        // one process per GPU on one node (BASELINE: "the 8 GPUs of one node"): the ranks share the host's cores for the
+        // plan and the multigrid setup; LOCAL_WORLD_SIZE (torchrun) / FEMSHELL_LOCAL_WORLD_SIZE say how many share this host
+        const char *lw = getenv("FEMSHELL_LOCAL_WORLD_SIZE");
+        if (!lw) lw = getenv("LOCAL_WORLD_SIZE");
+        set_host_share(lw && atoi(lw) > 0 ? atoi(lw) : cfg->world_size);
+    }
     {
         const char *e = getenv("FEMSHELL_PC");
         const bool amg = e && (std::strcmp(e, "amg") == 0 || std::strcmp(e, "gamg") == 0);
@@ -423,6 +450,9 @@ int femshell_comm_init(femshell_ctx *c, const uint8_t id[128])
 
 int32_t femshell_comm_ranks(femshell_ctx *c) { return c ? comm_count(c->comm) : 0; }
 
+static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri,
+                                 int32_t n_quad, const int32_t *quad);
+
 int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri,
                       int32_t n_quad, const int32_t *quad)
 {
@@ -432,6 +462,16 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
         return set_err(FEMSHELL_ERR_INVALID, "femshell_set_mesh: call femshell_comm_init first on a multi-rank context");
     int rc = select_device(c);
     if (rc) return rc;
+    // a failure that only this rank sees (its slices exceed the LDS staging, one of its nodes has too many neighbours, a
+    // HIP allocation failed) must reach the others: they would wait in the next collective forever
+    return agree_status(c, set_mesh_on_this_rank(c, n_nodes, xyz, n_tri, tri, n_quad, quad), "femshell_set_mesh");
+}
+
+static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri,
+                                 int32_t n_quad, const int32_t *quad)
+{
+    int rc = FEMSHELL_OK;
+    TraceRange trace("femshell_set_mesh (plan + upload)");
     for (int64_t i = 0; i < 3ll * n_nodes; i++)
         if (!std::isfinite(xyz[i])) return set_err(FEMSHELL_ERR_MESH, "femshell_set_mesh: non-finite coordinate");
     std::string e;
@@ -466,7 +506,7 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
         (void)femshell_destroy(c->amg_shadow);
         c->amg_shadow = nullptr;
     }
-    if (c->comm.active()) { // the multigrid preconditioner of a row-partitioned context builds its hierarchy from the whole mesh
+    if (c->cfg.world_size > 1 || c->comm.active()) { // the multigrid preconditioner of a row-partitioned context builds its hierarchy from the whole mesh
         c->mesh_xyz.assign(xyz, xyz + 3ll * n_nodes);
         c->mesh_tri.assign(tri, tri + 3ll * n_tri);
         c->mesh_quad.assign(quad, quad + 4ll * n_quad);
@@ -745,6 +785,7 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
     if (!c) return set_err(FEMSHELL_ERR_INVALID, "femshell_solve: null context");
     if (!c->have_mesh) return set_err(FEMSHELL_ERR_INVALID, "femshell_solve: no mesh set");
     if (max_it < 0) return set_err(FEMSHELL_ERR_INVALID, "femshell_solve: max_it < 0");
+    TraceRange trace("femshell_solve");
     int rc = select_device(c);
     if (rc) return rc;
     double asm_s = 0.0;
@@ -783,6 +824,7 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
         }
     }
     hipStream_t st = c->stream;
+    TraceRange trace_cg(use_amg ? "femshell_solve: multigrid-preconditioned CG" : "femshell_solve: block-Jacobi CG");
     FS_HIP(c->hist.alloc((size_t)std::min<int64_t>(std::max(max_it, 1), 1 << 22))); // history of the first 4M iterations
     CgVectors v = cg_vectors(c);
     const DeviceMatrix &m = c->dm;
@@ -845,6 +887,11 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
         info->amg_levels = use_amg ? (int32_t)c->amg->levels.size() : 0;
         info->pc_setup_seconds = pc_setup_s;
         info->operator_complexity = 0.0;
+        info->refine_passes_done = use_amg ? c->refine.passes : 0;
+        info->reserved0 = 0;
+        info->refine_correction_rel = use_amg ? c->refine.correction_rel : -1.0;
+        info->refine_residual_reduction = use_amg ? c->refine.residual_reduction : 0.0;
+        info->error_estimate = (use_amg && c->refine.passes > 0) ? c->refine.correction_rel * c->refine.residual_reduction : -1.0;
         if (use_amg) {
             double tot = 0.0;
             for (auto &L : c->amg->levels) tot += (double)L->nnzb;
@@ -935,14 +982,14 @@ int femshell_export_bsr(femshell_ctx *c, int32_t *rowptr, int32_t *colidx, doubl
         FS_HIP(hipMemcpyAsync(F, c->F.p, (size_t)p.n_own * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     Bsr A;
-    rc = download_matrix(c, &A);
-    if (rc) return rc;
     if (c->perm.empty()) {
+        rc = download_matrix(c, &A, colidx, vals);
+        if (rc) return rc;
         for (int32_t a = 0; a <= p.n_own; a++) rowptr[a] = (int32_t)A.ptr[a];
-        std::copy(A.col.begin(), A.col.end(), colidx);
-        std::copy(A.val.begin(), A.val.end(), vals);
         return FEMSHELL_OK;
     }
+    rc = download_matrix(c, &A);
+    if (rc) return rc;
     // internal numbering -> the caller's: rows in the caller's order, columns ascending in the caller's ids
     if (F) {
         std::vector<double> Fi(F, F + (size_t)p.n_own * 6);

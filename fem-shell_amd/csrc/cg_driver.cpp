@@ -5,12 +5,14 @@
 
 #include <cstddef>
 #include <cstdlib>
+#include "trace.hpp"
 
 namespace femshell {
 
 int halo_exchange(femshell_ctx *c, double *p, hipStream_t st)
 {
     if (!c->comm.active() || c->plan.peers.empty()) return FEMSHELL_OK;
+    TraceRange trace("femshell halo exchange");
     const Plan &pl = c->plan;
     for (size_t i = 0; i < pl.peers.size(); i++)
         launch_pack(p, c->send_nodes.p + c->send_offsets[i], (int32_t)pl.peers[i].send_nodes.size(),

@@ -11,16 +11,13 @@
 #include <vector>
 
 #include "comm.hpp"
+#include "errors.hpp"
 #include "kernels.hpp"
 #include "plan.hpp"
 
 namespace femshell {
 
 struct Amg; // multigrid hierarchy (amg_device.hpp)
-
-// records the message femshell_last_error() returns on the calling thread and passes `code` through
-int set_err(int code, const std::string &msg);
-const std::string &last_err();
 
 inline const char *fs_basename(const char *path)
 {
@@ -124,6 +121,13 @@ struct femshell_ctx {
     std::vector<double> mesh_xyz;
     std::vector<int32_t> mesh_tri, mesh_quad;
     femshell_ctx *amg_shadow = nullptr;
+
+    // error estimate of the last multigrid-preconditioned solve (femshell_solve_info, cg_amg)
+    struct RefineStats {
+        int32_t passes = 0;
+        double correction_rel = -1.0, residual_reduction = 0.0;
+    } refine;
+    femshell::DevBuf<double> dots_scratch;
 
     double last_assemble_s = 0.0, last_setup_s = 0.0;
     std::vector<double> hist_host;

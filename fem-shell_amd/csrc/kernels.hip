@@ -1134,7 +1134,9 @@ __device__ __forceinline__ void cg_scalar_phase(const CgVectors &v, int phase, d
         s->alpha = 0.0;
         s->beta = 0.0;
         s->rz = 0.0;
-        const double tol2_solve = rtol > 0.0 ? rtol * rtol * s->bb : 0.0; // the tolerance of the solve as a whole
+        // (cg_amg passes rtol = 0: a pass stops on the drop of its own right-hand side alone; with rtol > 0 it would also
+        //  stop at the tolerance of the solve as a whole)
+        const double tol2_solve = rtol > 0.0 ? rtol * rtol * s->bb : 0.0;
         s->done = (s->red[0] <= tol2_solve) ? 1 : 0;
         // the correction equation needs four digits, not the full tolerance again: its solution is added to an iterate
         // whose error it reduces by that factor (2e-10 -> 1e-13 and below on the shell systems), and every further

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <thread>
 
@@ -24,16 +25,21 @@ int available_cpus()
     return n < 1 ? 1 : n;
 }
 
-// host threads of the symbolic phase (FEMSHELL_HOST_THREADS, at most 64): contiguous chunks of [0, n), one per thread
-static int plan_threads()
+// Ranks that share this host's cores (set by femshell_create of a multi-rank context: one process per GPU, all on one
+// node): every rank takes its share of the cores for the symbolic phase and the multigrid setup instead of all of them.
+static std::atomic<int> g_host_share{1};
+void set_host_share(int ranks_on_this_host) { g_host_share.store(ranks_on_this_host < 1 ? 1 : ranks_on_this_host); }
+
+// host threads of the symbolic phase and the multigrid setup: FEMSHELL_HOST_THREADS, else the available cores divided by
+// the ranks on the host; at most 64
+int host_thread_count()
 {
-    static const int n = [] {
-        const char *e = getenv("FEMSHELL_HOST_THREADS");
-        int t = e ? atoi(e) : available_cpus();
-        return t < 1 ? 1 : (t > 64 ? 64 : t);
-    }();
-    return n;
+    const char *e = getenv("FEMSHELL_HOST_THREADS"); // (read per call: tests switch it inside one process)
+    const int from_env = e ? atoi(e) : 0;
+    int t = from_env > 0 ? from_env : available_cpus() / g_host_share.load();
+    return t < 1 ? 1 : (t > 64 ? 64 : t);
 }
+static int plan_threads() { return host_thread_count(); }
 template <class F> static void plan_parallel(int64_t n, int64_t min_chunk, F f) // f(thread, begin, end)
 {
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(plan_threads(), n / std::max<int64_t>(min_chunk, 1)));

@@ -117,6 +117,9 @@ struct Plan {
 // CPUs this process may run on (its affinity mask; a pinned or cpuset-confined rank does not start a thread per core of
 // the machine), at least 1
 int available_cpus();
+// threads of the host-side symbolic work (plan.cpp): FEMSHELL_HOST_THREADS, else available_cpus() / ranks on the host, <= 64
+int host_thread_count();
+void set_host_share(int ranks_on_this_host);
 
 // owned node range of `rank` when n_nodes rows are split over `world` ranks
 void partition_rows(int32_t n_nodes, int world, int rank, int32_t *begin, int32_t *end);

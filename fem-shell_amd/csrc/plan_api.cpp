@@ -6,7 +6,8 @@
 #include <vector>
 
 #include "amg.hpp"
-#include "context.hpp"
+#include "errors.hpp"
+#include "plan.hpp"
 #include "reorder.hpp"
 
 using namespace femshell;

@@ -12,12 +12,20 @@
 //       "compat" mode, adds the device-assembled rows into system.matrix / system.rhs so that
 //       any libMesh/PETSc solver can be used unchanged.
 //   (2) FemShellLinearSolver: a libMesh::LinearSolver<Number> that keeps K in HBM and runs the
-//       block-Jacobi CG there; assigned to system.linear_solver before equation_systems.solve()
-//       (fem-shell.cpp:138; fem-shell_precice.cpp:271).
+//       CG there; assigned to system.linear_solver before equation_systems.solve()
+//       (fem-shell.cpp:138; fem-shell_precice.cpp:271).  The binding selects the multigrid
+//       preconditioner unless FEMSHELL_PC says otherwise: equation_systems.solve() passes libMesh's
+//       "linear solver tolerance" / "maximum iterations" (fem-shell.cpp:130-133 leaves them at the
+//       library defaults, tight tolerance and 5000 iterations as far as the survey could tell), and
+//       6x6 block-Jacobi CG needs 5010 iterations for 1e-12 on the reference's own 64x64 Test-G-family
+//       panel (run_examples.sh:47-48) -- the multigrid 60.  get_converged_reason() reports what
+//       femshell_solve_info says, DIVERGED_ITS when the iteration limit was hit.
 #pragma once
 
 #ifdef FEMSHELL_HAVE_LIBMESH
 
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "femshell.h"
@@ -44,6 +52,8 @@ struct Binding {
     bool mesh_sent = false;
     bool compat_copy_back = true; // add K,F into libMesh's matrix/rhs after the device assembly
     EquationSystems *es = nullptr; // set by the assembly callback; the solver hook maps node dofs through it
+    femshell_solve_info last_info{}; // of the last FemShellLinearSolver::solve
+    int last_rc = FEMSHELL_OK;
 };
 inline Binding &binding()
 {
@@ -71,6 +81,11 @@ inline void send_mesh(EquationSystems &es)
         cfg.rank = (int32_t)mesh.processor_id();
         cfg.world_size = (int32_t)mesh.n_processors();
         check(femshell_create(&cfg, &b.ctx));
+        if (!std::getenv("FEMSHELL_PC")) { // (femshell_create has applied FEMSHELL_PC=amg|jacobi when it is set)
+            femshell_pc_options pc;
+            check(femshell_pc_defaults(FEMSHELL_PC_AMG, &pc));
+            check(femshell_set_preconditioner(b.ctx, &pc));
+        }
         if (cfg.world_size > 1) {
             // mpirun -n N (Test G, run_examples.sh:47-48): one GPU per MPI rank; rank 0 creates the RCCL id, libMesh's
             // communicator distributes it (replaces LibMeshInit's MPI setup for the device path, fem-shell.cpp:28, 35)
@@ -163,7 +178,12 @@ class FemShellLinearSolver : public LinearSolver<Number> {
         const MeshBase &mesh = b.es->get_mesh();
         const unsigned sys = b.es->get_system<LinearImplicitSystem>("Elasticity").number();
         std::vector<double> u(6 * (size_t)mesh.n_nodes());
-        check(femshell_solve(b.ctx, tol, (int32_t)m_its, u.data(), &info)); // full vector on every rank, 6*node+var
+        b.last_rc = femshell_solve(b.ctx, tol, (int32_t)m_its, u.data(), &info); // full vector on every rank, 6*node+var
+        b.last_info = info;
+        // a breakdown (K or the preconditioner not positive definite) is a solver outcome libMesh asks about through
+        // get_converged_reason(), like PETSc's KSP_DIVERGED_BREAKDOWN; every other failure is an error
+        if (b.last_rc == FEMSHELL_ERR_BREAKDOWN) return {(unsigned)info.iterations, info.rel_residual};
+        check(b.last_rc);
         // libMesh numbers dofs per processor and (by default) variable-major: go through dof_number(), like the
         // reference does when it reads the solution back (fem-shell.cpp:163-169); each rank sets the dofs it owns
         for (const Node *nd : mesh.local_node_ptr_range())
@@ -186,8 +206,21 @@ class FemShellLinearSolver : public LinearSolver<Number> {
     {
         libmesh_not_implemented();
     }
-    void print_converged_reason() const override {}
-    LinearConvergenceReason get_converged_reason() const override { return CONVERGED_RTOL_NORMAL; }
+    void print_converged_reason() const override
+    {
+        const Binding &b = binding();
+        const LinearConvergenceReason r = get_converged_reason();
+        std::printf("FemShellLinearSolver: %s after %d iterations, ||r||/||b|| = %.3e (%s, estimated relative error %.1e)\n",
+                    r == CONVERGED_RTOL_NORMAL ? "converged" : r == DIVERGED_ITS ? "iteration limit reached" : "breakdown",
+                    (int)b.last_info.iterations, b.last_info.rel_residual,
+                    b.last_info.pc_type == FEMSHELL_PC_AMG ? "multigrid" : "block-Jacobi", b.last_info.error_estimate);
+    }
+    LinearConvergenceReason get_converged_reason() const override
+    {
+        const Binding &b = binding();
+        if (b.last_rc == FEMSHELL_ERR_BREAKDOWN) return DIVERGED_BREAKDOWN;
+        return b.last_info.converged == 1 ? CONVERGED_RTOL_NORMAL : DIVERGED_ITS;
+    }
 };
 
 } // namespace femshell_libmesh

@@ -2,7 +2,9 @@
 #include "mesh_io.hpp"
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <set>
 #include <sstream>
@@ -125,6 +127,16 @@ ShellMesh read_xda(const std::string &path)
                                      " of an element with " + std::to_string(m.element_nodes(bc.elem).size()) + " sides");
         m.bcs.push_back(bc);
     }
+    if (L[0].rfind("libMesh-0.9.2+", 0) == 0 && pos < L.size() && !L[pos].empty() && L[pos].find_first_not_of(" \t\r") != std::string::npos) {
+        const long n_ns = std::stol(L[pos++]); // nodesets: (node, boundary id)
+        for (long b = 0; b < n_ns && pos < L.size(); b++, pos++) {
+            std::istringstream is(L[pos]);
+            int32_t node, id;
+            is >> node >> id;
+            if (!is || node < 0 || node >= n_nodes) throw std::runtime_error(path + ": bad nodeset line " + std::to_string(b));
+            m.node_bcs.push_back({node, id});
+        }
+    }
     m.loads.assign((size_t)n_nodes * 6, 0.0);
     return m;
 }
@@ -191,25 +203,36 @@ ShellMesh read_msh(const std::string &path)
         }
     }
     if (!have_nodes || !have_elems || m.order.empty()) throw std::runtime_error(path + ": no $Nodes / $Elements with triangles or quadrangles");
-    // lower-dimensional elements -> boundary conditions
+    // lower-dimensional elements -> boundary conditions.  Sides are looked up through one table of (min node, max node)
+    // -> (element, side), first element in file order wins: a scan over all elements per boundary line is quadratic
+    // (1e10 steps on a 4M-triangle mesh with its ~6000 boundary lines); libMesh's GmshIO goes through a node-to-element map too
     const int32_t n_elem = (int32_t)m.order.size();
+    struct SideRef { int64_t key; int32_t elem, side; };
+    std::vector<SideRef> sides;
+    if (std::any_of(lows.begin(), lows.end(), [](const Low &l) { return l.nn == 2; })) {
+        sides.reserve((size_t)m.n_tri() * 3 + (size_t)m.n_quad() * 4);
+        for (int32_t e = 0; e < n_elem; e++) {
+            const bool t = m.order[(size_t)e].first == 't';
+            const int32_t *nd = t ? &m.tri[3 * (size_t)m.order[(size_t)e].second] : &m.quad[4 * (size_t)m.order[(size_t)e].second];
+            const int nn = t ? 3 : 4;
+            for (int sd = 0; sd < nn; sd++) {
+                const int64_t a = nd[sd], b = nd[(sd + 1) % nn];
+                sides.push_back({(std::min(a, b) << 32) | std::max(a, b), e, sd});
+            }
+        }
+        std::sort(sides.begin(), sides.end(), [](const SideRef &x, const SideRef &y) {
+            return x.key != y.key ? x.key < y.key : (x.elem != y.elem ? x.elem < y.elem : x.side < y.side);
+        });
+    }
     for (const Low &l : lows) {
         if (l.nn == 1) {
             m.node_bcs.push_back({l.n[0], l.id});
             continue;
         }
-        bool found = false;
-        for (int32_t e = 0; e < n_elem && !found; e++) {
-            const std::vector<int32_t> nd = m.element_nodes(e);
-            for (size_t s = 0; s < nd.size() && !found; s++) {
-                const int32_t a = nd[s], b = nd[(s + 1) % nd.size()];
-                if ((a == l.n[0] && b == l.n[1]) || (a == l.n[1] && b == l.n[0])) {
-                    m.bcs.push_back({e, (int32_t)s, l.id});
-                    found = true;
-                }
-            }
-        }
-        if (!found) throw std::runtime_error(path + ": a boundary line is not a side of any element");
+        const int64_t a = l.n[0], b = l.n[1], key = (std::min(a, b) << 32) | std::max(a, b);
+        auto it = std::lower_bound(sides.begin(), sides.end(), key, [](const SideRef &x, int64_t k) { return x.key < k; });
+        if (it == sides.end() || it->key != key) throw std::runtime_error(path + ": a boundary line is not a side of any element");
+        m.bcs.push_back({it->elem, it->side, l.id});
     }
     m.loads.assign((size_t)m.n_nodes() * 6, 0.0);
     return m;
@@ -219,10 +242,177 @@ ShellMesh read_mesh(const std::string &path)
 {
     auto ends_with = [&](const char *ext) { const std::string e(ext); return path.size() >= e.size() && path.compare(path.size() - e.size(), e.size(), e) == 0; };
     if (ends_with(".msh")) return read_msh(path);
-    if (ends_with(".xdr"))
-        throw std::runtime_error(path + ": binary XDR meshes need libMesh's XDR codec, which this program does not carry; "
-                                        "convert to ASCII XDA (libMesh meshtool) or Gmsh .msh");
+    if (ends_with(".xdr")) return read_xdr(path);
     return read_xda(path);
+}
+
+// ---- binary XDR: the records of the XDA file in Sun XDR encoding (RFC 4506) -----------------------------------------
+// libMesh's XdrIO writes the same sequence of fields to both formats (mesh.read() picks the codec by extension,
+// fem-shell.cpp:35-37); in the binary one every integer is a big-endian 32-bit word, every coordinate a big-endian
+// IEEE double, a string its length as a 32-bit word followed by the bytes padded with zeros to a multiple of four,
+// and the comments of the ASCII file ("# number of elements") do not exist.  No libMesh exists in this image to
+// produce such a file, so the reader is tested against write_xdr below (round trip with the XDA reader), not against a
+// file libMesh wrote: format parity with libMesh's own writer is unpinned.
+namespace {
+
+struct XdrIn {
+    std::ifstream in;
+    std::string path;
+    explicit XdrIn(const std::string &p) : in(p, std::ios::binary), path(p)
+    {
+        if (!in) throw std::runtime_error("cannot open " + p);
+    }
+    void bytes(void *dst, size_t n)
+    {
+        in.read(static_cast<char *>(dst), (std::streamsize)n);
+        if ((size_t)in.gcount() != n) throw std::runtime_error(path + ": truncated XDR file");
+    }
+    uint32_t u32()
+    {
+        unsigned char b[4];
+        bytes(b, 4);
+        return ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | (uint32_t)b[3];
+    }
+    double f64()
+    {
+        unsigned char b[8];
+        bytes(b, 8);
+        uint64_t v = 0;
+        for (int i = 0; i < 8; i++) v = (v << 8) | b[i];
+        double d;
+        std::memcpy(&d, &v, 8);
+        return d;
+    }
+    std::string str()
+    {
+        const uint32_t n = u32();
+        if (n > 4096) throw std::runtime_error(path + ": implausible string length in XDR header (not an XDR mesh file?)");
+        std::string s((size_t)((n + 3u) & ~3u), '\0');
+        if (!s.empty()) bytes(&s[0], s.size());
+        s.resize(n);
+        return s;
+    }
+};
+
+struct XdrOut {
+    std::ofstream os;
+    explicit XdrOut(const std::string &p) : os(p, std::ios::binary)
+    {
+        if (!os) throw std::runtime_error("cannot write " + p);
+    }
+    void u32(uint32_t v)
+    {
+        const unsigned char b[4] = {(unsigned char)(v >> 24), (unsigned char)(v >> 16), (unsigned char)(v >> 8), (unsigned char)v};
+        os.write(reinterpret_cast<const char *>(b), 4);
+    }
+    void f64(double d)
+    {
+        uint64_t v;
+        std::memcpy(&v, &d, 8);
+        unsigned char b[8];
+        for (int i = 7; i >= 0; i--, v >>= 8) b[i] = (unsigned char)v;
+        os.write(reinterpret_cast<const char *>(b), 8);
+    }
+    void str(const std::string &s)
+    {
+        u32((uint32_t)s.size());
+        os.write(s.data(), (std::streamsize)s.size());
+        static const char zeros[4] = {0, 0, 0, 0};
+        os.write(zeros, (std::streamsize)(((s.size() + 3) & ~(size_t)3) - s.size()));
+    }
+};
+
+} // namespace
+
+ShellMesh read_xdr(const std::string &path)
+{
+    XdrIn x(path);
+    const std::string version = x.str();
+    if (version.rfind("libMesh-0.7.0+", 0) != 0 && version.rfind("libMesh-0.9.2+", 0) != 0)
+        throw std::runtime_error(path + ": XDR header \"" + version + "\" is not one this reader knows (libMesh-0.7.0+, libMesh-0.9.2+: 32-bit fields)");
+    const bool nodesets = version.rfind("libMesh-0.9.2+", 0) == 0;
+    const uint32_t n_elem = x.u32(), n_nodes = x.u32();
+    const std::string bc_file = x.str(), subdomain_file = x.str(), partition_file = x.str(), plevel_file = x.str();
+    if (subdomain_file != "n/a" || partition_file != "n/a" || plevel_file != "n/a")
+        throw std::runtime_error(path + ": subdomain / processor / p-level records are not supported (the reference's meshes carry none)");
+    const uint32_t n_level0 = x.u32();
+    if (n_level0 != n_elem) throw std::runtime_error(path + ": refined meshes (elements above level 0) are not supported");
+    ShellMesh m;
+    for (uint32_t e = 0; e < n_elem; e++) {
+        const uint32_t type = x.u32();
+        if (type == 3) {
+            m.order.push_back({'t', m.n_tri()});
+            for (int k = 0; k < 3; k++) m.tri.push_back((int32_t)x.u32());
+        } else if (type == 5) {
+            m.order.push_back({'q', m.n_quad()});
+            for (int k = 0; k < 4; k++) m.quad.push_back((int32_t)x.u32());
+        } else {
+            throw std::runtime_error(path + ": unsupported element type " + std::to_string(type) + " (only TRI3 = 3 and QUAD4 = 5)");
+        }
+    }
+    for (int32_t v : m.tri)
+        if (v < 0 || (uint32_t)v >= n_nodes) throw std::runtime_error(path + ": element references a node out of range");
+    for (int32_t v : m.quad)
+        if (v < 0 || (uint32_t)v >= n_nodes) throw std::runtime_error(path + ": element references a node out of range");
+    m.xyz.resize((size_t)n_nodes * 3);
+    for (double &c : m.xyz) c = x.f64();
+    if (bc_file == ".") { // the boundary conditions follow in this file
+        const uint32_t n_bc = x.u32();
+        for (uint32_t b = 0; b < n_bc; b++) {
+            SideBC bc;
+            bc.elem = (int32_t)x.u32();
+            bc.side = (int32_t)x.u32();
+            bc.id = (int32_t)x.u32();
+            if (bc.elem < 0 || (uint32_t)bc.elem >= n_elem) throw std::runtime_error(path + ": boundary element out of range");
+            if (bc.side < 0 || bc.side >= (int32_t)m.element_nodes(bc.elem).size())
+                throw std::runtime_error(path + ": boundary record " + std::to_string(b) + " names a side the element does not have");
+            m.bcs.push_back(bc);
+        }
+        if (nodesets) {
+            const uint32_t n_ns = x.u32();
+            for (uint32_t b = 0; b < n_ns; b++) {
+                const int32_t node = (int32_t)x.u32(), id = (int32_t)x.u32();
+                if (node < 0 || (uint32_t)node >= n_nodes) throw std::runtime_error(path + ": nodeset node out of range");
+                m.node_bcs.push_back({node, id});
+            }
+        }
+    }
+    m.loads.assign((size_t)n_nodes * 6, 0.0);
+    return m;
+}
+
+void write_xdr(const ShellMesh &m, const std::string &path)
+{
+    XdrOut o(path);
+    const uint32_t n_elem = (uint32_t)(m.n_tri() + m.n_quad());
+    o.str(m.node_bcs.empty() ? "libMesh-0.7.0+" : "libMesh-0.9.2+");
+    o.u32(n_elem);
+    o.u32((uint32_t)m.n_nodes());
+    o.str(".");
+    o.str("n/a");
+    o.str("n/a");
+    o.str("n/a");
+    o.u32(n_elem);
+    for (uint32_t e = 0; e < n_elem; e++) {
+        const std::vector<int32_t> nd = m.element_nodes((int32_t)e);
+        o.u32(nd.size() == 3 ? 3u : 5u);
+        for (int32_t v : nd) o.u32((uint32_t)v);
+    }
+    for (double c : m.xyz) o.f64(c);
+    o.u32((uint32_t)m.bcs.size());
+    for (const SideBC &b : m.bcs) {
+        o.u32((uint32_t)b.elem);
+        o.u32((uint32_t)b.side);
+        o.u32((uint32_t)b.id);
+    }
+    if (!m.node_bcs.empty()) {
+        o.u32((uint32_t)m.node_bcs.size());
+        for (const auto &nb : m.node_bcs) {
+            o.u32((uint32_t)nb.first);
+            o.u32((uint32_t)nb.second);
+        }
+    }
+    if (!o.os) throw std::runtime_error("cannot write " + path);
 }
 
 std::string force_file_name(const std::string &mesh_path)
@@ -259,7 +449,9 @@ void write_xda(const ShellMesh &m, const std::string &path, int precision)
     if (!os) throw std::runtime_error("cannot write " + path);
     os.precision(precision);
     const long n_elem = m.n_tri() + m.n_quad();
-    os << "libMesh-0.7.0+\n";
+    // (node boundary ids -- Gmsh point elements -- need the nodeset record libMesh added with the 0.9.2+ header; files
+    //  without them keep the header and bytes of the reference's generator)
+    os << (m.node_bcs.empty() ? "libMesh-0.7.0+\n" : "libMesh-0.9.2+\n");
     os << n_elem << "      # number of elements\n";
     os << m.n_nodes() << "      # number of nodes\n";
     os << ".        # boundary condition specification file\n";
@@ -276,6 +468,10 @@ void write_xda(const ShellMesh &m, const std::string &path, int precision)
     for (int32_t n = 0; n < m.n_nodes(); n++) os << m.xyz[3 * n] << " " << m.xyz[3 * n + 1] << " " << m.xyz[3 * n + 2] << "\n";
     os << m.bcs.size() << "        # number of boundary conditions\n";
     for (const SideBC &b : m.bcs) os << b.elem << " " << b.side << " " << b.id << "\n";
+    if (!m.node_bcs.empty()) {
+        os << m.node_bcs.size() << "        # number of nodesets\n";
+        for (const auto &nb : m.node_bcs) os << nb.first << " " << nb.second << "\n";
+    }
 }
 
 ShellMesh generate_structured(const MeshGenArgs &a)

@@ -50,8 +50,13 @@ ShellMesh read_xda(const std::string &path);
 // quadrangles (type 3) are the mesh; lower-dimensional elements define boundary conditions through their first tag
 // (the physical entity): 2-node lines (type 1) flag the element side they coincide with, points (type 15) the node.
 ShellMesh read_msh(const std::string &path);
-// what mesh.read(in_filename) does for the formats the reference program documents (fem-shell.cpp:37, :203): *.xda and
-// *.msh are read; the binary *.xdr needs libMesh's XDR codec and is refused with a message that says so
+// binary XDR form of the XDA records (fem-shell.cpp:35-37, :203: "*.xda/*.xdr"): big-endian 32-bit integers and IEEE
+// doubles, length-prefixed padded strings, headers libMesh-0.7.0+ and libMesh-0.9.2+ (the latter adds nodesets).
+// write_xdr is the writer the round-trip test uses; no libMesh-written file exists here to pin the layout (mesh_io.cpp)
+ShellMesh read_xdr(const std::string &path);
+void write_xdr(const ShellMesh &m, const std::string &path);
+// what mesh.read(in_filename) does for the formats the reference program documents (fem-shell.cpp:37, :203): *.xda,
+// *.xdr and *.msh, chosen by extension
 ShellMesh read_mesh(const std::string &path);
 // Reads "<n> <factor> n x 6"; rows missing at the end stay zero (the reference's stream
 // extraction leaves them zero, fem-shell.cpp:59-66).  Returns n_nodes x 6, scaled.

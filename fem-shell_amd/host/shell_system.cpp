@@ -10,6 +10,10 @@
 #include <stdexcept>
 #include <thread>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <time.h>
 #include <unistd.h>
 
 namespace femshell_host {
@@ -105,10 +109,16 @@ bool read_parameters(int argc, char **argv, Parameters &p, std::ostream &out, st
     }
     if (const char *v = arg_after(argc, argv, "-pc_type")) {
         p.pc_type = v;
-        static const char *known[] = {"jacobi", "bjacobi", "pbjacobi", "none", "gamg", "amg", "ml", "hypre", "mg"};
+        static const char *known[] = {"jacobi", "bjacobi", "pbjacobi", "gamg", "amg", "ml", "hypre", "mg"};
         bool ok = false;
         for (const char *k : known) ok = ok || p.pc_type == k;
-        if (!ok) {
+        if (p.pc_type == "none" || p.pc_type == "ilu" || p.pc_type == "icc" || p.pc_type == "sor" || p.pc_type == "asm" || p.pc_type == "lu") {
+            // PETSc's own defaults (ilu serial, bjacobi + ilu parallel) and other host-side preconditioners: handled like an
+            // unavailable -ksp_type -- say what runs instead, do not fail
+            err << "NOTE: -pc_type " << p.pc_type << " is not available on the GPU; using the 6x6 block-Jacobi preconditioner"
+                << " (-pc_type gamg selects the multigrid)\n";
+            p.pc_type = "pbjacobi";
+        } else if (!ok) {
             err << "ERROR: -pc_type " << p.pc_type << " is not available (jacobi|bjacobi|pbjacobi -> 6x6 block-Jacobi, gamg|amg|ml|hypre|mg -> multigrid)\n";
             failed = true;
         }
@@ -147,36 +157,82 @@ Launch Launch::from_environment()
     l.rank = env_int({"FEMSHELL_RANK", "RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK"}, 0);
     l.world_size = env_int({"FEMSHELL_WORLD_SIZE", "WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE"}, 1);
     l.device = env_int({"FEMSHELL_DEVICE", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK"}, -1);
+    if (std::getenv("FEMSHELL_SINGLE") && std::atoi(std::getenv("FEMSHELL_SINGLE")) == 1) { // ignore a launcher's RANK / WORLD_SIZE
+        l.rank = 0;
+        l.world_size = 1;
+    }
     if (const char *f = std::getenv("FEMSHELL_UID_FILE")) l.uid_file = f;
     else {
+        // per-user directory, not a name in /tmp anyone can squat: $XDG_RUNTIME_DIR, else /tmp/femshell-<uid> (0700, ours)
+        std::string dir;
+        if (const char *x = std::getenv("XDG_RUNTIME_DIR")) dir = x;
+        if (dir.empty()) {
+            dir = "/tmp/femshell-" + std::to_string((long)getuid());
+            (void)mkdir(dir.c_str(), 0700);
+            struct stat st;
+            if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 077) != 0)
+                throw std::runtime_error("launch environment: " + dir + " is not a private directory of this user (set FEMSHELL_UID_FILE)");
+        }
         const char *port = std::getenv("MASTER_PORT");
-        l.uid_file = "/tmp/femshell_uid_" + (port ? std::string(port) : std::to_string((long)getppid()));
+        l.uid_file = dir + "/femshell_uid_" + (port ? std::string(port) : std::to_string((long)getppid()));
     }
     if (l.world_size < 1 || l.rank < 0 || l.rank >= l.world_size) throw std::runtime_error("launch environment: invalid rank / world size");
+    if (l.world_size > 1) // a launcher's generic RANK / WORLD_SIZE turn a plain run into rank k of N: say so
+        std::cerr << "fem-shell: rank " << l.rank << " of " << l.world_size << " (from the launch environment; RCCL id through " << l.uid_file
+                  << "; FEMSHELL_SINGLE=1 runs single-process regardless)" << std::endl;
     return l;
 }
+
+namespace {
+
+// The RCCL id travels through a file: 8 bytes of magic, then the 128-byte id.  Rank 0 removes whatever an earlier run
+// left under the name, writes a temporary created with O_EXCL | O_NOFOLLOW and renames it into place; the others accept
+// only a regular file of this user that is not older than a minute before their own start (a crashed run's leftover).
+constexpr char kUidMagic[8] = {'F', 'S', 'H', 'L', 'U', 'I', 'D', '1'};
+
+void publish_uid(const std::string &path, const unsigned char id[128])
+{
+    (void)unlink(path.c_str());
+    const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+    (void)unlink(tmp.c_str());
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) throw std::runtime_error("cannot create " + tmp);
+    const bool ok = write(fd, kUidMagic, 8) == 8 && write(fd, id, 128) == 128;
+    (void)close(fd);
+    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) {
+        (void)unlink(tmp.c_str());
+        throw std::runtime_error("cannot publish " + path);
+    }
+}
+
+bool read_uid(const std::string &path, time_t not_before, unsigned char id[128])
+{
+    const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return false;
+    struct stat st;
+    char magic[8];
+    const bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == getuid() && st.st_mtime >= not_before &&
+                    read(fd, magic, 8) == 8 && std::memcmp(magic, kUidMagic, 8) == 0 && read(fd, id, 128) == 128;
+    (void)close(fd);
+    return ok;
+}
+
+} // namespace
 
 ShellSystem::ShellSystem(const Parameters &p, const Launch &launch, unsigned flags)
     : ShellSystem(p, launch.device, launch.rank, launch.world_size, flags)
 {
     if (launch.world_size > 1) {
         unsigned char id[128];
-        const std::string tmp = launch.uid_file + ".tmp";
+        const time_t started = time(nullptr);
         if (launch.rank == 0) {
             check(femshell_comm_unique_id(id), "femshell_comm_unique_id");
-            {
-                std::ofstream os(tmp, std::ios::binary);
-                os.write(reinterpret_cast<const char *>(id), 128);
-                if (!os) throw std::runtime_error("cannot write " + tmp);
-            }
-            if (std::rename(tmp.c_str(), launch.uid_file.c_str()) != 0) throw std::runtime_error("cannot publish " + launch.uid_file);
+            publish_uid(launch.uid_file, id);
         } else {
             const auto t0 = std::chrono::steady_clock::now();
-            for (;;) {
-                std::ifstream is(launch.uid_file, std::ios::binary);
-                if (is && is.read(reinterpret_cast<char *>(id), 128) && is.gcount() == 128) break;
+            while (!read_uid(launch.uid_file, started - 60, id)) {
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
-                    throw std::runtime_error("rank " + std::to_string(launch.rank) + ": no RCCL id in " + launch.uid_file + " after 120 s");
+                    throw std::runtime_error("rank " + std::to_string(launch.rank) + ": no fresh RCCL id in " + launch.uid_file + " after 120 s");
                 std::this_thread::sleep_for(std::chrono::milliseconds(10));
             }
         }

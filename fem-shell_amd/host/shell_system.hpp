@@ -51,7 +51,7 @@ struct Parameters {
 // One process per GPU.  How a rank learns its place: FEMSHELL_RANK / FEMSHELL_WORLD_SIZE, else the
 // launcher's variables (torchrun: RANK / WORLD_SIZE / LOCAL_RANK; Open MPI: OMPI_COMM_WORLD_*; MPICH/Slurm: PMI_RANK /
 // PMI_SIZE), else a single rank.  The 128-byte RCCL id travels through a file: rank 0 writes FEMSHELL_UID_FILE
-// (default: /tmp/femshell_uid_<MASTER_PORT or parent pid>), the others wait for it -- the role MPI plays for the
+// (default: $XDG_RUNTIME_DIR or /tmp/femshell-<uid>, 0700, file femshell_uid_<MASTER_PORT or parent pid>), the others wait for it -- the role MPI plays for the
 // reference (LibMeshInit, fem-shell.cpp:28).
 struct Launch {
     int rank = 0, world_size = 1, device = -1;

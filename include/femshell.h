@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FEMSHELL_VERSION 1
+#define FEMSHELL_VERSION 2
 
 typedef enum femshell_status {
     FEMSHELL_OK = 0,
@@ -114,6 +114,16 @@ typedef struct femshell_solve_info {
     int32_t amg_levels;     /* levels of the multigrid hierarchy (0 with block-Jacobi) */
     double pc_setup_seconds;/* host + device time of the multigrid setup done inside this call (0 if reused) */
     double operator_complexity; /* sum of the level matrices' blocks / blocks of K (0 with block-Jacobi) */
+    /* error estimate of the multigrid-preconditioned solve (version 2 of this struct; -1 / 0 when no refinement pass ran):
+     * a refinement pass solves K e = b - K x (residual in double-double) and adds e, so ||e||/||x|| of the last pass
+     * measures the relative displacement error of the iterate BEFORE that pass, and the pass leaves behind about
+     * that times the factor by which it reduced the residual of its correction equation.  Checked against manufactured
+     * solutions at the 4M-triangle sizes (tests/test_gpu_fullsize.py, bench.py time_to_solution.manufactured). */
+    int32_t refine_passes_done;       /* refinement passes that ran (<= femshell_pc_options::refine_passes) */
+    int32_t reserved0;
+    double refine_correction_rel;     /* ||e||_2 / ||x||_2 of the last pass */
+    double refine_residual_reduction; /* ||rhs - K e|| / ||rhs|| (recurrence) the last pass stopped at */
+    double error_estimate;            /* refine_correction_rel * refine_residual_reduction: estimated relative error of u */
 } femshell_solve_info;
 
 /* ---- preconditioner ------------------------------------------------------------------
@@ -137,10 +147,14 @@ typedef struct femshell_pc_options {
     int32_t coarse_degree;   /* Chebyshev degree on the coarser levels (default 4) */
     int32_t coarsest_nodes;  /* coarsening stops at this many nodes; dense inverse there (default 200) */
     int32_t max_levels;      /* default 12 */
-    int32_t refine_passes;   /* iterative refinement after convergence: the residual of the iterate is evaluated in
-                                double-double and the correction equation solved by the same method (default 1; 0 = off).
-                                Plain FP64 CG stalls at a displacement error of kappa*eps -- 2e-10 on the 250k-triangle
-                                roof -- one pass brings it to 1e-13 */
+    int32_t refine_passes;   /* iterative refinement after convergence, at most this many passes (default 1; 0 = off):
+                                the residual of the iterate is evaluated in double-double and the correction equation
+                                solved by the same method to a drop of 1e-4, whatever rtol is -- rtol bounds the
+                                residual, and on these systems the displacement error sits one to two decades above
+                                it (4M triangles, manufactured solution: 4e-9 at a residual of 9e-11 ||b||).  The
+                                first pass always runs, further ones while femshell_solve_info::error_estimate
+                                exceeds rtol.  Plain FP64 CG stalls at a displacement error of kappa*eps -- 2e-10 on the
+                                250k-triangle roof -- one pass brings it to 1e-13 */
     int32_t reserved;
     double eig_ratio;        /* the smoother targets [lambda_max/eig_ratio, lambda_max] of D^-1 A (default 30) */
 } femshell_pc_options;

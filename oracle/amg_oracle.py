@@ -335,19 +335,22 @@ def residual_extended(A, b, x):
 
 
 def solve(A, b, levels, kcycle=True, rtol=1e-10, max_it=1000, refine_passes=0):
-    """Flexible PCG around the cycle, then `refine_passes` steps of iterative refinement: residual of the iterate in
-    extended precision, correction equation solved by the same method until its residual has dropped by 1e-4 (or to the
-    tolerance of the solve, whichever comes first), x += e."""
+    """Flexible PCG around the cycle, then at most `refine_passes` steps of iterative refinement: residual of the
+    iterate in extended precision, correction equation solved by the same method until its residual has dropped by 1e-4,
+    x += e.  ||e|| / ||x|| times that drop estimates the error the pass leaves; passes after the first run while the
+    estimate exceeds rtol (csrc/amg_solve.cpp cg_amg)."""
     M = lambda r: cycle(levels, 0, r, kcycle)  # noqa: E731
     x, hist = flexible_pcg(A, b, M, rtol, max_it)
     nb = np.linalg.norm(b)
-    for _ in range(refine_passes):
+    est = None
+    for k in range(refine_passes):
         r = residual_extended(A, b, x)
         nr = np.linalg.norm(r)
-        if nr <= rtol * nb:
+        if nr == 0.0 or len(hist) >= max_it or (k >= 1 and est <= rtol):
             break
         # the correction needs four digits, not the full tolerance again (csrc/kernels.hip: kRefineDrop)
-        e, h = flexible_pcg(A, r, M, max(rtol * nb / nr, 1.0e-4), max_it - len(hist))
+        e, h = flexible_pcg(A, r, M, 1.0e-4, max_it - len(hist))
         hist = hist + [v * nr / nb for v in h]
+        est = np.linalg.norm(e) / np.linalg.norm(x) * (h[-1] if h else 1.0)
         x = x + e
     return x, hist

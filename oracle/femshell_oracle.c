@@ -716,9 +716,14 @@ static void scatter_element(int nodes, const int32_t *conn, const double *Kg, co
  * (elements on a range boundary are computed by both neighbours: no write is shared between threads) */
 static int assemble_rows(int32_t n0, int32_t n1, const double *xyz, int32_t n_tri, const int32_t *tri, int32_t n_quad,
                          const int32_t *quad, const fso_material *mat, const double *Dm, const double *Dp,
-                         const uint8_t *dirichlet, const int32_t *rowptr, const int32_t *colidx, double *vals)
+                         const uint8_t *dirichlet, const int32_t *rowptr, const int32_t *colidx, double *vals,
+                         const int32_t *tri_list, int64_t n_tri_list, const int32_t *quad_list, int64_t n_quad_list)
 {
-    for (int32_t e = 0; e < n_tri; e++) {
+    /* tri_list / quad_list: the elements touching a node of [n0,n1), ascending (the element partition of a thread,
+     * built once per mesh like libMesh's local element ranges); NULL: scan all elements */
+    const int64_t nt_loop = tri_list ? n_tri_list : n_tri;
+    for (int64_t le = 0; le < nt_loop; le++) {
+        const int32_t e = tri_list ? tri_list[le] : (int32_t)le;
         const int32_t *c = tri + 3 * (int64_t)e;
         int mine = 0;
         for (int i = 0; i < 3; i++) mine |= (c[i] >= n0 && c[i] < n1);
@@ -730,7 +735,9 @@ static int assemble_rows(int32_t n0, int32_t n1, const double *xyz, int32_t n_tr
         constrain_element(3, c, dirichlet, Kg);
         scatter_element(3, c, Kg, rowptr, colidx, vals, n0, n1);
     }
-    for (int32_t e = 0; e < n_quad; e++) {
+    const int64_t nq_loop = quad_list ? n_quad_list : n_quad;
+    for (int64_t le = 0; le < nq_loop; le++) {
+        const int32_t e = quad_list ? quad_list[le] : (int32_t)le;
         const int32_t *c = quad + 4 * (int64_t)e;
         int mine = 0;
         for (int i = 0; i < 4; i++) mine |= (c[i] >= n0 && c[i] < n1);
@@ -757,6 +764,87 @@ void fso_set_threads(int n)
 }
 int fso_threads(void) { return g_threads; }
 
+/* Element lists of the threads' node ranges [n_nodes t/nt, n_nodes (t+1)/nt): an element belongs to every range that owns
+ * one of its nodes.  Built once per (mesh, thread count) and kept: the threaded baseline's counterpart of the local element
+ * ranges libMesh hands each MPI rank after partitioning (assemble_elasticity iterates active_local_elements, SA:1180). */
+static struct {
+    const int32_t *tri, *quad;
+    int32_t n_tri, n_quad, n_nodes;
+    int nt;
+    uint64_t hash;
+    int64_t *tptr, *qptr; /* nt + 1 */
+    int32_t *tlist, *qlist;
+} g_own = {0};
+
+static int owner_of(int32_t node, int32_t n_nodes, int nt)
+{
+    int t = (int)(((int64_t)node * nt) / n_nodes);
+    /* (n0 = n_nodes t / nt rounds down: step to the range that holds the node) */
+    while (t + 1 < nt && node >= (int32_t)((int64_t)n_nodes * (t + 1) / nt)) t++;
+    while (t > 0 && node < (int32_t)((int64_t)n_nodes * t / nt)) t--;
+    return t;
+}
+
+static void build_lists(int nodes_per, int32_t n_el, const int32_t *conn, int32_t n_nodes, int nt, int64_t **ptr_out,
+                        int32_t **list_out)
+{
+    int64_t *ptr = (int64_t *)calloc((size_t)nt + 1, sizeof(int64_t));
+    int16_t *own = (int16_t *)malloc((size_t)(n_el ? n_el : 1) * 4 * sizeof(int16_t));
+#pragma omp parallel for schedule(static)
+    for (int32_t e = 0; e < n_el; e++) {
+        int16_t o[4] = {-1, -1, -1, -1};
+        int k = 0;
+        for (int i = 0; i < nodes_per; i++) {
+            const int16_t t = (int16_t)owner_of(conn[(int64_t)nodes_per * e + i], n_nodes, nt);
+            int seen = 0;
+            for (int j = 0; j < k; j++) seen |= (o[j] == t);
+            if (!seen) o[k++] = t;
+        }
+        for (int j = 0; j < 4; j++) own[4 * (int64_t)e + j] = o[j];
+    }
+    for (int32_t e = 0; e < n_el; e++)
+        for (int j = 0; j < 4 && own[4 * (int64_t)e + j] >= 0; j++) ptr[own[4 * (int64_t)e + j] + 1]++;
+    for (int t = 0; t < nt; t++) ptr[t + 1] += ptr[t];
+    int32_t *list = (int32_t *)malloc((size_t)(ptr[nt] ? ptr[nt] : 1) * sizeof(int32_t));
+    int64_t *fill = (int64_t *)malloc((size_t)nt * sizeof(int64_t));
+    memcpy(fill, ptr, (size_t)nt * sizeof(int64_t));
+    for (int32_t e = 0; e < n_el; e++)
+        for (int j = 0; j < 4 && own[4 * (int64_t)e + j] >= 0; j++) list[fill[own[4 * (int64_t)e + j]]++] = e;
+    free(fill);
+    free(own);
+    *ptr_out = ptr;
+    *list_out = list;
+}
+
+static uint64_t conn_hash(const int32_t *v, int64_t n)
+{
+    uint64_t h = 0;
+#pragma omp parallel for reduction(+ : h) schedule(static)
+    for (int64_t i = 0; i < n; i++) h += ((uint64_t)(uint32_t)v[i] + 0x9E3779B97F4A7C15ull) * (2 * (uint64_t)i + 1);
+    return h;
+}
+
+static void ownership_lists(int32_t n_nodes, int32_t n_tri, const int32_t *tri, int32_t n_quad, const int32_t *quad, int nt)
+{
+    /* (the hash guards against another mesh of the same size at the same address) */
+    const uint64_t h = conn_hash(tri, 3 * (int64_t)n_tri) ^ (conn_hash(quad, 4 * (int64_t)n_quad) << 1);
+    if (g_own.tptr && g_own.tri == tri && g_own.quad == quad && g_own.n_tri == n_tri && g_own.n_quad == n_quad &&
+        g_own.n_nodes == n_nodes && g_own.nt == nt && g_own.hash == h)
+        return;
+    g_own.hash = h;
+    free(g_own.tptr); free(g_own.qptr); free(g_own.tlist); free(g_own.qlist);
+    build_lists(3, n_tri, tri, n_nodes, nt, &g_own.tptr, &g_own.tlist);
+    build_lists(4, n_quad, quad, n_nodes, nt, &g_own.qptr, &g_own.qlist);
+    g_own.tri = tri; g_own.quad = quad; g_own.n_tri = n_tri; g_own.n_quad = n_quad; g_own.n_nodes = n_nodes; g_own.nt = nt;
+}
+
+/* forget the lists (the caller is about to free or rewrite the connectivity arrays they were built from) */
+void fso_drop_thread_lists(void)
+{
+    free(g_own.tptr); free(g_own.qptr); free(g_own.tlist); free(g_own.qlist);
+    memset(&g_own, 0, sizeof g_own);
+}
+
 int fso_assemble_bsr(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri,
                      int32_t n_quad, const int32_t *quad, const fso_material *mat,
                      const uint8_t *dirichlet, const double *loads, const int32_t *rowptr,
@@ -769,14 +857,18 @@ int fso_assemble_bsr(int32_t n_nodes, const double *xyz, int32_t n_tri, const in
     int rc = 0;
     if (nt <= 1) {
         memset(vals, 0, (size_t)rowptr[n_nodes] * 36 * sizeof(double));
-        rc = assemble_rows(0, n_nodes, xyz, n_tri, tri, n_quad, quad, mat, Dm, Dp, dirichlet, rowptr, colidx, vals);
+        rc = assemble_rows(0, n_nodes, xyz, n_tri, tri, n_quad, quad, mat, Dm, Dp, dirichlet, rowptr, colidx, vals, NULL, 0, NULL, 0);
     } else {
-        /* one contiguous node range per thread (the MPI ranks of the reference own contiguous dof ranges too) */
+        /* one contiguous node range per thread (the MPI ranks of the reference own contiguous dof ranges too) and the
+         * elements that touch it; a thread zeroes (first call: first-touches) and fills the rows of its own range */
+        ownership_lists(n_nodes, n_tri, tri, n_quad, quad, nt);
 #pragma omp parallel for schedule(static, 1)
         for (int t = 0; t < nt; t++) {
             const int32_t n0 = (int32_t)((int64_t)n_nodes * t / nt), n1 = (int32_t)((int64_t)n_nodes * (t + 1) / nt);
             memset(vals + 36 * (int64_t)rowptr[n0], 0, (size_t)(rowptr[n1] - rowptr[n0]) * 36 * sizeof(double));
-            const int r = assemble_rows(n0, n1, xyz, n_tri, tri, n_quad, quad, mat, Dm, Dp, dirichlet, rowptr, colidx, vals);
+            const int r = assemble_rows(n0, n1, xyz, n_tri, tri, n_quad, quad, mat, Dm, Dp, dirichlet, rowptr, colidx, vals,
+                                        g_own.tlist + g_own.tptr[t], g_own.tptr[t + 1] - g_own.tptr[t],
+                                        g_own.qlist + g_own.qptr[t], g_own.qptr[t + 1] - g_own.qptr[t]);
             if (r) {
 #pragma omp critical
                 rc = r;
@@ -785,12 +877,14 @@ int fso_assemble_bsr(int32_t n_nodes, const double *xyz, int32_t n_tri, const in
     }
     if (rc) return rc;
     /* SA:1118-1153: each node's load enters once; fixed dofs get rhs 0 (SA:1227) */
-    if (F)
+    if (F) {
+#pragma omp parallel for schedule(static)
         for (int32_t n = 0; n < n_nodes; n++)
             for (int v = 0; v < 6; v++) {
                 const int fixed = dirichlet && (dirichlet[n] & (1u << v));
                 F[6 * (int64_t)n + v] = (fixed || !loads) ? 0.0 : loads[6 * (int64_t)n + v];
             }
+    }
     return 0;
 }
 
@@ -864,28 +958,48 @@ int fso_pcg_block_jacobi(int32_t n_nodes, const int32_t *rowptr, const int32_t *
     double *p = (double *)malloc((size_t)n * sizeof(double));
     double *q = (double *)malloc((size_t)n * sizeof(double));
     int rc = 0;
-    for (int32_t a = 0; a < n_nodes && !rc; a++) {
+    /* every vector is first touched by the thread that streams its rows later (same static schedule over the node rows
+     * as fso_bsr_spmv and the vector loops below): on a multi-socket host the pages land on the right memory controller */
+#pragma omp parallel for schedule(static)
+    for (int32_t a = 0; a < n_nodes; a++) {
+        for (int i = 0; i < 6; i++) {
+            r[6 * (int64_t)a + i] = 0.0;
+            z[6 * (int64_t)a + i] = 0.0;
+            p[6 * (int64_t)a + i] = 0.0;
+            q[6 * (int64_t)a + i] = 0.0;
+        }
         const int64_t d = find_block(rowptr, colidx, a, a);
-        if (d < 0) { rc = -2; break; }
+        if (d < 0) {
+#pragma omp critical
+            if (!rc) rc = -2;
+            continue;
+        }
         memcpy(Minv + 36 * (int64_t)a, vals + 36 * d, 36 * sizeof(double));
-        if (inv6(Minv + 36 * (int64_t)a)) rc = -3;
+        if (inv6(Minv + 36 * (int64_t)a)) {
+#pragma omp critical
+            if (!rc) rc = -3;
+        }
     }
     fso_pcg_info res = {0, 0, 0.0, 0.0};
     if (!rc) {
         const double t0 = wall_seconds();
-        memset(x, 0, (size_t)n * sizeof(double));
-        memcpy(r, b, (size_t)n * sizeof(double));
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; i++) {
+            x[i] = 0.0;
+            r[i] = b[i];
+        }
         const double bnorm = sqrt(dot(n, b, b));
         if (bnorm == 0.0) {
             res.converged = 1;
         } else {
+#pragma omp parallel for schedule(static)
             for (int32_t a = 0; a < n_nodes; a++)
                 for (int i = 0; i < 6; i++) {
                     double s = 0.0;
                     for (int j = 0; j < 6; j++) s += Minv[36 * (int64_t)a + 6 * i + j] * r[6 * (int64_t)a + j];
                     z[6 * (int64_t)a + i] = s;
+                    p[6 * (int64_t)a + i] = s;
                 }
-            memcpy(p, z, (size_t)n * sizeof(double));
             double rz = dot(n, r, z);
             res.rel_residual = 1.0;
             for (int32_t it = 1; it <= max_it; it++) {
@@ -937,4 +1051,34 @@ double fso_time_assembly(int32_t n_nodes, const double *xyz, int32_t n_tri, cons
             return -1.0;
     const double dt = wall_seconds() - t0;
     return dt > 0.0 ? (double)n_tri * repeat / dt : 0.0;
+}
+
+/* STREAM triad a = b + s c on the host threads (arrays first touched by the threads that stream them), best of `reps`
+ * sweeps: the memory bandwidth the threaded baseline could reach, printed beside it by bench.py.  Returns GB/s counting
+ * 24 bytes per element (two reads, one write; write-allocate traffic not counted, as in STREAM). */
+double fso_stream_triad(int64_t n, int32_t reps)
+{
+    double *a = (double *)malloc((size_t)n * sizeof(double)), *b = (double *)malloc((size_t)n * sizeof(double)),
+           *c = (double *)malloc((size_t)n * sizeof(double));
+    if (!a || !b || !c) {
+        free(a); free(b); free(c);
+        return -1.0;
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        a[i] = 0.0;
+        b[i] = 1.0;
+        c[i] = 2.0;
+    }
+    double best = 0.0;
+    for (int32_t k = 0; k < reps; k++) {
+        const double t0 = wall_seconds();
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; i++) a[i] = b[i] + 3.0 * c[i];
+        const double dt = wall_seconds() - t0;
+        if (dt > 0.0 && 24.0 * (double)n / dt > best) best = 24.0 * (double)n / dt;
+    }
+    const double check = a[n / 2];
+    free(a); free(b); free(c);
+    return check == 7.0 ? best * 1e-9 : -1.0;
 }

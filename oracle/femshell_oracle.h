@@ -118,6 +118,12 @@ double fso_time_assembly(int32_t n_nodes, const double *xyz, int32_t n_tri, cons
                          const int32_t *rowptr, const int32_t *colidx, double *vals, double *F,
                          int32_t repeat);
 
+/* the threaded assembly keeps per-thread element lists keyed on the connectivity pointers: drop them before those arrays
+ * are freed or rewritten */
+void fso_drop_thread_lists(void);
+/* STREAM triad on the host threads, GB/s (24 bytes per element), best of reps: the bandwidth beside the CPU baseline */
+double fso_stream_triad(int64_t n, int32_t reps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,82 @@
+"""Full-size (BASELINE.json's 4M-triangle configurations) checks shared by tests/test_gpu_fullsize.py and bench.py:
+the assembled matrix against the oracle's, and the solver term of the multigrid solve against a manufactured solution.
+Test infrastructure only."""
+import time
+
+import numpy as np
+
+from tests.helpers import manufactured
+
+
+def workload(kind, n):
+    from tests.helpers import meshes
+
+    if kind == "panel":
+        m = meshes.structured(n, n, 0.0, 0.0, 10.0, 10.0, kind="t", ul_lr=True, bcids=(0, 0, 0, 0), factor=300.0, loading=2)
+        return m, (0.3, 1e7, 0.5)
+    if kind == "cylinder":
+        m = meshes.pinched_cylinder(n, n)
+        return m, m.material
+    raise ValueError(kind)
+
+
+def matrix_parity(fs, m, mat, chunk=1 << 20):
+    """HIP-assembled K (femshell_export_bsr) against the oracle's assembly of the same mesh: same pattern, largest entry
+    difference relative to the largest entry, and F bitwise.  Compared in chunks of blocks so that the temporaries stay
+    small beside the two 4 GB value arrays of a 4M-triangle mesh."""
+    from tests.helpers import oracle
+
+    t0 = time.perf_counter()
+    fs.assemble()
+    rg, cg, vg, Fg = fs.export_bsr()
+    t_export = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    r0, c0, v0, F0 = oracle.assemble(m.xyz, m.tri, m.quad, oracle.material(*mat), m.dirichlet_mask(), m.loads)
+    t_oracle = time.perf_counter() - t0
+    out = {"blocks": int(len(c0)), "same_pattern": bool(np.array_equal(rg, r0) and np.array_equal(cg, c0)),
+           "F_bitwise_equal": bool(np.array_equal(Fg, F0)), "export_seconds": t_export, "oracle_assembly_seconds": t_oracle}
+    if not out["same_pattern"]:
+        return out
+    scale, worst, sq_d, sq_v = 0.0, 0.0, 0.0, 0.0
+    for lo in range(0, len(c0), chunk):
+        a, b = vg[lo:lo + chunk], v0[lo:lo + chunk]
+        d = a - b
+        scale = max(scale, float(np.abs(b).max()))
+        worst = max(worst, float(np.abs(d).max()))
+        sq_d += float(np.einsum("ijk,ijk->", d, d))
+        sq_v += float(np.einsum("ijk,ijk->", b, b))
+    out["max_entry_diff_over_max_entry"] = worst / scale
+    out["frobenius_rel_diff"] = float(np.sqrt(sq_d / sq_v))
+    return out
+
+
+def manufactured_solve(fs, m, kind, rtol=1e-10, passes=(1,), max_it=3000, with_rounding_correction=True):
+    """Solver term at full size: ||u - u_ref|| / ||u_ref|| of multigrid solves of K u = fl(K u*) for the refinement
+    pass counts in `passes`; u_ref = u* + delta (tests/helpers/manufactured.py).  The context's loads are replaced."""
+    n = m.n_nodes
+    u_star = manufactured.smooth_field(m, kind)
+    fs.assemble()
+    b = manufactured.rhs_of(fs, u_star)
+    out = {"u_star_norm": float(np.linalg.norm(u_star)), "b_norm": float(np.linalg.norm(b)), "rtol": rtol, "runs": {}}
+    delta = np.zeros_like(u_star)
+    if with_rounding_correction:
+        fs.set_loads(b)
+        fs.set_preconditioner("amg", refine_passes=1)
+        delta, rho = manufactured.rounding_correction(fs, u_star)
+        out["rounding_of_b"] = {"residual_of_u_star_over_b": rho / out["b_norm"],
+                                "delta_over_u_star": float(np.linalg.norm(delta) / out["u_star_norm"])}
+    u_ref = u_star + delta
+    nrm = float(np.linalg.norm(u_ref))
+    fs.set_loads(b)
+    for p in passes:
+        fs.set_preconditioner("amg", refine_passes=int(p))
+        u, info = fs.solve(rtol=rtol, max_it=max_it)
+        out["runs"][int(p)] = {
+            "iterations": info["iterations"], "converged": info["converged"], "solve_seconds": info["solve_seconds"],
+            "rel_err_vs_manufactured": float(np.linalg.norm(u - u_ref) / nrm),
+            "rel_err_vs_u_star_alone": float(np.linalg.norm(u - u_star) / out["u_star_norm"]),
+            "max_err_over_max_u": float(np.abs(u - u_ref).max() / np.abs(u_ref).max()),
+            "true_rel_residual_double_double": info["true_rel_residual"],
+            "refine_passes_done": info["refine_passes_done"], "refine_correction_rel": info["refine_correction_rel"],
+            "refine_residual_reduction": info["refine_residual_reduction"], "error_estimate": info["error_estimate"]}
+    return out

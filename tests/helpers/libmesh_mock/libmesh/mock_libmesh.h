@@ -22,7 +22,7 @@ typedef uint32_t dof_id_type;
 typedef uint32_t numeric_index_type;
 typedef int16_t boundary_id_type;
 enum ElemType { TRI3 = 3, QUAD4 = 5 };
-enum LinearConvergenceReason { CONVERGED_RTOL_NORMAL = 1 };
+enum LinearConvergenceReason { CONVERGED_RTOL_NORMAL = 1, DIVERGED_ITS = -3, DIVERGED_BREAKDOWN = -5 }; // values of libMesh's enum_convergence_flags.h (= PETSc's KSPConvergedReason)
 template <class T> struct DenseVector { T operator()(unsigned) const; };
 template <class T> struct DenseMatrix { DenseMatrix(unsigned, unsigned); T &operator()(unsigned, unsigned); };
 template <class T> struct Range { T *begin() const; T *end() const; };

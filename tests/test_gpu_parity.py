@@ -84,20 +84,25 @@ def test_quad4_element_matrices_match_committed_goldens():
         assert np.linalg.norm(Ke[e] - g["Ke"][e]) <= 1e-12 * np.linalg.norm(g["Ke"][e])
 
 
-@pytest.mark.parametrize("name,tol", [("test_A_uv_t", 1e-10), ("test_B_uv_q", 1e-10), ("test_C_w_tA16", 1e-10),
-                                      ("test_D_w_q_uni16", 1e-9), ("test_E_uvw_t", 1e-10),
-                                      ("test_F_032_ss_uni", 1e-6), ("test_G_mpi_64_q", 1e-7)])
-def test_example_solutions_match_committed_goldens(name, tol):
+@pytest.mark.parametrize("name", ["test_A_uv_t", "test_B_uv_q", "test_C_w_tA16", "test_D_w_q_uni16", "test_E_uvw_t",
+                                  "test_F_032_ss_uni", "test_G_mpi_64_q"])
+def test_example_solutions_match_committed_goldens(name):
     """whole displacement vectors of the reference's shipped examples against tests/golden/example_solutions.npz
-    (refined direct solves of the oracle system); the thin plate F and the 64x64 mesh G are ill-conditioned:
-    the two assemblies differ by 1e-16 relative and the solutions by kappa times that"""
+    (refined direct solves of the oracle system) through the multigrid-preconditioned solve with its refinement pass:
+    one bound for all seven.  The solver term is 1e-15 ... 1e-13 (tests/test_gpu_amg.py holds it against the direct solve
+    of the GPU's own matrix); what remains is the sensitivity of the solution to the 1e-16 rounding differences of two
+    FP64 assemblies, largest on the thin plate F and the 64x64 mesh G (1.4e-10).  Block-Jacobi CG alone needed
+    tolerances of 1e-6 (F) and 1e-7 (G) here."""
     sols = np.load(meshes.GOLDEN + "/example_solutions.npz")
     nu, E, t = sols[name + "_params"]
     m = meshes.load_example(name)
-    u, info = make_ctx(m, nu, E, t).solve(rtol=1e-13, max_it=400000)
-    assert info["converged"] == 1
+    fs = make_ctx(m, nu, E, t)
+    fs.set_preconditioner("amg")
+    u, info = fs.solve(rtol=1e-12, max_it=2000)
+    assert info["converged"] == 1 and info["refine_passes_done"] >= 1
     err = np.linalg.norm(u - sols[name]) / np.linalg.norm(sols[name])
-    assert err < tol, err
+    assert err < 2e-10, err
+    assert 0.0 <= info["error_estimate"] < 1e-10, info
 
 
 def random_quads(n, seed):

@@ -93,7 +93,13 @@ def test_libmesh_adaptor_compiles_against_the_test_only_mock(tmp_path):
     tu.write_text('#define FEMSHELL_HAVE_LIBMESH 1\n#include "libmesh_adaptor.hpp"\n'
                   "void use(libMesh::EquationSystems &es, const libMesh::Parallel::Communicator &c) {\n"
                   '    femshell_libmesh::femshell_assemble_elasticity(es, "Elasticity");\n'
-                  "    femshell_libmesh::FemShellLinearSolver s(c);\n    (void)s;\n}\n")
+                  "    femshell_libmesh::FemShellLinearSolver s(c);\n"
+                  # the non-converged branches of the solver hook: iteration limit and breakdown map to libMesh's reasons
+                  "    femshell_libmesh::binding().last_info.converged = 0;\n"
+                  "    bool its = s.get_converged_reason() == libMesh::DIVERGED_ITS;\n"
+                  "    femshell_libmesh::binding().last_rc = FEMSHELL_ERR_BREAKDOWN;\n"
+                  "    bool brk = s.get_converged_reason() == libMesh::DIVERGED_BREAKDOWN;\n"
+                  "    s.print_converged_reason();\n    (void)its; (void)brk;\n}\n")
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
                            "-I" + HOST, "-I" + os.path.join(ROOT, "tests", "helpers", "libmesh_mock"), str(tu)])
 
@@ -264,9 +270,75 @@ def test_gmsh_reader_follows_the_thesis_listing(tools, tmp_path):
     r = subprocess.run([fem, "-nu", "0.3", "-e", "1", "-t", "1", "-mesh", str(bad)], capture_output=True, text=True)
     assert r.returncode != 0 and "not a side of any element" in r.stderr
     xdr = tmp_path / "m.xdr"
-    xdr.write_bytes(b"\\x00\\x00\\x00\\x0elibMesh-0.7.0+")
+    xdr.write_bytes(b"\x00\x00\x00\x0elibMesh-0.7.0+\x00\x00")  # header only
     r = subprocess.run([fem, "-nu", "0.3", "-e", "1", "-t", "1", "-mesh", str(xdr)], capture_output=True, text=True)
-    assert r.returncode != 0 and "XDR" in r.stderr
+    assert r.returncode != 0 and "truncated XDR" in r.stderr
+    xdr.write_bytes(b"\x00\x00\x00\x0elibMesh-1.9.9+\x00\x00")
+    r = subprocess.run([fem, "-nu", "0.3", "-e", "1", "-t", "1", "-mesh", str(xdr)], capture_output=True, text=True)
+    assert r.returncode != 0 and "not one this reader knows" in r.stderr
+
+
+def test_binary_xdr_round_trip(tools, tmp_path):
+    """mesh.read() of the reference accepts *.xdr beside *.xda (fem-shell.cpp:35-37): the binary form of the same records
+    (big-endian 32-bit integers / IEEE doubles, length-prefixed padded strings).  No libMesh here to write one, so the
+    reader is held to the twin's writer: XDA -> XDR -> XDA is the identity on every shipped example, the byte layout of
+    the header is checked by hand, and a Gmsh mesh with point boundary ids keeps them (nodeset record, 0.9.2+ header)."""
+    conv = os.path.join(HOST, "meshConvert")
+    for name in ("test_A_uv_t", "test_B_uv_q", "test_D_w_q_uni16", "test_G_mpi_64_q", "bending_tower_tri_test"):
+        src = os.path.join(meshes.MESH_DIR, name + ".xda")
+        xdr, back, direct = (str(tmp_path / (name + e)) for e in (".xdr", "_back.xda", "_direct.xda"))
+        subprocess.check_call([conv, src, xdr])
+        subprocess.check_call([conv, xdr, back])
+        subprocess.check_call([conv, src, direct])
+        assert open(back, "rb").read() == open(direct, "rb").read()
+        a, b = meshes.read_xda(src), meshes.read_xda(back)
+        np.testing.assert_array_equal(a.xyz, b.xyz)
+        np.testing.assert_array_equal(a.tri, b.tri)
+        np.testing.assert_array_equal(a.quad, b.quad)
+        assert a.bcs == b.bcs
+        raw = open(xdr, "rb").read()
+        n_el, n_no = len(a.tri) + len(a.quad), len(a.xyz)
+        head = (b"\x00\x00\x00\x0elibMesh-0.7.0+\x00\x00" + n_el.to_bytes(4, "big") + n_no.to_bytes(4, "big") +
+                b"\x00\x00\x00\x01.\x00\x00\x00" + 3 * b"\x00\x00\x00\x03n/a\x00" + n_el.to_bytes(4, "big"))
+        assert raw.startswith(head)
+        words = 4 * len(a.tri) + 5 * len(a.quad)
+        assert len(raw) == len(head) + 4 * words + 24 * n_no + 4 + 12 * len(a.bcs)
+        first = np.frombuffer(raw[len(head) + 4 * words:len(head) + 4 * words + 24], dtype=">f8")
+        np.testing.assert_array_equal(first, a.xyz[0])
+    msh = tmp_path / "two.msh"
+    msh.write_text(MSH_EXAMPLE)
+    subprocess.check_call([conv, str(msh), str(tmp_path / "two.xdr")])
+    subprocess.check_call([conv, str(tmp_path / "two.xdr"), str(tmp_path / "two.xda")])
+    txt = open(tmp_path / "two.xda").read()
+    assert txt.startswith("libMesh-0.9.2+") and "# number of nodesets" in txt
+    subprocess.check_call([conv, str(tmp_path / "two.xda"), str(tmp_path / "two2.xdr")])
+    assert open(tmp_path / "two.xdr", "rb").read() == open(tmp_path / "two2.xdr", "rb").read()
+
+
+def test_gmsh_boundary_lines_are_resolved_through_a_side_table(tools, tmp_path):
+    """every boundary line used to scan all elements (quadratic); 160k triangles with 1600 boundary lines
+    must read in a blink, and the sides found are those a scan finds (first element in file order)."""
+    import time
+
+    n = 282
+    m = meshes.structured(n, n, 0, 0, 1, 1, kind="t", ul_lr=True, bcids=(0, 0, 1, 1), factor=1.0, loading=0)
+    lines = ["$MeshFormat", "2.2 0 8", "$EndMeshFormat", "$Nodes", str(m.n_nodes)]
+    lines += ["%d %.17g %.17g %.17g" % (i + 1, *m.xyz[i]) for i in range(m.n_nodes)]
+    el = ["%d 2 2 0 0 %d %d %d" % (e + 1, *(m.tri[e] + 1)) for e in range(len(m.tri))]
+    for (e, s, bid) in m.bcs:
+        a, b = m.tri[e][s], m.tri[e][(s + 1) % 3]
+        el.append("%d 1 2 %d 0 %d %d" % (len(el) + 1, bid, b + 1, a + 1))  # reversed: orientation must not matter
+    lines += ["$EndNodes", "$Elements", str(len(el))] + el + ["$EndElements"]
+    p = tmp_path / "big.msh"
+    p.write_text("\n".join(lines) + "\n")
+    conv = os.path.join(HOST, "meshConvert")
+    t0 = time.time()
+    subprocess.check_call([conv, str(p), str(tmp_path / "big.xda")])
+    assert time.time() - t0 < 20.0
+    got = meshes.read_xda(str(tmp_path / "big.xda"))
+    np.testing.assert_array_equal(got.tri, m.tri)
+    assert sorted(got.bcs) == sorted(m.bcs)
+    np.testing.assert_array_equal(got.dirichlet_mask(), m.dirichlet_mask())
 
 
 def test_xda_side_index_is_range_checked(tools, tmp_path):
@@ -283,8 +355,11 @@ def test_petsc_style_options_are_understood(tools):
     fem, _ = tools
     mesh = os.path.join(meshes.MESH_DIR, "test_A_uv_t.xda")
     base = [fem, "-nu", "0.25", "-e", "30000", "-t", "1.0", "-mesh", mesh]
-    r = subprocess.run(base + ["-pc_type", "ilu"], capture_output=True, text=True)
-    assert r.returncode != 0 and "-pc_type ilu is not available" in r.stderr
+    r = subprocess.run(base + ["-pc_type", "nonsense"], capture_output=True, text=True)
+    assert r.returncode != 0 and "-pc_type nonsense is not available" in r.stderr
+    for pc in ("ilu", "none"):  # PETSc's serial default and "none": a note saying what runs, like an unavailable -ksp_type
+        r = subprocess.run(base + ["-pc_type", pc], capture_output=True, text=True)
+        assert "NOTE: -pc_type %s is not available on the GPU; using the 6x6 block-Jacobi" % pc in r.stderr
     r = subprocess.run(base + ["-ksp_type", "gmres", "-pc_type", "bjacobi"], capture_output=True, text=True)
     assert "using -ksp_type cg" in r.stderr
 

@@ -277,3 +277,61 @@ def test_products_that_stay_inside_a_slice():
         # row-major grid: the block towards the previous node of the row is the one that stays in the slice
         if len(m.tri):
             assert 0.25 < n_local / np.count_nonzero(ins >= 0) < 0.40
+
+
+def _host_side_digest():
+    import hashlib
+    import importlib
+
+    import scipy.sparse as sp
+
+    b = importlib.import_module("fem-shell_amd.binding")
+    h = hashlib.sha256()
+    m = meshes.structured(150, 140, 0, 0, 10, 9, kind="t", ul_lr=True, bcids=(0, 0, 1, 1), factor=1.0, loading=2)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(m.n_nodes)  # an unstructured numbering: wide slices, repairs of the balanced orientation
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(m.n_nodes)
+    tri = inv[m.tri].astype(np.int32)
+    xyz = m.xyz[perm]
+    for rank, world in ((0, 1), (1, 3)):
+        for xs, ts in ((m.xyz, m.tri), (xyz, tri)):
+            p = b.build_plan(xs, ts, None, rank=rank, world_size=world)
+            for k in sorted(p):
+                h.update(k.encode())
+                h.update(np.ascontiguousarray(p[k]).tobytes())
+    for kind in ("morton", "rcm"):
+        h.update(np.ascontiguousarray(b.reorder_host(kind, xyz, tri)).tobytes())
+    q = meshes.structured(40, 40, 0, 0, 10, 10, kind="q", bcids=(1, 1, 1, 1), factor=1.0, loading=2)
+    pq = b.build_plan(q.xyz, None, q.quad)
+    for k in sorted(pq):
+        h.update(np.ascontiguousarray(pq[k]).tobytes())
+    # a level operator for the host coarsening: block graph of the quad mesh with diagonally dominant SPD blocks
+    A = sp.lil_matrix((q.n_nodes, q.n_nodes))
+    for e in q.quad:
+        for i in e:
+            for j in e:
+                A[i, j] = 1.0
+    A = A.tocsr()
+    A.sort_indices()
+    vals = np.zeros((A.nnz, 6, 6))
+    rows = np.repeat(np.arange(q.n_nodes), np.diff(A.indptr))
+    vals[:] = -0.05 * np.eye(6)
+    vals[rows == A.indices] = 2.0 * np.eye(6)
+    B = b.amg_host_rbm(q.xyz, q.dirichlet_mask())
+    c = b.amg_host_coarsen(A.indptr.astype(np.int32), A.indices.astype(np.int32), vals, B, 2.0)
+    for k in sorted(c):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(c[k]).tobytes())
+    return h.hexdigest()
+
+
+def test_host_threads_do_not_change_the_plan(monkeypatch):
+    """The symbolic phase, the renumbering and the host coarsening run on FEMSHELL_HOST_THREADS threads (plan.cpp,
+    reorder.cpp, amg_setup.cpp): every array they produce is the same bit for bit on 1, 3 and 8 threads.  Under
+    tools/run_sanitizers.sh this is also the test that drives the threaded paths under ASan / UBSan / TSan."""
+    digests = []
+    for threads in (1, 3, 8):
+        monkeypatch.setenv("FEMSHELL_HOST_THREADS", str(threads))
+        digests.append(_host_side_digest())
+    assert digests[0] == digests[1] == digests[2], digests
