@@ -370,6 +370,82 @@ __global__ __launch_bounds__(256) void k_kcyc_r2(const double *__restrict__ rc, 
         r2[i] = rc[i] - t * v1[i];
 }
 
+// Small levels (a few thousand rows): the three launches of a K-cycle coefficient step -- stage-1 dots, finish, vector
+// update -- as one single-workgroup kernel; each of them costs the 4.5 us of a dependent launch, whatever its size.
+__global__ __launch_bounds__(1024) void k_kcyc_step1_small(const double *__restrict__ c1, const double *__restrict__ v1,
+                                                            const double *__restrict__ rc, double *__restrict__ r2, int n,
+                                                            KcycScalars *ks, const CgScalars *gate)
+{
+    __shared__ double sh[16];
+    __shared__ double tt;
+    if (gate != nullptr && gate->done != 0) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double c = c1[i];
+        s0 += c * v1[i];
+        s1 += c * rc[i];
+    }
+    const double rho1 = block_sum(s0, sh), a1 = block_sum(s1, sh);
+    if (threadIdx.x == 0) {
+        const double t = rho1 > 0.0 ? a1 / rho1 : 0.0;
+        ks->rho1 = rho1;
+        ks->a1 = a1;
+        ks->t = t;
+        tt = t;
+    }
+    __syncthreads();
+    const double t = tt;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) r2[i] = rc[i] - t * v1[i];
+}
+
+__global__ __launch_bounds__(1024) void k_kcyc_step2_small(const double *__restrict__ c1, const double *__restrict__ c2,
+                                                            const double *__restrict__ v1, const double *__restrict__ v2,
+                                                            const double *__restrict__ r2, double *__restrict__ x, int n,
+                                                            KcycScalars *ks, const CgScalars *gate)
+{
+    __shared__ double sh[16];
+    __shared__ double ww[2];
+    if (gate != nullptr && gate->done != 0) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double c = c2[i];
+        s0 += c * v1[i];
+        s1 += c * v2[i];
+        s2 += c * r2[i];
+    }
+    const double g = block_sum(s0, sh), b2 = block_sum(s1, sh), a2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) {
+        const double rho1 = ks->rho1, a1 = ks->a1;
+        double w1 = ks->t, w2 = 0.0;
+        if (rho1 > 0.0) {
+            const double rho2 = b2 - g * g / rho1;
+            if (rho2 > 0.0) {
+                w1 = a1 / rho1 - g * a2 / (rho1 * rho2);
+                w2 = a2 / rho2;
+            }
+        }
+        ks->w1 = w1;
+        ks->w2 = w2;
+        ww[0] = w1;
+        ww[1] = w2;
+    }
+    __syncthreads();
+    const double w1 = ww[0], w2 = ww[1];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) x[i] = w1 * c1[i] + w2 * c2[i];
+}
+
+void launch_kcyc_step1_small(const double *c1, const double *v1, const double *rc, double *r2, int64_t n6, KcycScalars *ks,
+                             const CgScalars *gate, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kcyc_step1_small, dim3(1), dim3(1024), 0, st, c1, v1, rc, r2, (int)n6, ks, gate);
+}
+
+void launch_kcyc_step2_small(const double *c1, const double *c2, const double *v1, const double *v2, const double *r2, double *x,
+                             int64_t n6, KcycScalars *ks, const CgScalars *gate, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kcyc_step2_small, dim3(1), dim3(1024), 0, st, c1, c2, v1, v2, r2, x, (int)n6, ks, gate);
+}
+
 int launch_two_dots(const double *a0, const double *b0, const double *a1, const double *b1, int64_t n, double *scratch, hipStream_t st)
 {
     int groups = (int)((n + 4095) / 4096);

@@ -54,6 +54,14 @@ struct KcycScalars {
 };
 void launch_kcyc_dots(int phase, const double *a0, const double *b0, const double *a1, const double *b1, const double *a2,
                       const double *b2, int64_t n6, KcycScalars *ks, double *scratch, const CgScalars *gate, hipStream_t st);
+// the two coefficient steps of a K cycle on a small level (n6 <= kKcycSmall) as one single-workgroup launch each:
+//   step 1: rho1 = c1.v1, a1 = c1.rc, t = a1 / rho1, r2 = rc - t v1
+//   step 2: w1, w2 from (c2.v1, c2.v2, c2.r2), x = w1 c1 + w2 c2
+constexpr int64_t kKcycSmall = 16384;
+void launch_kcyc_step1_small(const double *c1, const double *v1, const double *rc, double *r2, int64_t n6, KcycScalars *ks,
+                             const CgScalars *gate, hipStream_t st);
+void launch_kcyc_step2_small(const double *c1, const double *c2, const double *v1, const double *v2, const double *r2, double *x,
+                             int64_t n6, KcycScalars *ks, const CgScalars *gate, hipStream_t st);
 // stage 1 of two dot products a0.b0 and a1.b1 over n entries: scratch[g] and scratch[128 + g] for g < the returned group
 // count (<= 128) hold the partial sums, in a fixed order (error estimate of the refinement passes: the host adds them)
 int launch_two_dots(const double *a0, const double *b0, const double *a1, const double *b1, int64_t n, double *scratch, hipStream_t st);

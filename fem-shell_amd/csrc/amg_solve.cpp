@@ -562,14 +562,23 @@ struct Cycle {
         AmgLevel &L = *H.levels[l];
         const DeviceMatrix &A = amg_level_matrix(c, l);
         const int64_t n6 = 6ll * L.n_pad;
+        const bool small = n6 <= kKcycSmall; // coefficient steps as single launches (amg_kernels.hpp)
         cycle(l, L.b.p, L.c1.p);
         launch_spmv(A, L.c1.p, L.v1.p, nullptr, gate, st);
-        launch_kcyc_dots(1, L.c1.p, L.v1.p, L.c1.p, L.b.p, nullptr, nullptr, n6, L.ks.p, L.kscratch.p, gate, st);
-        launch_kcyc_r2(L.b.p, L.v1.p, L.r2.p, n6, L.ks.p, gate, st);
+        if (small) {
+            launch_kcyc_step1_small(L.c1.p, L.v1.p, L.b.p, L.r2.p, n6, L.ks.p, gate, st);
+        } else {
+            launch_kcyc_dots(1, L.c1.p, L.v1.p, L.c1.p, L.b.p, nullptr, nullptr, n6, L.ks.p, L.kscratch.p, gate, st);
+            launch_kcyc_r2(L.b.p, L.v1.p, L.r2.p, n6, L.ks.p, gate, st);
+        }
         cycle(l, L.r2.p, L.c2.p);
         launch_spmv(A, L.c2.p, L.v2.p, nullptr, gate, st);
-        launch_kcyc_dots(2, L.c2.p, L.v1.p, L.c2.p, L.v2.p, L.c2.p, L.r2.p, n6, L.ks.p, L.kscratch.p, gate, st);
-        launch_kcyc_combine(L.c1.p, L.c2.p, L.x.p, n6, L.ks.p, gate, st);
+        if (small) {
+            launch_kcyc_step2_small(L.c1.p, L.c2.p, L.v1.p, L.v2.p, L.r2.p, L.x.p, n6, L.ks.p, gate, st);
+        } else {
+            launch_kcyc_dots(2, L.c2.p, L.v1.p, L.c2.p, L.v2.p, L.c2.p, L.r2.p, n6, L.ks.p, L.kscratch.p, gate, st);
+            launch_kcyc_combine(L.c1.p, L.c2.p, L.x.p, n6, L.ks.p, gate, st);
+        }
     }
 };
 
