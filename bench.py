@@ -536,6 +536,7 @@ def main():
         fs.sync()
         wall = time.perf_counter() - t0
         sst = fs.amg_setup_stats()
+        dst = fs.amg_dense_stats()
         _, ib = fs.solve(rtol=1e-10, max_it=3000, fetch=False)  # hierarchy reused (the coupled program re-solves)
         fs.set_preconditioner("amg", refine_passes=0)            # same hierarchy, no refinement pass
         _, ic = fs.solve(rtol=1e-10, max_it=3000, fetch=False)
@@ -554,16 +555,37 @@ def main():
                "setup_first_coarsening_on_device": {
                    "prolongator_ms": sst["prolongator_ms"], "ap_ms": sst["ap_ms"], "restriction_ms": sst["restriction_ms"],
                    "galerkin_ms": sst["galerkin_ms"],
-                   "galerkin_kernel": "k_amg_galerkin_mfma (v_mfma_f64_16x16x4_f64, one wave per coarse row)" if sst["galerkin_on_matrix_cores"] else "k_amg_galerkin (vector ALUs)",
+                   "galerkin_kernel": "k_amg_galerkin_mfma (v_mfma_f64_16x16x4_f64, one wave per coarse row)" if sst["galerkin_on_matrix_cores"] else "k_amg_galerkin (vector ALUs, one lane per result block)",
                    "galerkin_useful_gflop": sst["galerkin_useful_flops"] / 1e9,
-                   "galerkin_mfma_gflop_issued": sst["galerkin_mfma_flops_issued"] / 1e9,
-                   "roofline": {"bound": "mfma", "achieved": sst["galerkin_mfma_flops_issued"] / max(sst["galerkin_ms"], 1e-9) / 1e9,
-                                "peak": 78.6, "unit": "TFLOP/s",
-                                "frac": sst["galerkin_mfma_flops_issued"] / max(sst["galerkin_ms"], 1e-9) / 1e9 / 78.6,
-                                "note": "FP64 matrix peak 78.6 TFLOP/s; the panels are 6 rows tall (10 of 16 tile rows idle) and gathered "
-                                        "8 bytes at a time from the block ELL layout: latency-bound, 11.6 ms against 5.8 ms of the "
-                                        "vector-ALU kernel (FEMSHELL_AMG_GALERKIN=valu), 1 % of the 1.2 s setup either way"}},
+                   "galerkin_useful_tflops": sst["galerkin_useful_flops"] / max(sst["galerkin_ms"], 1e-9) / 1e9},
+               # the dense, GEMM-shaped contraction of the preconditioner: inverse of the coarsest operator by symmetric block
+               # sweeps on the matrix cores (csrc/amg_dense.hip); `achieved` counts the flops issued as v_mfma_f64_16x16x4_f64
+               "setup_coarsest_inverse_on_matrix_cores": None if not dst["n"] else {
+                   "dofs": dst["n"], "ms": dst["ms"], "dropped_directions": dst["dropped_directions"],
+                   "mfma_gflop_issued": dst["mfma_flops_issued"] / 1e9, "useful_gflop_n_cubed": dst["useful_flops"] / 1e9,
+                   "lower_triangle_traffic_gb": dst["bytes"] / 1e9, "traffic_gb_per_s": dst["bytes"] / max(dst["ms"], 1e-9) / 1e6,
+                   "roofline": {"bound": "mfma", "achieved": dst["mfma_flops_issued"] / max(dst["ms"], 1e-9) / 1e9, "peak": 78.6,
+                                "unit": "TFLOP/s", "frac": dst["mfma_flops_issued"] / max(dst["ms"], 1e-9) / 1e9 / 78.6,
+                                "note": "FP64 matrix peak 78.6 TFLOP/s; 64x64 tiles, the lower triangle is read and written once "
+                                        "per block sweep (116 sweeps at 7386 dofs): the kernel sits between the HBM and the matrix-core bound"}},
                "block_jacobi_alone": jacobi_extrapolation(jacobi_hist)}
+        # the Galerkin product on the matrix cores, the measured alternative to the default vector-ALU kernel: one more setup
+        os.environ["FEMSHELL_AMG_GALERKIN"] = "mfma"
+        fs.assemble()
+        fs.set_preconditioner("amg")
+        _, iq = fs.solve(rtol=1e-10, max_it=3000, fetch=False)
+        sq = fs.amg_setup_stats()
+        del os.environ["FEMSHELL_AMG_GALERKIN"]
+        tts["setup_first_coarsening_on_device"]["galerkin_on_matrix_cores_alternative"] = {
+            "kernel": "k_amg_galerkin_mfma (v_mfma_f64_16x16x4_f64, one wave per coarse row; FEMSHELL_AMG_GALERKIN=mfma)",
+            "galerkin_ms": sq["galerkin_ms"], "mfma_gflop_issued": sq["galerkin_mfma_flops_issued"] / 1e9,
+            "mfma_tflops_issued": sq["galerkin_mfma_flops_issued"] / max(sq["galerkin_ms"], 1e-9) / 1e9,
+            "frac_of_78.6_tflops": sq["galerkin_mfma_flops_issued"] / max(sq["galerkin_ms"], 1e-9) / 1e9 / 78.6,
+            "iterations_with_it": iq["iterations"],
+            "note": "6-row panels leave 10 of 16 tile rows idle and the operands are gathered 8 bytes at a time: slower than the "
+                    "vector-ALU kernel, hence not the default"}
+        fs.assemble()  # the hierarchy of the default kernels again for what follows
+        fs.set_preconditioner("amg")
         if tts["block_jacobi_alone"] and "extrapolated_iterations_to_1e-10" in tts["block_jacobi_alone"]:
             tts["block_jacobi_alone"]["extrapolated_seconds"] = tts["block_jacobi_alone"]["extrapolated_iterations_to_1e-10"] * t_cg / max(info["iterations"], 1)
 

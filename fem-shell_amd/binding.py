@@ -24,7 +24,7 @@ SYMBOLS = [
     "femshell_nnz_blocks", "femshell_export_bsr", "femshell_spmv", "femshell_row_begin",
     "femshell_row_end", "femshell_comm_unique_id", "femshell_comm_init", "femshell_time_kernel",
     "femshell_sync", "femshell_pc_defaults", "femshell_set_preconditioner", "femshell_amg_levels", "femshell_amg_level",
-    "femshell_amg_export", "femshell_residual", "femshell_comm_ranks", "femshell_amg_setup_stats",
+    "femshell_amg_export", "femshell_residual", "femshell_comm_ranks", "femshell_amg_setup_stats", "femshell_amg_dense_stats",
 ]
 
 
@@ -133,6 +133,7 @@ def load_library():
     L.femshell_amg_export.argtypes = [vp, C.c_int32, C.c_int32, C.c_void_p]
     L.femshell_amg_export.restype = C.c_int64
     L.femshell_amg_setup_stats.argtypes = [vp, dp]
+    L.femshell_amg_dense_stats.argtypes = [vp, dp]
     for name in SYMBOLS:
         if name != "femshell_last_error" and not name.startswith("femshell_nnz") and \
                 not name.startswith("femshell_row") and name != "femshell_residual_history" and \
@@ -305,6 +306,13 @@ class FemShell:
         _check(self._L.femshell_amg_setup_stats(self._h, _d(out)))
         return {"prolongator_ms": out[0], "ap_ms": out[1], "restriction_ms": out[2], "galerkin_ms": out[3],
                 "galerkin_useful_flops": out[4], "galerkin_mfma_flops_issued": out[5], "galerkin_on_matrix_cores": bool(out[6])}
+
+    def amg_dense_stats(self):
+        """The dense inverse of the coarsest operator when the matrix cores computed it (n = 0: host path)."""
+        out = np.zeros(6)
+        _check(self._L.femshell_amg_dense_stats(self._h, _d(out)))
+        return {"n": int(out[0]), "ms": out[1], "mfma_flops_issued": out[2], "useful_flops": out[3], "dropped_directions": int(out[4]),
+                "bytes": out[5]}
 
     def amg_export(self, level):
         """Host copies of a level (small problems): dict with agg, A (rowptr, cols, vals), P (rowptr, cols, vals)."""

@@ -79,11 +79,20 @@ struct AmgDist {
     int32_t coarse_slice0 = 0;
 };
 
+// the dense inverse of a large coarsest operator, computed on the matrix cores (amg_dense.hip); n = 0: the host path ran
+struct AmgDenseStats {
+    int n = 0, dropped = 0;
+    double ms = 0.0, mfma_flops = 0.0, useful_flops = 0.0, bytes = 0.0;
+};
+
 struct Amg {
     femshell_pc_options opt{};
     AmgSetupStats stats;
+    AmgDenseStats dense;
     std::vector<std::unique_ptr<AmgLevel>> levels;
     DevBuf<double> coarse_inv; // dense inverse of the coarsest operator
+    DevBuf<float> coarse_inv32; // ... in single precision (FEMSHELL_AMG_DENSE_F32=1), device path only
+    int64_t coarse_lda = 0;    // row stride of the device-computed inverse (0: host path, rows of 6 n doubles)
     DevBuf<float> K32;         // K in single precision for the smoothing products of level 0 (FEMSHELL_AMG_SMOOTH_F32)
     bool valid = false;
     double setup_seconds = 0.0;
@@ -107,6 +116,14 @@ int cg_amg(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it, dou
 double amg_bytes_per_iteration(const femshell_ctx *c);
 // K of a single-rank context as host BSR with ascending columns (api.cpp)
 int download_matrix(femshell_ctx *c, Bsr *A, int32_t *col_out = nullptr, double *val_out = nullptr);
+// Dense inverse of the coarsest operator on the device (amg_dense.hip): symmetric block sweeps on v_mfma_f64_16x16x4_f64.
+// Exactly one of inv64 / inv32 is filled (rows of *lda entries); FEMSHELL_ERR_BREAKDOWN for an operator that is not
+// positive semi-definite (same pivot rules as the host's dense_inverse)
+int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precision, DevBuf<double> *inv64, DevBuf<float> *inv32,
+                             int64_t *lda_out, AmgDenseStats *stats);
+// y = Ainv b for such an inverse (one of A64 / A32 non-null); rows [n, n_pad6) of y are set to zero
+void launch_dense_gemv_big(const double *A64, const float *A32, int64_t lda, const double *b, double *y, int32_t n, int32_t n_pad6,
+                           const CgScalars *gate, hipStream_t st);
 // first coarsening step with the numerics on the device (amg_device_setup.cpp)
 // (A: the level operator in HBM, block-Jacobi inverse valid; pat: host copy of its pattern; want_host(coarse nodes): bring
 //  the coarse operator back as a host matrix -- needed when the next step runs on the host or the level is the coarsest)

@@ -439,8 +439,12 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     if (rc) return rc;
     FS_HIP(hipStreamSynchronize(st)); // the host vectors above go out of scope at the end of this function only, but be safe
     lap("uploads");
-    // FEMSHELL_AMG_GALERKIN=valu: one lane per result block on the vector ALUs instead of the matrix cores (A/B, tests)
-    static const bool use_mfma = !(getenv("FEMSHELL_AMG_GALERKIN") && std::string(getenv("FEMSHELL_AMG_GALERKIN")) == "valu");
+    // FEMSHELL_AMG_GALERKIN=mfma: one wave per coarse row on the matrix cores instead of one lane per result block on the
+    // vector ALUs.  Measured on the 4M-triangle panel with A P stored block-contiguously: 2.5 ms on the vector ALUs, 8.2 ms
+    // on the matrix cores (6-row panels leave 10 of 16 tile rows idle and the operands arrive 8 bytes at a time) -- the
+    // product is a gather of 288-byte blocks at 4 TFLOP/s, not a GEMM, so the vector-ALU kernel is the default and the
+    // matrix-core kernel the measured alternative (tests run both; bench.py reports both).  Read per setup.
+    const bool use_mfma = getenv("FEMSHELL_AMG_GALERKIN") && std::string(getenv("FEMSHELL_AMG_GALERKIN")) == "mfma";
     hipEvent_t ev[5];
     for (auto &e : ev) FS_HIP(hipEventCreate(&e));
     FS_HIP(hipEventRecord(ev[0], st));

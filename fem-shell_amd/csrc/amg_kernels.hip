@@ -513,6 +513,25 @@ __device__ __forceinline__ void ell_store(double *vals, int64_t slot, const doub
 #pragma unroll
         for (int j = 0; j < 6; j++) vals[ell_index(slot, i, j)] = b[6 * i + j];
 }
+// A P, the intermediate of a coarsening step that only the Galerkin product reads, keeps every block as 36 consecutive
+// doubles (slot-major): a block is then 288 contiguous bytes instead of 18 words in 18 different 512-byte groups of the
+// sliced layout, which is what the product's gather of whole blocks wants (8.7 -> see DESIGN.md section 5)
+__device__ __forceinline__ void blk_load_contig(const double *vals, int64_t slot, double b[36])
+{
+    const double2 *src = reinterpret_cast<const double2 *>(vals + slot * 36);
+#pragma unroll
+    for (int w = 0; w < 18; w++) {
+        const double2 v = src[w];
+        b[2 * w] = v.x;
+        b[2 * w + 1] = v.y;
+    }
+}
+__device__ __forceinline__ void blk_store_contig(double *vals, int64_t slot, const double b[36])
+{
+    double2 *dst = reinterpret_cast<double2 *>(vals + slot * 36);
+#pragma unroll
+    for (int w = 0; w < 18; w++) dst[w] = make_double2(b[2 * w], b[2 * w + 1]);
+}
 // c += a * b (row-major 6x6), a^T * b with ta
 __device__ __forceinline__ void blk_mac(const double a[36], const double b[36], double c[36], bool ta)
 {
@@ -642,7 +661,7 @@ __global__ __launch_bounds__(128) void k_amg_ap(DeviceMatrix A, EllView P, EllVi
             blk_mac(blk, pb, acc, false);
         });
     }
-    ell_store(AP.vals, t, acc);
+    blk_store_contig(AP.vals, t, acc);
 }
 
 __global__ __launch_bounds__(128) void k_amg_restriction(EllView P, const int64_t *__restrict__ rptr, const int32_t *__restrict__ rrow,
@@ -685,7 +704,7 @@ __global__ __launch_bounds__(128) void k_amg_galerkin(EllView P, EllView AP, con
             if (as < 0) continue;
             double pb[36], ab[36];
             ell_load(P.vals, ell_slot(P, i / kSliceNodes, rk[q], i % kSliceNodes), pb, false);
-            ell_load(AP.vals, as, ab, false);
+            blk_load_contig(AP.vals, as, ab);
             blk_mac(pb, ab, acc, true); // P_iI^T (A P)_iJ
         }
         if (J == I) // coarse dofs without fine support (zero column of P): unit diagonal keeps the level matrix SPD
@@ -746,7 +765,7 @@ __global__ __launch_bounds__(64) void k_amg_galerkin_mfma(EllView P, EllView AP,
                         double b = 0.0;
                         if (d < 6 && sj < gcnt) {
                             const int64_t as = apslot[sj];
-                            if (as >= 0) b = AP.vals[ell_index(as, d, cdof)];
+                            if (as >= 0) b = AP.vals[as * 36 + 6 * d + cdof];
                         }
                         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
                     }

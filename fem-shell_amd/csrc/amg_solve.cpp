@@ -156,7 +156,7 @@ void amg_default_options(femshell_pc_options *o)
     o->cycle = FEMSHELL_CYCLE_K;
     o->smoother_degree = 2; // tools/amg_sweep.py: on the 1M-triangle panel and the 250k roof (launch-bound) degree 3 / 3 is
     o->coarse_degree = 4;   // 8 % faster to 1e-10, on the 4M-triangle panel (HBM-bound) 2 / 4 wins: 1.72 s against 1.97 s
-    o->coarsest_nodes = 200;
+    o->coarsest_nodes = 1400; // the K cycle's last levels cost launches, not bytes: end with an exact solve early (amg_dense.hip)
     o->max_levels = 12;
     o->refine_passes = 1;
     o->eig_ratio = 30.0;
@@ -313,10 +313,25 @@ int amg_setup(femshell_ctx *c)
             std::vector<double> inv;
             if (L.n > 4096) return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: coarsest level too large for a dense inverse");
             if (!have_host) return set_err(FEMSHELL_ERR_INVALID, "multigrid setup: the coarsest operator was not brought to the host");
-            if (!dense_inverse(A, &inv))
-                return set_err(FEMSHELL_ERR_BREAKDOWN, "multigrid setup: coarsest operator is not positive definite");
-            FS_HIP(H.coarse_inv.upload(inv, st));
-            FS_HIP(hipStreamSynchronize(st));
+            // small operators are inverted on the host (a few GFLOP); beyond FEMSHELL_AMG_DENSE_DEVICE_MIN nodes (default
+            // 250) the inverse is computed on the matrix cores (amg_dense.hip: n^3 flops, 0.4 TFLOP at 1231 nodes)
+            // (read per setup: the tests switch them inside one process)
+            const long dense_device_min = getenv("FEMSHELL_AMG_DENSE_DEVICE_MIN") ? atol(getenv("FEMSHELL_AMG_DENSE_DEVICE_MIN")) : 250l;
+            const bool dense_f32 = getenv("FEMSHELL_AMG_DENSE_F32") && atoi(getenv("FEMSHELL_AMG_DENSE_F32")) != 0;
+            H.coarse_lda = 0;
+            H.dense = AmgDenseStats();
+            H.coarse_inv32.release();
+            if (L.n > dense_device_min) {
+                rc = amg_dense_inverse_device(c, A, dense_f32, &H.coarse_inv, &H.coarse_inv32, &H.coarse_lda, &H.dense);
+                if (rc) return rc;
+                lap("dense inverse on the matrix cores", l);
+            } else {
+                if (!dense_inverse(A, &inv))
+                    return set_err(FEMSHELL_ERR_BREAKDOWN, "multigrid setup: coarsest operator is not positive definite");
+                FS_HIP(H.coarse_inv.upload(inv, st));
+                FS_HIP(hipStreamSynchronize(st));
+                lap("dense inverse on the host", l);
+            }
             if (keep_host) L.hA = std::move(A);
             break;
         }
@@ -541,7 +556,8 @@ struct Cycle {
     {
         AmgLevel &L = *H.levels[l];
         if ((size_t)l + 1 == H.levels.size()) {
-            launch_dense_gemv(H.coarse_inv.p, b, x, 6 * L.n, 6 * L.n_pad, gate, st);
+            if (H.coarse_lda > 0) launch_dense_gemv_big(H.coarse_inv.p, H.coarse_inv32.p, H.coarse_lda, b, x, 6 * L.n, 6 * L.n_pad, gate, st);
+            else launch_dense_gemv(H.coarse_inv.p, b, x, 6 * L.n, 6 * L.n_pad, gate, st);
             return;
         }
         const DeviceMatrix &A = amg_level_matrix(c, l);
@@ -855,7 +871,7 @@ double amg_bytes_per_iteration(const femshell_ctx *c)
         visits[l + 1] = visits[l] * (next_k ? 2.0 : 1.0);
     }
     const AmgLevel &C = *H.levels.back();
-    bytes += visits.back() * 8.0 * 36.0 * (double)C.n * (double)C.n;
+    bytes += visits.back() * (H.coarse_inv32.p != nullptr ? 4.0 : 8.0) * 36.0 * (double)C.n * (double)C.n;
     return bytes;
 }
 

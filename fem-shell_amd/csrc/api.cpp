@@ -235,6 +235,9 @@ int amg_setup_through_shadow(femshell_ctx *c)
     if (!rc) rc = do_jacobi(sh);
     if (rc) return rc;
     sh->pc = c->pc;
+    // the distributed cycle smooths level 0 on the ranks' rows and needs a level below it: a mesh that is small enough to
+    // be its own coarsest level is coarsened once all the same
+    if (nn <= sh->pc.coarsest_nodes) sh->pc.coarsest_nodes = std::max(1, nn / 4);
     rc = amg_setup(sh);
     if (rc) return rc;
     FS_HIP(hipStreamSynchronize(sh->stream));
@@ -713,7 +716,7 @@ int femshell_set_preconditioner(femshell_ctx *c, const femshell_pc_options *opt)
         return set_err(FEMSHELL_ERR_INVALID, "femshell_set_preconditioner: unknown preconditioner type");
     if (opt->type == FEMSHELL_PC_AMG) {
         if ((opt->cycle != FEMSHELL_CYCLE_V && opt->cycle != FEMSHELL_CYCLE_K) || opt->smoother_degree < 1 || opt->smoother_degree > 16 ||
-            opt->coarse_degree < 1 || opt->coarse_degree > 16 || opt->coarsest_nodes < 1 || opt->coarsest_nodes > 680 ||
+            opt->coarse_degree < 1 || opt->coarse_degree > 16 || opt->coarsest_nodes < 1 || opt->coarsest_nodes > 1400 ||
             opt->max_levels < 2 || opt->max_levels > 32 || !(opt->eig_ratio > 1.0) || opt->refine_passes < 0 || opt->refine_passes > 4)
             return set_err(FEMSHELL_ERR_INVALID, "femshell_set_preconditioner: option out of range");
     }
@@ -756,6 +759,20 @@ int femshell_amg_setup_stats(femshell_ctx *c, double out[7])
     out[4] = S.galerkin_useful_flops;
     out[5] = S.galerkin_mfma_flops_issued;
     out[6] = (double)S.galerkin_mfma;
+    return FEMSHELL_OK;
+}
+
+int femshell_amg_dense_stats(femshell_ctx *c, double out[6])
+{
+    if (!c || !out) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_dense_stats: null argument");
+    if (!c->amg || !c->amg->valid) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_dense_stats: no multigrid hierarchy");
+    const AmgDenseStats &S = c->amg->dense;
+    out[0] = (double)S.n;
+    out[1] = S.ms;
+    out[2] = S.mfma_flops;
+    out[3] = S.useful_flops;
+    out[4] = (double)S.dropped;
+    out[5] = S.bytes;
     return FEMSHELL_OK;
 }
 

@@ -145,7 +145,11 @@ typedef struct femshell_pc_options {
     int32_t cycle;           /* femshell_cycle (default K: two flexible-CG steps per coarse level) */
     int32_t smoother_degree; /* Chebyshev degree on the finest level (default 2) */
     int32_t coarse_degree;   /* Chebyshev degree on the coarser levels (default 4) */
-    int32_t coarsest_nodes;  /* coarsening stops at this many nodes; dense inverse there (default 200) */
+    int32_t coarsest_nodes;  /* coarsening stops at the first level of at most this many nodes; dense inverse there (default
+                                and maximum 1400: the K cycle visits its last levels 8-16 times per iteration and each
+                                visit is a chain of launches, so an exact solve of 8400 dofs -- one dense matrix-vector
+                                product -- is cheaper than two more levels; inverses beyond 250 nodes are computed on the
+                                matrix cores) */
     int32_t max_levels;      /* default 12 */
     int32_t refine_passes;   /* iterative refinement after convergence, at most this many passes (default 1; 0 = off):
                                 the residual of the iterate is evaluated in double-double and the correction equation
@@ -183,6 +187,11 @@ int64_t femshell_amg_export(femshell_ctx *ctx, int32_t level, int32_t which, voi
  * restriction and Galerkin kernels, out[4] = useful flops of the Galerkin product, out[5] = flops issued on the
  * matrix cores (v_mfma_f64_16x16x4_f64 tiles; 0 when the vector-ALU kernel ran), out[6] = 1 if the matrix cores ran */
 int femshell_amg_setup_stats(femshell_ctx *ctx, double out[7]);
+/* the dense inverse of the coarsest operator when it was computed on the matrix cores (csrc/amg_dense.hip; symmetric block
+ * sweeps on v_mfma_f64_16x16x4_f64): out[0] = dofs n (0: the host inverted a small operator), out[1] = milliseconds,
+ * out[2] = flops issued on the matrix cores, out[3] = n^3 (the flops of a symmetric inversion), out[4] = dropped
+ * (semi-definite) directions, out[5] = bytes of the lower triangle read and written over all steps */
+int femshell_amg_dense_stats(femshell_ctx *ctx, double out[6]);
 
 /* replaces: equation_systems.solve() -> PETSc KSPSolve (SA:138, PC:271) followed by
  * build_solution_vector (SA:141; PC:274-280 broadcast): 6x6-block-Jacobi preconditioned CG,

@@ -42,6 +42,11 @@ print("first coarsening step on the device: P %.2f ms, AP %.2f ms, R %.2f ms, Ga
     ", %.1f GFLOP issued on the matrix cores = %.1f TFLOP/s" % (st["galerkin_mfma_flops_issued"] / 1e9,
                                                                st["galerkin_mfma_flops_issued"] / max(st["galerkin_ms"], 1e-9) / 1e9)
     if st["galerkin_on_matrix_cores"] else ""))
+ds = fs.amg_dense_stats()
+if ds["n"]:
+    print("dense inverse of the coarsest operator on the matrix cores: n = %d, %.2f ms, %.1f GFLOP issued = %.1f TFLOP/s (%.1f useful), "
+          "%.1f GB moved = %.2f TB/s, %d dropped directions" % (ds["n"], ds["ms"], ds["mfma_flops_issued"] / 1e9,
+          ds["mfma_flops_issued"] / ds["ms"] / 1e9, ds["useful_flops"] / ds["ms"] / 1e9, ds["bytes"] / 1e9, ds["bytes"] / ds["ms"] / 1e9, ds["dropped_directions"]))
 u2, info2 = fs.solve(rtol=rtol, max_it=3000, fetch=False)
 print("second solve (hierarchy reused):", json.dumps(info2))
 h = fs.residual_history()
