@@ -363,7 +363,11 @@ int fem_shell_precice_main(int argc, char **argv, std::ostream &out, std::ostrea
             << " s" << std::endl;
         for (size_t i = 0; i < log.tip_displacement.size(); i++)
             out << "tip[" << i << "] node " << probe << " = " << log.tip_displacement[i] << "\n";
-        if (p.isOutfileSet) write_vtk(mesh, system.build_solution_vector(), p.out_filename + ".vtk");
+        if (p.isOutfileSet) {
+            const std::vector<double> sols = system.build_solution_vector();
+            write_exodus(mesh, sols, p.out_filename + ".e");
+            write_vtk(mesh, sols, p.out_filename + ".vtk");
+        }
         out << "All done :)\n";
         return 0;
     } catch (const std::exception &e) {

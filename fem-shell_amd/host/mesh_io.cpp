@@ -596,4 +596,230 @@ void write_vtk(const ShellMesh &m, const std::vector<double> &u, const std::stri
     }
 }
 
+// ---- ExodusII output (fem-shell.cpp:1240-1251: ExodusII_IO(mesh).write_equation_systems(out + ".e", es)) ------------
+// ExodusII is a set of conventions on a netCDF file; the image has no netCDF library, but the classic netCDF format
+// (here "64-bit offset", CDF-2) is a header of dimensions, attributes and variables followed by the big-endian data, and
+// a writer for the handful of variables an ExodusII mesh with nodal fields needs is short.  What is written is what
+// libMesh's writer produces for this program in content: the displaced nodes (the reference adds the displacements to
+// the nodes before writing, fem-shell.cpp:172-175), one element block per element type (TRI3, QUAD4; 1-based
+// connectivity), the original element numbers as elem_num_map, and the six nodal variables u, v, w, tx, ty, tz of the
+// "Elasticity" system (fem-shell.cpp:75-80) at one time step.  tests/test_host_tools.py reads the file back with
+// scipy.io.netcdf_file; no libMesh / ParaView exists here to open it, which is all the pinning this format gets.
+namespace {
+
+struct NcWriter {
+    std::vector<unsigned char> hdr;
+    void i32(int32_t v)
+    {
+        for (int s = 24; s >= 0; s -= 8) hdr.push_back((unsigned char)((uint32_t)v >> s));
+    }
+    void i64(int64_t v)
+    {
+        for (int s = 56; s >= 0; s -= 8) hdr.push_back((unsigned char)((uint64_t)v >> s));
+    }
+    void name(const std::string &n)
+    {
+        i32((int32_t)n.size());
+        hdr.insert(hdr.end(), n.begin(), n.end());
+        while (hdr.size() % 4) hdr.push_back(0);
+    }
+};
+
+enum { NC_CHAR = 2, NC_INT = 4, NC_FLOAT = 5, NC_DOUBLE = 6 };
+
+struct NcAtt {
+    std::string name;
+    int type;
+    std::string text;          // NC_CHAR
+    std::vector<int32_t> ints; // NC_INT
+    std::vector<float> floats; // NC_FLOAT
+};
+
+struct NcVar {
+    std::string name;
+    int type;
+    std::vector<int> dims;      // dimension ids; a leading record dimension makes it a record variable
+    std::vector<NcAtt> atts;
+    std::vector<unsigned char> data; // big-endian payload (record variables: one record)
+    int64_t begin = 0;
+};
+
+void put_be(std::vector<unsigned char> &d, int32_t v)
+{
+    for (int s = 24; s >= 0; s -= 8) d.push_back((unsigned char)((uint32_t)v >> s));
+}
+void put_be(std::vector<unsigned char> &d, double x)
+{
+    uint64_t v;
+    std::memcpy(&v, &x, 8);
+    for (int s = 56; s >= 0; s -= 8) d.push_back((unsigned char)(v >> s));
+}
+
+void write_atts(NcWriter &w, const std::vector<NcAtt> &atts)
+{
+    if (atts.empty()) {
+        w.i32(0);
+        w.i32(0);
+        return;
+    }
+    w.i32(0x0C);
+    w.i32((int32_t)atts.size());
+    for (const NcAtt &a : atts) {
+        w.name(a.name);
+        w.i32(a.type);
+        if (a.type == NC_CHAR) {
+            w.i32((int32_t)a.text.size());
+            w.hdr.insert(w.hdr.end(), a.text.begin(), a.text.end());
+            while (w.hdr.size() % 4) w.hdr.push_back(0);
+        } else if (a.type == NC_INT) {
+            w.i32((int32_t)a.ints.size());
+            for (int32_t v : a.ints) w.i32(v);
+        } else {
+            w.i32((int32_t)a.floats.size());
+            for (float f : a.floats) {
+                uint32_t v;
+                std::memcpy(&v, &f, 4);
+                w.i32((int32_t)v);
+            }
+        }
+    }
+}
+
+} // namespace
+
+void write_exodus(const ShellMesh &m, const std::vector<double> &u, const std::string &path)
+{
+    const int32_t nn = m.n_nodes(), nt = m.n_tri(), nq = m.n_quad(), ne = nt + nq;
+    if ((int64_t)u.size() != 6ll * nn) throw std::runtime_error("write_exodus: solution vector has the wrong length");
+    // dimensions
+    struct Dim { std::string name; int32_t len; };
+    std::vector<Dim> dims = {{"len_string", 33}, {"len_line", 81}, {"four", 4}, {"len_name", 33}, {"time_step", 0},
+                             {"num_dim", 3}, {"num_nodes", nn}, {"num_elem", ne}, {"num_el_blk", (nt > 0) + (nq > 0)},
+                             {"num_nod_var", 6}};
+    enum { D_STRING = 0, D_LINE, D_FOUR, D_NAME, D_TIME, D_DIM, D_NODES, D_ELEM, D_BLK, D_NODVAR };
+    std::vector<NcVar> vars;
+    auto chars = [](const std::vector<std::string> &rows, int width) {
+        std::vector<unsigned char> d;
+        for (const std::string &r : rows)
+            for (int i = 0; i < width; i++) d.push_back(i < (int)r.size() ? (unsigned char)r[(size_t)i] : 0);
+        return d;
+    };
+    {
+        NcVar v{"time_whole", NC_DOUBLE, {D_TIME}, {}, {}};
+        put_be(v.data, 0.0);
+        vars.push_back(v);
+    }
+    const int nblk = dims[D_BLK].len;
+    {
+        NcVar st{"eb_status", NC_INT, {D_BLK}, {}, {}}, pr{"eb_prop1", NC_INT, {D_BLK}, {{"name", NC_CHAR, "ID", {}, {}}}, {}};
+        for (int b = 0; b < nblk; b++) {
+            put_be(st.data, (int32_t)1);
+            put_be(pr.data, (int32_t)(b + 1));
+        }
+        vars.push_back(st);
+        vars.push_back(pr);
+        NcVar names{"eb_names", NC_CHAR, {D_BLK, D_NAME}, {}, chars(std::vector<std::string>((size_t)nblk, ""), 33)};
+        vars.push_back(names);
+    }
+    for (int d = 0; d < 3; d++) {
+        NcVar c{std::string("coord") + "xyz"[d], NC_DOUBLE, {D_NODES}, {}, {}};
+        c.data.reserve((size_t)nn * 8);
+        for (int32_t n = 0; n < nn; n++) put_be(c.data, m.xyz[3 * (size_t)n + d] + u[6 * (size_t)n + d]); // displaced mesh
+        vars.push_back(std::move(c));
+    }
+    vars.push_back(NcVar{"coor_names", NC_CHAR, {D_DIM, D_NAME}, {}, chars({"x", "y", "z"}, 33)});
+    // element blocks: triangles first, then quadrilaterals; elem_num_map keeps the file-order numbers
+    std::vector<int32_t> order_t, order_q;
+    for (int32_t e = 0; e < ne; e++) {
+        const bool tri = m.order.empty() ? e < nt : m.order[(size_t)e].first == 't';
+        (tri ? order_t : order_q).push_back(e);
+    }
+    int blk = 0;
+    for (int kind = 0; kind < 2; kind++) {
+        const std::vector<int32_t> &lst = kind == 0 ? order_t : order_q;
+        if (lst.empty()) continue;
+        blk++;
+        const int npe = kind == 0 ? 3 : 4;
+        dims.push_back({"num_el_in_blk" + std::to_string(blk), (int32_t)lst.size()});
+        dims.push_back({"num_nod_per_el" + std::to_string(blk), npe});
+        NcVar c{"connect" + std::to_string(blk), NC_INT, {(int)dims.size() - 2, (int)dims.size() - 1},
+                {{"elem_type", NC_CHAR, kind == 0 ? "TRI3" : "QUAD4", {}, {}}}, {}};
+        c.data.reserve(lst.size() * (size_t)npe * 4);
+        for (int32_t e : lst)
+            for (int32_t nd : m.element_nodes(e)) put_be(c.data, (int32_t)(nd + 1));
+        vars.push_back(std::move(c));
+    }
+    {
+        NcVar em{"elem_num_map", NC_INT, {D_ELEM}, {}, {}}, nm{"node_num_map", NC_INT, {D_NODES}, {}, {}};
+        for (int32_t e : order_t) put_be(em.data, (int32_t)(e + 1));
+        for (int32_t e : order_q) put_be(em.data, (int32_t)(e + 1));
+        for (int32_t n = 0; n < nn; n++) put_be(nm.data, (int32_t)(n + 1));
+        vars.push_back(std::move(em));
+        vars.push_back(std::move(nm));
+    }
+    vars.push_back(NcVar{"name_nod_var", NC_CHAR, {D_NODVAR, D_NAME}, {}, chars({"u", "v", "w", "tx", "ty", "tz"}, 33)});
+    for (int v = 0; v < 6; v++) {
+        NcVar nv{"vals_nod_var" + std::to_string(v + 1), NC_DOUBLE, {D_TIME, D_NODES}, {}, {}};
+        nv.data.reserve((size_t)nn * 8);
+        for (int32_t n = 0; n < nn; n++) put_be(nv.data, u[6 * (size_t)n + v]);
+        vars.push_back(std::move(nv));
+    }
+    const std::vector<NcAtt> gatts = {{"api_version", NC_FLOAT, "", {}, {5.22f}}, {"version", NC_FLOAT, "", {}, {5.22f}},
+                                      {"floating_point_word_size", NC_INT, "", {8}, {}}, {"file_size", NC_INT, "", {1}, {}},
+                                      {"maximum_name_length", NC_INT, "", {32}, {}},
+                                      {"title", NC_CHAR, "fem-shell displaced mesh (libfemshell, MI355X)", {}, {}}};
+    auto padded = [](size_t n) { return (n + 3) & ~(size_t)3; };
+    auto is_record = [&](const NcVar &v) { return !v.dims.empty() && v.dims[0] == D_TIME; };
+    // two passes over the header: the first fixes its length, the second knows every variable's offset
+    int64_t header_len = 0;
+    std::vector<unsigned char> header;
+    for (int pass = 0; pass < 2; pass++) {
+        int64_t off = header_len;
+        for (NcVar &v : vars)
+            if (!is_record(v)) {
+                v.begin = off;
+                off += (int64_t)padded(v.data.size());
+            }
+        for (NcVar &v : vars)
+            if (is_record(v)) {
+                v.begin = off;
+                off += (int64_t)padded(v.data.size());
+            }
+        NcWriter w;
+        w.hdr = {'C', 'D', 'F', 2};
+        w.i32(1); // one record (time step)
+        w.i32(0x0A);
+        w.i32((int32_t)dims.size());
+        for (const Dim &d : dims) {
+            w.name(d.name);
+            w.i32(d.len);
+        }
+        write_atts(w, gatts);
+        w.i32(0x0B);
+        w.i32((int32_t)vars.size());
+        for (const NcVar &v : vars) {
+            w.name(v.name);
+            w.i32((int32_t)v.dims.size());
+            for (int d : v.dims) w.i32(d);
+            write_atts(w, v.atts);
+            w.i32(v.type);
+            w.i32((int32_t)padded(v.data.size())); // vsize (record variables: one record)
+            w.i64(v.begin);
+        }
+        header_len = (int64_t)w.hdr.size();
+        header.swap(w.hdr);
+    }
+    std::ofstream os(path, std::ios::binary);
+    if (!os) throw std::runtime_error("cannot write " + path);
+    os.write(reinterpret_cast<const char *>(header.data()), (std::streamsize)header.size());
+    static const char zeros[4] = {0, 0, 0, 0};
+    for (int rec = 0; rec < 2; rec++)
+        for (const NcVar &v : vars)
+            if (is_record(v) == (rec == 1)) {
+                os.write(reinterpret_cast<const char *>(v.data.data()), (std::streamsize)v.data.size());
+                os.write(zeros, (std::streamsize)(padded(v.data.size()) - v.data.size()));
+            }
+    if (!os) throw std::runtime_error("cannot write " + path);
+}
+
 } // namespace femshell_host

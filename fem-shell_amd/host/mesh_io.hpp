@@ -84,8 +84,10 @@ ShellMesh generate_structured(const MeshGenArgs &a);
 // writes "<name>.xda" and, if loading > 0, "<name>_f" in the reference tool's format
 void write_meshgen_files(const MeshGenArgs &a, const std::string &name);
 
-// legacy-VTK dump of the displaced mesh with the six solution fields (the reference writes
-// ExodusII through libMesh, fem-shell.cpp:1240-1251; ExodusII needs netCDF, absent here)
+// the reference's output (fem-shell.cpp:1240-1251, "<out>.e"): ExodusII file of the displaced mesh with the nodal variables
+// u, v, w, tx, ty, tz, written as a classic netCDF (CDF-2) file by hand -- the image has no netCDF library (mesh_io.cpp)
+void write_exodus(const ShellMesh &m, const std::vector<double> &u6, const std::string &path);
+// legacy-VTK dump of the same content (kept beside the ExodusII file: every viewer reads it)
 void write_vtk(const ShellMesh &m, const std::vector<double> &u6, const std::string &path);
 
 } // namespace femshell_host

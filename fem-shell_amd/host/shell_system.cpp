@@ -328,7 +328,10 @@ int fem_shell_main(int argc, char **argv, std::ostream &out, std::ostream &err)
             out << ", tx= " << s[3] << ", ty= " << s[4] << ", tz= " << s[5] << "]" << std::endl;
         }
         out << "]" << std::endl << std::endl;
-        if (p.isOutfileSet) write_vtk(mesh, sols, p.out_filename + ".vtk");
+        if (p.isOutfileSet) {
+            write_exodus(mesh, sols, p.out_filename + ".e"); // the reference's file (fem-shell.cpp:1249)
+            write_vtk(mesh, sols, p.out_filename + ".vtk");
+        }
         out << "All done :)\n";
         return res.converged ? 0 : 2;
     } catch (const std::exception &e) {

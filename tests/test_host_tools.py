@@ -140,6 +140,11 @@ def test_cli_reproduces_thesis_values(tools, tmp_path):
     assert u[22, 0] == pytest.approx(-0.0255988, abs=6e-8) and u[22, 1] == pytest.approx(0.0629549, abs=6e-8)
     assert u[26, 0] == pytest.approx(-0.0342621, abs=6e-8) and u[26, 1] == pytest.approx(0.1944070, abs=6e-7)
     assert os.path.exists(str(tmp_path / "A.vtk"))
+    ex = _read_exodus(str(tmp_path / "A.e"))  # the reference's output file (fem-shell.cpp:1249): displaced mesh + u, v, w, tx, ty, tz
+    m = meshes.load_example("test_A_uv_t")
+    for v in range(6):
+        np.testing.assert_allclose(ex["vals_nod_var%d" % (v + 1)][0], u[:, v], rtol=1e-5, atol=1e-12)  # stdout keeps 6 digits
+    np.testing.assert_allclose(ex["coordx"], m.xyz[:, 0] + ex["vals_nod_var1"][0], rtol=0, atol=1e-15)
     mesh = os.path.join(meshes.MESH_DIR, "test_C_w_tA16.xda")
     r = subprocess.run([fem, "-nu", "0.3", "-e", "10.92", "-t", "1.0", "-mesh", mesh], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -313,6 +318,48 @@ def test_binary_xdr_round_trip(tools, tmp_path):
     assert txt.startswith("libMesh-0.9.2+") and "# number of nodesets" in txt
     subprocess.check_call([conv, str(tmp_path / "two.xda"), str(tmp_path / "two2.xdr")])
     assert open(tmp_path / "two.xdr", "rb").read() == open(tmp_path / "two2.xdr", "rb").read()
+
+
+def _read_exodus(path):
+    from scipy.io import netcdf_file
+
+    with netcdf_file(path, "r", mmap=False) as f:
+        out = {"dims": dict(f.dimensions), "title": f.title.decode(), "word": int(f.floating_point_word_size)}
+        for k, v in f.variables.items():
+            out[k] = np.array(v[:])
+            if hasattr(v, "elem_type"):
+                out[k + ".elem_type"] = v.elem_type.decode()
+    return out
+
+
+@pytest.mark.parametrize("name", ["test_A_uv_t", "test_B_uv_q"])
+def test_exodus_file_reads_back(tools, tmp_path, name):
+    """fem-shell.cpp:1240-1251 writes "<out>.e" through libMesh's ExodusII_IO; here the file is a hand-written classic
+    netCDF (CDF-2) file with ExodusII's dimensions and variables (host/mesh_io.cpp write_exodus).  Read back with scipy's
+    netCDF reader: displaced coordinates, 1-based connectivity per element block, the six nodal variables."""
+    conv = os.path.join(HOST, "meshConvert")
+    src = os.path.join(meshes.MESH_DIR, name + ".xda")
+    out = str(tmp_path / (name + ".e"))
+    subprocess.check_call([conv, src, out, "ramp"])
+    assert open(out, "rb").read(4) == b"CDF\x02"
+    m = meshes.read_xda(src)
+    e = _read_exodus(out)
+    n = m.n_nodes
+    assert e["dims"]["num_nodes"] == n and e["dims"]["num_elem"] == len(m.tri) + len(m.quad) and e["dims"]["num_dim"] == 3
+    assert e["dims"]["time_step"] is None and e["dims"]["num_nod_var"] == 6 and e["word"] == 8
+    u = 1e-3 * np.outer(np.arange(1, n + 1), np.arange(1, 7))
+    for d, c in enumerate("xyz"):
+        np.testing.assert_allclose(e["coord" + c], m.xyz[:, d] + u[:, d], rtol=1e-15, atol=1e-17)  # the displaced mesh (fem-shell.cpp:172-175)
+    names = ["".join(ch.decode() for ch in row).rstrip("\x00") for row in e["name_nod_var"]]
+    assert names == ["u", "v", "w", "tx", "ty", "tz"]
+    for v in range(6):
+        np.testing.assert_allclose(e["vals_nod_var%d" % (v + 1)], u[None, :, v], rtol=1e-15, atol=0)
+    np.testing.assert_array_equal(e["time_whole"], [0.0])
+    conn = m.tri if len(m.tri) else m.quad
+    assert e["connect1.elem_type"] == ("TRI3" if len(m.tri) else "QUAD4")
+    np.testing.assert_array_equal(e["connect1"], conn + 1)
+    np.testing.assert_array_equal(e["elem_num_map"], np.arange(1, len(conn) + 1))
+    np.testing.assert_array_equal(e["node_num_map"], np.arange(1, n + 1))
 
 
 def test_gmsh_boundary_lines_are_resolved_through_a_side_table(tools, tmp_path):
