@@ -69,60 +69,133 @@ __global__ __launch_bounds__(256) void k_dense_symmetrize(double *__restrict__ D
     if (r == c) diag0[r] = v;
 }
 
-// B = (pivot block K)^-1 by 64 scalar symmetric sweeps in LDS; status[0] = 1 on a clearly negative pivot, status[1] counts
-// the dropped directions
+// B = (pivot block K)^-1; status[0] = 1 on a clearly negative pivot, status[1] counts the dropped directions.  One
+// workgroup; thread (bi, bj) keeps the 4 x 4 sub-block (4 bi .., 4 bj ..) of the 64 x 64 block in registers and the block is
+// swept four pivots at a time: the four rows of a step (= its four columns: the block stays symmetric) travel through a
+// double-buffered LDS panel, every thread sweeps the 4 x 4 pivot sub-block itself (scalar symmetric sweeps with the pivot
+// test) and applies the rank-4 update to its registers: 16 steps with one barrier each.  (Swept in LDS one pivot at a time
+// with three barriers per pivot the kernel took as long as the trailing update of the whole matrix, 111 us per step.)
 __global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ D, int64_t ld, int K, const double *__restrict__ diag0,
                                                      double *__restrict__ B, int32_t *status)
 {
-    __shared__ double S[kNB][kNB + 1];
+    __shared__ double rowbuf[2][4][kNB];
     __shared__ double a0[kNB];
-    const int tid = threadIdx.x, k0 = K * kNB;
-    for (int e = tid; e < kNB * kNB; e += 256) {
-        const int r = e / kNB, c = e % kNB;
-        S[r][c] = r >= c ? D[(int64_t)(k0 + r) * ld + k0 + c] : D[(int64_t)(k0 + c) * ld + k0 + r];
-    }
+    const int tid = threadIdx.x, k0 = K * kNB, bi = tid >> 4, bj = tid & 15;
+    double s[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int r = 4 * bi + a, c = 4 * bj + b;
+            s[a][b] = r >= c ? D[(int64_t)(k0 + r) * ld + k0 + c] : D[(int64_t)(k0 + c) * ld + k0 + r];
+        }
     if (tid < kNB) a0[tid] = diag0[k0 + tid];
-    __syncthreads();
-    for (int p = 0; p < kNB; p++) {
-        const double d = S[p][p], a = a0[p]; // uniform: every thread reads the same words
-        const bool failed = !(a > 0.0) || d < -1e-4 * fabs(a);
-        const bool dead = failed || d <= 1e-11 * a;
-        if (dead) {
-            __syncthreads();
-            if (tid < kNB) {
-                S[p][tid] = 0.0;
-                S[tid][p] = 0.0;
-            }
-            if (tid == 0) {
-                if (failed) status[0] = 1;
-                atomicAdd(&status[1], 1);
-            }
-            __syncthreads();
-            continue;
-        }
-        const double inv = 1.0 / d;
-        for (int e = tid; e < kNB * kNB; e += 256) {
-            const int i = e / kNB, j = e % kNB;
-            if (i != p && j != p) S[i][j] -= S[i][p] * S[p][j] * inv;
+    int n_dead = 0, n_failed = 0;
+    for (int g = 0; g < kNB / 4; g++) {
+        const int cur = g & 1;
+        if (bi == g) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) rowbuf[cur][k][4 * bj + b] = s[k][b];
         }
         __syncthreads();
-        if (tid < kNB) {
-            if (tid == p) {
-                S[p][p] = -inv;
-            } else {
-                const double v = S[tid][p] * inv;
-                S[tid][p] = v;
-                S[p][tid] = v;
+        // the 4 x 4 pivot sub-block, swept to minus its inverse on the live directions (every thread does the same)
+        double m[4][4];
+        bool dead[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int l = 0; l < 4; l++) m[k][l] = rowbuf[cur][k][4 * g + l];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double d = m[k][k], a = a0[4 * g + k];
+            const bool failed = !(a > 0.0) || d < -1e-4 * fabs(a);
+            dead[k] = failed || d <= 1e-11 * a;
+            n_failed += failed ? 1 : 0;
+            n_dead += dead[k] ? 1 : 0;
+            const double inv = dead[k] ? 0.0 : 1.0 / d;
+            double col[4];
+#pragma unroll
+            for (int l = 0; l < 4; l++) col[l] = m[l][k];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (i == k || j == k) continue;
+                    m[i][j] -= col[i] * col[j] * inv; // (dead: inv = 0, nothing moves)
+                }
+#pragma unroll
+            for (int l = 0; l < 4; l++) {
+                if (l == k) continue;
+                const double v = col[l] * inv; // dead: zero row and column
+                m[l][k] = v;
+                m[k][l] = v;
             }
+            m[k][k] = -inv;
         }
-        __syncthreads();
+        // rows of the step as they were before it, for the thread's rows and columns: R[k][.] with R = rows 4g .. 4g+3
+        double ri[4][4], rj[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                ri[k][q] = rowbuf[cur][k][4 * bi + q];
+                rj[k][q] = rowbuf[cur][k][4 * bj + q];
+            }
+        // block sweep with B4 = -m:  S_ij <- S_ij - R_i^T B4 R_j;  rows of the step <- B4 R_j;  columns <- (B4 R_i)^T;  pivot block <- m
+        double ti[4][4]; // ti[a][l] = sum_k ri[k][a] B4[k][l]
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int l = 0; l < 4; l++) {
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) v -= ri[k][a] * m[k][l];
+                ti[a][l] = v;
+            }
+        if (bi == g && bj == g) {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) s[a][b] = m[a][b];
+        } else if (bi == g) { // row panel: B4 R_j
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int l = 0; l < 4; l++) v -= m[a][l] * rj[l][b];
+                    s[a][b] = v;
+                }
+        } else if (bj == g) { // column panel: (B4 R_i)^T = R_i^T B4
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) s[a][b] = ti[a][b];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    double v = s[a][b];
+#pragma unroll
+                    for (int l = 0; l < 4; l++) v -= ti[a][l] * rj[l][b];
+                    s[a][b] = v;
+                }
+        }
     }
-    for (int e = tid; e < kNB * kNB; e += 256) B[e] = -S[e / kNB][e % kNB]; // the sweeps leave -inverse
+    if (tid == 0 && n_dead) {
+        if (n_failed) status[0] = 1;
+        atomicAdd(&status[1], n_dead);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) B[(4 * bi + a) * kNB + 4 * bj + b] = -s[a][b]; // the sweeps leave -inverse
 }
 
-// 32 x 32 quadrant (r0, c0) of X Y^T for two staged 64 x 64 operands (row stride kLdp): acc[ti][tj], tile (ti, tj) of the
-// quadrant.  Operand maps of v_mfma_f64_16x16x4_f64: lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15]; result register g
-// of lane l is D[(l >> 4) + 4 g][l & 15].  B[k][n] = Y[n][k]: both operands are read as (row l & 15, k l >> 4).
 template <int kDepth, int kStride>
 __device__ __forceinline__ void quadrant_xyt(const double *Xs, const double *Ys, int r0, int c0, int lane, v4d acc[2][2])
 {

@@ -11,7 +11,7 @@ out = open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout
 agg = defaultdict(lambda: [0, 0])
 ev = []
 for r in rows:
-    name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("femshell::", "")
+    name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "").replace("femshell::", "")
     grid = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
     wg = int(r.get("Workgroup_Size", r.get("Workgroup_Size_X", 1)) or 1)
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])

@@ -5,7 +5,7 @@
 #   gpurun_out/<tag>_pmc_hbm_traffic.json  FETCH_SIZE / WRITE_SIZE, one counter per pass (tools/pmc_summary.py)
 # Every profiler pass runs under its own timeout; no TA_* counters (they hang rocprofv3 on this pool).
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
@@ -27,6 +27,10 @@ rm -rf $out/${tag}_pmc_SQ_INSTS_VALU_FMA_F64 $out/${tag}_pmc_SQ_INSTS_VALU_MUL_F
 # keep the merged-back directory small: the raw counter tables are large
 rm -rf $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_stats
 tail -1 $out/${tag}_bench.json
-# the other two BASELINE workloads at full size (no CPU baseline, no direct-solve parity: those are in the panel run)
-timeout 400 python3 bench.py --workload cylinder --no-cpu-baseline --no-full-parity > $out/${tag}_bench_cylinder.json 2> $out/${tag}_bench_cylinder.err
+# configs[1] at full size as a run of its own (configs[2], the cylinder, is part of the default bench line)
 timeout 400 python3 bench.py --workload roof --no-cpu-baseline --no-full-parity --jacobi-probe-iters 0 > $out/${tag}_bench_roof.json 2> $out/${tag}_bench_roof.err
+# the multigrid solve: kernel statistics and the same trace by (kernel, grid size) = by level of the hierarchy
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_amg_stats -o a -- python3 tools/amg_probe.py panel 1414 > $out/${tag}_amg_probe.txt 2> $out/${tag}_amg_stats.err
+cp $(find $out/${tag}_amg_stats -name "*kernel_stats.csv" | head -1) $out/${tag}_amg_kernel_stats.csv 2> /dev/null
+python3 tools/kernel_trace_by_grid.py $(find $out/${tag}_amg_stats -name "*kernel_trace.csv" | head -1) $out/${tag}_amg_kernels_by_level.txt
+rm -rf $out/${tag}_amg_stats
