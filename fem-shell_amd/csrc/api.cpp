@@ -503,7 +503,8 @@ static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double 
         tri = tri_r.data();
         quad = quad_r.data();
     }
-    if (!build_plan(n_nodes, xyz, n_tri, tri, n_quad, quad, c->cfg.rank, c->cfg.world_size, &c->plan, &e, default_symmetric_storage()))
+    if (!build_plan(n_nodes, xyz, n_tri, tri, n_quad, quad, c->cfg.rank, c->cfg.world_size, &c->plan, &e, default_symmetric_storage(),
+                    /* geometric orientation of the symmetric storage when the library chose the numbering: */ !c->perm.empty()))
         return set_err(FEMSHELL_ERR_MESH, "femshell_set_mesh: " + e);
     if (c->amg_shadow) { // belongs to the previous mesh
         (void)femshell_destroy(c->amg_shadow);

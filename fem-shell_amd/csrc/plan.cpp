@@ -107,7 +107,7 @@ bool default_symmetric_storage()
 }
 
 bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri, int32_t n_quad,
-                const int32_t *quad, int rank, int world, Plan *P, std::string *err, bool symmetric)
+                const int32_t *quad, int rank, int world, Plan *P, std::string *err, bool symmetric, bool geometric_orientation)
 {
     auto fail = [&](const std::string &m) {
         if (err) *err = m;
@@ -283,13 +283,32 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         auto index_of = [&](int32_t row, int32_t col) -> int64_t {
             return std::lower_bound(nb.begin() + nb_ptr[row], nb.begin() + nb_ptr[row + 1], col) - nb.begin();
         };
-        plan_parallel(n_own, 4096, [&](int, int64_t a0, int64_t a1) { // start: the lower-numbered row keeps the block
+        // start: the lower-numbered row keeps the block -- or, for numberings that are not monotone along the mesh (Morton,
+        // Cuthill-McKee, arbitrary input), the row from which the neighbour lies in the "positive half space" (first
+        // non-zero coordinate difference positive): every interior node of a triangulation sees about half of its
+        // neighbours there whatever the numbering is (exactly three on the structured grids)
+        // (the caller asks for it when the library renumbered the nodes itself; FEMSHELL_SYM_ORIENT=geom|index overrides.
+        //  4M-triangle panel, Morton numbering: SpMV 0.466 -> 0.456 ms, Hilbert 0.546 -> 0.453 ms; row-major: same plan)
+        const char *oe = getenv("FEMSHELL_SYM_ORIENT");
+        const bool geometric = oe ? std::strcmp(oe, "geom") == 0 : geometric_orientation;
+        plan_parallel(n_own, 4096, [&](int, int64_t a0, int64_t a1) {
             for (int64_t a = a0; a < a1; a++)
-                for (int64_t q = nb_ptr[a]; q < nb_ptr[a + 1]; q++)
-                    if (nb[q] > a) {
+                for (int64_t q = nb_ptr[a]; q < nb_ptr[a + 1]; q++) {
+                    const int32_t c = nb[q];
+                    bool mine = c > a;
+                    if (geometric) {
+                        const double *xa = xyz + 3ll * (g0 + a), *xc = xyz + 3ll * (g0 + c);
+                        for (int d = 0; d < 3; d++)
+                            if (xc[d] != xa[d]) {
+                                mine = xc[d] > xa[d];
+                                break;
+                            }
+                    }
+                    if (mine) {
                         nb_mine[q] = 1;
                         cnt[a]++;
                     }
+                }
         });
         // local repair towards the mean
         const int target = (int)((nb.size() / 2 + (size_t)n_own - 1) / (size_t)std::max(n_own, 1));

@@ -132,7 +132,8 @@ void partition_bounds(int32_t n_nodes, int32_t n_tri, const int32_t *tri, int32_
 // Builds the plan.  Returns false and sets err on invalid input (index out of range,
 // repeated node in an element, too many elements).
 bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri, int32_t n_quad,
-                const int32_t *quad, int rank, int world, Plan *plan, std::string *err, bool symmetric = false);
+                const int32_t *quad, int rank, int world, Plan *plan, std::string *err, bool symmetric = false,
+                bool geometric_orientation = false);
 // the library's default storage: symmetric unless FEMSHELL_SYMMETRIC=0
 bool default_symmetric_storage();
 

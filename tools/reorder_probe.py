@@ -44,6 +44,7 @@ n = m.n_nodes
 ix = np.arange(n) % (nx + 1); iy = np.arange(n) // (nx + 1)
 orders = {"row-major (as generated)": None,
           "tiles 8x4": np.argsort(tile_index(ix, iy, 8, 4, nx + 1), kind="stable"),
+          "tiles 4x8": np.argsort(tile_index(ix, iy, 4, 8, nx + 1), kind="stable"),
           "tiles 16x2": np.argsort(tile_index(ix, iy, 16, 2, nx + 1), kind="stable"),
           "hilbert": np.argsort(hilbert_index(ix, iy, 11), kind="stable"),
           "morton": np.argsort(morton_index(ix, iy, 11), kind="stable")}
