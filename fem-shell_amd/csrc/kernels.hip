@@ -243,6 +243,18 @@ __global__ void k_block_jacobi(DeviceMatrix m)
         for (int j = i; j < 6; j++) mi[minv_word(i, j) * kSliceNodes] = B[i][j];
 }
 
+__global__ void k_status_flags(const int32_t *__restrict__ status, double *__restrict__ agree)
+{
+    const int32_t st = *status;
+    agree[0] = st > 0 ? 1.0 : 0.0;
+    agree[1] = st < 0 ? 1.0 : 0.0;
+}
+
+void launch_status_flags(const int32_t *status, double *agree, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_status_flags, dim3(1), dim3(1), 0, st, status, agree);
+}
+
 void launch_block_jacobi(const DeviceMatrix &m, hipStream_t st)
 {
     hipLaunchKernelGGL(k_block_jacobi, dim3((m.n_pad + 127) / 128), dim3(128), 0, st, m);

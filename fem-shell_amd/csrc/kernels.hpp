@@ -123,6 +123,9 @@ void launch_rhs(const DeviceMatrix &m, const double *loads /* n_pad x 6 */, doub
 // fills m.item_flags from cols / dmask / pair_ptr (after every change of the Dirichlet set)
 void launch_item_flags(const DeviceMatrix &m, int64_t n_items, hipStream_t st);
 void launch_block_jacobi(const DeviceMatrix &m, hipStream_t st);
+// agree[0] = 1 if *status > 0 (degenerate element), agree[1] = 1 if *status < 0 (singular diagonal block): the counters the
+// ranks of a row partition sum up after an assembly / block-Jacobi setup
+void launch_status_flags(const int32_t *status, double *agree, hipStream_t st);
 void launch_element_matrices(const DeviceMatrix &m, const MatConst &mc, int32_t first, int32_t count,
                              double *Ke_out, hipStream_t st);
 
