@@ -162,3 +162,56 @@ def test_row_partitioned_cg_matches_single_process(world, single_reduction):
     # solve that moves its iteration count by tens of percent, not its answer
     assert abs(its[0] - info["iterations"]) <= (0.25 * info["iterations"] if single_reduction else 3)
     assert np.linalg.norm(u - u_ref) <= 1e-9 * np.linalg.norm(u_ref)
+
+
+def test_bench_cpu_baseline_worker_runs_on_a_small_panel():
+    """bench.py's cpu_baseline leg runs in a child process with bound OpenMP threads (OMP_PROC_BIND / OMP_PLACES have to be
+    in the environment before the runtime starts); the child is exercised here on a 60 x 60 panel: thread sweep, STREAM
+    triad, first touch inside the threaded loops -- and the threaded assembly gives the serial checker's matrix."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_PROC_BIND="spread", OMP_PLACES="cores")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-baseline-worker", "--nx", "60"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["kind"] == "port" and out["unit"] == "elements/s" and out["value"] > 0 and out["cg_iters_per_s"] > 0
+    assert out["omp"]["OMP_PROC_BIND"] == "spread" and out["host_stream_triad_gb_per_s"] > 0
+    assert any(s["threads"] == 1 for s in out["thread_sweep"]) and out["single_thread"]["value"] > 0
+    assert "7200 tri3" in out["sample"]
+
+
+def test_threaded_baseline_assembly_equals_the_serial_checker():
+    """The CPU-baseline build of the oracle (-O3 -march=native -fopenmp) assembles by node ranges with per-thread element
+    lists (oracle/femshell_oracle.c ownership_lists): on 1, 3 and 8 threads it gives the matrix of the serial checker
+    build, also after the mesh behind the same pointers changed (the lists are keyed on a hash of the connectivity)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from tests.helpers import meshes, oracle
+mat = oracle.material(0.3, 1e7, 0.5)
+ms = [meshes.structured(40, 30, 0, 0, 10, 9, kind="t", ul_lr=u, bcids=(0, 1, 0, 1), factor=300.0, loading=2) for u in (True, False)]
+ref = [oracle.assemble(m.xyz, m.tri, m.quad, mat, m.dirichlet_mask(), m.loads) for m in ms]
+oracle.use_fast_build(1)
+tri = np.array(ms[0].tri, dtype=np.int32)                  # one buffer for both meshes: same pointer, other connectivity
+for th in (1, 3, 8, 3):
+    oracle.set_threads(th)
+    for m, (r0, c0, v0, F0) in zip(ms, ref):
+        tri[:] = m.tri
+        r1, c1, v1, F1 = oracle.assemble(m.xyz, tri, m.quad, mat, m.dirichlet_mask(), m.loads)
+        assert np.array_equal(r1, r0) and np.array_equal(c1, c0) and np.array_equal(F1, F0)
+        assert np.abs(v1 - v0).max() <= 1e-15 * np.abs(v0).max(), (th, np.abs(v1 - v0).max())
+print("ok")
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
