@@ -32,8 +32,9 @@ namespace femshell {
 namespace {
 
 constexpr int kNB = 64;   // tile edge
-constexpr int kLdp = 66;  // LDS row stride of a staged 64 x 64 operand (doubles)
-constexpr int kHalf = 32, kLdh = 34; // k_dense_update stages its operands in two halves of K
+constexpr int kSW = 128;  // sweep width: two tiles per block sweep (halves the passes over the lower triangle)
+constexpr int kLdp = 66;  // LDS row stride of a transposed 64 x 64 tile (doubles)
+constexpr int kHalf = 32, kLdh = 34; // the matrix-core kernels stage their operands in chunks of 32 columns of K
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 // D (n_pad x n_pad, row-major, zero-initialised) <- the blocks of the host BSR matrix
@@ -69,28 +70,16 @@ __global__ __launch_bounds__(256) void k_dense_symmetrize(double *__restrict__ D
     if (r == c) diag0[r] = v;
 }
 
-// B = (pivot block K)^-1; status[0] = 1 on a clearly negative pivot, status[1] counts the dropped directions.  One
-// workgroup; thread (bi, bj) keeps the 4 x 4 sub-block (4 bi .., 4 bj ..) of the 64 x 64 block in registers and the block is
-// swept four pivots at a time: the four rows of a step (= its four columns: the block stays symmetric) travel through a
+// ---- the 64 x 64 building block: s <- -(s^-1) on the live directions ---------------------------------------------
+// Thread (bi, bj) of a 256-thread workgroup keeps the 4 x 4 sub-block (4 bi .., 4 bj ..) of a symmetric 64 x 64 block in
+// registers; the block is swept four pivots at a time: the four rows of a step (= its four columns) travel through a
 // double-buffered LDS panel, every thread sweeps the 4 x 4 pivot sub-block itself (scalar symmetric sweeps with the pivot
-// test) and applies the rank-4 update to its registers: 16 steps with one barrier each.  (Swept in LDS one pivot at a time
-// with three barriers per pivot the kernel took as long as the trailing update of the whole matrix, 111 us per step.)
-__global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ D, int64_t ld, int K, const double *__restrict__ diag0,
-                                                     double *__restrict__ B, int32_t *status)
+// test against the ORIGINAL diagonal a0) and applies the rank-4 update to its registers: 16 steps, one barrier each.
+// (Swept in LDS one pivot at a time with three barriers per pivot this took as long as the trailing update of the whole
+// matrix, 111 us per step at 7386 dofs.)
+__device__ __forceinline__ void sweep64(double s[4][4], const double *a0, double (*rowbuf)[4][kNB], int bi, int bj, int &n_dead,
+                                        int &n_failed)
 {
-    __shared__ double rowbuf[2][4][kNB];
-    __shared__ double a0[kNB];
-    const int tid = threadIdx.x, k0 = K * kNB, bi = tid >> 4, bj = tid & 15;
-    double s[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int r = 4 * bi + a, c = 4 * bj + b;
-            s[a][b] = r >= c ? D[(int64_t)(k0 + r) * ld + k0 + c] : D[(int64_t)(k0 + c) * ld + k0 + r];
-        }
-    if (tid < kNB) a0[tid] = diag0[k0 + tid];
-    int n_dead = 0, n_failed = 0;
     for (int g = 0; g < kNB / 4; g++) {
         const int cur = g & 1;
         if (bi == g) {
@@ -100,9 +89,7 @@ __global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ 
                 for (int b = 0; b < 4; b++) rowbuf[cur][k][4 * bj + b] = s[k][b];
         }
         __syncthreads();
-        // the 4 x 4 pivot sub-block, swept to minus its inverse on the live directions (every thread does the same)
         double m[4][4];
-        bool dead[4];
 #pragma unroll
         for (int k = 0; k < 4; k++)
 #pragma unroll
@@ -111,10 +98,17 @@ __global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ 
         for (int k = 0; k < 4; k++) {
             const double d = m[k][k], a = a0[4 * g + k];
             const bool failed = !(a > 0.0) || d < -1e-4 * fabs(a);
-            dead[k] = failed || d <= 1e-11 * a;
+            const bool dead = failed || d <= 1e-11 * a;
             n_failed += failed ? 1 : 0;
-            n_dead += dead[k] ? 1 : 0;
-            const double inv = dead[k] ? 0.0 : 1.0 / d;
+            n_dead += dead ? 1 : 0;
+            // reciprocal by the hardware estimate and two Newton steps (an IEEE division is a forty-instruction dependent
+            // chain, and four of them sit on the critical path of every step)
+            double inv = 0.0;
+            if (!dead) {
+                inv = __builtin_amdgcn_rcp(d);
+                inv = inv * (2.0 - d * inv);
+                inv = inv * (2.0 - d * inv);
+            }
             double col[4];
 #pragma unroll
             for (int l = 0; l < 4; l++) col[l] = m[l][k];
@@ -134,7 +128,6 @@ __global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ 
             }
             m[k][k] = -inv;
         }
-        // rows of the step as they were before it, for the thread's rows and columns: R[k][.] with R = rows 4g .. 4g+3
         double ri[4][4], rj[4][4];
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -143,8 +136,8 @@ __global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ 
                 ri[k][q] = rowbuf[cur][k][4 * bi + q];
                 rj[k][q] = rowbuf[cur][k][4 * bj + q];
             }
-        // block sweep with B4 = -m:  S_ij <- S_ij - R_i^T B4 R_j;  rows of the step <- B4 R_j;  columns <- (B4 R_i)^T;  pivot block <- m
-        double ti[4][4]; // ti[a][l] = sum_k ri[k][a] B4[k][l]
+        // block sweep with B4 = -m:  S_ij <- S_ij - R_i^T B4 R_j;  rows of the step <- B4 R_j;  columns <- R_i^T B4;  pivot block <- m
+        double ti[4][4];
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -159,7 +152,7 @@ __global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ 
             for (int a = 0; a < 4; a++)
 #pragma unroll
                 for (int b = 0; b < 4; b++) s[a][b] = m[a][b];
-        } else if (bi == g) { // row panel: B4 R_j
+        } else if (bi == g) {
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -169,7 +162,7 @@ __global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ 
                     for (int l = 0; l < 4; l++) v -= m[a][l] * rj[l][b];
                     s[a][b] = v;
                 }
-        } else if (bj == g) { // column panel: (B4 R_i)^T = R_i^T B4
+        } else if (bj == g) {
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -186,16 +179,12 @@ __global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ 
                 }
         }
     }
-    if (tid == 0 && n_dead) {
-        if (n_failed) status[0] = 1;
-        atomicAdd(&status[1], n_dead);
-    }
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) B[(4 * bi + a) * kNB + 4 * bj + b] = -s[a][b]; // the sweeps leave -inverse
+    __syncthreads(); // rowbuf may be reused
 }
 
+// 32 x 32 quadrant (r0, c0) of X Y^T for two staged operands of kDepth columns (row stride kStride): acc[ti][tj], tile (ti, tj)
+// of the quadrant.  Operand maps of v_mfma_f64_16x16x4_f64: lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15]; result
+// register g of lane l is D[(l >> 4) + 4 g][l & 15].  B[k][n] = Y[n][k]: both operands are read as (row l & 15, k l >> 4).
 template <int kDepth, int kStride>
 __device__ __forceinline__ void quadrant_xyt(const double *Xs, const double *Ys, int r0, int c0, int lane, v4d acc[2][2])
 {
@@ -215,48 +204,177 @@ __device__ __forceinline__ void quadrant_xyt(const double *Xs, const double *Ys,
     }
 }
 
-// C_i = A(i, K) gathered from the lower triangle (tile (i, K) below the pivot block, tile (K, i) transposed above it),
-// W_i = C_i B.  One workgroup per block row; block row K itself is skipped (its tile becomes -B).
-__global__ __launch_bounds__(256) void k_dense_panels(const double *__restrict__ D, int64_t ld, int K, const double *__restrict__ B,
-                                                      double *__restrict__ Cp, double *__restrict__ Wp)
+// element loop of the 32 x 32 quadrant a wave owns in the matrix-core layout: f(ti, tj, g, row, col)
+template <class F> __device__ __forceinline__ void for_quadrant(int r0, int c0, int lane, F f)
 {
-    extern __shared__ double lds_dense[]; // two staged operands (67.6 KB: beyond the static limit)
-    double *Cs = lds_dense, *Bs = lds_dense + kNB * kLdp;
-    const int i = blockIdx.x, tid = threadIdx.x;
-    if (i == K) return;
-    for (int e = tid; e < kNB * kNB; e += 256) {
-        const int r = e / kNB, c = e % kNB;
-        // (above the pivot block the read is a transposed one: column-wise in memory, once per step and block row)
-        const double v = i > K ? D[(int64_t)(i * kNB + r) * ld + K * kNB + c] : D[(int64_t)(K * kNB + c) * ld + i * kNB + r];
-        Cs[r * kLdp + c] = v;
-        Bs[r * kLdp + c] = B[e]; // symmetric: B^T = B, so W = C B = C (B^T)^T has the X Y^T form
-        Cp[(int64_t)(i * kNB + r) * kNB + c] = v;
-    }
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63, r0 = 32 * (wave >> 1), c0 = 32 * (wave & 1);
-    v4d acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-    quadrant_xyt<kNB, kLdp>(Cs, Bs, r0, c0, lane, acc);
 #pragma unroll
     for (int ti = 0; ti < 2; ti++)
 #pragma unroll
         for (int tj = 0; tj < 2; tj++)
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int r = r0 + 16 * ti + (lane >> 4) + 4 * g, c = c0 + 16 * tj + (lane & 15);
-                Wp[(int64_t)(i * kNB + r) * kNB + c] = acc[ti][tj][g];
-            }
+            for (int g = 0; g < 4; g++) f(ti, tj, g, r0 + 16 * ti + (lane >> 4) + 4 * g, c0 + 16 * tj + (lane & 15));
 }
 
-// one workgroup per lower tile (i >= j): the sweep of block K
-__global__ __launch_bounds__(256, 4) void k_dense_update(double *__restrict__ D, int64_t ld, int K, const double *__restrict__ B,
-                                                      const double *__restrict__ Cp, const double *__restrict__ Wp)
+// B (128 x 128) = inverse of the pivot block K = [[A, C^T], [C, D]] of the sweep (tiles (2K,2K), (2K+1,2K), (2K+1,2K+1)),
+// restricted to the live directions: B_A = A^-1, W = C B_A, S = D - W C^T, B_S = S^-1, then
+//   B = [[B_A + W^T B_S W, -W^T B_S], [-B_S W, B_S]].
+// One workgroup: the two 64 x 64 inverses by sweep64 (registers, thread per 4 x 4), the four 64^3 products on the matrix
+// cores from LDS (row stride 66: conflict-free; a product with thread-per-4x4 FMAs from LDS took 98 us per sweep, more than
+// the trailing update it feeds).  LDS: P0 = B_A, P1 = C -> S -> B_S, P2 = W -> X21^T, P3 = W^T.
+// status[0] = 1 on a clearly negative pivot, status[1] counts the dropped directions.
+__global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ D, int64_t ld, int K, const double *__restrict__ diag0,
+                                                     double *__restrict__ B, int32_t *status)
 {
-    extern __shared__ double lds_dense[]; // 64 x 66 doubles: the transposed copy of the row-K tiles; else two 64 x 34 halves
-    double *Ws = lds_dense, *Cs = lds_dense + kNB * kLdh;
+    extern __shared__ double lds_dense[];
+    constexpr int L = kLdp;
+    double *P0 = lds_dense, *P1 = P0 + kNB * L, *P2 = P1 + kNB * L, *P3 = P2 + kNB * L;
+    double (*rowbuf)[4][kNB] = reinterpret_cast<double (*)[4][kNB]>(P3 + kNB * L);
+    double *a0 = reinterpret_cast<double *>(rowbuf) + 2 * 4 * kNB; // 128 original diagonal entries
+    const int tid = threadIdx.x, k0 = 2 * K * kNB, bi = tid >> 4, bj = tid & 15;
+    const int wave = tid >> 6, lane = tid & 63, r0 = 32 * (wave >> 1), c0 = 32 * (wave & 1);
+    double s[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int r = 4 * bi + a, c = 4 * bj + b;
+            s[a][b] = r >= c ? D[(int64_t)(k0 + r) * ld + k0 + c] : D[(int64_t)(k0 + c) * ld + k0 + r];
+            P1[r * L + c] = D[(int64_t)(k0 + kNB + r) * ld + k0 + c]; // C
+        }
+    // -D of the second diagonal tile in the matrix-core layout (the accumulator of S = D - W C^T starts from it)
+    v4d acc[2][2];
+    for_quadrant(r0, c0, lane, [&](int ti, int tj, int g, int r, int c) {
+        acc[ti][tj][g] = -(r >= c ? D[(int64_t)(k0 + kNB + r) * ld + k0 + kNB + c] : D[(int64_t)(k0 + kNB + c) * ld + k0 + kNB + r]);
+    });
+    if (tid < 2 * kNB) a0[tid] = diag0[k0 + tid];
+    __syncthreads();
+    int n_dead = 0, n_failed = 0;
+    sweep64(s, a0, rowbuf, bi, bj, n_dead, n_failed); // s = -B_A
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) P0[(4 * bi + a) * L + 4 * bj + b] = -s[a][b];
+    __syncthreads();
+    {
+        v4d w[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) w[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+        quadrant_xyt<kNB, L>(P1, P0, r0, c0, lane, w); // W = C B_A = C (B_A^T)^T
+        for_quadrant(r0, c0, lane, [&](int ti, int tj, int g, int r, int c) {
+            P2[r * L + c] = w[ti][tj][g];
+            P3[c * L + r] = w[ti][tj][g];
+        });
+    }
+    __syncthreads();
+    quadrant_xyt<kNB, L>(P2, P1, r0, c0, lane, acc); // W C^T - D
+    __syncthreads();                                  // every wave is through with C
+    for_quadrant(r0, c0, lane, [&](int ti, int tj, int g, int r, int c) { P1[r * L + c] = -acc[ti][tj][g]; }); // S
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) s[a][b] = P1[(4 * bi + a) * L + 4 * bj + b];
+    __syncthreads();
+    sweep64(s, a0 + kNB, rowbuf, bi, bj, n_dead, n_failed); // s = -B_S
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int r = 4 * bi + a, c = 4 * bj + b;
+            P1[r * L + c] = -s[a][b];
+            B[(kNB + r) * kSW + kNB + c] = -s[a][b]; // X22 = B_S
+        }
+    __syncthreads();
+    {
+        v4d x[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) x[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+        quadrant_xyt<kNB, L>(P1, P3, r0, c0, lane, x); // B_S W = B_S (W^T)^T
+        __syncthreads();                                // every wave is through with W^T ... and nobody reads W any more
+        for_quadrant(r0, c0, lane, [&](int ti, int tj, int g, int r, int c) {
+            const double v = -x[ti][tj][g]; // X21 = -B_S W
+            B[(kNB + r) * kSW + c] = v;
+            B[c * kSW + kNB + r] = v;       // X12 = X21^T
+            P2[c * L + r] = v;              // X21^T for the last product
+        });
+    }
+    __syncthreads();
+    {
+        v4d x[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) x[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+        quadrant_xyt<kNB, L>(P3, P2, r0, c0, lane, x); // W^T X21 = W^T (X21^T)^T
+        for_quadrant(r0, c0, lane, [&](int ti, int tj, int g, int r, int c) { B[r * kSW + c] = P0[r * L + c] - x[ti][tj][g]; }); // X11
+    }
+    if (tid == 0 && n_dead) {
+        if (n_failed) status[0] = 1;
+        atomicAdd(&status[1], n_dead);
+    }
+}
+
+// C_i = A(i, block K) (64 x 128), gathered from the lower triangle (tiles (i, 2K), (i, 2K+1) below the pivot block, the
+// transposed tiles (2K, i), (2K+1, i) above it), W_i = C_i B on the matrix cores.  One workgroup per 64-row block; the two
+// block rows of the pivot block itself are skipped.  K runs in four chunks of 32 through LDS (row stride 34 doubles: the 32
+// lanes of a ds_read_b64 group hit 32 different bank pairs); B is symmetric, so W = C B = C (B^T)^T has the X Y^T form and
+// both operands are read the same way.  Wave w computes the output columns [32 w, 32 w + 32) of all 64 rows.
+__global__ __launch_bounds__(256) void k_dense_panels(const double *__restrict__ D, int64_t ld, int K, const double *__restrict__ B,
+                                                      double *__restrict__ Cp, double *__restrict__ Wp)
+{
+    __shared__ double Cs[kNB * kLdh];
+    __shared__ double Bs[kSW * kLdh];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    if ((i >> 1) == K) return;
+    const int wave = tid >> 6, lane = tid & 63;
+    v4d acc[2][2][2]; // [row half][ti][tj]
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) acc[h][a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const bool below = i > 2 * K + 1;
+    for (int ch = 0; ch < kSW / kHalf; ch++) { // columns [32 ch, 32 ch + 32) of C_i = K range of the product
+        if (ch) __syncthreads();
+        for (int e = tid; e < kNB * kHalf; e += 256) {
+            const int r = e / kHalf, k = e % kHalf, col = kHalf * ch + k; // column of the sweep block
+            const int64_t gr = (int64_t)i * kNB + r, gc = (int64_t)2 * K * kNB + col;
+            const double v = below ? D[gr * ld + gc] : D[gc * ld + gr]; // (above: a transposed, column-wise read)
+            Cs[r * kLdh + k] = v;
+            Cp[gr * kSW + col] = v;
+        }
+        for (int e = tid; e < kSW * kHalf; e += 256) {
+            const int n = e / kHalf, k = e % kHalf;
+            Bs[n * kLdh + k] = B[n * kSW + kHalf * ch + k]; // B^T[k][n] = B[n][k]
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; h++) quadrant_xyt<kHalf, kLdh>(Cs, Bs, 32 * h, 32 * wave, lane, acc[h]);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+            for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int r = 32 * h + 16 * ti + (lane >> 4) + 4 * g, c = 32 * wave + 16 * tj + (lane & 15);
+                    Wp[((int64_t)i * kNB + r) * kSW + c] = acc[h][ti][tj][g];
+                }
+}
+
+// one workgroup per lower 64 x 64 tile (i >= j): the sweep of the 128-wide block K
+__global__ __launch_bounds__(256, 4) void k_dense_update(double *__restrict__ D, int64_t ld, int K, const double *__restrict__ B,
+                                                         const double *__restrict__ Cp, const double *__restrict__ Wp)
+{
+    __shared__ double lds_upd[2 * kNB * kLdh > kNB * kLdp ? 2 * kNB * kLdh : kNB * kLdp];
+    double *Ws = lds_upd, *Cs = lds_upd + kNB * kLdh;
     const int tid = threadIdx.x;
     // linear tile index -> (i, j), i >= j
     const int t = blockIdx.x;
@@ -265,16 +383,20 @@ __global__ __launch_bounds__(256, 4) void k_dense_update(double *__restrict__ D,
     while (i * (i + 1) / 2 > t) i--;
     const int j = t - i * (i + 1) / 2;
     double *tile = D + (int64_t)(i * kNB) * ld + j * kNB;
-    if (i == K && j == K) {
-        for (int e = tid; e < kNB * kNB; e += 256) tile[(int64_t)(e / kNB) * ld + e % kNB] = -B[e];
+    const bool ki = (i >> 1) == K, kj = (j >> 1) == K;
+    if (ki && kj) { // inside the pivot block: -B
+        for (int e = tid; e < kNB * kNB; e += 256)
+            tile[(int64_t)(e / kNB) * ld + e % kNB] = -B[((i & 1) * kNB + e / kNB) * kSW + (j & 1) * kNB + e % kNB];
         return;
     }
-    if (j == K) { // below the pivot block: A_iK <- W_i
-        for (int e = tid; e < kNB * kNB; e += 256) tile[(int64_t)(e / kNB) * ld + e % kNB] = Wp[(int64_t)(i * kNB) * kNB + e];
+    if (kj) { // below the pivot block: A_i,K <- W_i
+        for (int e = tid; e < kNB * kNB; e += 256)
+            tile[(int64_t)(e / kNB) * ld + e % kNB] = Wp[((int64_t)i * kNB + e / kNB) * kSW + (j & 1) * kNB + e % kNB];
         return;
     }
-    if (i == K) { // left of the pivot block: A_Kj <- W_j^T
-        for (int e = tid; e < kNB * kNB; e += 256) Ws[(e / kNB) * kLdp + e % kNB] = Wp[(int64_t)(j * kNB) * kNB + e];
+    if (ki) { // left of the pivot block: A_K,j <- W_j^T
+        for (int e = tid; e < kNB * kNB; e += 256)
+            Ws[(e / kNB) * kLdp + e % kNB] = Wp[((int64_t)j * kNB + e / kNB) * kSW + (i & 1) * kNB + e % kNB];
         __syncthreads();
         for (int e = tid; e < kNB * kNB; e += 256) tile[(int64_t)(e / kNB) * ld + e % kNB] = Ws[(e % kNB) * kLdp + e / kNB];
         return;
@@ -291,15 +413,14 @@ __global__ __launch_bounds__(256, 4) void k_dense_update(double *__restrict__ D,
                 const int r = r0 + 16 * ti + (lane >> 4) + 4 * g, c = c0 + 16 * tj + (lane & 15);
                 acc[ti][tj][g] = -tile[(int64_t)r * ld + c]; // accumulate W C^T - A, store its negative
             }
-    // K in two halves of 32 (row stride 34 doubles, again 2 mod 32: conflict-free): 35 KB of LDS per workgroup, four
-    // workgroups per CU instead of two with whole operands
-    const double *wsrc = Wp + (int64_t)(i * kNB) * kNB, *csrc = Cp + (int64_t)(j * kNB) * kNB;
-    for (int h = 0; h < 2; h++) {
-        if (h) __syncthreads(); // the first half's readers are through
-        for (int e = tid; e < kNB * kHalf / 2; e += 256) { // 16-byte words: 16 per row and half
+    // K = 128 in four chunks of 32 (row stride 34 doubles: conflict-free): 35 KB of LDS per workgroup, four per CU
+    const double *wsrc = Wp + (int64_t)(i * kNB) * kSW, *csrc = Cp + (int64_t)(j * kNB) * kSW;
+    for (int h = 0; h < kSW / kHalf; h++) {
+        if (h) __syncthreads(); // the previous chunk's readers are through
+        for (int e = tid; e < kNB * kHalf / 2; e += 256) { // 16-byte words: 16 per row and chunk
             const int r = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));
-            const double2 wv = *reinterpret_cast<const double2 *>(wsrc + r * kNB + h * kHalf + k);
-            const double2 cv = *reinterpret_cast<const double2 *>(csrc + r * kNB + h * kHalf + k);
+            const double2 wv = *reinterpret_cast<const double2 *>(wsrc + r * kSW + h * kHalf + k);
+            const double2 cv = *reinterpret_cast<const double2 *>(csrc + r * kSW + h * kHalf + k);
             *reinterpret_cast<double2 *>(Ws + r * kLdh + k) = wv;
             *reinterpret_cast<double2 *>(Cs + r * kLdh + k) = cv;
         }
@@ -373,7 +494,7 @@ int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precisio
                              int64_t *lda_out, AmgDenseStats *stats)
 {
     hipStream_t st = c->stream;
-    const int n = 6 * A.nr, n_pad = (n + kNB - 1) / kNB * kNB, nt = n_pad / kNB;
+    const int n = 6 * A.nr, n_pad = (n + kSW - 1) / kSW * kSW, nt = n_pad / kNB, ns = n_pad / kSW;
     const int64_t ld = n_pad;
     DevBuf<double> D, diag0, B, Cp, Wp;
     DevBuf<int64_t> dptr;
@@ -382,9 +503,9 @@ int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precisio
     FS_HIP(D.alloc((size_t)n_pad * n_pad));
     FS_HIP(D.zero(st));
     FS_HIP(diag0.alloc(n_pad));
-    FS_HIP(B.alloc(kNB * kNB));
-    FS_HIP(Cp.alloc((size_t)n_pad * kNB));
-    FS_HIP(Wp.alloc((size_t)n_pad * kNB));
+    FS_HIP(B.alloc(kSW * kSW));
+    FS_HIP(Cp.alloc((size_t)n_pad * kSW));
+    FS_HIP(Wp.alloc((size_t)n_pad * kSW));
     FS_HIP(dptr.upload(A.ptr, st));
     FS_HIP(dcol.upload(A.col, st));
     FS_HIP(dval.upload(A.val, st));
@@ -398,13 +519,16 @@ int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precisio
     hipLaunchKernelGGL(k_dense_scatter, dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, st, dptr.p, dcol.p, dval.p, A.nr, D.p, ld);
     hipLaunchKernelGGL(k_dense_symmetrize, dim3((unsigned)(((int64_t)n_pad * n_pad + 255) / 256)), dim3(256), 0, st, D.p, ld, n, n_pad, diag0.p);
     const int tiles = nt * (nt + 1) / 2;
-    const size_t lds = 2 * (size_t)kNB * kLdp * sizeof(double);
-    const size_t lds_update = std::max((size_t)kNB * kLdp, 2 * (size_t)kNB * kLdh) * sizeof(double);
-    FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_panels), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    for (int K = 0; K < nt; K++) {
-        hipLaunchKernelGGL(k_dense_pivot, dim3(1), dim3(256), 0, st, D.p, ld, K, diag0.p, B.p, dstatus.p);
-        hipLaunchKernelGGL(k_dense_panels, dim3(nt), dim3(256), lds, st, D.p, ld, K, B.p, Cp.p, Wp.p);
-        hipLaunchKernelGGL(k_dense_update, dim3(tiles), dim3(256), lds_update, st, D.p, ld, K, B.p, Cp.p, Wp.p);
+    // LDS of the pivot kernel: four 64 x 66 blocks, the row panel of the sweeps, 128 diagonal entries
+    const size_t lds_pivot = (4 * (size_t)kNB * kLdp + 2 * 4 * kNB + 2 * kNB) * sizeof(double);
+    FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_pivot), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pivot));
+    // (the pivot kernel is one workgroup and 70 us of dependent steps; running it on a second stream beside the previous
+    //  sweep's update, after bringing its three tiles up to date first, was measured: the two event waits per sweep cost more
+    //  than the overlap gains, 17.3 -> 29.7 ms)
+    for (int K = 0; K < ns; K++) {
+        hipLaunchKernelGGL(k_dense_pivot, dim3(1), dim3(256), lds_pivot, st, D.p, ld, K, diag0.p, B.p, dstatus.p);
+        hipLaunchKernelGGL(k_dense_panels, dim3(nt), dim3(256), 0, st, D.p, ld, K, B.p, Cp.p, Wp.p);
+        hipLaunchKernelGGL(k_dense_update, dim3(tiles), dim3(256), 0, st, D.p, ld, K, B.p, Cp.p, Wp.p);
     }
     const int64_t ldo = (n + 1) / 2 * 2;
     const unsigned gfin = (unsigned)(((int64_t)n * ldo + 255) / 256);
@@ -428,10 +552,11 @@ int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precisio
     if (stats) {
         stats->n = n;
         stats->ms = ms;
-        stats->mfma_flops = (double)nt * ((double)tiles + nt) * 2.0 * kNB * kNB * kNB; // issued on the matrix cores
-        stats->useful_flops = (double)n * n * n;                                       // n^3 of a symmetric inversion
+        // issued on the matrix cores: per sweep every lower tile 2 x 64 x 64 x 128 and every block row's panel 2 x 64 x 128 x 128
+        stats->mfma_flops = (double)ns * ((double)tiles * 2.0 * kNB * kNB * kSW + (double)nt * 2.0 * kNB * kSW * kSW);
+        stats->useful_flops = (double)n * n * n;                           // n^3 of a symmetric inversion
         stats->dropped = hstatus[1];
-        stats->bytes = (double)nt * (double)tiles * 2.0 * kNB * kNB * 8.0;             // lower triangle read + written per step
+        stats->bytes = (double)ns * (double)tiles * 2.0 * kNB * kNB * 8.0; // lower triangle read + written per sweep
     }
     if (hstatus[0] != 0) return set_err(FEMSHELL_ERR_BREAKDOWN, "multigrid setup: coarsest operator is not positive definite");
     return FEMSHELL_OK;

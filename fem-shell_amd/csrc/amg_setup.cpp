@@ -176,7 +176,11 @@ void aggregation_order(const Bsr &A, std::vector<int32_t> *order)
     for (int32_t i = 0; i < n; i++)
         for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++) dist += std::fabs((double)A.col[q] - (double)i);
     const int64_t edges = A.ptr[n];
-    if (edges == 0 || dist / (double)edges <= 8.0 * std::sqrt((double)n)) return;
+    // FEMSHELL_AMG_AGG_ORDER=bfs|index forces one of the two (experiments); default: by the scatter of the numbering
+    const char *force = getenv("FEMSHELL_AMG_AGG_ORDER");
+    if (force && std::strcmp(force, "index") == 0) return;
+    const bool bfs = force && std::strcmp(force, "bfs") == 0;
+    if (!bfs && (edges == 0 || dist / (double)edges <= 8.0 * std::sqrt((double)n))) return;
     order->reserve((size_t)n);
     std::vector<char> seen((size_t)n, 0);
     for (int32_t s0 = 0; s0 < n; s0++) {
