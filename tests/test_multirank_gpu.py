@@ -43,7 +43,7 @@ def run_ranks(world, kind, tmp_path, overlap=True, single_reduction=None, pc=Non
     return [np.load(o) for o in outs]
 
 
-@pytest.mark.parametrize("world,kind", [(2, "panel"), (3, "panel"), (2, "cylinder")])
+@pytest.mark.parametrize("world,kind", [(2, "panel"), (3, "panel"), (2, "cylinder"), (4, "panel")])
 def test_partitioned_solve_on_one_gpu_matches_single_rank(world, kind, tmp_path):
     single = run_ranks(1, kind, tmp_path)[0]
     ranks = run_ranks(world, kind, tmp_path)
@@ -71,7 +71,7 @@ def test_partitioned_solve_on_one_gpu_matches_single_rank(world, kind, tmp_path)
     assert err < 1e-8, err  # two CG runs with different summation order on an ill-conditioned system
 
 
-@pytest.mark.parametrize("world,kind", [(2, "panel"), (3, "cylinder")])
+@pytest.mark.parametrize("world,kind", [(2, "panel"), (3, "cylinder"), (4, "panel")])
 def test_multigrid_on_a_row_partitioned_context_is_the_single_rank_preconditioner(world, kind, tmp_path):
     # every rank holds the single-rank hierarchy (built by its shadow context from the whole K); level 0 is smoothed on
     # the rank's rows with the halo product, the restricted residuals are summed by an all-reduce: the same
