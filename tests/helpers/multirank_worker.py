@@ -66,12 +66,17 @@ def main():
         return
     u, info = fs.solve(rtol=1e-11, max_it=100000)
     b, e = fs.row_range()
+    extra = {}
+    if os.environ.get("FEMSHELL_TEST_EXPORT") == "1":
+        # the rows of K and F this rank assembled (global column ids), for the comparison with the oracle's assembly
+        rp, ci, vals, F = fs.export_bsr()
+        extra = dict(k_rowptr=rp[:e - b + 1], k_cols=ci, k_vals=vals, k_F=F[:6 * (e - b)])
     # a second solve on the same context with doubled loads (the coupled program re-solves every coupling iteration)
     fs.set_loads(2.0 * m.loads)
     u2, info2 = fs.solve(rtol=1e-11, max_it=100000)
     np.savez(out_file, u=u, iterations=info["iterations"], converged=info["converged"], begin=b, end=e,
              true_res=info["true_rel_residual"], u2=u2, converged2=info2["converged"], iterations2=info2["iterations"],
-             levels=info["amg_levels"])
+             levels=info["amg_levels"], **extra)
     fs.close()
 
 

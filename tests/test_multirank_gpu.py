@@ -71,6 +71,39 @@ def test_partitioned_solve_on_one_gpu_matches_single_rank(world, kind, tmp_path)
     assert err < 1e-8, err  # two CG runs with different summation order on an ill-conditioned system
 
 
+@pytest.mark.parametrize("world,kind", [(2, "panel"), (3, "cylinder")])
+def test_row_partitioned_assembly_and_solve_against_the_oracle(world, kind, tmp_path, monkeypatch):
+    """Parity of the partitioned path with the CPU oracle, not with the single-rank HIP path: every rank's rows of K and F
+    (femshell_export_bsr on a row-partitioned context: rows [row_begin, row_end), global column ids) equal the oracle's
+    assembly of the whole mesh, the ranks tile the matrix, and the multigrid-preconditioned solve of the partitioned
+    context equals the oracle's refined direct solve up to the sensitivity of the solution to the rounding of two FP64
+    assemblies (what the single-rank path shows too)."""
+    from tests.helpers import oracle
+    from tests.helpers.multirank_worker import build_problem
+
+    monkeypatch.setenv("FEMSHELL_TEST_EXPORT", "1")
+    ranks = run_ranks(world, kind, tmp_path, pc="amg")
+    m, mat = build_problem(kind)
+    r0, c0, v0, F0 = oracle.assemble(m.xyz, m.tri, m.quad, oracle.material(*mat), m.dirichlet_mask(), m.loads)
+    scale = np.abs(v0).max()
+    covered = 0
+    for r in sorted(ranks, key=lambda q: int(q["begin"])):
+        b, e = int(r["begin"]), int(r["end"])
+        assert b == covered  # contiguous, ascending, no overlap
+        covered = e
+        rp = np.asarray(r["k_rowptr"], dtype=np.int64)
+        np.testing.assert_array_equal(rp - rp[0], r0[b:e + 1] - r0[b])
+        lo, hi = int(r0[b]), int(r0[e])
+        np.testing.assert_array_equal(r["k_cols"][:hi - lo], c0[lo:hi])
+        assert np.abs(r["k_vals"][:hi - lo] - v0[lo:hi]).max() <= 1e-12 * scale
+        np.testing.assert_array_equal(r["k_F"], F0[6 * b:6 * e])
+    assert covered == m.n_nodes
+    u0 = oracle.refined_solve(r0, c0, v0, F0)
+    err = np.linalg.norm(ranks[0]["u"].ravel() - u0) / np.linalg.norm(u0)
+    assert all(int(r["converged"]) == 1 for r in ranks)
+    assert err < 1e-8, err  # solver term ~1e-13 + kappa x (1e-16 rounding differences of the two assemblies)
+
+
 @pytest.mark.parametrize("world,kind", [(2, "panel"), (3, "cylinder"), (4, "panel")])
 def test_multigrid_on_a_row_partitioned_context_is_the_single_rank_preconditioner(world, kind, tmp_path):
     # every rank holds the single-rank hierarchy (built by its shadow context from the whole K); level 0 is smoothed on
