@@ -427,6 +427,22 @@ def amg_host_coarsen(rowptr, colidx, vals, B, lambda_max):
     return out
 
 
+def amg_host_aggregate(rowptr, colidx, visit=None):
+    """The library's greedy aggregation of a node graph: (agg, n_aggregates); visit = order of the passes (optional)."""
+    L = load_library()
+    L.femshell_amg_host_aggregate.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                              C.POINTER(C.c_int32)]
+    L.femshell_amg_host_aggregate.restype = C.c_int32
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    agg = np.zeros(len(rowptr) - 1, dtype=np.int32)
+    v = None if visit is None else np.ascontiguousarray(visit, dtype=np.int32)
+    na = L.femshell_amg_host_aggregate(len(rowptr) - 1, _i(rowptr), _i(colidx), None if v is None else _i(v), _i(agg))
+    if na < 0:
+        _check(-1)  # FEMSHELL_ERR_INVALID; the message is in femshell_last_error
+    return agg, na
+
+
 def amg_host_dense_inverse(rowptr, colidx, vals):
     L = load_library()
     L.femshell_amg_host_dense_inverse.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double),

@@ -68,7 +68,9 @@ void node_normals(int32_t n, const double *xyz, int64_t n_tri, const int32_t *tr
                   std::vector<double> *normals);
 
 // greedy distance-1 aggregation of the block graph of A; returns the number of aggregates
-int32_t aggregate_nodes(const Bsr &A, std::vector<int32_t> *agg);
+// visit: order in which the greedy passes visit the nodes (visit[v] = node visited v-th); nullptr: index order, or
+// breadth-first order when the numbering is scattered (aggregation_order)
+int32_t aggregate_nodes(const Bsr &A, std::vector<int32_t> *agg, const std::vector<int32_t> *visit = nullptr);
 
 // tentative prolongator: per aggregate B_agg = Q R (modified Gram-Schmidt, two passes; dependent columns give a
 // zero column of Q and a zero diagonal of R).  Q[n][6][6] (row block of node n, column block agg[n]),

@@ -252,7 +252,13 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     Bsr G;
     graph_of_pattern(pat, &G);
     std::vector<int32_t> agg;
-    const int32_t na = aggregate_nodes(G, &agg);
+    // When the library renumbered the nodes itself (FEMSHELL_REORDER_*: Morton, Cuthill-McKee) the greedy passes of the
+    // FINEST level visit the nodes in the caller's order: the index order of a space-filling curve fragments the aggregates
+    // at its jumps (4M-triangle cylinder, Morton numbering: 443 iterations instead of 137; panel 160 instead of 147), and the
+    // aggregates -- hence every coarser level, whose numbering is the order of creation -- are then those of the caller's
+    // numbering, whatever the internal one is
+    const bool finest_renumbered = &Adev == &c->dm && !c->iperm.empty() && (int32_t)c->iperm.size() == n;
+    const int32_t na = aggregate_nodes(G, &agg, finest_renumbered ? &c->iperm : nullptr);
     lap("graph + aggregation");
     // tentative prolongator on the device: QR of every aggregate's rows of B, one wave each (k_amg_tentative_qr); the host
     // only groups the nodes by aggregate

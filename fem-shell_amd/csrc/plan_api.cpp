@@ -158,6 +158,34 @@ int femshell_amg_host_coarsen(int32_t n_nodes, const int32_t *rowptr, const int3
     return FEMSHELL_OK;
 }
 
+int32_t femshell_amg_host_aggregate(int32_t n_nodes, const int32_t *rowptr, const int32_t *colidx, const int32_t *visit,
+                                    int32_t *agg_out)
+{
+    if (n_nodes <= 0 || !rowptr || !colidx || !agg_out) {
+        set_err(FEMSHELL_ERR_INVALID, "femshell_amg_host_aggregate: invalid argument");
+        return -1;
+    }
+    Bsr A;
+    A.nr = A.nc = n_nodes;
+    A.ptr.assign(rowptr, rowptr + n_nodes + 1);
+    A.col.assign(colidx, colidx + rowptr[n_nodes]);
+    std::vector<int32_t> agg, order;
+    if (visit) {
+        order.assign(visit, visit + n_nodes);
+        std::vector<char> seen((size_t)n_nodes, 0);
+        for (int32_t v : order) {
+            if (v < 0 || v >= n_nodes || seen[(size_t)v]) {
+                set_err(FEMSHELL_ERR_INVALID, "femshell_amg_host_aggregate: visit is not a permutation of the nodes");
+                return -1;
+            }
+            seen[(size_t)v] = 1;
+        }
+    }
+    const int32_t na = aggregate_nodes(A, &agg, visit ? &order : nullptr);
+    std::memcpy(agg_out, agg.data(), (size_t)n_nodes * sizeof(int32_t));
+    return na;
+}
+
 void femshell_amg_coarsening_destroy(femshell_amg_coarsening *h) { delete h; }
 
 int64_t femshell_amg_coarsening_array(const femshell_amg_coarsening *h, int which, void *out)

@@ -88,6 +88,11 @@ enum {
     FEMSHELL_COARSEN_BC        /* double [n_coarse*36]: coarse near-null space */
 };
 int64_t femshell_amg_coarsening_array(const femshell_amg_coarsening *h, int which, void *out);
+/* the aggregation alone (graph of the block pattern).  visit: NULL, or the order in which the greedy passes meet the nodes
+ * (a permutation of 0..n-1) -- what femshell_set_mesh hands over when it renumbered the nodes itself, so that the
+ * aggregates are those of the caller's numbering.  Returns the number of aggregates (< 0: invalid argument). */
+int32_t femshell_amg_host_aggregate(int32_t n_nodes, const int32_t *rowptr, const int32_t *colidx, const int32_t *visit,
+                                    int32_t *agg_out);
 /* dense inverse of a small SPD block matrix (coarsest level): inv_out (6n)^2 doubles */
 int femshell_amg_host_dense_inverse(int32_t n_nodes, const int32_t *rowptr, const int32_t *colidx, const double *vals,
                                     double *inv_out);

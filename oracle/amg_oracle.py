@@ -85,12 +85,15 @@ def aggregation_order(rowptr, colidx):
     return order
 
 
-def aggregate(rowptr, colidx):
-    """Greedy distance-1 aggregation, three passes; returns (agg, n_aggregates)."""
+def aggregate(rowptr, colidx, visit=None):
+    """Greedy distance-1 aggregation, three passes; returns (agg, n_aggregates).  visit: the order in which the passes
+    meet the nodes (default: aggregation_order); a leftover of pass 1 joins the neighbour that comes first in it."""
     n = len(rowptr) - 1
     agg = -np.ones(n, dtype=np.int64)
     na = 0
-    order = aggregation_order(rowptr, colidx)
+    order = aggregation_order(rowptr, colidx) if visit is None else [int(i) for i in visit]
+    rank = np.empty(n, dtype=np.int64)
+    rank[np.fromiter(order, dtype=np.int64, count=n)] = np.arange(n)
     for i in order:
         if agg[i] >= 0:
             continue
@@ -104,10 +107,10 @@ def aggregate(rowptr, colidx):
     for i in range(n):
         if agg[i] >= 0:
             continue
-        cand = agg[colidx[rowptr[i]:rowptr[i + 1]]]
-        cand = cand[cand >= 0]
-        if len(cand):
-            agg2[i] = cand[0]
+        nb = colidx[rowptr[i]:rowptr[i + 1]]
+        nb = nb[agg[nb] >= 0]
+        if len(nb):
+            agg2[i] = agg[nb[np.argmin(rank[nb])]]
     agg = agg2
     for i in order:
         if agg[i] < 0:

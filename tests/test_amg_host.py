@@ -222,3 +222,40 @@ def test_symmetric_storage_image_of_a_coarse_operator():
     assert np.abs(y[:na].ravel() - y0).max() <= 1e-12 * np.abs(y0).max()
     assert stored == (Ac.tobsr((6, 6)).nnz // 36 - na) // 2
     assert np.abs(Asym - Ad).max() <= 1e-10 * np.abs(Ad).max()  # the Galerkin operator is symmetric to rounding
+
+
+@pytest.mark.parametrize("kind", ["panel", "cylinder"])
+def test_aggregates_of_a_renumbered_graph_are_those_of_the_callers_numbering(kind):
+    """femshell_set_mesh may renumber the nodes (FEMSHELL_REORDER_*); it then hands the caller's order to the aggregation
+    (csrc/amg_device_setup.cpp), whose passes -- visiting order and the choice among a leftover's neighbours -- follow
+    it: the partition into aggregates is the one the caller's numbering gives, whatever the internal numbering is.
+    Library and restatement alike."""
+    ensure_built()
+    if kind == "panel":
+        _, _, rp, ci, _, _ = _problem("panel")
+    else:
+        m = meshes.pinched_cylinder(40, 36)
+        rp, ci, _, _ = oracle.assemble(m.xyz, m.tri, m.quad, oracle.material(*m.material), m.dirichlet_mask(), m.loads)
+    n = len(rp) - 1
+    agg0, na0 = _binding().amg_host_aggregate(rp, ci)
+    agg0_o, na0_o = amg_oracle.aggregate(rp, ci)
+    np.testing.assert_array_equal(agg0, agg0_o)
+    assert na0 == na0_o
+    # internal numbering: new = perm[old]; the graph in internal numbering, columns ascending as the library stores them
+    perm = np.random.default_rng(11).permutation(n)
+    iperm = np.argsort(perm)  # iperm[new] = old
+    G = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(n, n))
+    Gp = G[iperm][:, iperm].tocsr()
+    Gp.sort_indices()
+    rpp, cip = Gp.indptr.astype(np.int32), Gp.indices.astype(np.int32)
+    # visiting order = the caller's order expressed in internal ids: caller node 0 first, ... -> perm[0], perm[1], ...
+    agg1, na1 = _binding().amg_host_aggregate(rpp, cip, visit=perm)
+    agg1_o, na1_o = amg_oracle.aggregate(rpp, cip, visit=perm)
+    np.testing.assert_array_equal(agg1, agg1_o)
+    assert na1 == na0
+    np.testing.assert_array_equal(agg1[perm], agg0)  # same aggregate, same aggregate number, node by node
+    # without the order the partition is another one (breadth-first over a scattered numbering)
+    agg2, na2 = _binding().amg_host_aggregate(rpp, cip)
+    assert not np.array_equal(agg2[perm], agg0)
+    with pytest.raises(Exception):
+        _binding().amg_host_aggregate(rpp, cip, visit=np.zeros(n, np.int32))

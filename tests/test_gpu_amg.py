@@ -400,3 +400,28 @@ def test_dense_inverse_on_the_matrix_cores_drops_semi_definite_directions(monkey
     assert sols["device"][1]["n"] == 6 * m.n_nodes and sols["device"][1]["dropped_directions"] >= 1
     rg = np.linalg.norm(sols["host"][0] - sols["device"][0]) / np.linalg.norm(sols["host"][0])
     assert rg < 1e-9, rg
+
+
+@pytest.mark.parametrize("flag", ["REORDER_MORTON", "REORDER_RCM"])
+def test_aggregates_do_not_depend_on_the_internal_numbering(flag):
+    """With FEMSHELL_REORDER_* the library numbers the nodes its own way (csrc/reorder.cpp), and the greedy aggregation
+    passes depend on the order in which they meet the nodes.  They follow the caller's numbering in that case (visiting
+    order and the tie-break of the leftovers: csrc/amg_setup.cpp aggregate_nodes), so the hierarchy -- level sizes and
+    iteration count -- is the one of the context without the flag (the 4M-triangle cylinder went from 139 to 443
+    iterations under Morton numbering before)."""
+    m, mat = _make("cylinder", 160)
+    out = {}
+    for name, flags in (("plain", pkg.REF_DEFAULT), ("reordered", pkg.REF_DEFAULT | getattr(pkg, flag))):
+        ensure_built()
+        fs = pkg.FemShell(*mat, device=0, flags=flags)
+        fs.set_mesh(m.xyz, m.tri, m.quad)
+        fs.set_dirichlet(m.dirichlet_mask())
+        fs.set_loads(m.loads)
+        fs.set_preconditioner("amg", coarsest_nodes=200)
+        u, info = fs.solve(rtol=1e-10, max_it=2000)
+        assert info["converged"] == 1
+        out[name] = (u, info["iterations"], [lv["n_nodes"] for lv in fs.amg_levels()])
+        fs.close()
+    assert out["reordered"][2] == out["plain"][2], (out["plain"][2], out["reordered"][2])
+    assert abs(out["reordered"][1] - out["plain"][1]) <= 0.1 * out["plain"][1] + 2, (out["plain"][1], out["reordered"][1])
+    assert np.linalg.norm(out["reordered"][0] - out["plain"][0]) <= 1e-7 * np.linalg.norm(out["plain"][0])
