@@ -613,6 +613,8 @@ static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double 
     FS_HIP(c->item_flags.alloc(p.items.size()));
     c->dm.item_flags = c->item_flags.p;
     c->dm.max_stage_rows = p.max_stage_rows;
+    c->dm.pipe = p.pipe ? 1 : 0;
+    c->dm.slice_elem_ptr_last = (int32_t)(p.slice_elem_nodes.size() / 4);
     {
         // LDS of k_assemble: element records + partial-sum staging
         const size_t lds = assemble_lds_layout(c->dm, p.max_slice_elems, p.max_stage_rows, p.n_lquad() > 0);

@@ -392,4 +392,384 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
     }
 }
 
+
+// =====================================================================================
+// The same assembly as a producer / consumer pipeline (plans with Plan::pipe: triangles only, slices whose two record
+// buffers fit twice into a CU's LDS).
+//
+// k_assemble runs a slice in two phases -- records, barrier, blocks -- and its four waves do different amounts of work
+// (one wave: diagonal items; two waves: records and off-diagonal items; one wave: records only): the longest wave and the
+// serial phases set the time of a slice, and the two SIMDs that hold the long waves of both resident workgroups are busy
+// while the others idle.  Here one wave of the workgroup -- the producer -- builds the records of the NEXT slice into a
+// second LDS buffer while the other three -- the consumers -- compute and store the blocks of the current one: one
+// barrier per slice, four waves of about equal work (records 3 passes | diagonal items | off-diagonal items x 2), no
+// staging of partial sums in LDS (the chunks of a block slot sit in neighbouring lanes of one wave, plan.cpp
+// pack_items_pipe, and meet through lane permutes).  Which wave does what follows the SIMD it runs on, and the second
+// workgroup of a CU shifts the roles by two SIMDs, so that every SIMD carries one long and one short wave.
+// Records are RecLean (34 doubles), items and flags as in k_assemble, in rounds of 192.
+// kAblate (lab): 8 = no record math, 16 = roles by wave index and the same in every workgroup, 32 = s_memtime stamps;
+// 0 in the product.
+// =====================================================================================
+// value of the next lane of the wave (lane 63: unspecified): DPP wave_shl:1 on both halves of the double
+__device__ __forceinline__ double lane_below(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi2, lo2);
+}
+
+constexpr int kPipeConsumers = 192;  // lanes that own work items (three waves)
+constexpr int kPipeRecPasses = 3;    // record passes the producer wave runs at most per slice: 192 records, more than a slice
+                                     // of a plan with Plan::pipe has (kPipeMaxSliceElems)
+
+template <int kAblate = 0>
+__global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatConst mc)
+{
+    extern __shared__ double lds[];
+    __shared__ int simd_of_wave[4];
+    constexpr int kRec = RecLean::doubles;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- roles: by the SIMD a wave runs on when the four waves sit on four SIMDs (they do; the order varies from
+    //      workgroup to workgroup), else by wave index.  The workgroups b and b + G/2 of a 2-per-CU grid share a CU.
+    int vwave;
+    {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        const int simd = (int)((hw >> 4) & 3u);
+        if (lane == 0) simd_of_wave[wave] = simd;
+        __syncthreads();
+        const int seen = (1 << simd_of_wave[0]) | (1 << simd_of_wave[1]) | (1 << simd_of_wave[2]) | (1 << simd_of_wave[3]);
+        const int place = (seen == 15 && !(kAblate & 16)) ? simd : wave;
+        const int shift = (blockIdx.x >= (gridDim.x >> 1) && !(kAblate & 16)) ? 2 : 0;
+        vwave = __builtin_amdgcn_readfirstlane((place + shift) & 3);
+    }
+    SliceWalk w(m.n_slices);
+    if (!w.valid()) return;
+    const int n_iter = (w.last - w.s + w.step - 1) / w.step; // slices of this workgroup
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int slot) {
+        if (kAblate & 32) {
+            unsigned long long tnow;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
+            if (slot >= 0) tacc[slot] += tnow - tprev;
+            tprev = tnow;
+        }
+    };
+    stamp(-1);
+    // first int4 of a slice's descriptor {elem begin, elem count, item begin, item count}, second {slot base lo, hi, width}
+    auto desc_a_of = [&](int s_) { return (s_ < w.last) ? m.slice_desc[2 * s_] : make_int4(0, 0, 0, 0); };
+    auto desc_b_of = [&](int s_) { return (s_ < w.last) ? m.slice_desc[2 * s_ + 1] : make_int4(0, 0, 0, 0); };
+
+    if (vwave == 3) {
+        // ================= producer: records of slice j+1 while the consumers work on slice j =================
+        // The element lists of the workgroup's slices are one stream of records, built in passes of 64 lanes: the lanes of a
+        // slice's last pass that its own list does not fill (62 of 64 when a structured slice of 130 elements starts a
+        // pass) build the first records of the NEXT slice.  Those cannot go to LDS yet -- their buffer is the one the
+        // consumers are reading -- so the lane holds them in registers until the barrier and writes them first thing in
+        // the next iteration.  2.03 passes per structured slice instead of 3.
+        // Operands in flight: coordinates of the passes of the next iteration (fetched while this one computes), node ids
+        // one iteration further, element ranges (first word of the descriptors) of four slices.
+        const int4 *enodes = m.slice_elem_nodes;
+        const int n_entries = m.slice_elem_ptr_last; // entries of slice_elem_nodes (clamp for idle lanes)
+        struct Range {
+            int e0, ne;
+        };
+        // passes of an iteration that starts at record r0 of a slice with range a
+        auto passes_of = [&](int r0, const Range &a) { return (a.ne > r0) ? (a.ne - r0 + 63) >> 6 : 0; };
+        // element of a lane in such an iteration, b being the range of the following slice
+        // (slots 0 and 1 are the full passes, if any; slot 2 is the last pass, the one that may reach into the next slice)
+        auto stream_elem = [&](int r0, const Range &a, const Range &b, int slot) {
+            const int pi = (slot < kPipeRecPasses - 1) ? slot : max(passes_of(r0, a) - 1, 0);
+            const int li = r0 + 64 * pi + lane, li2 = li - a.ne;
+            int e = (li < a.ne) ? a.e0 + li : ((li2 < b.ne) ? b.e0 + li2 : a.e0 + max(a.ne - 1, 0));
+            return min(max(e, 0), n_entries - 1);
+        };
+        // records of the following slice the last pass builds
+        auto carry_of = [&](int r0, const Range &a, const Range &b) {
+            return min(max(r0 + 64 * passes_of(r0, a) - a.ne, 0), b.ne);
+        };
+        auto fetch_coords = [&](const int4 &c, double X[9]) {
+            const double *pa = m.xyz + 3 * (int64_t)c.x, *pb = m.xyz + 3 * (int64_t)c.y, *pc = m.xyz + 3 * (int64_t)c.z;
+            X[0] = pa[0]; X[1] = pa[1]; X[2] = pa[2];
+            X[3] = pb[0]; X[4] = pb[1]; X[5] = pb[2];
+            X[6] = pc[0]; X[7] = pc[1]; X[8] = pc[2];
+        };
+        auto range_of = [&](const int4 &a) {
+            Range r;
+            r.e0 = __builtin_amdgcn_readfirstlane(a.x);
+            r.ne = __builtin_amdgcn_readfirstlane(a.y);
+            return r;
+        };
+        // the producer is the longest wave of the four: it goes first whenever the SIMD has a choice
+        if (!(kAblate & 64)) __builtin_amdgcn_s_setprio(3);
+        int s_build = w.s; // slice whose records are built next
+        Range ra = range_of(desc_a_of(s_build)), rb = range_of(desc_a_of(s_build + w.step)),
+              rc = range_of(desc_a_of(s_build + 2 * w.step));
+        int4 dvec = desc_a_of(s_build + 3 * w.step); // becomes rd in the first iteration
+        int r0 = 0;                                   // records of slice s_build that are built already
+        int r0n = carry_of(r0, ra, rb);
+        double X[kPipeRecPasses][9];
+        int4 ndn[kPipeRecPasses];
+#pragma unroll
+        for (int p = 0; p < kPipeRecPasses; p++) {
+            fetch_coords(enodes[stream_elem(r0, ra, rb, p)], X[p]);
+            ndn[p] = enodes[stream_elem(r0n, rb, rc, p)];
+        }
+        double held[kRec]; // a record of the next slice, lean layout
+        int held_at = -1;  // its index there, -1: none
+#pragma unroll
+        for (int q = 0; q < kRec; q++) held[q] = 0.0;
+        auto write_lean = [&](double *buf, int i, const double rec[kRec]) {
+            double2 *dst = reinterpret_cast<double2 *>(buf + (size_t)i * kRec);
+#pragma unroll
+            for (int q = 0; q < kRec / 2; q++) dst[q] = make_double2(rec[2 * q], rec[2 * q + 1]);
+        };
+        auto record_of = [&](const double Xp[9], double lean[kRec]) __attribute__((always_inline)) {
+            double rec[kRecDoubles];
+            bool ok;
+            if (kAblate & 8) {
+#pragma unroll
+                for (int q = 0; q < kRecDoubles; q++) rec[q] = 1.0 + 0.01 * q + Xp[q % 9] * 1e-9;
+                ok = true;
+            } else {
+                ok = tri3_record(Xp, mc, rec);
+            }
+#pragma unroll
+            for (int q = 0; q < kRec; q++) lean[q] = rec[lean_from_full(q)];
+            return ok;
+        };
+        auto produce = [&](double *buf) {
+            if (held_at >= 0) write_lean(buf, held_at, held);
+            held_at = -1;
+            const int np = passes_of(r0, ra);
+#pragma unroll
+            for (int p = 0; p < kPipeRecPasses - 1; p++) { // full passes
+                if (p < np - 1) {
+                    double lean[kRec];
+                    const bool ok = record_of(X[p], lean);
+                    const int li = r0 + 64 * p + lane;
+                    if (!ok) atomicCAS(m.status, 0, ra.e0 + li + 1);
+                    write_lean(buf, li, lean);
+                }
+                fetch_coords(ndn[p], X[p]); // the next iteration's element of this lane and slot
+            }
+            if (np > 0) { // last pass: the slice's last records, then the first of the next slice
+                const bool ok = record_of(X[kPipeRecPasses - 1], held);
+                const int li = r0 + 64 * (np - 1) + lane, li2 = li - ra.ne;
+                if (li < ra.ne) {
+                    if (!ok) atomicCAS(m.status, 0, ra.e0 + li + 1);
+                    write_lean(buf, li, held);
+                } else if (li2 < rb.ne) {
+                    if (!ok) atomicCAS(m.status, 0, rb.e0 + li2 + 1);
+                    held_at = li2;
+                }
+            } else { // (every path defines the held record anew: its registers are free during the full passes)
+#pragma unroll
+                for (int q = 0; q < kRec; q++) held[q] = 0.0;
+            }
+            fetch_coords(ndn[kPipeRecPasses - 1], X[kPipeRecPasses - 1]);
+            // roll the window
+            const Range rd = range_of(dvec);
+            const int r0nn = carry_of(r0n, rb, rc);
+            r0 = r0n;
+            r0n = r0nn;
+            ra = rb;
+            rb = rc;
+            rc = rd;
+            s_build += w.step;
+#pragma unroll
+            for (int p = 0; p < kPipeRecPasses; p++) ndn[p] = enodes[stream_elem(r0n, rb, rc, p)];
+            dvec = desc_a_of(s_build + 3 * w.step);
+        };
+        produce(lds);
+        stamp(0);
+        lds_barrier();
+        stamp(1);
+        for (int j = 0; j < n_iter; j++) {
+            if (j + 1 < n_iter) produce(lds + (size_t)((j + 1) & 1) * m.lds_rec_off);
+            stamp(0);
+            lds_barrier();
+            stamp(1);
+        }
+    } else {
+        // ================= consumers: block slots of slice j from record buffer j & 1 =================
+        const int vtid = vwave * 64 + lane; // 0..191
+        struct Desc {
+            int e0, ne, i0, ni;
+            int64_t base;
+        };
+        auto decode = [&](const int4 &a, const int4 &b) {
+            Desc d;
+            d.e0 = __builtin_amdgcn_readfirstlane(a.x);
+            d.ne = __builtin_amdgcn_readfirstlane(a.y);
+            d.i0 = __builtin_amdgcn_readfirstlane(a.z);
+            d.ni = __builtin_amdgcn_readfirstlane(a.w);
+            d.base = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(b.y) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane(b.x));
+            return d;
+        };
+        Desc d0 = decode(desc_a_of(w.s), desc_b_of(w.s)), d1 = decode(desc_a_of(w.s + w.step), desc_b_of(w.s + w.step));
+        int4 dva = desc_a_of(w.s + 2 * w.step), dvb = desc_b_of(w.s + 2 * w.step);
+        double rhs_pre = 0.0;
+        uint32_t rhs_mask = 0u;
+        auto fetch_rhs = [&](int s_) {
+            if (m.rhs_F != nullptr && s_ < w.last) {
+                rhs_pre = m.rhs_loads[(int64_t)s_ * kSliceRows + vtid];
+                rhs_mask = m.dmask[s_ * kSliceNodes + vtid / 6];
+            }
+        };
+        fetch_rhs(w.s);
+        uint4 item_pre = make_uint4(0xffffu, 0, 0, 0);
+        uint32_t flags_pre = 0u;
+        if (vtid < d0.ni) {
+            item_pre = m.items[d0.i0 + vtid];
+            flags_pre = m.item_flags[d0.i0 + vtid];
+        }
+        lds_barrier(); // records of the first slice
+        stamp(1);
+        for (int j = 0; j < n_iter; j++, w.next()) {
+            const int s = w.s;
+            const double *lds_rec = lds + (size_t)(j & 1) * m.lds_rec_off;
+            const int64_t base = d0.base;
+            const int i0 = d0.i0, ni = d0.ni;
+            uint4 item = item_pre;
+            uint32_t flags = flags_pre;
+            // the wait for the prefetched words belongs here, in front of this slice's prefetches (see k_assemble)
+            asm volatile("" : "+v"(item.x), "+v"(item.y), "+v"(item.z), "+v"(item.w), "+v"(flags));
+            const Desc d2 = decode(dva, dvb);
+            if (m.rhs_F != nullptr) {
+                const bool fixed = (rhs_mask >> (vtid % 6)) & 1u;
+                m.rhs_F[(int64_t)s * kSliceRows + vtid] = (fixed || s * kSliceNodes + vtid / 6 >= m.n_own) ? 0.0 : rhs_pre;
+            }
+            stamp(5);
+            // prefetches that overlap the block math: descriptor three slices ahead, right-hand side and items of the next
+            dva = desc_a_of(s + 3 * w.step);
+            dvb = desc_b_of(s + 3 * w.step);
+            fetch_rhs(s + w.step);
+            uint4 item_next = make_uint4(0xffffu, 0, 0, 0);
+            uint32_t flags_next = 0u;
+            if (vtid < d1.ni) {
+                item_next = m.items[d1.i0 + vtid];
+                flags_next = m.item_flags[d1.i0 + vtid];
+            }
+            stamp(6);
+            double2 *out = reinterpret_cast<double2 *>(m.vals + base * 36);
+            for (int r0 = 0; r0 < ni; r0 += kPipeConsumers) {
+                const int it = r0 + vtid;
+                const bool live = it < ni;
+                if (r0 > 0) {
+                    item = make_uint4(0xffffu, 0, 0, 0);
+                    flags = 0u;
+                    if (live) {
+                        item = m.items[i0 + it];
+                        flags = m.item_flags[i0 + it];
+                    }
+                    asm volatile("" : "+v"(item.x), "+v"(item.y), "+v"(item.z), "+v"(item.w), "+v"(flags));
+                }
+                const int slot_in_slice = (int)(item.x & 0xffffu), chunk = (int)((item.x >> 16) & 0xffu),
+                          nchunks = (int)(item.x >> 24);
+                const int cnt = (int)(item.z >> 16);
+                // what the plan says about this wave of the round: most chunks of a slot, and whether every item is diagonal
+                const int wave_chunks = __builtin_amdgcn_readfirstlane((int)(item.w & 0xffu));
+                const bool wave_sym = __builtin_amdgcn_readfirstlane((int)((item.w >> 8) & 1u)) != 0;
+                const bool sym_item = slot_in_slice < kSliceNodes;
+                double blk[36];
+#pragma unroll
+                for (int i = 0; i < 36; i++) blk[i] = 0.0;
+                if (sym_item) {
+                    for (int q = 0; q < cnt; q++) {
+                        const uint32_t pr = (q == 0) ? (item.y & 0xffffu) : (q == 1 ? (item.y >> 16) : (item.z & 0xffffu));
+                        tri3_diag_add_rec<RecLean>(lds_rec + (size_t)(pr >> 4) * kRec, (int)(pr & 3u), mc, blk);
+                    }
+                } else {
+                    for (int q = 0; q < cnt; q++) {
+                        const uint32_t pr = (q == 0) ? (item.y & 0xffffu) : (q == 1 ? (item.y >> 16) : (item.z & 0xffffu));
+                        tri3_block_add_rec<RecLean>(lds_rec + (size_t)(pr >> 4) * kRec, (int)((pr >> 2) & 3u), (int)(pr & 3u), mc, blk);
+                    }
+                }
+                stamp(2);
+                const bool owner = live && chunk == 0 && nchunks > 0;
+                // partial sums of the slot's other chunks: they sit in the next lanes of this wave, in chunk order
+                // (wave_shl:1 moves every lane's value one lane down, a VALU move; c steps bring chunk c to its owner)
+                if (wave_chunks > 1) {
+#pragma unroll
+                    for (int i = 0; i < 36; i++) {
+                        if (i < 21 || !wave_sym) {
+                            double t = blk[i];
+                            for (int c = 1; c < wave_chunks; c++) {
+                                t = lane_below(t);
+                                if (owner && c < nchunks) blk[i] += t;
+                            }
+                        }
+                    }
+                }
+                stamp(3);
+                if (owner) {
+                    const uint32_t mrow = flags & 63u, mcol = (flags >> 6) & 63u;
+                    const int valence = (int)((flags >> 12) & 255u);
+                    const bool diag_slot = (flags >> 20) & 1u;
+                    typedef double v2d __attribute__((ext_vector_type(2)));
+                    if (sym_item) {
+                        if (mrow) {
+#pragma unroll
+                            for (int i = 0; i < 6; i++)
+#pragma unroll
+                                for (int jj = i; jj < 6; jj++)
+                                    if (((mrow >> i) & 1u) | ((mrow >> jj) & 1u)) blk[sym6(i, jj)] = (i == jj) ? (double)valence : 0.0;
+                        }
+                        v2d *dst = reinterpret_cast<v2d *>(out) + (slot_in_slice & 31);
+#pragma unroll
+                        for (int jp = 0; jp < 3; jp++)
+#pragma unroll
+                            for (int i = 0; i < 6; i++) {
+                                const int j0 = 2 * jp, j1 = 2 * jp + 1;
+                                v2d vv;
+                                vv.x = blk[i <= j0 ? sym6(i, j0) : sym6(j0, i)];
+                                vv.y = blk[i <= j1 ? sym6(i, j1) : sym6(j1, i)];
+                                __builtin_nontemporal_store(vv, dst + (jp * 6 + i) * kSliceNodes);
+                            }
+                    } else {
+                        if (mrow | mcol) {
+#pragma unroll
+                            for (int i = 0; i < 6; i++)
+#pragma unroll
+                                for (int jj = 0; jj < 6; jj++)
+                                    if (((mrow >> i) & 1u) | ((mcol >> jj) & 1u)) blk[6 * i + jj] = 0.0;
+                            if (diag_slot) {
+#pragma unroll
+                                for (int i = 0; i < 6; i++)
+                                    if ((mrow >> i) & 1u) blk[7 * i] = (double)valence;
+                            }
+                        }
+                        v2d *dst = reinterpret_cast<v2d *>(out) + (size_t)(slot_in_slice >> 5) * 3 * kSliceRows + (slot_in_slice & 31);
+#pragma unroll
+                        for (int jp = 0; jp < 3; jp++)
+#pragma unroll
+                            for (int i = 0; i < 6; i++) {
+                                v2d vv;
+                                vv.x = blk[6 * i + 2 * jp];
+                                vv.y = blk[6 * i + 2 * jp + 1];
+                                __builtin_nontemporal_store(vv, dst + (jp * 6 + i) * kSliceNodes);
+                            }
+                    }
+                }
+                stamp(4);
+            }
+            item_pre = item_next;
+            flags_pre = flags_next;
+            d0 = d1;
+            d1 = d2;
+            lds_barrier(); // this slice's records are free, the next slice's are complete
+            stamp(1);
+        }
+    }
+    if (kAblate & 32) {
+        if (lane == 0) {
+            unsigned long long *dst = m.stamps + ((size_t)blockIdx.x * 4 + vwave) * 8;
+            for (int q = 0; q < 8; q++) dst[q] = tacc[q];
+        }
+    }
+}
+
 } // namespace femshell

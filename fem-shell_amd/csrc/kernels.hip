@@ -52,6 +52,17 @@ void launch_assemble(const DeviceMatrix &m, const MatConst &mc, hipStream_t st)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kernel, dim3(g), dim3(256), lds, st, m, mc);
     };
+    if (m.pipe) { // two workgroups per CU, b and b + G/2 on the same one: their roles complement each other
+        static const int pipe_cap = [] {
+            const char *e = getenv("FEMSHELL_ASM_PIPE_GRID");
+            return e ? atoi(e) : 512;
+        }();
+        const int gp = g < pipe_cap ? g : pipe_cap;
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_assemble_pipe<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_assemble_pipe<0>, dim3(gp), dim3(256), lds, st, m, mc);
+        return;
+    }
     if (m.n_lquad > 0) {
         launch(k_assemble<2, 0, true>);
         return;

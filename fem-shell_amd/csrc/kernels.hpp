@@ -35,7 +35,9 @@ struct DeviceMatrix {
                                              // = diagonal slot; 0 for items that do not own their slot
     int32_t max_stage_rows = 0;
     int32_t lds_bytes = 0;                   // dynamic LDS of k_assemble (assemble_lds_layout)
-    int32_t lds_rec_off = 0, lds_stage_off = 0; // offsets in doubles
+    int32_t lds_rec_off = 0, lds_stage_off = 0; // offsets in doubles (pipe: lds_rec_off = doubles of one record buffer)
+    int32_t pipe = 0;                        // items laid out for k_assemble_pipe (Plan::pipe)
+    int32_t slice_elem_ptr_last = 0;         // entries of slice_elem_nodes
     const uint8_t *dmask = nullptr;     // per local node (owned, padding, ghosts)
     double *vals = nullptr;             // total_slots x 36, sliced layout
     const float *vals32 = nullptr;      // the same in single precision (smoothing products of the multigrid cycle only)
@@ -64,6 +66,12 @@ struct DeviceMatrix {
 // rows per slice: [records | partial sums].  Returns the dynamic LDS size in bytes.
 inline size_t assemble_lds_layout(DeviceMatrix &m, int32_t max_slice_elems, int32_t max_stage_rows, bool has_quads)
 {
+    if (m.pipe) { // k_assemble_pipe: two buffers of lean records, no staging
+        m.lds_rec_off = max_slice_elems * RecLean::doubles;
+        m.lds_stage_off = 0;
+        m.lds_bytes = (int32_t)(2 * (size_t)m.lds_rec_off * sizeof(double));
+        return (size_t)m.lds_bytes;
+    }
     const int rec = has_quads ? kRecDoublesQuad : kRecDoubles;
     m.lds_rec_off = 0;
     m.lds_stage_off = max_slice_elems * rec;

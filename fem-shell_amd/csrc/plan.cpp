@@ -106,6 +106,56 @@ bool default_symmetric_storage()
     return !(e && atoi(e) == 0);
 }
 
+// Items of one slice (slot by slot, chunk 0 first: Plan::Item) into the lanes of the pipelined kernel's rounds: 192 lanes
+// = three waves per round; all chunks of a slot in consecutive lanes of one wave (their partial sums meet through lane
+// permutes, no LDS, no barrier); diagonal slots first, off-diagonal slots from the next wave on when the round has the
+// room (a wave that holds both kinds runs both code paths).  Unused lanes carry inert items.  Word w of every item of a
+// wave: most chunks of a slot in this wave | all-diagonal flag << 8.
+static void pack_items_pipe(const std::vector<Plan::Item> &in, std::vector<Plan::Item> *out)
+{
+    constexpr int kRound = 192, kWave = 64;
+    const Plan::Item pad{0xffffu, 0, 0, 0};
+    out->clear();
+    size_t round_begin = 0;
+    int pos = 0; // lane within the current round
+    auto place = [&](size_t first, int n) {
+        if (pos % kWave + n > kWave) pos = (pos / kWave + 1) * kWave; // the slot's chunks stay in one wave
+        if (pos + n > kRound) {
+            out->resize(round_begin + kRound, pad);
+            round_begin += kRound;
+            pos = 0;
+        }
+        out->resize(round_begin + pos, pad);
+        for (int c = 0; c < n; c++) out->push_back(in[first + c]);
+        pos += n;
+    };
+    // diagonal slots (slot index below 32), in the order given; then the others by decreasing work (stable)
+    int diag_lanes = 0, off_lanes = 0;
+    for (size_t i = 0; i < in.size(); i += in[i].x >> 24) {
+        if ((in[i].x & 0xffffu) < (uint32_t)kSliceNodes) diag_lanes += (int)(in[i].x >> 24);
+        else off_lanes += (int)(in[i].x >> 24);
+    }
+    for (size_t i = 0; i < in.size(); i += in[i].x >> 24)
+        if ((in[i].x & 0xffffu) < (uint32_t)kSliceNodes) place(i, (int)(in[i].x >> 24));
+    if (pos % kWave != 0 && (pos / kWave + 1) * kWave + off_lanes <= kRound) pos = (pos / kWave + 1) * kWave;
+    for (int np = kItemPairs; np >= 0; np--)
+        for (size_t i = 0; i < in.size(); i += in[i].x >> 24)
+            if ((in[i].x & 0xffffu) >= (uint32_t)kSliceNodes && (int)(in[i].z >> 16) == np) place(i, (int)(in[i].x >> 24));
+    (void)diag_lanes;
+    // the waves' words
+    for (size_t w0 = 0; w0 < out->size(); w0 += kWave) {
+        const size_t w1 = std::min(out->size(), w0 + kWave);
+        uint32_t most = 0, all_diag = 1;
+        for (size_t i = w0; i < w1; i++) {
+            const Plan::Item &it = (*out)[i];
+            if ((it.x >> 24) == 0) continue; // inert
+            most = std::max(most, it.x >> 24);
+            if ((it.x & 0xffffu) >= (uint32_t)kSliceNodes) all_diag = 0;
+        }
+        for (size_t i = w0; i < w1; i++) (*out)[i].w = most | (all_diag << 8);
+    }
+}
+
 bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri, int32_t n_quad,
                 const int32_t *quad, int rank, int world, Plan *P, std::string *err, bool symmetric, bool geometric_orientation)
 {
@@ -677,6 +727,18 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     // against items of 3 (160 items): 0.904 vs 0.875 ms -- fewer items and partial-sum rows win, 3 stays
     static const int item_pairs_env = getenv("FEMSHELL_ITEM_PAIRS") ? atoi(getenv("FEMSHELL_ITEM_PAIRS")) : 0;
     const int item_pairs = (item_pairs_env >= 1 && item_pairs_env <= kItemPairs) ? item_pairs_env : kItemPairs;
+    // Item layout of the pipelined kernel (k_assemble_pipe, assemble_kernel.hpp): rounds of 192 lanes, the chunks of a
+    // slot in neighbouring lanes of one wave, diagonal slots in waves of their own where the round has room.  For meshes of
+    // triangles whose slices leave room for two record buffers per workgroup, two workgroups per CU; FEMSHELL_ASM_PIPE=0
+    // keeps the two-phase kernel (read per plan).
+    p.pipe = false;
+    {
+        const char *e = getenv("FEMSHELL_ASM_PIPE");
+        const bool wanted = !(e && atoi(e) == 0);
+        int32_t max_cnt = 0;
+        for (size_t i = 0; i + 1 < p.pair_ptr.size(); i++) max_cnt = std::max(max_cnt, p.pair_ptr[i + 1] - p.pair_ptr[i]);
+        p.pipe = wanted && p.n_lquad() == 0 && p.max_slice_elems <= kPipeMaxSliceElems && (max_cnt + item_pairs - 1) / item_pairs <= 64;
+    }
     p.item_ptr.assign((size_t)p.n_slices + 1, 0);
     {
         // chunks of slices on the host threads, each into an item list of its own, joined in slice order afterwards
@@ -724,7 +786,11 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                         }
                         stage += nchunks - 1;
                     }
-                if (tmp.size() <= 256) {
+                if (p.pipe) {
+                    pack_items_pipe(tmp, &packed);
+                    tmp.swap(packed);
+                    stage = 0;
+                } else if (tmp.size() <= 256) {
                     // one round: order by decreasing work so that the waves are uniform
                     order_by_work(tmp, 0);
                 } else {

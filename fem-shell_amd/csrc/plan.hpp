@@ -28,6 +28,9 @@ namespace femshell {
 constexpr int kSliceNodes = 32;             // node rows per slice
 constexpr int kSliceRows = 6 * kSliceNodes; // scalar rows per slice
 constexpr int kItemPairs = 3;                // element contributions per assembly work item
+// most elements a slice may touch for the pipelined assembly kernel: two buffers of 34-double records per workgroup, two
+// workgroups in the 160 KiB of a CU
+constexpr int kPipeMaxSliceElems = 150;
 
 struct HaloPeer {
     int rank = -1;
@@ -80,6 +83,9 @@ struct Plan {
     std::vector<int32_t> slice_desc; // 8 per slice: elem begin, elem count, item begin, item count, slot base lo, hi, width, 0
     std::vector<Item> items;
     int32_t max_stage_rows = 0;    // staging rows (36 doubles each) a slice needs at most
+    // pipe == true: the items are laid out for the pipelined kernel (plan.cpp pack_items_pipe: rounds of 192 lanes,
+    // a slot's chunks in neighbouring lanes of one wave, w = wave word) and no staging rows are needed
+    bool pipe = false;
     int32_t max_slice_width = 0;
     int64_t nnz_blocks = 0;            // blocks of the owned rows of K (what femshell_export_bsr returns)
     // Symmetric storage (default; FEMSHELL_SYMMETRIC=0 stores every block): K = K^T, so of an off-diagonal pair

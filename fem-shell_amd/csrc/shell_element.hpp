@@ -226,9 +226,46 @@ __device__ __forceinline__ bool tri3_record(const double X[9], const MatConst &m
     return ok;
 }
 
+// Where the fields of a TRI3 record sit.  RecFull is the record tri3_record writes (k_assemble keeps it in LDS as it is);
+// RecLean drops what the block functions can do without -- ey = ez x ex and the kind word -- and is 34 doubles = 4*17
+// dwords (an odd multiple of a bank quad, like 38): the pipelined assembly kernel keeps two slices of records in LDS.
+struct RecFull {
+    static constexpr int ex = 0, ey = 3, ez = 6, xs = 9, ys = 12, sm = 15, QQ = kRecQQ, QC = kRecQC, CC = kRecCC;
+    static constexpr bool has_ey = true;
+};
+struct RecLean {
+    static constexpr int ex = 0, ey = 0, ez = 3, xs = 6, ys = 9, sm = 12, QQ = 13, QC = 19, CC = 28;
+    static constexpr bool has_ey = false;
+    static constexpr int doubles = 34;
+};
+// full record -> lean record, field by field (q = 0..33)
+__host__ __device__ constexpr int lean_from_full(int q)
+{
+    return q < 3 ? q : (q < 6 ? q + 3 : (q < 12 ? q + 3 : (q == 12 ? 15 : q + 4)));
+}
+// the three frame axes of a record
+template <class L> __device__ __forceinline__ void rec_axes(const double *rec, double ex[3], double ey[3], double ez[3])
+{
+#pragma clang fp reassociate(on) contract(fast)
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        ex[d] = rec[L::ex + d];
+        ez[d] = rec[L::ez + d];
+    }
+    if (L::has_ey) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) ey[d] = rec[L::ey + d];
+    } else { // as in tri3_frame
+        ey[0] = ez[1] * ex[2] - ez[2] * ex[1];
+        ey[1] = ez[2] * ex[0] - ez[0] * ex[2];
+        ey[2] = ez[0] * ex[1] - ez[1] * ex[0];
+    }
+}
+
 // Adds the global-axes 6x6 block K_e(ia, ib) of the element described by rec to acc (row-major).
 // rec may live in LDS (assembly kernel) or in registers/global (export kernel).  No selects: everything
 // that depends on the (runtime) node indices is fetched by address.
+template <class L = RecFull>
 __device__ __forceinline__ void tri3_block_add_rec(const double *rec, int ia, int ib, const MatConst &mc, double acc[36])
 {
 #pragma clang fp reassociate(on) contract(fast) // element math only; parity bar is 1e-12, not bitwise
@@ -238,20 +275,20 @@ __device__ __forceinline__ void tri3_block_add_rec(const double *rec, int ia, in
     // (x_ji,y_ji) = -row {0,2,1}[i]; membrane: beta = y of row {2,1,0}[i], gamma = -x of that row
     const int rki_a = (ia == 2) ? 2 : 1 - ia, rji_a = (ia == 0) ? 0 : 3 - ia;
     const int rki_b = (ib == 2) ? 2 : 1 - ib, rji_b = (ib == 0) ? 0 : 3 - ib;
-    const double xki_a = rec[9 + rki_a], yki_a = rec[12 + rki_a], xji_a = -rec[9 + rji_a], yji_a = -rec[12 + rji_a];
-    const double xki_b = rec[9 + rki_b], yki_b = rec[12 + rki_b], xji_b = -rec[9 + rji_b], yji_b = -rec[12 + rji_b];
-    const double bi = rec[12 + 2 - ia], gi = -rec[9 + 2 - ia];
-    const double bj = rec[12 + 2 - ib], gj = -rec[9 + 2 - ib];
+    const double xki_a = rec[L::xs + rki_a], yki_a = rec[L::ys + rki_a], xji_a = -rec[L::xs + rji_a], yji_a = -rec[L::ys + rji_a];
+    const double xki_b = rec[L::xs + rki_b], yki_b = rec[L::ys + rki_b], xji_b = -rec[L::xs + rji_b], yji_b = -rec[L::ys + rji_b];
+    const double bi = rec[L::ys + 2 - ia], gi = -rec[L::xs + 2 - ia];
+    const double bj = rec[L::ys + 2 - ib], gj = -rec[L::xs + 2 - ib];
 
     // ---- membrane block (2x2), closed form of t*A*B_i^T Dm B_j  (SA:448-467)
-    const double sm = rec[15];
+    const double sm = rec[L::sm];
     const double m00 = sm * (bi * bj + mc.g * gi * gj);
     const double m01 = sm * (mc.nu * bi * gj + mc.g * gi * bj);
     const double m10 = sm * (mc.nu * gi * bj + mc.g * bi * gj);
     const double m11 = sm * (gi * gj + mc.g * bi * bj);
 
     // ---- plate block (3x3)  (SA:555-603): p = L_i^T S L_j from the record's Gram tables
-    const double *QQ = rec + kRecQQ, *QC = rec + kRecQC, *CC = rec + kRecCC;
+    const double *QQ = rec + L::QQ, *QC = rec + L::QC, *CC = rec + L::CC;
     const int s_ab = sym3(ia, ib), s_akb = sym3(ia, kb), s_kab = sym3(ka, ib), s_kakb = sym3(ka, kb);
     double S[4][4];
     S[0][0] = QQ[s_ab];        S[0][1] = QQ[s_akb];       S[0][2] = QC[3 * ia + kb]; S[0][3] = QC[3 * ia + ib];
@@ -285,7 +322,8 @@ __device__ __forceinline__ void tri3_block_add_rec(const double *rec, int ia, in
 
     // ---- rotation: [T^T A11 T, T^T A12 T; T^T A21 T, T^T A22 T] as outer products of the
     //      frame axes (SA:1084-1102 with TSub = diag(T,T))
-    const double ex[3] = {rec[0], rec[1], rec[2]}, ey[3] = {rec[3], rec[4], rec[5]}, ez[3] = {rec[6], rec[7], rec[8]};
+    double ex[3], ey[3], ez[3];
+    rec_axes<L>(rec, ex, ey, ez);
 #pragma unroll
     for (int s = 0; s < 3; s++) {
         const double a_x = m00 * ex[s] + m01 * ey[s]; // row ex of A11
@@ -318,23 +356,24 @@ __host__ __device__ constexpr int sym6(int i, int j)
 // contributions of a mesh with symmetric storage -- so its lanes accumulate the upper triangle alone:
 // 21 accumulators instead of 36, 26 record fields instead of 38, about 0.7 of the arithmetic.
 // acc is the packed upper triangle (sym6).
+template <class L = RecFull>
 __device__ __forceinline__ void tri3_diag_add_rec(const double *rec, int ia, const MatConst &mc, double acc[21])
 {
 #pragma clang fp reassociate(on) contract(fast) // element math only; parity bar is 1e-12, not bitwise
 
     const int ka = (ia == 0) ? 2 : ia - 1;
     const int rki = (ia == 2) ? 2 : 1 - ia, rji = (ia == 0) ? 0 : 3 - ia;
-    const double xki = rec[9 + rki], yki = rec[12 + rki], xji = -rec[9 + rji], yji = -rec[12 + rji];
-    const double bi = rec[12 + 2 - ia], gi = -rec[9 + 2 - ia];
+    const double xki = rec[L::xs + rki], yki = rec[L::ys + rki], xji = -rec[L::xs + rji], yji = -rec[L::ys + rji];
+    const double bi = rec[L::ys + 2 - ia], gi = -rec[L::xs + 2 - ia];
 
     // membrane (SA:448-467) with i == j
-    const double sm = rec[15];
+    const double sm = rec[L::sm];
     const double m00 = sm * (bi * bi + mc.g * gi * gi);
     const double m01 = sm * ((mc.nu + mc.g) * bi * gi);
     const double m11 = sm * (gi * gi + mc.g * bi * bi);
 
     // plate (SA:555-603): p = L^T S L, S symmetric
-    const double *QQ = rec + kRecQQ, *QC = rec + kRecQC, *CC = rec + kRecCC;
+    const double *QQ = rec + L::QQ, *QC = rec + L::QC, *CC = rec + L::CC;
     const int s_aa = sym3(ia, ia), s_ak = sym3(ia, ka), s_kk = sym3(ka, ka);
     const double S00 = QQ[s_aa], S01 = QQ[s_ak], S02 = QC[3 * ia + ka], S03 = QC[3 * ia + ia];
     const double S11 = QQ[s_kk], S12 = QC[3 * ka + ka], S13 = QC[3 * ka + ia];
@@ -360,7 +399,8 @@ __device__ __forceinline__ void tri3_diag_add_rec(const double *rec, int ia, con
                                                  : fmin(fmin(fmin(m00, m11), fmin(p0[0], p11)), p22)) * 1.0e-3;
 
     // rotation (SA:1084-1102), upper triangle only
-    const double ex[3] = {rec[0], rec[1], rec[2]}, ey[3] = {rec[3], rec[4], rec[5]}, ez[3] = {rec[6], rec[7], rec[8]};
+    double ex[3], ey[3], ez[3];
+    rec_axes<L>(rec, ex, ey, ez);
 #pragma unroll
     for (int s = 0; s < 3; s++) {
         const double a_x = m00 * ex[s] + m01 * ey[s];

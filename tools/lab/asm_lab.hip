@@ -59,6 +59,44 @@ int main(int argc, char **argv)
     mc.cm = E / (1 - nu * nu); mc.cp = E * t * t * t / (12 * (1 - nu * nu)); mc.nu = nu; mc.g = (1 - nu) / 2; mc.t = t; mc.flags = 3; mc.pad = 0;
     printf("nx=%d slices=%d max_elems=%d max_stage=%d items=%zu lds=%d grid=%d\n", nx, p.n_slices, p.max_slice_elems, p.max_stage_rows, p.items.size(), m.lds_bytes, grid);
     const int R = 5;
+    if (p.pipe) { // the plan's items are laid out for the pipelined kernel: nothing else can run on them
+        m.pipe = 1;
+        m.slice_elem_ptr_last = (int32_t)(p.slice_elem_nodes.size() / 4);
+        assemble_lds_layout(m, p.max_slice_elems, 0, false);
+        auto runp = [&](auto kernel, int g, int reps) {
+            CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, m.lds_bytes));
+            for (int i = 0; i < 25; i++) hipLaunchKernelGGL(kernel, dim3(g), dim3(256), m.lds_bytes, 0, m, mc);
+            CK(hipDeviceSynchronize());
+            hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+            CK(hipEventRecord(a));
+            for (int i = 0; i < reps; i++) hipLaunchKernelGGL(kernel, dim3(g), dim3(256), m.lds_bytes, 0, m, mc);
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b));
+            return ms / reps;
+        };
+        printf("pipe lds=%d\n", m.lds_bytes);
+        for (int g : {512, 256, 1024, 2048}) printf("pipe grid %4d          : %.3f ms\n", g, runp(k_assemble_pipe<0>, g, R));
+        unsigned long long *st; const int g = 512;
+        CK(hipMalloc(&st, (size_t)g * 4 * 8 * 8 + 16)); CK(hipMemset(st, 0, (size_t)g * 4 * 8 * 8 + 16));
+        m.stamps = st;
+        printf("pipe, no record math   : %.3f ms\n", runp(k_assemble_pipe<8>, g, R));
+        printf("pipe, roles by wave id : %.3f ms\n", runp(k_assemble_pipe<16>, g, R));
+        printf("pipe, no priority      : %.3f ms\n", runp(k_assemble_pipe<64>, g, R));
+        printf("pipe again             : %.3f ms\n", runp(k_assemble_pipe<0>, g, R));
+        const bool fake = getenv("LAB_FAKE_RECORDS") != nullptr;
+        const float ms = fake ? runp(k_assemble_pipe<40>, g, 1) : runp(k_assemble_pipe<32>, g, 1);
+        std::vector<unsigned long long> h((size_t)g * 4 * 8);
+        CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+        printf("stamped pipe: %.3f ms; cycles per slice by role (0: diagonal items, 1-2: off-diagonal items, 3: records):\n", ms);
+        for (int wv = 0; wv < 4; wv++) {
+            double tw[8] = {0}, allw = 0;
+            for (size_t b_ = 0; b_ < (size_t)g; b_++) for (int q = 0; q < 8; q++) { tw[q] += (double)h[(b_ * 4 + wv) * 8 + q]; allw += (double)h[(b_ * 4 + wv) * 8 + q]; }
+            printf("  role %d:", wv);
+            for (int q = 0; q < 7; q++) printf(" %6.0f", tw[q] / (double)p.n_slices);
+            printf("  (records, barrier, block math, lane sums, stores, top, prefetch)  total %.0f\n", allw / (double)p.n_slices);
+        }
+        return 0;
+    }
     printf("W2 full               : %.3f ms\n", run<2, 0>(m, mc, grid, R));
     printf("W3 full               : %.3f ms\n", run<3, 0>(m, mc, grid, R));
     printf("W2 plain stores       : %.3f ms\n", run<2, 64>(m, mc, grid, R));
