@@ -24,7 +24,7 @@ SYMBOLS = [
     "femshell_nnz_blocks", "femshell_export_bsr", "femshell_spmv", "femshell_row_begin",
     "femshell_row_end", "femshell_comm_unique_id", "femshell_comm_init", "femshell_time_kernel",
     "femshell_sync", "femshell_pc_defaults", "femshell_set_preconditioner", "femshell_amg_levels", "femshell_amg_level",
-    "femshell_amg_export", "femshell_residual", "femshell_comm_ranks", "femshell_amg_setup_stats", "femshell_amg_dense_stats",
+    "femshell_amg_export", "femshell_residual", "femshell_comm_ranks", "femshell_amg_setup_stats", "femshell_amg_dense_stats", "femshell_assembly_kernel",
 ]
 
 
@@ -134,6 +134,7 @@ def load_library():
     L.femshell_amg_export.restype = C.c_int64
     L.femshell_amg_setup_stats.argtypes = [vp, dp]
     L.femshell_amg_dense_stats.argtypes = [vp, dp]
+    L.femshell_assembly_kernel.argtypes = [vp]
     for name in SYMBOLS:
         if name != "femshell_last_error" and not name.startswith("femshell_nnz") and \
                 not name.startswith("femshell_row") and name != "femshell_residual_history" and \
@@ -307,6 +308,13 @@ class FemShell:
         return {"prolongator_ms": out[0], "ap_ms": out[1], "restriction_ms": out[2], "galerkin_ms": out[3],
                 "galerkin_useful_flops": out[4], "galerkin_mfma_flops_issued": out[5], "galerkin_on_matrix_cores": bool(out[6])}
 
+    def assembly_kernel(self):
+        """Name of the kernel femshell_assemble launches for this mesh."""
+        k = self._L.femshell_assembly_kernel(self._h)
+        if k < 0:
+            _check(k)
+        return "k_assemble_pipe" if k == 1 else "k_assemble"
+
     def amg_dense_stats(self):
         """The dense inverse of the coarsest operator when the matrix cores computed it (n = 0: host path)."""
         out = np.zeros(6)
@@ -335,7 +343,7 @@ class FemShell:
 
 PLAN_INFO = ["n_own", "n_pad", "n_ghost", "n_slices", "n_ltri", "n_lquad", "total_slots", "n_pairs",
              "n_peers", "row_begin", "row_end", "nnz_blocks", "n_interior_slices", "n_items",
-             "n_multi_round_slices", "max_slice_elems", "max_slice_width", "symmetric", "stored_blocks"]
+             "n_multi_round_slices", "max_slice_elems", "max_slice_width", "symmetric", "stored_blocks", "pipe"]
 PLAN_ARRAYS = {
     "ghost_global": (0, np.int32), "tri_local": (1, np.int32), "tri_global_id": (2, np.int32),
     "quad_local": (3, np.int32), "quad_global_id": (4, np.int32), "slice_width": (5, np.int32),
@@ -344,6 +352,7 @@ PLAN_ARRAYS = {
     "peer_recv_count": (13, np.int32), "peer_send_ptr": (14, np.int32), "peer_send_nodes": (15, np.int32),
     "spmv_order": (16, np.int32), "in_width": (17, np.int32), "in_base": (18, np.int64), "in_slots": (19, np.int32),
     "gat_slots": (20, np.int32), "loc_list": (21, np.uint8), "loc_index": (22, np.uint8),
+    "item_ptr": (23, np.int32), "items": (24, np.uint32), "pairs16": (25, np.uint16), "slice_elem_ptr": (26, np.int32),
 }
 
 

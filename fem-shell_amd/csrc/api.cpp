@@ -797,6 +797,13 @@ int femshell_amg_setup_stats(femshell_ctx *c, double out[7])
     return FEMSHELL_OK;
 }
 
+int femshell_assembly_kernel(femshell_ctx *c)
+{
+    if (!c) return set_err(FEMSHELL_ERR_INVALID, "femshell_assembly_kernel: null context");
+    if (!c->have_mesh) return set_err(FEMSHELL_ERR_INVALID, "femshell_assembly_kernel: no mesh");
+    return c->dm.pipe ? 1 : 0;
+}
+
 int femshell_amg_dense_stats(femshell_ctx *c, double out[6])
 {
     if (!c || !out) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_dense_stats: null argument");

@@ -407,7 +407,8 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
 // pack_items_pipe, and meet through lane permutes).  Which wave does what follows the SIMD it runs on, and the second
 // workgroup of a CU shifts the roles by two SIMDs, so that every SIMD carries one long and one short wave.
 // Records are RecLean (34 doubles), items and flags as in k_assemble, in rounds of 192.
-// kAblate (lab): 8 = no record math, 16 = roles by wave index and the same in every workgroup, 32 = s_memtime stamps;
+// kAblate (lab): 8 = no record math, 16 = roles by wave index and the same in every workgroup, 32 = s_memtime stamps,
+// 64 = no priority for the producer, 128 = the second workgroup swaps neighbouring roles instead of shifting them by two SIMDs;
 // 0 in the product.
 // =====================================================================================
 // value of the next lane of the wave (lane 63: unspecified): DPP wave_shl:1 on both halves of the double
@@ -441,8 +442,11 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
         __syncthreads();
         const int seen = (1 << simd_of_wave[0]) | (1 << simd_of_wave[1]) | (1 << simd_of_wave[2]) | (1 << simd_of_wave[3]);
         const int place = (seen == 15 && !(kAblate & 16)) ? simd : wave;
-        const int shift = (blockIdx.x >= (gridDim.x >> 1) && !(kAblate & 16)) ? 2 : 0;
-        vwave = __builtin_amdgcn_readfirstlane((place + shift) & 3);
+        const bool second = blockIdx.x >= (gridDim.x >> 1) && !(kAblate & 16);
+        // roles of the first workgroup on SIMDs 0..3: diagonal | off-diagonal | off-diagonal (last wave) | producer; the
+        // second one is shifted by two SIMDs: diagonal opposite the last off-diagonal wave, producer opposite the full
+        // off-diagonal wave (measured against swapping neighbours, producer opposite the last wave: 0.56 against 0.62 ms)
+        vwave = __builtin_amdgcn_readfirstlane((kAblate & 128) ? (second ? (place ^ 1) : place) : ((place + (second ? 2 : 0)) & 3));
     }
     SliceWalk w(m.n_slices);
     if (!w.valid()) return;
@@ -692,7 +696,21 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
                 const bool owner = live && chunk == 0 && nchunks > 0;
                 // partial sums of the slot's other chunks: they sit in the next lanes of this wave, in chunk order
                 // (wave_shl:1 moves every lane's value one lane down, a VALU move; c steps bring chunk c to its owner)
-                if (wave_chunks > 1) {
+                if (wave_chunks == 2 && wave_sym) { // the common case spelled out: six-element nodes, two chunks of three
+                    const bool take = owner && nchunks == 2;
+#pragma unroll
+                    for (int i = 0; i < 21; i++) {
+                        const double t = lane_below(blk[i]);
+                        blk[i] += take ? t : 0.0;
+                    }
+                } else if (wave_chunks == 2) { // (a wave of off-diagonal slots cut in two: plan.cpp pack_items_pipe)
+                    const bool take = owner && nchunks == 2;
+#pragma unroll
+                    for (int i = 0; i < 36; i++) {
+                        const double t = lane_below(blk[i]);
+                        blk[i] += take ? t : 0.0;
+                    }
+                } else if (wave_chunks > 1) {
 #pragma unroll
                     for (int i = 0; i < 36; i++) {
                         if (i < 21 || !wave_sym) {

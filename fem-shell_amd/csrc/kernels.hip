@@ -53,9 +53,13 @@ void launch_assemble(const DeviceMatrix &m, const MatConst &mc, hipStream_t st)
         hipLaunchKernelGGL(kernel, dim3(g), dim3(256), lds, st, m, mc);
     };
     if (m.pipe) { // two workgroups per CU, b and b + G/2 on the same one: their roles complement each other
-        static const int pipe_cap = [] {
+        static const int pipe_cap = [] { // two workgroups per CU of this device (FEMSHELL_ASM_PIPE_GRID overrides)
             const char *e = getenv("FEMSHELL_ASM_PIPE_GRID");
-            return e ? atoi(e) : 512;
+            if (e) return atoi(e);
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                cus = 256;
+            return 8 * ((2 * cus + 7) / 8);
         }();
         const int gp = g < pipe_cap ? g : pipe_cap;
         if (lds > 64 * 1024)

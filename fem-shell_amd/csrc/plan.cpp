@@ -142,6 +142,48 @@ static void pack_items_pipe(const std::vector<Plan::Item> &in, std::vector<Plan:
         for (size_t i = 0; i < in.size(); i += in[i].x >> 24)
             if ((in[i].x & 0xffffu) >= (uint32_t)kSliceNodes && (int)(in[i].z >> 16) == np) place(i, (int)(in[i].x >> 24));
     (void)diag_lanes;
+    // A last wave that is at most half full of whole off-diagonal slots (32 of a structured slice's 96) is cut finer: every
+    // slot of two or three contributions becomes two chunks in neighbouring lanes, so that the wave runs one contribution
+    // (two for a slot of three) plus a lane sum instead of two or three -- it shares its SIMD with the other workgroup's
+    // producer wave, the longest one (assemble_kernel.hpp)
+    {
+        const size_t w0 = round_begin + (size_t)(pos > 0 ? (pos - 1) / kWave : 0) * kWave;
+        const size_t w1 = out->size();
+        bool fits = pos > 0 && w1 > w0;
+        int lanes_after = 0;
+        for (size_t i = w0; i < w1 && fits; i++) {
+            const Plan::Item &it = (*out)[i];
+            const uint32_t nch = it.x >> 24, np = it.z >> 16;
+            if (nch == 0) continue;
+            if (nch != 1 || (it.x & 0xffffu) < (uint32_t)kSliceNodes) fits = false;
+            lanes_after += np >= 2 ? 2 : 1;
+        }
+        if (fits && lanes_after <= kWave && lanes_after > (int)(w1 - w0) - 0) {
+            std::vector<Plan::Item> cut;
+            for (size_t i = w0; i < w1; i++) {
+                const Plan::Item &it = (*out)[i];
+                const uint32_t nch = it.x >> 24, np = it.z >> 16;
+                if (nch == 0) continue; // (padding inside the wave is dropped)
+                if (np < 2) {
+                    cut.push_back(it);
+                    continue;
+                }
+                const uint32_t pr[3] = {it.y & 0xffffu, it.y >> 16, it.z & 0xffffu};
+                const uint32_t n0 = np - 1; // first chunk: all but the last contribution
+                Plan::Item a = it, b = it;
+                a.x = (it.x & 0xffffu) | (0u << 16) | (2u << 24);
+                a.y = pr[0] | ((n0 > 1 ? pr[1] : 0u) << 16);
+                a.z = 0u | (n0 << 16);
+                b.x = (it.x & 0xffffu) | (1u << 16) | (2u << 24);
+                b.y = pr[np - 1];
+                b.z = 0u | (1u << 16);
+                cut.push_back(a);
+                cut.push_back(b);
+            }
+            out->resize(w0);
+            out->insert(out->end(), cut.begin(), cut.end());
+        }
+    }
     // the waves' words
     for (size_t w0 = 0; w0 < out->size(); w0 += kWave) {
         const size_t w1 = std::min(out->size(), w0 + kWave);

@@ -54,12 +54,13 @@ int femshell_plan_info(const femshell_plan *plan, int64_t *info)
     info[FEMSHELL_PLAN_N_INTERIOR_SLICES] = p.n_interior_slices;
     info[FEMSHELL_PLAN_N_ITEMS] = (int64_t)p.items.size();
     int64_t multi = 0;
-    for (int32_t s = 0; s < p.n_slices; s++) multi += (p.item_ptr[s + 1] - p.item_ptr[s]) > 256;
+    for (int32_t s = 0; s < p.n_slices; s++) multi += (p.item_ptr[s + 1] - p.item_ptr[s]) > (p.pipe ? 192 : 256);
     info[FEMSHELL_PLAN_N_MULTI_ROUND_SLICES] = multi;
     info[FEMSHELL_PLAN_MAX_SLICE_ELEMS] = p.max_slice_elems;
     info[FEMSHELL_PLAN_MAX_SLICE_WIDTH] = p.max_slice_width;
     info[FEMSHELL_PLAN_SYMMETRIC] = p.symmetric ? 1 : 0;
     info[FEMSHELL_PLAN_STORED_BLOCKS] = p.stored_blocks;
+    info[FEMSHELL_PLAN_PIPE] = p.pipe ? 1 : 0;
     return FEMSHELL_OK;
 }
 
@@ -91,6 +92,12 @@ int64_t femshell_plan_array(const femshell_plan *plan, int which, void *out)
     case FEMSHELL_PLAN_GAT_SLOTS: return give(p.gat_slots);
     case FEMSHELL_PLAN_LOC_LIST: return give(p.loc_list);
     case FEMSHELL_PLAN_LOC_INDEX: return give(p.loc_index);
+    case FEMSHELL_PLAN_ITEM_PTR: return give(p.item_ptr);
+    case FEMSHELL_PLAN_ITEMS:
+        if (out && !p.items.empty()) std::memcpy(out, p.items.data(), p.items.size() * sizeof(Plan::Item));
+        return (int64_t)p.items.size() * 4;
+    case FEMSHELL_PLAN_PAIRS16: return give(p.pairs16);
+    case FEMSHELL_PLAN_SLICE_ELEM_PTR: return give(p.slice_elem_ptr);
     case FEMSHELL_PLAN_PEER_RANKS:
         for (auto &h : p.peers) tmp.push_back(h.rank);
         return give(tmp);

@@ -34,6 +34,10 @@ enum {
     FEMSHELL_PLAN_SYMMETRIC,         /* 1: symmetric storage -- of an off-diagonal pair of owned nodes only the block of
                                         the lower-numbered row has a slot (FEMSHELL_SYMMETRIC=0 turns it off) */
     FEMSHELL_PLAN_STORED_BLOCKS,     /* blocks that have a slot (NNZ_BLOCKS counts the blocks of the owned rows of K) */
+    FEMSHELL_PLAN_PIPE,              /* 1: the work items are laid out for the pipelined assembly kernel -- rounds of 192
+                                        lanes, the chunks of a slot in neighbouring lanes of one wave (csrc/plan.cpp
+                                        pack_items_pipe; FEMSHELL_ASM_PIPE=0 turns it off); N_MULTI_ROUND_SLICES then counts
+                                        the slices with more than 192 items */
     FEMSHELL_PLAN_INFO_COUNT
 };
 /* fills info[FEMSHELL_PLAN_INFO_COUNT] */
@@ -63,7 +67,13 @@ enum {
     /* transposed products that stay inside a slice go through LDS in the SpMV kernel (csrc/plan.hpp): */
     FEMSHELL_PLAN_GAT_SLOTS,        /* int32 [in_base.back()] IN_SLOTS without the blocks of the row's own slice (-1 there) */
     FEMSHELL_PLAN_LOC_LIST,         /* uint8 [in_base.back()] position of the block among its slice's in-slice blocks, 255 = none */
-    FEMSHELL_PLAN_LOC_INDEX         /* uint8 [total_slots]    the same position per slot, 255 = the product leaves the slice */
+    FEMSHELL_PLAN_LOC_INDEX,        /* uint8 [total_slots]    the same position per slot, 255 = the product leaves the slice */
+    /* assembly work items (csrc/plan.hpp Plan::Item): four words each */
+    FEMSHELL_PLAN_ITEM_PTR,         /* int32 [n_slices+1]                                          */
+    FEMSHELL_PLAN_ITEMS,            /* uint32 [n_items*4]     x = slot in slice | chunk << 16 | chunks << 24, y, z = up to three
+                                                              16-bit contributions and their count << 16, w          */
+    FEMSHELL_PLAN_PAIRS16,          /* uint16 [n_pairs]       PAIRS with the element as index into the slice's element list */
+    FEMSHELL_PLAN_SLICE_ELEM_PTR    /* int32 [n_slices+1]     range of a slice in its element list              */
 };
 /* returns the element count of the array; copies it to out when out != NULL */
 int64_t femshell_plan_array(const femshell_plan *plan, int which, void *out);

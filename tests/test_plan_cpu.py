@@ -335,3 +335,89 @@ def test_host_threads_do_not_change_the_plan(monkeypatch):
         monkeypatch.setenv("FEMSHELL_HOST_THREADS", str(threads))
         digests.append(_host_side_digest())
     assert digests[0] == digests[1] == digests[2], digests
+
+
+def _slot_lists_from_items(plan):
+    """Per slice: {slot in slice: contributions in chunk order}, lane of every item, the items themselves."""
+    items = plan["items"].reshape(-1, 4)
+    out = []
+    for s in range(plan["n_slices"]):
+        i0, i1 = plan["item_ptr"][s], plan["item_ptr"][s + 1]
+        slots = {}
+        for lane, (x, y, z, w) in enumerate(items[i0:i1]):
+            slot, chunk, nch, cnt = int(x & 0xffff), int((x >> 16) & 0xff), int(x >> 24), int(z >> 16)
+            if nch == 0:
+                assert slot == 0xffff and cnt == 0  # inert
+                continue
+            prs = [int(y & 0xffff), int(y >> 16), int(z & 0xffff)][:cnt]
+            slots.setdefault(slot, {})[chunk] = (lane, nch, prs)
+        out.append(slots)
+    return out
+
+
+@pytest.mark.parametrize("mesh", ["panel", "patch", "hub"])
+@pytest.mark.parametrize("symmetric", ["1", "0"])
+def test_work_items_of_both_assembly_kernels_carry_the_gather_lists(monkeypatch, mesh, symmetric):
+    """The work items (Plan::Item) are the gather lists cut into chunks of three contributions, laid out for the kernel that
+    reads them: k_assemble takes rounds of 256 ordered by work; k_assemble_pipe (csrc/plan.cpp pack_items_pipe) rounds of
+    192 lanes with the chunks of a slot in consecutive lanes of one wave, and a word per wave (most chunks of a slot, all
+    items diagonal).  Either way every slot's chunks, in order, are its gather list."""
+    monkeypatch.setenv("FEMSHELL_SYMMETRIC", symmetric)
+    if mesh == "panel":
+        m = meshes.structured(70, 45, 0, 0, 7, 4.5, kind="t", ul_lr=True)
+        xyz, tri = m.xyz, m.tri
+    elif mesh == "patch":
+        xyz, tri = meshes.delaunay_patch(3000, 7)
+    else:  # a fan of 40 triangles around one node among a regular grid: a slot with 14 chunks, others with one
+        m = meshes.structured(20, 20, 0, 0, 2, 2, kind="t", ul_lr=True)
+        ang = np.linspace(0.0, 2.0 * np.pi, 41)[:-1]
+        hub = len(m.xyz)
+        ring = np.stack([3.0 + 0.5 * np.cos(ang), 1.0 + 0.5 * np.sin(ang), np.zeros(40)], axis=1)
+        xyz = np.concatenate([m.xyz, [[3.0, 1.0, 0.2]], ring])
+        fan = np.array([[hub, hub + 1 + k, hub + 1 + (k + 1) % 40] for k in range(40)], dtype=np.int32)
+        tri = np.concatenate([m.tri, fan]).astype(np.int32)
+    plans = {}
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("FEMSHELL_ASM_PIPE", pipe)
+        plans[pipe] = pkg.build_plan(xyz, tri)
+    assert plans["0"]["pipe"] == 0
+    assert plans["1"]["pipe"] == (1 if plans["1"]["max_slice_elems"] <= 150 else 0)
+    assert plans["1"]["pipe"] == 1, plans["1"]["max_slice_elems"]  # (all three meshes are numbered compactly enough)
+    for pipe, plan in plans.items():
+        per_slice = _slot_lists_from_items(plan)
+        items = plan["items"].reshape(-1, 4)
+        for s, slots in enumerate(per_slice):
+            base, width = plan["slice_base"][s], plan["slice_width"][s]
+            seen = 0
+            for k in range(width):
+                for n in range(32):
+                    idx = base + k * 32 + n
+                    want = list(plan["pairs16"][plan["pair_ptr"][idx]:plan["pair_ptr"][idx + 1]])
+                    if not want:
+                        assert k * 32 + n not in slots
+                        continue
+                    chunks = slots[k * 32 + n]
+                    nch = len(chunks)
+                    assert sorted(chunks) == list(range(nch)) and all(c[1] == nch for c in chunks.values())
+                    got = [p for c in range(nch) for p in chunks[c][2]]
+                    assert got == [int(v) for v in want]
+                    if pipe == "0":
+                        assert all(len(chunks[c][2]) == 3 for c in range(nch - 1))  # only the last chunk may be short
+                    else:  # (a half-empty last wave of off-diagonal slots is cut into chunks of one or two contributions)
+                        assert all(1 <= len(chunks[c][2]) <= 3 for c in range(nch))
+                    seen += 1
+                    if pipe == "1":  # consecutive lanes of one wave of a round of 192
+                        lanes = [chunks[c][0] for c in range(nch)]
+                        assert lanes == list(range(lanes[0], lanes[0] + nch))
+                        assert (lanes[0] % 192) // 64 == (lanes[-1] % 192) // 64 and lanes[0] // 192 == lanes[-1] // 192
+            assert seen == len(slots)
+            if pipe == "1":  # the wave words
+                i0, i1 = plan["item_ptr"][s], plan["item_ptr"][s + 1]
+                for w0 in range(i0, i1, 64):
+                    wv = items[w0:min(w0 + 64, i1)]
+                    live = wv[(wv[:, 0] >> 24) > 0]
+                    most = int((live[:, 0] >> 24).max()) if len(live) else 0
+                    all_diag = int(len(live) == 0 or bool(np.all((live[:, 0] & 0xffff) < 32)))
+                    assert np.all(wv[:, 3] == (most | (all_diag << 8)))
+    if mesh == "hub":
+        assert max(len(c) for slots in _slot_lists_from_items(plans["1"]) for c in slots.values()) >= 14

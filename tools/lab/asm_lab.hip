@@ -82,6 +82,7 @@ int main(int argc, char **argv)
         printf("pipe, no record math   : %.3f ms\n", runp(k_assemble_pipe<8>, g, R));
         printf("pipe, roles by wave id : %.3f ms\n", runp(k_assemble_pipe<16>, g, R));
         printf("pipe, no priority      : %.3f ms\n", runp(k_assemble_pipe<64>, g, R));
+        printf("pipe, neighbours swapped: %.3f ms\n", runp(k_assemble_pipe<128>, g, R));
         printf("pipe again             : %.3f ms\n", runp(k_assemble_pipe<0>, g, R));
         const bool fake = getenv("LAB_FAKE_RECORDS") != nullptr;
         const float ms = fake ? runp(k_assemble_pipe<40>, g, 1) : runp(k_assemble_pipe<32>, g, 1);
