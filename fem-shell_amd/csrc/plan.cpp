@@ -780,6 +780,25 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         int32_t max_cnt = 0;
         for (size_t i = 0; i + 1 < p.pair_ptr.size(); i++) max_cnt = std::max(max_cnt, p.pair_ptr[i + 1] - p.pair_ptr[i]);
         p.pipe = wanted && p.n_lquad() == 0 && p.max_slice_elems <= kPipeMaxSliceElems && (max_cnt + item_pairs - 1) / item_pairs <= 64;
+        // ... and whose slices fill the three consumer waves the way the kernel is balanced for: the diagonal slots' chunks
+        // in one wave, the others in two.  A slice beyond that gets a wave that runs both code paths or a second round; a
+        // mesh of such slices (Delaunay meshes: valences 3..12, 70 and more diagonal chunks per slice) is assembled faster
+        // by the two-phase kernel (500k-point triangulation, Morton numbering: 3.5 against 4.0 G elements/s), structured
+        // meshes (64 + 96 lanes) faster by this one.  FEMSHELL_ASM_PIPE=2 takes it wherever it can run.
+        if (p.pipe && !(e && atoi(e) == 2)) {
+            int64_t ragged = 0;
+            for (int32_t s = 0; s < p.n_slices; s++) {
+                int diag = 0, off = 0;
+                for (int k = 0; k < p.slice_width[s]; k++)
+                    for (int n = 0; n < kSliceNodes; n++) {
+                        const int64_t idx = Plan::slot_index(p.slice_base[s], k, n);
+                        const int cnt = p.pair_ptr[idx + 1] - p.pair_ptr[idx];
+                        (k == 0 ? diag : off) += (cnt + item_pairs - 1) / item_pairs;
+                    }
+                ragged += diag > 64 || off > 128;
+            }
+            if (20 * ragged > p.n_slices) p.pipe = false;
+        }
     }
     p.item_ptr.assign((size_t)p.n_slices + 1, 0);
     {

@@ -377,12 +377,15 @@ def test_work_items_of_both_assembly_kernels_carry_the_gather_lists(monkeypatch,
         fan = np.array([[hub, hub + 1 + k, hub + 1 + (k + 1) % 40] for k in range(40)], dtype=np.int32)
         tri = np.concatenate([m.tri, fan]).astype(np.int32)
     plans = {}
-    for pipe in ("1", "0"):
-        monkeypatch.setenv("FEMSHELL_ASM_PIPE", pipe)
+    for pipe, env in (("1", "2"), ("0", "0")):  # 2: the pipelined layout wherever the kernel can run
+        monkeypatch.setenv("FEMSHELL_ASM_PIPE", env)
         plans[pipe] = pkg.build_plan(xyz, tri)
     assert plans["0"]["pipe"] == 0
-    assert plans["1"]["pipe"] == (1 if plans["1"]["max_slice_elems"] <= 150 else 0)
     assert plans["1"]["pipe"] == 1, plans["1"]["max_slice_elems"]  # (all three meshes are numbered compactly enough)
+    # the default takes it where it pays: slices whose diagonal chunks fill one wave and whose other chunks fill two
+    monkeypatch.delenv("FEMSHELL_ASM_PIPE")
+    # (full storage: 192 off-diagonal slots per structured slice, more than two waves)
+    assert pkg.build_plan(xyz, tri)["pipe"] == (1 if mesh != "patch" and symmetric == "1" else 0)
     for pipe, plan in plans.items():
         per_slice = _slot_lists_from_items(plan)
         items = plan["items"].reshape(-1, 4)
