@@ -19,7 +19,7 @@ KERNEL_ASSEMBLE, KERNEL_SPMV, KERNEL_CG_UPDATE, KERNEL_CG_DIRECTION = 0, 1, 2, 3
 
 SYMBOLS = [
     "femshell_create", "femshell_destroy", "femshell_last_error", "femshell_set_mesh",
-    "femshell_set_dirichlet", "femshell_set_loads", "femshell_assemble", "femshell_solve",
+    "femshell_set_dirichlet", "femshell_set_loads", "femshell_assemble", "femshell_assemble_async", "femshell_solve",
     "femshell_get_solution", "femshell_residual_history", "femshell_element_matrices",
     "femshell_nnz_blocks", "femshell_export_bsr", "femshell_spmv", "femshell_row_begin",
     "femshell_row_end", "femshell_comm_unique_id", "femshell_comm_init", "femshell_time_kernel",
@@ -105,6 +105,7 @@ def load_library():
     L.femshell_set_dirichlet.argtypes = [vp, C.c_int32, ip, bp]
     L.femshell_set_loads.argtypes = [vp, C.c_int32, ip, dp]
     L.femshell_assemble.argtypes = [vp]
+    L.femshell_assemble_async.argtypes = [vp]
     L.femshell_solve.argtypes = [vp, C.c_double, C.c_int32, dp, C.POINTER(SolveInfo)]
     L.femshell_get_solution.argtypes = [vp, dp]
     L.femshell_residual_history.argtypes = [vp, dp, C.c_int32]
@@ -215,8 +216,9 @@ class FemShell:
         ids = None if node_ids is None else np.ascontiguousarray(node_ids, dtype=np.int32)
         _check(self._L.femshell_set_loads(self._h, len(f6), _i(ids), _d(f6)))
 
-    def assemble(self):
-        _check(self._L.femshell_assemble(self._h))
+    def assemble(self, wait=True):
+        """wait=False: femshell_assemble_async -- enqueued only; sync(), solve() ... report a failed element."""
+        _check(self._L.femshell_assemble(self._h) if wait else self._L.femshell_assemble_async(self._h))
 
     def solve(self, rtol=1e-10, max_it=10000, fetch=True):
         u = np.zeros((self.n_nodes, 6)) if fetch else None

@@ -172,23 +172,51 @@ int upload_node_data(femshell_ctx *c)
     return FEMSHELL_OK;
 }
 
-int do_assemble(femshell_ctx *c)
+// status and timing of an assembly that femshell_assemble_async enqueued: every entry point that reads results, changes
+// inputs or synchronises calls this first
+int finish_pending_assembly(femshell_ctx *c)
+{
+    if (!c->assembly_pending) return FEMSHELL_OK;
+    c->assembly_pending = false;
+    int rc = select_device(c);
+    if (rc) return rc;
+    rc = check_and_agree(c, "femshell_assemble_async");
+    if (rc) {
+        c->matrix_valid = false;
+        c->rhs_valid = false;
+        return rc;
+    }
+    float ms = 0.f;
+    FS_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_assemble_s = 1e-3 * ms;
+    return FEMSHELL_OK;
+}
+
+int do_assemble(femshell_ctx *c, bool wait = true)
 {
     if (!c->have_mesh) return set_err(FEMSHELL_ERR_INVALID, "femshell_assemble: no mesh set");
     TraceRange trace("femshell_assemble");
     int rc = select_device(c);
     if (rc) return rc;
+    if (c->assembly_pending && wait) { // (async after async: one status word collects both)
+        rc = finish_pending_assembly(c);
+        if (rc) return rc;
+    }
     FS_HIP(hipEventRecord(c->ev0, c->stream));
     c->dm.rhs_loads = c->loads.p;
     c->dm.rhs_F = c->F.p;
     launch_assemble(c->dm, c->mc, c->stream); // K and F (k_rhs alone serves changes of the loads)
     FS_HIP(hipEventRecord(c->ev1, c->stream));
     FS_HIP(hipGetLastError());
-    rc = check_and_agree(c, "femshell_assemble");
-    if (rc) return rc;
-    float ms = 0.f;
-    FS_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    c->last_assemble_s = 1e-3 * ms;
+    if (wait) {
+        rc = check_and_agree(c, "femshell_assemble");
+        if (rc) return rc;
+        float ms = 0.f;
+        FS_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->last_assemble_s = 1e-3 * ms;
+    } else {
+        c->assembly_pending = true; // (a failed element leaves its mark in the status word until someone looks)
+    }
     c->matrix_valid = true;
     c->rhs_valid = true;
     c->jacobi_valid = false;
@@ -497,6 +525,7 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
         return set_err(FEMSHELL_ERR_INVALID, "femshell_set_mesh: call femshell_comm_init first on a multi-rank context");
     int rc = select_device(c);
     if (rc) return rc;
+    c->assembly_pending = false; // (an assembly of the previous mesh whose status nobody asked for)
     // a failure that only this rank sees (its slices exceed the LDS staging, one of its nodes has too many neighbours, a
     // HIP allocation failed) must reach the others: they would wait in the next collective forever
     return agree_status(c, set_mesh_on_this_rank(c, n_nodes, xyz, n_tri, tri, n_quad, quad), "femshell_set_mesh");
@@ -679,6 +708,10 @@ static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double 
 int femshell_set_dirichlet(femshell_ctx *c, int32_t n, const int32_t *node_ids, const uint8_t *mask6)
 {
     if (!c || (n > 0 && !mask6)) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_dirichlet: null argument");
+    if (c->assembly_pending) {
+        const int prc = finish_pending_assembly(c);
+        if (prc) return prc;
+    }
     if (!c->have_mesh) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_dirichlet: call femshell_set_mesh first");
     const int32_t nn = c->plan.n_nodes;
     if (!node_ids && n != nn) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_dirichlet: dense form needs n == n_nodes");
@@ -701,6 +734,10 @@ int femshell_set_dirichlet(femshell_ctx *c, int32_t n, const int32_t *node_ids, 
 int femshell_set_loads(femshell_ctx *c, int32_t n, const int32_t *node_ids, const double *f6)
 {
     if (!c || (n > 0 && !f6)) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_loads: null argument");
+    if (c->assembly_pending) {
+        const int prc = finish_pending_assembly(c);
+        if (prc) return prc;
+    }
     if (!c->have_mesh) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_loads: call femshell_set_mesh first");
     const int32_t nn = c->plan.n_nodes;
     if (!node_ids && n != nn) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_loads: dense form needs n == n_nodes");
@@ -726,6 +763,12 @@ int femshell_assemble(femshell_ctx *c)
 {
     if (!c) return set_err(FEMSHELL_ERR_INVALID, "femshell_assemble: null context");
     return do_assemble(c);
+}
+
+int femshell_assemble_async(femshell_ctx *c)
+{
+    if (!c) return set_err(FEMSHELL_ERR_INVALID, "femshell_assemble_async: null context");
+    return do_assemble(c, false);
 }
 
 int femshell_pc_defaults(int32_t type, femshell_pc_options *out)
@@ -844,6 +887,10 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
     if (!c) return set_err(FEMSHELL_ERR_INVALID, "femshell_solve: null context");
     if (!c->have_mesh) return set_err(FEMSHELL_ERR_INVALID, "femshell_solve: no mesh set");
     if (max_it < 0) return set_err(FEMSHELL_ERR_INVALID, "femshell_solve: max_it < 0");
+    if (c->assembly_pending) {
+        const int prc = finish_pending_assembly(c);
+        if (prc) return prc;
+    }
     TraceRange trace("femshell_solve");
     int rc = select_device(c);
     if (rc) return rc;
@@ -1029,6 +1076,10 @@ int64_t femshell_nnz_blocks(femshell_ctx *c) { return (c && c->have_mesh) ? real
 int femshell_export_bsr(femshell_ctx *c, int32_t *rowptr, int32_t *colidx, double *vals, double *F)
 {
     if (!c || !rowptr || !colidx || !vals) return set_err(FEMSHELL_ERR_INVALID, "femshell_export_bsr: null argument");
+    if (c->assembly_pending) {
+        const int prc = finish_pending_assembly(c);
+        if (prc) return prc;
+    }
     if (!c->matrix_valid) return set_err(FEMSHELL_ERR_INVALID, "femshell_export_bsr: call femshell_assemble first");
     int rc = select_device(c);
     if (rc) return rc;
@@ -1080,6 +1131,10 @@ int femshell_export_bsr(femshell_ctx *c, int32_t *rowptr, int32_t *colidx, doubl
 int femshell_spmv(femshell_ctx *c, const double *x, double *y)
 {
     if (!c || !x || !y) return set_err(FEMSHELL_ERR_INVALID, "femshell_spmv: null argument");
+    if (c->assembly_pending) {
+        const int prc = finish_pending_assembly(c);
+        if (prc) return prc;
+    }
     if (!c->matrix_valid) return set_err(FEMSHELL_ERR_INVALID, "femshell_spmv: call femshell_assemble first");
     if (c->cfg.world_size != 1) return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_spmv: single-rank contexts only");
     int rc = select_device(c);
@@ -1107,6 +1162,10 @@ int femshell_spmv(femshell_ctx *c, const double *x, double *y)
 int femshell_residual(femshell_ctx *c, const double *x, double *r)
 {
     if (!c || !x || !r) return set_err(FEMSHELL_ERR_INVALID, "femshell_residual: null argument");
+    if (c->assembly_pending) {
+        const int prc = finish_pending_assembly(c);
+        if (prc) return prc;
+    }
     if (!c->matrix_valid) return set_err(FEMSHELL_ERR_INVALID, "femshell_residual: call femshell_assemble first");
     if (c->cfg.world_size != 1) return set_err(FEMSHELL_ERR_UNSUPPORTED, "femshell_residual: single-rank contexts only");
     int rc = select_device(c);
@@ -1141,6 +1200,10 @@ int32_t femshell_row_end(femshell_ctx *c) { return (c && c->have_mesh) ? c->plan
 int femshell_time_kernel(femshell_ctx *c, femshell_kernel which, int32_t reps, double *mean_ms_out, double *bytes_out)
 {
     if (!c || !mean_ms_out) return set_err(FEMSHELL_ERR_INVALID, "femshell_time_kernel: null argument");
+    if (c->assembly_pending) {
+        const int prc = finish_pending_assembly(c);
+        if (prc) return prc;
+    }
     if (!c->have_mesh || reps <= 0) return set_err(FEMSHELL_ERR_INVALID, "femshell_time_kernel: no mesh or reps <= 0");
     int rc = select_device(c);
     if (rc) return rc;
@@ -1235,6 +1298,7 @@ int femshell_sync(femshell_ctx *c)
     if (!c) return set_err(FEMSHELL_ERR_INVALID, "femshell_sync: null context");
     int rc = select_device(c);
     if (rc) return rc;
+    if (c->assembly_pending) return finish_pending_assembly(c); // (synchronises)
     FS_HIP(hipStreamSynchronize(c->stream));
     return FEMSHELL_OK;
 }

@@ -130,6 +130,7 @@ struct femshell_ctx {
     femshell::DevBuf<double> dots_scratch;
 
     double last_assemble_s = 0.0, last_setup_s = 0.0;
+    bool assembly_pending = false; // femshell_assemble_async: status word and timing of the last assembly not collected yet
     std::vector<double> hist_host;
     int32_t last_iters = 0;
 };

@@ -54,6 +54,9 @@ def main():
     pc = os.environ.get("FEMSHELL_TEST_PC", "")
     if pc == "amg":
         fs.set_preconditioner("amg", coarsest_nodes=60)
+    if os.environ.get("FEMSHELL_TEST_ASYNC") == "1":
+        fs.assemble(wait=False)  # twice: one status word collects both
+        fs.assemble(wait=False)
     if kind == "panel_bad":
         # every rank must come back with an error (none may hang in a collective of the CG loop)
         try:

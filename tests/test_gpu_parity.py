@@ -844,3 +844,43 @@ def test_pipelined_and_two_phase_assembly_kernels_agree(monkeypatch, mesh, symme
     np.testing.assert_array_equal(c1, co)
     np.testing.assert_array_equal(F1, Fo)
     assert np.abs(v1 - vo).max() <= 1e-12 * np.abs(vo).max()
+
+
+def test_asynchronous_assembly_reports_its_status_at_the_next_synchronising_call():
+    """femshell_assemble_async enqueues the assembly and returns; a degenerate element is reported by the next call that
+    synchronises, reads K or changes the inputs -- and the context works on after the mesh is repaired.  A good mesh gives
+    the bits of the synchronous call."""
+    m = meshes.structured(24, 18, 0, 0, 4, 3, kind="t", ul_lr=True, bcids=(0, 0, 1, -1), factor=2.0, loading=2)
+    fs = pkg.FemShell(0.3, 1e6, 0.1)
+    fs.set_mesh(m.xyz, m.tri)
+    fs.set_dirichlet(m.dirichlet_mask())
+    fs.set_loads(m.loads)
+    fs.assemble()
+    ref = fs.export_bsr()
+    for _ in range(3):
+        fs.assemble(wait=False)
+    fs.sync()
+    got = fs.export_bsr()
+    for a, b in zip(ref, got):
+        np.testing.assert_array_equal(a, b)
+    u, info = fs.solve(rtol=1e-9, max_it=20000)
+    assert info["converged"] == 1
+    bad = m.xyz.copy()
+    a, b, c = m.tri[37]
+    bad[c] = bad[b]  # a triangle of zero area
+    for how in ("sync", "solve", "export", "assemble", "set_loads"):
+        fs.set_mesh(bad, m.tri)
+        fs.set_dirichlet(m.dirichlet_mask())
+        fs.set_loads(m.loads)
+        fs.assemble(wait=False)  # returns: nothing has looked at the status yet
+        with pytest.raises(pkg.FemShellError) as ei:
+            {"sync": fs.sync, "solve": lambda: fs.solve(rtol=1e-6, max_it=10), "export": fs.export_bsr, "assemble": fs.assemble,
+             "set_loads": lambda: fs.set_loads(m.loads)}[how]()
+        assert ei.value.code == -4 and "degenerate" in str(ei.value), how  # FEMSHELL_ERR_MESH
+    fs.set_mesh(m.xyz, m.tri)
+    fs.set_dirichlet(m.dirichlet_mask())
+    fs.set_loads(m.loads)
+    fs.assemble(wait=False)
+    u2, info2 = fs.solve(rtol=1e-9, max_it=20000)
+    assert info2["converged"] == 1 and np.array_equal(u2, u)
+    fs.close()

@@ -16,13 +16,15 @@ FAKE_DIR = os.path.join(ROOT, "tests", "helpers", "fake_rccl")
 WORKER = os.path.join(ROOT, "tests", "helpers", "multirank_worker.py")
 
 
-def run_ranks(world, kind, tmp_path, overlap=True, single_reduction=None, pc=None):
+def run_ranks(world, kind, tmp_path, overlap=True, single_reduction=None, pc=None, async_assembly=False):
     ensure_built()
     subprocess.check_call(["make", "-C", FAKE_DIR, "-s"])
     env = dict(os.environ, FEMSHELL_RCCL_LIB=os.path.join(FAKE_DIR, "libfake_rccl.so"),
                FEMSHELL_HALO_OVERLAP="1" if overlap else "0")
     if pc is not None:
         env["FEMSHELL_TEST_PC"] = pc
+    if async_assembly:
+        env["FEMSHELL_TEST_ASYNC"] = "1"
     if single_reduction is not None:  # default: multi-rank solves use the single-reduction recurrence
         env["FEMSHELL_CG_SINGLE_REDUCTION"] = "1" if single_reduction else "0"
     uid = str(tmp_path / ("uid_%d_%s.npy" % (world, kind)))
@@ -134,10 +136,12 @@ def test_multigrid_on_a_row_partitioned_context_is_the_single_rank_preconditione
     assert errj < 1e-8, errj
 
 
-def test_rank_local_failure_is_reported_by_every_rank(tmp_path):
+@pytest.mark.parametrize("async_assembly", [False, True])
+def test_rank_local_failure_is_reported_by_every_rank(tmp_path, async_assembly):
     # a degenerate element exists on the rank that owns its rows only; the others must not walk on into the
-    # collectives of the CG loop (they would hang): all ranks agree on the outcome after the assembly
-    ranks = run_ranks(3, "panel_bad", tmp_path)
+    # collectives of the CG loop (they would hang): all ranks agree on the outcome after the assembly -- also when the
+    # assembly was enqueued with femshell_assemble_async and the solve is the call that collects its status
+    ranks = run_ranks(3, "panel_bad", tmp_path, async_assembly=async_assembly)
     codes = [int(r["code"]) for r in ranks]
     # the same class of error everywhere: FEMSHELL_ERR_MESH (-4) when the assembly flags the element, FEMSHELL_ERR_BREAKDOWN
     # (-5) when its zero block only shows in the block-Jacobi setup
