@@ -424,12 +424,15 @@ constexpr int kPipeConsumers = 192;  // lanes that own work items (three waves)
 constexpr int kPipeRecPasses = 3;    // record passes the producer wave runs at most per slice: 192 records, more than a slice
                                      // of a plan with Plan::pipe has (kPipeMaxSliceElems)
 
-template <int kAblate = 0>
+// kHasQuads: meshes with quadrilaterals -- records in the full 66-double layout (tri3_record / quad4_record as in k_assemble),
+// every block through block_add_rec, diagonal blocks as full 6x6 blocks
+template <int kAblate = 0, bool kHasQuads = false>
 __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatConst mc)
 {
     extern __shared__ double lds[];
     __shared__ int simd_of_wave[4];
-    constexpr int kRec = RecLean::doubles;
+    constexpr int kRec = kHasQuads ? kRecDoublesQuad : RecLean::doubles;
+    constexpr int kCoords = kHasQuads ? 12 : 9; // coordinates of an element
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- roles: by the SIMD a wave runs on when the four waves sit on four SIMDs (they do; the order varies from
     //      workgroup to workgroup), else by wave index.  The workgroups b and b + G/2 of a 2-per-CU grid share a CU.
@@ -493,11 +496,15 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
         auto carry_of = [&](int r0, const Range &a, const Range &b) {
             return min(max(r0 + 64 * passes_of(r0, a) - a.ne, 0), b.ne);
         };
-        auto fetch_coords = [&](const int4 &c, double X[9]) {
+        auto fetch_coords = [&](const int4 &c, double X[kCoords]) {
             const double *pa = m.xyz + 3 * (int64_t)c.x, *pb = m.xyz + 3 * (int64_t)c.y, *pc = m.xyz + 3 * (int64_t)c.z;
             X[0] = pa[0]; X[1] = pa[1]; X[2] = pa[2];
             X[3] = pb[0]; X[4] = pb[1]; X[5] = pb[2];
             X[6] = pc[0]; X[7] = pc[1]; X[8] = pc[2];
+            if (kHasQuads) { // (a triangle's fourth node is -1: its first node again, a valid address)
+                const double *pd = m.xyz + 3 * (int64_t)(c.w >= 0 ? c.w : c.x);
+                X[kCoords - 3] = pd[0]; X[kCoords - 2] = pd[1]; X[kCoords - 1] = pd[2];
+            }
         };
         auto range_of = [&](const int4 &a) {
             Range r;
@@ -513,11 +520,14 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
         int4 dvec = desc_a_of(s_build + 3 * w.step); // becomes rd in the first iteration
         int r0 = 0;                                   // records of slice s_build that are built already
         int r0n = carry_of(r0, ra, rb);
-        double X[kPipeRecPasses][9];
+        double X[kPipeRecPasses][kCoords];
         int4 ndn[kPipeRecPasses];
+        bool is_quad[kPipeRecPasses]; // the element whose coordinates X[p] holds
 #pragma unroll
         for (int p = 0; p < kPipeRecPasses; p++) {
-            fetch_coords(enodes[stream_elem(r0, ra, rb, p)], X[p]);
+            const int4 c0 = enodes[stream_elem(r0, ra, rb, p)];
+            fetch_coords(c0, X[p]);
+            is_quad[p] = kHasQuads && c0.w >= 0;
             ndn[p] = enodes[stream_elem(r0n, rb, rc, p)];
         }
         double held[kRec]; // a record of the next slice, lean layout
@@ -529,7 +539,18 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
 #pragma unroll
             for (int q = 0; q < kRec / 2; q++) dst[q] = make_double2(rec[2 * q], rec[2 * q + 1]);
         };
-        auto record_of = [&](const double Xp[9], double lean[kRec]) __attribute__((always_inline)) {
+        auto record_of = [&](const double Xp[kCoords], bool quad, double lean[kRec]) __attribute__((always_inline)) {
+            if (kHasQuads) { // the record as k_assemble keeps it
+                bool okq;
+                if (quad) {
+                    okq = quad4_record(Xp, mc, lean);
+                } else {
+                    okq = tri3_record(Xp, mc, lean);
+#pragma unroll
+                    for (int q = kRecDoubles; q < kRec; q++) lean[q] = 0.0;
+                }
+                return okq;
+            }
             double rec[kRecDoubles];
             bool ok;
             if (kAblate & 8) {
@@ -551,15 +572,16 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
             for (int p = 0; p < kPipeRecPasses - 1; p++) { // full passes
                 if (p < np - 1) {
                     double lean[kRec];
-                    const bool ok = record_of(X[p], lean);
+                    const bool ok = record_of(X[p], is_quad[p], lean);
                     const int li = r0 + 64 * p + lane;
                     if (!ok) atomicCAS(m.status, 0, ra.e0 + li + 1);
                     write_lean(buf, li, lean);
                 }
                 fetch_coords(ndn[p], X[p]); // the next iteration's element of this lane and slot
+                is_quad[p] = kHasQuads && ndn[p].w >= 0;
             }
             if (np > 0) { // last pass: the slice's last records, then the first of the next slice
-                const bool ok = record_of(X[kPipeRecPasses - 1], held);
+                const bool ok = record_of(X[kPipeRecPasses - 1], is_quad[kPipeRecPasses - 1], held);
                 const int li = r0 + 64 * (np - 1) + lane, li2 = li - ra.ne;
                 if (li < ra.ne) {
                     if (!ok) atomicCAS(m.status, 0, ra.e0 + li + 1);
@@ -573,6 +595,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
                 for (int q = 0; q < kRec; q++) held[q] = 0.0;
             }
             fetch_coords(ndn[kPipeRecPasses - 1], X[kPipeRecPasses - 1]);
+            is_quad[kPipeRecPasses - 1] = kHasQuads && ndn[kPipeRecPasses - 1].w >= 0;
             // roll the window
             const Range rd = range_of(dvec);
             const int r0nn = carry_of(r0n, rb, rc);
@@ -676,8 +699,8 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
                 const int cnt = (int)(item.z >> 16);
                 // what the plan says about this wave of the round: most chunks of a slot, and whether every item is diagonal
                 const int wave_chunks = __builtin_amdgcn_readfirstlane((int)(item.w & 0xffu));
-                const bool wave_sym = __builtin_amdgcn_readfirstlane((int)((item.w >> 8) & 1u)) != 0;
-                const bool sym_item = slot_in_slice < kSliceNodes;
+                const bool wave_sym = !kHasQuads && __builtin_amdgcn_readfirstlane((int)((item.w >> 8) & 1u)) != 0;
+                const bool sym_item = !kHasQuads && slot_in_slice < kSliceNodes;
                 double blk[36];
 #pragma unroll
                 for (int i = 0; i < 36; i++) blk[i] = 0.0;
@@ -689,7 +712,9 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
                 } else {
                     for (int q = 0; q < cnt; q++) {
                         const uint32_t pr = (q == 0) ? (item.y & 0xffffu) : (q == 1 ? (item.y >> 16) : (item.z & 0xffffu));
-                        tri3_block_add_rec<RecLean>(lds_rec + (size_t)(pr >> 4) * kRec, (int)((pr >> 2) & 3u), (int)(pr & 3u), mc, blk);
+                        const double *rec = lds_rec + (size_t)(pr >> 4) * kRec;
+                        if (kHasQuads) block_add_rec<true>(rec, (int)((pr >> 2) & 3u), (int)(pr & 3u), mc, blk);
+                        else tri3_block_add_rec<RecLean>(rec, (int)((pr >> 2) & 3u), (int)(pr & 3u), mc, blk);
                     }
                 }
                 stamp(2);

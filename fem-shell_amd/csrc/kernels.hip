@@ -62,9 +62,13 @@ void launch_assemble(const DeviceMatrix &m, const MatConst &mc, hipStream_t st)
             return 8 * ((2 * cus + 7) / 8);
         }();
         const int gp = g < pipe_cap ? g : pipe_cap;
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_assemble_pipe<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_assemble_pipe<0>, dim3(gp), dim3(256), lds, st, m, mc);
+        auto launch_pipe = [&](auto kernel) {
+            if (lds > 64 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kernel, dim3(gp), dim3(256), lds, st, m, mc);
+        };
+        if (m.n_lquad > 0) launch_pipe(k_assemble_pipe<0, true>);
+        else launch_pipe(k_assemble_pipe<0, false>);
         return;
     }
     if (m.n_lquad > 0) {

@@ -67,7 +67,7 @@ struct DeviceMatrix {
 inline size_t assemble_lds_layout(DeviceMatrix &m, int32_t max_slice_elems, int32_t max_stage_rows, bool has_quads)
 {
     if (m.pipe) { // k_assemble_pipe: two buffers of lean records, no staging
-        m.lds_rec_off = max_slice_elems * RecLean::doubles;
+        m.lds_rec_off = max_slice_elems * (has_quads ? kRecDoublesQuad : RecLean::doubles);
         m.lds_stage_off = 0;
         m.lds_bytes = (int32_t)(2 * (size_t)m.lds_rec_off * sizeof(double));
         return (size_t)m.lds_bytes;

@@ -31,6 +31,7 @@ constexpr int kItemPairs = 3;                // element contributions per assemb
 // most elements a slice may touch for the pipelined assembly kernel: two buffers of 34-double records per workgroup, two
 // workgroups in the 160 KiB of a CU
 constexpr int kPipeMaxSliceElems = 150;
+constexpr int kPipeMaxSliceElemsQuad = 77; // meshes with quadrilaterals: 66-double records
 
 struct HaloPeer {
     int rank = -1;

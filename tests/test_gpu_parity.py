@@ -797,13 +797,14 @@ def _fan_mesh():
     return xyz, np.concatenate([m.tri, fan]).astype(np.int32)
 
 
-@pytest.mark.parametrize("mesh", ["panel", "patch", "hub"])
+@pytest.mark.parametrize("mesh", ["panel", "patch", "hub", "quads", "mixed"])
 @pytest.mark.parametrize("symmetric", ["1", "0"])
 def test_pipelined_and_two_phase_assembly_kernels_agree(monkeypatch, mesh, symmetric):
     """k_assemble_pipe (producer wave + three consumer waves, records as a stream across slices, partial sums through lane
     shifts) against k_assemble (records, barrier, blocks) and against the oracle: structured panel, Delaunay patch with
     valences 3..12 (slots of one to four chunks, mixed waves, several rounds), a fan of 40 triangles around one node (a
-    slot of 14 chunks); Dirichlet rows and columns, right-hand side; symmetric and full storage."""
+    slot of 14 chunks), quadrilaterals and a mix of both element types (66-double records, every block through the
+    general block function); Dirichlet rows and columns, right-hand side; symmetric and full storage."""
     monkeypatch.setenv("FEMSHELL_SYMMETRIC", symmetric)
     if mesh == "panel":
         m = meshes.structured(70, 45, 0, 0, 7, 4.5, kind="t", ul_lr=True)
@@ -811,8 +812,20 @@ def test_pipelined_and_two_phase_assembly_kernels_agree(monkeypatch, mesh, symme
         xyz[:, 2] = 0.3 * np.sin(0.9 * xyz[:, 0]) * np.cos(0.7 * xyz[:, 1])
     elif mesh == "patch":
         xyz, tri = meshes.delaunay_patch(3000, 7)
-    else:
+    elif mesh == "hub":
         xyz, tri = _fan_mesh()
+    quad = np.zeros((0, 4), np.int32)
+    if mesh in ("quads", "mixed"):  # planar quadrilaterals, tilted; "mixed": every eighth one cut into two triangles (a
+        # slice may touch 77 elements at most when their records are the 66-double ones)
+        m = meshes.structured(40, 30, 0, 0, 4.0, 3.3, kind="q")
+        qm, _ = np.linalg.qr(np.random.default_rng(3).normal(size=(3, 3)))
+        xyz, quad = m.xyz @ qm.T, m.quad.copy()
+        tri = np.zeros((0, 3), np.int32)
+        if mesh == "mixed":
+            pick = np.arange(len(quad)) % 8 == 0
+            q = quad[pick]
+            tri = np.concatenate([q[:, [0, 1, 2]], q[:, [0, 2, 3]]]).astype(np.int32)
+            quad = quad[~pick]
     n = len(xyz)
     rng = np.random.default_rng(12)
     dmask = np.zeros(n, np.uint8)
@@ -821,9 +834,10 @@ def test_pipelined_and_two_phase_assembly_kernels_agree(monkeypatch, mesh, symme
     out = {}
     for pipe in ("1", "0"):
         monkeypatch.setenv("FEMSHELL_ASM_PIPE", "2" if pipe == "1" else "0")  # 2: wherever the pipelined kernel can run
-        assert pkg.build_plan(xyz, tri)["pipe"] == int(pipe)
+        assert pkg.build_plan(xyz, tri, quad)["pipe"] == int(pipe)
         fs = pkg.FemShell(0.3, 2.1e5, 0.04)
-        fs.set_mesh(xyz, tri)
+        fs.set_mesh(xyz, tri, quad)
+        assert fs.assembly_kernel() == ("k_assemble_pipe" if pipe == "1" else "k_assemble")
         fs.set_dirichlet(dmask)
         fs.set_loads(loads)
         fs.assemble()
@@ -839,7 +853,7 @@ def test_pipelined_and_two_phase_assembly_kernels_agree(monkeypatch, mesh, symme
     np.testing.assert_array_equal(c1, c0)
     np.testing.assert_array_equal(F1, F0)
     assert np.abs(v1 - v0).max() <= 1e-13 * np.abs(v0).max()
-    ro, co, vo, Fo = oracle.assemble(xyz, tri, np.zeros((0, 4), np.int32), oracle.material(0.3, 2.1e5, 0.04), dmask, loads)
+    ro, co, vo, Fo = oracle.assemble(xyz, tri, quad, oracle.material(0.3, 2.1e5, 0.04), dmask, loads)
     np.testing.assert_array_equal(r1, ro)
     np.testing.assert_array_equal(c1, co)
     np.testing.assert_array_equal(F1, Fo)

@@ -355,7 +355,7 @@ def _slot_lists_from_items(plan):
     return out
 
 
-@pytest.mark.parametrize("mesh", ["panel", "patch", "hub"])
+@pytest.mark.parametrize("mesh", ["panel", "patch", "hub", "quads"])
 @pytest.mark.parametrize("symmetric", ["1", "0"])
 def test_work_items_of_both_assembly_kernels_carry_the_gather_lists(monkeypatch, mesh, symmetric):
     """The work items (Plan::Item) are the gather lists cut into chunks of three contributions, laid out for the kernel that
@@ -363,11 +363,15 @@ def test_work_items_of_both_assembly_kernels_carry_the_gather_lists(monkeypatch,
     192 lanes with the chunks of a slot in consecutive lanes of one wave, and a word per wave (most chunks of a slot, all
     items diagonal).  Either way every slot's chunks, in order, are its gather list."""
     monkeypatch.setenv("FEMSHELL_SYMMETRIC", symmetric)
+    quad = None
     if mesh == "panel":
         m = meshes.structured(70, 45, 0, 0, 7, 4.5, kind="t", ul_lr=True)
         xyz, tri = m.xyz, m.tri
     elif mesh == "patch":
         xyz, tri = meshes.delaunay_patch(3000, 7)
+    elif mesh == "quads":
+        m = meshes.structured(40, 30, 0, 0, 4.0, 3.3, kind="q")
+        xyz, tri, quad = m.xyz, None, m.quad
     else:  # a fan of 40 triangles around one node among a regular grid: a slot with 14 chunks, others with one
         m = meshes.structured(20, 20, 0, 0, 2, 2, kind="t", ul_lr=True)
         ang = np.linspace(0.0, 2.0 * np.pi, 41)[:-1]
@@ -379,13 +383,13 @@ def test_work_items_of_both_assembly_kernels_carry_the_gather_lists(monkeypatch,
     plans = {}
     for pipe, env in (("1", "2"), ("0", "0")):  # 2: the pipelined layout wherever the kernel can run
         monkeypatch.setenv("FEMSHELL_ASM_PIPE", env)
-        plans[pipe] = pkg.build_plan(xyz, tri)
+        plans[pipe] = pkg.build_plan(xyz, tri, quad)
     assert plans["0"]["pipe"] == 0
     assert plans["1"]["pipe"] == 1, plans["1"]["max_slice_elems"]  # (all three meshes are numbered compactly enough)
     # the default takes it where it pays: slices whose diagonal chunks fill one wave and whose other chunks fill two
     monkeypatch.delenv("FEMSHELL_ASM_PIPE")
     # (full storage: 192 off-diagonal slots per structured slice, more than two waves)
-    assert pkg.build_plan(xyz, tri)["pipe"] == (1 if mesh != "patch" and symmetric == "1" else 0)
+    assert pkg.build_plan(xyz, tri, quad)["pipe"] == (1 if mesh != "patch" and symmetric == "1" else 0)
     for pipe, plan in plans.items():
         per_slice = _slot_lists_from_items(plan)
         items = plan["items"].reshape(-1, 4)

@@ -12,6 +12,6 @@ fs.set_mesh(m.xyz, m.tri, m.quad); fs.set_dirichlet(m.dirichlet_mask()); fs.set_
 print("setup %.1f s, %d quads, %d nodes" % (time.time() - t0, len(m.quad), m.n_nodes))
 fs.assemble()
 ms, by = fs.time_kernel(pkg.KERNEL_ASSEMBLE, 5)
-print("k_assemble (QUAD4): %.3f ms  %.1f Melem/s  %.0f GB/s" % (ms, len(m.quad) / ms / 1e3, by / ms / 1e6))
+print("%s (QUAD4): %.3f ms  %.1f Melem/s  %.0f GB/s" % (fs.assembly_kernel(), ms, len(m.quad) / ms / 1e3, by / ms / 1e6))
 _, info = fs.solve(rtol=0.0, max_it=200, fetch=False)
 print("cg: %.4f ms/iter" % (1e3 * info["solve_seconds"] / info["iterations"]))
