@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
             return r;
         };
         // the producer is the longest wave of the four: it goes first whenever the SIMD has a choice
-        if (!(kAblate & 64)) __builtin_amdgcn_s_setprio(3);
+        if (!(kAblate & 64)) __builtin_amdgcn_s_setprio(3); // (1 does as well; without: 0.61 against 0.55 ms)
         int s_build = w.s; // slice whose records are built next
         Range ra = range_of(desc_a_of(s_build)), rb = range_of(desc_a_of(s_build + w.step)),
               rc = range_of(desc_a_of(s_build + 2 * w.step));
@@ -721,19 +721,23 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
                 const bool owner = live && chunk == 0 && nchunks > 0;
                 // partial sums of the slot's other chunks: they sit in the next lanes of this wave, in chunk order
                 // (wave_shl:1 moves every lane's value one lane down, a VALU move; c steps bring chunk c to its owner)
+                // (the moves run in every lane -- a lane shift reads the lanes it reads whether they want the result or not --
+                // and the owners' additions under one branch: per word two moves and an addition instead of seven instructions)
                 if (wave_chunks == 2 && wave_sym) { // the common case spelled out: six-element nodes, two chunks of three
-                    const bool take = owner && nchunks == 2;
+                    double t[21];
 #pragma unroll
-                    for (int i = 0; i < 21; i++) {
-                        const double t = lane_below(blk[i]);
-                        blk[i] += take ? t : 0.0;
+                    for (int i = 0; i < 21; i++) t[i] = lane_below(blk[i]);
+                    if (owner && nchunks == 2) {
+#pragma unroll
+                        for (int i = 0; i < 21; i++) blk[i] += t[i];
                     }
                 } else if (wave_chunks == 2) { // (a wave of off-diagonal slots cut in two: plan.cpp pack_items_pipe)
-                    const bool take = owner && nchunks == 2;
+                    double t[36];
 #pragma unroll
-                    for (int i = 0; i < 36; i++) {
-                        const double t = lane_below(blk[i]);
-                        blk[i] += take ? t : 0.0;
+                    for (int i = 0; i < 36; i++) t[i] = lane_below(blk[i]);
+                    if (owner && nchunks == 2) {
+#pragma unroll
+                        for (int i = 0; i < 36; i++) blk[i] += t[i];
                     }
                 } else if (wave_chunks > 1) {
 #pragma unroll
