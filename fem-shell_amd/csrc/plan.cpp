@@ -787,17 +787,23 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         // by the two-phase kernel (500k-point triangulation, Morton numbering: 3.5 against 4.0 G elements/s), structured
         // meshes (64 + 96 lanes) faster by this one.  FEMSHELL_ASM_PIPE=2 takes it wherever it can run.
         if (p.pipe && !(e && atoi(e) == 2)) {
+            std::vector<int64_t> part((size_t)plan_chunks(p.n_slices, 256), 0);
+            plan_parallel(p.n_slices, 256, [&](int t, int64_t s0, int64_t s1) {
+                int64_t r = 0;
+                for (int64_t s = s0; s < s1; s++) {
+                    int diag = 0, off = 0;
+                    for (int k = 0; k < p.slice_width[s]; k++)
+                        for (int n = 0; n < kSliceNodes; n++) {
+                            const int64_t idx = Plan::slot_index(p.slice_base[s], k, n);
+                            const int cnt = p.pair_ptr[idx + 1] - p.pair_ptr[idx];
+                            (k == 0 ? diag : off) += (cnt + item_pairs - 1) / item_pairs;
+                        }
+                    r += diag > 64 || off > 128;
+                }
+                part[(size_t)t] += r;
+            });
             int64_t ragged = 0;
-            for (int32_t s = 0; s < p.n_slices; s++) {
-                int diag = 0, off = 0;
-                for (int k = 0; k < p.slice_width[s]; k++)
-                    for (int n = 0; n < kSliceNodes; n++) {
-                        const int64_t idx = Plan::slot_index(p.slice_base[s], k, n);
-                        const int cnt = p.pair_ptr[idx + 1] - p.pair_ptr[idx];
-                        (k == 0 ? diag : off) += (cnt + item_pairs - 1) / item_pairs;
-                    }
-                ragged += diag > 64 || off > 128;
-            }
+            for (int64_t r : part) ragged += r;
             if (20 * ragged > p.n_slices) p.pipe = false;
         }
     }
