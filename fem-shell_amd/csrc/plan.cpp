@@ -779,7 +779,8 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         const bool wanted = !(e && atoi(e) == 0);
         int32_t max_cnt = 0;
         for (size_t i = 0; i + 1 < p.pair_ptr.size(); i++) max_cnt = std::max(max_cnt, p.pair_ptr[i + 1] - p.pair_ptr[i]);
-        p.pipe = wanted && p.max_slice_elems <= (p.n_lquad() > 0 ? kPipeMaxSliceElemsQuad : kPipeMaxSliceElems) &&
+        p.pipe = wanted && !p.slice_elem_nodes.empty() && // (the kernel's idle lanes read a valid element: there must be one)
+                 p.max_slice_elems <= (p.n_lquad() > 0 ? kPipeMaxSliceElemsQuad : kPipeMaxSliceElems) &&
                  (max_cnt + item_pairs - 1) / item_pairs <= 64;
         // ... and whose slices fill the three consumer waves the way the kernel is balanced for: the diagonal slots' chunks
         // in one wave, the others in two.  A slice beyond that gets a wave that runs both code paths or a second round; a
