@@ -696,11 +696,12 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
                 }
                 const int slot_in_slice = (int)(item.x & 0xffffu), chunk = (int)((item.x >> 16) & 0xffu),
                           nchunks = (int)(item.x >> 24);
-                const int cnt = (int)(item.z >> 16);
+                const int cnt = (int)((item.z >> 16) & 0xffu);
+                const bool general = (item.z >> 31) != 0u; // a diagonal slot outside the first wave: the general routine
                 // what the plan says about this wave of the round: most chunks of a slot, and whether every item is diagonal
                 const int wave_chunks = __builtin_amdgcn_readfirstlane((int)(item.w & 0xffu));
                 const bool wave_sym = !kHasQuads && __builtin_amdgcn_readfirstlane((int)((item.w >> 8) & 1u)) != 0;
-                const bool sym_item = !kHasQuads && slot_in_slice < kSliceNodes;
+                const bool sym_item = !kHasQuads && slot_in_slice < kSliceNodes && !general;
                 double blk[36];
 #pragma unroll
                 for (int i = 0; i < 36; i++) blk[i] = 0.0;
@@ -739,15 +740,28 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
 #pragma unroll
                         for (int i = 0; i < 36; i++) blk[i] += t[i];
                     }
-                } else if (wave_chunks > 1) {
+                } else if (wave_chunks > 1 && wave_sym) { // more chunks: shift by shift, every owner adding what is its own
+                    double t[21];
 #pragma unroll
-                    for (int i = 0; i < 36; i++) {
-                        if (i < 21 || !wave_sym) {
-                            double t = blk[i];
-                            for (int c = 1; c < wave_chunks; c++) {
-                                t = lane_below(t);
-                                if (owner && c < nchunks) blk[i] += t;
-                            }
+                    for (int i = 0; i < 21; i++) t[i] = blk[i];
+                    for (int c = 1; c < wave_chunks; c++) {
+#pragma unroll
+                        for (int i = 0; i < 21; i++) t[i] = lane_below(t[i]);
+                        if (owner && c < nchunks) {
+#pragma unroll
+                            for (int i = 0; i < 21; i++) blk[i] += t[i];
+                        }
+                    }
+                } else if (wave_chunks > 1) {
+                    double t[36];
+#pragma unroll
+                    for (int i = 0; i < 36; i++) t[i] = blk[i];
+                    for (int c = 1; c < wave_chunks; c++) {
+#pragma unroll
+                        for (int i = 0; i < 36; i++) t[i] = lane_below(t[i]);
+                        if (owner && c < nchunks) {
+#pragma unroll
+                            for (int i = 0; i < 36; i++) blk[i] += t[i];
                         }
                     }
                 }
@@ -788,6 +802,13 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
                                 for (int i = 0; i < 6; i++)
                                     if ((mrow >> i) & 1u) blk[7 * i] = (double)valence;
                             }
+                        }
+                        if (!kHasQuads && general) { // the two halves of a diagonal block as mirror images, as the
+                                                     // upper-triangle routine leaves them (k_spmv_sym reads one half)
+#pragma unroll
+                            for (int i = 0; i < 6; i++)
+#pragma unroll
+                                for (int jj = i + 1; jj < 6; jj++) blk[6 * jj + i] = blk[6 * i + jj];
                         }
                         v2d *dst = reinterpret_cast<v2d *>(out) + (size_t)(slot_in_slice >> 5) * 3 * kSliceRows + (slot_in_slice & 31);
 #pragma unroll

@@ -108,9 +108,11 @@ bool default_symmetric_storage()
 
 // Items of one slice (slot by slot, chunk 0 first: Plan::Item) into the lanes of the pipelined kernel's rounds: 192 lanes
 // = three waves per round; all chunks of a slot in consecutive lanes of one wave (their partial sums meet through lane
-// permutes, no LDS, no barrier); diagonal slots first, off-diagonal slots from the next wave on when the round has the
-// room (a wave that holds both kinds runs both code paths).  Unused lanes carry inert items.  Word w of every item of a
-// wave: most chunks of a slot in this wave | all-diagonal flag << 8.
+// shifts, no LDS, no barrier).  The first wave holds diagonal slots only -- its lanes run the upper-triangle routine, three
+// contributions each; diagonal slots it has no room for (a Delaunay slice has 74 chunks of three) join the other slots in
+// the following waves, cut into chunks of two and marked (bit 31 of z): there every lane runs the general block routine
+// on at most two or three contributions, and no wave runs both routines.  Unused lanes carry inert items.  Word w of every
+// item of a wave: most chunks of a slot in this wave | all-upper-triangle flag << 8.
 static void pack_items_pipe(const std::vector<Plan::Item> &in, std::vector<Plan::Item> *out)
 {
     constexpr int kRound = 192, kWave = 64;
@@ -118,7 +120,7 @@ static void pack_items_pipe(const std::vector<Plan::Item> &in, std::vector<Plan:
     out->clear();
     size_t round_begin = 0;
     int pos = 0; // lane within the current round
-    auto place = [&](size_t first, int n) {
+    auto place = [&](const Plan::Item *first, int n) {
         if (pos % kWave + n > kWave) pos = (pos / kWave + 1) * kWave; // the slot's chunks stay in one wave
         if (pos + n > kRound) {
             out->resize(round_begin + kRound, pad);
@@ -126,22 +128,49 @@ static void pack_items_pipe(const std::vector<Plan::Item> &in, std::vector<Plan:
             pos = 0;
         }
         out->resize(round_begin + pos, pad);
-        for (int c = 0; c < n; c++) out->push_back(in[first + c]);
+        for (int c = 0; c < n; c++) out->push_back(first[c]);
         pos += n;
     };
-    // diagonal slots (slot index below 32), in the order given; then the others by decreasing work (stable)
-    int diag_lanes = 0, off_lanes = 0;
+    auto is_diag = [&](const Plan::Item &it) { return (it.x & 0xffffu) < (uint32_t)kSliceNodes; };
+    // diagonal slots into the first wave while they fit; the others are cut into chunks of two for the general routine
+    std::vector<Plan::Item> general;
+    int off_lanes = 0;
     for (size_t i = 0; i < in.size(); i += in[i].x >> 24) {
-        if ((in[i].x & 0xffffu) < (uint32_t)kSliceNodes) diag_lanes += (int)(in[i].x >> 24);
-        else off_lanes += (int)(in[i].x >> 24);
+        const int n = (int)(in[i].x >> 24);
+        if (!is_diag(in[i])) {
+            off_lanes += n;
+            continue;
+        }
+        if (round_begin == 0 && pos + n <= kWave) {
+            place(&in[i], n);
+            continue;
+        }
+        uint32_t pr[3 * 64];
+        int np = 0;
+        for (int c = 0; c < n; c++) {
+            const Plan::Item &it = in[i + c];
+            const int k = (int)((it.z >> 16) & 0xffu);
+            const uint32_t q[3] = {it.y & 0xffffu, it.y >> 16, it.z & 0xffffu};
+            for (int j = 0; j < k; j++) pr[np++] = q[j];
+        }
+        const int nch = (np + 1) / 2;
+        for (int c = 0; c < nch; c++) {
+            const int k = std::min(2, np - 2 * c);
+            Plan::Item g;
+            g.x = (in[i].x & 0xffffu) | ((uint32_t)c << 16) | ((uint32_t)nch << 24);
+            g.y = pr[2 * c] | ((k > 1 ? pr[2 * c + 1] : 0u) << 16);
+            g.z = ((uint32_t)k << 16) | 0x80000000u;
+            g.w = 0;
+            general.push_back(g);
+        }
     }
-    for (size_t i = 0; i < in.size(); i += in[i].x >> 24)
-        if ((in[i].x & 0xffffu) < (uint32_t)kSliceNodes) place(i, (int)(in[i].x >> 24));
-    if (pos % kWave != 0 && (pos / kWave + 1) * kWave + off_lanes <= kRound) pos = (pos / kWave + 1) * kWave;
+    // the other slots start a wave of their own when the round has the room
+    const int general_lanes = (int)general.size();
+    if (pos % kWave != 0 && (pos / kWave + 1) * kWave + general_lanes + off_lanes <= kRound) pos = (pos / kWave + 1) * kWave;
+    for (size_t i = 0; i < general.size(); i += general[i].x >> 24) place(&general[i], (int)(general[i].x >> 24));
     for (int np = kItemPairs; np >= 0; np--)
         for (size_t i = 0; i < in.size(); i += in[i].x >> 24)
-            if ((in[i].x & 0xffffu) >= (uint32_t)kSliceNodes && (int)(in[i].z >> 16) == np) place(i, (int)(in[i].x >> 24));
-    (void)diag_lanes;
+            if (!is_diag(in[i]) && (int)((in[i].z >> 16) & 0xffu) == np) place(&in[i], (int)(in[i].x >> 24));
     // A last wave that is at most half full of whole off-diagonal slots (32 of a structured slice's 96) is cut finer: every
     // slot of two or three contributions becomes two chunks in neighbouring lanes, so that the wave runs one contribution
     // (two for a slot of three) plus a lane sum instead of two or three -- it shares its SIMD with the other workgroup's
@@ -153,7 +182,7 @@ static void pack_items_pipe(const std::vector<Plan::Item> &in, std::vector<Plan:
         int lanes_after = 0;
         for (size_t i = w0; i < w1 && fits; i++) {
             const Plan::Item &it = (*out)[i];
-            const uint32_t nch = it.x >> 24, np = it.z >> 16;
+            const uint32_t nch = it.x >> 24, np = (it.z >> 16) & 0xffu;
             if (nch == 0) continue;
             if (nch != 1 || (it.x & 0xffffu) < (uint32_t)kSliceNodes) fits = false;
             lanes_after += np >= 2 ? 2 : 1;
@@ -162,7 +191,7 @@ static void pack_items_pipe(const std::vector<Plan::Item> &in, std::vector<Plan:
             std::vector<Plan::Item> cut;
             for (size_t i = w0; i < w1; i++) {
                 const Plan::Item &it = (*out)[i];
-                const uint32_t nch = it.x >> 24, np = it.z >> 16;
+                const uint32_t nch = it.x >> 24, np = (it.z >> 16) & 0xffu;
                 if (nch == 0) continue; // (padding inside the wave is dropped)
                 if (np < 2) {
                     cut.push_back(it);
@@ -192,7 +221,7 @@ static void pack_items_pipe(const std::vector<Plan::Item> &in, std::vector<Plan:
             const Plan::Item &it = (*out)[i];
             if ((it.x >> 24) == 0) continue; // inert
             most = std::max(most, it.x >> 24);
-            if ((it.x & 0xffffu) >= (uint32_t)kSliceNodes) all_diag = 0;
+            if ((it.x & 0xffffu) >= (uint32_t)kSliceNodes || (it.z >> 31)) all_diag = 0;
         }
         for (size_t i = w0; i < w1; i++) (*out)[i].w = most | (all_diag << 8);
     }
@@ -781,12 +810,13 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         for (size_t i = 0; i + 1 < p.pair_ptr.size(); i++) max_cnt = std::max(max_cnt, p.pair_ptr[i + 1] - p.pair_ptr[i]);
         p.pipe = wanted && !p.slice_elem_nodes.empty() && // (the kernel's idle lanes read a valid element: there must be one)
                  p.max_slice_elems <= (p.n_lquad() > 0 ? kPipeMaxSliceElemsQuad : kPipeMaxSliceElems) &&
-                 (max_cnt + item_pairs - 1) / item_pairs <= 64;
+                 (max_cnt + 1) / 2 <= 64; // (a slot's chunks -- of two contributions at the least -- share a wave)
         // ... and whose slices fill the three consumer waves the way the kernel is balanced for: the diagonal slots' chunks
-        // in one wave, the others in two.  A slice beyond that gets a wave that runs both code paths or a second round; a
-        // mesh of such slices (Delaunay meshes: valences 3..12, 70 and more diagonal chunks per slice) is assembled faster
-        // by the two-phase kernel (500k-point triangulation, Morton numbering: 3.5 against 4.0 G elements/s), structured
-        // meshes (64 + 96 lanes) faster by this one.  FEMSHELL_ASM_PIPE=2 takes it wherever it can run.
+        // in the first wave, the others in two.  Meshes of other slices are assembled as fast or faster by the two-phase kernel --
+        // Delaunay meshes (valences 3..12: 74 diagonal chunks per slice, the ones beyond the first wave as chunks of two
+        // among the off-diagonal slots; 500k-point triangulation, Morton numbering: 3.99 against 4.00 G elements/s), full
+        // storage (192 off-diagonal slots per structured slice: two rounds).  FEMSHELL_ASM_PIPE=2 takes the layout
+        // wherever the kernel can run.
         if (p.pipe && !(e && atoi(e) == 2)) {
             std::vector<int64_t> part((size_t)plan_chunks(p.n_slices, 256), 0);
             plan_parallel(p.n_slices, 256, [&](int t, int64_t s0, int64_t s1) {

@@ -345,7 +345,7 @@ def _slot_lists_from_items(plan):
         i0, i1 = plan["item_ptr"][s], plan["item_ptr"][s + 1]
         slots = {}
         for lane, (x, y, z, w) in enumerate(items[i0:i1]):
-            slot, chunk, nch, cnt = int(x & 0xffff), int((x >> 16) & 0xff), int(x >> 24), int(z >> 16)
+            slot, chunk, nch, cnt = int(x & 0xffff), int((x >> 16) & 0xff), int(x >> 24), int((z >> 16) & 0xff)
             if nch == 0:
                 assert slot == 0xffff and cnt == 0  # inert
                 continue
@@ -387,9 +387,15 @@ def test_work_items_of_both_assembly_kernels_carry_the_gather_lists(monkeypatch,
     assert plans["0"]["pipe"] == 0
     assert plans["1"]["pipe"] == 1, plans["1"]["max_slice_elems"]  # (all three meshes are numbered compactly enough)
     # the default takes it where it pays: slices whose diagonal chunks fill one wave and whose other chunks fill two
-    monkeypatch.delenv("FEMSHELL_ASM_PIPE")
     # (full storage: 192 off-diagonal slots per structured slice, more than two waves)
+    monkeypatch.delenv("FEMSHELL_ASM_PIPE")
     assert pkg.build_plan(xyz, tri, quad)["pipe"] == (1 if mesh != "patch" and symmetric == "1" else 0)
+    if mesh == "patch":  # diagonal slots beyond the first wave: chunks of two, marked for the general routine
+        items = plans["1"]["items"].reshape(-1, 4)
+        marked = items[(items[:, 2] >> 31) == 1]
+        assert len(marked) > 0 and np.all((marked[:, 0] & 0xffff) < 32) and np.all(((marked[:, 2] >> 16) & 0xff) <= 2)
+        lanes = np.concatenate([np.arange(a, b) - a for a, b in zip(plans["1"]["item_ptr"][:-1], plans["1"]["item_ptr"][1:])])
+        assert np.all(lanes[(items[:, 2] >> 31) == 1] % 192 >= 64)  # never in the first wave of a round
     for pipe, plan in plans.items():
         per_slice = _slot_lists_from_items(plan)
         items = plan["items"].reshape(-1, 4)
@@ -424,7 +430,7 @@ def test_work_items_of_both_assembly_kernels_carry_the_gather_lists(monkeypatch,
                     wv = items[w0:min(w0 + 64, i1)]
                     live = wv[(wv[:, 0] >> 24) > 0]
                     most = int((live[:, 0] >> 24).max()) if len(live) else 0
-                    all_diag = int(len(live) == 0 or bool(np.all((live[:, 0] & 0xffff) < 32)))
+                    all_diag = int(len(live) == 0 or bool(np.all(((live[:, 0] & 0xffff) < 32) & ((live[:, 2] >> 31) == 0))))
                     assert np.all(wv[:, 3] == (most | (all_diag << 8)))
     if mesh == "hub":
         assert max(len(c) for slots in _slot_lists_from_items(plans["1"]) for c in slots.values()) >= 14
