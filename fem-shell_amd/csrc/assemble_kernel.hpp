@@ -394,19 +394,20 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
 
 
 // =====================================================================================
-// The same assembly as a producer / consumer pipeline (plans with Plan::pipe: triangles only, slices whose two record
-// buffers fit twice into a CU's LDS).
+// The same assembly as a producer / consumer pipeline (plans with Plan::pipe: slices whose two record buffers fit twice
+// into a CU's LDS and whose items fill the consumer waves evenly -- structured meshes; plan.cpp decides).
 //
 // k_assemble runs a slice in two phases -- records, barrier, blocks -- and its four waves do different amounts of work
 // (one wave: diagonal items; two waves: records and off-diagonal items; one wave: records only): the longest wave and the
 // serial phases set the time of a slice, and the two SIMDs that hold the long waves of both resident workgroups are busy
 // while the others idle.  Here one wave of the workgroup -- the producer -- builds the records of the NEXT slice into a
 // second LDS buffer while the other three -- the consumers -- compute and store the blocks of the current one: one
-// barrier per slice, four waves of about equal work (records 3 passes | diagonal items | off-diagonal items x 2), no
-// staging of partial sums in LDS (the chunks of a block slot sit in neighbouring lanes of one wave, plan.cpp
-// pack_items_pipe, and meet through lane permutes).  Which wave does what follows the SIMD it runs on, and the second
-// workgroup of a CU shifts the roles by two SIMDs, so that every SIMD carries one long and one short wave.
-// Records are RecLean (34 doubles), items and flags as in k_assemble, in rounds of 192.
+// barrier per slice, four waves of about equal work (records, as one stream of 64-lane passes across the workgroup's
+// slices: 2.03 per structured slice | diagonal items | off-diagonal items x 2), no staging of partial sums in LDS (the
+// chunks of a block slot sit in neighbouring lanes of one wave, plan.cpp pack_items_pipe, and meet through lane shifts).
+// Which wave does what follows the SIMD it runs on, and the second workgroup of a CU shifts the roles by two SIMDs, so
+// that every SIMD carries one long and one short wave; the producer runs at raised priority.
+// Records of triangles are RecLean (34 doubles), items and flags as in k_assemble, in rounds of 192 lanes.
 // kAblate (lab): 8 = no record math, 16 = roles by wave index and the same in every workgroup, 32 = s_memtime stamps,
 // 64 = no priority for the producer, 128 = the second workgroup swaps neighbouring roles instead of shifting them by two SIMDs;
 // 0 in the product.
@@ -577,6 +578,8 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
                     if (!ok) atomicCAS(m.status, 0, ra.e0 + li + 1);
                     write_lean(buf, li, lean);
                 }
+                // (for every slot, needed by the next iteration or not: loads under a condition cost the wave's memory
+                // counter its precision -- 0.62 against 0.55 ms with the second slot's nine loads skipped when unused)
                 fetch_coords(ndn[p], X[p]); // the next iteration's element of this lane and slot
                 is_quad[p] = kHasQuads && ndn[p].w >= 0;
             }
