@@ -639,7 +639,7 @@ static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double 
     c->dm.item_ptr = c->item_ptr.p;
     c->dm.slice_desc = reinterpret_cast<const int4 *>(c->slice_desc.p);
     c->dm.items = reinterpret_cast<const uint4 *>(c->items.p);
-    FS_HIP(c->item_flags.alloc(p.items.size()));
+    FS_HIP(c->item_flags.alloc(p.pipe ? 0 : p.items.size())); // (pipelined layout: the word rides in the item, kernels.hip)
     c->dm.item_flags = c->item_flags.p;
     c->dm.max_stage_rows = p.max_stage_rows;
     c->dm.pipe = p.pipe ? 1 : 0;

@@ -422,6 +422,7 @@ __device__ __forceinline__ double lane_below(double v)
 }
 
 constexpr int kPipeConsumers = 192;  // lanes that own work items (three waves)
+constexpr int kPipeFlagShift = 9;    // item.w of the pipelined layout: wave word (9 bits) | constraint word << 9
 constexpr int kPipeRecPasses = 3;    // record passes the producer wave runs at most per slice: 192 records, more than a slice
                                      // of a plan with Plan::pipe has (kPipeMaxSliceElems)
 
@@ -651,11 +652,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
         };
         fetch_rhs(w.s);
         uint4 item_pre = make_uint4(0xffffu, 0, 0, 0);
-        uint32_t flags_pre = 0u;
-        if (vtid < d0.ni) {
-            item_pre = m.items[d0.i0 + vtid];
-            flags_pre = m.item_flags[d0.i0 + vtid];
-        }
+        if (vtid < d0.ni) item_pre = m.items[d0.i0 + vtid];
         lds_barrier(); // records of the first slice
         stamp(1);
         for (int j = 0; j < n_iter; j++, w.next()) {
@@ -664,9 +661,8 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
             const int64_t base = d0.base;
             const int i0 = d0.i0, ni = d0.ni;
             uint4 item = item_pre;
-            uint32_t flags = flags_pre;
             // the wait for the prefetched words belongs here, in front of this slice's prefetches (see k_assemble)
-            asm volatile("" : "+v"(item.x), "+v"(item.y), "+v"(item.z), "+v"(item.w), "+v"(flags));
+            asm volatile("" : "+v"(item.x), "+v"(item.y), "+v"(item.z), "+v"(item.w));
             const Desc d2 = decode(dva, dvb);
             if (m.rhs_F != nullptr) {
                 const bool fixed = (rhs_mask >> (vtid % 6)) & 1u;
@@ -678,11 +674,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
             dvb = desc_b_of(s + 3 * w.step);
             fetch_rhs(s + w.step);
             uint4 item_next = make_uint4(0xffffu, 0, 0, 0);
-            uint32_t flags_next = 0u;
-            if (vtid < d1.ni) {
-                item_next = m.items[d1.i0 + vtid];
-                flags_next = m.item_flags[d1.i0 + vtid];
-            }
+            if (vtid < d1.ni) item_next = m.items[d1.i0 + vtid];
             stamp(6);
             double2 *out = reinterpret_cast<double2 *>(m.vals + base * 36);
             for (int r0 = 0; r0 < ni; r0 += kPipeConsumers) {
@@ -690,12 +682,8 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
                 const bool live = it < ni;
                 if (r0 > 0) {
                     item = make_uint4(0xffffu, 0, 0, 0);
-                    flags = 0u;
-                    if (live) {
-                        item = m.items[i0 + it];
-                        flags = m.item_flags[i0 + it];
-                    }
-                    asm volatile("" : "+v"(item.x), "+v"(item.y), "+v"(item.z), "+v"(item.w), "+v"(flags));
+                    if (live) item = m.items[i0 + it];
+                    asm volatile("" : "+v"(item.x), "+v"(item.y), "+v"(item.z), "+v"(item.w));
                 }
                 const int slot_in_slice = (int)(item.x & 0xffffu), chunk = (int)((item.x >> 16) & 0xffu),
                           nchunks = (int)(item.x >> 24);
@@ -770,6 +758,8 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
                 }
                 stamp(3);
                 if (owner) {
+                    // the slot's constraint word rides in the item (k_item_flags: bits 9.. of w, beside the wave's word)
+                    const uint32_t flags = item.w >> kPipeFlagShift;
                     const uint32_t mrow = flags & 63u, mcol = (flags >> 6) & 63u;
                     const int valence = (int)((flags >> 12) & 255u);
                     const bool diag_slot = (flags >> 20) & 1u;
@@ -828,7 +818,6 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
                 stamp(4);
             }
             item_pre = item_next;
-            flags_pre = flags_next;
             d0 = d1;
             d1 = d2;
             lds_barrier(); // this slice's records are free, the next slice's are complete
