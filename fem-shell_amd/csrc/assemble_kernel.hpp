@@ -489,7 +489,9 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
         // element of a lane in such an iteration, b being the range of the following slice
         // (slots 0 and 1 are the full passes, if any; slot 2 is the last pass, the one that may reach into the next slice)
         auto stream_elem = [&](int r0, const Range &a, const Range &b, int slot) {
-            const int pi = (slot < kPipeRecPasses - 1) ? slot : max(passes_of(r0, a) - 1, 0);
+            // (a full-pass slot the iteration does not use reads what slot 0 reads: a cache hit instead of HBM traffic)
+            const int last = max(passes_of(r0, a) - 1, 0);
+            const int pi = (slot < kPipeRecPasses - 1) ? (slot < last ? slot : 0) : last;
             const int li = r0 + 64 * pi + lane, li2 = li - a.ne;
             int e = (li < a.ne) ? a.e0 + li : ((li2 < b.ne) ? b.e0 + li2 : a.e0 + max(a.ne - 1, 0));
             return min(max(e, 0), n_entries - 1);
