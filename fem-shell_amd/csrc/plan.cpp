@@ -811,12 +811,12 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         p.pipe = wanted && !p.slice_elem_nodes.empty() && // (the kernel's idle lanes read a valid element: there must be one)
                  p.max_slice_elems <= (p.n_lquad() > 0 ? kPipeMaxSliceElemsQuad : kPipeMaxSliceElems) &&
                  (max_cnt + 1) / 2 <= 64; // (a slot's chunks -- of two contributions at the least -- share a wave)
-        // ... and whose slices fill the three consumer waves the way the kernel is balanced for: the diagonal slots' chunks
-        // in the first wave, the others in two.  Meshes of other slices are assembled as fast or faster by the two-phase kernel --
-        // Delaunay meshes (valences 3..12: 74 diagonal chunks per slice, the ones beyond the first wave as chunks of two
-        // among the off-diagonal slots; 500k-point triangulation, Morton numbering: 3.99 against 4.00 G elements/s), full
-        // storage (192 off-diagonal slots per structured slice: two rounds).  FEMSHELL_ASM_PIPE=2 takes the layout
-        // wherever the kernel can run.
+        // ... and whose slices fit one round of the three consumer waves: the diagonal slots' chunks of three in the first,
+        // the rest -- diagonal slots beyond 64 lanes as chunks of two -- in the other two.  Structured meshes (64 + 96
+        // lanes): 0.57 against 0.72 ms at 4M triangles; Delaunay meshes (valences 3..12: 74 + 96 chunks per slice): 5.1
+        // against 4.5 G elements/s at 1M triangles.  A second round per slice (full storage: 192 off-diagonal slots per
+        // structured slice) is left to the two-phase kernel.  FEMSHELL_ASM_PIPE=2 takes the layout wherever the kernel can
+        // run.
         if (p.pipe && !(e && atoi(e) == 2)) {
             std::vector<int64_t> part((size_t)plan_chunks(p.n_slices, 256), 0);
             plan_parallel(p.n_slices, 256, [&](int t, int64_t s0, int64_t s1) {
@@ -829,7 +829,8 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                             const int cnt = p.pair_ptr[idx + 1] - p.pair_ptr[idx];
                             (k == 0 ? diag : off) += (cnt + item_pairs - 1) / item_pairs;
                         }
-                    r += diag > 64 || off > 128;
+                    const int beyond = diag > 64 ? ((diag - 64) * 3 + 1) / 2 : 0; // (chunks of two in the other waves)
+                    r += std::min(diag, 64) + beyond + off > 192;
                 }
                 part[(size_t)t] += r;
             });

@@ -200,9 +200,9 @@ int femshell_amg_setup_stats(femshell_ctx *ctx, double out[7]);
  * (semi-definite) directions, out[5] = bytes of the lower triangle read and written over all steps */
 int femshell_amg_dense_stats(femshell_ctx *ctx, double out[6]);
 /* which assembly kernel femshell_assemble launches for the mesh of this context (after femshell_set_mesh): 1 = the
- * pipelined one (k_assemble_pipe: meshes whose slices touch at most 150 elements -- 77 with quadrilaterals -- and fill its
- * waves evenly: structured meshes), 0 = the two-phase one (k_assemble: scattered numberings, irregular valences,
- * FEMSHELL_ASM_PIPE=0); < 0: error.  Same results either way. */
+ * pipelined one (k_assemble_pipe: meshes whose slices touch at most 150 elements -- 77 with quadrilaterals -- and whose
+ * work items fit one round of its waves: structured meshes, unstructured ones numbered with locality), 0 = the two-phase
+ * one (k_assemble: scattered numberings, full storage, FEMSHELL_ASM_PIPE=0); < 0: error.  Same results either way. */
 int femshell_assembly_kernel(femshell_ctx *ctx);
 
 /* replaces: equation_systems.solve() -> PETSc KSPSolve (SA:138, PC:271) followed by

@@ -386,10 +386,10 @@ def test_work_items_of_both_assembly_kernels_carry_the_gather_lists(monkeypatch,
         plans[pipe] = pkg.build_plan(xyz, tri, quad)
     assert plans["0"]["pipe"] == 0
     assert plans["1"]["pipe"] == 1, plans["1"]["max_slice_elems"]  # (all three meshes are numbered compactly enough)
-    # the default takes it where it pays: slices whose diagonal chunks fill one wave and whose other chunks fill two
-    # (full storage: 192 off-diagonal slots per structured slice, more than two waves)
+    # the default takes it where a slice's items fit one round of 192 lanes (full storage: 192 off-diagonal slots per
+    # structured slice beside the diagonal ones)
     monkeypatch.delenv("FEMSHELL_ASM_PIPE")
-    assert pkg.build_plan(xyz, tri, quad)["pipe"] == (1 if mesh != "patch" and symmetric == "1" else 0)
+    assert pkg.build_plan(xyz, tri, quad)["pipe"] == (1 if symmetric == "1" else 0)
     if mesh == "patch":  # diagonal slots beyond the first wave: chunks of two, marked for the general routine
         items = plans["1"]["items"].reshape(-1, 4)
         marked = items[(items[:, 2] >> 31) == 1]

@@ -31,11 +31,23 @@ int main(int argc, char **argv)
 {
     const int nx = argc > 1 ? atoi(argv[1]) : 1414;
     const int grid = argc > 2 ? atoi(argv[2]) : 2048;
-    const int nn = (nx + 1) * (nx + 1);
-    std::vector<double> xyz(3 * (size_t)nn);
-    for (int j = 0; j <= nx; j++) for (int i = 0; i <= nx; i++) { size_t a = (size_t)j * (nx + 1) + i; xyz[3*a] = 10.0 * i / nx; xyz[3*a+1] = 10.0 * j / nx; xyz[3*a+2] = 0.0; }
-    std::vector<int32_t> tri; tri.reserve(6 * (size_t)nx * nx);
-    for (int j = 0; j < nx; j++) for (int i = 0; i < nx; i++) { int n = i + j * (nx + 1), up_ = nx + 1; tri.insert(tri.end(), {n, n + 1, n + up_, n + 1, n + up_ + 1, n + up_}); }
+    int nn = (nx + 1) * (nx + 1);
+    std::vector<double> xyz;
+    std::vector<int32_t> tri;
+    if (argc > 3) { // a mesh file: int64 n_nodes, int64 n_tri, doubles xyz, int32 triangles (tools/lab/write_mesh.py)
+        FILE *f = fopen(argv[3], "rb");
+        long long hdr[2];
+        if (!f || fread(hdr, 8, 2, f) != 2) { printf("cannot read %s\n", argv[3]); return 1; }
+        nn = (int)hdr[0];
+        xyz.resize(3 * (size_t)nn); tri.resize(3 * (size_t)hdr[1]);
+        if (fread(xyz.data(), 8, xyz.size(), f) != xyz.size() || fread(tri.data(), 4, tri.size(), f) != tri.size()) { printf("short file\n"); return 1; }
+        fclose(f);
+    } else {
+        xyz.resize(3 * (size_t)nn);
+        for (int j = 0; j <= nx; j++) for (int i = 0; i <= nx; i++) { size_t a = (size_t)j * (nx + 1) + i; xyz[3*a] = 10.0 * i / nx; xyz[3*a+1] = 10.0 * j / nx; xyz[3*a+2] = 0.0; }
+        tri.reserve(6 * (size_t)nx * nx);
+        for (int j = 0; j < nx; j++) for (int i = 0; i < nx; i++) { int n = i + j * (nx + 1), up_ = nx + 1; tri.insert(tri.end(), {n, n + 1, n + up_, n + 1, n + up_ + 1, n + up_}); }
+    }
     Plan p; std::string err;
     if (!build_plan(nn, xyz.data(), (int)tri.size() / 3, tri.data(), 0, nullptr, 0, 1, &p, &err, default_symmetric_storage())) { printf("plan: %s\n", err.c_str()); return 1; }
     DeviceMatrix m;
@@ -54,6 +66,11 @@ int main(int argc, char **argv)
     std::vector<uint8_t> dm(p.n_local_nodes(), 0); m.dmask = up(dm);
     std::vector<uint32_t> fl(p.items.size(), 0u); m.item_flags = up(fl); // no Dirichlet nodes in the lab mesh
     std::vector<int32_t> st(1, 0); m.status = up(st);
+    if (getenv("LAB_RHS")) { // the right-hand side beside K, as the library assembles it
+        std::vector<double> ld((size_t)p.n_pad * 6, 1.0);
+        m.rhs_loads = up(ld);
+        double *F; CK(hipMalloc(&F, (size_t)p.n_pad * 6 * 8)); m.rhs_F = F;
+    }
     double *vals; CK(hipMalloc(&vals, (size_t)p.total_slots() * 36 * 8)); m.vals = vals;
     MatConst mc; const double nu = 0.3, E = 1e7, t = 0.5;
     mc.cm = E / (1 - nu * nu); mc.cp = E * t * t * t / (12 * (1 - nu * nu)); mc.nu = nu; mc.g = (1 - nu) / 2; mc.t = t; mc.flags = 3; mc.pad = 0;
