@@ -287,6 +287,8 @@ def fullsize_parity(fs, m, mat, kind):
         "true_rel_residual_double_double": r1["true_rel_residual_double_double"],
         "without_refinement_pass": {"rel_err_manufactured": r0["rel_err_vs_manufactured"], "iterations": r0["iterations"],
                                     "true_rel_residual_double_double": r0["true_rel_residual_double_double"]},
+        "first_phase_alone_to_100_rtol": {"rel_err_manufactured": man["runs"]["first_phase"]["rel_err_vs_manufactured"],
+                                          "iterations": man["runs"]["first_phase"]["iterations"]},
         "rounding_of_b": man.get("rounding_of_b"),
         "note": "u* smooth, zero on the fixed dofs; b = K u* evaluated in double-double on the device and rounded to double; "
                 "the reference is u* + K^-1 (fl(b) - K u*)"}

@@ -107,8 +107,10 @@ int femshell_assemble_async(femshell_ctx *ctx);
 
 typedef struct femshell_solve_info {
     int32_t iterations;     /* CG iterations performed */
-    int32_t converged;      /* 1: ||r|| <= rtol*||b||, 0: max_it reached */
-    double rel_residual;    /* recurrence ||r||_2 / ||b||_2 at exit (what the stopping rule tests) */
+    int32_t converged;      /* 1: ||r|| <= rtol*||b|| (multigrid with refinement: <= 100 rtol*||b|| after the first phase,
+                               then the refinement pass -- see femshell_pc_options::refine_passes), 0: max_it reached */
+    double rel_residual;    /* recurrence ||r||_2 / ||b||_2 at exit (what the stopping rule tests; multigrid with
+                               refinement: at the end of the first phase) */
     double true_rel_residual; /* ||b - K u||_2 / ||b||_2 recomputed explicitly after a converged solve, -1 if not
                                computed (rtol <= 0, iteration limit, breakdown).  On ill-conditioned shells the
                                recurrence drifts and this floors near kappa*eps; it is reported, not enforced:
@@ -126,7 +128,7 @@ typedef struct femshell_solve_info {
      * measures the relative displacement error of the iterate BEFORE that pass, and the pass leaves behind about
      * that times the factor by which it reduced the residual of its correction equation.  Checked against manufactured
      * solutions at the 4M-triangle sizes (tests/test_gpu_fullsize.py, bench.py time_to_solution.manufactured). */
-    int32_t refine_passes_done;       /* refinement passes that ran (<= femshell_pc_options::refine_passes) */
+    int32_t refine_passes_done;       /* refinement passes that ran (<= femshell_pc_options::refine_passes + 1) */
     int32_t reserved0;
     double refine_correction_rel;     /* ||e||_2 / ||x||_2 of the last pass */
     double refine_residual_reduction; /* ||rhs - K e|| / ||rhs|| (recurrence) the last pass stopped at */
@@ -163,9 +165,14 @@ typedef struct femshell_pc_options {
                                 solved by the same method to a drop of 1e-4, whatever rtol is -- rtol bounds the
                                 residual, and on these systems the displacement error sits one to two decades above
                                 it (4M triangles, manufactured solution: 4e-9 at a residual of 9e-11 ||b||).  The
-                                first pass always runs, further ones while femshell_solve_info::error_estimate
-                                exceeds rtol.  Plain FP64 CG stalls at a displacement error of kappa*eps -- 2e-10 on the
-                                250k-triangle roof -- one pass brings it to 1e-13 */
+                                first pass always runs, further ones (one more than this number at most) while
+                                femshell_solve_info::error_estimate exceeds rtol.  Plain FP64 CG stalls at a displacement
+                                error of kappa*eps -- 2e-10 on the 250k-triangle roof -- one pass brings it to 1e-13.
+                                With refinement on, the recurrence of the first phase runs to 100 rtol only: what rtol
+                                is for is the displacement error, the pass reduces the error of whatever iterate it
+                                starts from by its drop, and the digits between 100 rtol and rtol are the ones the
+                                recurrence's rounding noise spoils (4M triangles: 132 instead of 148 iterations, error
+                                estimate 4e-12; manufactured solutions 1e-12 / 2e-11) */
     int32_t reserved;
     double eig_ratio;        /* the smoother targets [lambda_max/eig_ratio, lambda_max] of D^-1 A (default 30) */
 } femshell_pc_options;
