@@ -2,6 +2,8 @@
 the same inputs.  Tolerances (FP64): element matrices and assembled K <= 1e-12 relative
 (Frobenius / max-entry scaled); displacements < 1e-10 relative to the oracle's direct solve
 where CG can attain it (small meshes), otherwise as stated per test."""
+import os
+
 import numpy as np
 import pytest
 
@@ -897,4 +899,23 @@ def test_asynchronous_assembly_reports_its_status_at_the_next_synchronising_call
     fs.assemble(wait=False)
     u2, info2 = fs.solve(rtol=1e-9, max_it=20000)
     assert info2["converged"] == 1 and np.array_equal(u2, u)
+    fs.close()
+
+
+def test_assembly_kernel_query():
+    """femshell_assembly_kernel: an error before femshell_set_mesh, then the kernel the plan chose -- the pipelined one for
+    a structured mesh, the two-phase one with FEMSHELL_ASM_PIPE=0 (read per femshell_set_mesh)."""
+    m = meshes.structured(12, 9, 0, 0, 2, 1.5, kind="t", ul_lr=True)
+    fs = pkg.FemShell(0.3, 1e6, 0.1)
+    with pytest.raises(pkg.FemShellError) as ei:
+        fs.assembly_kernel()
+    assert ei.value.code == -1
+    fs.set_mesh(m.xyz, m.tri)
+    assert fs.assembly_kernel() == "k_assemble_pipe"
+    os.environ["FEMSHELL_ASM_PIPE"] = "0"
+    try:
+        fs.set_mesh(m.xyz, m.tri)
+        assert fs.assembly_kernel() == "k_assemble"
+    finally:
+        del os.environ["FEMSHELL_ASM_PIPE"]
     fs.close()
