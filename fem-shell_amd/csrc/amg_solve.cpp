@@ -154,8 +154,9 @@ void amg_default_options(femshell_pc_options *o)
     std::memset(o, 0, sizeof *o);
     o->type = FEMSHELL_PC_AMG;
     o->cycle = FEMSHELL_CYCLE_K;
-    o->smoother_degree = 2; // tools/amg_sweep.py: on the 1M-triangle panel and the 250k roof (launch-bound) degree 3 / 3 is
-    o->coarse_degree = 4;   // 8 % faster to 1e-10, on the 4M-triangle panel (HBM-bound) 2 / 4 wins: 1.72 s against 1.97 s
+    o->smoother_degree = 3; // tools/lab/amg_degree_probe.py, 4M triangles, rtol 1e-10 with the refinement pass: degrees 3 / 4
+    o->coarse_degree = 4;   // against 2 / 4: panel 104 against 132 iterations, 0.98 against 1.04 s; cylinder 97 / 119, 0.91 /
+                            // 0.94 s; roof 99 / 112, 0.087 / 0.089 s (3 / 3: 1.04 s on the panel; V cycles: twice the time)
     o->coarsest_nodes = 1400; // the K cycle's last levels cost launches, not bytes: end with an exact solve early (amg_dense.hip)
     o->max_levels = 12;
     o->refine_passes = 1;

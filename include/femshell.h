@@ -152,7 +152,7 @@ typedef enum femshell_cycle { FEMSHELL_CYCLE_V = 0, FEMSHELL_CYCLE_K = 1 } femsh
 typedef struct femshell_pc_options {
     int32_t type;            /* femshell_pc_type */
     int32_t cycle;           /* femshell_cycle (default K: two flexible-CG steps per coarse level) */
-    int32_t smoother_degree; /* Chebyshev degree on the finest level (default 2) */
+    int32_t smoother_degree; /* Chebyshev degree on the finest level (default 3) */
     int32_t coarse_degree;   /* Chebyshev degree on the coarser levels (default 4) */
     int32_t coarsest_nodes;  /* coarsening stops at the first level of at most this many nodes; dense inverse there (default
                                 and maximum 1400: the K cycle visits its last levels 8-16 times per iteration and each

@@ -215,7 +215,7 @@ class Level:
     pass
 
 
-def setup(A, xyz, dmask, lams=None, coarsest_nodes=200, max_levels=12, eig_ratio=30.0, degree=2, coarse_degree=4,
+def setup(A, xyz, dmask, lams=None, coarsest_nodes=200, max_levels=12, eig_ratio=30.0, degree=3, coarse_degree=4,
           tri=None, quad=None):
     """lams: upper bounds of the spectrum per level as the library reports them (femshell_amg_level); computed
     here (1.1 x power iteration) when None.  tri / quad: connectivity for the node normals of rigid_body_modes."""

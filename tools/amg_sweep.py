@@ -25,7 +25,7 @@ fs.set_loads(m.loads)
 fs.assemble()
 print("%s %d: %d tri" % (kind, n, len(m.tri)), flush=True)
 for cyc, sd, cd, ratio in itertools.product(("K", "V"), (1, 2, 3), (2, 3, 4, 6), (30.0,)):
-    fs.set_preconditioner("amg", cycle=cyc, smoother_degree=sd, coarse_degree=cd, eig_ratio=ratio, refine_passes=0)
+    fs.set_preconditioner("amg", cycle=cyc, smoother_degree=sd, coarse_degree=cd, eig_ratio=ratio, refine_passes=1)
     try:
         u, info = fs.solve(rtol=1e-10, max_it=1500, fetch=False)
         print("cycle %s fine %d coarse %d ratio %g: %4d its %.3f s (%.2f ms/it) conv %d setup %.2f s" % (
@@ -34,6 +34,6 @@ for cyc, sd, cd, ratio in itertools.product(("K", "V"), (1, 2, 3), (2, 3, 4, 6),
     except pkg.FemShellError as e:
         print("cycle %s fine %d coarse %d ratio %g: %s" % (cyc, sd, cd, ratio, e), flush=True)
 for ratio in (10.0, 20.0, 50.0, 100.0):
-    fs.set_preconditioner("amg", eig_ratio=ratio, refine_passes=0)
+    fs.set_preconditioner("amg", eig_ratio=ratio, refine_passes=1)
     u, info = fs.solve(rtol=1e-10, max_it=1500, fetch=False)
     print("default K 2/4 ratio %g: %4d its %.3f s" % (ratio, info["iterations"], info["solve_seconds"]), flush=True)
