@@ -85,9 +85,10 @@ void launch_assemble(const DeviceMatrix &m, const MatConst &mc, hipStream_t st)
 
 // Constraint word of every assembly work item (DeviceMatrix::item_flags): the assembly kernel fetches it together
 // with the item, one slice ahead, instead of chasing cols -> dmask[col] in its block phase.
-// (In kernel statistics this kernel shows 15-27 ms per call at 4M triangles: it is the first kernel after the host-side
-// work and the uploads of femshell_set_dirichlet, and pays for the device's way back from idle -- launched twice in a row
-// it takes 17 ms and 78 us, tools/lab/flags_prof.sh.)
+// (In kernel statistics this kernel can show 15-27 ms per call at 4M triangles: it is the first kernel behind the uploads
+// of femshell_set_mesh / femshell_set_dirichlet -- launched twice in a row it takes 17 ms and 78 us, and 115 us behind the
+// uploads of femshell_set_loads alone (tools/lab/flags_prof.sh, idle_prof.sh).  Idle gaps of up to half a second in front
+// of a kernel cost it nothing.)
 __global__ __launch_bounds__(256) void k_item_flags(DeviceMatrix m)
 {
     for (int s = blockIdx.x; s < m.n_slices; s += gridDim.x) {
