@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void k_kcyc_dots(const double *__restrict__ a0
     if (threadIdx.x == 0) {
         scratch[blockIdx.x] = t0;
         scratch[kKcycGroups + blockIdx.x] = t1;
-        scratch[2 * kKcycGroups + blockIdx.x] = t2;
+        if (a2 != nullptr) scratch[2 * kKcycGroups + blockIdx.x] = t2; // (two-product callers hand over 2 x kKcycGroups doubles)
     }
 }
 

@@ -822,7 +822,9 @@ int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, do
         if (pass > 0) {
             // error estimate of the solve: ||e|| / ||x|| of this pass (the error of the iterate before it) and the factor
             // by which the pass reduced the residual of its correction equation
-            FS_HIP(c->dots_scratch.alloc(2 * 128 + 2));
+            // (two partial arrays of 128 groups, room for a third, and behind them the two-word staging slot of the all-reduce)
+            constexpr size_t kDotsStage = 3 * 128;
+            FS_HIP(c->dots_scratch.alloc(kDotsStage + 2));
             const int groups = launch_two_dots(v.x, v.x, c->xacc.p, c->xacc.p, n6, c->dots_scratch.p, st);
             double hp[2 * 128];
             FS_HIP(hipMemcpyAsync(hp, c->dots_scratch.p, sizeof hp, hipMemcpyDeviceToHost, st));
@@ -833,10 +835,10 @@ int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, do
                 sums[1] += hp[128 + g];
             }
             if (c->comm.active()) { // every rank holds its own rows
-                FS_HIP(hipMemcpyAsync(c->dots_scratch.p + 256, sums, sizeof sums, hipMemcpyHostToDevice, st));
+                FS_HIP(hipMemcpyAsync(c->dots_scratch.p + kDotsStage, sums, sizeof sums, hipMemcpyHostToDevice, st));
                 std::string e;
-                if (!comm_allreduce_sum(c->comm, c->dots_scratch.p + 256, 2, st, &e)) return set_err(FEMSHELL_ERR_COMM, e);
-                FS_HIP(hipMemcpyAsync(sums, c->dots_scratch.p + 256, sizeof sums, hipMemcpyDeviceToHost, st));
+                if (!comm_allreduce_sum(c->comm, c->dots_scratch.p + kDotsStage, 2, st, &e)) return set_err(FEMSHELL_ERR_COMM, e);
+                FS_HIP(hipMemcpyAsync(sums, c->dots_scratch.p + kDotsStage, sizeof sums, hipMemcpyDeviceToHost, st));
                 FS_HIP(hipStreamSynchronize(st));
             }
             c->refine.passes = pass;

@@ -104,7 +104,9 @@ int interpret_status(femshell_ctx *c, int32_t st, const char *what)
 // block exists on the owning rank only; without this the healthy ranks would walk on into the halo exchange and
 // the all-reduces of the CG loop and wait there forever.  Every rank calls this at the same points (after the
 // assembly and after the block-Jacobi setup); all of them leave with an error when any of them has one.
-int agree_status(femshell_ctx *c, int local_rc, const char *what)
+// (neutral: the caller is neither the assembly nor the block-Jacobi setup -- the healthy ranks then report "failed on N
+//  other rank(s)" with FEMSHELL_ERR_COMM instead of guessing at a degenerate element or a non-SPD block over there)
+int agree_status(femshell_ctx *c, int local_rc, const char *what, bool neutral = false)
 {
     if (!c->comm.active()) return local_rc;
     const std::string local_msg = last_err();
@@ -118,6 +120,12 @@ int agree_status(femshell_ctx *c, int local_rc, const char *what)
     FS_HIP(hipMemcpyAsync(c->agree_host, c->agree.p, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     FS_HIP(hipStreamSynchronize(c->stream));
     if (local_rc) return set_err(local_rc, local_msg);
+    if (neutral && c->agree_host[0] + c->agree_host[1] > 0.0) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "%s: failed on %d other rank(s) of the row partition (their own message says why)", what,
+                 (int)(c->agree_host[0] + c->agree_host[1]));
+        return set_err(FEMSHELL_ERR_COMM, buf);
+    }
     if (c->agree_host[0] + c->agree_host[1] > 0.0) {
         char buf[200];
         snprintf(buf, sizeof buf, "%s: failed on %d other rank(s) of the row partition (%s there)", what,
@@ -525,10 +533,15 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
         return set_err(FEMSHELL_ERR_INVALID, "femshell_set_mesh: call femshell_comm_init first on a multi-rank context");
     int rc = select_device(c);
     if (rc) return rc;
-    c->assembly_pending = false; // (an assembly of the previous mesh whose status nobody asked for)
+    if (c->assembly_pending) {
+        // an assembly of the previous mesh whose status nobody asked for: its mark in the device status word (a degenerate
+        // element of the OLD mesh) must not surface as a failure of the first assembly on the new one
+        c->assembly_pending = false;
+        if (c->status.p) FS_HIP(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), c->stream));
+    }
     // a failure that only this rank sees (its slices exceed the LDS staging, one of its nodes has too many neighbours, a
     // HIP allocation failed) must reach the others: they would wait in the next collective forever
-    return agree_status(c, set_mesh_on_this_rank(c, n_nodes, xyz, n_tri, tri, n_quad, quad), "femshell_set_mesh");
+    return agree_status(c, set_mesh_on_this_rank(c, n_nodes, xyz, n_tri, tri, n_quad, quad), "femshell_set_mesh", true);
 }
 
 static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t *tri,
@@ -914,7 +927,7 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
     if (use_amg && (!c->amg || !c->amg->valid)) {
         if (c->comm.active()) {
             const double t0 = wall_s();
-            rc = agree_status(c, amg_setup_through_shadow(c), "multigrid setup");
+            rc = agree_status(c, amg_setup_through_shadow(c), "multigrid setup", true);
             if (rc) {
                 c->amg.reset();
                 return rc;
@@ -1060,6 +1073,10 @@ int femshell_element_matrices(femshell_ctx *c, int32_t first, int32_t count, dou
         return set_err(FEMSHELL_ERR_INVALID, "femshell_element_matrices: range mixes triangles and quads");
     int rc = select_device(c);
     if (rc) return rc;
+    if (c->assembly_pending) { // (its status word is the one this call checks below)
+        rc = finish_pending_assembly(c);
+        if (rc) return rc;
+    }
     DevBuf<double> out;
     const size_t per = quads ? 576 : 324;
     FS_HIP(out.alloc((size_t)count * per));

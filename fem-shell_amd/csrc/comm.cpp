@@ -6,6 +6,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace femshell {
 
@@ -28,8 +29,11 @@ struct Api {
 
 Api g_api;
 
+std::mutex g_api_mutex; // distinct contexts are thread-safe (include/femshell.h): two threads may get here together
+
 bool load_api(std::string *err)
 {
+    std::lock_guard<std::mutex> lock(g_api_mutex);
     if (g_api.lib) return true;
     // FEMSHELL_RCCL_LIB: tests point this at tests/helpers/fake_rccl (several ranks on one GPU)
     const char *override_path = getenv("FEMSHELL_RCCL_LIB");

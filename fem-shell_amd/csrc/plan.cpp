@@ -4,6 +4,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <chrono>
 #include <cstdio>
@@ -419,11 +420,15 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                     bool mine = c > a;
                     if (geometric) {
                         const double *xa = xyz + 3ll * (g0 + a), *xc = xyz + 3ll * (g0 + c);
-                        for (int d = 0; d < 3; d++)
+                        for (int d = 0; d < 3; d++) {
+                            // (a non-finite coordinate compares false from both rows and the block would be lost: such a
+                            //  pair keeps the index rule -- femshell_plan_create does not validate coordinates)
+                            if (!std::isfinite(xa[d]) || !std::isfinite(xc[d])) break;
                             if (xc[d] != xa[d]) {
                                 mine = xc[d] > xa[d];
                                 break;
                             }
+                        }
                     }
                     if (mine) {
                         nb_mine[q] = 1;
@@ -810,7 +815,8 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         for (size_t i = 0; i + 1 < p.pair_ptr.size(); i++) max_cnt = std::max(max_cnt, p.pair_ptr[i + 1] - p.pair_ptr[i]);
         p.pipe = wanted && !p.slice_elem_nodes.empty() && // (the kernel's idle lanes read a valid element: there must be one)
                  p.max_slice_elems <= (p.n_lquad() > 0 ? kPipeMaxSliceElemsQuad : kPipeMaxSliceElems) &&
-                 (max_cnt + 1) / 2 <= 64; // (a slot's chunks -- of two contributions at the least -- share a wave)
+                 item_pairs >= 2 && (max_cnt + 1) / 2 <= 64; // (a slot's chunks -- of two contributions at the least -- share
+                                                             //  a wave; FEMSHELL_ITEM_PAIRS=1 cuts chunks of one: two-phase kernel)
         // ... and whose slices fit one round of the three consumer waves: the diagonal slots' chunks of three in the first,
         // the rest -- diagonal slots beyond 64 lanes as chunks of two -- in the other two.  Structured meshes (64 + 96
         // lanes): 0.57 against 0.72 ms at 4M triangles; Delaunay meshes (valences 3..12: 74 + 96 chunks per slice): 5.1

@@ -85,7 +85,16 @@ ShellMesh read_xda(const std::string &path)
     const std::vector<std::string> L = read_lines(path);
     if (L.size() < 8 || L[0].rfind("libMesh", 0) != 0) throw std::runtime_error(path + ": not an ASCII XDA file");
     ShellMesh m;
-    const long n_elem = std::stol(L[1]), n_nodes = std::stol(L[2]);
+    auto count_of = [&](const std::string &line, const char *what) -> long {
+        try {
+            const long v = std::stol(line);
+            if (v < 0) throw std::out_of_range("negative");
+            return v;
+        } catch (const std::exception &) {
+            throw std::runtime_error(path + ": bad " + what + " \"" + line.substr(0, 40) + "\"");
+        }
+    };
+    const long n_elem = count_of(L[1], "element count"), n_nodes = count_of(L[2], "node count");
     size_t pos = 8;
     if (L.size() < pos + (size_t)n_elem + (size_t)n_nodes + 1) throw std::runtime_error(path + ": truncated XDA file");
     for (long e = 0; e < n_elem; e++, pos++) {
@@ -115,7 +124,7 @@ ShellMesh read_xda(const std::string &path)
         if (!is) throw std::runtime_error(path + ": bad node line " + std::to_string(n));
         m.xyz.insert(m.xyz.end(), {x, y, z});
     }
-    const long n_bc = std::stol(L[pos++]);
+    const long n_bc = count_of(L[pos++], "boundary condition count");
     for (long b = 0; b < n_bc && pos < L.size(); b++, pos++) {
         std::istringstream is(L[pos]);
         SideBC bc;
@@ -128,7 +137,7 @@ ShellMesh read_xda(const std::string &path)
         m.bcs.push_back(bc);
     }
     if (L[0].rfind("libMesh-0.9.2+", 0) == 0 && pos < L.size() && !L[pos].empty() && L[pos].find_first_not_of(" \t\r") != std::string::npos) {
-        const long n_ns = std::stol(L[pos++]); // nodesets: (node, boundary id)
+        const long n_ns = count_of(L[pos++], "nodeset count"); // nodesets: (node, boundary id)
         for (long b = 0; b < n_ns && pos < L.size(); b++, pos++) {
             std::istringstream is(L[pos]);
             int32_t node, id;
@@ -267,6 +276,15 @@ struct XdrIn {
         in.read(static_cast<char *>(dst), (std::streamsize)n);
         if ((size_t)in.gcount() != n) throw std::runtime_error(path + ": truncated XDR file");
     }
+    // bytes between the read position and the end of the file
+    uint64_t remaining()
+    {
+        const std::streampos here = in.tellg();
+        in.seekg(0, std::ios::end);
+        const std::streampos end = in.tellg();
+        in.seekg(here);
+        return (here < 0 || end < here) ? 0 : (uint64_t)(end - here);
+    }
     uint32_t u32()
     {
         unsigned char b[4];
@@ -337,6 +355,11 @@ ShellMesh read_xdr(const std::string &path)
         throw std::runtime_error(path + ": subdomain / processor / p-level records are not supported (the reference's meshes carry none)");
     const uint32_t n_level0 = x.u32();
     if (n_level0 != n_elem) throw std::runtime_error(path + ": refined meshes (elements above level 0) are not supported");
+    // the counts come from the file: hold them against its size before anything is allocated for them (an element record is
+    // at least 16 bytes, a node 24)
+    if ((uint64_t)n_elem * 16u + (uint64_t)n_nodes * 24u > x.remaining())
+        throw std::runtime_error(path + ": header announces " + std::to_string(n_elem) + " elements and " + std::to_string(n_nodes) +
+                                 " nodes, more than the file holds (truncated, or not an XDR mesh file)");
     ShellMesh m;
     for (uint32_t e = 0; e < n_elem; e++) {
         const uint32_t type = x.u32();

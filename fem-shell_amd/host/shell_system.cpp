@@ -54,7 +54,8 @@ bool read_parameters(int argc, char **argv, Parameters &p, std::ostream &out, st
             << "-out:\t Output file name (without extension, optional)\n"
             << "-d:\t Additional (debug) messages (1=on, 0=off (default))\n"
             << "-tol:\t relative residual tolerance of the CG solve (optional, default 1e-12)\n"
-            << "-max_it:\t iteration limit of the CG solve (optional, default 100000)\n";
+            << "-max_it:\t iteration limit of the CG solve (optional, default 5000)\n"
+            << "-pc_type:\t gamg (multigrid, default) | bjacobi (6x6 block-Jacobi)\n";
         return false;
     }
     bool failed = false;

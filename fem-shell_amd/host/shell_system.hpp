@@ -40,12 +40,14 @@ struct Parameters {
     // extensions (not in the reference): solver controls that libMesh/PETSc take from
     // equation_systems.parameters / -ksp_* options
     double tol = 1e-12;       // libMesh "linear solver tolerance" default (TOLERANCE^2); also -ksp_rtol
-    int max_it = 100000;      // also -ksp_max_it
+    int max_it = 5000;        // libMesh's "linear solver maximum iterations" default; also -ksp_max_it
     // the reference passes -ksp_type / -pc_type through to PETSc (doc/implementation.tex:68-72).  K is SPD and the
     // library's Krylov method is CG: -ksp_type cg is accepted, anything else is reported and replaced by cg;
     // -pc_type jacobi|bjacobi|pbjacobi|none -> 6x6 block-Jacobi, gamg|amg|ml|hypre|mg -> the multigrid preconditioner
     std::string ksp_type = "cg";
-    std::string pc_type = "bjacobi";
+    // default: the multigrid.  The reference's default (PETSc's GMRES + ILU) is a stronger preconditioner than point-block
+    // Jacobi, whose iteration count grows with the element count (no convergence at 4M triangles); -pc_type bjacobi opts in
+    std::string pc_type = "gamg";
 };
 
 // One process per GPU.  How a rank learns its place: FEMSHELL_RANK / FEMSHELL_WORLD_SIZE, else the
