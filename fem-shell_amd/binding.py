@@ -24,7 +24,7 @@ SYMBOLS = [
     "femshell_nnz_blocks", "femshell_export_bsr", "femshell_spmv", "femshell_row_begin",
     "femshell_row_end", "femshell_comm_unique_id", "femshell_comm_init", "femshell_time_kernel",
     "femshell_sync", "femshell_pc_defaults", "femshell_set_preconditioner", "femshell_amg_levels", "femshell_amg_level",
-    "femshell_amg_export", "femshell_residual", "femshell_comm_ranks", "femshell_amg_setup_stats", "femshell_amg_dense_stats", "femshell_assembly_kernel",
+    "femshell_amg_export", "femshell_residual", "femshell_comm_ranks", "femshell_amg_setup_stats", "femshell_amg_dense_stats", "femshell_amg_partition_info", "femshell_assembly_kernel",
 ]
 
 
@@ -135,6 +135,7 @@ def load_library():
     L.femshell_amg_export.restype = C.c_int64
     L.femshell_amg_setup_stats.argtypes = [vp, dp]
     L.femshell_amg_dense_stats.argtypes = [vp, dp]
+    L.femshell_amg_partition_info.argtypes = [vp, dp]
     L.femshell_assembly_kernel.argtypes = [vp]
     for name in SYMBOLS:
         if name != "femshell_last_error" and not name.startswith("femshell_nnz") and \
@@ -323,6 +324,15 @@ class FemShell:
         _check(self._L.femshell_amg_dense_stats(self._h, _d(out)))
         return {"n": int(out[0]), "ms": out[1], "mfma_flops_issued": out[2], "useful_flops": out[3], "dropped_directions": int(out[4]),
                 "bytes": out[5]}
+
+    def amg_partition_info(self):
+        """Row-partitioned hierarchy (femshell_amg_partition_info): levels split over the ranks, bytes that shrink with the
+        rank count, bytes every rank holds in full."""
+        out = np.zeros(6)
+        _check(self._L.femshell_amg_partition_info(self._h, _d(out)))
+        return {"partitioned_levels": int(out[0]), "bytes_partitioned": out[1], "bytes_replicated": out[2],
+                "rows_on_last_partitioned_level": int(out[3]), "ghost_rows_on_last_partitioned_level": int(out[4]),
+                "nodes_of_first_replicated_level": int(out[5])}
 
     def amg_export(self, level):
         """Host copies of a level (small problems): dict with agg, A (rowptr, cols, vals), P (rowptr, cols, vals)."""

@@ -39,8 +39,29 @@ struct HostEllPattern {
     bool empty() const { return slice_base.empty(); }
 };
 
+// Ghost exchange of the vectors of a row-partitioned level (amg_dist.cpp): which of the rank's rows every neighbour reads,
+// and where the rows it reads from them land (behind the padded owned rows, peer after peer).  Level 0 copies the plan's.
+struct LevelHalo {
+    int32_t n_pad = 0, n_ghost = 0;
+    std::vector<HaloPeer> peers;
+    std::vector<int32_t> send_offsets; // per peer, in nodes
+    int32_t total_send = 0;
+    DevBuf<int32_t> send_nodes;        // peer after peer
+    DevBuf<double> sendbuf;            // total_send x the widest row sent so far
+    int sendbuf_width = 0;
+};
+
 struct AmgLevel {
-    int32_t n = 0, n_pad = 0; // nodes (6 dofs each) / padded to whole slices
+    int32_t n = 0, n_pad = 0; // nodes (6 dofs each) / padded to whole slices (row-partitioned levels: the rank's own rows)
+    // row-partitioned levels (contexts with a communicator, amg_dist.cpp): the rank holds the rows [part[rank], part[rank+1])
+    // of the level's global numbering -- aggregates are numbered rank by rank -- and the ghost nodes its blocks reach
+    bool dist = false;
+    int32_t n_ghost = 0, n_global = 0;
+    std::vector<int32_t> part;
+    std::shared_ptr<LevelHalo> halo;
+    DevBuf<double> bown;      // last row-partitioned level: the rank's rows of the restricted residual, all-gathered into the
+                              // replicated level below
+    DevBuf<double> ksums;     // three words for the all-reduce of a K-cycle coefficient step
     int64_t nnzb = 0;         // blocks of the level matrix
     AmgOperator A;            // levels >= 1 (level 0 is the context's K)
     bool A_on_device = false; // the level matrix was computed in HBM (amg_device_setup.cpp), nothing to upload
@@ -70,13 +91,9 @@ struct AmgSetupStats {
 // Level 0 of a row-partitioned context (see amg_solve.cpp): work vectors in the rank's numbering (x0, d0 with ghost
 // space: they are inputs of the halo product) and two fine-level vectors in global numbering for the transfer operators
 struct AmgDist {
-    DevBuf<double> x0, r0, d0, q0;
-    DevBuf<double> gfine;
-    // the rank's part of the shadow's level-0 transfer operators, as views of whole slices of their block ELL arrays:
-    // the rows of P of the rank's nodes; the rows of R (coarse nodes) between the lowest and the highest aggregate that
-    // the rank's nodes and their neighbours belong to -- all others get nothing from this rank's residual
-    DeviceMatrix Pown{}, Rsub{};
-    int32_t coarse_slice0 = 0;
+    DevBuf<double> x0;          // the cycle's iterate on level 0: an input of the halo product, so it carries ghost space (the CG's z does not)
+    int dist_levels = 0;        // levels 0 .. dist_levels-1 are row-partitioned, the rest is replicated on every rank
+    double hierarchy_bytes_partitioned = 0.0, hierarchy_bytes_replicated = 0.0; // HBM of the rank's operators (femshell_amg_memory)
 };
 
 // the dense inverse of a large coarsest operator, computed on the matrix cores (amg_dense.hip); n = 0: the host path ran
@@ -99,15 +116,27 @@ struct Amg {
     std::shared_ptr<AmgDist> dist; // row-partitioned contexts only
 };
 
+// K itself (level 0) is the coarsest level -- a dense inverse and nothing else -- only up to this many nodes (amg_solve.cpp)
+constexpr int32_t kDirectNodes = 200;
 void amg_default_options(femshell_pc_options *o);
 // symmetric storage of a coarse level operator of n_nodes nodes (large levels only, see amg_solve.cpp)
 bool coarse_symmetric_storage(int32_t n_nodes);
 // in-lists of a symmetric-storage operator into HBM and into op.dm (the slot arrays of op are in place already)
 int attach_in_lists(AmgOperator &op, const SlicedEllSym &S, int64_t total_slots, hipStream_t st);
 int amg_setup(femshell_ctx *c);
-// contexts with a communicator: c->amg_shadow holds the whole K and has run amg_setup; shares its hierarchy with c and
-// allocates the level-0 vectors of the rank
-int amg_attach_shadow(femshell_ctx *c);
+// contexts with a communicator (amg_dist.cpp): levels 0 .. d-1 row-partitioned like K -- aggregates never span ranks, the
+// rows of Q, P and A P of the nodes along the cuts are exchanged once so that every rank computes its rows of the Galerkin
+// operator itself -- and the first level of at most dist_min nodes all-gathered and replicated, with everything below it
+int amg_setup_dist(femshell_ctx *c);
+// the replicated part of a hierarchy from level first_level on (A: that level's operator as a host matrix, B: its near-null
+// space; empty A: the level is in HBM already with its pattern, Bdev its near-null space): coarsening steps down to the
+// coarsest level, dense inverse, Chebyshev coefficients of all levels
+int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf<double> &Bdev, int first_level);
+int alloc_level_vectors(AmgLevel &L, bool top, bool kcycle, hipStream_t st);
+// ghost entries of vec (width doubles per node, ghosts behind the n_pad owned rows) from their owners
+int level_halo_exchange(femshell_ctx *c, LevelHalo &H, double *vec, int width, hipStream_t st);
+// nodes above which a coarse level stays row-partitioned (FEMSHELL_AMG_DIST_MIN, default 60000)
+int32_t amg_dist_min();
 // z = M(r): one multigrid cycle on the context's stream (all launches are no-ops once gate->done != 0)
 int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate);
 // *true_rr_out: ||b - K x||^2 of the returned iterate when the residual replacement computed it, else -1

@@ -11,6 +11,7 @@
 // below.  A coarse operator travels back only when the next step runs on the host.  FEMSHELL_AMG_SETUP=host keeps
 // everything on the host (the path tests compare this one with).
 #include "amg_device.hpp"
+#include "amg_pattern.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -20,21 +21,10 @@
 
 namespace femshell {
 
-namespace {
-
 // rows as sorted lists -> sliced ELL pattern (32 rows per slice, `count` real entries per row, padding columns 0;
 // diag_first: the entry equal to the row index is moved to slot 0)
-struct EllPattern {
-    int32_t n_rows = 0, n_pad = 0, n_slices = 0, max_width = 0;
-    std::vector<int32_t> slice_width;
-    std::vector<int64_t> slice_base;
-    std::vector<int32_t> cols;
-    std::vector<uint8_t> count;
-    int64_t nnzb = 0;
-    int64_t total() const { return slice_base.empty() ? 0 : slice_base.back(); }
-};
-
-bool pack_pattern(int32_t n_rows, const std::vector<int64_t> &ptr, const std::vector<int32_t> &col, bool diag_first, EllPattern *out)
+bool pack_pattern(int32_t n_rows, const std::vector<int64_t> &ptr, const std::vector<int32_t> &col, bool diag_first, EllPattern *out,
+                  int32_t diag_key)
 {
     EllPattern &E = *out;
     E = EllPattern();
@@ -67,11 +57,11 @@ bool pack_pattern(int32_t n_rows, const std::vector<int64_t> &ptr, const std::ve
                 if (a >= n_rows) continue;
                 int k = 0;
                 if (diag_first) {
-                    E.cols[(size_t)(E.slice_base[s] + n)] = a;
+                    E.cols[(size_t)(E.slice_base[s] + n)] = a + diag_key;
                     k = 1;
                 }
                 for (int64_t q = ptr[a]; q < ptr[a + 1]; q++) {
-                    if (diag_first && col[q] == a) continue;
+                    if (diag_first && col[q] == a + diag_key) continue;
                     E.cols[(size_t)(E.slice_base[s] + (int64_t)k * kSliceNodes + n)] = col[q];
                     k++;
                 }
@@ -79,12 +69,6 @@ bool pack_pattern(int32_t n_rows, const std::vector<int64_t> &ptr, const std::ve
     }, 64);
     return true;
 }
-
-struct DevPattern {
-    DevBuf<int32_t> slice_width, cols;
-    DevBuf<int64_t> slice_base;
-    DevBuf<uint8_t> count;
-};
 
 int upload_pattern(const EllPattern &E, DevPattern &D, double *vals, EllView *view, hipStream_t st)
 {
@@ -166,8 +150,6 @@ int download_vals(const DevBuf<double> &d, std::vector<double, default_init_allo
     return FEMSHELL_OK;
 }
 
-} // namespace
-
 // the pattern of the context's K: the plan's slot arrays (padding slots of a row repeat the row's own index; multi-rank
 // contexts never get here -- their hierarchy is built by the shadow context)
 void pattern_of_plan(const Plan &p, HostEllPattern *out)
@@ -198,8 +180,6 @@ void pattern_of_plan(const Plan &p, HostEllPattern *out)
         H.in_rows = p.in_rows;
     }
 }
-
-namespace {
 
 // the block graph of a level operator as a pattern-only BSR with ascending columns (both directions of a symmetric one)
 void graph_of_pattern(const HostEllPattern &H, Bsr *G)
@@ -233,8 +213,6 @@ void graph_of_pattern(const HostEllPattern &H, Bsr *G)
         }
     });
 }
-
-} // namespace
 
 // One coarsening step of level 0 on the device.  In: the context's K (c->dm, block-Jacobi inverse valid), the near-null
 // space B of the fine nodes, the spectral bound lam.  Out: L.P, L.R (operators of the cycle), next.A (the coarse level

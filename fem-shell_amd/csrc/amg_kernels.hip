@@ -319,17 +319,25 @@ __global__ __launch_bounds__(256) void k_kcyc_dots(const double *__restrict__ a0
     }
 }
 
-__global__ __launch_bounds__(128) void k_kcyc_finish(int phase, int groups, const double *__restrict__ scratch, KcycScalars *ks,
-                                                     const CgScalars *gate)
+// (sums_out != nullptr: the three sums go there and no coefficient step is taken -- row-partitioned levels all-reduce them
+//  first and finish with groups = 1, stride = 1 on the reduced words)
+__global__ __launch_bounds__(128) void k_kcyc_finish(int phase, int groups, int stride, const double *__restrict__ scratch,
+                                                     KcycScalars *ks, const CgScalars *gate, double *sums_out)
 {
     __shared__ double sh[4];
     if (gate != nullptr && gate->done != 0) return;
     double s[3];
     for (int a = 0; a < 3; a++) {
-        const double part = (int)threadIdx.x < groups ? scratch[a * kKcycGroups + threadIdx.x] : 0.0;
+        const double part = (int)threadIdx.x < groups ? scratch[a * stride + threadIdx.x] : 0.0;
         s[a] = block_sum(part, sh);
     }
     if (threadIdx.x != 0) return;
+    if (sums_out != nullptr) {
+        sums_out[0] = s[0];
+        sums_out[1] = s[1];
+        sums_out[2] = phase == 1 ? 0.0 : s[2];
+        return;
+    }
     if (phase == 1) {
         const double rho1 = s[0], a1 = s[1];
         ks->rho1 = rho1;
@@ -358,7 +366,22 @@ void launch_kcyc_dots(int phase, const double *a0, const double *b0, const doubl
     if (groups > kKcycGroups) groups = kKcycGroups;
     if (groups < 1) groups = 1;
     hipLaunchKernelGGL(k_kcyc_dots, dim3(groups), dim3(256), 0, st, a0, b0, a1, b1, a2, b2, n6, scratch, gate);
-    hipLaunchKernelGGL(k_kcyc_finish, dim3(1), dim3(128), 0, st, phase, groups, scratch, ks, gate);
+    hipLaunchKernelGGL(k_kcyc_finish, dim3(1), dim3(128), 0, st, phase, groups, kKcycGroups, scratch, ks, gate, (double *)nullptr);
+}
+
+void launch_kcyc_dots_local(int phase, const double *a0, const double *b0, const double *a1, const double *b1, const double *a2,
+                            const double *b2, int64_t n6, double *scratch, double *sums, const CgScalars *gate, hipStream_t st)
+{
+    int groups = (int)((n6 + 4095) / 4096);
+    if (groups > kKcycGroups) groups = kKcycGroups;
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL(k_kcyc_dots, dim3(groups), dim3(256), 0, st, a0, b0, a1, b1, a2, b2, n6, scratch, gate);
+    hipLaunchKernelGGL(k_kcyc_finish, dim3(1), dim3(128), 0, st, phase, groups, kKcycGroups, scratch, (KcycScalars *)nullptr, gate, sums);
+}
+
+void launch_kcyc_coefficients(int phase, const double *sums, KcycScalars *ks, const CgScalars *gate, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kcyc_finish, dim3(1), dim3(128), 0, st, phase, 1, 1, sums, ks, gate, (double *)nullptr);
 }
 
 __global__ __launch_bounds__(256) void k_kcyc_r2(const double *__restrict__ rc, const double *__restrict__ v1,
@@ -684,8 +707,11 @@ __global__ __launch_bounds__(128) void k_amg_restriction(EllView P, const int64_
     ell_store(R.vals, t, out);
 }
 
+// (diag_key: the column key of row I's diagonal block is I + diag_key -- row-partitioned levels carry global coarse ids as
+//  column keys through the setup, amg_dist.cpp)
 __global__ __launch_bounds__(128) void k_amg_galerkin(EllView P, EllView AP, const int64_t *__restrict__ rptr,
-                                                      const int32_t *__restrict__ rrow, const uint8_t *__restrict__ rk, EllView Ac)
+                                                      const int32_t *__restrict__ rrow, const uint8_t *__restrict__ rk, EllView Ac,
+                                                      int diag_key)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= Ac.total) return;
@@ -707,7 +733,7 @@ __global__ __launch_bounds__(128) void k_amg_galerkin(EllView P, EllView AP, con
             blk_load_contig(AP.vals, as, ab);
             blk_mac(pb, ab, acc, true); // P_iI^T (A P)_iJ
         }
-        if (J == I) // coarse dofs without fine support (zero column of P): unit diagonal keeps the level matrix SPD
+        if (J == I + diag_key) // coarse dofs without fine support (zero column of P): unit diagonal keeps the level matrix SPD
 #pragma unroll
             for (int v = 0; v < 6; v++)
                 if (acc[7 * v] == 0.0) acc[7 * v] = 1.0;
@@ -966,12 +992,97 @@ void launch_amg_restriction(const EllView &P, const int64_t *rptr, const int32_t
 }
 
 void launch_amg_galerkin(const EllView &P, const EllView &AP, const int64_t *rptr, const int32_t *rrow, const uint8_t *rk,
-                         const EllView &Ac, hipStream_t st, bool mfma)
+                         const EllView &Ac, hipStream_t st, bool mfma, int diag_key)
 {
-    if (mfma) // one wave per coarse row (padding rows of the last slice included: they get zero blocks)
+    if (mfma && diag_key == 0) // one wave per coarse row (padding rows of the last slice included: they get zero blocks)
         hipLaunchKernelGGL(k_amg_galerkin_mfma, dim3((unsigned)(Ac.n_slices * kSliceNodes)), dim3(64), 0, st, P, AP, rptr, rrow, rk, Ac);
     else
-        hipLaunchKernelGGL(k_amg_galerkin, dim3((unsigned)((Ac.total + 127) / 128)), dim3(128), 0, st, P, AP, rptr, rrow, rk, Ac);
+        hipLaunchKernelGGL(k_amg_galerkin, dim3((unsigned)((Ac.total + 127) / 128)), dim3(128), 0, st, P, AP, rptr, rrow, rk, Ac,
+                           diag_key);
+}
+
+// ---- rows of an ELL operator on their way to another rank (amg_dist.cpp): W entries of 37 doubles per node -- the column
+// key (-1: no block) and the block, row-major
+__global__ __launch_bounds__(128) void k_pack_ell_rows(EllView M, int contig, const int32_t *__restrict__ nodes, int32_t count, int W,
+                                                       double *__restrict__ buf)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)count * W) return;
+    const int r = nodes[t / W], k = (int)(t % W);
+    double *o = buf + t * 37;
+    if (k < M.count[r]) {
+        const int64_t slot = ell_slot(M, r / kSliceNodes, k, r % kSliceNodes);
+        double b[36];
+        if (contig) blk_load_contig(M.vals, slot, b);
+        else ell_load(M.vals, slot, b, false);
+        o[0] = (double)M.cols[slot];
+#pragma unroll
+        for (int e = 0; e < 36; e++) o[1 + e] = b[e];
+    } else {
+        o[0] = -1.0;
+#pragma unroll
+        for (int e = 0; e < 36; e++) o[1 + e] = 0.0;
+    }
+}
+
+void launch_pack_ell_rows(const EllView &M, bool contig, const int32_t *nodes, int32_t count, int W, double *buf, hipStream_t st)
+{
+    const int64_t n = (int64_t)count * W;
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_pack_ell_rows, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, M, contig ? 1 : 0, nodes, count, W, buf);
+}
+
+__global__ void k_extract_keys(const double *__restrict__ buf, int64_t entries, int32_t *__restrict__ keys)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < entries) keys[t] = (int32_t)buf[t * 37];
+}
+
+void launch_extract_keys(const double *buf, int64_t entries, int32_t *keys, hipStream_t st)
+{
+    if (entries == 0) return;
+    hipLaunchKernelGGL(k_extract_keys, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st, buf, entries, keys);
+}
+
+// the received rows become the rows first_row ... of M: the host has compacted their keys into M.cols / M.count (entry k of
+// the buffer with a key >= 0 is block number [its rank among the row's valid entries]); every slot of these rows is written
+__global__ __launch_bounds__(128) void k_unpack_ell_rows(const double *__restrict__ buf, int32_t count, int W, EllView M, int contig,
+                                                         int32_t first_row)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)count * W) return;
+    const int g = (int)(t / W), k = (int)(t % W);
+    const int r = first_row + g;
+    const int sl = r / kSliceNodes, n = r % kSliceNodes;
+    if (k >= M.slice_width[sl]) return;
+    const int64_t slot = ell_slot(M, sl, k, n);
+    double b[36];
+#pragma unroll
+    for (int e = 0; e < 36; e++) b[e] = 0.0;
+    if (k < M.count[r]) {
+        // the k-th valid entry of the row in the buffer
+        int seen = 0;
+        for (int q = 0; q < W; q++) {
+            const double *e = buf + ((int64_t)g * W + q) * 37;
+            if (e[0] >= 0.0) {
+                if (seen == k) {
+#pragma unroll
+                    for (int v = 0; v < 36; v++) b[v] = e[1 + v];
+                    break;
+                }
+                seen++;
+            }
+        }
+    }
+    if (contig) blk_store_contig(M.vals, slot, b);
+    else ell_store(M.vals, slot, b);
+}
+
+void launch_unpack_ell_rows(const double *buf, int32_t count, int W, const EllView &M, bool contig, int32_t first_row, hipStream_t st)
+{
+    const int64_t n = (int64_t)count * W;
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_unpack_ell_rows, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, buf, count, W, M, contig ? 1 : 0, first_row);
 }
 
 } // namespace femshell

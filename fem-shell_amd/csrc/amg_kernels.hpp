@@ -54,6 +54,11 @@ struct KcycScalars {
 };
 void launch_kcyc_dots(int phase, const double *a0, const double *b0, const double *a1, const double *b1, const double *a2,
                       const double *b2, int64_t n6, KcycScalars *ks, double *scratch, const CgScalars *gate, hipStream_t st);
+// row-partitioned levels: the rank's three sums into sums[0..2] (no coefficient step), and -- once they are all-reduced --
+// the coefficient step from them
+void launch_kcyc_dots_local(int phase, const double *a0, const double *b0, const double *a1, const double *b1, const double *a2,
+                            const double *b2, int64_t n6, double *scratch, double *sums, const CgScalars *gate, hipStream_t st);
+void launch_kcyc_coefficients(int phase, const double *sums, KcycScalars *ks, const CgScalars *gate, hipStream_t st);
 // the two coefficient steps of a K cycle on a small level (n6 <= kKcycSmall) as one single-workgroup launch each:
 //   step 1: rho1 = c1.v1, a1 = c1.rc, t = a1 / rho1, r2 = rc - t v1
 //   step 2: w1, w2 from (c2.v1, c2.v2, c2.r2), x = w1 c1 + w2 c2
@@ -115,7 +120,15 @@ void launch_amg_restriction(const EllView &P, const int64_t *rptr, const int32_t
                             hipStream_t st);
 // Ac = P^T (A P); diagonal slot first; coarse dofs without fine support get a unit diagonal.  mfma: one wave per coarse
 // row contracts its tall-skinny panels with v_mfma_f64_16x16x4_f64; else one lane per result block on the vector ALUs
+// (diag_key: row I's diagonal block carries the column key I + diag_key; vector-ALU kernel only when it is not zero)
 void launch_amg_galerkin(const EllView &P, const EllView &AP, const int64_t *rptr, const int32_t *rrow, const uint8_t *rk,
-                         const EllView &Ac, hipStream_t st, bool mfma);
+                         const EllView &Ac, hipStream_t st, bool mfma, int diag_key = 0);
+
+// ---- row-partitioned setup (amg_dist.cpp): rows of an ELL operator travel as W entries of 37 doubles per node, the column
+// key (-1: none) in front of the row-major block.  contig: the operator keeps its blocks as 36 consecutive doubles (A P)
+void launch_pack_ell_rows(const EllView &M, bool contig, const int32_t *nodes, int32_t count, int W, double *buf, hipStream_t st);
+void launch_extract_keys(const double *buf, int64_t entries, int32_t *keys, hipStream_t st);
+// the values of `count` received rows into the rows first_row ... of M (whose cols / count the host filled from the keys)
+void launch_unpack_ell_rows(const double *buf, int32_t count, int W, const EllView &M, bool contig, int32_t first_row, hipStream_t st);
 
 } // namespace femshell

@@ -651,6 +651,7 @@ void build_in_lists(int32_t n_rows, const std::vector<int32_t> &slice_width, con
                     const int32_t a = s * kSliceNodes + n;
                     if (a >= n_rows || k >= count[a]) continue;
                     const int64_t slot = slice_base[s] + (int64_t)k * kSliceNodes + n;
+                    if (cols[(size_t)slot] >= n_pad) continue; // ghost column of a row-partitioned level: no transpose on this rank
                     f(a, cols[(size_t)slot], slot);
                 }
     };

@@ -101,9 +101,12 @@ int power_iteration(femshell_ctx *c, AmgLevel &L, const DeviceMatrix &A, int ite
     return FEMSHELL_OK;
 }
 
+} // namespace
+
+// (row-partitioned levels: every vector carries ghost space -- any of them may be the input of a halo product)
 int alloc_level_vectors(AmgLevel &L, bool top, bool kcycle, hipStream_t st)
 {
-    const size_t n6 = (size_t)L.n_pad * 6;
+    const size_t n6 = (size_t)(L.n_pad + (L.dist ? L.n_ghost : 0)) * 6;
     if (!top) {
         FS_HIP(L.b.alloc(n6));
         FS_HIP(L.x.alloc(n6));
@@ -130,11 +133,13 @@ int alloc_level_vectors(AmgLevel &L, bool top, bool kcycle, hipStream_t st)
         FS_HIP(L.ks.alloc(1));
         FS_HIP(L.ks.zero(st));
         FS_HIP(L.kscratch.alloc(3 * 128));
+        if (L.dist) {
+            FS_HIP(L.ksums.alloc(4));
+            FS_HIP(L.ksums.zero(st));
+        }
     }
     return FEMSHELL_OK;
 }
-
-} // namespace
 
 bool coarse_symmetric_storage(int32_t n_nodes)
 {
@@ -167,6 +172,50 @@ const DeviceMatrix &amg_level_matrix(const femshell_ctx *c, int l) { return l ==
 
 // Builds the hierarchy for the matrix currently in HBM.  Host: aggregation, prolongators, Galerkin products
 // (amg_setup.cpp); device: lambda_max of every level, block-Jacobi inverses of the coarse operators.
+namespace {
+
+// which levels are coarsened where, and where the hierarchy ends
+struct SetupRules {
+    femshell_pc_options opt{};
+    bool host_only = false;
+    int32_t device_min = 20000;
+    // Levels of more than device_min nodes are coarsened with the numerics on the device (amg_device_setup.cpp): their
+    // operator is in HBM already and only its pattern is needed on the host.  The coarse operator of such a step comes
+    // back as a host matrix only when the next step runs on the host (a small level, the coarsest one, the last allowed).
+    bool device_step(int l, int32_t n_nodes) const
+    {
+        return !host_only && n_nodes > std::max(device_min, opt.coarsest_nodes) && l + 2 < opt.max_levels;
+    }
+    // The hierarchy ends at the first level of at most coarsest_nodes nodes -- but K itself is only "solved" by a dense
+    // inverse when it is really small (kDirectNodes): the explicit FP64 inverse of a thin-shell K of a thousand nodes is not
+    // a positive definite operator any more (coupled flap of 2,000 triangles, 6666 dofs: one pivot dropped, the CG residual
+    // grows to 1e14), while the Galerkin operators below it are harmless (7386 dofs at 4M triangles).
+    bool is_coarsest(int l, int32_t n_nodes) const
+    {
+        const int32_t limit = l == 0 ? std::min(opt.coarsest_nodes, kDirectNodes) : opt.coarsest_nodes;
+        return n_nodes <= limit || l + 1 >= opt.max_levels;
+    }
+};
+
+SetupRules setup_rules(const femshell_pc_options &opt)
+{
+    SetupRules r;
+    r.opt = opt;
+    // the first coarsening step runs its numerics on the device unless FEMSHELL_AMG_SETUP=host (amg_device_setup.cpp)
+    r.host_only = getenv("FEMSHELL_AMG_SETUP") && std::string(getenv("FEMSHELL_AMG_SETUP")) == "host";
+    const char *dmin_env = getenv("FEMSHELL_AMG_DEVICE_MIN"); // nodes; levels at or below it are coarsened on the host
+    r.device_min = dmin_env ? (int32_t)atol(dmin_env) : (int32_t)20000;
+    return r;
+}
+
+bool setup_verbose()
+{
+    static const bool verbose = getenv("FEMSHELL_AMG_VERBOSE") && atoi(getenv("FEMSHELL_AMG_VERBOSE")) != 0;
+    return verbose;
+}
+
+} // namespace
+
 int amg_setup(femshell_ctx *c)
 {
     TraceRange trace("femshell multigrid setup");
@@ -179,15 +228,14 @@ int amg_setup(femshell_ctx *c)
     H.opt = opt;
     const Plan &pl = c->plan;
 
-    static const bool verbose = getenv("FEMSHELL_AMG_VERBOSE") && atoi(getenv("FEMSHELL_AMG_VERBOSE")) != 0;
     double tl = now_s();
     auto lap = [&](const char *what, int level) {
         const double t = now_s();
-        if (verbose) fprintf(stderr, "[femshell amg setup] level %d %-28s %.3f s\n", level, what, t - tl);
+        if (setup_verbose()) fprintf(stderr, "[femshell amg setup] level %d %-28s %.3f s\n", level, what, t - tl);
         tl = t;
     };
-    // the first coarsening step runs its numerics on the device unless FEMSHELL_AMG_SETUP=host (amg_device_setup.cpp)
-    static const bool host_only = getenv("FEMSHELL_AMG_SETUP") && std::string(getenv("FEMSHELL_AMG_SETUP")) == "host";
+    const SetupRules rules = setup_rules(opt);
+    const bool host_only = rules.host_only;
     const bool keep_host = pl.nnz_blocks <= (int64_t)2000000; // inspection exports (tests) on small problems only
     Bsr A;
     std::vector<double> B;  // near-null space of the current level on the host (levels coarsened on the host) ...
@@ -197,21 +245,13 @@ int amg_setup(femshell_ctx *c)
     std::vector<double> normals;
     if (!plain)
         node_normals(pl.n_own, pl.xyz_local.data(), pl.n_ltri(), pl.tri_local.data(), pl.n_lquad(), pl.quad_local.data(), &normals);
-    // Levels of more than device_min nodes are coarsened with the numerics on the device (amg_device_setup.cpp): their
-    // operator is in HBM already and only its pattern is needed on the host.  The coarse operator of such a step comes
-    // back as a host matrix only when the next step runs on the host (a small level, the coarsest one, the last allowed).
-    const char *dmin_env = getenv("FEMSHELL_AMG_DEVICE_MIN"); // nodes; levels at or below it are coarsened on the host
-    const int32_t device_min = dmin_env ? (int32_t)atol(dmin_env) : (int32_t)20000;
-    auto device_step = [&](int l, int32_t n_nodes) { // does level l take a device step?
-        return !host_only && n_nodes > std::max(device_min, opt.coarsest_nodes) && l + 2 < opt.max_levels;
-    };
     // (decided by amg_device_coarsen for the level it creates: it knows the coarse size only after the aggregation)
     auto want_host_matrix = [&](int next_level) {
-        return std::function<bool(int32_t)>([&, next_level](int32_t na) { return !device_step(next_level, na); });
+        return std::function<bool(int32_t)>([&, next_level](int32_t na) { return !rules.device_step(next_level, na); });
     };
     int rc = FEMSHELL_OK;
     int first_level = 0;
-    if (!host_only && pl.n_own > opt.coarsest_nodes && opt.max_levels > 1) {
+    if (!host_only && pl.n_own > opt.coarsest_nodes && opt.max_levels > 1) { // (small meshes: host algebra below)
         H.levels.emplace_back(new AmgLevel());
         AmgLevel &L0 = *H.levels.back();
         L0.n = pl.n_own;
@@ -263,6 +303,36 @@ int amg_setup(femshell_ctx *c)
     }
     normals = std::vector<double>();
 
+    rc = amg_finish_hierarchy(c, A, B, Bdev, first_level);
+    if (rc) return rc;
+    H.setup_seconds = now_s() - t0;
+    return FEMSHELL_OK;
+}
+
+// The levels from first_level on, on one rank or replicated on every rank of a row partition (amg_dist.cpp hands over the
+// all-gathered operator of the first replicated level).  A: that level's operator as a host matrix (empty: the level is in
+// HBM with its pattern and Bdev is its near-null space), B: its near-null space on the host.
+int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf<double> &Bdev, int first_level)
+{
+    hipStream_t st = c->stream;
+    Amg &H = *c->amg;
+    const femshell_pc_options opt = H.opt;
+    const bool kcycle = opt.cycle == FEMSHELL_CYCLE_K;
+    const Plan &pl = c->plan;
+    const SetupRules rules = setup_rules(opt);
+    auto device_step = [&](int l, int32_t n_nodes) { return rules.device_step(l, n_nodes); };
+    auto is_coarsest = [&](int l, int32_t n_nodes) { return rules.is_coarsest(l, n_nodes); };
+    auto want_host_matrix = [&](int next_level) {
+        return std::function<bool(int32_t)>([&, next_level](int32_t na) { return !device_step(next_level, na); });
+    };
+    const bool keep_host = pl.nnz_blocks <= (int64_t)2000000; // inspection exports (tests) on small problems only
+    double tl = now_s();
+    auto lap = [&](const char *what, int level) {
+        const double t = now_s();
+        if (setup_verbose()) fprintf(stderr, "[femshell amg setup] level %d %-28s %.3f s\n", level, what, t - tl);
+        tl = t;
+    };
+    int rc = FEMSHELL_OK;
     for (int l = first_level;; l++) {
         if ((int)H.levels.size() <= l) H.levels.emplace_back(new AmgLevel());
         AmgLevel &L = *H.levels[l];
@@ -309,7 +379,7 @@ int amg_setup(femshell_ctx *c)
         if (rc) return rc;
         lap("upload + block-Jacobi", l);
         const DeviceMatrix &Adev = amg_level_matrix(c, l);
-        const bool coarsest = L.n <= opt.coarsest_nodes || l + 1 >= opt.max_levels;
+        const bool coarsest = is_coarsest(l, L.n);
         if (coarsest) {
             std::vector<double> inv;
             if (L.n > 4096) return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: coarsest level too large for a dense inverse");
@@ -431,80 +501,16 @@ int amg_setup(femshell_ctx *c)
         }
     }
     FS_HIP(hipStreamSynchronize(st));
-    H.setup_seconds = now_s() - t0;
     H.valid = true;
     return FEMSHELL_OK;
 }
 
-// ---- multigrid on row-partitioned contexts -------------------------------------------------------------------------
-// The hierarchy is the single-rank one, held by every rank: the context's shadow (api.cpp) assembles the whole K on the
-// rank's own GPU (a millisecond) and runs amg_setup on it, so all ranks compute the same levels from the same numbers and
-// the preconditioner -- hence the iteration count -- is the one of a single-rank solve.  Level 0 is the only level that
-// is split: its smoother runs on the rank's rows of the partitioned K (halo product), the transfer operators of the
-// shadow act on fine vectors in global numbering that are zero outside the rank's rows, and one all-reduce sums the
-// restricted residuals; the coarse levels (a ninth of the rows and below) run replicated, without communication.
-// What this costs: the coarse part of the cycle is not divided by the rank count (it is what bounds the speed-up), one
-// all-reduce of a level-1 vector per cycle, and HBM for the whole K and the hierarchy on every GPU (5 GB of 288 for
-// the 4M-triangle meshes).  Aggregates across the row partition with distributed coarse operators are what would lift
-// that bound.
-int amg_attach_shadow(femshell_ctx *c)
-{
-    femshell_ctx *sh = c->amg_shadow;
-    if (!sh || !sh->amg || !sh->amg->valid) return set_err(FEMSHELL_ERR_INVALID, "multigrid setup: no hierarchy on the shadow context");
-    if (sh->amg->levels.size() < 2)
-        return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid on a row-partitioned context needs at least two levels");
-    c->amg = sh->amg; // one hierarchy, two owners
-    Amg &H = *c->amg;
-    H.dist.reset(new AmgDist());
-    AmgDist &D = *H.dist;
-    const Plan &p = c->plan;
-    hipStream_t st = c->stream;
-    const size_t n6 = (size_t)p.n_pad * 6, n6g = (size_t)(p.n_pad + p.n_ghost) * 6;
-    FS_HIP(D.x0.alloc(n6g));
-    FS_HIP(D.d0.alloc(n6g));
-    FS_HIP(D.r0.alloc(n6));
-    FS_HIP(D.q0.alloc(n6));
-    FS_HIP(D.x0.zero(st));
-    FS_HIP(D.d0.zero(st));
-    FS_HIP(D.r0.zero(st));
-    FS_HIP(D.q0.zero(st));
-    const size_t g6 = (size_t)H.levels[0]->n_pad * 6; // a fine vector in global numbering
-    FS_HIP(D.gfine.alloc(g6));
-    FS_HIP(D.gfine.zero(st)); // stays zero outside the rank's rows
-    FS_HIP(hipStreamSynchronize(st));
-    // the rank's views of the transfer operators (whole slices; row ranges of the partition are slice-aligned)
-    AmgLevel &L0 = *H.levels[0], &L1 = *H.levels[1];
-    if (p.row_begin % kSliceNodes != 0 || (int64_t)L0.agg.size() != (int64_t)L0.n)
-        return set_err(FEMSHELL_ERR_INVALID, "multigrid setup: the shadow hierarchy does not match the row partition");
-    const int32_t s0 = p.row_begin / kSliceNodes;
-    D.Pown = L0.P.dm;
-    D.Pown.slice_width = L0.P.dm.slice_width + s0;
-    D.Pown.slice_base = L0.P.dm.slice_base + s0;
-    D.Pown.n_slices = p.n_slices;
-    D.Pown.n_own = p.n_own;
-    D.Pown.n_pad = p.n_pad;
-    int32_t lo = L1.n, hi = -1;
-    auto see = [&](int32_t node) {
-        const int32_t I = L0.agg[(size_t)node];
-        lo = std::min(lo, I);
-        hi = std::max(hi, I);
-    };
-    for (int32_t a = p.row_begin; a < p.row_end; a++) see(a);
-    for (int32_t g : p.ghost_global) see(g);
-    if (hi < lo) {
-        lo = 0;
-        hi = 0;
-    }
-    const int32_t c0 = lo / kSliceNodes, c1 = hi / kSliceNodes + 1;
-    D.coarse_slice0 = c0;
-    D.Rsub = L0.R.dm;
-    D.Rsub.slice_width = L0.R.dm.slice_width + c0;
-    D.Rsub.slice_base = L0.R.dm.slice_base + c0;
-    D.Rsub.n_slices = c1 - c0;
-    D.Rsub.n_own = D.Rsub.n_pad = (c1 - c0) * kSliceNodes;
-    return FEMSHELL_OK;
-}
-
+// ---- the cycle -------------------------------------------------------------------------------------------------------
+// One code path for single-rank contexts and for row-partitioned ones (amg_dist.cpp).  On a row-partitioned level every
+// operator product is preceded by a halo exchange of its input (level 0: beside the interior slices, cg_driver.cpp), a
+// restriction by one of the residual and a prolongation by one of the coarse correction (P was smoothed across the cuts);
+// the K cycle's dot products are all-reduced; below the last row-partitioned level the rank's rows of the restricted
+// residual are all-gathered and the replicated levels run as on one rank.
 namespace {
 
 // FEMSHELL_AMG_FUSED_CHEB=0: product and Chebyshev step of the full-storage levels as two launches (A/B runs)
@@ -519,20 +525,60 @@ struct Cycle {
     Amg &H;
     const CgScalars *gate;
     hipStream_t st;
+    int rc = FEMSHELL_OK;
+
+    bool dist(int l) const { return H.levels[(size_t)l]->dist; }
+    void halo(int l, double *x)
+    {
+        if (rc || !dist(l)) return;
+        rc = level_halo_exchange(c, *H.levels[(size_t)l]->halo, x, 6, st);
+    }
+    // y = K x on level 0 of a row-partitioned context: the halo exchange beside the interior slices (symmetric storage with
+    // defer: the direct part only, the consumer collects the transposed products)
+    void product0(double *x, double *y, bool defer)
+    {
+        if (rc) return;
+        CgVectors vv;
+        vv.s = const_cast<CgScalars *>(gate);
+        int np = 0;
+        rc = spmv_with_halo(c, vv, x, y, nullptr, &np, defer);
+    }
+    // out = b - A_l x
+    void residual(int l, const double *b, double *x, double *out)
+    {
+        AmgLevel &L = *H.levels[(size_t)l];
+        const DeviceMatrix &A = amg_level_matrix(c, l);
+        if (l == 0 && dist(0)) {
+            if (A.symmetric) {
+                product0(x, out, true);
+                launch_sym_gather(A, out, b, -1.0, gate, st);
+            } else {
+                product0(x, L.q.p, false);
+                launch_sub(b, L.q.p, out, 6ll * A.n_pad, st);
+            }
+            return;
+        }
+        halo(l, x);
+        launch_spmv_axpy(A, x, out, b, -1.0, gate, st);
+    }
 
     void smooth(int l, const double *b, double *x, bool zero_guess)
     {
-        AmgLevel &L = *H.levels[l];
+        AmgLevel &L = *H.levels[(size_t)l];
         const DeviceMatrix &A = amg_level_matrix(c, l);
         const double *rcur = b;
         if (!zero_guess) {
-            launch_spmv_axpy(A, x, L.r.p, b, -1.0, gate, st);
+            residual(l, b, x, L.r.p);
             rcur = L.r.p;
         }
         launch_cheb_start(A, rcur, L.d.p, x, L.inv_theta, !zero_guess, gate, st);
         double *d_cur = L.d.p, *d_next = L.q.p; // full-storage levels: the direction alternates between the two vectors
         for (size_t k = 0; k < L.cheb_a.size(); k++) {
-            if (A.symmetric) { // first phase of the product; the step kernel collects the transposed products
+            if (l == 0 && dist(0)) {
+                product0(L.d.p, L.q.p, A.symmetric != 0);
+                launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, A.symmetric != 0);
+            } else if (A.symmetric) { // first phase of the product; the step kernel collects the transposed products
+                halo(l, L.d.p);
                 if (l == 0 && H.K32.p != nullptr) {
                     DeviceMatrix A32 = A;
                     A32.vals32 = H.K32.p;
@@ -542,9 +588,11 @@ struct Cycle {
                 }
                 launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, true);
             } else if (fused_cheb()) { // product and step in one launch (the small levels are bound by launch latency)
+                halo(l, d_cur);
                 launch_spmv_cheb(A, d_cur, rcur, L.r.p, d_next, x, L.cheb_a[k], L.cheb_c[k], gate, st);
                 std::swap(d_cur, d_next);
             } else {
+                halo(l, L.d.p);
                 launch_spmv(A, L.d.p, L.q.p, nullptr, gate, st);
                 launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st);
             }
@@ -555,124 +603,78 @@ struct Cycle {
     // x = M_l(b): one cycle on level l
     void cycle(int l, const double *b, double *x)
     {
-        AmgLevel &L = *H.levels[l];
+        AmgLevel &L = *H.levels[(size_t)l];
         if ((size_t)l + 1 == H.levels.size()) {
             if (H.coarse_lda > 0) launch_dense_gemv_big(H.coarse_inv.p, H.coarse_inv32.p, H.coarse_lda, b, x, 6 * L.n, 6 * L.n_pad, gate, st);
             else launch_dense_gemv(H.coarse_inv.p, b, x, 6 * L.n, 6 * L.n_pad, gate, st);
             return;
         }
-        const DeviceMatrix &A = amg_level_matrix(c, l);
-        AmgLevel &N = *H.levels[l + 1];
+        AmgLevel &N = *H.levels[(size_t)l + 1];
         smooth(l, b, x, true);
-        launch_spmv_axpy(A, x, L.r.p, b, -1.0, gate, st);       // r = b - A x
-        launch_spmv(L.R.dm, L.r.p, N.b.p, nullptr, gate, st);   // b_c = R r
+        residual(l, b, x, L.r.p); // r = b - A x
+        // b_c = R r
+        if (dist(l)) {
+            halo(l, L.r.p); // (R = P^T reaches the rows of the neighbours' nodes along the cut)
+            if (N.dist) {
+                launch_spmv(L.R.dm, L.r.p, N.b.p, nullptr, gate, st);
+            } else {
+                // the rank's rows of the restricted residual, all-gathered into the replicated level
+                launch_spmv(L.R.dm, L.r.p, L.bown.p, nullptr, gate, st);
+                std::vector<int32_t> begin(N.part.begin(), N.part.end() - 1), end(N.part.begin() + 1, N.part.end());
+                std::string e;
+                if (!rc && !comm_gather_rows(c->comm, L.bown.p, N.b.p, begin, end, st, &e)) rc = set_err(FEMSHELL_ERR_COMM, e);
+            }
+        } else {
+            launch_spmv(L.R.dm, L.r.p, N.b.p, nullptr, gate, st);
+        }
         const bool next_is_coarsest = (size_t)l + 2 == H.levels.size();
         if (H.opt.cycle == FEMSHELL_CYCLE_K && !next_is_coarsest) kcycle(l + 1);
         else cycle(l + 1, N.b.p, N.x.p);
-        launch_spmv_axpy(L.P.dm, N.x.p, x, x, 1.0, gate, st);   // x += P x_c
+        if (N.dist) halo(l + 1, N.x.p);
+        launch_spmv_axpy(L.P.dm, N.x.p, x, x, 1.0, gate, st); // x += P x_c
         smooth(l, b, x, false);
     }
 
     // two steps of flexible CG on A_l x = b_l preconditioned by the cycle (Notay & Vassilevski's K cycle)
     void kcycle(int l)
     {
-        AmgLevel &L = *H.levels[l];
+        AmgLevel &L = *H.levels[(size_t)l];
         const DeviceMatrix &A = amg_level_matrix(c, l);
         const int64_t n6 = 6ll * L.n_pad;
-        const bool small = n6 <= kKcycSmall; // coefficient steps as single launches (amg_kernels.hpp)
+        const bool small = n6 <= kKcycSmall && !L.dist; // coefficient steps as single launches (amg_kernels.hpp)
+        auto reduce = [&](int phase) { // row-partitioned level: the rank's sums are in L.ksums
+            std::string e;
+            if (!rc && !comm_allreduce_sum(c->comm, L.ksums.p, 3, st, &e)) rc = set_err(FEMSHELL_ERR_COMM, e);
+            launch_kcyc_coefficients(phase, L.ksums.p, L.ks.p, gate, st);
+        };
         cycle(l, L.b.p, L.c1.p);
+        halo(l, L.c1.p);
         launch_spmv(A, L.c1.p, L.v1.p, nullptr, gate, st);
         if (small) {
             launch_kcyc_step1_small(L.c1.p, L.v1.p, L.b.p, L.r2.p, n6, L.ks.p, gate, st);
         } else {
-            launch_kcyc_dots(1, L.c1.p, L.v1.p, L.c1.p, L.b.p, nullptr, nullptr, n6, L.ks.p, L.kscratch.p, gate, st);
+            if (L.dist) {
+                launch_kcyc_dots_local(1, L.c1.p, L.v1.p, L.c1.p, L.b.p, nullptr, nullptr, n6, L.kscratch.p, L.ksums.p, gate, st);
+                reduce(1);
+            } else {
+                launch_kcyc_dots(1, L.c1.p, L.v1.p, L.c1.p, L.b.p, nullptr, nullptr, n6, L.ks.p, L.kscratch.p, gate, st);
+            }
             launch_kcyc_r2(L.b.p, L.v1.p, L.r2.p, n6, L.ks.p, gate, st);
         }
         cycle(l, L.r2.p, L.c2.p);
+        halo(l, L.c2.p);
         launch_spmv(A, L.c2.p, L.v2.p, nullptr, gate, st);
         if (small) {
             launch_kcyc_step2_small(L.c1.p, L.c2.p, L.v1.p, L.v2.p, L.r2.p, L.x.p, n6, L.ks.p, gate, st);
         } else {
-            launch_kcyc_dots(2, L.c2.p, L.v1.p, L.c2.p, L.v2.p, L.c2.p, L.r2.p, n6, L.ks.p, L.kscratch.p, gate, st);
+            if (L.dist) {
+                launch_kcyc_dots_local(2, L.c2.p, L.v1.p, L.c2.p, L.v2.p, L.c2.p, L.r2.p, n6, L.kscratch.p, L.ksums.p, gate, st);
+                reduce(2);
+            } else {
+                launch_kcyc_dots(2, L.c2.p, L.v1.p, L.c2.p, L.v2.p, L.c2.p, L.r2.p, n6, L.ks.p, L.kscratch.p, gate, st);
+            }
             launch_kcyc_combine(L.c1.p, L.c2.p, L.x.p, n6, L.ks.p, gate, st);
         }
-    }
-};
-
-// level 0 of a row-partitioned context (amg_attach_shadow); everything below level 0 is `coarse`, the shadow's cycle
-struct DistCycle {
-    femshell_ctx *c;
-    Amg &H;
-    const CgScalars *gate;
-    hipStream_t st;
-    int rc = FEMSHELL_OK;
-
-    // y = K x, halo exchange beside the interior slices (symmetric storage: the direct part; the consumer collects the
-    // transposed products)
-    void product(double *x, double *y, bool defer)
-    {
-        if (rc) return;
-        CgVectors vv;
-        vv.s = const_cast<CgScalars *>(gate);
-        int np = 0;
-        rc = spmv_with_halo(c, vv, x, y, nullptr, &np, defer);
-    }
-    // r0 = b - K x
-    void residual(const double *b, double *x)
-    {
-        AmgDist &D = *H.dist;
-        const DeviceMatrix &A = c->dm;
-        if (A.symmetric) {
-            product(x, D.r0.p, true);
-            launch_sym_gather(A, D.r0.p, b, -1.0, gate, st);
-        } else {
-            product(x, D.q0.p, false);
-            launch_sub(b, D.q0.p, D.r0.p, 6ll * A.n_pad, st);
-        }
-    }
-    void smooth(const double *b, double *x, bool zero_guess)
-    {
-        AmgLevel &L = *H.levels[0];
-        AmgDist &D = *H.dist;
-        const DeviceMatrix &A = c->dm;
-        const double *rcur = b;
-        if (!zero_guess) {
-            residual(b, x);
-            rcur = D.r0.p;
-        }
-        launch_cheb_start(A, rcur, D.d0.p, x, L.inv_theta, !zero_guess, gate, st);
-        for (size_t k = 0; k < L.cheb_a.size(); k++) {
-            product(D.d0.p, D.q0.p, A.symmetric != 0);
-            launch_cheb_step(A, rcur, D.q0.p, D.r0.p, D.d0.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, A.symmetric != 0);
-            rcur = D.r0.p;
-        }
-    }
-    int cycle(const double *b, double *z)
-    {
-        AmgLevel &N = *H.levels[1];
-        AmgDist &D = *H.dist;
-        const Plan &p = c->plan;
-        const int64_t own6 = 6ll * p.n_own, off = 6ll * p.row_begin;
-        double *x = D.x0.p;
-        smooth(b, x, true);
-        residual(b, x);
-        // restriction: the rank's rows of the residual in a global fine vector, the coarse rows of the shadow's R that
-        // these rows reach, sum over the ranks
-        launch_copy(D.r0.p, D.gfine.p + off, own6, gate, st);
-        if (hipMemsetAsync(N.b.p, 0, N.b.n * sizeof(double), st) != hipSuccess) return set_err(FEMSHELL_ERR_HIP, "hipMemsetAsync");
-        launch_spmv(D.Rsub, D.gfine.p, N.b.p + 6ll * kSliceNodes * D.coarse_slice0, nullptr, gate, st);
-        if (rc) return rc;
-        std::string e;
-        if (!comm_allreduce_sum(c->comm, N.b.p, (int)(6ll * N.n_pad), st, &e)) return set_err(FEMSHELL_ERR_COMM, e);
-        Cycle coarse{c->amg_shadow, H, gate, st};
-        const bool next_is_coarsest = H.levels.size() == 2;
-        if (H.opt.cycle == FEMSHELL_CYCLE_K && !next_is_coarsest) coarse.kcycle(1);
-        else coarse.cycle(1, N.b.p, N.x.p);
-        // prolongation: the rank's rows of the shadow's P
-        launch_spmv_axpy(D.Pown, N.x.p, x, x, 1.0, gate, st);
-        smooth(b, x, false);
-        launch_copy(x, z, 6ll * p.n_pad, gate, st);
-        return rc;
     }
 };
 
@@ -695,15 +697,16 @@ struct AmgPoll {
 
 int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate)
 {
-    if (c->amg->dist) {
-        DistCycle dc{c, *c->amg, gate, c->stream};
-        const int rc = dc.cycle(r, z);
-        if (rc) return rc;
-        FS_HIP(hipGetLastError());
-        return FEMSHELL_OK;
-    }
     Cycle cy{c, *c->amg, gate, c->stream};
-    cy.cycle(0, r, z);
+    if (c->amg->dist) {
+        // the iterate of level 0 is an input of the halo product: it needs ghost space, which the CG's z does not have
+        double *x = c->amg->dist->x0.p;
+        cy.cycle(0, r, x);
+        launch_copy(x, z, 6ll * c->plan.n_pad, gate, c->stream);
+    } else {
+        cy.cycle(0, r, z);
+    }
+    if (cy.rc) return cy.rc;
     FS_HIP(hipGetLastError());
     return FEMSHELL_OK;
 }

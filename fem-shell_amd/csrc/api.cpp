@@ -262,56 +262,6 @@ double wall_s()
     return duration<double>(steady_clock::now().time_since_epoch()).count();
 }
 
-// Multigrid on a context with a communicator (amg_solve.cpp, "multigrid on row-partitioned contexts"): a single-rank
-// context on the same device gets the whole mesh and the Dirichlet set, assembles K, and builds the hierarchy this
-// context then shares.
-int amg_setup_through_shadow(femshell_ctx *c)
-{
-    if (c->mesh_xyz.empty()) return set_err(FEMSHELL_ERR_INVALID, "multigrid setup: the context holds no copy of the mesh");
-    const int32_t nn = (int32_t)(c->mesh_xyz.size() / 3);
-    femshell_ctx *sh = c->amg_shadow; // kept while the mesh stays (femshell_set_mesh drops it): only K is assembled again
-    int rc = FEMSHELL_OK;
-    if (!sh) {
-        // the whole K, its plan and the hierarchy on this GPU: 1.3 KB per triangle measured on the 4M-triangle meshes
-        // (5.2 GB); a mesh that was partitioned because it does not fit one GPU cannot take this path
-        size_t free_b = 0, total_b = 0;
-        FS_HIP(hipMemGetInfo(&free_b, &total_b));
-        const double need = 1.6e3 * ((double)c->mesh_tri.size() / 3.0 + 1.4 * (double)c->mesh_quad.size() / 4.0);
-        if (need > (double)free_b) {
-            char buf[256];
-            snprintf(buf, sizeof buf, "multigrid on a row-partitioned context keeps the whole K and its hierarchy on every GPU: about %.1f GB "
-                     "for this mesh, %.1f GB free on device %d; use -pc_type bjacobi or fewer, larger partitions", need / 1e9, (double)free_b / 1e9, c->device);
-            return set_err(FEMSHELL_ERR_UNSUPPORTED, buf);
-        }
-        femshell_config cfg = c->cfg;
-        cfg.rank = 0;
-        cfg.world_size = 1;
-        cfg.device = c->device;
-        cfg.flags &= ~(uint32_t)(FEMSHELL_REORDER_MORTON | FEMSHELL_REORDER_RCM); // the copy of the mesh is in internal numbering
-        rc = femshell_create(&cfg, &sh);
-        if (rc) return rc;
-        c->amg_shadow = sh;
-        sh->cfg.flags = cfg.flags; // (femshell_create reads FEMSHELL_REORDER from the environment)
-        rc = femshell_set_mesh(sh, nn, c->mesh_xyz.data(), (int32_t)(c->mesh_tri.size() / 3), c->mesh_tri.data(),
-                               (int32_t)(c->mesh_quad.size() / 4), c->mesh_quad.data());
-        if (rc) return rc;
-    }
-    sh->mc = c->mc;
-    sh->amg.reset();
-    rc = femshell_set_dirichlet(sh, nn, nullptr, c->dmask_global.data());
-    if (!rc) rc = do_assemble(sh);
-    if (!rc) rc = do_jacobi(sh);
-    if (rc) return rc;
-    sh->pc = c->pc;
-    // the distributed cycle smooths level 0 on the ranks' rows and needs a level below it: a mesh that is small enough to
-    // be its own coarsest level is coarsened once all the same
-    if (nn <= sh->pc.coarsest_nodes) sh->pc.coarsest_nodes = std::max(1, nn / 4);
-    rc = amg_setup(sh);
-    if (rc) return rc;
-    FS_HIP(hipStreamSynchronize(sh->stream));
-    return amg_attach_shadow(c);
-}
-
 } // namespace
 
 namespace femshell {
@@ -481,8 +431,6 @@ int femshell_destroy(femshell_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->amg.reset();
-    if (c->amg_shadow) (void)femshell_destroy(c->amg_shadow);
-    c->amg_shadow = nullptr;
     comm_destroy(c->comm);
     if (c->halo_stream) (void)hipStreamSynchronize(c->halo_stream);
     if (c->ev_p_ready) (void)hipEventDestroy(c->ev_p_ready);
@@ -580,10 +528,6 @@ static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double 
     if (!build_plan(n_nodes, xyz, n_tri, tri, n_quad, quad, c->cfg.rank, c->cfg.world_size, &c->plan, &e, default_symmetric_storage(),
                     /* geometric orientation of the symmetric storage when the library chose the numbering: */ !c->perm.empty()))
         return set_err(FEMSHELL_ERR_MESH, "femshell_set_mesh: " + e);
-    if (c->amg_shadow) { // belongs to the previous mesh
-        (void)femshell_destroy(c->amg_shadow);
-        c->amg_shadow = nullptr;
-    }
     if (c->cfg.world_size > 1 || c->comm.active()) { // the multigrid preconditioner of a row-partitioned context builds its hierarchy from the whole mesh
         c->mesh_xyz.assign(xyz, xyz + 3ll * n_nodes);
         c->mesh_tri.assign(tri, tri + 3ll * n_tri);
@@ -830,8 +774,10 @@ int femshell_amg_level(femshell_ctx *c, int32_t level, femshell_amg_level_info *
     if (level < 0 || level >= femshell_amg_levels(c)) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_level: no such level");
     const AmgLevel &L = *c->amg->levels[level];
     const bool last = level + 1 == (int32_t)c->amg->levels.size();
-    info->n_nodes = L.n;
-    info->n_coarse = last ? 0 : c->amg->levels[level + 1]->n;
+    // (row-partitioned levels: the level as a whole, not the rank's rows)
+    auto nodes_of = [](const AmgLevel &lv) { return lv.dist || lv.n_global > 0 ? lv.n_global : lv.n; };
+    info->n_nodes = nodes_of(L);
+    info->n_coarse = last ? 0 : nodes_of(*c->amg->levels[level + 1]);
     info->nnz_blocks = L.nnzb;
     info->p_blocks = last ? 0 : L.P.nnzb;
     info->lambda_max = L.lam;
@@ -850,6 +796,24 @@ int femshell_amg_setup_stats(femshell_ctx *c, double out[7])
     out[4] = S.galerkin_useful_flops;
     out[5] = S.galerkin_mfma_flops_issued;
     out[6] = (double)S.galerkin_mfma;
+    return FEMSHELL_OK;
+}
+
+int femshell_amg_partition_info(femshell_ctx *c, double out[6])
+{
+    if (!c || !out) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_partition_info: null argument");
+    if (!c->amg || !c->amg->valid) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_partition_info: no multigrid hierarchy");
+    const Amg &H = *c->amg;
+    for (int i = 0; i < 6; i++) out[i] = 0.0;
+    if (H.dist) {
+        out[0] = (double)H.dist->dist_levels;
+        out[1] = H.dist->hierarchy_bytes_partitioned;
+        out[2] = H.dist->hierarchy_bytes_replicated;
+        const AmgLevel &last = *H.levels[(size_t)H.dist->dist_levels - 1];
+        out[3] = (double)last.n;        // the rank's rows of the last row-partitioned level
+        out[4] = (double)last.n_ghost;  // ... and the ghost rows it reads
+        out[5] = (double)H.levels[(size_t)H.dist->dist_levels]->n; // nodes of the first replicated level
+    }
     return FEMSHELL_OK;
 }
 
@@ -927,7 +891,8 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
     if (use_amg && (!c->amg || !c->amg->valid)) {
         if (c->comm.active()) {
             const double t0 = wall_s();
-            rc = agree_status(c, amg_setup_through_shadow(c), "multigrid setup", true);
+            // row-partitioned hierarchy (amg_dist.cpp); a failure only one rank sees must reach the others
+            rc = agree_status(c, amg_setup_dist(c), "multigrid setup", true);
             if (rc) {
                 c->amg.reset();
                 return rc;

@@ -11,7 +11,7 @@ namespace femshell {
 
 int halo_exchange(femshell_ctx *c, double *p, hipStream_t st)
 {
-    if (!c->comm.active() || c->plan.peers.empty()) return FEMSHELL_OK;
+    if (!c->comm.active() || c->comm.world == 1) return FEMSHELL_OK; // (a rank without neighbours still joins the group)
     TraceRange trace("femshell halo exchange");
     const Plan &pl = c->plan;
     for (size_t i = 0; i < pl.peers.size(); i++)

@@ -125,18 +125,19 @@ bool comm_allreduce_sum(Comm &c, double *buf, int count, hipStream_t st, std::st
 }
 
 bool comm_halo(Comm &c, const std::vector<HaloPeer> &peers, const std::vector<int32_t> &send_offsets,
-               const double *sendbuf, double *p_ghost, hipStream_t st, std::string *err)
+               const double *sendbuf, double *p_ghost, hipStream_t st, std::string *err, int width)
 {
+    const int64_t w = width;
     ncclComm_t comm = static_cast<ncclComm_t>(c.comm);
     if (!check(g_api.GroupStart(), "ncclGroupStart", err)) return false;
     bool ok = true;
     for (size_t i = 0; i < peers.size() && ok; i++) {
         const HaloPeer &h = peers[i];
         if (!h.send_nodes.empty())
-            ok = check(g_api.Send(sendbuf + 6ll * send_offsets[i], 6 * h.send_nodes.size(), ncclDouble, h.rank, comm, st),
+            ok = check(g_api.Send(sendbuf + w * send_offsets[i], (size_t)w * h.send_nodes.size(), ncclDouble, h.rank, comm, st),
                        "ncclSend", err);
         if (ok && h.recv_count > 0)
-            ok = check(g_api.Recv(p_ghost + 6ll * h.recv_offset, 6 * (size_t)h.recv_count, ncclDouble, h.rank, comm, st),
+            ok = check(g_api.Recv(p_ghost + w * h.recv_offset, (size_t)w * (size_t)h.recv_count, ncclDouble, h.rank, comm, st),
                        "ncclRecv", err);
     }
     const bool ended = check(g_api.GroupEnd(), "ncclGroupEnd", ok ? err : nullptr);
@@ -154,6 +155,22 @@ bool comm_gather_rows(Comm &c, const double *x_owned, double *full, const std::v
         if (cnt == 0) continue;
         double *dst = full + 6ll * row_begin[r];
         ok = check(g_api.Broadcast(r == c.rank ? x_owned : dst, dst, cnt, ncclDouble, r, comm, st), "ncclBroadcast", err);
+    }
+    const bool ended = check(g_api.GroupEnd(), "ncclGroupEnd", ok ? err : nullptr);
+    return ok && ended;
+}
+
+bool comm_gather_pieces(Comm &c, const double *mine, double *full, const std::vector<int64_t> &begin,
+                        const std::vector<int64_t> &end, hipStream_t st, std::string *err)
+{
+    ncclComm_t comm = static_cast<ncclComm_t>(c.comm);
+    if (!check(g_api.GroupStart(), "ncclGroupStart", err)) return false;
+    bool ok = true;
+    for (int r = 0; r < c.world && ok; r++) {
+        const size_t cnt = (size_t)(end[r] - begin[r]);
+        if (cnt == 0) continue;
+        double *dst = full + begin[r];
+        ok = check(g_api.Broadcast(r == c.rank ? mine : dst, dst, cnt, ncclDouble, r, comm, st), "ncclBroadcast", err);
     }
     const bool ended = check(g_api.GroupEnd(), "ncclGroupEnd", ok ? err : nullptr);
     return ok && ended;

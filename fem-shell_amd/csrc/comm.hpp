@@ -37,11 +37,15 @@ bool comm_allreduce_sum(Comm &c, double *buf, int count, hipStream_t st, std::st
 
 // one grouped send/recv per peer: sendbuf holds the packed owned entries peer after peer
 // (send_offsets in nodes), ghosts of `p` start at p + 6*n_pad
+// (width: doubles per node)
 bool comm_halo(Comm &c, const std::vector<HaloPeer> &peers, const std::vector<int32_t> &send_offsets,
-               const double *sendbuf, double *p_ghost, hipStream_t st, std::string *err);
+               const double *sendbuf, double *p_ghost, hipStream_t st, std::string *err, int width = 6);
 
 // all ranks receive every rank's owned rows: full[6*row_begin(r) ...] <- rank r's x
 bool comm_gather_rows(Comm &c, const double *x_owned, double *full, const std::vector<int32_t> &row_begin,
                       const std::vector<int32_t> &row_end, hipStream_t st, std::string *err);
+// the same for pieces of any length: full[begin[r] .. end[r]) <- rank r's `mine` (doubles)
+bool comm_gather_pieces(Comm &c, const double *mine, double *full, const std::vector<int64_t> &begin,
+                        const std::vector<int64_t> &end, hipStream_t st, std::string *err);
 
 } // namespace femshell

@@ -115,12 +115,10 @@ struct femshell_ctx {
 
     femshell_pc_options pc{};           // preconditioner of femshell_solve (block-Jacobi unless set otherwise)
     std::shared_ptr<femshell::Amg> amg; // hierarchy of the multigrid preconditioner, rebuilt when K changes
-    // contexts with a communicator: the mesh as it was handed over (internal numbering), and a single-rank context on
-    // the same device that assembles the whole K and owns the hierarchy all ranks hold a copy of (amg_solve.cpp,
-    // "multigrid on row-partitioned contexts")
+    // contexts with a communicator: the mesh as it was handed over (internal numbering; the row-partitioned multigrid
+    // takes the centre of the rigid-body modes from it, amg_dist.cpp)
     std::vector<double> mesh_xyz;
     std::vector<int32_t> mesh_tri, mesh_quad;
-    femshell_ctx *amg_shadow = nullptr;
 
     // error estimate of the last multigrid-preconditioned solve (femshell_solve_info, cg_amg)
     struct RefineStats {

@@ -1274,18 +1274,18 @@ void launch_cg_scalar(const DeviceMatrix &m, const CgVectors &v, bool reduce, in
                        gate_phase < 0 ? (int)phase : gate_phase);
 }
 
-__global__ void k_pack(const double *p, const int32_t *nodes, int32_t count, double *buf)
+__global__ void k_pack(const double *p, const int32_t *nodes, int32_t count, int32_t width, double *buf)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)count * 6) return;
-    buf[i] = p[(int64_t)nodes[i / 6] * 6 + i % 6];
+    if (i >= (int64_t)count * width) return;
+    buf[i] = p[(int64_t)nodes[i / width] * width + i % width];
 }
 
-void launch_pack(const double *p, const int32_t *send_nodes, int32_t count, double *sendbuf, hipStream_t st)
+void launch_pack(const double *p, const int32_t *send_nodes, int32_t count, double *sendbuf, hipStream_t st, int width)
 {
-    const int64_t n = (int64_t)count * 6;
+    const int64_t n = (int64_t)count * width;
     if (n == 0) return;
-    hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, send_nodes, count, sendbuf);
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, send_nodes, count, (int32_t)width, sendbuf);
 }
 
 } // namespace femshell

@@ -194,7 +194,8 @@ void launch_cgcg_init(const DeviceMatrix &m, const CgVectors &v, hipStream_t st)
 // rows add the transposed products of their in-lists
 void launch_cgcg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st, int step = -1, bool gather = false);
 
-// halo: gather owned entries of p into a contiguous send buffer
-void launch_pack(const double *p, const int32_t *send_nodes, int32_t count, double *sendbuf, hipStream_t st);
+// halo: gather owned entries of p into a contiguous send buffer (width doubles per node: 6 for the vectors of the solve;
+// the multigrid setup of row-partitioned contexts sends rows of 1, 36 and more doubles the same way)
+void launch_pack(const double *p, const int32_t *send_nodes, int32_t count, double *sendbuf, hipStream_t st, int width = 6);
 
 } // namespace femshell

@@ -206,6 +206,12 @@ int femshell_amg_setup_stats(femshell_ctx *ctx, double out[7]);
  * out[2] = flops issued on the matrix cores, out[3] = n^3 (the flops of a symmetric inversion), out[4] = dropped
  * (semi-definite) directions, out[5] = bytes of the lower triangle read and written over all steps */
 int femshell_amg_dense_stats(femshell_ctx *ctx, double out[6]);
+/* Multigrid hierarchy of a row-partitioned context (the reference's PETSc preconditioner lives on the distributed matrix,
+ * doc/implementation.tex:463-472): out[0] = levels whose rows are split over the ranks (0: single-rank context), out[1] =
+ * bytes of this rank's operators on those levels (they shrink with the rank count), out[2] = bytes of the levels below,
+ * which every rank holds in full (dense inverse included), out[3] / out[4] = this rank's rows / ghost rows on the last
+ * row-partitioned level, out[5] = nodes of the first replicated level. */
+int femshell_amg_partition_info(femshell_ctx *ctx, double out[6]);
 /* which assembly kernel femshell_assemble launches for the mesh of this context (after femshell_set_mesh): 1 = the
  * pipelined one (k_assemble_pipe: meshes whose slices touch at most 150 elements -- 77 with quadrilaterals -- and whose
  * work items fit one round of its waves: structured meshes, unstructured ones numbered with locality), 0 = the two-phase

@@ -179,12 +179,39 @@ def bd_matrix(Dinv):
     return sp.bsr_matrix((Dinv, np.arange(n, dtype=np.int32), np.arange(n + 1, dtype=np.int32)), shape=(6 * n, 6 * n))
 
 
-def coarsen(A, B, lam):
-    """One coarsening step with the upper spectral bound lam of D^-1 A: returns (agg, P, Ac, Bc)."""
+def aggregate_by_rank(rowptr, colidx, bounds):
+    """Aggregation of a level whose rows are split over ranks (csrc/amg_dist.cpp): every rank aggregates the graph of its
+    own rows without the edges that leave it -- aggregates never span ranks -- and the aggregates are numbered rank by
+    rank.  bounds: the world + 1 row boundaries.  Returns (agg, n_aggregates, coarse bounds)."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    colidx = np.asarray(colidx, dtype=np.int64)
+    n = len(rowptr) - 1
+    agg = np.empty(n, dtype=np.int64)
+    cb = [0]
+    for r in range(len(bounds) - 1):
+        b0, b1 = int(bounds[r]), int(bounds[r + 1])
+        ci = colidx[rowptr[b0]:rowptr[b1]]
+        rows = np.repeat(np.arange(b0, b1), np.diff(rowptr[b0:b1 + 1]))
+        keep = (ci >= b0) & (ci < b1)
+        lp = np.concatenate([[0], np.cumsum(np.bincount(rows[keep] - b0, minlength=b1 - b0))])
+        a, na = aggregate(lp, ci[keep] - b0) if b1 > b0 else (np.zeros(0, dtype=np.int64), 0)
+        agg[b0:b1] = a + cb[-1]
+        cb.append(cb[-1] + na)
+    return agg, cb[-1], cb
+
+
+def coarsen(A, B, lam, bounds=None):
+    """One coarsening step with the upper spectral bound lam of D^-1 A: returns (agg, P, Ac, Bc), and the coarse row
+    boundaries as a fifth item when the level is split over ranks (bounds: its row boundaries).  Only the aggregation knows
+    about the ranks: tentative prolongator, smoothing with the whole A and the Galerkin product are the single-rank ones (the
+    library exchanges the rows of Q, P and A P of the nodes along the cuts to that end)."""
     A = A.tobsr((6, 6))
     A.sort_indices()
     n = A.shape[0] // 6
-    agg, na = aggregate(A.indptr, A.indices)
+    if bounds is not None:
+        agg, na, cbounds = aggregate_by_rank(A.indptr, A.indices, bounds)
+    else:
+        agg, na = aggregate(A.indptr, A.indices)
     Q, Bc = tentative(agg, na, B)
     P0 = sp.bsr_matrix((Q, agg.astype(np.int32), np.arange(n + 1, dtype=np.int32)), shape=(6 * n, 6 * na))
     Dm = bd_matrix(block_diag_inverse(A))
@@ -195,6 +222,8 @@ def coarsen(A, B, lam):
     if np.any(d == 0.0):
         fix = sp.diags((d == 0.0).astype(np.float64))
         Ac = (Ac + fix).tobsr((6, 6))
+    if bounds is not None:
+        return agg, P, Ac, Bc, cbounds
     return agg, P, Ac, Bc
 
 
@@ -215,10 +244,18 @@ class Level:
     pass
 
 
+def partition_bounds_equal(n, world):
+    """Row boundaries of `world` ranks in whole slices of 32 nodes (csrc/plan.cpp partition_rows: the split of a regular grid)."""
+    slices = (n + 31) // 32
+    return [min(n, 32 * (slices * k // world)) for k in range(world + 1)]
+
+
 def setup(A, xyz, dmask, lams=None, coarsest_nodes=200, max_levels=12, eig_ratio=30.0, degree=3, coarse_degree=4,
-          tri=None, quad=None):
+          tri=None, quad=None, bounds=None, dist_min=60000):
     """lams: upper bounds of the spectrum per level as the library reports them (femshell_amg_level); computed
-    here (1.1 x power iteration) when None.  tri / quad: connectivity for the node normals of rigid_body_modes."""
+    here (1.1 x power iteration) when None.  tri / quad: connectivity for the node normals of rigid_body_modes.
+    bounds: row boundaries of a row-partitioned context (world + 1 entries): level 0, and every coarser level of more than
+    dist_min nodes, is aggregated rank by rank; level 0 is then coarsened whatever its size."""
     levels = []
     normals = node_normals(xyz, tri, quad) if (tri is not None or quad is not None) else None
     B = rigid_body_modes(xyz, dmask, normals)
@@ -230,11 +267,19 @@ def setup(A, xyz, dmask, lams=None, coarsest_nodes=200, max_levels=12, eig_ratio
         L.Dm = bd_matrix(block_diag_inverse(A))
         levels.append(L)
         li = len(levels) - 1
-        if L.n <= coarsest_nodes or len(levels) >= max_levels:
+        split = bounds is not None and (li == 0 or L.n > dist_min)
+        L.bounds = list(bounds) if split else None
+        # (K itself is the coarsest level only up to 200 nodes: csrc/amg_device.hpp kDirectNodes)
+        limit = min(coarsest_nodes, 200) if li == 0 else coarsest_nodes
+        if (L.n <= limit and not (split and li == 0)) or len(levels) >= max_levels:
             L.dense_inv = np.linalg.inv(A.toarray())
             break
         L.lam = lams[li] if lams is not None else 1.1 * lambda_max(A, L.Dm)
-        L.agg, L.P, Ac, B = coarsen(A, B, L.lam)
+        if split:
+            L.agg, L.P, Ac, B, bounds = coarsen(A, B, L.lam, bounds)
+        else:
+            L.agg, L.P, Ac, B = coarsen(A, B, L.lam)
+            bounds = None
         L.R = L.P.T.tobsr((6, 6))
         deg = degree if li == 0 else coarse_degree
         lmax, lmin = L.lam, L.lam / eig_ratio

@@ -53,6 +53,7 @@ struct Op {
 };
 thread_local int g_group_depth = 0;
 thread_local std::vector<Op> g_ops;
+FakeComm *g_comm = nullptr; // the process's communicator: a group without operations still takes part in the pair walk
 
 void barrier(FakeComm *c)
 {
@@ -71,10 +72,10 @@ ncclResult_t run_ops()
 {
     // every rank issues the same NUMBER of steps: sends/recvs are matched pairwise by walking all
     // (from, to) pairs in a fixed global order; broadcasts in call order
-    if (g_ops.empty()) return ncclSuccess;
-    FakeComm *c = g_ops[0].comm;
-    hipStream_t st = g_ops[0].stream;
-    if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;
+    // (a rank whose lists for a coarse level's halo are empty issues an empty group while its peers issue theirs)
+    if (g_ops.empty() && g_comm == nullptr) return ncclSuccess;
+    FakeComm *c = g_ops.empty() ? g_comm : g_ops[0].comm;
+    if (!g_ops.empty() && hipStreamSynchronize(g_ops[0].stream) != hipSuccess) return ncclUnhandledCudaError;
     // broadcasts first, in call order (comm.cpp never mixes them with send/recv in one group)
     for (const Op &op : g_ops)
         if (op.kind == 2) {
@@ -151,6 +152,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
     c->sh = static_cast<Shared *>(p);
     c->slots = static_cast<char *>(p) + sizeof(Shared);
     *comm = reinterpret_cast<ncclComm_t>(c);
+    g_comm = c;
     barrier(c); // everybody has mapped the segment
     return ncclSuccess;
 }
@@ -160,6 +162,7 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
     FakeComm *c = reinterpret_cast<FakeComm *>(comm);
     if (!c) return ncclSuccess;
     if (c->rank == 0) shm_unlink(c->name.c_str());
+    if (g_comm == c) g_comm = nullptr;
     munmap(c->sh, c->bytes);
     delete c;
     return ncclSuccess;
@@ -200,7 +203,6 @@ ncclResult_t ncclGroupStart()
 ncclResult_t ncclGroupEnd()
 {
     if (--g_group_depth > 0) return ncclSuccess;
-    if (g_ops.empty()) return ncclSuccess;
     if (group_has_only_broadcasts()) {
         // run_ops handles broadcasts and would then walk the (empty) p2p pairs with barriers on every rank
     }

@@ -102,7 +102,8 @@ def setup_part(A, xyz, dmask, tri, part, variant, dist_min, coarsest_nodes):
             L.dense_inv = np.linalg.inv(A.toarray()); break
         L.lam = 1.1 * ao.lambda_max(A, L.Dm)
         if part is not None and (li == 0 or L.n > dist_min):
-            L.agg, L.P, Ac, B, part = coarsen_part(A, B, L.lam, part, variant)
+            vs = variant.split("/")
+            L.agg, L.P, Ac, B, part = coarsen_part(A, B, L.lam, part, vs[min(li, len(vs) - 1)])
             L.dist = True
         else:
             L.agg, L.P, Ac, B = ao.coarsen(A, B, L.lam); part = None
