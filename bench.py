@@ -541,8 +541,8 @@ def main():
     tts = None
     if not args.profile:
         # ---- time to solution on the same system: multigrid-preconditioned flexible CG to rtol 1e-10.  Row-partitioned
-        # runs: every rank builds the single-rank hierarchy through its shadow context; all ranks
-        # take the same path, so a failure there shows up as the same exception on every rank
+        # runs: the hierarchy is row-partitioned too (csrc/amg_dist.cpp: rank-local aggregates, levels above 60,000 nodes split
+        # over the ranks, the rest all-gathered); a failure on one rank reaches all of them as an error
         fs.set_preconditioner("amg")
         fs.sync()
         t0 = time.perf_counter()
@@ -588,10 +588,18 @@ def main():
         tts["hbm_in_use_gb_max_over_ranks"] = max_over_ranks((total_b - free_b) / 1e9)
         tts["pc_setup_seconds_max_over_ranks"] = max_over_ranks(ia["pc_setup_seconds"])
         if world > 1:
-            tts["row_partition_note"] = ("multigrid on %d ranks: every rank holds the whole K and the whole hierarchy (shadow context, "
-                                         "DESIGN section 5); level 0 is smoothed on the rank's rows, levels >= 1 run replicated: "
-                                         "time to solution does NOT scale with the rank count (bounded near 2x), elements/s and CG "
-                                         "iterations/s -- the BASELINE metric -- do" % world)
+            pi = fs.amg_partition_info()
+            tts["row_partitioned_hierarchy"] = {
+                "levels_split_over_the_ranks": pi["partitioned_levels"],
+                "operator_bytes_of_those_levels_max_over_ranks_gb": max_over_ranks(pi["bytes_partitioned"] / 1e9),
+                "operator_bytes_of_those_levels_this_rank_gb": pi["bytes_partitioned"] / 1e9,
+                "operator_bytes_replicated_on_every_rank_gb": pi["bytes_replicated"] / 1e9,
+                "rows_of_the_last_split_level_on_rank_0": pi["rows_on_last_partitioned_level"],
+                "ghost_rows_there": pi["ghost_rows_on_last_partitioned_level"],
+                "nodes_of_the_first_replicated_level": pi["nodes_of_first_replicated_level"],
+                "note": "aggregates never span ranks; rows of Q, P and A P along the cuts are exchanged once at setup; per cycle every "
+                        "product of a split level is preceded by a halo exchange, the K cycle's sums are all-reduced, the first "
+                        "replicated level's right-hand side is all-gathered (DESIGN section 6)"}
         if world == 1:
             # the Galerkin product on the matrix cores, the measured alternative to the default vector-ALU kernel: one more setup
             os.environ["FEMSHELL_AMG_GALERKIN"] = "mfma"

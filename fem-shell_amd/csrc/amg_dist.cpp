@@ -789,9 +789,10 @@ int amg_setup_dist(femshell_ctx *c)
             FS_HIP(hipStreamSynchronize(st));
             src.normals = d_normals.p;
         }
-        if (c->mesh_xyz.empty()) return set_err(FEMSHELL_ERR_INVALID, "multigrid setup: the context holds no copy of the mesh");
         double ctr[3];
-        mesh_centre((int32_t)(c->mesh_xyz.size() / 3), c->mesh_xyz.data(), ctr);
+        if (!c->mesh_xyz.empty()) mesh_centre((int32_t)(c->mesh_xyz.size() / 3), c->mesh_xyz.data(), ctr);
+        else if (c->comm.world == 1) mesh_centre(pl.n_own, pl.xyz_local.data(), ctr); // (a one-rank communicator: tests)
+        else return set_err(FEMSHELL_ERR_INVALID, "multigrid setup: the context holds no copy of the mesh");
         src.cx = ctr[0];
         src.cy = ctr[1];
         src.cz = ctr[2];

@@ -74,6 +74,19 @@ def main():
         # the rows of K and F this rank assembled (global column ids), for the comparison with the oracle's assembly
         rp, ci, vals, F = fs.export_bsr()
         extra = dict(k_rowptr=rp[:e - b + 1], k_cols=ci, k_vals=vals, k_F=F[:6 * (e - b)])
+    if os.environ.get("FEMSHELL_TEST_AMG_EXPORT") == "1":
+        # the rank's part of the multigrid hierarchy (row-partitioned levels: its rows, global column ids)
+        lv = fs.amg_levels()
+        extra["amg_n_nodes"] = np.array([l["n_nodes"] for l in lv])
+        extra["amg_lambda"] = np.array([l["lambda_max"] for l in lv])
+        pi = fs.amg_partition_info() if world > 1 else {"partitioned_levels": 0, "bytes_partitioned": 0.0, "bytes_replicated": 0.0}
+        extra["amg_partitioned_levels"] = pi["partitioned_levels"]
+        extra["amg_bytes"] = np.array([pi["bytes_partitioned"], pi["bytes_replicated"]])
+        for li in range(len(lv) - 1):
+            for name, arr in fs.amg_export(li).items():
+                if arr is not None:
+                    extra["amg_L%d_%s" % (li, name)] = arr
+        extra["residual_history"] = fs.residual_history()
     # a second solve on the same context with doubled loads (the coupled program re-solves every coupling iteration)
     fs.set_loads(2.0 * m.loads)
     u2, info2 = fs.solve(rtol=1e-11, max_it=100000)

@@ -265,8 +265,9 @@ def test_restriction_rows_wider_than_the_lds_panel():
 
 
 def test_multigrid_through_a_one_rank_rccl_communicator(monkeypatch):
-    # the row-partitioned multigrid path (shadow context, halo product in the smoother, all-reduce of the restricted
-    # residual) with the real librccl, on the one GPU a test box has: same iterations and solution as without a communicator
+    # the row-partitioned multigrid path (csrc/amg_dist.cpp: rank-local aggregation, row exchanges of the setup, halo products
+    # and all-reduced K-cycle sums in the cycle) with the real librccl, on the one GPU a test box has: one rank's aggregates
+    # are the single-rank ones, so same iterations and solution as without a communicator
     m = meshes.structured(40, 36, 0, 0, 10, 9, kind="t", ul_lr=True, bcids=(0, 0, 0, 0), factor=300.0, loading=2)
     m.xyz[:, 2] = 0.4 * np.sin(0.5 * m.xyz[:, 0]) * np.cos(0.4 * m.xyz[:, 1])
     ref = pkg.FemShell(0.3, 1e7, 0.1)
@@ -289,7 +290,7 @@ def test_multigrid_through_a_one_rank_rccl_communicator(monkeypatch):
     assert np.linalg.norm(u1 - u0) <= 1e-10 * np.linalg.norm(u0)
     u2, i2 = fs.solve(rtol=1e-11, max_it=2000)  # hierarchy reused
     assert i2["pc_setup_seconds"] == 0.0 and np.array_equal(u2, u1)
-    # K changes (another Dirichlet set): the shadow context stays, only its K and the hierarchy are built again
+    # K changes (another Dirichlet set): the hierarchy is built again
     dm2 = m.dirichlet_mask().copy()
     dm2[m.n_nodes // 2] |= 0x3F
     for ctx in (fs, ref):
