@@ -295,6 +295,36 @@ def fullsize_parity(fs, m, mat, kind):
     return out
 
 
+def config4_coupled_flap():
+    """BASELINE configs[4] at its own size on one GPU: the coupled program (FEM-shell-precice, in-process dummy fluid) on the
+    1M-triangle flap, three time steps; K against the oracle, tip series against the unit-load solution, manufactured
+    solution (tests/helpers/fullsize.py: the checks of tests/test_host_tools.py::test_coupled_flap_config5_full_size)."""
+    import tempfile
+
+    from tests.helpers import fullsize
+    host = os.path.join(ROOT, "fem-shell_amd", "host")
+    config = os.path.join(ROOT, "tests", "golden", "coupling", "inprocess_config.xml")
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            o = fullsize.coupled_flap_full_size(os.path.join(host, "FEM-shell-precice"), os.path.join(host, "meshGen"), td, config, steps=3)
+    except Exception as ex:  # noqa: BLE001 -- the headline line must still be printed
+        return {"error": str(ex)[-300:]}
+    if o.get("returncode") != 0:
+        return {"error": o.get("stderr_tail")}
+    man = o["manufactured"]["runs"][1]
+    return {"workload": "flap 0.1 x 1 in the x-z plane, 500 x 1000 squares = %d tri3, E 1e6 nu 0.3 t 0.1, dummy fluid f_x = 1 + sin(t/25.01) on "
+                        "the %d left-edge interface nodes, 3 time steps (the reference's run: 400), 1 GPU (the config's 2 GPUs: no such lease)"
+                        % (o["triangles"], o["left_edge_nodes"]),
+            "linear_solver": o["linear_solver"], "time_steps": o["time_steps"], "coupling_iterations": o["coupling_iterations"],
+            "cg_iterations": o["cg_iterations"], "solve_seconds": o["solve_seconds"], "assemblies_of_K": o["assemblies_of_K"],
+            "assembly_ms": o["assembly_ms"], "wall_seconds_program": o["wall_seconds_program"],
+            "wall_note": "mesh reading (30 MB of XDA text), symbolic phase, assembly, multigrid setup, coupling loop, process start",
+            "tip_displacements": o["tips"], "tip_series_max_rel_diff_vs_unit_load_solution": o["tip_series_max_rel_diff"],
+            "matrix_vs_oracle": o["matrix_vs_oracle"],
+            "manufactured_solution_rel_err": man["rel_err_vs_manufactured"], "manufactured_solution_iterations": man["iterations"],
+            "manufactured_solution_error_estimate": man["error_estimate"]}
+
+
 def config2_cylinder(pkg, device, steps, warmup, nx, roof):
     """BASELINE configs[2]: pinched cylinder, 4M tri3, one GPU, 'assembly HBM-GB/s vs roofline reported' -- the same
     measurements as the headline panel (timed assembly steps, k_assemble from HIP events, a short CG run), the multigrid
@@ -666,6 +696,7 @@ def main():
             if not args.no_fullsize_parity and args.workload == "panel" and args.nx == 1414:
                 out["parity"]["config3_flat_panel_4M"] = fullsize_parity(fs, m, (nu, E, thick), "panel")
                 out["config2_pinched_cylinder_4M"] = config2_cylinder(pkg, local_rank, args.steps, args.warmup, 1414, roof)
+                out["config4_coupled_flap_1M"] = config4_coupled_flap()
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.nx if args.workload == "panel" else 1414)
         print(json.dumps(out))

@@ -1,6 +1,8 @@
 // coupling.cpp -- see coupling.hpp
 #include "coupling.hpp"
 
+#include <cstdio>
+
 #ifdef FEMSHELL_HAVE_PRECICE
 // build with -DFEMSHELL_HAVE_PRECICE -lprecice: the coupled program then talks to the real coupling library (pre-1.0
 // SolverInterface API, the one the reference uses, PC:15, 50-52); -inprocess keeps the built-in stand-in
@@ -345,6 +347,20 @@ int fem_shell_precice_main(int argc, char **argv, std::ostream &out, std::ostrea
             if (mesh.xyz[3 * (size_t)n + ax[1]] > mesh.xyz[3 * (size_t)probe + ax[1]]) probe = n;
         std::ostream quiet(nullptr); // ranks other than 0 compute the same coupling steps silently
         CoupledRunLog log;
+        // per converged time step, named as the reference names them (PC:1526-1560): <out>_NNNN.e when several processes run,
+        // <out>_NNN.pvtu (+ its piece) in a serial run; rank 0 writes (every rank holds the gathered solution)
+        std::function<void(int, const std::vector<double> &)> write_step;
+        if (p.isOutfileSet && launch.rank == 0)
+            write_step = [&](int t, const std::vector<double> &sols) {
+                char tag[16];
+                if (launch.world_size > 1) {
+                    snprintf(tag, sizeof tag, "_%04d", t);
+                    write_exodus(mesh, sols, p.out_filename + tag + ".e");
+                } else {
+                    snprintf(tag, sizeof tag, "_%03d", t);
+                    write_pvtu(mesh, sols, p.out_filename + tag + ".pvtu");
+                }
+            };
 #ifdef FEMSHELL_HAVE_PRECICE
         if (!in_process) {
             // the reference's participant: a real coupling library and a real fluid solver on the other side (PC:50-52);
@@ -352,15 +368,18 @@ int fem_shell_precice_main(int argc, char **argv, std::ostream &out, std::ostrea
             precice::SolverInterface real("STRUCTURE", config, launch.rank, launch.world_size);
             out << "preCICE configured..." << std::endl;
             log = run_coupled_structure(real, system, mesh, deadAxis, deltaT, p.tol, p.max_it, probe, ax[0],
-                                        stepsv ? std::atoi(stepsv) : -1, launch.rank == 0 ? out : quiet, p.debug);
+                                        stepsv ? std::atoi(stepsv) : -1, launch.rank == 0 ? out : quiet, p.debug, write_step);
         } else
 #endif
             log = run_coupled_structure(interface, system, mesh, deadAxis, deltaT, p.tol, p.max_it, probe, ax[0],
-                                        stepsv ? std::atoi(stepsv) : -1, launch.rank == 0 ? out : quiet, p.debug);
+                                        stepsv ? std::atoi(stepsv) : -1, launch.rank == 0 ? out : quiet, p.debug, write_step);
         if (launch.rank != 0) return 0;
+        out << "Linear solver: " << (log.pc_type == FEMSHELL_PC_AMG ? "multigrid-preconditioned" : "6x6 block-Jacobi") << " CG on MI355X";
+        if (launch.world_size > 1) out << " (" << launch.world_size << " ranks)";
+        out << std::endl;
         out << "Coupled run: " << log.time_steps << " time steps, " << log.coupling_iterations << " coupling iterations, "
-            << log.cg_iterations << " CG iterations, assembly " << log.assemble_seconds << " s, solves " << log.solve_seconds
-            << " s" << std::endl;
+            << log.cg_iterations << " CG iterations, " << log.assemblies << " assemblies of K, assembly " << log.assemble_seconds
+            << " s, solves " << log.solve_seconds << " s" << std::endl;
         for (size_t i = 0; i < log.tip_displacement.size(); i++)
             out << "tip[" << i << "] node " << probe << " = " << log.tip_displacement[i] << "\n";
         if (p.isOutfileSet) {

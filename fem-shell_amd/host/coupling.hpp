@@ -133,13 +133,17 @@ struct CoupledRunLog {
     std::vector<double> tip_displacement; // per finished time step: displacement of `probe_node` along `probe_dof`
     double solve_seconds = 0.0, assemble_seconds = 0.0;
     long cg_iterations = 0;
+    int pc_type = 0;    // femshell_solve_info::pc_type of the solves
+    int assemblies = 0; // solves that assembled K (the reference: every one, PC:271; here: the first, K is constant)
 };
 
 // The coupling loop of PC:256-412 on any interface type with the SolverInterface method names.
+// (on_time_step(t, sols): called after every converged time step -- the reference's writeOutput(mesh, es, t), PC:393)
 template <class Interface>
 CoupledRunLog run_coupled_structure(Interface &interface, ShellSystem &system, const ShellMesh &mesh, char deadAxis,
                                     double deltaT, double tol, int max_it, int32_t probe_node, int probe_dof,
-                                    int max_time_steps, std::ostream &out, bool debug = false)
+                                    int max_time_steps, std::ostream &out, bool debug = false,
+                                    const std::function<void(int, const std::vector<double> &)> &on_time_step = nullptr)
 {
     CoupledStructure cs;
     cs.init(mesh, interface.getDimensions(), deadAxis);
@@ -168,6 +172,8 @@ CoupledRunLog run_coupled_structure(Interface &interface, ShellSystem &system, c
         const SolveResult res = system.solve(tol, max_it);
         log.solve_seconds += res.info.solve_seconds;
         log.assemble_seconds += res.info.assemble_seconds;
+        log.assemblies += res.info.assemble_seconds > 0.0 ? 1 : 0;
+        log.pc_type = res.info.pc_type;
         log.cg_iterations += res.iterations;
         const std::vector<double> &sols = system.build_solution_vector();
         cs.displacement_increments(sols);
@@ -181,6 +187,7 @@ CoupledRunLog run_coupled_structure(Interface &interface, ShellSystem &system, c
             interface.fulfilledAction(actionReadIterationCheckpoint());
         } else {
             out << "Advancing in time, finished timestep: " << t << std::endl;
+            if (on_time_step) on_time_step(t, sols); // write output files (if desired), PC:392-393
             t++;
             cs.accept_time_step(sols);
             log.tip_displacement.push_back(sols[6 * (size_t)probe_node + probe_dof]);

@@ -619,6 +619,52 @@ void write_vtk(const ShellMesh &m, const std::vector<double> &u, const std::stri
     }
 }
 
+// VTK XML output as libMesh's VTKIO names it (fem-shell_precice.cpp:1552-1559: <out>_NNN.pvtu per converged time step of a
+// serial run): the .pvtu index and one piece, <stem>_0.vtu, with the displaced nodes and the six nodal variables.  ASCII
+// data arrays; no VTK library here to read it back -- the tests parse the XML and compare the numbers.
+void write_pvtu(const ShellMesh &m, const std::vector<double> &u, const std::string &path)
+{
+    if (path.size() < 5 || path.substr(path.size() - 5) != ".pvtu") throw std::runtime_error("write_pvtu: the name must end in .pvtu");
+    const std::string stem = path.substr(0, path.size() - 5), piece = stem + "_0.vtu";
+    const std::string piece_name = piece.substr(piece.find_last_of('/') == std::string::npos ? 0 : piece.find_last_of('/') + 1);
+    static const char *names[6] = {"u", "v", "w", "tx", "ty", "tz"};
+    {
+        std::ofstream os(path);
+        if (!os) throw std::runtime_error("cannot write " + path);
+        os << "<?xml version=\"1.0\"?>\n<VTKFile type=\"PUnstructuredGrid\" version=\"0.1\" byte_order=\"LittleEndian\">\n"
+           << "  <PUnstructuredGrid GhostLevel=\"0\">\n    <PPointData>\n";
+        for (const char *nm : names) os << "      <PDataArray type=\"Float64\" Name=\"" << nm << "\"/>\n";
+        os << "    </PPointData>\n    <PPoints>\n      <PDataArray type=\"Float64\" NumberOfComponents=\"3\"/>\n    </PPoints>\n"
+           << "    <Piece Source=\"" << piece_name << "\"/>\n  </PUnstructuredGrid>\n</VTKFile>\n";
+    }
+    std::ofstream os(piece);
+    if (!os) throw std::runtime_error("cannot write " + piece);
+    os.precision(17);
+    const int32_t nn = m.n_nodes();
+    const long ne = m.n_tri() + m.n_quad();
+    os << "<?xml version=\"1.0\"?>\n<VTKFile type=\"UnstructuredGrid\" version=\"0.1\" byte_order=\"LittleEndian\">\n  <UnstructuredGrid>\n"
+       << "    <Piece NumberOfPoints=\"" << nn << "\" NumberOfCells=\"" << ne << "\">\n      <PointData>\n";
+    for (int v = 0; v < 6; v++) {
+        os << "        <DataArray type=\"Float64\" Name=\"" << names[v] << "\" format=\"ascii\">\n";
+        for (int32_t n = 0; n < nn; n++) os << u[6 * (size_t)n + v] << "\n";
+        os << "        </DataArray>\n";
+    }
+    os << "      </PointData>\n      <Points>\n        <DataArray type=\"Float64\" NumberOfComponents=\"3\" format=\"ascii\">\n";
+    for (int32_t n = 0; n < nn; n++)
+        os << m.xyz[3 * n] + u[6 * (size_t)n] << " " << m.xyz[3 * n + 1] + u[6 * (size_t)n + 1] << " " << m.xyz[3 * n + 2] + u[6 * (size_t)n + 2] << "\n";
+    os << "        </DataArray>\n      </Points>\n      <Cells>\n        <DataArray type=\"Int32\" Name=\"connectivity\" format=\"ascii\">\n";
+    for (long e = 0; e < ne; e++) {
+        for (int32_t v : m.element_nodes((int32_t)e)) os << v << " ";
+        os << "\n";
+    }
+    os << "        </DataArray>\n        <DataArray type=\"Int32\" Name=\"offsets\" format=\"ascii\">\n";
+    long off = 0;
+    for (long e = 0; e < ne; e++) os << (off += (long)m.element_nodes((int32_t)e).size()) << "\n";
+    os << "        </DataArray>\n        <DataArray type=\"UInt8\" Name=\"types\" format=\"ascii\">\n";
+    for (long e = 0; e < ne; e++) os << (m.element_nodes((int32_t)e).size() == 3 ? 5 : 9) << "\n";
+    os << "        </DataArray>\n      </Cells>\n    </Piece>\n  </UnstructuredGrid>\n</VTKFile>\n";
+}
+
 // ---- ExodusII output (fem-shell.cpp:1240-1251: ExodusII_IO(mesh).write_equation_systems(out + ".e", es)) ------------
 // ExodusII is a set of conventions on a netCDF file; the image has no netCDF library, but the classic netCDF format
 // (here "64-bit offset", CDF-2) is a header of dimensions, attributes and variables followed by the big-endian data, and

@@ -89,5 +89,8 @@ void write_meshgen_files(const MeshGenArgs &a, const std::string &name);
 void write_exodus(const ShellMesh &m, const std::vector<double> &u6, const std::string &path);
 // legacy-VTK dump of the same content (kept beside the ExodusII file: every viewer reads it)
 void write_vtk(const ShellMesh &m, const std::vector<double> &u6, const std::string &path);
+// <stem>.pvtu + <stem>_0.vtu: the VTK XML pair libMesh's VTKIO writes per time step of a serial coupled run
+// (fem-shell_precice.cpp:1552-1559); path must end in .pvtu
+void write_pvtu(const ShellMesh &m, const std::vector<double> &u6, const std::string &path);
 
 } // namespace femshell_host

@@ -84,3 +84,68 @@ def manufactured_solve(fs, m, kind, rtol=1e-10, passes=(1,), max_it=3000, with_r
             "refine_passes_done": info["refine_passes_done"], "refine_correction_rel": info["refine_correction_rel"],
             "refine_residual_reduction": info["refine_residual_reduction"], "error_estimate": info["error_estimate"]}
     return out
+
+
+def coupled_flap_full_size(coupled_tool, meshgen, workdir, config, steps=3, nx=500, nz=1000):
+    """BASELINE configs[4] at its own size: the flap 0.1 x 1 in the x-z plane (dead axis y), nx x nz squares = 1M tri3 at
+    500 x 1000, E = 1e6, nu = 0.3, t = 0.1 (preCICE/run_example.sh:51-53), bottom edge id 20, other edges id 2, forces
+    f_x = 1 + sin(t / 25.01) on the left-edge interface nodes (fluid_solver.cpp:192), `steps` time steps of the coupled
+    program (fem-shell_precice.cpp:256-412).  Returns what the program reported plus the checks of the same mesh through
+    the C ABI: K against the oracle's assembly, the tip series against (1 + sin(t / 25.01)) x the unit-load solution, and
+    the solver term of that solve against a manufactured solution."""
+    import importlib
+    import os
+    import re
+    import subprocess
+
+    from tests.helpers import meshes, oracle
+
+    pkg = importlib.import_module("fem-shell_amd")
+    name = os.path.join(str(workdir), "flap_full")
+    subprocess.check_call([meshgen, "t", str(nx), str(nz), "0", "0", "0.1", "1", "2,20,2,2", "1", "0", "1", "y", name])
+    t0 = time.perf_counter()
+    r = subprocess.run([coupled_tool, "-nu", "0.3", "-e", "1e6", "-t", "0.1", "-mesh", name + ".xda", "-config", config,
+                        "-dt", "0.01", "-axis", "y", "-steps", str(steps), "-fluid", "edge"], capture_output=True, text=True)
+    wall = time.perf_counter() - t0
+    out = {"returncode": r.returncode, "stderr_tail": r.stderr[-500:], "wall_seconds_program": wall, "steps": steps}
+    if r.returncode != 0:
+        return out
+    g = re.search(r"Coupled run: (\d+) time steps, (\d+) coupling iterations, (\d+) CG iterations, (\d+) assemblies of K, "
+                  r"assembly (\S+) s, solves (\S+) s", r.stdout)
+    out.update(time_steps=int(g.group(1)), coupling_iterations=int(g.group(2)), cg_iterations=int(g.group(3)),
+               assemblies_of_K=int(g.group(4)), assembly_ms=1e3 * float(g.group(5)), solve_seconds=float(g.group(6)),
+               linear_solver=re.search(r"Linear solver: ([^\n]*)", r.stdout).group(1) if "Linear solver:" in r.stdout else None)
+    tips = [float(v) for v in re.findall(r"tip\[\d+\] node \d+ = (\S+)", r.stdout)]
+    probe = int(re.search(r"tip\[0\] node (\d+)", r.stdout).group(1))
+    out["tips"] = tips
+    # the same mesh through the C ABI
+    m = meshes.read_xda(name + ".xda")
+    out["triangles"] = int(len(m.tri))
+    mat = (0.3, 1e6, 0.1)
+    left = [n for n in m.interface_nodes() if abs(m.xyz[n, 0]) < 1e-12]
+    loads = np.zeros((m.n_nodes, 6))
+    loads[left, 0] = 1.0
+    m.loads = loads
+    fs = pkg.FemShell(*mat, device=0)
+    try:
+        fs.set_mesh(m.xyz, m.tri)
+        fs.set_dirichlet(m.dirichlet_mask())
+        fs.set_loads(loads)
+        out["matrix_vs_oracle"] = matrix_parity(fs, m, mat)
+        fs.set_preconditioner("amg")
+        u_unit, info = fs.solve(rtol=1e-12, max_it=2000)
+        out["unit_load_solve"] = {"iterations": info["iterations"], "converged": info["converged"], "solve_seconds": info["solve_seconds"],
+                                  "pc_setup_seconds": info["pc_setup_seconds"], "error_estimate": info["error_estimate"]}
+        want = [(1.0 + np.sin(t / 25.01)) * u_unit[probe, 0] for t in range(steps)]
+        out["tip_series_expected"] = [float(v) for v in want]
+        out["tip_series_max_rel_diff"] = float(max(abs(a - b) / abs(b) for a, b in zip(tips, want))) if len(tips) == steps else None
+        out["left_edge_nodes"] = len(left)
+        out["manufactured"] = manufactured_solve(fs, m, "flap", rtol=1e-10, passes=(1,))
+    finally:
+        fs.close()
+    for ext in (".xda", "_f"):
+        try:
+            os.remove(name + ext)
+        except OSError:
+            pass
+    return out
