@@ -137,6 +137,10 @@ int alloc_level_vectors(AmgLevel &L, bool top, bool kcycle, hipStream_t st);
 int level_halo_exchange(femshell_ctx *c, LevelHalo &H, double *vec, int width, hipStream_t st);
 // nodes above which a coarse level stays row-partitioned (FEMSHELL_AMG_DIST_MIN, default 60000)
 int32_t amg_dist_min();
+// the smoother's upper bound of the spectrum of D^-1 A: safety factor x the estimate of a power iteration of that many steps
+// (FEMSHELL_AMG_LAMBDA_SAFETY, FEMSHELL_AMG_POWER_ITS; read per setup)
+double amg_lambda_safety();
+int amg_power_iterations();
 // z = M(r): one multigrid cycle on the context's stream (all launches are no-ops once gate->done != 0)
 int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate);
 // *true_rr_out: ||b - K x||^2 of the returned iterate when the residual replacement computed it, else -1

@@ -827,9 +827,9 @@ int amg_setup_dist(femshell_ctx *c)
         int rc = alloc_level_vectors(L, l == 0, kcycle, st);
         if (rc) return rc;
         double lam = 0.0;
-        rc = power_iteration_dist(c, L, Adev, 30, &lam);
+        rc = power_iteration_dist(c, L, Adev, amg_power_iterations(), &lam);
         if (rc) return rc;
-        L.lam = 1.1 * lam;
+        L.lam = amg_lambda_safety() * lam;
         lap("block-Jacobi, power iteration");
         H.levels.emplace_back(new AmgLevel());
         AmgLevel &N = *H.levels.back();

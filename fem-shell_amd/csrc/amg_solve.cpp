@@ -141,6 +141,20 @@ int alloc_level_vectors(AmgLevel &L, bool top, bool kcycle, hipStream_t st)
     return FEMSHELL_OK;
 }
 
+double amg_lambda_safety()
+{
+    const char *e = getenv("FEMSHELL_AMG_LAMBDA_SAFETY");
+    const double v = e ? atof(e) : 1.1;
+    return v >= 1.0 && v <= 4.0 ? v : 1.1;
+}
+
+int amg_power_iterations()
+{
+    const char *e = getenv("FEMSHELL_AMG_POWER_ITS");
+    const int v = e ? atoi(e) : 30;
+    return v >= 2 && v <= 10000 ? v : 30;
+}
+
 bool coarse_symmetric_storage(int32_t n_nodes)
 {
     // levels of at least 100,000 nodes (FEMSHELL_AMG_COARSE_SYM overrides; 1 = all levels, 0 = none) are stored like K,
@@ -260,9 +274,9 @@ int amg_setup(femshell_ctx *c)
         rc = alloc_level_vectors(L0, true, kcycle, st);
         if (rc) return rc;
         double lam = 0.0;
-        rc = power_iteration(c, L0, c->dm, 30, &lam);
+        rc = power_iteration(c, L0, c->dm, amg_power_iterations(), &lam);
         if (rc) return rc;
-        L0.lam = 1.1 * lam;
+        L0.lam = amg_lambda_safety() * lam;
         lap("power iteration", 0);
         H.levels.emplace_back(new AmgLevel());
         AmgLevel &L1 = *H.levels.back();
@@ -407,9 +421,9 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
             break;
         }
         double lam = 0.0;
-        rc = power_iteration(c, L, Adev, 30, &lam);
+        rc = power_iteration(c, L, Adev, amg_power_iterations(), &lam);
         if (rc) return rc;
-        L.lam = 1.1 * lam; // the power iteration approaches from below
+        L.lam = amg_lambda_safety() * lam; // the power iteration approaches from below
         lap("power iteration", l);
         // coarsen
         if (L.A_on_device && !L.pattern.empty() && device_step(l, L.n)) {
@@ -686,6 +700,7 @@ struct AmgPoll {
         if (it + 1 != next_check && it + 1 < max_it) return 0;
         FS_HIP(hipMemcpyAsync(hs, v.s, sizeof *hs, hipMemcpyDeviceToHost, c->stream));
         FS_HIP(hipStreamSynchronize(c->stream));
+        CommWatch::heartbeat(); // (progress: the watchdog of multi-rank contexts counts from here again)
         if (hs->done != 0) return 1;
         if (step < 4) step *= 2;
         next_check += step;

@@ -204,6 +204,7 @@ int do_assemble(femshell_ctx *c, bool wait = true)
 {
     if (!c->have_mesh) return set_err(FEMSHELL_ERR_INVALID, "femshell_assemble: no mesh set");
     TraceRange trace("femshell_assemble");
+    CommWatch watch(c->cfg.rank, c->comm.active() ? c->cfg.world_size : 1, "femshell_assemble (agreement of the ranks on the outcome)");
     int rc = select_device(c);
     if (rc) return rc;
     if (c->assembly_pending && wait) { // (async after async: one status word collects both)
@@ -464,6 +465,21 @@ int femshell_comm_init(femshell_ctx *c, const uint8_t id[128])
     if (rc) return rc;
     std::string e;
     if (!comm_init(c->comm, id, c->cfg.rank, c->cfg.world_size, &e)) return set_err(FEMSHELL_ERR_COMM, e);
+    {
+        // the first collective, under the watch: an all-reduce of one word that must come back as the rank count.  A
+        // communicator that initialises but cannot move data (a fabric or IPC problem) shows here, not in the first solve.
+        CommWatch watch(c->cfg.rank, c->cfg.world_size, "first all-reduce after ncclCommInitRank");
+        FS_HIP(c->agree.alloc(2));
+        const double one = 1.0;
+        FS_HIP(hipMemcpyAsync(c->agree.p, &one, sizeof one, hipMemcpyHostToDevice, c->stream));
+        if (!comm_allreduce_sum(c->comm, c->agree.p, 1, c->stream, &e)) return set_err(FEMSHELL_ERR_COMM, e);
+        double got = 0.0;
+        FS_HIP(hipMemcpyAsync(&got, c->agree.p, sizeof got, hipMemcpyDeviceToHost, c->stream));
+        FS_HIP(hipStreamSynchronize(c->stream));
+        if (got != (double)c->cfg.world_size)
+            return set_err(FEMSHELL_ERR_COMM, "femshell_comm_init: the first all-reduce returned " + std::to_string(got) + " instead of the rank count " +
+                                                  std::to_string(c->cfg.world_size));
+    }
     return FEMSHELL_OK;
 }
 
@@ -479,6 +495,7 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
         return set_err(FEMSHELL_ERR_INVALID, "femshell_set_mesh: null argument");
     if (c->cfg.world_size > 1 && !c->comm.active())
         return set_err(FEMSHELL_ERR_INVALID, "femshell_set_mesh: call femshell_comm_init first on a multi-rank context");
+    CommWatch watch(c->cfg.rank, c->comm.active() ? c->cfg.world_size : 1, "femshell_set_mesh (agreement of the ranks on the outcome)");
     int rc = select_device(c);
     if (rc) return rc;
     if (c->assembly_pending) {
@@ -869,6 +886,8 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
         if (prc) return prc;
     }
     TraceRange trace("femshell_solve");
+    // (the CG loops report progress at every poll of the convergence flag: CommWatch::heartbeat)
+    CommWatch watch(c->cfg.rank, c->comm.active() ? c->cfg.world_size : 1, "femshell_solve (halo exchanges and all-reduces of the solve)");
     int rc = select_device(c);
     if (rc) return rc;
     double asm_s = 0.0;

@@ -85,6 +85,7 @@ struct DonePoll {
         if (it + 1 != next_check || it + 1 >= max_it) return 0;
         FS_HIP(hipMemcpyAsync(hs, v.s, sizeof *hs, hipMemcpyDeviceToHost, c->stream));
         FS_HIP(hipStreamSynchronize(c->stream));
+        CommWatch::heartbeat(); // (progress: the watchdog of multi-rank contexts counts from here again)
         if (hs->done != 0) return 1;
         if (check_step < 64) check_step *= 2;
         next_check += check_step;

@@ -5,8 +5,14 @@
 #include <rccl/rccl.h>
 
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <thread>
+
+#include <unistd.h>
 
 namespace femshell {
 
@@ -81,6 +87,68 @@ bool check(ncclResult_t r, const char *what, std::string *err)
 
 } // namespace
 
+// ---- watchdog (comm.hpp) ---------------------------------------------------------------------------------------
+namespace {
+
+std::atomic<const char *> g_watch_phase{nullptr};
+std::atomic<int64_t> g_watch_since_ms{0};
+std::atomic<int> g_watch_rank{0}, g_watch_world{1};
+std::once_flag g_watch_once;
+
+int64_t now_ms()
+{
+    return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+double watch_timeout_s()
+{
+    const char *e = getenv("FEMSHELL_COMM_TIMEOUT"); // read per check: tests shorten it inside one process
+    return e ? atof(e) : 120.0;
+}
+
+void watch_loop()
+{
+    for (;;) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(200));
+        const char *phase = g_watch_phase.load(std::memory_order_acquire);
+        const double limit = watch_timeout_s();
+        if (phase == nullptr || !(limit > 0.0)) continue;
+        const double waited = 1e-3 * (double)(now_ms() - g_watch_since_ms.load(std::memory_order_acquire));
+        if (waited < limit) continue;
+        fprintf(stderr,
+                "[femshell watchdog] rank %d of %d: no progress for %.0f s in \"%s\" -- a peer rank never joined or stalled in a "
+                "collective.  Exiting with status 86 so that the launcher ends the rank group.  To look further: NCCL_DEBUG=WARN for "
+                "RCCL's own diagnostics, FEMSHELL_HALO_OVERLAP=0 to take the halo exchange off its second stream, "
+                "FEMSHELL_COMM_TIMEOUT=<seconds> (0 = wait forever).\n",
+                g_watch_rank.load(), g_watch_world.load(), waited, phase);
+        fflush(stderr);
+        _exit(86);
+    }
+}
+
+} // namespace
+
+CommWatch::CommWatch(int rank, int world, const char *phase) : prev_phase_(nullptr), active_(world > 1 || phase == nullptr)
+{
+    active_ = world > 1;
+    if (!active_) return;
+    std::call_once(g_watch_once, [] { std::thread(watch_loop).detach(); });
+    g_watch_rank.store(rank);
+    g_watch_world.store(world);
+    prev_phase_ = g_watch_phase.load(std::memory_order_acquire);
+    g_watch_since_ms.store(now_ms(), std::memory_order_release);
+    g_watch_phase.store(phase, std::memory_order_release);
+}
+
+CommWatch::~CommWatch()
+{
+    if (!active_) return;
+    g_watch_since_ms.store(now_ms(), std::memory_order_release); // (the outer phase starts over)
+    g_watch_phase.store(prev_phase_, std::memory_order_release);
+}
+
+void CommWatch::heartbeat() { g_watch_since_ms.store(now_ms(), std::memory_order_release); }
+
 bool comm_unique_id(uint8_t id_out[128], std::string *err)
 {
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
@@ -97,7 +165,11 @@ bool comm_init(Comm &c, const uint8_t id_bytes[128], int rank, int world, std::s
     ncclUniqueId id;
     std::memcpy(&id, id_bytes, 128);
     ncclComm_t comm = nullptr;
-    if (!check(g_api.CommInitRank(&comm, world, id, rank), "ncclCommInitRank", err)) return false;
+    {
+        // every rank must arrive: a missing one leaves the others here for good (comm.hpp: CommWatch)
+        CommWatch watch(rank, world, "ncclCommInitRank (waiting for all ranks of the row partition to join)");
+        if (!check(g_api.CommInitRank(&comm, world, id, rank), "ncclCommInitRank", err)) return false;
+    }
     c.lib = g_api.lib;
     c.comm = comm;
     c.rank = rank;

@@ -27,6 +27,24 @@ struct Comm {
     bool active() const { return comm != nullptr; }
 };
 
+// Hang protection of multi-rank contexts.  A rank that waits for a peer that never joined (ncclCommInitRank), or for a
+// collective a stalled peer never enters, waits forever -- RCCL has no timeout of its own here and a blocked call cannot be
+// cancelled.  The library's blocking phases are therefore watched: while a CommWatch is alive a monitor thread ends the
+// PROCESS (exit status 86, one line on stderr naming rank, phase and what to try) once the phase has made no progress for
+// FEMSHELL_COMM_TIMEOUT seconds (default 120; 0 switches the watch off).  A launcher that sees one rank exit tears the
+// group down; nothing is ever re-executed.  heartbeat(): progress inside a long phase (the CG loop's polls).
+struct CommWatch {
+    CommWatch(int rank, int world, const char *phase);
+    ~CommWatch();
+    CommWatch(const CommWatch &) = delete;
+    CommWatch &operator=(const CommWatch &) = delete;
+    static void heartbeat();
+
+  private:
+    const char *prev_phase_;
+    bool active_;
+};
+
 bool comm_unique_id(uint8_t id_out[128], std::string *err);
 bool comm_init(Comm &c, const uint8_t id[128], int rank, int world, std::string *err);
 void comm_destroy(Comm &c);

@@ -533,3 +533,46 @@ def test_coupled_program_on_two_ranks(tools, coupled_tool, tmp_path):
     np.testing.assert_allclose(tips3, tips1, rtol=1e-7)
     its = lambda out: int(re.search(r"(\d+) CG iterations", out).group(1))
     assert its(outs_mg[0][1]) * 3 < its(outs[0][1])
+
+
+@pytest.mark.gpu
+def test_coupled_program_writes_one_output_per_converged_time_step(tools, coupled_tool, tmp_path):
+    """fem-shell_precice.cpp:393 calls writeOutput(mesh, es, t) after every converged time step, and :1526-1560 names the
+    files: <out>_NNNN.e (ExodusII) when several processes run, <out>_NNN.pvtu (VTK XML, with its piece) in a serial run.
+    Same names and the same content here: the displaced mesh of that step and its six nodal variables."""
+    import xml.etree.ElementTree as ET
+
+    _, meshgen = tools
+    name = str(tmp_path / "flap")
+    subprocess.check_call([meshgen, "t", "6", "40", "0", "0", "0.1", "1", "2,20,2,2", "1", "0", "1", "y", name])
+    m = meshes.read_xda(name + ".xda")
+    cmd = [coupled_tool, "-nu", "0.3", "-e", "1e6", "-t", "0.1", "-mesh", name + ".xda", "-config", CONFIG, "-dt", "0.01",
+           "-axis", "y", "-steps", "3", "-fluid", "edge"]
+    serial = subprocess.run(cmd + ["-out", str(tmp_path / "ser")], capture_output=True, text=True)
+    assert serial.returncode == 0, serial.stderr
+    tips = [float(v) for v in re.findall(r"tip\[\d+\] node \d+ = (\S+)", serial.stdout)]
+    probe = int(re.search(r"tip\[0\] node (\d+)", serial.stdout).group(1))
+    for t in range(3):
+        index = tmp_path / ("ser_%03d.pvtu" % t)
+        piece = tmp_path / ("ser_%03d_0.vtu" % t)
+        assert index.exists() and piece.exists()
+        assert ET.parse(index).getroot().find(".//Piece").get("Source") == piece.name
+        root = ET.parse(piece).getroot()
+        pc = root.find(".//Piece")
+        assert int(pc.get("NumberOfPoints")) == m.n_nodes and int(pc.get("NumberOfCells")) == len(m.tri)
+        arrays = {a.get("Name"): np.array(a.text.split(), dtype=float) for a in root.iter("DataArray") if a.get("Name")}
+        assert arrays["u"][probe] == pytest.approx(tips[t], rel=1e-5)  # the step's own solution (six printed digits), not the last one
+        assert t == 0 or abs(arrays["u"][probe] - tips[t - 1]) > 1e-4 * abs(tips[t])
+        pts = np.array(root.find(".//Points/DataArray").text.split(), dtype=float).reshape(-1, 3)
+        disp = np.stack([arrays["u"], arrays["v"], arrays["w"]], axis=1)
+        np.testing.assert_allclose(pts, m.xyz + disp, rtol=0, atol=1e-12)  # displaced nodes (PC:380-390)
+        np.testing.assert_array_equal(arrays["connectivity"].reshape(-1, 3).astype(int), m.tri)
+        assert set(arrays["types"].astype(int)) == {5} and arrays["offsets"][-1] == 3 * len(m.tri)
+    assert not (tmp_path / "ser_003.pvtu").exists()
+    outs = _run_ranks(cmd + ["-out", str(tmp_path / "par")], 2, tmp_path)
+    assert [rc for rc, _, _ in outs] == [0, 0], outs
+    for t in range(3):
+        e = _read_exodus(str(tmp_path / ("par_%04d.e" % t)))
+        assert e["dims"]["num_nodes"] == m.n_nodes
+        assert e["vals_nod_var1"][0][probe] == pytest.approx(tips[t], rel=1e-7)
+    assert not (tmp_path / "par_0003.e").exists() and not (tmp_path / "par_000.pvtu").exists()
