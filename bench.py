@@ -379,7 +379,80 @@ def jacobi_extrapolation(hist, target=1e-10):
     return out
 
 
+def guarded_multi_rank_run():
+    """N > 1: the rank's work runs in a CHILD process started before anything has touched the GPU; this parent only waits.
+    A first run on real RCCL that stalls (a rank that never joins, a collective a peer never enters) then ends with a
+    message instead of a hang: the library's own watchdog (csrc/comm.hpp CommWatch, FEMSHELL_COMM_TIMEOUT, default 120 s)
+    ends the stuck child with status 86, and should even that not fire the parent kills the child's process group after
+    FEMSHELL_BENCH_TIMEOUT seconds (default 1500).  Either way rank 0's parent prints one JSON line with "error", the
+    phase, the tail of the child's stderr and of RCCL's own log (NCCL_DEBUG=WARN into a per-rank file) and every parent exits
+    non-zero, which makes the launcher end the rank group.  Nothing is re-executed in a process that has used the GPU."""
+    import collections
+    import signal
+    import subprocess
+    import tempfile
+    import threading
+
+    rank = int(os.environ.get("RANK", "0"))
+    limit = float(os.environ.get("FEMSHELL_BENCH_TIMEOUT", "1500"))
+    logdir = tempfile.mkdtemp(prefix="femshell_bench_")
+    env = dict(os.environ, FEMSHELL_BENCH_CHILD="1")
+    env.setdefault("NCCL_DEBUG", "WARN")
+    env.setdefault("NCCL_DEBUG_FILE", os.path.join(logdir, "rccl_rank%d.log" % rank))
+    child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stderr=subprocess.PIPE,
+                             start_new_session=True)
+    tail = collections.deque(maxlen=40)
+
+    def pump():
+        for raw in child.stderr:
+            line = raw.decode(errors="replace")
+            sys.stderr.write(line)
+            tail.append(line.rstrip())
+
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+
+    def end_group(*_):
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except OSError:
+            pass
+
+    signal.signal(signal.SIGTERM, lambda *_: (end_group(), sys.exit(143)))
+    why = None
+    try:
+        rc = child.wait(timeout=limit)
+        if rc != 0:
+            why = "rank %d: the bench process ended with status %d%s" % (rank, rc, " (the library's watchdog: a blocking phase made no "
+                                                                         "progress, see stderr_tail)" if rc == 86 else "")
+    except subprocess.TimeoutExpired:
+        end_group()
+        rc = 124
+        why = "rank %d: no result after %.0f s (FEMSHELL_BENCH_TIMEOUT); process group killed" % (rank, limit)
+    th.join(timeout=2.0)
+    if why is None:
+        return 0
+    rccl = []
+    try:
+        with open(env["NCCL_DEBUG_FILE"], errors="replace") as f:
+            rccl = f.read().splitlines()[-20:]
+    except OSError:
+        pass
+    phase = next((ln for ln in reversed(tail) if "[femshell watchdog]" in ln or "femshell error" in ln), None)
+    line = {"metric": "elements assembled/s + CG iters/s, 4M-tri shell, 1/2/4/8 MI355X", "value": None, "unit": "elements/s",
+            "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "error": why, "phase": phase, "stderr_tail": list(tail)[-15:],
+            "rccl_debug_tail": rccl,
+            "retry_hint": "FEMSHELL_HALO_OVERLAP=0 takes the halo send/recv group off its second stream (it shares the communicator "
+                          "with the all-reduce on the main stream, csrc/cg_driver.cpp); FEMSHELL_COMM_TIMEOUT=<s> widens the watchdog"}
+    sys.stderr.write(why + "\n")
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    return rc if rc != 0 else 1
+
+
 def main():
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("FEMSHELL_BENCH_CHILD") != "1" and "--cpu-baseline-worker" not in sys.argv:
+        sys.exit(guarded_multi_rank_run())
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)

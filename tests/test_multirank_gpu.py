@@ -233,6 +233,39 @@ def test_rank_local_failure_is_reported_by_every_rank(tmp_path, async_assembly):
     assert len(local) >= 1 and len(remote) >= 1 and len(local) + len(remote) == 3, [str(r["msg"]) for r in ranks]
 
 
+def test_a_rank_that_never_joins_ends_the_others_with_a_message(tmp_path):
+    """The first real N > 1 run must fail loudly, not hang: ncclCommInitRank waits for every rank, RCCL has no timeout of its
+    own there, and a blocked call cannot be cancelled.  The library watches its blocking phases (csrc/comm.hpp CommWatch): a
+    monitor thread ends the process with status 86 and one line naming rank and phase once nothing has moved for
+    FEMSHELL_COMM_TIMEOUT seconds.  Three ranks expected, the third never starts: the other two end within a minute."""
+    import glob
+    import time
+
+    ensure_built()
+    subprocess.check_call(["make", "-C", FAKE_DIR, "-s"])
+    env = dict(os.environ, FEMSHELL_RCCL_LIB=os.path.join(FAKE_DIR, "libfake_rccl.so"), FEMSHELL_COMM_TIMEOUT="6")
+    uid = str(tmp_path / "uid.npy")
+    before = set(glob.glob("/dev/shm/fsfake_*"))
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), "3", uid, str(tmp_path / ("out_%d.npz" % r)), "panel"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=60)
+            logs.append(out.decode(errors="replace"))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for f in set(glob.glob("/dev/shm/fsfake_*")) - before:  # (the test transport's segment: nobody reached the cleanup)
+            os.remove(f)
+    assert time.time() - t0 < 60
+    for r, p in enumerate(procs):
+        assert p.returncode == 86, (p.returncode, logs[r][-1500:])
+        assert "[femshell watchdog] rank %d of 3" % r in logs[r] and "ncclCommInitRank" in logs[r], logs[r][-1500:]
+
+
 def test_halo_overlap_and_single_stream_exchange_agree(tmp_path):
     # the halo exchange beside the interior SpMV (second stream, the default) and the single-stream
     # exchange multiply the same rows by the same numbers; only the order of the p.q partial sums differs
