@@ -518,6 +518,18 @@ __device__ __forceinline__ int64_t ell_index(int64_t slot, int i, int j)
     const int n = (int)(slot & 31);
     return (slot - n) * 36 + ((int64_t)((j >> 1) * 6 + i) * kSliceNodes + n) * 2 + (j & 1);
 }
+// (upper_only: a diagonal block of K that holds its upper triangle only -- DeviceMatrix::diag_upper)
+__device__ __forceinline__ void ell_load_sym(const double *vals, int64_t slot, double b[36])
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++) {
+            const double v = vals[ell_index(slot, i, j)];
+            b[6 * i + j] = v;
+            b[6 * j + i] = v;
+        }
+}
 __device__ __forceinline__ void ell_load(const double *vals, int64_t slot, double b[36], bool transposed)
 {
 #pragma unroll
@@ -639,7 +651,8 @@ __global__ __launch_bounds__(128) void k_amg_prolongator(DeviceMatrix A, const i
             const uint8_t target = transposed ? pmap_in[map_index] : pmap_own[map_index];
             if (target != kP) return;
             double blk[36], q[36];
-            ell_load(A.vals, slot, blk, transposed);
+            if (A.diag_upper && c == a && !transposed) ell_load_sym(A.vals, slot, blk);
+            else ell_load(A.vals, slot, blk, transposed);
 #pragma unroll
             for (int e = 0; e < 36; e++) q[e] = Q[(int64_t)c * 36 + e];
             blk_mac(blk, q, acc, false);
@@ -679,7 +692,8 @@ __global__ __launch_bounds__(128) void k_amg_ap(DeviceMatrix A, EllView P, EllVi
             const int64_t ps = ell_find(P, c, J);
             if (ps < 0) return;
             double blk[36], pb[36];
-            ell_load(A.vals, slot, blk, transposed);
+            if (A.diag_upper && c == a && !transposed) ell_load_sym(A.vals, slot, blk);
+            else ell_load(A.vals, slot, blk, transposed);
             ell_load(P.vals, ps, pb, false);
             blk_mac(blk, pb, acc, false);
         });

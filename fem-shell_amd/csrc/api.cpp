@@ -329,9 +329,12 @@ int download_matrix(femshell_ctx *c, Bsr *Aout, int32_t *col_out, double *val_ou
                 double *blk = val_out + (size_t)nb * 36;
                 const int ns = (int)(sc.slot % kSliceNodes);
                 const double *src = h.data() + (sc.slot - ns) * 36; // the (slice, k) group of 32 blocks
+                // (a diagonal block of K holds its upper triangle only: DeviceMatrix::diag_upper)
+                const bool upper_only = c->dm.diag_upper && !sc.transposed && sc.col == p.row_begin + (int32_t)a;
                 for (int i = 0; i < 6; i++)
                     for (int j = 0; j < 6; j++) {
-                        const double v = src[(((int64_t)(j / 2) * 6 + i) * kSliceNodes + ns) * 2 + (j & 1)];
+                        const int r = (upper_only && j < i) ? j : i, cl = (upper_only && j < i) ? i : j;
+                        const double v = src[(((int64_t)(cl / 2) * 6 + r) * kSliceNodes + ns) * 2 + (cl & 1)];
                         if (sc.transposed) blk[6 * j + i] = v; else blk[6 * i + j] = v;
                     }
                 nb++;
@@ -627,6 +630,8 @@ static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double 
     }
     c->dm.vals = c->vals.p;
     c->dm.symmetric = p.symmetric ? 1 : 0;
+    // the lower words of the diagonal blocks are not written (kernels.hpp); FEMSHELL_DIAG_UPPER=0: all 18 words (A/B runs)
+    c->dm.diag_upper = (p.symmetric && !(getenv("FEMSHELL_DIAG_UPPER") && atoi(getenv("FEMSHELL_DIAG_UPPER")) == 0)) ? 1 : 0;
     c->dm.max_in_width = p.max_in_width;
     c->dm.in_width = c->in_width.p;
     c->dm.in_base = c->in_base.p;

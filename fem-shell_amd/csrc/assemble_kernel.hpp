@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                             v2d vv;
                             vv.x = blk[i <= j0 ? sym6(i, j0) : sym6(j0, i)];
                             vv.y = blk[i <= j1 ? sym6(i, j1) : sym6(j1, i)];
+                            if (m.diag_upper && j1 < i) continue; // (a word below the diagonal: nobody reads it, kernels.hpp)
                             if (kAblate & 64) dst[(jp * 6 + i) * kSliceNodes] = vv;
                             else __builtin_nontemporal_store(vv, dst + (jp * 6 + i) * kSliceNodes);
                         }
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
 #pragma unroll
                         for (int i = 0; i < 6; i++) {
                             v2d vv; vv.x = blk[6 * i + 2 * jp]; vv.y = blk[6 * i + 2 * jp + 1];
+                            if (m.diag_upper && diag_slot && 2 * jp + 1 < i) continue; // (below the diagonal of a diagonal block)
                             if (kAblate & 64) dst[(jp * 6 + i) * kSliceNodes] = vv; // lab: plain instead of non-temporal stores
                             else __builtin_nontemporal_store(vv, dst + (jp * 6 + i) * kSliceNodes);
                         }
@@ -783,6 +785,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
                                 v2d vv;
                                 vv.x = blk[i <= j0 ? sym6(i, j0) : sym6(j0, i)];
                                 vv.y = blk[i <= j1 ? sym6(i, j1) : sym6(j1, i)];
+                                if (m.diag_upper && j1 < i) continue; // (a word below the diagonal: nobody reads it, kernels.hpp)
                                 __builtin_nontemporal_store(vv, dst + (jp * 6 + i) * kSliceNodes);
                             }
                     } else {
@@ -813,6 +816,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
                                 v2d vv;
                                 vv.x = blk[6 * i + 2 * jp];
                                 vv.y = blk[6 * i + 2 * jp + 1];
+                                if (m.diag_upper && diag_slot && 2 * jp + 1 < i) continue;
                                 __builtin_nontemporal_store(vv, dst + (jp * 6 + i) * kSliceNodes);
                             }
                     }

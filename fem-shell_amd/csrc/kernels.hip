@@ -209,10 +209,17 @@ __global__ void k_block_jacobi(DeviceMatrix m)
     for (int jp = 0; jp < 3; jp++)
 #pragma unroll
         for (int i = 0; i < 6; i++) {
+            if (m.diag_upper && 2 * jp + 1 < i) continue; // (never written: the mirror image below fills it in)
             const double2 v = src[(jp * 6 + i) * kSliceNodes + n];
             A[i][2 * jp] = v.x;
             A[i][2 * jp + 1] = v.y;
         }
+    if (m.diag_upper) {
+#pragma unroll
+        for (int i = 1; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j < i; j++) A[i][j] = A[j][i];
+    }
     // Cholesky A = L L^T (the blocks are SPD), then A^-1 = L^-T L^-1: symmetric by construction and backward
     // stable without pivoting, which matters on sliver elements (block condition numbers around 1e9)
     double L[6][6], Li[6][6];
@@ -700,6 +707,15 @@ __global__ __launch_bounds__(192) void k_residual_dd_sym(DeviceMatrix m, const d
             const int c = (k == 0) ? a : m.cols[base + (int64_t)k * kSliceNodes + n];
             const double *blk = m.vals + base * 36 + (int64_t)k * 36 * kSliceNodes; // [(jp*6 + i)*32 + n]*2 + jj
             const double *xc = x + 6 * (int64_t)c;
+            if (k == 0 && m.diag_upper) {
+                // the diagonal block holds its upper triangle only: (i, j), j < i, is (j, i) -- same order of the sum over j
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const int r = j >= i ? i : j, cl = j >= i ? j : i;
+                    dd_fma_acc(acc, blk[((size_t)((cl >> 1) * 6 + r) * kSliceNodes + n) * 2 + (cl & 1)], xc[j]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int jp = 0; jp < 3; jp++) {
                 const double *wd = blk + ((size_t)(jp * 6 + i) * kSliceNodes + n) * 2;

@@ -45,6 +45,13 @@ struct DeviceMatrix {
     double *rhs_F = nullptr;            // the right-hand side k_assemble fills beside K (nullptr: K only)
     // symmetric storage (plan.hpp): transposed products K_ac^T x_a next to every slot, collected per row
     int32_t symmetric = 0;
+    // ... and of a diagonal block (slot 0 of a row, symmetric itself) only the 12 of its 18 words that hold the upper
+    // triangle are ever WRITTEN: word (jp, i) carries the columns 2jp, 2jp+1 of row i and lies below the diagonal when
+    // 2jp+1 < i.  The assembly kernels skip those six stores (192 of 288 bytes per node reach HBM), the other six words of
+    // the slot are never-written memory, and every reader of a diagonal slot takes (i, j), j < i, from (j, i): k_spmv_sym,
+    // k_residual_dd_sym, k_block_jacobi, the multigrid setup's block loads, the exports.  K only (1 with symmetric storage
+    // unless FEMSHELL_DIAG_UPPER=0); the level operators of the multigrid write whole blocks.
+    int32_t diag_upper = 0;
     int32_t max_in_width = 0;
     const int32_t *in_width = nullptr;  // n_slices
     const int64_t *in_base = nullptr;   // n_slices+1

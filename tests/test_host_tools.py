@@ -254,7 +254,7 @@ def test_coupled_flap_config5_full_size(tools, coupled_tool, tmp_path):
     mp = out["matrix_vs_oracle"]
     assert mp["same_pattern"] and mp["F_bitwise_equal"] and mp["max_entry_diff_over_max_entry"] <= 1e-12, mp
     assert out["unit_load_solve"]["converged"] == 1
-    assert out["tip_series_max_rel_diff"] < 1e-7, out
+    assert out["tip_series_max_rel_diff"] < 1e-5, out  # (the program prints six digits)
     run = out["manufactured"]["runs"][1]
     assert run["converged"] == 1 and run["rel_err_vs_manufactured"] < 1e-10, out["manufactured"]
     assert out["cg_iterations"] < 150 * out["coupling_iterations"], out
@@ -574,5 +574,5 @@ def test_coupled_program_writes_one_output_per_converged_time_step(tools, couple
     for t in range(3):
         e = _read_exodus(str(tmp_path / ("par_%04d.e" % t)))
         assert e["dims"]["num_nodes"] == m.n_nodes
-        assert e["vals_nod_var1"][0][probe] == pytest.approx(tips[t], rel=1e-7)
+        assert e["vals_nod_var1"][0][probe] == pytest.approx(tips[t], rel=1e-5)  # (six printed digits)
     assert not (tmp_path / "par_0003.e").exists() and not (tmp_path / "par_000.pvtu").exists()
