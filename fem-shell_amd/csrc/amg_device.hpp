@@ -67,6 +67,11 @@ struct AmgLevel {
     bool A_on_device = false; // the level matrix was computed in HBM (amg_device_setup.cpp), nothing to upload
     HostEllPattern pattern;   // ... and then this is the host copy of its pattern (for a further step on the device)
     AmgOperator P, R;         // to / from the next coarser level (absent on the coarsest)
+    DevBuf<float> A32;        // single-precision copy of the level operator's values for the smoothing products
+                              // (FEMSHELL_AMG_SMOOTH_F32; level 0: of K)
+    DevBuf<float> minv32, P32, R32; // ... of the block-Jacobi inverse the smoothers apply, and of the transfer operators
+    DeviceMatrix smooth_dm{}; // the level operator as the smoothers see it (vals32 / minv32 set where the copies exist)
+    bool smooth_ready = false;
     DevBuf<double> minv;      // block-Jacobi inverse of A (levels >= 1)
     double lam = 0.0;         // upper bound of the spectrum of D^-1 A used by the smoother
     double inv_theta = 0.0;
@@ -110,7 +115,6 @@ struct Amg {
     DevBuf<double> coarse_inv; // dense inverse of the coarsest operator
     DevBuf<float> coarse_inv32; // ... in single precision (FEMSHELL_AMG_DENSE_F32=1), device path only
     int64_t coarse_lda = 0;    // row stride of the device-computed inverse (0: host path, rows of 6 n doubles)
-    DevBuf<float> K32;         // K in single precision for the smoothing products of level 0 (FEMSHELL_AMG_SMOOTH_F32)
     bool valid = false;
     double setup_seconds = 0.0;
     std::shared_ptr<AmgDist> dist; // row-partitioned contexts only

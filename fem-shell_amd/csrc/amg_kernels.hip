@@ -18,7 +18,7 @@ __global__ __launch_bounds__(192) void k_cheb_start(DeviceMatrix m, const double
     for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
         const int sl = w.s;
         const int64_t row = (int64_t)sl * kSliceRows + t;
-        const MinvRow mr = load_minv(m, sl, t);
+        const MinvRow mr = load_minv_smoother(m, sl, t);
         const double rv = rin[row];
         const double xv = accumulate ? x[row] : 0.0;
         __syncthreads();
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(192) void k_cheb_step(DeviceMatrix m, const double 
     for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
         const int sl = w.s;
         const int64_t row = (int64_t)sl * kSliceRows + t;
-        const MinvRow mr = load_minv(m, sl, t);
+        const MinvRow mr = load_minv_smoother(m, sl, t);
         double qv = q[row];
         if (kGather) {
             const int Wi = m.in_width[sl], n = t / 6, j = t % 6;

@@ -503,15 +503,44 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
         }
     }
     {
-        // FEMSHELL_AMG_SMOOTH_F32=1 (experimental): the Chebyshev products of level 0 stream a single-precision copy of K
-        // (residuals, the Krylov product and the coarse operators stay FP64)
+        // FEMSHELL_AMG_SMOOTH_F32: the Chebyshev products of the levels stream a single-precision copy of the operator's
+        // values (half the bytes of the HBM-bound part of the cycle); residuals, the Krylov product, the K cycle's products,
+        // the Galerkin operators themselves and the transfers stay FP64.  The soft modes of a shell sit twelve decades
+        // below ||K||: only the smoother -- a polynomial in D^-1 A whose job is the upper end of the spectrum -- tolerates
+        // 1e-7, and the flexible Krylov method around the cycle does not care that the preconditioner moved a little.
+        // 1 (default): levels of at least 4096 nodes; 2: level 0 only; 3: every level whatever its size (tests); 0: off.
         const char *e = getenv("FEMSHELL_AMG_SMOOTH_F32");
-        H.K32.release();
-        if (e && atoi(e) != 0 && c->dm.symmetric && !H.levels.empty() && H.levels.size() > 1) {
-            const int64_t nv = (int64_t)pl.total_slots() * 36;
-            FS_HIP(H.K32.alloc((size_t)nv));
-            launch_to_f32(c->dm.vals, H.K32.p, nv, st);
+        const int mode = e ? atoi(e) : 1;
+        for (size_t l = 0; l + 1 < H.levels.size(); l++) {
+            AmgLevel &L = *H.levels[l];
+            L.A32.release();
+            const DeviceMatrix &A = amg_level_matrix(c, (int)l);
+            if (mode == 0 || (mode == 2 && l > 0) || (mode != 3 && L.n < 4096) || A.vals == nullptr) continue;
+            if (L.dist && l == 0) continue; // (level 0 of a row-partitioned context: products through spmv_with_halo)
+            const int64_t nv = (l == 0 ? (int64_t)pl.total_slots() : (int64_t)L.A.vals.n / 36) * 36;
+            FS_HIP(L.A32.alloc((size_t)nv));
+            launch_to_f32(A.vals, L.A32.p, nv, st);
+            // the block-Jacobi inverse the smoothers apply, and the transfer operators (R = P^T value by value, so the
+            // rounded pair is still a transposed pair and the cycle stays symmetric)
+            const int64_t nm = (int64_t)A.n_slices * 21 * kSliceNodes;
+            FS_HIP(L.minv32.alloc((size_t)nm));
+            launch_to_f32(A.minv, L.minv32.p, nm, st);
+            if (mode != 2 && L.P.vals.n > 0 && L.R.vals.n > 0) {
+                FS_HIP(L.P32.alloc(L.P.vals.n));
+                FS_HIP(L.R32.alloc(L.R.vals.n));
+                launch_to_f32(L.P.vals.p, L.P32.p, (int64_t)L.P.vals.n, st);
+                launch_to_f32(L.R.vals.p, L.R32.p, (int64_t)L.R.vals.n, st);
+            }
             FS_HIP(hipGetLastError());
+        }
+        for (size_t l = 0; l + 1 < H.levels.size(); l++) { // what the smoothers and the transfers of the cycle multiply with
+            AmgLevel &L = *H.levels[l];
+            L.smooth_dm = amg_level_matrix(c, (int)l);
+            L.smooth_dm.vals32 = L.A32.p;
+            L.smooth_dm.minv32 = L.minv32.p;
+            L.P.dm.vals32 = L.P32.p;
+            L.R.dm.vals32 = L.R32.p;
+            L.smooth_ready = true;
         }
     }
     FS_HIP(hipStreamSynchronize(st));
@@ -579,7 +608,8 @@ struct Cycle {
     void smooth(int l, const double *b, double *x, bool zero_guess)
     {
         AmgLevel &L = *H.levels[(size_t)l];
-        const DeviceMatrix &A = amg_level_matrix(c, l);
+        // (the operator as the smoother sees it: single-precision copies of the values and of D^-1 where the level has them)
+        const DeviceMatrix &A = L.smooth_ready ? L.smooth_dm : amg_level_matrix(c, l);
         const double *rcur = b;
         if (!zero_guess) {
             residual(l, b, x, L.r.p);
@@ -593,13 +623,7 @@ struct Cycle {
                 launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, A.symmetric != 0);
             } else if (A.symmetric) { // first phase of the product; the step kernel collects the transposed products
                 halo(l, L.d.p);
-                if (l == 0 && H.K32.p != nullptr) {
-                    DeviceMatrix A32 = A;
-                    A32.vals32 = H.K32.p;
-                    launch_spmv_direct(A32, L.d.p, L.q.p, nullptr, gate, st, true);
-                } else {
-                    launch_spmv_direct(A, L.d.p, L.q.p, nullptr, gate, st);
-                }
+                launch_spmv_direct(A, L.d.p, L.q.p, nullptr, gate, st, A.vals32 != nullptr);
                 launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, true);
             } else if (fused_cheb()) { // product and step in one launch (the small levels are bound by launch latency)
                 halo(l, d_cur);
@@ -607,7 +631,7 @@ struct Cycle {
                 std::swap(d_cur, d_next);
             } else {
                 halo(l, L.d.p);
-                launch_spmv(A, L.d.p, L.q.p, nullptr, gate, st);
+                launch_spmv(amg_level_matrix(c, l), L.d.p, L.q.p, nullptr, gate, st);
                 launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st);
             }
             rcur = L.r.p;

@@ -65,6 +65,17 @@ __device__ __forceinline__ MinvRow load_minv(const DeviceMatrix &m, int sl, int 
     for (int j = 0; j < 6; j++) r.a[j] = mi[minv_word(i < j ? i : j, i < j ? j : i) * kSliceNodes];
     return r;
 }
+// the smoothers of the multigrid cycle: from the single-precision copy when the level has one
+__device__ __forceinline__ MinvRow load_minv_smoother(const DeviceMatrix &m, int sl, int t)
+{
+    if (m.minv32 == nullptr) return load_minv(m, sl, t);
+    const int n = t / 6, i = t % 6;
+    const float *mi = m.minv32 + (int64_t)sl * kMinvWords * kSliceNodes + n;
+    MinvRow r;
+#pragma unroll
+    for (int j = 0; j < 6; j++) r.a[j] = (double)mi[minv_word(i < j ? i : j, i < j ? j : i) * kSliceNodes];
+    return r;
+}
 __device__ __forceinline__ double apply_minv(const MinvRow &mr, int t, const double *rs)
 {
     const int nb = (t / 6) * 6;

@@ -308,12 +308,23 @@ void launch_block_jacobi(const DeviceMatrix &m, hipStream_t st)
 template <int kChunk> struct SpmvChunk {
     double2 a[kChunk][3];
 };
-template <int kChunk>
-__device__ __forceinline__ void spmv_load(SpmvChunk<kChunk> &c, const double2 *__restrict__ v, int k0, int W)
+// (kF32: the words come from a single-precision copy of the values in the same layout, v32 -- smoothing products of the
+//  multigrid cycle only; the arithmetic stays FP64)
+template <int kChunk, bool kF32 = false>
+__device__ __forceinline__ void spmv_load(SpmvChunk<kChunk> &c, const double2 *__restrict__ v, int k0, int W,
+                                          const float2 *__restrict__ v32 = nullptr)
 {
 #pragma unroll
     for (int q = 0; q < kChunk; q++) {
-        if (k0 + q < W) {
+        if (kF32 && k0 + q < W) {
+            typedef float v2f_ __attribute__((ext_vector_type(2)));
+            const v2f_ *vv = reinterpret_cast<const v2f_ *>(v32 + (size_t)(k0 + q) * 3 * kSliceRows);
+            const v2f_ w0 = __builtin_nontemporal_load(vv), w1 = __builtin_nontemporal_load(vv + kSliceRows),
+                       w2 = __builtin_nontemporal_load(vv + 2 * kSliceRows);
+            c.a[q][0] = make_double2((double)w0.x, (double)w0.y);
+            c.a[q][1] = make_double2((double)w1.x, (double)w1.y);
+            c.a[q][2] = make_double2((double)w2.x, (double)w2.y);
+        } else if (k0 + q < W) {
             typedef double v2d __attribute__((ext_vector_type(2)));
             const v2d *vv = reinterpret_cast<const v2d *>(v + (size_t)(k0 + q) * 3 * kSliceRows);
             // K is read once per launch: non-temporal loads leave the caches to x
@@ -354,7 +365,7 @@ struct ChebEpilogue {
     double a = 0.0, c = 0.0;
 };
 
-template <int kChunk>
+template <int kChunk, bool kF32 = false>
 __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__restrict__ x,
                                               double *__restrict__ y, double *__restrict__ partials,
                                               const CgScalars *s, const int32_t *__restrict__ order, int count,
@@ -380,8 +391,9 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
             const int Wp = W - p0 < panel ? W - p0 : panel;
             const double2 *v = reinterpret_cast<const double2 *>(m.vals + base * 36) + (size_t)p0 * 3 * kSliceRows + t;
             const int32_t *cols = m.cols + base + (int64_t)p0 * kSliceNodes;
+            const float2 *v32 = kF32 ? reinterpret_cast<const float2 *>(m.vals32 + base * 36) + (size_t)p0 * 3 * kSliceRows + t : nullptr;
             SpmvChunk<kChunk> ch;
-            spmv_load<kChunk>(ch, v, 0, Wp);
+            spmv_load<kChunk, kF32>(ch, v, 0, Wp, v32);
             __syncthreads(); // the previous panel's readers are done with xs_all
             for (int e = t; e < Wp * kSliceNodes; e += kSliceRows) {
                 const double2 *xv = x2 + 3 * (int64_t)cols[e];
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
             __syncthreads();
             acc = spmv_fma<kChunk>(ch, xs, 0, Wp, acc);
             for (int k0 = kChunk; k0 < Wp; k0 += kChunk) {
-                spmv_load<kChunk>(ch, v, k0, Wp);
+                spmv_load<kChunk, kF32>(ch, v, k0, Wp, v32);
                 acc = spmv_fma<kChunk>(ch, xs, k0, Wp, acc);
             }
             // x[row] is in LDS during the first panel: slot 0 is the diagonal block, its column is the lane's own node
@@ -407,10 +419,16 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
             // d_out = a d_in + c D^-1 r_out on the lane's row; the six residual entries of its node sit in six lanes of
             // three waves (lane = node + 32 dof): exchanged through LDS
             const int n = t & 31, i = t >> 5;
-            const double *mi = m.minv + (int64_t)sl * kMinvWords * kSliceNodes + n;
             double mrow[6];
+            if (m.minv32 != nullptr) {
+                const float *mi = m.minv32 + (int64_t)sl * kMinvWords * kSliceNodes + n;
 #pragma unroll
-            for (int j = 0; j < 6; j++) mrow[j] = mi[minv_word(i < j ? i : j, i < j ? j : i) * kSliceNodes];
+                for (int j = 0; j < 6; j++) mrow[j] = (double)mi[minv_word(i < j ? i : j, i < j ? j : i) * kSliceNodes];
+            } else {
+                const double *mi = m.minv + (int64_t)sl * kMinvWords * kSliceNodes + n;
+#pragma unroll
+                for (int j = 0; j < 6; j++) mrow[j] = mi[minv_word(i < j ? i : j, i < j ? j : i) * kSliceNodes];
+            }
             const double dv = x[row], xv = cheb.xsol[row];
             __syncthreads();
             rs[n * 6 + i] = yv;
@@ -777,6 +795,10 @@ static void spmv_dispatch(const DeviceMatrix &m, const double *x, double *y, dou
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kernel, g, b, lds, st, m, x, y, partials, s, order, count, base_vec, sign, panel, cheb);
     };
+    if (m.vals32 != nullptr) { // a product of the multigrid cycle on a single-precision copy of the values (amg_solve.cpp)
+        launch(k_spmv<8, true>);
+        return;
+    }
     switch (chunk) {
     case 1: launch(k_spmv<1>); break;
     case 2: launch(k_spmv<2>); break;

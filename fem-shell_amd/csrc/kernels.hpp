@@ -64,6 +64,8 @@ struct DeviceMatrix {
     int32_t max_loc = 0;
     double *tbuf = nullptr;             // total_slots x 6: per (slice, slot k) [component j][node n]
     double *minv = nullptr;             // n_slices x 21 x 32: upper triangles of the inverse diagonal blocks
+    const float *minv32 = nullptr;      // the same in single precision: the Chebyshev smoothers of the multigrid cycle read it
+                                        // when set (amg_solve.cpp); the CG's own block-Jacobi step never does
     unsigned long long *stamps = nullptr; // profiling builds of k_assemble only (tools/lab)
     int32_t *status = nullptr;          // device int: 0 ok, e+1 = first degenerate local element,
                                         // -(node+1) = singular diagonal block

@@ -109,21 +109,25 @@ def test_every_level_coarsened_on_the_device_follows_the_restatement_too(monkeyp
 
 
 def test_single_precision_smoothing_products_leave_the_solution_alone(monkeypatch):
-    # FEMSHELL_AMG_SMOOTH_F32=1 (off by default): the Chebyshev products of level 0 read a float copy of K; the solve is
-    # flexible CG on the FP64 operator, so the answer is the same and the iteration count moves by a few at most
+    # FEMSHELL_AMG_SMOOTH_F32 (default 1: levels of at least 4096 nodes; 3: every level): the Chebyshev products read a float
+    # copy of the level operators' values; the solve is flexible CG on the FP64 operator, so the answer is the same and the
+    # iteration count moves by a few at most
     m, mat = _make("roof", 48)
+    monkeypatch.setenv("FEMSHELL_AMG_SMOOTH_F32", "0")
     fs = _context(m, mat)
-    fs.set_preconditioner("amg")
+    fs.set_preconditioner("amg", coarsest_nodes=60)
     u, info = fs.solve(rtol=1e-12, max_it=500)
     fs.close()
-    monkeypatch.setenv("FEMSHELL_AMG_SMOOTH_F32", "1")
-    fs = _context(m, mat)
-    fs.set_preconditioner("amg")
-    u32, info32 = fs.solve(rtol=1e-12, max_it=500)
-    assert info32["converged"] == 1 and abs(info32["iterations"] - info["iterations"]) <= 3, (info["iterations"], info32["iterations"])
-    assert not np.array_equal(u32, u)  # (the knob did something)
-    assert np.linalg.norm(u32 - u) / np.linalg.norm(u) < 1e-10
-    fs.close()
+    for mode in ("3", "2"):
+        monkeypatch.setenv("FEMSHELL_AMG_SMOOTH_F32", mode)
+        fs = _context(m, mat)
+        fs.set_preconditioner("amg", coarsest_nodes=60)
+        u32, info32 = fs.solve(rtol=1e-12, max_it=500)
+        assert info32["converged"] == 1 and info32["amg_levels"] >= 3
+        assert abs(info32["iterations"] - info["iterations"]) <= 3, (mode, info["iterations"], info32["iterations"])
+        assert not np.array_equal(u32, u)  # (the knob did something)
+        assert np.linalg.norm(u32 - u) / np.linalg.norm(u) < 1e-10
+        fs.close()
 
 
 def test_tentative_prolongator_with_the_rows_in_memory(monkeypatch):
