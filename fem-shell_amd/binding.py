@@ -337,7 +337,8 @@ class FemShell:
     def amg_export(self, level):
         """Host copies of a level (small problems): dict with agg, A (rowptr, cols, vals), P (rowptr, cols, vals)."""
         names = {"agg": (0, np.int32), "A_rowptr": (1, np.int64), "A_cols": (2, np.int32), "A_vals": (3, np.float64),
-                 "P_rowptr": (4, np.int64), "P_cols": (5, np.int32), "P_vals": (6, np.float64)}
+                 "P_rowptr": (4, np.int64), "P_cols": (5, np.int32), "P_vals": (6, np.float64),
+                 "coarse_inverse": (7, np.float64)}  # (the coarsest level only: its dense inverse, n x n)
         out = {}
         for name, (which, dt) in names.items():
             n = self._L.femshell_amg_export(self._h, level, which, None)
@@ -347,7 +348,7 @@ class FemShell:
             a = np.zeros(n, dtype=dt)
             if n:
                 self._L.femshell_amg_export(self._h, level, which, a.ctypes.data_as(C.c_void_p))
-            out[name] = a.reshape(-1, 6, 6) if name.endswith("vals") else a
+            out[name] = a.reshape(-1, 6, 6) if name.endswith("vals") else (a.reshape(int(round(np.sqrt(n))), -1) if name == "coarse_inverse" else a)
         return out
 
 

@@ -417,7 +417,7 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
                 FS_HIP(hipStreamSynchronize(st));
                 lap("dense inverse on the host", l);
             }
-            if (keep_host) L.hA = std::move(A);
+            L.hA = std::move(A); // (kept at every size: a few MB, and the operator the dense inverse is checked against)
             break;
         }
         double lam = 0.0;

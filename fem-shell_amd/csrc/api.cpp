@@ -868,6 +868,25 @@ int64_t femshell_amg_export(femshell_ctx *c, int32_t level, int32_t which, void 
         if (out && count) std::memcpy(out, src, count * elem);
         return (int64_t)count;
     };
+    if (which == FEMSHELL_AMG_COARSE_INVERSE) {
+        const Amg &H = *c->amg;
+        if (level + 1 != (int32_t)H.levels.size()) return -1;
+        const int64_t n = 6ll * L.n;
+        if (!out) return n * n;
+        if (select_device(c)) return -1;
+        double *o = static_cast<double *>(out);
+        if (H.coarse_lda > 0 && H.coarse_inv.p) { // computed on the matrix cores: rows of coarse_lda doubles
+            if (hipMemcpy2D(o, (size_t)n * 8, H.coarse_inv.p, (size_t)H.coarse_lda * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        } else if (H.coarse_lda > 0 && H.coarse_inv32.p) {
+            std::vector<float> h((size_t)n * H.coarse_lda);
+            if (hipMemcpy(h.data(), H.coarse_inv32.p, h.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            for (int64_t r = 0; r < n; r++)
+                for (int64_t q = 0; q < n; q++) o[r * n + q] = (double)h[(size_t)(r * H.coarse_lda + q)];
+        } else {
+            if (hipMemcpy(o, H.coarse_inv.p, (size_t)n * n * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        }
+        return n * n;
+    }
     const Bsr &M = (which >= FEMSHELL_AMG_P_ROWPTR) ? L.hP : L.hA;
     switch (which) {
     case FEMSHELL_AMG_AGGREGATES: return L.agg.empty() ? -1 : give(L.agg.data(), L.agg.size(), sizeof(int32_t));

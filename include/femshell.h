@@ -194,7 +194,10 @@ int32_t femshell_amg_levels(femshell_ctx *ctx);
 int femshell_amg_level(femshell_ctx *ctx, int32_t level, femshell_amg_level_info *info);
 enum { FEMSHELL_AMG_AGGREGATES = 0, /* int32 [n_nodes] */
        FEMSHELL_AMG_A_ROWPTR, FEMSHELL_AMG_A_COLS, FEMSHELL_AMG_A_VALS,   /* int64 [n+1], int32 [nnzb], double [nnzb*36] */
-       FEMSHELL_AMG_P_ROWPTR, FEMSHELL_AMG_P_COLS, FEMSHELL_AMG_P_VALS };
+       FEMSHELL_AMG_P_ROWPTR, FEMSHELL_AMG_P_COLS, FEMSHELL_AMG_P_VALS,
+       /* the coarsest level only: the dense inverse the cycle multiplies with, double [n][n] row-major (n = 6 x its nodes;
+        * the operator it inverts is that level's FEMSHELL_AMG_A_*, kept at every problem size) */
+       FEMSHELL_AMG_COARSE_INVERSE };
 /* returns the element count of the array (-1: not available); copies it to out when out != NULL */
 int64_t femshell_amg_export(femshell_ctx *ctx, int32_t level, int32_t which, void *out);
 /* device timings of the first coarsening step of the last setup: out[0..3] = milliseconds of the prolongator, A P,

@@ -383,6 +383,17 @@ def test_dense_inverse_on_the_matrix_cores_equals_the_host_inverse(monkeypatch, 
         st = fs.amg_dense_stats()
         assert info["converged"] == 1 and len(lv) == 2 and 200 < lv[-1]["n_nodes"] <= 300
         out[path] = (u, info["iterations"], st, lv[-1]["n_nodes"])
+        if path == "device":
+            # the inverse the matrix cores computed against the CHECKER's coarsest operator (oracle/amg_oracle.py builds its own
+            # hierarchy from the exported K), not only against the product's host inverse
+            rg, cg, vg, Fg = fs.export_bsr()
+            levels = amg_oracle.setup(_bsr(rg, cg, vg, m.n_nodes), m.xyz, m.dirichlet_mask(), lams=[l["lambda_max"] for l in lv],
+                                      coarsest_nodes=300, tri=m.tri, quad=m.quad)
+            inv = fs.amg_export(len(lv) - 1)["coarse_inverse"]
+            Ac = levels[-1].A.toarray()
+            assert len(levels) == 2 and inv.shape == Ac.shape == (6 * lv[-1]["n_nodes"],) * 2
+            defect = np.abs(Ac @ inv - np.eye(len(Ac))).max()
+            assert defect <= (1e-9 if not f32 else 2e-4), defect
         fs.close()
     assert out["host"][2]["n"] == 0 and out["device"][2]["n"] == 6 * out["device"][3]
     assert out["device"][2]["dropped_directions"] == 0 and out["device"][2]["mfma_flops_issued"] > 0
