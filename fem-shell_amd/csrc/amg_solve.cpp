@@ -508,14 +508,14 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
         // the Galerkin operators themselves and the transfers stay FP64.  The soft modes of a shell sit twelve decades
         // below ||K||: only the smoother -- a polynomial in D^-1 A whose job is the upper end of the spectrum -- tolerates
         // 1e-7, and the flexible Krylov method around the cycle does not care that the preconditioner moved a little.
-        // 1 (default): levels of at least 4096 nodes; 2: level 0 only; 3: every level whatever its size (tests); 0: off.
+        // 1 (default): levels of at least 4096 nodes; 2: level 0 only, 3: every level, whatever their size (A/B runs, tests); 0: off.
         const char *e = getenv("FEMSHELL_AMG_SMOOTH_F32");
         const int mode = e ? atoi(e) : 1;
         for (size_t l = 0; l + 1 < H.levels.size(); l++) {
             AmgLevel &L = *H.levels[l];
             L.A32.release();
             const DeviceMatrix &A = amg_level_matrix(c, (int)l);
-            if (mode == 0 || (mode == 2 && l > 0) || (mode != 3 && L.n < 4096) || A.vals == nullptr) continue;
+            if (mode == 0 || (mode == 2 && l > 0) || (mode == 1 && L.n < 4096) || A.vals == nullptr) continue;
             if (L.dist && l == 0) continue; // (level 0 of a row-partitioned context: products through spmv_with_halo)
             const int64_t nv = (l == 0 ? (int64_t)pl.total_slots() : (int64_t)L.A.vals.n / 36) * 36;
             FS_HIP(L.A32.alloc((size_t)nv));
