@@ -516,7 +516,6 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
             L.A32.release();
             const DeviceMatrix &A = amg_level_matrix(c, (int)l);
             if (mode == 0 || (mode == 2 && l > 0) || (mode == 1 && L.n < 4096) || A.vals == nullptr) continue;
-            if (L.dist && l == 0) continue; // (level 0 of a row-partitioned context: products through spmv_with_halo)
             const int64_t nv = (l == 0 ? (int64_t)pl.total_slots() : (int64_t)L.A.vals.n / 36) * 36;
             FS_HIP(L.A32.alloc((size_t)nv));
             launch_to_f32(A.vals, L.A32.p, nv, st);
@@ -578,13 +577,14 @@ struct Cycle {
     }
     // y = K x on level 0 of a row-partitioned context: the halo exchange beside the interior slices (symmetric storage with
     // defer: the direct part only, the consumer collects the transposed products)
-    void product0(double *x, double *y, bool defer)
+    // (vals32: a smoothing product on the single-precision copy of K's values)
+    void product0(double *x, double *y, bool defer, const float *vals32 = nullptr)
     {
         if (rc) return;
         CgVectors vv;
         vv.s = const_cast<CgScalars *>(gate);
         int np = 0;
-        rc = spmv_with_halo(c, vv, x, y, nullptr, &np, defer);
+        rc = spmv_with_halo(c, vv, x, y, nullptr, &np, defer, vals32);
     }
     // out = b - A_l x
     void residual(int l, const double *b, double *x, double *out)
@@ -619,7 +619,7 @@ struct Cycle {
         double *d_cur = L.d.p, *d_next = L.q.p; // full-storage levels: the direction alternates between the two vectors
         for (size_t k = 0; k < L.cheb_a.size(); k++) {
             if (l == 0 && dist(0)) {
-                product0(L.d.p, L.q.p, A.symmetric != 0);
+                product0(L.d.p, L.q.p, A.symmetric != 0, A.vals32);
                 launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, A.symmetric != 0);
             } else if (A.symmetric) { // first phase of the product; the step kernel collects the transposed products
                 halo(l, L.d.p);

@@ -30,15 +30,17 @@ int halo_exchange(femshell_ctx *c, double *p, hipStream_t st)
 // (xin: input vector with ghost space, yout = K xin, partial sums of xin.yout from partials[0] on)
 // (defer_gather: symmetric storage, the caller's next kernel collects the transposed products -- k_cg_update<true>)
 int spmv_with_halo(femshell_ctx *c, const CgVectors &v, double *xin, double *yout, double *partials, int *n_partials,
-                   bool defer_gather)
+                   bool defer_gather, const float *vals32)
 {
     hipStream_t st = c->stream;
     *n_partials = 0;
     defer_gather = defer_gather && c->dm.symmetric;
+    DeviceMatrix dm = c->dm;
+    dm.vals32 = (defer_gather && c->dm.symmetric) ? vals32 : nullptr; // (the single-precision copy serves the symmetric first phase)
     if (!c->halo_overlap) {
         int rc = halo_exchange(c, xin, st);
         if (rc) return rc;
-        if (defer_gather) launch_spmv_direct(c->dm, xin, yout, partials, v.s, st);
+        if (defer_gather) launch_spmv_direct(dm, xin, yout, partials, v.s, st, dm.vals32 != nullptr);
         else launch_spmv(c->dm, xin, yout, partials, v.s, st);
         return FEMSHELL_OK;
     }
@@ -49,9 +51,9 @@ int spmv_with_halo(femshell_ctx *c, const CgVectors &v, double *xin, double *you
     if (rc) return rc;
     FS_HIP(hipEventRecord(c->ev_halo_done, c->halo_stream));
     const int ni = pl.n_interior_slices, nb = pl.n_slices - ni;
-    const int gi = launch_spmv_span(c->dm, xin, yout, partials, v.s, c->spmv_order.p, 0, ni, 0, st);
+    const int gi = launch_spmv_span(dm, xin, yout, partials, v.s, c->spmv_order.p, 0, ni, 0, st);
     FS_HIP(hipStreamWaitEvent(st, c->ev_halo_done, 0));
-    const int gb = launch_spmv_span(c->dm, xin, yout, partials, v.s, c->spmv_order.p, ni, nb, gi, st);
+    const int gb = launch_spmv_span(dm, xin, yout, partials, v.s, c->spmv_order.p, ni, nb, gi, st);
     if (c->dm.symmetric && !defer_gather) launch_sym_gather(c->dm, yout, nullptr, 1.0, v.s, st); // all transposed products are in place
     *n_partials = gi + gb;
     return FEMSHELL_OK;

@@ -852,7 +852,9 @@ int launch_spmv_span(const DeviceMatrix &m, const double *x, double *y, double *
     if (count <= 0) return 0;
     const int grid = span_grid(m, count);
     if (m.symmetric) { // phase 1 only: the caller runs launch_sym_gather once all spans are through
-        spmv_sym_phase1(m, x, y, partials != nullptr ? partials + partial_offset : nullptr, s, order + begin, count, grid, st);
+        // (m.vals32 set: a smoothing product of the multigrid cycle on the single-precision copy of the values)
+        spmv_sym_phase1(m, x, y, partials != nullptr ? partials + partial_offset : nullptr, s, order + begin, count, grid, st,
+                        m.vals32 != nullptr);
         return grid;
     }
     spmv_dispatch(m, x, y, partials != nullptr ? partials + partial_offset : nullptr, s, order + begin, count, grid, st);

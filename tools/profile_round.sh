@@ -5,7 +5,7 @@
 #   gpurun_out/<tag>_pmc_hbm_traffic.json  FETCH_SIZE / WRITE_SIZE, one counter per pass (tools/pmc_summary.py)
 # Every profiler pass runs under its own timeout; no TA_* counters (they hang rocprofv3 on this pool).
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
