@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -222,14 +223,17 @@ template <class F> __device__ __forceinline__ void for_quadrant(int r0, int c0, 
 // cores from LDS (row stride 66: conflict-free; a product with thread-per-4x4 FMAs from LDS took 98 us per sweep, more than
 // the trailing update it feeds).  LDS: P0 = B_A, P1 = C -> S -> B_S, P2 = W -> X21^T, P3 = W^T.
 // status[0] = 1 on a clearly negative pivot, status[1] counts the dropped directions.
-__global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ D, int64_t ld, int K, const double *__restrict__ diag0,
-                                                     double *__restrict__ B, int32_t *status)
+// (panels: the four 64 x 66 work blocks P0 .. P3 -- LDS in k_dense_pivot; in the look-ahead of k_dense_update, whose
+//  workgroups have 35 KB of LDS each, a scratch buffer in HBM that stays in the caches: the products then read their operands
+//  through global loads, slower than from LDS but beside the trailing update instead of in front of it.  small: 2 x 4 x 64
+//  doubles of row panel + 128 diagonal entries, LDS in both.)
+__device__ __forceinline__ void pivot_block(const double *__restrict__ D, int64_t ld, int K, const double *__restrict__ diag0,
+                                            double *__restrict__ B, int32_t *status, double *panels, double *small_lds)
 {
-    extern __shared__ double lds_dense[];
     constexpr int L = kLdp;
-    double *P0 = lds_dense, *P1 = P0 + kNB * L, *P2 = P1 + kNB * L, *P3 = P2 + kNB * L;
-    double (*rowbuf)[4][kNB] = reinterpret_cast<double (*)[4][kNB]>(P3 + kNB * L);
-    double *a0 = reinterpret_cast<double *>(rowbuf) + 2 * 4 * kNB; // 128 original diagonal entries
+    double *P0 = panels, *P1 = P0 + kNB * L, *P2 = P1 + kNB * L, *P3 = P2 + kNB * L;
+    double (*rowbuf)[4][kNB] = reinterpret_cast<double (*)[4][kNB]>(small_lds);
+    double *a0 = small_lds + 2 * 4 * kNB; // 128 original diagonal entries
     const int tid = threadIdx.x, k0 = 2 * K * kNB, bi = tid >> 4, bj = tid & 15;
     const int wave = tid >> 6, lane = tid & 63, r0 = 32 * (wave >> 1), c0 = 32 * (wave & 1);
     double s[4][4];
@@ -318,6 +322,13 @@ __global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ 
     }
 }
 
+__global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ D, int64_t ld, int K, const double *__restrict__ diag0,
+                                                     double *__restrict__ B, int32_t *status)
+{
+    extern __shared__ double lds_dense[];
+    pivot_block(D, ld, K, diag0, B, status, lds_dense, lds_dense + 4 * kNB * kLdp);
+}
+
 // C_i = A(i, block K) (64 x 128), gathered from the lower triangle (tiles (i, 2K), (i, 2K+1) below the pivot block, the
 // transposed tiles (2K, i), (2K+1, i) above it), W_i = C_i B on the matrix cores.  One workgroup per 64-row block; the two
 // block rows of the pivot block itself are skipped.  K runs in four chunks of 32 through LDS (row stride 34 doubles: the 32
@@ -369,15 +380,83 @@ __global__ __launch_bounds__(256) void k_dense_panels(const double *__restrict__
                 }
 }
 
+// Look-ahead of the block sweep (la.on; FEMSHELL_AMG_DENSE_LOOKAHEAD=1, off by default): the three tiles of the NEXT pivot
+// block are the first workgroups of the grid; they count themselves done in la.flag (release), and workgroup 3 -- which has
+// no tile -- waits for them (acquire, bounded) and inverts that block into la.B_next while the other workgroups update the
+// rest of the triangle, so that the one-workgroup pivot inverse (71 us of dependent steps per sweep, 4.1 of 17.2 ms at 7386
+// dofs) would leave the critical path without a second stream and its event waits (round 3: 29.7 ms).  Its 64 x 66 work
+// blocks live in la.scratch (HBM, cache resident) because a workgroup of this kernel has 35 KB of LDS, not the 138 KB
+// k_dense_pivot takes.  MEASURED (round 4, 7386 dofs): same inverse, same iterations, but 19.2 ms against 17.2: with its
+// operands behind global loads and 194 live registers squeezed into 128 the pivot workgroup takes about 290 us, longer than
+// the 161 us update it was meant to hide behind.  Kept as the measured alternative; what it would take: the products staged
+// through the 35 KB in chunks of 32 columns like the update's own, and a sweep64 that lives in 64 doubles of registers.
+struct DenseLookAhead {
+    int on = 0;
+    const double *diag0 = nullptr;
+    double *B_next = nullptr, *scratch = nullptr;
+    int32_t *status = nullptr;
+    unsigned int *flag = nullptr; // one counter per sweep, zero-initialised
+};
+
 // one workgroup per lower 64 x 64 tile (i >= j): the sweep of the 128-wide block K
+// (kLookAhead = false: the kernel without the pivot workgroup's code -- that code spills at the 128 VGPRs four workgroups per
+//  CU leave, 544 B of scratch per lane, and a kernel that carries it pays for it in every workgroup: 17.5 against 17.2 ms)
+template <bool kLookAhead>
 __global__ __launch_bounds__(256, 4) void k_dense_update(double *__restrict__ D, int64_t ld, int K, const double *__restrict__ B,
-                                                         const double *__restrict__ Cp, const double *__restrict__ Wp)
+                                                         const double *__restrict__ Cp, const double *__restrict__ Wp, int tiles,
+                                                         DenseLookAhead la)
 {
     __shared__ double lds_upd[2 * kNB * kLdh > kNB * kLdp ? 2 * kNB * kLdh : kNB * kLdp];
     double *Ws = lds_upd, *Cs = lds_upd + kNB * kLdh;
     const int tid = threadIdx.x;
+    // workgroup -> tile.  With the look-ahead: workgroups 0, 1, 2 take the tiles (2K+2, 2K+2), (2K+3, 2K+2), (2K+3, 2K+3) of the
+    // next pivot block, workgroup 3 is the pivot workgroup, and the tiles those three took are handed to the workgroups that
+    // would have had the indices 0 .. 2 (a swap: every tile still has exactly one workgroup)
+    int t = blockIdx.x;
+    bool ahead_tile = false;
+    if (kLookAhead && la.on) {
+        const int i2 = 2 * K + 2;
+        const int t_a = i2 * (i2 + 1) / 2 + i2, t_b = (i2 + 1) * (i2 + 2) / 2 + i2, t_c = t_b + 1; // linear indices of the three tiles
+        if (blockIdx.x == 3) {
+            // ---- the pivot workgroup
+            __shared__ int ok;
+            if (tid == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(la.flag + K, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < 3u && spins < (1 << 24)) {
+                    __builtin_amdgcn_s_sleep(8);
+                    spins++;
+                }
+                ok = spins < (1 << 24) ? 1 : 0;
+                if (!ok) la.status[0] = 2; // (never seen: the three tile workgroups precede this one in dispatch order)
+            }
+            __syncthreads();
+            if (!ok) return;
+            __threadfence(); // (acquire for every thread's loads of the three tiles)
+            pivot_block(D, ld, K + 1, la.diag0, la.B_next, la.status, la.scratch, lds_upd);
+            return;
+        }
+        // blockIdx 0..2 -> t_a, t_b, t_c; blockIdx 4.. -> its own index shifted by one, and whoever lands on t_a / t_b / t_c
+        // takes the tile of the workgroup that left (0, 1, 2)
+        if (blockIdx.x < 3) {
+            t = blockIdx.x == 0 ? t_a : (blockIdx.x == 1 ? t_b : t_c);
+            ahead_tile = true;
+        } else {
+            t = blockIdx.x - 1;                 // 3 .. tiles-1 (the pivot workgroup took index 3)
+            if (t == t_a) t = 0;
+            else if (t == t_b) t = 1;
+            else if (t == t_c) t = 2;
+            // (t = 3 .. tiles-1 covers every tile but 0, 1, 2 and, through the swap, t_a, t_b, t_c are replaced by them)
+        }
+        if (t >= tiles) return;
+    }
+    auto done = [&]() { // a tile of the next pivot block is in place
+        if (ahead_tile) {
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(la.flag + K, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     // linear tile index -> (i, j), i >= j
-    const int t = blockIdx.x;
     int i = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
     while ((i + 1) * (i + 2) / 2 <= t) i++;
     while (i * (i + 1) / 2 > t) i--;
@@ -436,6 +515,7 @@ __global__ __launch_bounds__(256, 4) void k_dense_update(double *__restrict__ D,
                 const int r = r0 + 16 * ti + (lane >> 4) + 4 * g, c = c0 + 16 * tj + (lane & 15);
                 tile[(int64_t)r * ld + c] = -acc[ti][tj][g];
             }
+    done();
 }
 
 // out (n x ldo, both triangles) <- -(lower triangle of D)
@@ -496,14 +576,18 @@ int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precisio
     hipStream_t st = c->stream;
     const int n = 6 * A.nr, n_pad = (n + kSW - 1) / kSW * kSW, nt = n_pad / kNB, ns = n_pad / kSW;
     const int64_t ld = n_pad;
-    DevBuf<double> D, diag0, B, Cp, Wp;
+    DevBuf<double> D, diag0, B, Cp, Wp, pivot_scratch;
+    DevBuf<unsigned int> la_flags;
     DevBuf<int64_t> dptr;
     DevBuf<int32_t> dcol, dstatus;
     DevBuf<double> dval;
     FS_HIP(D.alloc((size_t)n_pad * n_pad));
     FS_HIP(D.zero(st));
     FS_HIP(diag0.alloc(n_pad));
-    FS_HIP(B.alloc(kSW * kSW));
+    FS_HIP(B.alloc(2 * kSW * kSW)); // (two: the look-ahead writes the next sweep's while this sweep's is read)
+    FS_HIP(pivot_scratch.alloc(4 * (size_t)kNB * kLdp));
+    FS_HIP(la_flags.alloc((size_t)ns + 1));
+    FS_HIP(la_flags.zero(st));
     FS_HIP(Cp.alloc((size_t)n_pad * kSW));
     FS_HIP(Wp.alloc((size_t)n_pad * kSW));
     FS_HIP(dptr.upload(A.ptr, st));
@@ -525,10 +609,25 @@ int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precisio
     // (the pivot kernel is one workgroup and 70 us of dependent steps; running it on a second stream beside the previous
     //  sweep's update, after bringing its three tiles up to date first, was measured: the two event waits per sweep cost more
     //  than the overlap gains, 17.3 -> 29.7 ms)
+    // FEMSHELL_AMG_DENSE_LOOKAHEAD=1: the next sweep's pivot inverse inside the update's launch (measured: slower, see
+    // DenseLookAhead); default: a launch of its own in front of every sweep
+    const bool lookahead = getenv("FEMSHELL_AMG_DENSE_LOOKAHEAD") && atoi(getenv("FEMSHELL_AMG_DENSE_LOOKAHEAD")) == 1;
     for (int K = 0; K < ns; K++) {
-        hipLaunchKernelGGL(k_dense_pivot, dim3(1), dim3(256), lds_pivot, st, D.p, ld, K, diag0.p, B.p, dstatus.p);
-        hipLaunchKernelGGL(k_dense_panels, dim3(nt), dim3(256), 0, st, D.p, ld, K, B.p, Cp.p, Wp.p);
-        hipLaunchKernelGGL(k_dense_update, dim3(tiles), dim3(256), 0, st, D.p, ld, K, B.p, Cp.p, Wp.p);
+        double *Bk = B.p + (size_t)(K & 1) * kSW * kSW;
+        if (K == 0 || !lookahead)
+            hipLaunchKernelGGL(k_dense_pivot, dim3(1), dim3(256), lds_pivot, st, D.p, ld, K, diag0.p, Bk, dstatus.p);
+        hipLaunchKernelGGL(k_dense_panels, dim3(nt), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p);
+        DenseLookAhead la;
+        if (lookahead && K + 1 < ns) {
+            la.on = 1;
+            la.diag0 = diag0.p;
+            la.B_next = B.p + (size_t)((K + 1) & 1) * kSW * kSW;
+            la.scratch = pivot_scratch.p;
+            la.status = dstatus.p;
+            la.flag = la_flags.p;
+        }
+        if (la.on) hipLaunchKernelGGL(k_dense_update<true>, dim3(tiles + 1), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p, tiles, la);
+        else hipLaunchKernelGGL(k_dense_update<false>, dim3(tiles), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p, tiles, la);
     }
     const int64_t ldo = (n + 1) / 2 * 2;
     const unsigned gfin = (unsigned)(((int64_t)n * ldo + 255) / 256);
@@ -558,6 +657,7 @@ int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precisio
         stats->dropped = hstatus[1];
         stats->bytes = (double)ns * (double)tiles * 2.0 * kNB * kNB * 8.0; // lower triangle read + written per sweep
     }
+    if (hstatus[0] == 2) return set_err(FEMSHELL_ERR_HIP, "multigrid setup: the look-ahead of the dense inverse timed out");
     if (hstatus[0] != 0) return set_err(FEMSHELL_ERR_BREAKDOWN, "multigrid setup: coarsest operator is not positive definite");
     return FEMSHELL_OK;
 }

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
 #pragma unroll
         for (int q = 0; q < kRec; q++) held[q] = 0.0;
         auto write_lean = [&](double *buf, int i, const double rec[kRec]) {
-            double2 *dst = reinterpret_cast<double2 *>(buf + (size_t)i * kRec);
+            double2 *dst = reinterpret_cast<double2 *>(buf + pipe_rec_offset(i, kRec));
 #pragma unroll
             for (int q = 0; q < kRec / 2; q++) dst[q] = make_double2(rec[2 * q], rec[2 * q + 1]);
         };
@@ -703,12 +703,12 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
                 if (sym_item) {
                     for (int q = 0; q < cnt; q++) {
                         const uint32_t pr = (q == 0) ? (item.y & 0xffffu) : (q == 1 ? (item.y >> 16) : (item.z & 0xffffu));
-                        tri3_diag_add_rec<RecLean>(lds_rec + (size_t)(pr >> 4) * kRec, (int)(pr & 3u), mc, blk);
+                        tri3_diag_add_rec<RecLean>(lds_rec + pipe_rec_offset((int)(pr >> 4), kRec), (int)(pr & 3u), mc, blk);
                     }
                 } else {
                     for (int q = 0; q < cnt; q++) {
                         const uint32_t pr = (q == 0) ? (item.y & 0xffffu) : (q == 1 ? (item.y >> 16) : (item.z & 0xffffu));
-                        const double *rec = lds_rec + (size_t)(pr >> 4) * kRec;
+                        const double *rec = lds_rec + pipe_rec_offset((int)(pr >> 4), kRec);
                         if (kHasQuads) block_add_rec<true>(rec, (int)((pr >> 2) & 3u), (int)(pr & 3u), mc, blk);
                         else tri3_block_add_rec<RecLean>(rec, (int)((pr >> 2) & 3u), (int)(pr & 3u), mc, blk);
                     }

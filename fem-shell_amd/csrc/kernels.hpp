@@ -71,12 +71,26 @@ struct DeviceMatrix {
                                         // -(node+1) = singular diagonal block
 };
 
+// Record i of a slice in a record buffer of k_assemble_pipe.  34 (66) doubles per record are 68 (132) dwords = 4 mod 64
+// banks: records whose indices differ by 16 start in the same bank, and on a structured slice the lanes n and n + 8 of a wave
+// read exactly such records (node n's elements sit at 2n + const in the slice's list) -- a four-way conflict per 32-lane
+// group.  Two doubles of padding behind every 16 records move them four banks apart; the records stay 16-byte aligned.
+// MEASURED (round 4, 4M-triangle panel, alternating libraries on one box): 0.550-0.552 ms with the padding against
+// 0.543-0.552 ms without -- the conflicts the counters show (33 % of the LDS-active cycles) are not on the critical path.
+// Off by default; -DFEMSHELL_PIPE_REC_PAD=2 builds the padded layout.
+#ifndef FEMSHELL_PIPE_REC_PAD
+#define FEMSHELL_PIPE_REC_PAD 0
+#endif
+constexpr int kPipeRecPad = FEMSHELL_PIPE_REC_PAD;
+__host__ __device__ constexpr int pipe_rec_offset(int i, int rec_doubles) { return i * rec_doubles + kPipeRecPad * (i >> 4); }
+
 // LDS layout of k_assemble for a plan with at most max_slice_elems element records and max_stage_rows partial-sum
 // rows per slice: [records | partial sums].  Returns the dynamic LDS size in bytes.
 inline size_t assemble_lds_layout(DeviceMatrix &m, int32_t max_slice_elems, int32_t max_stage_rows, bool has_quads)
 {
     if (m.pipe) { // k_assemble_pipe: two buffers of lean records, no staging
-        m.lds_rec_off = max_slice_elems * (has_quads ? kRecDoublesQuad : RecLean::doubles);
+        // (+ two doubles of padding behind every 16 records: pipe_rec_offset)
+        m.lds_rec_off = pipe_rec_offset(max_slice_elems, has_quads ? kRecDoublesQuad : RecLean::doubles);
         m.lds_stage_off = 0;
         m.lds_bytes = (int32_t)(2 * (size_t)m.lds_rec_off * sizeof(double));
         return (size_t)m.lds_bytes;
