@@ -402,7 +402,10 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
             // 250) the inverse is computed on the matrix cores (amg_dense.hip: n^3 flops, 0.4 TFLOP at 1231 nodes)
             // (read per setup: the tests switch them inside one process)
             const long dense_device_min = getenv("FEMSHELL_AMG_DENSE_DEVICE_MIN") ? atol(getenv("FEMSHELL_AMG_DENSE_DEVICE_MIN")) : 250l;
-            const bool dense_f32 = getenv("FEMSHELL_AMG_DENSE_F32") && atoi(getenv("FEMSHELL_AMG_DENSE_F32")) != 0;
+            // (stored and applied in single precision unless FEMSHELL_AMG_DENSE_F32=0: the coarsest solve sits inside a K cycle
+            //  inside a flexible Krylov method, 1e-7 there moves the iteration count by one or two and halves the 436 MB the
+            //  four visits per iteration stream: panel 0.809 -> 0.785 s, cylinder 0.755 -> 0.744 s)
+            const bool dense_f32 = !(getenv("FEMSHELL_AMG_DENSE_F32") && atoi(getenv("FEMSHELL_AMG_DENSE_F32")) == 0);
             H.coarse_lda = 0;
             H.dense = AmgDenseStats();
             H.coarse_inv32.release();
@@ -562,6 +565,13 @@ bool fused_cheb()
     return !(e && atoi(e) == 0);
 }
 
+// FEMSHELL_AMG_RESIDUAL_INCREMENT=0: the residual in front of a restriction as b - A x, a product of its own in FP64 (A/B runs)
+bool residual_increment()
+{
+    const char *e = getenv("FEMSHELL_AMG_RESIDUAL_INCREMENT");
+    return !(e && atoi(e) == 0);
+}
+
 struct Cycle {
     femshell_ctx *c;
     Amg &H;
@@ -636,6 +646,39 @@ struct Cycle {
             }
             rcur = L.r.p;
         }
+        last_r = rcur;
+        last_d = A.symmetric || (l == 0 && dist(0)) ? L.d.p : d_cur;
+    }
+    // what the last smooth() left: the residual of its iterate BEFORE the last direction was added, and that direction
+    const double *last_r = nullptr;
+    double *last_d = nullptr;
+
+    // r = b - A x right behind a pre-smoothing from a zero guess, without a product with x: the smoother carries the
+    // residual of its iterate up to the last direction d it added, so r = last_r - A d, and since ||A d|| is of the size of
+    // the residual itself -- not of ||A|| ||x||, seven to nine decades above it -- the single-precision copy of the values
+    // serves (relative error 1e-7 of the increment).  Returns where the residual is (L.r or L.q).
+    double *residual_after_presmoothing(int l)
+    {
+        AmgLevel &L = *H.levels[(size_t)l];
+        const DeviceMatrix &A = L.smooth_ready ? L.smooth_dm : amg_level_matrix(c, l);
+        if (l == 0 && dist(0)) {
+            if (A.symmetric) {
+                product0(last_d, L.q.p, true, A.vals32);
+                launch_sym_gather(A, L.q.p, last_r, -1.0, gate, st);
+                return L.q.p;
+            }
+            product0(last_d, L.q.p, false);
+            launch_sub(last_r, L.q.p, L.r.p, 6ll * A.n_pad, st);
+            return L.r.p;
+        }
+        halo(l, last_d);
+        if (A.symmetric) {
+            launch_spmv_direct(A, last_d, L.q.p, nullptr, gate, st, A.vals32 != nullptr);
+            launch_sym_gather(A, L.q.p, last_r, -1.0, gate, st);
+            return L.q.p;
+        }
+        launch_spmv_axpy(A, last_d, L.r.p, last_r, -1.0, gate, st); // (last_d is L.d or L.q, never L.r)
+        return L.r.p;
     }
 
     // x = M_l(b): one cycle on level l
@@ -649,21 +692,23 @@ struct Cycle {
         }
         AmgLevel &N = *H.levels[(size_t)l + 1];
         smooth(l, b, x, true);
-        residual(l, b, x, L.r.p); // r = b - A x
+        double *rf = L.r.p; // r = b - A x
+        if (residual_increment()) rf = residual_after_presmoothing(l);
+        else residual(l, b, x, L.r.p);
         // b_c = R r
         if (dist(l)) {
-            halo(l, L.r.p); // (R = P^T reaches the rows of the neighbours' nodes along the cut)
+            halo(l, rf); // (R = P^T reaches the rows of the neighbours' nodes along the cut)
             if (N.dist) {
-                launch_spmv(L.R.dm, L.r.p, N.b.p, nullptr, gate, st);
+                launch_spmv(L.R.dm, rf, N.b.p, nullptr, gate, st);
             } else {
                 // the rank's rows of the restricted residual, all-gathered into the replicated level
-                launch_spmv(L.R.dm, L.r.p, L.bown.p, nullptr, gate, st);
+                launch_spmv(L.R.dm, rf, L.bown.p, nullptr, gate, st);
                 std::vector<int32_t> begin(N.part.begin(), N.part.end() - 1), end(N.part.begin() + 1, N.part.end());
                 std::string e;
                 if (!rc && !comm_gather_rows(c->comm, L.bown.p, N.b.p, begin, end, st, &e)) rc = set_err(FEMSHELL_ERR_COMM, e);
             }
         } else {
-            launch_spmv(L.R.dm, L.r.p, N.b.p, nullptr, gate, st);
+            launch_spmv(L.R.dm, rf, N.b.p, nullptr, gate, st);
         }
         const bool next_is_coarsest = (size_t)l + 2 == H.levels.size();
         if (H.opt.cycle == FEMSHELL_CYCLE_K && !next_is_coarsest) kcycle(l + 1);

@@ -44,9 +44,10 @@ int64_t real_blocks(const femshell_ctx *c) { return c->plan.nnz_blocks; }
 double bytes_assemble(const femshell_ctx *c)
 {
     const Plan &p = c->plan;
-    // (symmetric storage: only the stored blocks are computed and written -- the algorithmic bytes of that layout)
-    return 12.0 * p.n_ltri() + 16.0 * p.n_lquad() + 24.0 * (p.n_own + p.n_ghost) + 292.0 * (double)p.stored_blocks +
-           4.0 * (p.n_own + 1) + 48.0 * p.n_own;
+    // (symmetric storage: only the stored blocks are computed and written -- the algorithmic bytes of that layout -- and of a
+    //  diagonal block, symmetric itself, the 12 words of the upper triangle: 192 instead of 288 bytes per node)
+    return 12.0 * p.n_ltri() + 16.0 * p.n_lquad() + 24.0 * (p.n_own + p.n_ghost) + 292.0 * (double)p.stored_blocks -
+           (c->dm.diag_upper ? 96.0 * p.n_own : 0.0) + 4.0 * (p.n_own + 1) + 48.0 * p.n_own;
 }
 double bytes_spmv(const femshell_ctx *c)
 {
