@@ -259,3 +259,42 @@ def test_aggregates_of_a_renumbered_graph_are_those_of_the_callers_numbering(kin
     assert not np.array_equal(agg2[perm], agg0)
     with pytest.raises(Exception):
         _binding().amg_host_aggregate(rpp, cip, visit=np.zeros(n, np.int32))
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_rank_local_aggregation_of_the_restatement(world):
+    """Row-partitioned contexts (csrc/amg_dist.cpp): every rank aggregates the graph of its own rows without the edges that
+    leave it, aggregates are numbered rank by rank, everything else is the single-rank method.  CPU side of that contract: the
+    restatement's aggregate_by_rank equals the library's host aggregation (femshell_amg_host_aggregate) run rank by rank on
+    the rank's sub-graph, no aggregate spans two ranks, and the hierarchy built from such aggregates still solves the system
+    in about the iterations of the single-rank hierarchy."""
+    ensure_built()
+    b = _binding()
+    m = meshes.structured(48, 40, 0, 0, 6, 5, kind="t", ul_lr=True, bcids=(0, 0, 1, -1), factor=300.0, loading=2)
+    mat = oracle.material(0.3, 1e7, 0.5)
+    r, c, v, F = oracle.assemble(m.xyz, m.tri, m.quad, mat, m.dirichlet_mask(), m.loads)
+    A = oracle.to_scipy(r, c, v).tobsr((6, 6))
+    A.sort_indices()
+    n = m.n_nodes
+    bounds = amg_oracle.partition_bounds_equal(n, world)
+    assert bounds[0] == 0 and bounds[-1] == n and all(x % 32 == 0 for x in bounds[1:-1])
+    agg, na, cb = amg_oracle.aggregate_by_rank(A.indptr, A.indices, bounds)
+    assert len(cb) == world + 1 and cb[-1] == na
+    rank_of_node = np.searchsorted(bounds, np.arange(n), side="right") - 1
+    rank_of_agg = np.searchsorted(cb, agg, side="right") - 1
+    np.testing.assert_array_equal(rank_of_node, rank_of_agg)  # no aggregate spans two ranks
+    for k in range(world):  # the library's host aggregation on the rank's own sub-graph
+        b0, b1 = bounds[k], bounds[k + 1]
+        sub = A.tocsr()[6 * b0:6 * b1, 6 * b0:6 * b1].tobsr((6, 6))
+        sub.sort_indices()
+        got, got_na = b.amg_host_aggregate(sub.indptr, sub.indices)
+        assert got_na == cb[k + 1] - cb[k]
+        np.testing.assert_array_equal(got + cb[k], agg[b0:b1])
+    one = amg_oracle.setup(A, m.xyz, m.dirichlet_mask(), coarsest_nodes=60, tri=m.tri)
+    u1, h1 = amg_oracle.solve(A, F.ravel(), one, rtol=1e-10, max_it=300, refine_passes=1)
+    for dist_min in (60000, 100):
+        lv = amg_oracle.setup(A, m.xyz, m.dirichlet_mask(), coarsest_nodes=60, tri=m.tri, bounds=bounds, dist_min=dist_min)
+        assert [L.bounds is not None for L in lv][:2] == [True, dist_min == 100]
+        u, h = amg_oracle.solve(A, F.ravel(), lv, rtol=1e-10, max_it=300, refine_passes=1)
+        assert len(h) <= 1.2 * len(h1) + 2, (world, dist_min, len(h), len(h1))
+        assert np.linalg.norm(u - u1) <= 1e-9 * np.linalg.norm(u1)
