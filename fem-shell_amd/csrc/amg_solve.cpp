@@ -527,7 +527,10 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
             const int64_t nm = (int64_t)A.n_slices * 21 * kSliceNodes;
             FS_HIP(L.minv32.alloc((size_t)nm));
             launch_to_f32(A.minv, L.minv32.p, nm, st);
-            if (mode != 2 && L.P.vals.n > 0 && L.R.vals.n > 0) {
+            // (transfers onto a small level are bound by latency, where half-width loads lose: R onto the 1231-node level
+            //  22 -> 36 us in single precision)
+            const bool big_coarse = mode == 3 || H.levels[l + 1]->n >= 4096 || H.levels[l + 1]->n_global >= 4096;
+            if (mode != 2 && big_coarse && L.P.vals.n > 0 && L.R.vals.n > 0) {
                 FS_HIP(L.P32.alloc(L.P.vals.n));
                 FS_HIP(L.R32.alloc(L.R.vals.n));
                 launch_to_f32(L.P.vals.p, L.P32.p, (int64_t)L.P.vals.n, st);
