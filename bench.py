@@ -684,8 +684,9 @@ def main():
                    "roofline": {"bound": "mfma", "achieved": dst["mfma_flops_issued"] / max(dst["ms"], 1e-9) / 1e9, "peak": 78.6,
                                 "unit": "TFLOP/s", "frac": dst["mfma_flops_issued"] / max(dst["ms"], 1e-9) / 1e9 / 78.6,
                                 "note": "FP64 matrix peak 78.6 TFLOP/s; 64x64 tiles, block sweeps of width 128: the lower triangle is read and "
-                                        "written once per sweep (58 sweeps at 7386 dofs); of the 17 ms the trailing update takes 9.4, the "
-                                        "one-workgroup inverse of the 128 x 128 pivot blocks 4.1, the panel products 2.3"}},
+                                        "written once per sweep (58 sweeps at 7386 dofs); the pivot block of the next sweep is inverted by a "
+                                        "reserved workgroup inside the trailing update's launch (17.1 ms with a launch of its own in front of "
+                                        "every sweep, FEMSHELL_AMG_DENSE_LOOKAHEAD=0)"}},
                "block_jacobi_alone": jacobi_extrapolation(jacobi_hist)}
         free_b, total_b = torch.cuda.mem_get_info()
         tts["hbm_in_use_gb_max_over_ranks"] = max_over_ranks((total_b - free_b) / 1e9)

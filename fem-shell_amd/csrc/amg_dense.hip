@@ -71,6 +71,47 @@ __global__ __launch_bounds__(256) void k_dense_symmetrize(double *__restrict__ D
     if (r == c) diag0[r] = v;
 }
 
+// The sweeps read and write the lower triangle only, and the lower triangle of a Galerkin operator is as good a symmetric
+// matrix as the mean of its two triangles (they differ in the 16th digit): nothing to symmetrise, only the diagonal to copy
+// for the pivot test and a unit diagonal to put on the padding rows (0.31 ms of transposed reads less at 7386 dofs).
+__global__ __launch_bounds__(256) void k_dense_prepare(double *__restrict__ D, int64_t ld, int n, int n_pad, double *__restrict__ diag0)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_pad) diag0[e] = e < n ? D[e * ld + e] : 1.0;
+    // padding rows: (n_pad - n) x n_pad entries
+    const int64_t q = e;
+    if (q < (int64_t)(n_pad - n) * n_pad) {
+        const int r = n + (int)(q / n_pad), c = (int)(q % n_pad);
+        if (c <= r) D[(int64_t)r * ld + c] = r == c ? 1.0 : 0.0;
+    }
+}
+
+// out (n x ldo, both triangles) <- -(lower triangle of D), tile by tile: the tile goes out as it is and, transposed through
+// LDS, as its mirror image (coalesced on both sides; the element-wise version read the upper half column-wise)
+template <class T>
+__global__ __launch_bounds__(256) void k_dense_finish_tiled(const double *__restrict__ D, int64_t ld, int n, T *__restrict__ out, int64_t ldo)
+{
+    __shared__ double tile[kNB][kNB + 1];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    int i = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= t) i++;
+    while (i * (i + 1) / 2 > t) i--;
+    const int j = t - i * (i + 1) / 2;
+    for (int e = tid; e < kNB * kNB; e += 256) {
+        const int r = e / kNB, c = e % kNB;
+        const int gr = i * kNB + r, gc = j * kNB + c;
+        const double v = (gr < n && gc < n) ? -D[(int64_t)gr * ld + gc] : 0.0;
+        tile[r][c] = v;
+        if (gr < n && gc < ldo && (i != j || c <= r)) out[(int64_t)gr * ldo + gc] = (T)v; // (gc in [n, ldo): the zero padding column)
+    }
+    __syncthreads();
+    for (int e = tid; e < kNB * kNB; e += 256) {
+        const int c = e / kNB, r = e % kNB; // out row = tile column
+        const int gr = j * kNB + c, gc = i * kNB + r;
+        if (gr < n && gc < ldo && (i != j || r > c)) out[(int64_t)gr * ldo + gc] = (T)((gc < n) ? tile[r][c] : 0.0);
+    }
+}
+
 // ---- the 64 x 64 building block: s <- -(s^-1) on the live directions ---------------------------------------------
 // Thread (bi, bj) of a 256-thread workgroup keeps the 4 x 4 sub-block (4 bi .., 4 bj ..) of a symmetric 64 x 64 block in
 // registers; the block is swept four pivots at a time: the four rows of a step (= its four columns) travel through a
@@ -329,22 +370,228 @@ __global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ 
     pivot_block(D, ld, K, diag0, B, status, lds_dense, lds_dense + 4 * kNB * kLdp);
 }
 
+// ---- the same pivot inverse for a workgroup that has 35 KB of LDS and 128 VGPRs (the look-ahead inside k_dense_update) --------
+// sweep64 with the row panel consumed as it is read: s, the 4 x 4 pivot sub-block and one 4 x 4 product live in registers
+// (52 doubles instead of 100), the rows of the step come from LDS a row of four at a time
+__device__ __forceinline__ void sweep64_lean(double s[4][4], const double *a0, double (*rowbuf)[4][kNB], int bi, int bj, int &n_dead,
+                                             int &n_failed)
+{
+    for (int g = 0; g < kNB / 4; g++) {
+        const int cur = g & 1;
+        if (bi == g) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) rowbuf[cur][k][4 * bj + b] = s[k][b];
+        }
+        __syncthreads();
+        double m[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int l = 0; l < 4; l++) m[k][l] = rowbuf[cur][k][4 * g + l];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double d = m[k][k], a = a0[4 * g + k];
+            const bool failed = !(a > 0.0) || d < -1e-4 * fabs(a);
+            const bool dead = failed || d <= 1e-11 * a;
+            n_failed += failed ? 1 : 0;
+            n_dead += dead ? 1 : 0;
+            double inv = 0.0;
+            if (!dead) {
+                inv = __builtin_amdgcn_rcp(d);
+                inv = inv * (2.0 - d * inv);
+                inv = inv * (2.0 - d * inv);
+            }
+            double col[4];
+#pragma unroll
+            for (int l = 0; l < 4; l++) col[l] = m[l][k];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (i == k || j == k) continue;
+                    m[i][j] -= col[i] * col[j] * inv;
+                }
+#pragma unroll
+            for (int l = 0; l < 4; l++) {
+                if (l == k) continue;
+                const double v = col[l] * inv;
+                m[l][k] = v;
+                m[k][l] = v;
+            }
+            m[k][k] = -inv;
+        }
+        // ti = -R_i^T m, one row of the panel at a time
+        double ti[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int l = 0; l < 4; l++) ti[a][l] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            double ri[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) ri[q] = rowbuf[cur][k][4 * bi + q];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int l = 0; l < 4; l++) ti[a][l] -= ri[a] * m[k][l];
+        }
+        if (bi == g && bj == g) {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) s[a][b] = m[a][b];
+        } else if (bj == g) {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) s[a][b] = ti[a][b];
+        } else {
+            const bool row_of_step = bi == g;
+            if (row_of_step) {
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++) s[a][b] = 0.0;
+            }
+#pragma unroll
+            for (int l = 0; l < 4; l++) {
+                double rj[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) rj[q] = rowbuf[cur][l][4 * bj + q];
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++) s[a][b] -= (row_of_step ? m[a][l] : ti[a][l]) * rj[b];
+            }
+        }
+    }
+    __syncthreads(); // rowbuf may be reused
+}
+
+// acc += X Y^T for two 64 x 64 blocks in HBM (row stride kLdp), staged through LDS in two chunks of 32 columns of K (two
+// 64 x 34 panels = the 35 KB of an update workgroup), the wave's 32 x 32 quadrant on the matrix cores
+__device__ __forceinline__ void staged_xyt(const double *__restrict__ Xg, const double *__restrict__ Yg, double *lds, int r0, int c0,
+                                           int lane, int tid, v4d acc[2][2])
+{
+    double *Xs = lds, *Ys = lds + kNB * kLdh;
+    for (int ch = 0; ch < kNB / kHalf; ch++) {
+        __syncthreads(); // the previous readers of the panels are through; the blocks in HBM are complete
+        for (int e = tid; e < kNB * kHalf / 2; e += 256) {
+            const int r = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));
+            *reinterpret_cast<double2 *>(Xs + r * kLdh + k) = *reinterpret_cast<const double2 *>(Xg + r * kLdp + ch * kHalf + k);
+            *reinterpret_cast<double2 *>(Ys + r * kLdh + k) = *reinterpret_cast<const double2 *>(Yg + r * kLdp + ch * kHalf + k);
+        }
+        __syncthreads();
+        quadrant_xyt<kHalf, kLdh>(Xs, Ys, r0, c0, lane, acc);
+    }
+}
+
+// pivot_block for such a workgroup: P0 .. P3 in HBM scratch (cache resident), lds = 2 x 64 x 34 doubles, used as the row
+// panel + diagonal entries during the sweeps and as the two operand panels during the products
+__device__ __forceinline__ void pivot_block_lean(const double *__restrict__ D, int64_t ld, int K, const double *__restrict__ diag0,
+                                                 double *__restrict__ B, int32_t *status, double *panels, double *lds)
+{
+    constexpr int L = kLdp;
+    double *P0 = panels, *P1 = P0 + kNB * L, *P2 = P1 + kNB * L, *P3 = P2 + kNB * L;
+    double (*rowbuf)[4][kNB] = reinterpret_cast<double (*)[4][kNB]>(lds);
+    double *a0 = lds + 2 * 4 * kNB;
+    const int tid = threadIdx.x, k0 = 2 * K * kNB, bi = tid >> 4, bj = tid & 15;
+    const int wave = tid >> 6, lane = tid & 63, r0 = 32 * (wave >> 1), c0 = 32 * (wave & 1);
+    double s[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int r = 4 * bi + a, c = 4 * bj + b;
+            s[a][b] = r >= c ? D[(int64_t)(k0 + r) * ld + k0 + c] : D[(int64_t)(k0 + c) * ld + k0 + r];
+            P1[r * L + c] = D[(int64_t)(k0 + kNB + r) * ld + k0 + c]; // C
+        }
+    if (tid < 2 * kNB) a0[tid] = diag0[k0 + tid];
+    __syncthreads();
+    int n_dead = 0, n_failed = 0;
+    sweep64_lean(s, a0, rowbuf, bi, bj, n_dead, n_failed); // s = -B_A
+    double a0_second = tid < kNB ? a0[kNB + tid] : 0.0;     // (the products take the LDS: the second block's diagonal rides in registers)
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) P0[(4 * bi + a) * L + 4 * bj + b] = -s[a][b];
+    v4d w[2][2];
+    auto zero = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) w[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    };
+    zero();
+    staged_xyt(P1, P0, lds, r0, c0, lane, tid, w); // W = C B_A
+    for_quadrant(r0, c0, lane, [&](int ti, int tj, int g, int r, int c) {
+        P2[r * L + c] = w[ti][tj][g];
+        P3[c * L + r] = w[ti][tj][g];
+    });
+    // S = D22 - W C^T: the accumulator starts from -D22
+    for_quadrant(r0, c0, lane, [&](int ti, int tj, int g, int r, int c) {
+        w[ti][tj][g] = -(r >= c ? D[(int64_t)(k0 + kNB + r) * ld + k0 + kNB + c] : D[(int64_t)(k0 + kNB + c) * ld + k0 + kNB + r]);
+    });
+    staged_xyt(P2, P1, lds, r0, c0, lane, tid, w); // W C^T - D22
+    __syncthreads();                                // every wave is through with C
+    for_quadrant(r0, c0, lane, [&](int ti, int tj, int g, int r, int c) { P1[r * L + c] = -w[ti][tj][g]; }); // S
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) s[a][b] = P1[(4 * bi + a) * L + 4 * bj + b];
+    if (tid < kNB) a0[tid] = a0_second;
+    __syncthreads();
+    sweep64_lean(s, a0, rowbuf, bi, bj, n_dead, n_failed); // s = -B_S
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int r = 4 * bi + a, c = 4 * bj + b;
+            P1[r * L + c] = -s[a][b];
+            B[(kNB + r) * kSW + kNB + c] = -s[a][b]; // X22 = B_S
+        }
+    zero();
+    staged_xyt(P1, P3, lds, r0, c0, lane, tid, w); // B_S W = B_S (W^T)^T
+    __syncthreads();                                // every wave is through with W^T ... and nobody reads W any more
+    for_quadrant(r0, c0, lane, [&](int ti, int tj, int g, int r, int c) {
+        const double v = -w[ti][tj][g]; // X21 = -B_S W
+        B[(kNB + r) * kSW + c] = v;
+        B[c * kSW + kNB + r] = v;       // X12 = X21^T
+        P2[c * L + r] = v;              // X21^T for the last product
+    });
+    zero();
+    staged_xyt(P3, P2, lds, r0, c0, lane, tid, w); // W^T X21 = W^T (X21^T)^T
+    for_quadrant(r0, c0, lane, [&](int ti, int tj, int g, int r, int c) { B[r * kSW + c] = P0[r * L + c] - w[ti][tj][g]; }); // X11
+    if (tid == 0 && n_dead) {
+        if (n_failed) status[0] = 1;
+        atomicAdd(&status[1], n_dead);
+    }
+}
+
 // C_i = A(i, block K) (64 x 128), gathered from the lower triangle (tiles (i, 2K), (i, 2K+1) below the pivot block, the
 // transposed tiles (2K, i), (2K+1, i) above it), W_i = C_i B on the matrix cores.  One workgroup per 64-row block; the two
 // block rows of the pivot block itself are skipped.  K runs in four chunks of 32 through LDS (row stride 34 doubles: the 32
 // lanes of a ds_read_b64 group hit 32 different bank pairs); B is symmetric, so W = C B = C (B^T)^T has the X Y^T form and
 // both operands are read the same way.  Wave w computes the output columns [32 w, 32 w + 32) of all 64 rows.
+// (kSplit: two workgroups per 64-row block, 32 rows each -- 2 x 116 workgroups instead of 116 on 256 CUs; the panel product
+//  sits between the pivot inverse and the trailing update of every sweep, on the critical path)
+template <bool kSplit>
 __global__ __launch_bounds__(256) void k_dense_panels(const double *__restrict__ D, int64_t ld, int K, const double *__restrict__ B,
                                                       double *__restrict__ Cp, double *__restrict__ Wp)
 {
-    __shared__ double Cs[kNB * kLdh];
+    constexpr int kRows = kSplit ? kNB / 2 : kNB; // rows of C_i this workgroup takes
+    __shared__ double Cs[kRows * kLdh];
     __shared__ double Bs[kSW * kLdh];
-    const int i = blockIdx.x, tid = threadIdx.x;
+    const int i = kSplit ? blockIdx.x >> 1 : blockIdx.x, row0 = kSplit ? (blockIdx.x & 1) * kRows : 0, tid = threadIdx.x;
     if ((i >> 1) == K) return;
     const int wave = tid >> 6, lane = tid & 63;
-    v4d acc[2][2][2]; // [row half][ti][tj]
+    v4d acc[kRows / 32][2][2]; // [row half][ti][tj]
 #pragma unroll
-    for (int h = 0; h < 2; h++)
+    for (int h = 0; h < kRows / 32; h++)
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -352,9 +599,9 @@ __global__ __launch_bounds__(256) void k_dense_panels(const double *__restrict__
     const bool below = i > 2 * K + 1;
     for (int ch = 0; ch < kSW / kHalf; ch++) { // columns [32 ch, 32 ch + 32) of C_i = K range of the product
         if (ch) __syncthreads();
-        for (int e = tid; e < kNB * kHalf; e += 256) {
+        for (int e = tid; e < kRows * kHalf; e += 256) {
             const int r = e / kHalf, k = e % kHalf, col = kHalf * ch + k; // column of the sweep block
-            const int64_t gr = (int64_t)i * kNB + r, gc = (int64_t)2 * K * kNB + col;
+            const int64_t gr = (int64_t)i * kNB + row0 + r, gc = (int64_t)2 * K * kNB + col;
             const double v = below ? D[gr * ld + gc] : D[gc * ld + gr]; // (above: a transposed, column-wise read)
             Cs[r * kLdh + k] = v;
             Cp[gr * kSW + col] = v;
@@ -365,31 +612,33 @@ __global__ __launch_bounds__(256) void k_dense_panels(const double *__restrict__
         }
         __syncthreads();
 #pragma unroll
-        for (int h = 0; h < 2; h++) quadrant_xyt<kHalf, kLdh>(Cs, Bs, 32 * h, 32 * wave, lane, acc[h]);
+        for (int h = 0; h < kRows / 32; h++) quadrant_xyt<kHalf, kLdh>(Cs, Bs, 32 * h, 32 * wave, lane, acc[h]);
     }
 #pragma unroll
-    for (int h = 0; h < 2; h++)
+    for (int h = 0; h < kRows / 32; h++)
 #pragma unroll
         for (int ti = 0; ti < 2; ti++)
 #pragma unroll
             for (int tj = 0; tj < 2; tj++)
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    const int r = 32 * h + 16 * ti + (lane >> 4) + 4 * g, c = 32 * wave + 16 * tj + (lane & 15);
+                    const int r = row0 + 32 * h + 16 * ti + (lane >> 4) + 4 * g, c = 32 * wave + 16 * tj + (lane & 15);
                     Wp[((int64_t)i * kNB + r) * kSW + c] = acc[h][ti][tj][g];
                 }
 }
 
-// Look-ahead of the block sweep (la.on; FEMSHELL_AMG_DENSE_LOOKAHEAD=1, off by default): the three tiles of the NEXT pivot
+// Look-ahead of the block sweep (la.on; FEMSHELL_AMG_DENSE_LOOKAHEAD=0 switches it off): the three tiles of the NEXT pivot
 // block are the first workgroups of the grid; they count themselves done in la.flag (release), and workgroup 3 -- which has
 // no tile -- waits for them (acquire, bounded) and inverts that block into la.B_next while the other workgroups update the
-// rest of the triangle, so that the one-workgroup pivot inverse (71 us of dependent steps per sweep, 4.1 of 17.2 ms at 7386
-// dofs) would leave the critical path without a second stream and its event waits (round 3: 29.7 ms).  Its 64 x 66 work
-// blocks live in la.scratch (HBM, cache resident) because a workgroup of this kernel has 35 KB of LDS, not the 138 KB
-// k_dense_pivot takes.  MEASURED (round 4, 7386 dofs): same inverse, same iterations, but 19.2 ms against 17.2: with its
-// operands behind global loads and 194 live registers squeezed into 128 the pivot workgroup takes about 290 us, longer than
-// the 161 us update it was meant to hide behind.  Kept as the measured alternative; what it would take: the products staged
-// through the 35 KB in chunks of 32 columns like the update's own, and a sweep64 that lives in 64 doubles of registers.
+// rest of the triangle.  The one-workgroup pivot inverse (71 us of dependent steps per sweep, 4.1 of 17.2 ms at 7386 dofs)
+// thereby leaves the critical path without a second stream and its event waits (round 3: 29.7 ms that way).  A workgroup of
+// this kernel has 35 KB of LDS and 128 VGPRs where k_dense_pivot takes 138 KB and 194, so the look-ahead runs
+// pivot_block_lean: the 64 x 66 work blocks in la.scratch (HBM, cache resident), every product staged through the 35 KB
+// in two chunks of 32 columns like the update's own operands, and a sweep that consumes its row panel as it reads it.
+// MEASURED (round 4, 7386 dofs, alternating on one box): 17.1 ms without -> 14.2 ms -> 13.2 ms with the panel kernel's rows
+// split over two workgroups and the symmetrisation pass dropped = 32.2 TFLOP/s issued = 41 % of the FP64 matrix peak.  (The
+// first version ran the unchanged pivot_block with its blocks in HBM: its products behind global loads and 68 spilled
+// doubles took 290 us per sweep, longer than the 161 us update -- 19.2 ms.)
 struct DenseLookAhead {
     int on = 0;
     const double *diag0 = nullptr;
@@ -399,8 +648,7 @@ struct DenseLookAhead {
 };
 
 // one workgroup per lower 64 x 64 tile (i >= j): the sweep of the 128-wide block K
-// (kLookAhead = false: the kernel without the pivot workgroup's code -- that code spills at the 128 VGPRs four workgroups per
-//  CU leave, 544 B of scratch per lane, and a kernel that carries it pays for it in every workgroup: 17.5 against 17.2 ms)
+// (kLookAhead = false: the kernel without the pivot workgroup's code -- the last sweep, and FEMSHELL_AMG_DENSE_LOOKAHEAD=0)
 template <bool kLookAhead>
 __global__ __launch_bounds__(256, 4) void k_dense_update(double *__restrict__ D, int64_t ld, int K, const double *__restrict__ B,
                                                          const double *__restrict__ Cp, const double *__restrict__ Wp, int tiles,
@@ -432,7 +680,7 @@ __global__ __launch_bounds__(256, 4) void k_dense_update(double *__restrict__ D,
             __syncthreads();
             if (!ok) return;
             __threadfence(); // (acquire for every thread's loads of the three tiles)
-            pivot_block(D, ld, K + 1, la.diag0, la.B_next, la.status, la.scratch, lds_upd);
+            pivot_block_lean(D, ld, K + 1, la.diag0, la.B_next, la.status, la.scratch, lds_upd);
             return;
         }
         // blockIdx 0..2 -> t_a, t_b, t_c; blockIdx 4.. -> its own index shifted by one, and whoever lands on t_a / t_b / t_c
@@ -601,7 +849,13 @@ int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precisio
     FS_HIP(hipEventRecord(e0, st));
     const int64_t nent = (int64_t)A.val.size();
     hipLaunchKernelGGL(k_dense_scatter, dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, st, dptr.p, dcol.p, dval.p, A.nr, D.p, ld);
-    hipLaunchKernelGGL(k_dense_symmetrize, dim3((unsigned)(((int64_t)n_pad * n_pad + 255) / 256)), dim3(256), 0, st, D.p, ld, n, n_pad, diag0.p);
+    // FEMSHELL_AMG_DENSE_SYMMETRIZE=1: the mean of the two triangles as before round 4 (A/B runs)
+    if (getenv("FEMSHELL_AMG_DENSE_SYMMETRIZE") && atoi(getenv("FEMSHELL_AMG_DENSE_SYMMETRIZE")) == 1) {
+        hipLaunchKernelGGL(k_dense_symmetrize, dim3((unsigned)(((int64_t)n_pad * n_pad + 255) / 256)), dim3(256), 0, st, D.p, ld, n, n_pad, diag0.p);
+    } else {
+        const int64_t work = std::max<int64_t>(n_pad, (int64_t)(n_pad - n) * n_pad);
+        hipLaunchKernelGGL(k_dense_prepare, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, D.p, ld, n, n_pad, diag0.p);
+    }
     const int tiles = nt * (nt + 1) / 2;
     // LDS of the pivot kernel: four 64 x 66 blocks, the row panel of the sweeps, 128 diagonal entries
     const size_t lds_pivot = (4 * (size_t)kNB * kLdp + 2 * 4 * kNB + 2 * kNB) * sizeof(double);
@@ -609,14 +863,15 @@ int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precisio
     // (the pivot kernel is one workgroup and 70 us of dependent steps; running it on a second stream beside the previous
     //  sweep's update, after bringing its three tiles up to date first, was measured: the two event waits per sweep cost more
     //  than the overlap gains, 17.3 -> 29.7 ms)
-    // FEMSHELL_AMG_DENSE_LOOKAHEAD=1: the next sweep's pivot inverse inside the update's launch (measured: slower, see
-    // DenseLookAhead); default: a launch of its own in front of every sweep
-    const bool lookahead = getenv("FEMSHELL_AMG_DENSE_LOOKAHEAD") && atoi(getenv("FEMSHELL_AMG_DENSE_LOOKAHEAD")) == 1;
+    // FEMSHELL_AMG_DENSE_LOOKAHEAD=0: the pivot inverse as a launch of its own in front of every sweep (A/B runs)
+    const bool lookahead = !(getenv("FEMSHELL_AMG_DENSE_LOOKAHEAD") && atoi(getenv("FEMSHELL_AMG_DENSE_LOOKAHEAD")) == 0);
+    const bool panel_split = !(getenv("FEMSHELL_AMG_DENSE_PANEL_SPLIT") && atoi(getenv("FEMSHELL_AMG_DENSE_PANEL_SPLIT")) == 0);
     for (int K = 0; K < ns; K++) {
         double *Bk = B.p + (size_t)(K & 1) * kSW * kSW;
         if (K == 0 || !lookahead)
             hipLaunchKernelGGL(k_dense_pivot, dim3(1), dim3(256), lds_pivot, st, D.p, ld, K, diag0.p, Bk, dstatus.p);
-        hipLaunchKernelGGL(k_dense_panels, dim3(nt), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p);
+        if (panel_split) hipLaunchKernelGGL(k_dense_panels<true>, dim3(2 * nt), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p);
+        else hipLaunchKernelGGL(k_dense_panels<false>, dim3(nt), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p);
         DenseLookAhead la;
         if (lookahead && K + 1 < ns) {
             la.on = 1;
@@ -631,12 +886,13 @@ int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precisio
     }
     const int64_t ldo = (n + 1) / 2 * 2;
     const unsigned gfin = (unsigned)(((int64_t)n * ldo + 255) / 256);
+    (void)gfin;
     if (single_precision) {
         FS_HIP(inv32->alloc((size_t)n * ldo));
-        hipLaunchKernelGGL(k_dense_finish<float>, dim3(gfin), dim3(256), 0, st, D.p, ld, n, inv32->p, ldo);
+        hipLaunchKernelGGL(k_dense_finish_tiled<float>, dim3(tiles), dim3(256), 0, st, D.p, ld, n, inv32->p, ldo);
     } else {
         FS_HIP(inv64->alloc((size_t)n * ldo));
-        hipLaunchKernelGGL(k_dense_finish<double>, dim3(gfin), dim3(256), 0, st, D.p, ld, n, inv64->p, ldo);
+        hipLaunchKernelGGL(k_dense_finish_tiled<double>, dim3(tiles), dim3(256), 0, st, D.p, ld, n, inv64->p, ldo);
     }
     FS_HIP(hipEventRecord(e1, st));
     int32_t hstatus[2] = {0, 0};

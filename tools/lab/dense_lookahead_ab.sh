@@ -1,6 +1,8 @@
 #!/bin/bash
-# the pivot inverse of the coarsest inverse inside the trailing update's launch (FEMSHELL_AMG_DENSE_LOOKAHEAD=1) against a launch of its own (default)
-for f in 1 0 1 0; do
-  echo "== FEMSHELL_AMG_DENSE_LOOKAHEAD=$f"
-  FEMSHELL_AMG_DENSE_LOOKAHEAD=$f python3 tools/amg_probe.py panel 1414 2>&1 | grep -E "dense inverse|second solve" | cut -c1-330
+# the coarsest inverse (7386 dofs): pivot inverse inside the trailing update's launch (FEMSHELL_AMG_DENSE_LOOKAHEAD) and the
+# panel kernel's rows split over two workgroups (FEMSHELL_AMG_DENSE_PANEL_SPLIT), alternating on one box
+for cfg in "1 1" "0 0" "1 0" "0 1" "1 1" "0 0"; do
+  set -- $cfg
+  echo "== LOOKAHEAD=$1 PANEL_SPLIT=$2"
+  FEMSHELL_AMG_DENSE_LOOKAHEAD=$1 FEMSHELL_AMG_DENSE_PANEL_SPLIT=$2 python3 tools/amg_probe.py panel 1414 2>&1 | grep -E "dense inverse" | cut -c1-200
 done
