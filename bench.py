@@ -749,8 +749,10 @@ def main():
                                    % (args.nx, args.nx, n_elem, n_nodes, 6 * n_nodes),
                        "parallelism": "row-partition x%d" % world, "cg_iters_per_step": args.cg_iters,
                        "assembly_step": "femshell_assemble_async x steps, one femshell_sync (status of all steps collected there)",
+                       "untimed_before_the_timed_steps": "1 cold assembly (ms_first_assembly_cold), 30 assemblies + 200 CG iterations of device warm-up "
+                                                         "(clocks, TLBs), then the --warmup steps of the contract",
                        "preconditioner": "6x6 block-Jacobi", "symbolic_setup_s": setup_s,
-                       "matrix_storage": "symmetric (diagonal + blocks of the lower-numbered row)" if symmetric else "full",
+                       "matrix_storage": "symmetric (upper triangles of the diagonal blocks + the blocks of the lower-numbered row)" if symmetric else "full",
                        "rccl_ranks_seen": rccl_ranks, "box_streaming_copy_gb_per_s": copy_gbs},
             # `roofline` belongs to `value`: the kernel the timed assembly steps consist of
             "roofline": dict(roof(asm_ms, asm_bytes, asm_kernel), kernel=asm_kernel + " (element records -> block slots -> K and F; the kernel "
