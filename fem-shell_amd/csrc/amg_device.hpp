@@ -165,10 +165,11 @@ void launch_dense_gemv_big(const double *A64, const float *A32, int64_t lda, con
 // (A: the level operator in HBM, block-Jacobi inverse valid; pat: host copy of its pattern; want_host(coarse nodes): bring
 //  the coarse operator back as a host matrix -- needed when the next step runs on the host or the level is the coarsest)
 // (B: the level's near-null space in HBM -- generated from the mesh on level 0, the previous step's Bc_dev below; the
-//  tentative prolongator is factorised there.  Bc_dev: the coarse level's near-null space in HBM; Bc_out: its host copy,
+//  tentative prolongator is factorised there.  lam_of: hands over the spectral bound of the level when the prolongator is
+//  smoothed -- its power iteration runs on the device beside this function's host work.  Bc_dev: the coarse level's near-null space in HBM; Bc_out: its host copy,
 //  filled under the same condition as Ac_host)
 int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &A, const HostEllPattern &pat, AmgLevel &L, AmgLevel &next,
-                       const NearNullSrc &B, double lam, bool keep_host, const std::function<bool(int32_t)> &want_host,
+                       const NearNullSrc &B, const std::function<int(double *)> &lam_of, bool keep_host, const std::function<bool(int32_t)> &want_host,
                        Bsr *Ac_host, std::vector<double> *Bc_out, DevBuf<double> *Bc_dev,
                        const std::function<void(const char *)> &lap);
 // the pattern of the context's K (level 0) from the plan

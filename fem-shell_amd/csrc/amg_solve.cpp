@@ -67,26 +67,41 @@ int attach_in_lists(AmgOperator &op, const SlicedEllSym &S, int64_t total_slots,
 
 namespace {
 
-// lambda_max(D^-1 A) of a level by power iteration on the device (x <- D^-1 A x, ratio of consecutive norms)
-int power_iteration(femshell_ctx *c, AmgLevel &L, const DeviceMatrix &A, int iterations, double *lam_out)
+// lambda_max(D^-1 A) of a level by power iteration on the device (x <- D^-1 A x, ratio of consecutive norms).  In two halves:
+// the launches, and -- when lambda is needed -- the one synchronisation that brings the last two norms back; a coarsening
+// step on the device does its host-side graph work (aggregation, patterns: 0.16 s on the 4M-triangle meshes) in between
+// while the GPU iterates.
+struct PowerIteration {
+    DevBuf<double> part;
+    int G = 0, iterations = 0;
+};
+
+int power_iteration_start(femshell_ctx *c, AmgLevel &L, const DeviceMatrix &A, int iterations, PowerIteration *pw)
 {
     hipStream_t st = c->stream;
-    const int G = slice_grid(A);
+    pw->G = slice_grid(A);
     // lambda is the ratio of the last two norms: only those come back to the host (one synchronisation instead of one per
     // step; without normalisation the iterate grows like lambda^k, lambda ~ 2, which 30 steps of FP64 take easily)
-    DevBuf<double> part;
-    FS_HIP(part.alloc(2 * (size_t)G));
-    std::vector<double> h(2 * (size_t)G);
+    FS_HIP(pw->part.alloc(2 * (size_t)pw->G));
     double *x = L.d.p, *z = L.r.p;
     launch_fill_hash(x, 6ll * L.n, 6ll * L.n_pad, st);
     if (iterations < 2) iterations = 2;
+    pw->iterations = iterations;
     for (int it = 0; it < iterations; it++) {
         launch_spmv(A, x, L.q.p, nullptr, nullptr, st);
-        launch_minv_apply_norm(A, L.q.p, z, part.p + (size_t)(it & 1) * G, st);
+        launch_minv_apply_norm(A, L.q.p, z, pw->part.p + (size_t)(it & 1) * pw->G, st);
         std::swap(x, z);
     }
     FS_HIP(hipGetLastError());
-    FS_HIP(hipMemcpyAsync(h.data(), part.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    return FEMSHELL_OK;
+}
+
+int power_iteration_finish(femshell_ctx *c, PowerIteration &pw, double *lam_out)
+{
+    hipStream_t st = c->stream;
+    const int G = pw.G, iterations = pw.iterations;
+    std::vector<double> h(2 * (size_t)G);
+    FS_HIP(hipMemcpyAsync(h.data(), pw.part.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     FS_HIP(hipStreamSynchronize(st));
     double s_last = 0.0, s_prev = 0.0;
     const size_t last = (size_t)((iterations - 1) & 1) * G, prev = (size_t)((iterations - 2) & 1) * G;
@@ -192,7 +207,7 @@ namespace {
 struct SetupRules {
     femshell_pc_options opt{};
     bool host_only = false;
-    int32_t device_min = 20000;
+    int32_t device_min = 5000;
     // Levels of more than device_min nodes are coarsened with the numerics on the device (amg_device_setup.cpp): their
     // operator is in HBM already and only its pattern is needed on the host.  The coarse operator of such a step comes
     // back as a host matrix only when the next step runs on the host (a small level, the coarsest one, the last allowed).
@@ -218,7 +233,9 @@ SetupRules setup_rules(const femshell_pc_options &opt)
     // the first coarsening step runs its numerics on the device unless FEMSHELL_AMG_SETUP=host (amg_device_setup.cpp)
     r.host_only = getenv("FEMSHELL_AMG_SETUP") && std::string(getenv("FEMSHELL_AMG_SETUP")) == "host";
     const char *dmin_env = getenv("FEMSHELL_AMG_DEVICE_MIN"); // nodes; levels at or below it are coarsened on the host
-    r.device_min = dmin_env ? (int32_t)atol(dmin_env) : (int32_t)20000;
+    // (5000 since round 4: the 18.6k-node level of the 4M-triangle meshes on the device as well, 46 -> 32 ms for the two
+    //  steps below level 0)
+    r.device_min = dmin_env ? (int32_t)atol(dmin_env) : (int32_t)5000;
     return r;
 }
 
@@ -273,11 +290,16 @@ int amg_setup(femshell_ctx *c)
         L0.nnzb = pl.nnz_blocks;
         rc = alloc_level_vectors(L0, true, kcycle, st);
         if (rc) return rc;
-        double lam = 0.0;
-        rc = power_iteration(c, L0, c->dm, amg_power_iterations(), &lam);
+        PowerIteration pw0; // (its launches now, its result when the prolongator is smoothed: amg_device_coarsen asks for it)
+        rc = power_iteration_start(c, L0, c->dm, amg_power_iterations(), &pw0);
         if (rc) return rc;
-        L0.lam = amg_lambda_safety() * lam;
-        lap("power iteration", 0);
+        auto lam0 = [&](double *out) {
+            double lam = 0.0;
+            const int r2 = power_iteration_finish(c, pw0, &lam);
+            if (r2) return r2;
+            *out = L0.lam = amg_lambda_safety() * lam;
+            return (int)FEMSHELL_OK;
+        };
         H.levels.emplace_back(new AmgLevel());
         AmgLevel &L1 = *H.levels.back();
         std::vector<double> Bc;
@@ -297,7 +319,7 @@ int amg_setup(femshell_ctx *c)
             src.cx = ctr[0];
             src.cy = ctr[1];
             src.cz = ctr[2];
-            rc = amg_device_coarsen(c, c->dm, L0.pattern, L0, L1, src, L0.lam, keep_host, want_host_matrix(1), &A, &Bc, &Bdev,
+            rc = amg_device_coarsen(c, c->dm, L0.pattern, L0, L1, src, lam0, keep_host, want_host_matrix(1), &A, &Bc, &Bdev,
                                     [&](const char *what) { lap(what, 0); });
         }
         if (rc) return rc;
@@ -423,11 +445,21 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
             L.hA = std::move(A); // (kept at every size: a few MB, and the operator the dense inverse is checked against)
             break;
         }
-        double lam = 0.0;
-        rc = power_iteration(c, L, Adev, amg_power_iterations(), &lam);
+        PowerIteration pw;
+        rc = power_iteration_start(c, L, Adev, amg_power_iterations(), &pw);
         if (rc) return rc;
-        L.lam = amg_lambda_safety() * lam; // the power iteration approaches from below
-        lap("power iteration", l);
+        bool lam_known = false;
+        auto lam_of = [&](double *out) {
+            if (!lam_known) {
+                double lam = 0.0;
+                const int r2 = power_iteration_finish(c, pw, &lam);
+                if (r2) return r2;
+                L.lam = amg_lambda_safety() * lam; // the power iteration approaches from below
+                lam_known = true;
+            }
+            *out = L.lam;
+            return (int)FEMSHELL_OK;
+        };
         // coarsen
         if (L.A_on_device && !L.pattern.empty() && device_step(l, L.n)) {
             // on the device: the operator is in HBM, its pattern on the host (amg_device_setup.cpp)
@@ -441,7 +473,7 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
                 FS_HIP(Bdev.upload(B, st));
             }
             src.B = Bdev.p;
-            rc = amg_device_coarsen(c, L.A.dm, L.pattern, L, N, src, L.lam, keep_host, want_host_matrix(l + 1), &Anext, &Bc, &Bnext,
+            rc = amg_device_coarsen(c, L.A.dm, L.pattern, L, N, src, lam_of, keep_host, want_host_matrix(l + 1), &Anext, &Bc, &Bnext,
                                     [&](const char *what) { lap(what, l); });
             if (rc) return rc;
             std::swap(Bdev.p, Bnext.p);
@@ -454,6 +486,12 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
             continue;
         }
         if (!have_host) return set_err(FEMSHELL_ERR_INVALID, "multigrid setup: level operator neither on the host nor coarsened on the device");
+        {
+            double lam_now = 0.0;
+            rc = lam_of(&lam_now);
+            if (rc) return rc;
+            lap("power iteration", l);
+        }
         std::vector<int32_t> agg;
         const int32_t na = aggregate_nodes(A, &agg);
         lap("aggregation", l);
