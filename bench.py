@@ -635,6 +635,9 @@ def main():
                "ms_per_launch": ms, "algorithmic_bytes_per_launch": nbytes}
         if kernel in traffic:
             out["traffic_gb_per_s"] = traffic[kernel] / (ms * 1e-3) / 1e9
+            # (how fast the kernel moves the bytes it really moves, against what this box reaches with a plain device-to-device
+            #  copy of 1 GiB -- the practical roof of a mixed read / write stream, 4.8-5.2 TB/s on the boxes of this pool)
+            out["traffic_rate_over_box_streaming_copy_rate"] = out["traffic_gb_per_s"] / copy_gbs
         if kernel in fp64:  # FP64 vector peak 78.6 TFLOP/s (MI355X_MICROARCH.md)
             out["fp64_gflop_per_launch"] = fp64[kernel] / 1e9
             out["fp64_tflops"] = fp64[kernel] / (ms * 1e-3) / 1e12
