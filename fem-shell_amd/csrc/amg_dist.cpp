@@ -165,11 +165,21 @@ void fill_ghost_rows(EllPattern &E, int32_t first_row, int32_t n_ghost, int W, c
     }
 }
 
-int global_max(femshell_ctx *c, int64_t mine, int64_t *out)
+// the largest of the ranks' values -- and the ranks' agreement on a failure only some of them see: a rank hands over -1 for
+// "my part failed" (its own error text is set), and every rank leaves with an error instead of walking on into the next
+// exchange, where the healthy ones would wait for the failed one until the watchdog ends them
+int global_max(femshell_ctx *c, int64_t mine, int64_t *out, const char *what)
 {
     std::vector<int64_t> all;
+    const std::string local = mine < 0 ? last_err() : std::string();
     const int rc = allgather_i64(c, mine, &all);
     if (rc) return rc;
+    int failed = 0;
+    for (int64_t v : all) failed += v < 0 ? 1 : 0;
+    if (mine < 0) return set_err(FEMSHELL_ERR_UNSUPPORTED, local);
+    if (failed)
+        return set_err(FEMSHELL_ERR_COMM, std::string("multigrid setup: ") + what + " failed on " + std::to_string(failed) +
+                                              " other rank(s) of the row partition (their own message says why)");
     *out = *std::max_element(all.begin(), all.end());
     return FEMSHELL_OK;
 }
@@ -311,10 +321,10 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
         }
     });
     EllPattern eP, eAP, eR, eAc;
-    if (!pack_pattern(n, pptr, pcol, false, &eP))
-        return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: a row of the prolongator has more than 255 blocks");
+    bool ok = pack_pattern(n, pptr, pcol, false, &eP);
+    if (!ok) (void)set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: a row of the prolongator has more than 255 blocks");
     int64_t Wp = 0;
-    rc = global_max(c, eP.max_width, &Wp);
+    rc = global_max(c, ok ? eP.max_width : -1, &Wp, "the pattern of the prolongator");
     if (rc) return rc;
     const int64_t own_total_P = eP.total();
     append_ghost_rows(eP, n_ghost, (int)Wp);
@@ -394,10 +404,10 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
         acol.resize((size_t)aptr[(size_t)n]);
         for (int32_t a = 0; a < n; a++) std::copy(rows[(size_t)a].begin(), rows[(size_t)a].end(), acol.begin() + aptr[(size_t)a]);
     }
-    if (!pack_pattern(n, aptr, acol, false, &eAP))
-        return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: a row of A P has more than 255 blocks");
+    ok = pack_pattern(n, aptr, acol, false, &eAP);
+    if (!ok) (void)set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: a row of A P has more than 255 blocks");
     int64_t Wap = 0;
-    rc = global_max(c, eAP.max_width, &Wap);
+    rc = global_max(c, ok ? eAP.max_width : -1, &Wap, "the pattern of A P");
     if (rc) return rc;
     const int64_t own_total_AP = eAP.total();
     append_ghost_rows(eAP, n_ghost, (int)Wap);
@@ -479,12 +489,17 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
         ccol.resize((size_t)cptr[(size_t)na]);
         for (int32_t I = 0; I < na; I++) std::copy(rows[(size_t)I].begin(), rows[(size_t)I].end(), ccol.begin() + cptr[(size_t)I]);
     }
-    if (!pack_pattern(na, cptr, ccol, true, &eAc, key0))
-        return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: a row of a coarse operator has more than 255 blocks");
-    {
+    ok = pack_pattern(na, cptr, ccol, true, &eAc, key0);
+    if (!ok) (void)set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: a row of a coarse operator has more than 255 blocks");
+    if (ok) {
         std::vector<int32_t> rcol(rrow);
-        if (!pack_pattern(na, rptr, rcol, false, &eR))
-            return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: an aggregate is seen by more than 255 fine rows");
+        ok = pack_pattern(na, rptr, rcol, false, &eR);
+        if (!ok) (void)set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: an aggregate is seen by more than 255 fine rows");
+    }
+    {
+        int64_t unused = 0; // (the ranks agree before the step goes on: the exchanges below are collective)
+        rc = global_max(c, ok ? 0 : -1, &unused, "the patterns of R and the coarse operator");
+        if (rc) return rc;
     }
     DevBuf<int64_t> d_rptr;
     DevBuf<int32_t> d_rrow;
@@ -814,11 +829,15 @@ int amg_setup_dist(femshell_ctx *c)
             FS_HIP(hipGetLastError());
             FS_HIP(hipMemcpyAsync(c->status_host, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
             FS_HIP(hipStreamSynchronize(st));
-            if (*c->status_host != 0) {
+            const bool bad = *c->status_host != 0; // (seen by the rank that owns the block only: the ranks agree below)
+            if (bad) {
                 FS_HIP(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), st));
-                return set_err(FEMSHELL_ERR_BREAKDOWN, "multigrid setup: a diagonal block of coarse level " + std::to_string(l) +
-                                                           " is not positive definite");
+                (void)set_err(FEMSHELL_ERR_BREAKDOWN, "multigrid setup: a diagonal block of coarse level " + std::to_string(l) +
+                                                          " is not positive definite");
             }
+            int64_t unused = 0;
+            const int arc = global_max(c, bad ? -1 : 0, &unused, "the block-Jacobi inverse of a coarse level");
+            if (arc) return bad ? FEMSHELL_ERR_BREAKDOWN : arc;
             int64_t stored = 0;
             for (int32_t a = 0; a < L.n; a++) stored += L.pattern.count[(size_t)a];
             L.nnzb = stored;
