@@ -160,7 +160,7 @@ void pattern_of_plan(const Plan &p, HostEllPattern *out)
     H.symmetric = p.symmetric;
     H.slice_width = p.slice_width;
     H.slice_base = p.slice_base;
-    H.cols = p.cols;
+    H.cols.assign(p.cols.begin(), p.cols.end());
     H.count.assign((size_t)p.n_pad, 0);
     parallel_chunks(p.n_own, [&](int64_t a0, int64_t a1) {
         for (int64_t a = a0; a < a1; a++) {
@@ -176,8 +176,8 @@ void pattern_of_plan(const Plan &p, HostEllPattern *out)
     if (p.symmetric) {
         H.in_width = p.in_width;
         H.in_base = p.in_base;
-        H.in_slots = p.in_slots;
-        H.in_rows = p.in_rows;
+        H.in_slots.assign(p.in_slots.begin(), p.in_slots.end());
+        H.in_rows.assign(p.in_rows.begin(), p.in_rows.end());
     }
 }
 

@@ -518,6 +518,14 @@ static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double 
 {
     int rc = FEMSHELL_OK;
     TraceRange trace("femshell_set_mesh (plan + upload)");
+    // FEMSHELL_PLAN_VERBOSE=1: wall time of the call's parts on stderr (the plan prints its own phases)
+    static const bool verbose = getenv("FEMSHELL_PLAN_VERBOSE") && atoi(getenv("FEMSHELL_PLAN_VERBOSE")) != 0;
+    double t_part = wall_s();
+    auto part_done = [&](const char *what) {
+        const double t = wall_s();
+        if (verbose) fprintf(stderr, "[femshell set_mesh] %-40s %.3f s\n", what, t - t_part);
+        t_part = t;
+    };
     for (int64_t i = 0; i < 3ll * n_nodes; i++)
         if (!std::isfinite(xyz[i])) return set_err(FEMSHELL_ERR_MESH, "femshell_set_mesh: non-finite coordinate");
     std::string e;
@@ -549,6 +557,7 @@ static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double 
     if (!build_plan(n_nodes, xyz, n_tri, tri, n_quad, quad, c->cfg.rank, c->cfg.world_size, &c->plan, &e, default_symmetric_storage(),
                     /* geometric orientation of the symmetric storage when the library chose the numbering: */ !c->perm.empty()))
         return set_err(FEMSHELL_ERR_MESH, "femshell_set_mesh: " + e);
+    part_done("coordinate check, renumbering, plan");
     if (c->cfg.world_size > 1 || c->comm.active()) { // the multigrid preconditioner of a row-partitioned context builds its hierarchy from the whole mesh
         c->mesh_xyz.assign(xyz, xyz + 3ll * n_nodes);
         c->mesh_tri.assign(tri, tri + 3ll * n_tri);
@@ -575,6 +584,7 @@ static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double 
     FS_HIP(c->gat_slots.upload(p.gat_slots, st));
     FS_HIP(c->loc_index.upload(p.loc_index, st));
     FS_HIP(c->loc_list.upload(p.loc_list, st));
+    part_done("uploads of the plan");
     if (p.symmetric) {
         FS_HIP(c->tbuf.alloc((size_t)p.total_slots() * 6)); // transposed products next to every slot
         FS_HIP(c->tbuf.zero(st));
@@ -680,6 +690,7 @@ static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double 
     rc = upload_node_data(c);
     if (rc) return rc;
     FS_HIP(hipStreamSynchronize(st));
+    part_done("allocations, fills, node data");
     c->have_mesh = true;
     c->matrix_valid = c->rhs_valid = c->jacobi_valid = c->have_solution = false;
     return FEMSHELL_OK;

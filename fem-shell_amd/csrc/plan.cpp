@@ -4,6 +4,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <chrono>
@@ -23,6 +24,26 @@ int available_cpus()
         const int m = CPU_COUNT(&set);
         if (m > 0 && (n < 1 || m < n)) n = m;
     }
+    // a container's CPU quota (cgroup v2 cpu.max "quota period", v1 cfs_quota_us / cfs_period_us): a box that shows 256
+    // cores to sched_getaffinity under a quota of 16 runs 64 threads for a quarter of every period and stalls them for the
+    // rest of it
+    auto quota_cpus = []() -> int {
+        long long quota = -1, period = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = {0};
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else {
+            FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+            if (fq && fp && (fscanf(fq, "%lld", &quota) != 1 || fscanf(fp, "%lld", &period) != 1)) quota = -1;
+            if (fq) fclose(fq);
+            if (fp) fclose(fp);
+        }
+        if (quota <= 0 || period <= 0) return 0;
+        return (int)((quota + period - 1) / period);
+    };
+    static const int quota = quota_cpus();
+    if (quota > 0 && quota < n) n = quota;
     return n < 1 ? 1 : n;
 }
 
@@ -51,6 +72,10 @@ template <class F> static void plan_parallel(int64_t n, int64_t min_chunk, F f) 
     std::vector<std::thread> th;
     for (int t = 0; t < nt; t++) th.emplace_back([&f, t, n, nt] { f(t, n * t / nt, n * (t + 1) / nt); });
     for (auto &t : th) t.join();
+}
+template <class V, class T> static void plan_fill(V &v, T value) // v[i] = value on the host threads (first touch included)
+{
+    plan_parallel((int64_t)v.size(), 1 << 20, [&](int, int64_t b, int64_t e) { std::fill(v.begin() + b, v.begin() + e, value); });
 }
 static int plan_chunks(int64_t n, int64_t min_chunk)
 {
@@ -299,7 +324,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         if (adj_ptr[a + 1] == 0) return fail("node " + std::to_string(g0 + a) + " is not attached to any element");
         adj_ptr[a + 1] += adj_ptr[a];
     }
-    std::vector<uint32_t> adj((size_t)adj_ptr[n_own]);
+    RawVec<uint32_t> adj((size_t)adj_ptr[n_own]);
     {
         std::vector<int64_t> fill(adj_ptr.begin(), adj_ptr.end() - 1);
         for (int32_t e = 0; e < n_tri; e++)
@@ -340,9 +365,9 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         int32_t count;
     };
     std::vector<int32_t> node_slot_ptr((size_t)n_own + 1, 0);
-    std::vector<int32_t> slot_col;                         // global ids, per node contiguous
-    std::vector<int32_t> slot_pair_ptr(1, 0);              // per slot
-    std::vector<uint32_t> slot_pairs;
+    RawVec<int32_t> slot_col;                         // global ids, per node contiguous
+    RawVec<int32_t> slot_pair_ptr(1, 0);              // per slot
+    RawVec<uint32_t> slot_pairs;
     lap("symmetric storage: neighbour lists");
     // ---- symmetric storage: which row of an owned pair (a,c) holds the block.  Any choice works -- the SpMV applies
     // every stored off-diagonal block to both rows -- so it is made to balance the rows: the ELL width of a slice is the
@@ -352,8 +377,8 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     // intermediate row, until nothing moves.  Planar triangulations admit 3 per inner node (Schnyder); the repair gets unstructured Delaunay
     // meshes to width 4-5 where "lower row keeps" gives 6-7 and full storage 10-11.
     std::vector<int64_t> nb_ptr;
-    std::vector<int32_t> nb;      // owned neighbours (local ids), ascending per row
-    std::vector<uint8_t> nb_mine; // 1: the block (row, nb) is stored with this row
+    RawVec<int32_t> nb;      // owned neighbours (local ids), ascending per row
+    RawVec<uint8_t> nb_mine; // 1: the block (row, nb) is stored with this row
     int64_t lower_blocks = 0;
     if (symmetric) {
         nb_ptr.assign((size_t)n_own + 1, 0);
@@ -366,7 +391,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             for (int64_t q = adj_ptr[a]; q < adj_ptr[a + 1]; q++) m += ((adj[q] >> 2) < (uint32_t)n_tri) ? 2 : 3;
             ub[(size_t)a + 1] = ub[(size_t)a] + m;
         }
-        std::vector<int32_t> scratch((size_t)ub[(size_t)n_own]);
+        RawVec<int32_t> scratch((size_t)ub[(size_t)n_own]);
         std::vector<int32_t> n_distinct((size_t)n_own, 0);
         plan_parallel(n_own, 4096, [&](int, int64_t a0, int64_t a1) {
             for (int64_t a = a0; a < a1; a++) {
@@ -398,10 +423,10 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             for (int64_t a = a0; a < a1; a++)
                 std::copy_n(scratch.data() + ub[(size_t)a], n_distinct[(size_t)a], nb.data() + nb_ptr[(size_t)a]);
         });
-        std::vector<int32_t>().swap(scratch);
+        RawVec<int32_t>().swap(scratch);
         lap("symmetric storage: which row holds a block");
         std::vector<int32_t> cnt(cnt_ghost); // blocks a row stores besides its diagonal (ghost columns included)
-        nb_mine.assign(nb.size(), 0);
+        nb_mine.resize(nb.size()); // (every entry written by the loop below)
         auto index_of = [&](int32_t row, int32_t col) -> int64_t {
             return std::lower_bound(nb.begin() + nb_ptr[row], nb.begin() + nb_ptr[row + 1], col) - nb.begin();
         };
@@ -430,10 +455,8 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                             }
                         }
                     }
-                    if (mine) {
-                        nb_mine[q] = 1;
-                        cnt[a]++;
-                    }
+                    nb_mine[q] = mine ? 1 : 0;
+                    if (mine) cnt[a]++;
                 }
         });
         // local repair towards the mean
@@ -492,8 +515,10 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             std::vector<uint32_t> tmp_pairs; // packed pair
             std::vector<int32_t> tmp_next;
             std::vector<int> order;
-            std::vector<int32_t> &pc = part_col[(size_t)t], &pp = part_ptr[(size_t)t];
-            std::vector<uint32_t> &pairs_t = part_pairs[(size_t)t];
+            // (lists of the thread's own, handed over at the end: the headers of part_col[t] and part_col[t + 1] share a cache
+            //  line, and every push_back through them made the threads take turns -- this loop did not scale at all)
+            std::vector<int32_t> pc, pp;
+            std::vector<uint32_t> pairs_t;
             pc.reserve((size_t)(a1 - a0) * 8);
             pp.reserve((size_t)(a1 - a0) * 8);
             pairs_t.reserve((size_t)(adj_ptr[a1] - adj_ptr[a0]) * 3);
@@ -534,6 +559,9 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                 }
                 node_slot_ptr[(size_t)a + 1] = (int32_t)slots.size(); // count; prefix sums below
             }
+            part_col[(size_t)t].swap(pc);
+            part_ptr[(size_t)t].swap(pp);
+            part_pairs[(size_t)t].swap(pairs_t);
         });
         size_t n_slots = 0, n_pairs = 0;
         for (int t = 0; t < nchunks_r; t++) {
@@ -545,6 +573,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         for (int32_t a = 0; a < n_own; a++) node_slot_ptr[(size_t)a + 1] += node_slot_ptr[(size_t)a];
         slot_col.resize(n_slots);
         slot_pair_ptr.resize(n_slots + 1);
+        slot_pair_ptr[0] = 0;
         slot_pairs.resize(n_pairs);
         std::vector<size_t> so_of((size_t)nchunks_r + 1, 0), po_of((size_t)nchunks_r + 1, 0);
         for (int t = 0; t < nchunks_r; t++) {
@@ -585,18 +614,23 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     lap("local connectivity and coordinates");
     // ---- local copies of connectivity and coordinates
     p.tri_local.resize((size_t)n_ltri * 3);
-    for (int32_t le = 0; le < n_ltri; le++)
-        for (int i = 0; i < 3; i++) p.tri_local[3ll * le + i] = to_local(tri[3ll * p.tri_global_id[le] + i]);
+    plan_parallel(n_ltri, 1 << 16, [&](int, int64_t e0, int64_t e1) {
+        for (int64_t le = e0; le < e1; le++)
+            for (int i = 0; i < 3; i++) p.tri_local[3 * le + i] = to_local(tri[3ll * p.tri_global_id[(size_t)le] + i]);
+    });
     p.quad_local.resize(p.quad_global_id.size() * 4);
-    for (size_t le = 0; le < p.quad_global_id.size(); le++)
-        for (int i = 0; i < 4; i++) p.quad_local[4 * le + i] = to_local(quad[4ll * p.quad_global_id[le] + i]);
-    p.xyz_local.assign((size_t)p.n_local_nodes() * 3, 0.0);
-    for (int32_t a = 0; a < n_own; a++)
-        for (int d = 0; d < 3; d++) p.xyz_local[3ll * a + d] = xyz[3ll * (g0 + a) + d];
-    for (int32_t a = n_own; a < p.n_pad; a++) // padding rows: harmless copies of a real point
-        for (int d = 0; d < 3; d++) p.xyz_local[3ll * a + d] = xyz[3ll * g0 + d];
-    for (int32_t q = 0; q < p.n_ghost; q++)
-        for (int d = 0; d < 3; d++) p.xyz_local[3ll * (p.n_pad + q) + d] = xyz[3ll * p.ghost_global[q] + d];
+    plan_parallel((int64_t)p.quad_global_id.size(), 1 << 16, [&](int, int64_t e0, int64_t e1) {
+        for (int64_t le = e0; le < e1; le++)
+            for (int i = 0; i < 4; i++) p.quad_local[4 * le + i] = to_local(quad[4ll * p.quad_global_id[(size_t)le] + i]);
+    });
+    p.xyz_local.resize((size_t)p.n_local_nodes() * 3);
+    plan_parallel(p.n_local_nodes(), 1 << 16, [&](int, int64_t a0, int64_t a1) {
+        for (int64_t a = a0; a < a1; a++) {
+            // owned rows; padding rows: harmless copies of a real point; ghosts
+            const int64_t src = a < n_own ? g0 + a : (a < p.n_pad ? g0 : p.ghost_global[(size_t)(a - p.n_pad)]);
+            for (int d = 0; d < 3; d++) p.xyz_local[3 * a + d] = xyz[3 * src + d];
+        }
+    });
 
     lap("pack into slices");
     // ---- pack into slices
@@ -681,8 +715,10 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             p.max_in_width = std::max(p.max_in_width, w);
             p.in_base[s2 + 1] = p.in_base[s2] + (int64_t)w * kSliceNodes;
         }
-        p.in_slots.assign((size_t)p.in_base[p.n_slices], -1);
-        p.in_rows.assign((size_t)p.in_base[p.n_slices], 0);
+        p.in_slots.resize((size_t)p.in_base[p.n_slices]);
+        p.in_rows.resize((size_t)p.in_base[p.n_slices]);
+        plan_fill(p.in_slots, (int32_t)-1);
+        plan_fill(p.in_rows, (int32_t)0);
         plan_parallel(n_own, 4096, [&](int, int64_t c0, int64_t c1) {
             std::vector<std::pair<int64_t, int32_t>> src; // (slot index, source row)
             for (int64_t c = c0; c < c1; c++) {
@@ -709,9 +745,13 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         // the SpMV, read again by the kernel that collects the products).  loc_index: per slot, the position of its u
         // among the slice's in-slice blocks (255: the product leaves the slice); loc_list: per in-list entry the same
         // position (255: collect it from HBM); gat_slots: the in-list without the in-slice entries.
-        p.loc_index.assign((size_t)total, 255);
-        p.loc_list.assign(p.in_slots.size(), 255);
-        p.gat_slots = p.in_slots;
+        p.loc_index.resize((size_t)total);
+        p.loc_list.resize(p.in_slots.size());
+        p.gat_slots.resize(p.in_slots.size());
+        plan_fill(p.loc_index, (uint8_t)255);
+        plan_fill(p.loc_list, (uint8_t)255);
+        plan_parallel((int64_t)p.in_slots.size(), 1 << 20,
+                      [&](int, int64_t b, int64_t e) { std::copy(p.in_slots.begin() + b, p.in_slots.begin() + e, p.gat_slots.begin() + b); });
         std::vector<int32_t> per_slice((size_t)p.n_slices, 0);
         plan_parallel(p.n_slices, 256, [&](int, int64_t s0, int64_t s1) {
             for (int64_t s2 = s0; s2 < s1; s2++) {
@@ -740,31 +780,74 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         std::vector<std::vector<int32_t>> part_elems((size_t)nchunks), part_nodes((size_t)nchunks);
         std::vector<int32_t> part_max((size_t)nchunks, 0), part_bad((size_t)nchunks, 0);
         plan_parallel(p.n_slices, 256, [&](int t, int64_t s0, int64_t s1) {
+            // local element ids of a slice within this span: bitmap + rank table (FEMSHELL_PLAN_DENSE_SPAN: the tests set 0 to
+            // drive the sort-and-search path on small meshes; read per plan)
+            const char *span_env = getenv("FEMSHELL_PLAN_DENSE_SPAN");
+            const int64_t kDenseSpan = span_env ? atoll(span_env) : (int64_t)1 << 18;
             std::vector<int32_t> ids, placed;
-            std::vector<int32_t> &elems = part_elems[(size_t)t], &nodes = part_nodes[(size_t)t];
+            std::vector<uint64_t> bits;
+            std::vector<uint16_t> pos_of;
+            std::vector<int32_t> elems, nodes; // (the thread's own; handed over at the end, see the slot loop above)
+            int32_t most = 0;
             elems.reserve((size_t)(s1 - s0) * 136);
             nodes.reserve((size_t)(s1 - s0) * 136 * 4);
             for (int64_t s = s0; s < s1; s++) {
                 const int32_t q0 = p.pair_ptr[p.slice_base[s]], q1 = p.pair_ptr[p.slice_base[s + 1]];
+                // the slice's elements, ascending: every element that touches a row of the slice contributes to that row's
+                // diagonal slot, so the pairs of the first 32 slots (k = 0) name them all.  Local element ids of a slice lie
+                // close together for numberings that follow the mesh: they are then marked in a bitmap and read off in order,
+                // and a table indexed by (id - smallest id) answers the rank queries below; other slices sort and search.
+                const int32_t qd = p.pair_ptr[p.slice_base[s] + kSliceNodes];
+                int32_t lo = INT32_MAX, hi = -1;
+                for (int32_t q = q0; q < qd; q++) {
+                    const int32_t le = (int32_t)(p.pairs[q] >> 4);
+                    lo = std::min(lo, le);
+                    hi = std::max(hi, le);
+                }
+                const bool dense = hi >= lo && (int64_t)hi - lo < kDenseSpan;
                 ids.clear();
-                for (int32_t q = q0; q < q1; q++) ids.push_back((int32_t)(p.pairs[q] >> 4));
-                std::sort(ids.begin(), ids.end());
-                ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+                if (dense) {
+                    const int32_t words = (hi - lo) / 64 + 1;
+                    if ((int32_t)bits.size() < words) bits.resize((size_t)words, 0); // (all zero between slices)
+                    for (int32_t q = q0; q < qd; q++) {
+                        const int32_t d = (int32_t)(p.pairs[q] >> 4) - lo;
+                        bits[(size_t)(d >> 6)] |= 1ull << (d & 63);
+                    }
+                    for (int32_t w = 0; w < words; w++) {
+                        uint64_t b = bits[(size_t)w];
+                        bits[(size_t)w] = 0;
+                        while (b) {
+                            ids.push_back(lo + w * 64 + __builtin_ctzll(b));
+                            b &= b - 1;
+                        }
+                    }
+                } else {
+                    for (int32_t q = q0; q < qd; q++) ids.push_back((int32_t)(p.pairs[q] >> 4));
+                    std::sort(ids.begin(), ids.end());
+                    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+                }
                 if (ids.size() > 4095) {
                     part_bad[(size_t)t] = 1;
                     return;
                 }
-                part_max[(size_t)t] = std::max<int32_t>(part_max[(size_t)t], (int32_t)ids.size());
+                most = std::max<int32_t>(most, (int32_t)ids.size());
                 // LDS position of the records: even-ranked elements first, then the odd-ranked ones.  Neighbouring
                 // lanes (neighbouring node rows) gather from neighbouring cells; mesh generators emit the two
                 // triangles of a cell back to back, so in ascending order those records are two apart and a
                 // wave's LDS reads fall on half of the banks; de-interleaved they are adjacent.
                 const int32_t n_even = ((int32_t)ids.size() + 1) / 2;
                 auto lds_pos = [&](int32_t rank) { return (rank & 1) ? n_even + (rank >> 1) : (rank >> 1); };
-                for (int32_t q = q0; q < q1; q++) {
-                    const int32_t le = (int32_t)(p.pairs[q] >> 4);
-                    const int32_t idx = lds_pos((int32_t)(std::lower_bound(ids.begin(), ids.end(), le) - ids.begin()));
-                    p.pairs16[q] = (uint16_t)((idx << 4) | (p.pairs[q] & 15u));
+                if (dense) {
+                    if (pos_of.size() < (size_t)(hi - lo + 1)) pos_of.resize((size_t)(hi - lo + 1));
+                    for (size_t r = 0; r < ids.size(); r++) pos_of[(size_t)(ids[r] - lo)] = (uint16_t)lds_pos((int32_t)r);
+                    for (int32_t q = q0; q < q1; q++) // (only ids of the slice are looked up: the table needs no clearing)
+                        p.pairs16[q] = (uint16_t)(((uint32_t)pos_of[(size_t)((int32_t)(p.pairs[q] >> 4) - lo)] << 4) | (p.pairs[q] & 15u));
+                } else {
+                    for (int32_t q = q0; q < q1; q++) {
+                        const int32_t le = (int32_t)(p.pairs[q] >> 4);
+                        const int32_t idx = lds_pos((int32_t)(std::lower_bound(ids.begin(), ids.end(), le) - ids.begin()));
+                        p.pairs16[q] = (uint16_t)((idx << 4) | (p.pairs[q] & 15u));
+                    }
                 }
                 placed.resize(ids.size());
                 for (size_t r = 0; r < ids.size(); r++) placed[lds_pos((int32_t)r)] = ids[r];
@@ -779,6 +862,9 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                 }
                 p.slice_elem_ptr[(size_t)s + 1] = (int32_t)placed.size(); // count; prefix sums below
             }
+            part_max[(size_t)t] = most;
+            part_elems[(size_t)t].swap(elems);
+            part_nodes[(size_t)t].swap(nodes);
         });
         for (int t = 0; t < nchunks; t++) {
             if (part_bad[(size_t)t]) return fail("more than 4095 elements touch one 32-node slice");
@@ -787,12 +873,16 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         for (int32_t s = 0; s < p.n_slices; s++) p.slice_elem_ptr[(size_t)s + 1] += p.slice_elem_ptr[(size_t)s];
         p.slice_elems.resize((size_t)p.slice_elem_ptr[(size_t)p.n_slices]);
         p.slice_elem_nodes.resize(4 * p.slice_elems.size());
-        size_t off = 0;
-        for (int t = 0; t < nchunks; t++) { // chunks are contiguous slice ranges in thread order
-            std::copy(part_elems[(size_t)t].begin(), part_elems[(size_t)t].end(), p.slice_elems.begin() + off);
-            std::copy(part_nodes[(size_t)t].begin(), part_nodes[(size_t)t].end(), p.slice_elem_nodes.begin() + 4 * off);
-            off += part_elems[(size_t)t].size();
-        }
+        std::vector<size_t> off((size_t)nchunks + 1, 0); // chunks are contiguous slice ranges in thread order
+        for (int t = 0; t < nchunks; t++) off[(size_t)t + 1] = off[(size_t)t] + part_elems[(size_t)t].size();
+        plan_parallel(nchunks, 1, [&](int, int64_t t0, int64_t t1) {
+            for (int64_t t = t0; t < t1; t++) {
+                std::copy(part_elems[(size_t)t].begin(), part_elems[(size_t)t].end(), p.slice_elems.begin() + off[(size_t)t]);
+                std::copy(part_nodes[(size_t)t].begin(), part_nodes[(size_t)t].end(), p.slice_elem_nodes.begin() + 4 * off[(size_t)t]);
+                std::vector<int32_t>().swap(part_elems[(size_t)t]);
+                std::vector<int32_t>().swap(part_nodes[(size_t)t]);
+            }
+        });
     }
 
     lap("assembly work items");
@@ -853,7 +943,8 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         std::vector<int32_t> part_stage((size_t)nchunks_t, 0), part_bad((size_t)nchunks_t, 0);
         plan_parallel(p.n_slices, 256, [&](int t, int64_t s0, int64_t s1) {
             std::vector<Plan::Item> tmp, sorted, packed;
-            std::vector<Plan::Item> &out = part_items[(size_t)t];
+            std::vector<Plan::Item> out; // (the thread's own; handed over at the end)
+            int32_t most_stage = 0;
             out.reserve((size_t)(s1 - s0) * 168);
             // stable order by decreasing number of contributions (0..kItemPairs): a bucket pass, no allocation
             auto order_by_work = [&](std::vector<Plan::Item> &v, size_t begin) {
@@ -920,10 +1011,12 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                     }
                     tmp.swap(packed);
                 }
-                part_stage[(size_t)t] = std::max(part_stage[(size_t)t], stage);
+                most_stage = std::max(most_stage, stage);
                 out.insert(out.end(), tmp.begin(), tmp.end());
                 p.item_ptr[(size_t)s + 1] = (int32_t)tmp.size(); // count; prefix sums below
             }
+            part_stage[(size_t)t] = most_stage;
+            part_items[(size_t)t].swap(out);
         });
         size_t total_items = 0;
         for (int t = 0; t < nchunks_t; t++) {
@@ -934,12 +1027,14 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         if (total_items > (size_t)0x7fffffff) return fail("more than 2^31 assembly work items on one rank");
         for (int32_t s = 0; s < p.n_slices; s++) p.item_ptr[(size_t)s + 1] += p.item_ptr[(size_t)s];
         p.items.resize(total_items);
-        size_t off = 0;
-        for (int t = 0; t < nchunks_t; t++) {
-            std::copy(part_items[(size_t)t].begin(), part_items[(size_t)t].end(), p.items.begin() + off);
-            off += part_items[(size_t)t].size();
-            std::vector<Plan::Item>().swap(part_items[(size_t)t]);
-        }
+        std::vector<size_t> off((size_t)nchunks_t + 1, 0);
+        for (int t = 0; t < nchunks_t; t++) off[(size_t)t + 1] = off[(size_t)t] + part_items[(size_t)t].size();
+        plan_parallel(nchunks_t, 1, [&](int, int64_t t0, int64_t t1) {
+            for (int64_t t = t0; t < t1; t++) {
+                std::copy(part_items[(size_t)t].begin(), part_items[(size_t)t].end(), p.items.begin() + off[(size_t)t]);
+                std::vector<Plan::Item>().swap(part_items[(size_t)t]);
+            }
+        });
     }
     lap("slice descriptors");
     // ---- per-slice descriptors of the assembly kernel

@@ -20,10 +20,26 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace femshell {
+
+// The large arrays of a plan (hundreds of MB at 4M triangles): resize() leaves new elements uninitialised instead of
+// zero-filling them on the calling thread, so that the host threads that write an array are also the ones that take its
+// page faults.  Every element is written before it is read (fills where a value is needed are explicit and parallel).
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind {
+        using other = NoInitAlloc<U>;
+    };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+template <class T> using RawVec = std::vector<T, NoInitAlloc<T>>;
 
 constexpr int kSliceNodes = 32;             // node rows per slice
 constexpr int kSliceRows = 6 * kSliceNodes; // scalar rows per slice
@@ -51,24 +67,24 @@ struct Plan {
     std::vector<int32_t> ghost_global;  // ascending global ids
     // local elements (those touching an owned node), local node ids
     std::vector<int32_t> tri_global_id, quad_global_id;
-    std::vector<int32_t> tri_local, quad_local; // 3*n_ltri, 4*n_lquad
-    std::vector<double> xyz_local;              // (n_pad+n_ghost)*3
+    RawVec<int32_t> tri_local, quad_local; // 3*n_ltri, 4*n_lquad
+    RawVec<double> xyz_local;              // (n_pad+n_ghost)*3
     // sliced block ELL structure over the owned rows
     int32_t n_slices = 0;
     std::vector<int32_t> slice_width;  // n_slices
     std::vector<int64_t> slice_base;   // n_slices+1, in slots (one slot = one 6x6 block of one node)
-    std::vector<int32_t> cols;         // per slot: local column node id (padding slots: own row, no pairs)
-    std::vector<int32_t> pair_ptr;     // per slot + 1
-    std::vector<uint32_t> pairs;       // (local element << 4) | (row node in element << 2) | column node in element
+    RawVec<int32_t> cols;         // per slot: local column node id (padding slots: own row, no pairs)
+    RawVec<int32_t> pair_ptr;     // per slot + 1
+    RawVec<uint32_t> pairs;       // (local element << 4) | (row node in element << 2) | column node in element
                                        // local element index: triangles [0,n_ltri), quads n_ltri + q
     // per slice: the distinct local elements its gather lists reference (ascending); the device
     // kernel stages one record per such element in LDS and addresses it with the 16-bit entries
     //   pairs16 = (index into the slice's element list << 4) | (row node << 2) | column node
     std::vector<int32_t> slice_elem_ptr; // n_slices+1
-    std::vector<int32_t> slice_elems;
-    std::vector<uint16_t> pairs16;       // same order as pairs
+    RawVec<int32_t> slice_elems;
+    RawVec<uint16_t> pairs16;       // same order as pairs
     int32_t max_slice_elems = 0;
-    std::vector<int32_t> slice_elem_nodes; // 4 local node ids per entry of slice_elems (4th = -1 for TRI3)
+    RawVec<int32_t> slice_elem_nodes; // 4 local node ids per entry of slice_elems (4th = -1 for TRI3)
     // work items of the assembly kernel: a block slot's gather list is cut into chunks of at most
     // kItemPairs contributions so that every lane has the same amount of work; chunk 0 owns the
     // slot (it adds the other chunks' partial sums in chunk order and writes the block).  Per
@@ -82,7 +98,7 @@ struct Plan {
     struct Item { uint32_t x, y, z, w; };
     std::vector<int32_t> item_ptr; // n_slices+1
     std::vector<int32_t> slice_desc; // 8 per slice: elem begin, elem count, item begin, item count, slot base lo, hi, width, 0
-    std::vector<Item> items;
+    RawVec<Item> items;
     int32_t max_stage_rows = 0;    // staging rows (36 doubles each) a slice needs at most
     // pipe == true: the items are laid out for the pipelined kernel (plan.cpp pack_items_pipe: rounds of 192 lanes,
     // a slot's chunks in neighbouring lanes of one wave, w = wave word) and no staging rows are needed
@@ -100,13 +116,13 @@ struct Plan {
     int64_t stored_blocks = 0;         // blocks that have a slot (== nnz_blocks without symmetric storage)
     std::vector<int32_t> in_width;     // n_slices
     std::vector<int64_t> in_base;      // n_slices+1, in entries
-    std::vector<int32_t> in_slots;     // entry (in_base[s] + k*32 + n): slot index, -1 = none
-    std::vector<int32_t> in_rows;      // same shape: the local row a of that block (its x entries multiply the transpose)
+    RawVec<int32_t> in_slots;     // entry (in_base[s] + k*32 + n): slot index, -1 = none
+    RawVec<int32_t> in_rows;      // same shape: the local row a of that block (its x entries multiply the transpose)
     int32_t max_in_width = 0;
     // transposed products that stay inside a slice go through LDS (plan.cpp): per slot / per in-list entry the position
     // among the slice's in-slice blocks (255 = none), the in-list without those entries, and the largest count of a slice
-    std::vector<uint8_t> loc_index, loc_list;
-    std::vector<int32_t> gat_slots;
+    RawVec<uint8_t> loc_index, loc_list;
+    RawVec<int32_t> gat_slots;
     int32_t max_loc = 0;
     std::vector<HaloPeer> peers;
     // slices in SpMV order: the first n_interior_slices read no ghost column (they overlap the halo exchange)
