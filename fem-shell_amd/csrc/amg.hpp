@@ -30,23 +30,19 @@
 #include <utility>
 #include <vector>
 
+#include "plan.hpp"
+
 namespace femshell {
 
-// allocator that leaves doubles uninitialised on resize: the gigabyte-sized value arrays of the setup are written
-// in full by parallel loops; a serial zero fill first would cost as much as the loop itself
-template <class T> struct default_init_allocator : std::allocator<T> {
-    template <class U> struct rebind { using other = default_init_allocator<U>; };
-    using std::allocator<T>::allocator;
-    template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
-    template <class U, class... Args> void construct(U *p, Args &&...args) { ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...); }
-};
-using ValueArray = std::vector<double, default_init_allocator<double>>;
+// arrays that stay uninitialised on resize (RawVec, plan.hpp): the gigabyte-sized value arrays and the large index arrays
+// of the setup are written in full by parallel loops; a serial zero fill first would cost as much as the loop itself
+using ValueArray = RawVec<double>;
 
 // block CSR with 6x6 blocks (row-major inside a block), columns ascending within a row
 struct Bsr {
     int32_t nr = 0, nc = 0; // block rows / block columns
     std::vector<int64_t> ptr;
-    std::vector<int32_t> col;
+    RawVec<int32_t> col;
     ValueArray val;
     int64_t nnzb() const { return (int64_t)col.size(); }
 };
@@ -113,12 +109,12 @@ struct SlicedEllSym : SlicedEll {
     int32_t max_in_width = 0;
     std::vector<int32_t> in_width;
     std::vector<int64_t> in_base;
-    std::vector<int32_t> in_slots, in_rows;
+    RawVec<int32_t> in_slots, in_rows;
 };
 void pack_sliced_ell_sym(const Bsr &A, SlicedEllSym *out);
 // in-lists of a diagonal-first upper pattern given as ELL arrays (rows kept their blocks (a, c >= a) only)
 void build_in_lists(int32_t n_rows, const std::vector<int32_t> &slice_width, const std::vector<int64_t> &slice_base,
-                    const std::vector<int32_t> &cols, const std::vector<uint8_t> &count, SlicedEllSym *out);
+                    const int32_t *cols, const std::vector<uint8_t> &count, SlicedEllSym *out);
 // A += strict upper part transposed (A holds the diagonal and upper blocks of a symmetric matrix): full BSR
 void mirror_upper(Bsr *A);
 

@@ -32,9 +32,10 @@ struct HostEllPattern {
     bool symmetric = false;            // diagonal + upper blocks stored, in-lists below
     std::vector<int32_t> slice_width;
     std::vector<int64_t> slice_base;
-    std::vector<int32_t> cols;
+    RawVec<int32_t> cols;
     std::vector<uint8_t> count;        // real entries per row (slots 0 .. count-1)
-    std::vector<int32_t> in_width, in_slots, in_rows;
+    std::vector<int32_t> in_width;
+    RawVec<int32_t> in_slots, in_rows;
     std::vector<int64_t> in_base;
     bool empty() const { return slice_base.empty(); }
 };

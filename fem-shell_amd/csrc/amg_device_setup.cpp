@@ -17,14 +17,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <thread>
 
 namespace femshell {
 
 // rows as sorted lists -> sliced ELL pattern (32 rows per slice, `count` real entries per row, padding columns 0;
 // diag_first: the entry equal to the row index is moved to slot 0)
-bool pack_pattern(int32_t n_rows, const std::vector<int64_t> &ptr, const std::vector<int32_t> &col, bool diag_first, EllPattern *out,
-                  int32_t diag_key)
+bool pack_pattern(int32_t n_rows, const int64_t *ptr, const int32_t *col, bool diag_first, EllPattern *out, int32_t diag_key)
 {
     EllPattern &E = *out;
     E = EllPattern();
@@ -34,24 +34,34 @@ bool pack_pattern(int32_t n_rows, const std::vector<int64_t> &ptr, const std::ve
     E.slice_width.assign((size_t)E.n_slices, 1);
     E.slice_base.assign((size_t)E.n_slices + 1, 0);
     E.count.assign((size_t)E.n_pad, 0);
-    for (int32_t s = 0; s < E.n_slices; s++) {
-        int w = 1;
-        for (int n = 0; n < kSliceNodes; n++) {
-            const int32_t a = s * kSliceNodes + n;
-            if (a >= n_rows) continue;
-            const int64_t c = ptr[a + 1] - ptr[a];
-            if (c > 255) return false;
-            E.count[a] = (uint8_t)c;
-            w = std::max<int>(w, (int)c);
+    std::atomic<int> too_wide{0};
+    parallel_chunks(E.n_slices, [&](int64_t s0, int64_t s1) {
+        for (int64_t s = s0; s < s1; s++) {
+            int w = 1;
+            for (int n = 0; n < kSliceNodes; n++) {
+                const int32_t a = (int32_t)s * kSliceNodes + n;
+                if (a >= n_rows) continue;
+                const int64_t c = ptr[a + 1] - ptr[a];
+                if (c > 255) {
+                    too_wide.store(1);
+                    return;
+                }
+                E.count[(size_t)a] = (uint8_t)c;
+                w = std::max<int>(w, (int)c);
+            }
+            E.slice_width[(size_t)s] = w;
         }
-        E.slice_width[s] = w;
-        E.max_width = std::max(E.max_width, w);
-        E.slice_base[s + 1] = E.slice_base[s] + (int64_t)w * kSliceNodes;
+    }, 64);
+    if (too_wide.load()) return false;
+    for (int32_t s = 0; s < E.n_slices; s++) {
+        E.max_width = std::max(E.max_width, E.slice_width[(size_t)s]);
+        E.slice_base[(size_t)s + 1] = E.slice_base[(size_t)s] + (int64_t)E.slice_width[(size_t)s] * kSliceNodes;
     }
     E.nnzb = ptr[n_rows];
-    E.cols.assign((size_t)E.total(), 0);
+    E.cols.resize((size_t)E.total()); // (padding columns 0: every slice is cleared by the thread that fills it)
     parallel_chunks(E.n_slices, [&](int64_t s0, int64_t s1) {
-        for (int64_t s = s0; s < s1; s++)
+        for (int64_t s = s0; s < s1; s++) {
+            std::fill(E.cols.begin() + E.slice_base[(size_t)s], E.cols.begin() + E.slice_base[(size_t)s + 1], 0);
             for (int n = 0; n < kSliceNodes; n++) {
                 const int32_t a = (int32_t)s * kSliceNodes + n;
                 if (a >= n_rows) continue;
@@ -66,6 +76,7 @@ bool pack_pattern(int32_t n_rows, const std::vector<int64_t> &ptr, const std::ve
                     k++;
                 }
             }
+        }
     }, 64);
     return true;
 }
@@ -142,7 +153,7 @@ void ell_to_bsr(const EllPattern &E, const double *vals, int32_t n_cols, Bsr *ou
     });
 }
 
-int download_vals(const DevBuf<double> &d, std::vector<double, default_init_allocator<double>> *h, hipStream_t st)
+int download_vals(const DevBuf<double> &d, ValueArray *h, hipStream_t st)
 {
     h->resize(d.n);
     FS_HIP(hipMemcpyAsync(h->data(), d.p, d.n * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -160,7 +171,11 @@ void pattern_of_plan(const Plan &p, HostEllPattern *out)
     H.symmetric = p.symmetric;
     H.slice_width = p.slice_width;
     H.slice_base = p.slice_base;
-    H.cols.assign(p.cols.begin(), p.cols.end());
+    auto copy_of = [](const RawVec<int32_t> &from, RawVec<int32_t> *to) { // (on the host threads: 32 + 2 x 24 MB at 4M triangles)
+        to->resize(from.size());
+        parallel_chunks((int64_t)from.size(), [&](int64_t b, int64_t e) { std::copy(from.begin() + b, from.begin() + e, to->begin() + b); }, 1 << 18);
+    };
+    copy_of(p.cols, &H.cols);
     H.count.assign((size_t)p.n_pad, 0);
     parallel_chunks(p.n_own, [&](int64_t a0, int64_t a1) {
         for (int64_t a = a0; a < a1; a++) {
@@ -176,8 +191,8 @@ void pattern_of_plan(const Plan &p, HostEllPattern *out)
     if (p.symmetric) {
         H.in_width = p.in_width;
         H.in_base = p.in_base;
-        H.in_slots.assign(p.in_slots.begin(), p.in_slots.end());
-        H.in_rows.assign(p.in_rows.begin(), p.in_rows.end());
+        copy_of(p.in_slots, &H.in_slots);
+        copy_of(p.in_rows, &H.in_rows);
     }
 }
 
@@ -197,7 +212,10 @@ void graph_of_pattern(const HostEllPattern &H, Bsr *G)
                 if (H.in_slots[(size_t)(H.in_base[s] + (int64_t)k * kSliceNodes + nn)] >= 0) cnt++;
         return cnt;
     };
-    for (int32_t a = 0; a < n; a++) A.ptr[a + 1] = A.ptr[a] + count_row(a);
+    parallel_chunks(n, [&](int64_t a0, int64_t a1) {
+        for (int64_t a = a0; a < a1; a++) A.ptr[(size_t)a + 1] = count_row((int32_t)a);
+    });
+    for (int32_t a = 0; a < n; a++) A.ptr[(size_t)a + 1] += A.ptr[(size_t)a];
     A.col.resize((size_t)A.ptr[n]);
     parallel_chunks(n, [&](int64_t a0, int64_t a1) {
         for (int64_t a = a0; a < a1; a++) {
@@ -274,10 +292,10 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     // ---- patterns
     // P: per fine row the sorted distinct aggregates of its neighbours (the row itself included)
     std::vector<int64_t> pptr((size_t)n + 1, 0);
-    std::vector<int32_t> pcol;
+    RawVec<int32_t> pcol;
     {
         std::vector<uint8_t> cnt((size_t)n, 0);
-        std::vector<int32_t> tmp_all((size_t)G.ptr[n]); // upper bound storage: distinct aggregates per row, compacted below
+        RawVec<int32_t> tmp_all((size_t)G.ptr[n]); // upper bound storage: distinct aggregates per row, compacted below
         parallel_chunks(n, [&](int64_t a0, int64_t a1) {
             for (int64_t a = a0; a < a1; a++) {
                 int32_t *t = &tmp_all[(size_t)G.ptr[a]];
@@ -299,24 +317,27 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
         return (int)(std::lower_bound(b, e, J) - b);
     };
     // which slot of P's row every block of K feeds (own slots and in-list entries, in the order the kernels walk them)
-    std::vector<uint8_t> pmap_own((size_t)pat.slice_base.back(), 0), pmap_in(pat.in_slots.size(), 0);
-    parallel_chunks(n, [&](int64_t a0, int64_t a1) {
+    // (entries of padding slots and of empty in-list places: 0, written by the row's thread like the real ones)
+    RawVec<uint8_t> pmap_own((size_t)pat.slice_base.back()), pmap_in(pat.in_slots.size());
+    const int32_t n_rows_padded = (int32_t)(pat.slice_width.size() * (size_t)kSliceNodes);
+    parallel_chunks(n_rows_padded, [&](int64_t a0, int64_t a1) {
         for (int64_t a = a0; a < a1; a++) {
             const int s = (int)(a / kSliceNodes), nn = (int)(a % kSliceNodes);
-            for (int k = 0; k < pat.count[(size_t)a]; k++) {
+            const int real = a < n ? pat.count[(size_t)a] : 0;
+            for (int k = 0; k < pat.slice_width[(size_t)s]; k++) {
                 const int64_t slot = pat.slice_base[s] + (int64_t)k * kSliceNodes + nn;
-                pmap_own[(size_t)slot] = (uint8_t)p_index((int32_t)a, agg[pat.cols[(size_t)slot]]);
+                pmap_own[(size_t)slot] = k < real ? (uint8_t)p_index((int32_t)a, agg[pat.cols[(size_t)slot]]) : (uint8_t)0;
             }
             if (pat.symmetric)
                 for (int k = 0; k < pat.in_width[s]; k++) {
                     const size_t e = (size_t)(pat.in_base[s] + (int64_t)k * kSliceNodes + nn);
-                    if (pat.in_slots[e] >= 0) pmap_in[e] = (uint8_t)p_index((int32_t)a, agg[pat.in_rows[e]]);
+                    pmap_in[e] = a < n && pat.in_slots[e] >= 0 ? (uint8_t)p_index((int32_t)a, agg[pat.in_rows[e]]) : (uint8_t)0;
                 }
         }
     });
     // A P: per fine row the union of the P rows of its neighbours
     std::vector<int64_t> aptr((size_t)n + 1, 0);
-    std::vector<int32_t> acol;
+    RawVec<int32_t> acol;
     {
         std::vector<std::vector<int32_t>> parts; // per chunk, concatenated afterwards
         std::vector<int32_t> cnt((size_t)n, 0);
@@ -325,7 +346,9 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
         std::vector<std::thread> th;
         auto work = [&](int t) {
             const int64_t a0 = (int64_t)n * t / nchunks, a1 = (int64_t)n * (t + 1) / nchunks;
-            std::vector<int32_t> tmp;
+            std::vector<int32_t> tmp, mine; // (the thread's own list, handed over at the end: the headers of parts[t] and
+                                            //  parts[t + 1] share a cache line)
+            mine.reserve((size_t)(a1 - a0) * 8);
             for (int64_t a = a0; a < a1; a++) {
                 tmp.clear();
                 for (int64_t q = G.ptr[a]; q < G.ptr[a + 1]; q++) {
@@ -335,8 +358,9 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
                 std::sort(tmp.begin(), tmp.end());
                 tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
                 cnt[a] = (int32_t)tmp.size();
-                parts[(size_t)t].insert(parts[(size_t)t].end(), tmp.begin(), tmp.end());
+                mine.insert(mine.end(), tmp.begin(), tmp.end());
             }
+            parts[(size_t)t].swap(mine);
         };
         for (int t = 1; t < nchunks; t++) th.emplace_back(work, t);
         work(0);
@@ -353,8 +377,8 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     }
     // R = P^T as lists: per aggregate the fine rows (ascending) and the slot of the aggregate in their P row
     std::vector<int64_t> rptr((size_t)na + 1, 0);
-    std::vector<int32_t> rrow((size_t)pptr[n]);
-    std::vector<uint8_t> rk((size_t)pptr[n]);
+    RawVec<int32_t> rrow((size_t)pptr[n]);
+    RawVec<uint8_t> rk((size_t)pptr[n]);
     {
         // a counting sort by aggregate that keeps the rows ascending within an aggregate, on T ranges of rows at once: every
         // range counts into a histogram of its own, the histograms are stacked range after range per aggregate, every range
@@ -411,36 +435,45 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     // coarse operator is symmetric, the cycle applies the stored blocks to both rows)
     const bool sym_coarse = coarse_symmetric_storage(na);
     std::vector<int64_t> cptr((size_t)na + 1, 0);
-    std::vector<int32_t> ccol;
+    RawVec<int32_t> ccol;
     {
-        std::vector<std::vector<int32_t>> rows((size_t)na);
-        parallel_chunks(na, [&](int64_t I0, int64_t I1) {
-            std::vector<int32_t> tmp;
-            for (int64_t I = I0; I < I1; I++) {
-                tmp.clear();
-                for (int64_t q = rptr[I]; q < rptr[I + 1]; q++) {
-                    const int32_t i = rrow[(size_t)q];
-                    tmp.insert(tmp.end(), acol.begin() + aptr[i], acol.begin() + aptr[i + 1]);
+        // ranges of aggregates on the host threads, each into a list of its own, joined in order afterwards
+        const int nchunks = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (na + 1023) / 1024));
+        std::vector<std::vector<int32_t>> parts((size_t)nchunks);
+        std::vector<int32_t> cnt((size_t)na, 0);
+        parallel_chunks(nchunks, [&](int64_t t0, int64_t t1) {
+            for (int64_t t = t0; t < t1; t++) {
+                const int64_t I0 = (int64_t)na * t / nchunks, I1 = (int64_t)na * (t + 1) / nchunks;
+                std::vector<int32_t> tmp, mine;
+                for (int64_t I = I0; I < I1; I++) {
+                    tmp.clear();
+                    for (int64_t q = rptr[I]; q < rptr[I + 1]; q++) {
+                        const int32_t i = rrow[(size_t)q];
+                        tmp.insert(tmp.end(), acol.begin() + aptr[i], acol.begin() + aptr[i + 1]);
+                    }
+                    std::sort(tmp.begin(), tmp.end());
+                    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                    const auto first = sym_coarse ? std::lower_bound(tmp.begin(), tmp.end(), (int32_t)I) : tmp.begin(); // diagonal and upper blocks
+                    cnt[(size_t)I] = (int32_t)(tmp.end() - first);
+                    mine.insert(mine.end(), first, tmp.end());
                 }
-                std::sort(tmp.begin(), tmp.end());
-                tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-                if (sym_coarse) tmp.erase(tmp.begin(), std::lower_bound(tmp.begin(), tmp.end(), (int32_t)I)); // diagonal and upper blocks
-                rows[(size_t)I] = tmp;
+                parts[(size_t)t].swap(mine);
             }
-        }, 64);
-        for (int32_t I = 0; I < na; I++) cptr[I + 1] = cptr[I] + (int64_t)rows[(size_t)I].size();
-        ccol.resize((size_t)cptr[na]);
-        for (int32_t I = 0; I < na; I++) std::copy(rows[(size_t)I].begin(), rows[(size_t)I].end(), ccol.begin() + cptr[I]);
+        }, 1);
+        for (int32_t I = 0; I < na; I++) cptr[(size_t)I + 1] = cptr[(size_t)I] + cnt[(size_t)I];
+        ccol.resize((size_t)cptr[(size_t)na]);
+        parallel_chunks(nchunks, [&](int64_t t0, int64_t t1) {
+            for (int64_t t = t0; t < t1; t++)
+                std::copy(parts[(size_t)t].begin(), parts[(size_t)t].end(), ccol.begin() + cptr[(size_t)((int64_t)na * t / nchunks)]);
+        }, 1);
     }
     EllPattern eP, eAP, eR, eAc;
-    if (!pack_pattern(n, pptr, pcol, false, &eP) || !pack_pattern(n, aptr, acol, false, &eAP) ||
-        !pack_pattern(na, cptr, ccol, true, &eAc))
+    if (!pack_pattern(n, pptr.data(), pcol.data(), false, &eP) || !pack_pattern(n, aptr.data(), acol.data(), false, &eAP) ||
+        !pack_pattern(na, cptr.data(), ccol.data(), true, &eAc))
         return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: a row of an intermediate operator has more than 255 blocks");
-    {
-        std::vector<int32_t> rcol(rrow); // R's columns are the fine rows, already ascending per aggregate
-        if (!pack_pattern(na, rptr, rcol, false, &eR))
-            return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: an aggregate is seen by more than 255 fine rows");
-    }
+    // (R's columns are the fine rows, already ascending per aggregate)
+    if (!pack_pattern(na, rptr.data(), rrow.data(), false, &eR))
+        return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: an aggregate is seen by more than 255 fine rows");
     lap("patterns of P, AP, R, Ac");
 
     // ---- values on the device
@@ -544,7 +577,7 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     next.pattern.symmetric = sym_coarse;
     if (sym_coarse) {
         SlicedEllSym S;
-        build_in_lists(na, eAc.slice_width, eAc.slice_base, eAc.cols, eAc.count, &S);
+        build_in_lists(na, eAc.slice_width, eAc.slice_base, eAc.cols.data(), eAc.count, &S);
         rc = attach_in_lists(next.A, S, eAc.total(), st);
         if (rc) return rc;
         next.pattern.in_width.swap(S.in_width);

@@ -321,7 +321,7 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
         }
     });
     EllPattern eP, eAP, eR, eAc;
-    bool ok = pack_pattern(n, pptr, pcol, false, &eP);
+    bool ok = pack_pattern(n, pptr.data(), pcol.data(), false, &eP);
     if (!ok) (void)set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: a row of the prolongator has more than 255 blocks");
     int64_t Wp = 0;
     rc = global_max(c, ok ? eP.max_width : -1, &Wp, "the pattern of the prolongator");
@@ -404,7 +404,7 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
         acol.resize((size_t)aptr[(size_t)n]);
         for (int32_t a = 0; a < n; a++) std::copy(rows[(size_t)a].begin(), rows[(size_t)a].end(), acol.begin() + aptr[(size_t)a]);
     }
-    ok = pack_pattern(n, aptr, acol, false, &eAP);
+    ok = pack_pattern(n, aptr.data(), acol.data(), false, &eAP);
     if (!ok) (void)set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: a row of A P has more than 255 blocks");
     int64_t Wap = 0;
     rc = global_max(c, ok ? eAP.max_width : -1, &Wap, "the pattern of A P");
@@ -489,11 +489,10 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
         ccol.resize((size_t)cptr[(size_t)na]);
         for (int32_t I = 0; I < na; I++) std::copy(rows[(size_t)I].begin(), rows[(size_t)I].end(), ccol.begin() + cptr[(size_t)I]);
     }
-    ok = pack_pattern(na, cptr, ccol, true, &eAc, key0);
+    ok = pack_pattern(na, cptr.data(), ccol.data(), true, &eAc, key0);
     if (!ok) (void)set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: a row of a coarse operator has more than 255 blocks");
     if (ok) {
-        std::vector<int32_t> rcol(rrow);
-        ok = pack_pattern(na, rptr, rcol, false, &eR);
+        ok = pack_pattern(na, rptr.data(), rrow.data(), false, &eR); // (R's columns are the fine rows, ascending per aggregate)
         if (!ok) (void)set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: an aggregate is seen by more than 255 fine rows");
     }
     {
@@ -648,7 +647,7 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
     N.pattern.symmetric = sym_coarse;
     if (sym_coarse) {
         SlicedEllSym S;
-        build_in_lists(na, eAc.slice_width, eAc.slice_base, eAc.cols, eAc.count, &S);
+        build_in_lists(na, eAc.slice_width, eAc.slice_base, eAc.cols.data(), eAc.count, &S);
         rc = attach_in_lists(N.A, S, eAc.total(), st);
         if (rc) return rc;
         N.pattern.in_width.swap(S.in_width);

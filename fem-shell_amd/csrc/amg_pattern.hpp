@@ -15,14 +15,13 @@ struct EllPattern {
     int32_t n_rows = 0, n_pad = 0, n_slices = 0, max_width = 0;
     std::vector<int32_t> slice_width;
     std::vector<int64_t> slice_base;
-    std::vector<int32_t> cols;
+    RawVec<int32_t> cols;
     std::vector<uint8_t> count;
     int64_t nnzb = 0;
     int64_t total() const { return slice_base.empty() ? 0 : slice_base.back(); }
 };
 
-bool pack_pattern(int32_t n_rows, const std::vector<int64_t> &ptr, const std::vector<int32_t> &col, bool diag_first, EllPattern *out,
-                  int32_t diag_key = 0);
+bool pack_pattern(int32_t n_rows, const int64_t *ptr, const int32_t *col, bool diag_first, EllPattern *out, int32_t diag_key = 0);
 
 struct DevPattern {
     DevBuf<int32_t> slice_width, cols;

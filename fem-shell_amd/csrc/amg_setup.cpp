@@ -3,6 +3,7 @@
 #include "amg.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -84,10 +85,6 @@ void node_normals(int32_t n, const double *xyz, int64_t n_tri, const int32_t *tr
 {
     std::vector<double> &N = *out;
     N.assign((size_t)n * 3, 0.0);
-    auto add = [&](int32_t a, const double w[3]) {
-        if (a < n)
-            for (int d = 0; d < 3; d++) N[3ull * a + d] += w[d];
-    };
     auto cross_of = [&](int32_t a, int32_t b, int32_t c, double w[3]) { // (b - a) x (c - a): twice the area times the normal
         const double *A = xyz + 3ll * a, *B = xyz + 3ll * b, *C = xyz + 3ll * c;
         const double u[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, v[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
@@ -95,24 +92,43 @@ void node_normals(int32_t n, const double *xyz, int64_t n_tri, const int32_t *tr
         w[1] = u[2] * v[0] - u[0] * v[2];
         w[2] = u[0] * v[1] - u[1] * v[0];
     };
-    for (int64_t e = 0; e < n_tri; e++) {
-        double w[3];
-        cross_of(tri[3 * e], tri[3 * e + 1], tri[3 * e + 2], w);
-        for (int i = 0; i < 3; i++) add(tri[3 * e + i], w);
-    }
-    for (int64_t e = 0; e < n_quad; e++) {
-        double w[3], w2[3];
-        cross_of(quad[4 * e], quad[4 * e + 1], quad[4 * e + 2], w);
-        cross_of(quad[4 * e], quad[4 * e + 2], quad[4 * e + 3], w2);
-        for (int d = 0; d < 3; d++) w[d] += w2[d];
-        for (int i = 0; i < 4; i++) add(quad[4 * e + i], w);
-    }
-    for (int32_t a = 0; a < n; a++) {
-        double *v = &N[3ull * a];
-        const double l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-        if (l > 0.0)
-            for (int d = 0; d < 3; d++) v[d] /= l;
-    }
+    // Ranges of nodes on the host threads: every thread walks all elements and adds to the nodes of its own range only, so
+    // that a node's sum runs over its elements in ascending order (triangles, then quadrilaterals) whatever the number of
+    // threads is -- the serial scatter loop's result, bit for bit.
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / 32768));
+    parallel_chunks(T, [&](int64_t t0, int64_t t1) {
+        for (int64_t t = t0; t < t1; t++) {
+            const int32_t a0 = (int32_t)((int64_t)n * t / T), a1 = (int32_t)((int64_t)n * (t + 1) / T);
+            const uint32_t span = (uint32_t)(a1 - a0);
+            auto mine = [&](int32_t a) { return (uint32_t)(a - a0) < span; };
+            auto add = [&](int32_t a, const double w[3]) {
+                if (mine(a))
+                    for (int d = 0; d < 3; d++) N[3ull * a + d] += w[d];
+            };
+            for (int64_t e = 0; e < n_tri; e++) {
+                const int32_t *c = tri + 3 * e;
+                if (!(mine(c[0]) | mine(c[1]) | mine(c[2]))) continue;
+                double w[3];
+                cross_of(c[0], c[1], c[2], w);
+                for (int i = 0; i < 3; i++) add(c[i], w);
+            }
+            for (int64_t e = 0; e < n_quad; e++) {
+                const int32_t *c = quad + 4 * e;
+                if (!(mine(c[0]) | mine(c[1]) | mine(c[2]) | mine(c[3]))) continue;
+                double w[3], w2[3];
+                cross_of(c[0], c[1], c[2], w);
+                cross_of(c[0], c[2], c[3], w2);
+                for (int d = 0; d < 3; d++) w[d] += w2[d];
+                for (int i = 0; i < 4; i++) add(c[i], w);
+            }
+            for (int32_t a = a0; a < a1; a++) {
+                double *v = &N[3ull * a];
+                const double l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                if (l > 0.0)
+                    for (int d = 0; d < 3; d++) v[d] /= l;
+            }
+        }
+    }, 1);
 }
 
 // Near-null space: the six rigid-body modes of the mesh -- with one correction for this element.  The drilling stiffness
@@ -172,9 +188,15 @@ void aggregation_order(const Bsr &A, std::vector<int32_t> *order)
     const int32_t n = A.nr;
     order->clear();
     if (n < 64) return;
-    double dist = 0.0;
-    for (int32_t i = 0; i < n; i++)
-        for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++) dist += std::fabs((double)A.col[q] - (double)i);
+    // (an integer sum: exact whatever the number of host threads is)
+    std::atomic<int64_t> dist_sum{0};
+    parallel_chunks(n, [&](int64_t i0, int64_t i1) {
+        int64_t d = 0;
+        for (int64_t i = i0; i < i1; i++)
+            for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++) d += std::llabs((int64_t)A.col[q] - i);
+        dist_sum.fetch_add(d);
+    }, 1 << 16);
+    const double dist = (double)dist_sum.load();
     const int64_t edges = A.ptr[n];
     // FEMSHELL_AMG_AGG_ORDER=bfs|index forces one of the two (experiments); default: by the scatter of the numbering
     const char *force = getenv("FEMSHELL_AMG_AGG_ORDER");
@@ -230,23 +252,26 @@ int32_t aggregate_nodes(const Bsr &A, std::vector<int32_t> *aggout, const std::v
         rank.resize((size_t)n);
         for (int32_t v = 0; v < n; v++) rank[(size_t)order[(size_t)v]] = v;
     }
-    std::vector<int32_t> agg2(agg);
-    for (int32_t i = 0; i < n; i++) { // (reads the state of pass 1 only)
-        if (agg[i] >= 0) continue;
-        int32_t best = -1, best_rank = 0;
-        for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++) {
-            const int32_t j = A.col[q];
-            if (agg[j] < 0) continue;
-            const int32_t rj = rank.empty() ? j : rank[(size_t)j];
-            if (best < 0 || rj < best_rank) {
-                best = agg[j];
-                best_rank = rj;
+    RawVec<int32_t> agg2((size_t)n);
+    parallel_chunks(n, [&](int64_t i0, int64_t i1) { // (reads the state of pass 1 only: the rows are independent)
+        for (int64_t i = i0; i < i1; i++) {
+            agg2[(size_t)i] = agg[(size_t)i];
+            if (agg[(size_t)i] >= 0) continue;
+            int32_t best = -1, best_rank = 0;
+            for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++) {
+                const int32_t j = A.col[q];
+                if (agg[j] < 0) continue;
+                const int32_t rj = rank.empty() ? j : rank[(size_t)j];
+                if (best < 0 || rj < best_rank) {
+                    best = agg[j];
+                    best_rank = rj;
+                }
+                if (rank.empty()) break; // ascending columns: the first hit is the lowest
             }
-            if (rank.empty()) break; // ascending columns: the first hit is the lowest
+            if (best >= 0) agg2[(size_t)i] = best;
         }
-        if (best >= 0) agg2[i] = best;
-    }
-    agg.swap(agg2);
+    }, 1 << 14);
+    parallel_chunks(n, [&](int64_t i0, int64_t i1) { std::copy(agg2.begin() + i0, agg2.begin() + i1, agg.begin() + i0); }, 1 << 16);
     // pass 3: what is still free forms aggregates of its own
     for (int32_t v = 0; v < n; v++) {
         const int32_t i = order.empty() ? v : order[(size_t)v];
@@ -638,7 +663,7 @@ void pack_sliced_ell(const Bsr &A, bool diag_first, SlicedEll *out)
 }
 
 void build_in_lists(int32_t n_rows, const std::vector<int32_t> &slice_width, const std::vector<int64_t> &slice_base,
-                    const std::vector<int32_t> &cols, const std::vector<uint8_t> &count, SlicedEllSym *out)
+                    const int32_t *cols, const std::vector<uint8_t> &count, SlicedEllSym *out)
 {
     SlicedEllSym &S = *out;
     const int32_t n_slices = (int32_t)slice_width.size();
@@ -707,7 +732,7 @@ void pack_sliced_ell_sym(const Bsr &A, SlicedEllSym *out)
     static_cast<SlicedEll &>(*out) = std::move(base);
     std::vector<uint8_t> count((size_t)out->n_pad, 0);
     for (int32_t a = 0; a < A.nr; a++) count[a] = (uint8_t)std::min<int64_t>(255, U.ptr[a + 1] - U.ptr[a]);
-    build_in_lists(A.nr, out->slice_width, out->slice_base, out->cols, count, out);
+    build_in_lists(A.nr, out->slice_width, out->slice_base, out->cols.data(), count, out);
 }
 
 void mirror_upper(Bsr *Aio)

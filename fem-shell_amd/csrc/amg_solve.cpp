@@ -304,6 +304,7 @@ int amg_setup(femshell_ctx *c)
         AmgLevel &L1 = *H.levels.back();
         std::vector<double> Bc;
         pattern_of_plan(pl, &L0.pattern);
+        lap("node normals, pattern of K", 0);
         {
             // the near-null space of the finest level is generated from the mesh in HBM (never stored: n x 36 doubles)
             NearNullSrc src;
@@ -587,6 +588,7 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
         }
     }
     FS_HIP(hipStreamSynchronize(st));
+    lap("smoother coefficients, single-precision copies", (int)H.levels.size() - 1);
     H.valid = true;
     return FEMSHELL_OK;
 }
