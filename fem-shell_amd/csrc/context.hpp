@@ -86,7 +86,7 @@ struct femshell_ctx {
     // when the caller's numbering is kept.  dmask_global / loads_global and everything below are in internal numbering.
     std::vector<int32_t> perm, iperm;
     std::vector<uint8_t> dmask_global;  // n_nodes
-    std::vector<double> loads_global;   // n_nodes*6
+    femshell::RawVec<double> loads_global; // n_nodes*6
 
     femshell::DevBuf<double> xyz, vals, minv, loads, F;
     femshell::DevBuf<int32_t> tri, quad, slice_width, cols, pair_ptr, status;

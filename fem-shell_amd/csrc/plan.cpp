@@ -264,19 +264,40 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     if (n_tri < 0 || n_quad < 0 || (int64_t)n_tri + n_quad <= 0) return fail("mesh has no elements");
     if (world < 1 || rank < 0 || rank >= world) return fail("invalid rank/world_size");
     if ((int64_t)n_tri + n_quad >= (1ll << 28)) return fail("more than 2^28 elements");
-    for (int64_t q = 0; q < 3ll * n_tri; q++)
-        if (tri[q] < 0 || tri[q] >= n_nodes) return fail("triangle " + std::to_string(q / 3) + " references a node out of range");
-    for (int64_t q = 0; q < 4ll * n_quad; q++)
-        if (quad[q] < 0 || quad[q] >= n_nodes) return fail("quad " + std::to_string(q / 4) + " references a node out of range");
-    for (int32_t e = 0; e < n_tri; e++) {
-        const int32_t *c = tri + 3ll * e;
-        if (c[0] == c[1] || c[1] == c[2] || c[0] == c[2]) return fail("triangle " + std::to_string(e) + " repeats a node");
-    }
-    for (int32_t e = 0; e < n_quad; e++) {
-        const int32_t *c = quad + 4ll * e;
-        for (int i = 0; i < 4; i++)
-            for (int j = i + 1; j < 4; j++)
-                if (c[i] == c[j]) return fail("quad " + std::to_string(e) + " repeats a node");
+    {
+        // the first element (lowest index) of either kind that references a node out of range, and the first that repeats a
+        // node: found on the host threads, reported in the order the serial checks would find them
+        auto first_bad = [&](const int32_t *conn, int nn, int32_t ne, int64_t *out_of_range, int64_t *repeats) {
+            std::atomic<int64_t> oor{INT64_MAX}, rep{INT64_MAX};
+            auto lower = [](std::atomic<int64_t> &a, int64_t v) {
+                int64_t cur = a.load();
+                while (v < cur && !a.compare_exchange_weak(cur, v)) {}
+            };
+            plan_parallel(ne, 1 << 16, [&](int, int64_t e0, int64_t e1) {
+                int64_t o = INT64_MAX, r = INT64_MAX;
+                for (int64_t e = e0; e < e1 && (o == INT64_MAX || r == INT64_MAX); e++) {
+                    const int32_t *c = conn + nn * e;
+                    bool bad = false, twice = false;
+                    for (int i = 0; i < nn; i++) {
+                        bad |= c[i] < 0 || c[i] >= n_nodes;
+                        for (int j = i + 1; j < nn; j++) twice |= c[i] == c[j];
+                    }
+                    if (bad && o == INT64_MAX) o = e;
+                    if (twice && r == INT64_MAX) r = e;
+                }
+                lower(oor, o);
+                lower(rep, r);
+            });
+            *out_of_range = oor.load();
+            *repeats = rep.load();
+        };
+        int64_t t_oor, t_rep, q_oor, q_rep;
+        first_bad(tri, 3, n_tri, &t_oor, &t_rep);
+        first_bad(quad, 4, n_quad, &q_oor, &q_rep);
+        if (t_oor != INT64_MAX) return fail("triangle " + std::to_string(t_oor) + " references a node out of range");
+        if (q_oor != INT64_MAX) return fail("quad " + std::to_string(q_oor) + " references a node out of range");
+        if (t_rep != INT64_MAX) return fail("triangle " + std::to_string(t_rep) + " repeats a node");
+        if (q_rep != INT64_MAX) return fail("quad " + std::to_string(q_rep) + " repeats a node");
     }
 
     // FEMSHELL_PLAN_VERBOSE=1: wall time of the phases below on stderr.  lap(name) opens the phase `name` and prints the
