@@ -319,6 +319,7 @@ def config4_coupled_flap():
             "cg_iterations": o["cg_iterations"], "solve_seconds": o["solve_seconds"], "assemblies_of_K": o["assemblies_of_K"],
             "assembly_ms": o["assembly_ms"], "wall_seconds_program": o["wall_seconds_program"],
             "wall_note": "mesh reading (30 MB of XDA text), symbolic phase, assembly, multigrid setup, coupling loop, process start",
+            "program_phase_seconds": o.get("program_phase_seconds"),
             "tip_displacements": o["tips"], "tip_series_max_rel_diff_vs_unit_load_solution": o["tip_series_max_rel_diff"],
             "matrix_vs_oracle": o["matrix_vs_oracle"],
             "manufactured_solution_rel_err": man["rel_err_vs_manufactured"], "manufactured_solution_iterations": man["iterations"],

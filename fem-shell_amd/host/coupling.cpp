@@ -277,6 +277,7 @@ InProcessCoupling::Scheme scheme_from_xml(const std::string &path, int *dimensio
 
 int fem_shell_precice_main(int argc, char **argv, std::ostream &out, std::ostream &err)
 {
+    PhaseClock clock;
     out << "Starting Structure Solver..." << std::endl;
     if (argc < 7) {
         err << "Error, must choose valid parameters.\n"
@@ -311,6 +312,7 @@ int fem_shell_precice_main(int argc, char **argv, std::ostream &out, std::ostrea
     out << "Read command-line arguments.......OK" << std::endl;
     try {
         ShellMesh mesh = read_mesh(p.in_filename);
+        clock.done("read mesh");
         int dims = 2;
         const InProcessCoupling::Scheme scheme = scheme_from_xml(config, &dims);
         const char *fluid = arg_after(argc, argv, "-fluid"); // extension: "tower" (default) | "edge"
@@ -339,8 +341,10 @@ int fem_shell_precice_main(int argc, char **argv, std::ostream &out, std::ostrea
         // deterministic and see the full solution vector, PC:274-280), the structure solve is row-partitioned
         const Launch launch = Launch::from_environment();
         ShellSystem system(p, launch);
+        clock.done("coupling set-up, context (device, ranks)");
         mesh.loads.assign((size_t)mesh.n_nodes() * 6, 0.0);
         system.set_mesh(mesh);
+        clock.done("symbolic phase, boundary conditions");
         const std::array<int, 2> ax = dead_axis_components(deadAxis == '0' ? 'z' : deadAxis);
         int32_t probe = ifn[0];
         for (int32_t n : ifn)
@@ -374,6 +378,12 @@ int fem_shell_precice_main(int argc, char **argv, std::ostream &out, std::ostrea
             log = run_coupled_structure(interface, system, mesh, deadAxis, deltaT, p.tol, p.max_it, probe, ax[0],
                                         stepsv ? std::atoi(stepsv) : -1, launch.rank == 0 ? out : quiet, p.debug, write_step);
         if (launch.rank != 0) return 0;
+        clock.done("coupling loop (assembly, preconditioner setup, solves, per-step output)");
+        {
+            char note[120];
+            snprintf(note, sizeof note, "of which assembly %.4f, solves %.3f", log.assemble_seconds, log.solve_seconds);
+            clock.note(note);
+        }
         out << "Linear solver: " << (log.pc_type == FEMSHELL_PC_AMG ? "multigrid-preconditioned" : "6x6 block-Jacobi") << " CG on MI355X";
         if (launch.world_size > 1) out << " (" << launch.world_size << " ranks)";
         out << std::endl;
@@ -386,8 +396,10 @@ int fem_shell_precice_main(int argc, char **argv, std::ostream &out, std::ostrea
             const std::vector<double> sols = system.build_solution_vector();
             write_exodus(mesh, sols, p.out_filename + ".e");
             write_vtk(mesh, sols, p.out_filename + ".vtk");
+            clock.done("final output files");
         }
         out << "All done :)\n";
+        clock.report(err);
         return 0;
     } catch (const std::exception &e) {
         err << "ERROR: " << e.what() << std::endl;

@@ -291,8 +291,42 @@ SolveResult ShellSystem::solve(double tol, int max_it)
 
 const std::vector<double> &ShellSystem::build_solution_vector() { return sols_; }
 
+namespace {
+double wall_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+} // namespace
+
+PhaseClock::PhaseClock()
+{
+    const char *e = std::getenv("FEMSHELL_TIMING");
+    enabled_ = e && std::atoi(e) != 0;
+    start_ = last_ = wall_now();
+}
+
+void PhaseClock::done(const std::string &phase)
+{
+    const double t = wall_now();
+    phases_.emplace_back(phase, t - last_);
+    last_ = t;
+}
+
+void PhaseClock::report(std::ostream &err) const
+{
+    if (!enabled_) return;
+    char buf[64];
+    err << "Times [s]:";
+    for (const auto &p : phases_) {
+        snprintf(buf, sizeof buf, " %.3f", p.second);
+        err << " " << p.first << buf << " |";
+    }
+    snprintf(buf, sizeof buf, " %.3f", last_ - start_);
+    err << " total" << buf;
+    for (const std::string &n : notes_) err << " | " << n;
+    err << std::endl;
+}
+
 int fem_shell_main(int argc, char **argv, std::ostream &out, std::ostream &err)
 {
+    PhaseClock clock;
     Parameters p;
     if (read_parameters(argc, argv, p, out, err)) {
         out << "Read command-line arguments.......OK" << std::endl;
@@ -311,10 +345,20 @@ int fem_shell_main(int argc, char **argv, std::ostream &out, std::ostream &err)
         } catch (const std::exception &) {
             mesh.loads.assign((size_t)mesh.n_nodes() * 6, 0.0);
         }
+        clock.done("read mesh and loads");
         const Launch launch = Launch::from_environment();
         ShellSystem system(p, launch);
+        clock.done("context (device, ranks)");
         system.set_mesh(mesh);
+        clock.done("symbolic phase, boundary conditions, loads");
         const SolveResult res = system.solve(p.tol, p.max_it);
+        clock.done("assembly, preconditioner setup, solve");
+        {
+            char note[160];
+            snprintf(note, sizeof note, "of which assembly %.4f, preconditioner setup %.3f, iterations %.3f", res.info.assemble_seconds,
+                     res.info.pc_setup_seconds, res.info.solve_seconds);
+            clock.note(note);
+        }
         const std::vector<double> &sols = system.build_solution_vector();
         if (launch.rank != 0) return res.converged ? 0 : 2; // every rank holds the solution (SA:141); rank 0 reports it
         out << "Linear solver: " << (res.info.pc_type == FEMSHELL_PC_AMG ? "multigrid-preconditioned" : "6x6 block-Jacobi")
@@ -329,11 +373,14 @@ int fem_shell_main(int argc, char **argv, std::ostream &out, std::ostream &err)
             out << ", tx= " << s[3] << ", ty= " << s[4] << ", tz= " << s[5] << "]" << std::endl;
         }
         out << "]" << std::endl << std::endl;
+        clock.done("print the solution");
         if (p.isOutfileSet) {
             write_exodus(mesh, sols, p.out_filename + ".e"); // the reference's file (fem-shell.cpp:1249)
             write_vtk(mesh, sols, p.out_filename + ".vtk");
+            clock.done("output files");
         }
         out << "All done :)\n";
+        clock.report(err);
         return res.converged ? 0 : 2;
     } catch (const std::exception &e) {
         err << "ERROR: " << e.what() << std::endl;

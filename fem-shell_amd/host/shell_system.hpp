@@ -21,6 +21,7 @@
 
 #include <iosfwd>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "femshell.h"
@@ -55,6 +56,22 @@ struct Parameters {
 // PMI_SIZE), else a single rank.  The 128-byte RCCL id travels through a file: rank 0 writes FEMSHELL_UID_FILE
 // (default: $XDG_RUNTIME_DIR or /tmp/femshell-<uid>, 0700, file femshell_uid_<MASTER_PORT or parent pid>), the others wait for it -- the role MPI plays for the
 // reference (LibMeshInit, fem-shell.cpp:28).
+// FEMSHELL_TIMING=1: the wall time of the program's phases, one line on stderr when rank 0 is done (the reference's runs end
+// with libMesh's performance log; this is the twin's short form of it)
+class PhaseClock {
+public:
+    PhaseClock();
+    void done(const std::string &phase); // closes the phase that ran since the last call (or since construction)
+    void note(const std::string &text) { notes_.push_back(text); }
+    void report(std::ostream &err) const;
+
+private:
+    bool enabled_ = false;
+    double start_ = 0.0, last_ = 0.0;
+    std::vector<std::pair<std::string, double>> phases_;
+    std::vector<std::string> notes_;
+};
+
 struct Launch {
     int rank = 0, world_size = 1, device = -1;
     std::string uid_file;

@@ -105,9 +105,12 @@ def coupled_flap_full_size(coupled_tool, meshgen, workdir, config, steps=3, nx=5
     subprocess.check_call([meshgen, "t", str(nx), str(nz), "0", "0", "0.1", "1", "2,20,2,2", "1", "0", "1", "y", name])
     t0 = time.perf_counter()
     r = subprocess.run([coupled_tool, "-nu", "0.3", "-e", "1e6", "-t", "0.1", "-mesh", name + ".xda", "-config", config,
-                        "-dt", "0.01", "-axis", "y", "-steps", str(steps), "-fluid", "edge"], capture_output=True, text=True)
+                        "-dt", "0.01", "-axis", "y", "-steps", str(steps), "-fluid", "edge"], capture_output=True, text=True,
+                       env=dict(os.environ, FEMSHELL_TIMING="1"))
     wall = time.perf_counter() - t0
     out = {"returncode": r.returncode, "stderr_tail": r.stderr[-500:], "wall_seconds_program": wall, "steps": steps}
+    times = re.search(r"Times \[s\]: ([^\n]*)", r.stderr)  # the program's own account of its phases (FEMSHELL_TIMING=1)
+    out["program_phase_seconds"] = times.group(1) if times else None
     if r.returncode != 0:
         return out
     g = re.search(r"Coupled run: (\d+) time steps, (\d+) coupling iterations, (\d+) CG iterations, (\d+) assemblies of K, "

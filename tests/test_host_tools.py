@@ -145,10 +145,15 @@ def test_cli_reproduces_thesis_values(tools, tmp_path):
     for v in range(6):
         np.testing.assert_allclose(ex["vals_nod_var%d" % (v + 1)][0], u[:, v], rtol=1e-5, atol=1e-12)  # stdout keeps 6 digits
     np.testing.assert_allclose(ex["coordx"], m.xyz[:, 0] + ex["vals_nod_var1"][0], rtol=0, atol=1e-15)
+    assert "Times [s]" not in r.stderr
     mesh = os.path.join(meshes.MESH_DIR, "test_C_w_tA16.xda")
-    r = subprocess.run([fem, "-nu", "0.3", "-e", "10.92", "-t", "1.0", "-mesh", mesh], capture_output=True, text=True)
+    r = subprocess.run([fem, "-nu", "0.3", "-e", "10.92", "-t", "1.0", "-mesh", mesh], capture_output=True, text=True,
+                       env=dict(os.environ, FEMSHELL_TIMING="1"))
     assert r.returncode == 0, r.stderr
     assert parse_solution(r.stdout)[144, 2] == pytest.approx(1.15169, abs=6e-6)
+    # FEMSHELL_TIMING=1: the phases of the run on stderr (the twin's short form of libMesh's performance log)
+    line = [l for l in r.stderr.splitlines() if l.startswith("Times [s]:")]
+    assert len(line) == 1 and "read mesh and loads" in line[0] and "symbolic phase" in line[0] and "total" in line[0], r.stderr
 
 
 # ---------------------------------------------------------------- coupled program (preCICE adapter twin)
@@ -258,6 +263,7 @@ def test_coupled_flap_config5_full_size(tools, coupled_tool, tmp_path):
     run = out["manufactured"]["runs"][1]
     assert run["converged"] == 1 and run["rel_err_vs_manufactured"] < 1e-10, out["manufactured"]
     assert out["cg_iterations"] < 150 * out["coupling_iterations"], out
+    assert out["program_phase_seconds"] and "coupling loop" in out["program_phase_seconds"], out
 
 
 # ---------------------------------------------------------------- Gmsh input, PETSc-style options, several ranks
