@@ -2,6 +2,7 @@
 #include "mesh_io.hpp"
 
 #include <algorithm>
+#include <charconv>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -14,21 +15,64 @@ namespace femshell_host {
 
 namespace {
 
-std::string strip_comment(const std::string &line)
-{
-    const size_t h = line.find('#');
-    return h == std::string::npos ? line : line.substr(0, h);
-}
+// A text file held in memory as a whole, read line by line without copies: the readers of the large formats (ASCII XDA
+// and the force file: 30 MB / 60 MB at 1M triangles) parse numbers straight out of the buffer with std::from_chars --
+// a stream per line made reading the mesh the longest phase of a run of the coupled program.
+struct TextFile {
+    std::string buf;
+    std::vector<size_t> starts; // offset of every line, plus one past the end
 
-std::vector<std::string> read_lines(const std::string &path)
-{
-    std::ifstream in(path);
-    if (!in) throw std::runtime_error("cannot open " + path);
-    std::vector<std::string> out;
-    std::string l;
-    while (std::getline(in, l)) out.push_back(strip_comment(l));
-    return out;
-}
+    explicit TextFile(const std::string &path)
+    {
+        std::ifstream in(path, std::ios::binary);
+        if (!in) throw std::runtime_error("cannot open " + path);
+        in.seekg(0, std::ios::end);
+        const std::streamoff size = in.tellg();
+        in.seekg(0, std::ios::beg);
+        buf.resize(size > 0 ? (size_t)size : 0);
+        if (size > 0) in.read(&buf[0], size);
+        if (!in && size > 0) throw std::runtime_error("cannot read " + path);
+        const char *b = buf.data(), *e = b + buf.size();
+        for (const char *p = b; p < e;) {
+            starts.push_back((size_t)(p - b));
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+            p = nl ? nl + 1 : e;
+        }
+        starts.push_back(buf.size() + 1); // (as if a newline ended the last line)
+    }
+    size_t n_lines() const { return starts.size() - 1; }
+    // line i without its newline and without a trailing comment
+    void line(size_t i, const char **b, const char **e) const
+    {
+        *b = buf.data() + starts[i];
+        *e = buf.data() + std::min(starts[i + 1] - 1, buf.size());
+        if (const char *h = (const char *)memchr(*b, '#', (size_t)(*e - *b))) *e = h;
+    }
+    std::string line_text(size_t i) const
+    {
+        const char *b, *e;
+        line(i, &b, &e);
+        return std::string(b, e);
+    }
+};
+
+// numbers of one line (or of a whole buffer), the way `stream >> value` reads them: blanks skipped, an optional sign
+struct NumberCursor {
+    const char *p, *e;
+    void skip_blanks()
+    {
+        while (p < e && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n' || *p == '\f' || *p == '\v')) p++;
+    }
+    template <class T> bool read(T *v)
+    {
+        skip_blanks();
+        if (p < e && *p == '+' && p + 1 < e && p[1] != '-' && p[1] != '+') p++; // (from_chars takes no plus sign)
+        const std::from_chars_result r = std::from_chars(p, e, *v);
+        if (r.ec != std::errc()) return false;
+        p = r.ptr;
+        return true;
+    }
+};
 
 } // namespace
 
@@ -82,8 +126,9 @@ std::vector<int32_t> ShellMesh::nodes_with_ids(const std::vector<int32_t> &ids) 
 
 ShellMesh read_xda(const std::string &path)
 {
-    const std::vector<std::string> L = read_lines(path);
-    if (L.size() < 8 || L[0].rfind("libMesh", 0) != 0) throw std::runtime_error(path + ": not an ASCII XDA file");
+    const TextFile F(path);
+    if (F.n_lines() < 8 || F.line_text(0).rfind("libMesh", 0) != 0) throw std::runtime_error(path + ": not an ASCII XDA file");
+    const std::string header = F.line_text(0);
     ShellMesh m;
     auto count_of = [&](const std::string &line, const char *what) -> long {
         try {
@@ -94,55 +139,53 @@ ShellMesh read_xda(const std::string &path)
             throw std::runtime_error(path + ": bad " + what + " \"" + line.substr(0, 40) + "\"");
         }
     };
-    const long n_elem = count_of(L[1], "element count"), n_nodes = count_of(L[2], "node count");
+    const long n_elem = count_of(F.line_text(1), "element count"), n_nodes = count_of(F.line_text(2), "node count");
     size_t pos = 8;
-    if (L.size() < pos + (size_t)n_elem + (size_t)n_nodes + 1) throw std::runtime_error(path + ": truncated XDA file");
+    if (F.n_lines() < pos + (size_t)n_elem + (size_t)n_nodes + 1) throw std::runtime_error(path + ": truncated XDA file");
+    m.order.reserve((size_t)n_elem);
+    NumberCursor c{nullptr, nullptr};
     for (long e = 0; e < n_elem; e++, pos++) {
-        std::istringstream is(L[pos]);
-        int type;
-        is >> type;
-        if (type == 3) {
-            int32_t a, b, c;
-            is >> a >> b >> c;
+        F.line(pos, &c.p, &c.e);
+        int type = 0;
+        int32_t v[4] = {0, 0, 0, 0};
+        bool ok = c.read(&type);
+        if (ok && type == 3) {
+            ok = c.read(&v[0]) && c.read(&v[1]) && c.read(&v[2]);
             m.order.push_back({'t', m.n_tri()});
-            m.tri.insert(m.tri.end(), {a, b, c});
-        } else if (type == 5) {
-            int32_t a, b, c, d;
-            is >> a >> b >> c >> d;
+            m.tri.insert(m.tri.end(), {v[0], v[1], v[2]});
+        } else if (ok && type == 5) {
+            ok = c.read(&v[0]) && c.read(&v[1]) && c.read(&v[2]) && c.read(&v[3]);
             m.order.push_back({'q', m.n_quad()});
-            m.quad.insert(m.quad.end(), {a, b, c, d});
-        } else {
+            m.quad.insert(m.quad.end(), {v[0], v[1], v[2], v[3]});
+        } else if (ok) {
             throw std::runtime_error(path + ": unsupported element type " + std::to_string(type) +
                                      " (only TRI3 = 3 and QUAD4 = 5)");
         }
-        if (!is) throw std::runtime_error(path + ": bad element line " + std::to_string(e));
+        if (!ok) throw std::runtime_error(path + ": bad element line " + std::to_string(e));
     }
+    m.xyz.resize((size_t)n_nodes * 3);
     for (long n = 0; n < n_nodes; n++, pos++) {
-        std::istringstream is(L[pos]);
-        double x, y, z;
-        is >> x >> y >> z;
-        if (!is) throw std::runtime_error(path + ": bad node line " + std::to_string(n));
-        m.xyz.insert(m.xyz.end(), {x, y, z});
+        F.line(pos, &c.p, &c.e);
+        double *x = &m.xyz[3 * (size_t)n];
+        if (!(c.read(&x[0]) && c.read(&x[1]) && c.read(&x[2]))) throw std::runtime_error(path + ": bad node line " + std::to_string(n));
     }
-    const long n_bc = count_of(L[pos++], "boundary condition count");
-    for (long b = 0; b < n_bc && pos < L.size(); b++, pos++) {
-        std::istringstream is(L[pos]);
+    const long n_bc = count_of(F.line_text(pos++), "boundary condition count");
+    for (long b = 0; b < n_bc && pos < F.n_lines(); b++, pos++) {
+        F.line(pos, &c.p, &c.e);
         SideBC bc;
-        is >> bc.elem >> bc.side >> bc.id;
-        if (!is) throw std::runtime_error(path + ": bad boundary line " + std::to_string(b));
+        if (!(c.read(&bc.elem) && c.read(&bc.side) && c.read(&bc.id))) throw std::runtime_error(path + ": bad boundary line " + std::to_string(b));
         if (bc.elem < 0 || bc.elem >= n_elem) throw std::runtime_error(path + ": boundary element out of range");
         if (bc.side < 0 || bc.side >= (int32_t)m.element_nodes(bc.elem).size())
             throw std::runtime_error(path + ": boundary line " + std::to_string(b) + " names side " + std::to_string(bc.side) +
                                      " of an element with " + std::to_string(m.element_nodes(bc.elem).size()) + " sides");
         m.bcs.push_back(bc);
     }
-    if (L[0].rfind("libMesh-0.9.2+", 0) == 0 && pos < L.size() && !L[pos].empty() && L[pos].find_first_not_of(" \t\r") != std::string::npos) {
-        const long n_ns = count_of(L[pos++], "nodeset count"); // nodesets: (node, boundary id)
-        for (long b = 0; b < n_ns && pos < L.size(); b++, pos++) {
-            std::istringstream is(L[pos]);
-            int32_t node, id;
-            is >> node >> id;
-            if (!is || node < 0 || node >= n_nodes) throw std::runtime_error(path + ": bad nodeset line " + std::to_string(b));
+    if (header.rfind("libMesh-0.9.2+", 0) == 0 && pos < F.n_lines() && F.line_text(pos).find_first_not_of(" \t\r") != std::string::npos) {
+        const long n_ns = count_of(F.line_text(pos++), "nodeset count"); // nodesets: (node, boundary id)
+        for (long b = 0; b < n_ns && pos < F.n_lines(); b++, pos++) {
+            F.line(pos, &c.p, &c.e);
+            int32_t node = 0, id = 0;
+            if (!(c.read(&node) && c.read(&id)) || node < 0 || node >= n_nodes) throw std::runtime_error(path + ": bad nodeset line " + std::to_string(b));
             m.node_bcs.push_back({node, id});
         }
     }
@@ -451,17 +494,18 @@ std::string force_file_name(const std::string &mesh_path)
 
 std::vector<double> read_forces(const std::string &path, int32_t n_nodes)
 {
-    std::ifstream in(path);
-    if (!in) throw std::runtime_error("cannot open " + path);
+    const TextFile F(path);
+    NumberCursor c{F.buf.data(), F.buf.data() + F.buf.size()}; // (numbers in sequence, line breaks are blanks like any other)
     long n = 0;
     double factor = 1.0;
-    in >> n >> factor;
-    if (!in) throw std::runtime_error(path + ": bad force file header");
+    if (!(c.read(&n) && c.read(&factor))) throw std::runtime_error(path + ": bad force file header");
     std::vector<double> out((size_t)n_nodes * 6, 0.0);
-    for (long i = 0; i < n && i < n_nodes; i++)
-        for (int j = 0; j < 6; j++) {
+    bool more = true; // (a file that ends early, or holds something that is no number, leaves the rest zero)
+    for (long i = 0; i < n && i < n_nodes && more; i++)
+        for (int j = 0; j < 6 && more; j++) {
             double v = 0.0;
-            if (in >> v) out[(size_t)i * 6 + j] = v * factor;
+            more = c.read(&v);
+            if (more) out[(size_t)i * 6 + j] = v * factor;
         }
     return out;
 }

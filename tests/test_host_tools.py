@@ -313,6 +313,37 @@ def test_gmsh_reader_follows_the_thesis_listing(tools, tmp_path):
     assert r.returncode != 0 and "not one this reader knows" in r.stderr
 
 
+def test_ascii_xda_reader_takes_what_a_stream_would_take(tools, tmp_path):
+    """The XDA and force-file readers parse numbers straight out of the file buffer (host/mesh_io.cpp TextFile /
+    NumberCursor): the same files a `stream >> value` reader accepts are accepted -- comments behind the numbers, CR LF line
+    ends, plus signs, exponents, blank-separated columns -- and what it rejected is still rejected with the same words."""
+    conv = os.path.join(HOST, "meshConvert")
+    text = ("libMesh-0.7.0+\n2\t # number of elements\n4 # number of nodes\n.\nn/a\nn/a\nn/a\n2 # n_elem at level 0\n"
+            "3 0 1 2 # a triangle\n3   1\t3 2\n"
+            "+0.0 0.0 0\n1e0 0 0.\n.0 +1.5E+0 -0\n1 1.5 2.5e-1   # a node\n"
+            "2\n0 0 1\n1 1 0\n")
+    want_xyz = np.array([[0, 0, 0], [1, 0, 0], [0, 1.5, 0], [1, 1.5, 0.25]], dtype=float)
+    for name, body in (("unix", text), ("dos", text.replace("\n", "\r\n"))):
+        src = tmp_path / (name + ".xda")
+        src.write_bytes(body.encode())
+        out = str(tmp_path / (name + "_out.xda"))
+        subprocess.check_call([conv, str(src), out])
+        m = meshes.read_xda(out)
+        np.testing.assert_array_equal(m.xyz, want_xyz)
+        np.testing.assert_array_equal(m.tri, [[0, 1, 2], [1, 3, 2]])
+        assert m.bcs == [(0, 0, 1), (1, 1, 0)]
+    for broken, words in ((text.replace("3   1\t3 2", "3 1 x 2"), "bad element line 1"),
+                          (text.replace("1e0 0 0.", "1e0 zero 0."), "bad node line 1"),
+                          (text.replace("3 0 1 2 # a triangle", "4 0 1 2"), "unsupported element type 4"),
+                          (text.replace("1 1 0\n", "1 7 0\n"), "names side 7"),
+                          (text[:text.index("+0.0")], "truncated XDA file"),
+                          (text.replace("2\t # number of elements", "two"), "bad element count")):
+        src = tmp_path / "broken.xda"
+        src.write_text(broken)
+        r = subprocess.run([conv, str(src), str(tmp_path / "never.xda")], capture_output=True, text=True)
+        assert r.returncode != 0 and words in r.stderr, (words, r.stderr)
+
+
 def test_binary_xdr_round_trip(tools, tmp_path):
     """mesh.read() of the reference accepts *.xdr beside *.xda (fem-shell.cpp:35-37): the binary form of the same records
     (big-endian 32-bit integers / IEEE doubles, length-prefixed padded strings).  No libMesh here to write one, so the
