@@ -336,45 +336,16 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
         }
     });
     // A P: per fine row the union of the P rows of its neighbours
-    std::vector<int64_t> aptr((size_t)n + 1, 0);
+    std::vector<int64_t> aptr;
     RawVec<int32_t> acol;
-    {
-        std::vector<std::vector<int32_t>> parts; // per chunk, concatenated afterwards
-        std::vector<int32_t> cnt((size_t)n, 0);
-        const int nchunks = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (n + 4095) / 4096));
-        parts.resize((size_t)nchunks);
-        std::vector<std::thread> th;
-        auto work = [&](int t) {
-            const int64_t a0 = (int64_t)n * t / nchunks, a1 = (int64_t)n * (t + 1) / nchunks;
-            std::vector<int32_t> tmp, mine; // (the thread's own list, handed over at the end: the headers of parts[t] and
-                                            //  parts[t + 1] share a cache line)
-            mine.reserve((size_t)(a1 - a0) * 8);
-            for (int64_t a = a0; a < a1; a++) {
-                tmp.clear();
-                for (int64_t q = G.ptr[a]; q < G.ptr[a + 1]; q++) {
-                    const int32_t j = G.col[q];
-                    tmp.insert(tmp.end(), pcol.begin() + pptr[j], pcol.begin() + pptr[j + 1]);
-                }
-                std::sort(tmp.begin(), tmp.end());
-                tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-                cnt[a] = (int32_t)tmp.size();
-                mine.insert(mine.end(), tmp.begin(), tmp.end());
-            }
-            parts[(size_t)t].swap(mine);
-        };
-        for (int t = 1; t < nchunks; t++) th.emplace_back(work, t);
-        work(0);
-        for (auto &t : th) t.join();
-        for (int32_t a = 0; a < n; a++) aptr[a + 1] = aptr[a] + cnt[a];
-        acol.resize((size_t)aptr[n]);
-        parallel_chunks(nchunks, [&](int64_t t0, int64_t t1) { // every chunk's list to its place
-            for (int64_t t = t0; t < t1; t++) {
-                const int64_t a0 = (int64_t)n * t / nchunks;
-                std::copy(parts[(size_t)t].begin(), parts[(size_t)t].end(), acol.begin() + aptr[a0]);
-                std::vector<int32_t>().swap(parts[(size_t)t]);
-            }
-        }, 1);
-    }
+    build_rows(n, [&](int32_t a, std::vector<int32_t> &out) {
+        for (int64_t q = G.ptr[a]; q < G.ptr[a + 1]; q++) {
+            const int32_t j = G.col[q];
+            out.insert(out.end(), pcol.begin() + pptr[j], pcol.begin() + pptr[j + 1]);
+        }
+        std::sort(out.begin(), out.end());
+        out.erase(std::unique(out.begin(), out.end()), out.end());
+    }, &aptr, &acol);
     // R = P^T as lists: per aggregate the fine rows (ascending) and the slot of the aggregate in their P row
     std::vector<int64_t> rptr((size_t)na + 1, 0);
     RawVec<int32_t> rrow((size_t)pptr[n]);
@@ -434,39 +405,17 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     // A_c: per aggregate the union of the A P rows of its fine rows (symmetric storage: columns >= the row only; the
     // coarse operator is symmetric, the cycle applies the stored blocks to both rows)
     const bool sym_coarse = coarse_symmetric_storage(na);
-    std::vector<int64_t> cptr((size_t)na + 1, 0);
+    std::vector<int64_t> cptr;
     RawVec<int32_t> ccol;
-    {
-        // ranges of aggregates on the host threads, each into a list of its own, joined in order afterwards
-        const int nchunks = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (na + 1023) / 1024));
-        std::vector<std::vector<int32_t>> parts((size_t)nchunks);
-        std::vector<int32_t> cnt((size_t)na, 0);
-        parallel_chunks(nchunks, [&](int64_t t0, int64_t t1) {
-            for (int64_t t = t0; t < t1; t++) {
-                const int64_t I0 = (int64_t)na * t / nchunks, I1 = (int64_t)na * (t + 1) / nchunks;
-                std::vector<int32_t> tmp, mine;
-                for (int64_t I = I0; I < I1; I++) {
-                    tmp.clear();
-                    for (int64_t q = rptr[I]; q < rptr[I + 1]; q++) {
-                        const int32_t i = rrow[(size_t)q];
-                        tmp.insert(tmp.end(), acol.begin() + aptr[i], acol.begin() + aptr[i + 1]);
-                    }
-                    std::sort(tmp.begin(), tmp.end());
-                    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-                    const auto first = sym_coarse ? std::lower_bound(tmp.begin(), tmp.end(), (int32_t)I) : tmp.begin(); // diagonal and upper blocks
-                    cnt[(size_t)I] = (int32_t)(tmp.end() - first);
-                    mine.insert(mine.end(), first, tmp.end());
-                }
-                parts[(size_t)t].swap(mine);
-            }
-        }, 1);
-        for (int32_t I = 0; I < na; I++) cptr[(size_t)I + 1] = cptr[(size_t)I] + cnt[(size_t)I];
-        ccol.resize((size_t)cptr[(size_t)na]);
-        parallel_chunks(nchunks, [&](int64_t t0, int64_t t1) {
-            for (int64_t t = t0; t < t1; t++)
-                std::copy(parts[(size_t)t].begin(), parts[(size_t)t].end(), ccol.begin() + cptr[(size_t)((int64_t)na * t / nchunks)]);
-        }, 1);
-    }
+    build_rows(na, [&](int32_t I, std::vector<int32_t> &out) {
+        for (int64_t q = rptr[I]; q < rptr[I + 1]; q++) {
+            const int32_t i = rrow[(size_t)q];
+            out.insert(out.end(), acol.begin() + aptr[i], acol.begin() + aptr[i + 1]);
+        }
+        std::sort(out.begin(), out.end());
+        out.erase(std::unique(out.begin(), out.end()), out.end());
+        if (sym_coarse) out.erase(out.begin(), std::lower_bound(out.begin(), out.end(), I)); // diagonal and upper blocks
+    }, &cptr, &ccol);
     EllPattern eP, eAP, eR, eAc;
     if (!pack_pattern(n, pptr.data(), pcol.data(), false, &eP) || !pack_pattern(n, aptr.data(), acol.data(), false, &eAP) ||
         !pack_pattern(na, cptr.data(), ccol.data(), true, &eAc))

@@ -281,10 +281,10 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
 
     // ---- P: per own row the sorted distinct aggregates (keys) of its neighbours, ghost neighbours included
     std::vector<int64_t> pptr((size_t)n + 1, 0);
-    std::vector<int32_t> pcol;
+    RawVec<int32_t> pcol;
     {
         std::vector<uint8_t> cnt((size_t)n, 0);
-        std::vector<int32_t> tmp_all((size_t)G.ptr[(size_t)n]);
+        RawVec<int32_t> tmp_all((size_t)G.ptr[(size_t)n]);
         parallel_chunks(n, [&](int64_t a0, int64_t a1) {
             for (int64_t a = a0; a < a1; a++) {
                 int32_t *t = &tmp_all[(size_t)G.ptr[(size_t)a]];
@@ -386,24 +386,13 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
         const int s = r / kSliceNodes, nn = r % kSliceNodes;
         for (int k = 0; k < eP.count[(size_t)r]; k++) out.push_back(eP.cols[(size_t)(eP.slice_base[(size_t)s] + (int64_t)k * kSliceNodes + nn)]);
     };
-    std::vector<int64_t> aptr((size_t)n + 1, 0);
-    std::vector<int32_t> acol;
-    {
-        std::vector<std::vector<int32_t>> rows((size_t)n);
-        parallel_chunks(n, [&](int64_t a0, int64_t a1) {
-            std::vector<int32_t> tmp;
-            for (int64_t a = a0; a < a1; a++) {
-                tmp.clear();
-                for (int64_t q = G.ptr[(size_t)a]; q < G.ptr[(size_t)a + 1]; q++) p_row(G.col[(size_t)q], tmp);
-                std::sort(tmp.begin(), tmp.end());
-                tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-                rows[(size_t)a] = tmp;
-            }
-        }, 64);
-        for (int32_t a = 0; a < n; a++) aptr[(size_t)a + 1] = aptr[(size_t)a] + (int64_t)rows[(size_t)a].size();
-        acol.resize((size_t)aptr[(size_t)n]);
-        for (int32_t a = 0; a < n; a++) std::copy(rows[(size_t)a].begin(), rows[(size_t)a].end(), acol.begin() + aptr[(size_t)a]);
-    }
+    std::vector<int64_t> aptr;
+    RawVec<int32_t> acol;
+    build_rows(n, [&](int32_t a, std::vector<int32_t> &out) {
+        for (int64_t q = G.ptr[(size_t)a]; q < G.ptr[(size_t)a + 1]; q++) p_row(G.col[(size_t)q], out);
+        std::sort(out.begin(), out.end());
+        out.erase(std::unique(out.begin(), out.end()), out.end());
+    }, &aptr, &acol);
     ok = pack_pattern(n, aptr.data(), acol.data(), false, &eAP);
     if (!ok) (void)set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: a row of A P has more than 255 blocks");
     int64_t Wap = 0;
@@ -432,7 +421,7 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
     std::vector<uint8_t> rk;
     {
         auto own_key = [&](int32_t k) { return k >= key0 && k < key0 + na; };
-        auto each_entry = [&](const std::function<void(int32_t, int, int32_t)> &f) {
+        auto each_entry = [&](auto &&f) {
             for (int32_t r = 0; r < eP.n_rows; r++) {
                 if (r >= n && r < n_pad) continue;
                 const int s = r / kSliceNodes, nn = r % kSliceNodes;
@@ -456,39 +445,22 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
     // ---- A_c: per own aggregate the union of the A P rows of those fine rows; symmetric storage keeps the diagonal, the
     // own columns above it and every ghost column (the owner of a ghost column has its own copy of the block)
     const bool sym_coarse = res->next_dist && coarse_symmetric_storage(na);
-    std::vector<int64_t> cptr((size_t)na + 1, 0);
-    std::vector<int32_t> ccol;
-    {
-        std::vector<std::vector<int32_t>> rows((size_t)na);
-        parallel_chunks(na, [&](int64_t I0, int64_t I1) {
-            std::vector<int32_t> tmp;
-            for (int64_t I = I0; I < I1; I++) {
-                tmp.clear();
-                for (int64_t q = rptr[(size_t)I]; q < rptr[(size_t)I + 1]; q++) {
-                    const int32_t r = rrow[(size_t)q];
-                    const int s = r / kSliceNodes, nn = r % kSliceNodes;
-                    for (int k = 0; k < eAP.count[(size_t)r]; k++)
-                        tmp.push_back(eAP.cols[(size_t)(eAP.slice_base[(size_t)s] + (int64_t)k * kSliceNodes + nn)]);
-                }
-                std::sort(tmp.begin(), tmp.end());
-                tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-                if (sym_coarse) {
-                    const int32_t Ig = key0 + (int32_t)I;
-                    tmp.erase(std::remove_if(tmp.begin(), tmp.end(), [&](int32_t J) { return J >= key0 && J < Ig; }), tmp.end());
-                }
-                rows[(size_t)I] = tmp;
-            }
-        }, 64);
-        for (int32_t I = 0; I < na; I++) {
-            if (rows[(size_t)I].empty() || !std::binary_search(rows[(size_t)I].begin(), rows[(size_t)I].end(), key0 + I)) {
-                rows[(size_t)I].push_back(key0 + I); // (an aggregate without any support keeps a unit diagonal)
-                std::sort(rows[(size_t)I].begin(), rows[(size_t)I].end());
-            }
-            cptr[(size_t)I + 1] = cptr[(size_t)I] + (int64_t)rows[(size_t)I].size();
+    std::vector<int64_t> cptr;
+    RawVec<int32_t> ccol;
+    build_rows(na, [&](int32_t I, std::vector<int32_t> &out) {
+        for (int64_t q = rptr[(size_t)I]; q < rptr[(size_t)I + 1]; q++) {
+            const int32_t r = rrow[(size_t)q];
+            const int s = r / kSliceNodes, nn = r % kSliceNodes;
+            for (int k = 0; k < eAP.count[(size_t)r]; k++)
+                out.push_back(eAP.cols[(size_t)(eAP.slice_base[(size_t)s] + (int64_t)k * kSliceNodes + nn)]);
         }
-        ccol.resize((size_t)cptr[(size_t)na]);
-        for (int32_t I = 0; I < na; I++) std::copy(rows[(size_t)I].begin(), rows[(size_t)I].end(), ccol.begin() + cptr[(size_t)I]);
-    }
+        std::sort(out.begin(), out.end());
+        out.erase(std::unique(out.begin(), out.end()), out.end());
+        const int32_t Ig = key0 + I;
+        if (sym_coarse) out.erase(std::remove_if(out.begin(), out.end(), [&](int32_t J) { return J >= key0 && J < Ig; }), out.end());
+        if (!std::binary_search(out.begin(), out.end(), Ig)) // (an aggregate without any support keeps a unit diagonal)
+            out.insert(std::lower_bound(out.begin(), out.end(), Ig), Ig);
+    }, &cptr, &ccol);
     ok = pack_pattern(na, cptr.data(), ccol.data(), true, &eAc, key0);
     if (!ok) (void)set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: a row of a coarse operator has more than 255 blocks");
     if (ok) {

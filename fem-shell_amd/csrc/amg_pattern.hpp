@@ -3,6 +3,7 @@
 // back from ELL values to a host BSR matrix.
 #pragma once
 
+#include <algorithm>
 #include <vector>
 
 #include "amg_device.hpp"
@@ -20,6 +21,38 @@ struct EllPattern {
     int64_t nnzb = 0;
     int64_t total() const { return slice_base.empty() ? 0 : slice_base.back(); }
 };
+
+// Rows [0, n) as lists built by row(i, out) -- which appends the entries of row i to `out` (it arrives empty) -- on the host
+// threads: ranges of rows into lists of their own (a thread's list is its own until it is handed over: neighbouring
+// std::vector headers share cache lines), joined in row order.  Result: CSR arrays.
+template <class F> void build_rows(int32_t n, F row, std::vector<int64_t> *ptr_out, RawVec<int32_t> *col_out)
+{
+    const int nchunks = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), ((int64_t)n + 1023) / 1024));
+    std::vector<std::vector<int32_t>> parts((size_t)nchunks);
+    std::vector<int32_t> cnt((size_t)std::max(n, 0), 0);
+    parallel_chunks(nchunks, [&](int64_t t0, int64_t t1) {
+        for (int64_t t = t0; t < t1; t++) {
+            const int64_t a0 = (int64_t)n * t / nchunks, a1 = (int64_t)n * (t + 1) / nchunks;
+            std::vector<int32_t> tmp, mine;
+            mine.reserve((size_t)(a1 - a0) * 8);
+            for (int64_t a = a0; a < a1; a++) {
+                tmp.clear();
+                row((int32_t)a, tmp);
+                cnt[(size_t)a] = (int32_t)tmp.size();
+                mine.insert(mine.end(), tmp.begin(), tmp.end());
+            }
+            parts[(size_t)t].swap(mine);
+        }
+    }, 1);
+    std::vector<int64_t> &ptr = *ptr_out;
+    ptr.assign((size_t)n + 1, 0);
+    for (int32_t a = 0; a < n; a++) ptr[(size_t)a + 1] = ptr[(size_t)a] + cnt[(size_t)a];
+    col_out->resize((size_t)ptr[(size_t)n]);
+    parallel_chunks(nchunks, [&](int64_t t0, int64_t t1) {
+        for (int64_t t = t0; t < t1; t++)
+            std::copy(parts[(size_t)t].begin(), parts[(size_t)t].end(), col_out->begin() + ptr[(size_t)((int64_t)n * t / nchunks)]);
+    }, 1);
+}
 
 bool pack_pattern(int32_t n_rows, const int64_t *ptr, const int32_t *col, bool diag_first, EllPattern *out, int32_t diag_key = 0);
 
