@@ -9,6 +9,8 @@ namespace femshell {
 
 // ---- Chebyshev smoother ------------------------------------------------------------------------------------
 
+// (kD32: the direction is kept in single precision -- the input of a smoothing product with DeviceMatrix::vec32 == 2)
+template <bool kD32>
 __global__ __launch_bounds__(192) void k_cheb_start(DeviceMatrix m, const double *__restrict__ rin, double *__restrict__ d,
                                                     double *x, double inv_theta, int accumulate, const CgScalars *gate)
 {
@@ -25,20 +27,24 @@ __global__ __launch_bounds__(192) void k_cheb_start(DeviceMatrix m, const double
         rs[t] = rv;
         __syncthreads();
         const double dv = inv_theta * apply_minv(mr, t, rs);
-        d[row] = dv;
+        if (kD32) reinterpret_cast<float *>(d)[row] = (float)dv;
+        else d[row] = dv;
         x[row] = xv + dv;
     }
 }
 
 void launch_cheb_start(const DeviceMatrix &m, const double *rin, double *d, double *x, double inv_theta, bool accumulate,
-                       const CgScalars *gate, hipStream_t st)
+                       const CgScalars *gate, hipStream_t st, int vec32)
 {
-    hipLaunchKernelGGL(k_cheb_start, dim3(slice_grid(m)), dim3(192), 0, st, m, rin, d, x, inv_theta, accumulate ? 1 : 0, gate);
+    if (vec32 == 2) hipLaunchKernelGGL(k_cheb_start<true>, dim3(slice_grid(m)), dim3(192), 0, st, m, rin, d, x, inv_theta, accumulate ? 1 : 0, gate);
+    else hipLaunchKernelGGL(k_cheb_start<false>, dim3(slice_grid(m)), dim3(192), 0, st, m, rin, d, x, inv_theta, accumulate ? 1 : 0, gate);
 }
 
 // (kGather: symmetric storage, q holds the direct part of A d only -- launch_spmv_direct -- and the row adds the
 // transposed products of its in-list here, as k_cg_update<true> does for the CG iteration)
-template <bool kGather>
+// (kVec: what the smoothing product left in single precision, DeviceMatrix::vec32 -- 1: q and the transposed products are
+// floats in their buffers, 2: the direction d is kept as floats too; residual and iterate stay FP64)
+template <bool kGather, int kVec>
 __global__ __launch_bounds__(192) void k_cheb_step(DeviceMatrix m, const double *rin, const double *__restrict__ q,
                                                    double *rout, double *__restrict__ d, double *__restrict__ x, double a,
                                                    double c, const CgScalars *gate)
@@ -46,36 +52,54 @@ __global__ __launch_bounds__(192) void k_cheb_step(DeviceMatrix m, const double 
     __shared__ double rs[kSliceRows];
     if (gate != nullptr && gate->done != 0) return;
     const int t = threadIdx.x;
+    const float *qf = reinterpret_cast<const float *>(q), *tf = reinterpret_cast<const float *>(m.tbuf);
+    float *df = reinterpret_cast<float *>(d);
     for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
         const int sl = w.s;
         const int64_t row = (int64_t)sl * kSliceRows + t;
         const MinvRow mr = load_minv_smoother(m, sl, t);
-        double qv = q[row];
+        double qv = kVec >= 1 ? (double)qf[row] : q[row];
         if (kGather) {
             const int Wi = m.in_width[sl], n = t / 6, j = t % 6;
             const int64_t ib = m.in_base[sl];
-            for (int k = 0; k < Wi; k++) {
+            // the slot indices of the first entries together, then their products together (as in k_cg_update): one entry
+            // at a time is two dependent memory round trips per entry; the order of the additions is the same
+            int32_t slot4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) slot4[k] = (k < Wi) ? m.gat_slots[ib + (int64_t)k * kSliceNodes + n] : -1;
+            double t4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                t4[k] = slot4[k] < 0 ? 0.0 : (kVec >= 1 ? (double)tf[(int64_t)slot4[k] * 6 + j] : m.tbuf[(int64_t)slot4[k] * 6 + j]);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (slot4[k] >= 0) qv += t4[k];
+            for (int k = 4; k < Wi; k++) {
                 const int32_t slot = m.gat_slots[ib + (int64_t)k * kSliceNodes + n];
-                if (slot >= 0) qv += m.tbuf[(int64_t)slot * 6 + j];
+                if (slot >= 0) qv += kVec >= 1 ? (double)tf[(int64_t)slot * 6 + j] : m.tbuf[(int64_t)slot * 6 + j];
             }
         }
         const double rn = rin[row] - qv;
-        const double dv = d[row], xv = x[row];
+        const double dv = kVec == 2 ? (double)df[row] : d[row], xv = x[row];
         rout[row] = rn;
         __syncthreads();
         rs[t] = rn;
         __syncthreads();
         const double dn = a * dv + c * apply_minv(mr, t, rs);
-        d[row] = dn;
+        if (kVec == 2) df[row] = (float)dn;
+        else d[row] = dn;
         x[row] = xv + dn;
     }
 }
 
 void launch_cheb_step(const DeviceMatrix &m, const double *rin, const double *q, double *rout, double *d, double *x,
-                      double a, double c, const CgScalars *gate, hipStream_t st, bool gather)
+                      double a, double c, const CgScalars *gate, hipStream_t st, bool gather, int vec32)
 {
-    if (gather) hipLaunchKernelGGL(k_cheb_step<true>, dim3(slice_grid(m)), dim3(192), 0, st, m, rin, q, rout, d, x, a, c, gate);
-    else hipLaunchKernelGGL(k_cheb_step<false>, dim3(slice_grid(m)), dim3(192), 0, st, m, rin, q, rout, d, x, a, c, gate);
+    const dim3 grid(slice_grid(m)), block(192);
+    if (gather && vec32 == 2) hipLaunchKernelGGL((k_cheb_step<true, 2>), grid, block, 0, st, m, rin, q, rout, d, x, a, c, gate);
+    else if (gather && vec32 == 1) hipLaunchKernelGGL((k_cheb_step<true, 1>), grid, block, 0, st, m, rin, q, rout, d, x, a, c, gate);
+    else if (gather) hipLaunchKernelGGL((k_cheb_step<true, 0>), grid, block, 0, st, m, rin, q, rout, d, x, a, c, gate);
+    else hipLaunchKernelGGL((k_cheb_step<false, 0>), grid, block, 0, st, m, rin, q, rout, d, x, a, c, gate);
 }
 
 // ---- power iteration ---------------------------------------------------------------------------------------

@@ -14,11 +14,13 @@ namespace femshell {
 //   start: d = inv_theta * D^-1 rin;  x = d (zero initial guess) or x += d (accumulate)
 //   step:  r = rin - q (q = A d);  d = a d + c D^-1 r;  x += d        (rin may be r itself)
 // every kernel is a no-op once gate->done != 0 (gate may be null)
+// (vec32: what the smoothing products of the level keep in single precision, DeviceMatrix::vec32 -- 1: q and the transposed
+//  products, 2: the direction d as well; d and q are then arrays of floats in the same buffers)
 void launch_cheb_start(const DeviceMatrix &m, const double *rin, double *d, double *x, double inv_theta, bool accumulate,
-                       const CgScalars *gate, hipStream_t st);
+                       const CgScalars *gate, hipStream_t st, int vec32 = 0);
 // (gather: symmetric storage, q is the direct part of A d from launch_spmv_direct; the kernel collects the transposed products)
 void launch_cheb_step(const DeviceMatrix &m, const double *rin, const double *q, double *rout, double *d, double *x,
-                      double a, double c, const CgScalars *gate, hipStream_t st, bool gather = false);
+                      double a, double c, const CgScalars *gate, hipStream_t st, bool gather = false, int vec32 = 0);
 
 // power iteration for lambda_max(D^-1 A): z = D^-1 q with the partial sums of z.z (one per workgroup of slice_grid(m))
 void launch_minv_apply_norm(const DeviceMatrix &m, const double *q, double *z, double *partials, hipStream_t st);

@@ -17,6 +17,16 @@ namespace femshell {
 
 namespace {
 
+// FEMSHELL_AMG_VEC_F32: what a smoothing product on the single-precision copy of a level operator (symmetric storage) keeps
+// in single precision besides the values -- 2 (default): its results (direct part, transposed products) and its input, the
+// Chebyshev direction; 1: the results only; 0: nothing.  Residuals and iterates stay FP64.  Read per setup.
+int smooth_vectors_f32()
+{
+    const char *e = getenv("FEMSHELL_AMG_VEC_F32");
+    const int v = e ? atoi(e) : 2;
+    return v < 0 ? 0 : (v > 2 ? 2 : v);
+}
+
 double now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -582,6 +592,9 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
             L.smooth_dm = amg_level_matrix(c, (int)l);
             L.smooth_dm.vals32 = L.A32.p;
             L.smooth_dm.minv32 = L.minv32.p;
+            // a level whose vectors are exchanged with the neighbour ranks keeps the input of its products FP64 (the halo
+            // exchange moves six doubles per node)
+            L.smooth_dm.vec32 = L.A32.p == nullptr ? 0 : std::min(smooth_vectors_f32(), L.dist ? 1 : 2);
             L.P.dm.vals32 = L.P32.p;
             L.R.dm.vals32 = L.R32.p;
             L.smooth_ready = true;
@@ -631,13 +644,13 @@ struct Cycle {
     // y = K x on level 0 of a row-partitioned context: the halo exchange beside the interior slices (symmetric storage with
     // defer: the direct part only, the consumer collects the transposed products)
     // (vals32: a smoothing product on the single-precision copy of K's values)
-    void product0(double *x, double *y, bool defer, const float *vals32 = nullptr)
+    void product0(double *x, double *y, bool defer, const float *vals32 = nullptr, int vec32 = 0)
     {
         if (rc) return;
         CgVectors vv;
         vv.s = const_cast<CgScalars *>(gate);
         int np = 0;
-        rc = spmv_with_halo(c, vv, x, y, nullptr, &np, defer, vals32);
+        rc = spmv_with_halo(c, vv, x, y, nullptr, &np, defer, vals32, vec32);
     }
     // out = b - A_l x
     void residual(int l, const double *b, double *x, double *out)
@@ -663,21 +676,23 @@ struct Cycle {
         AmgLevel &L = *H.levels[(size_t)l];
         // (the operator as the smoother sees it: single-precision copies of the values and of D^-1 where the level has them)
         const DeviceMatrix &A = L.smooth_ready ? L.smooth_dm : amg_level_matrix(c, l);
+        // what the smoothing products keep in single precision besides the operator's values (DeviceMatrix::vec32)
+        const int v32 = (A.symmetric && A.vals32 != nullptr) ? A.vec32 : 0;
         const double *rcur = b;
         if (!zero_guess) {
             residual(l, b, x, L.r.p);
             rcur = L.r.p;
         }
-        launch_cheb_start(A, rcur, L.d.p, x, L.inv_theta, !zero_guess, gate, st);
+        launch_cheb_start(A, rcur, L.d.p, x, L.inv_theta, !zero_guess, gate, st, v32);
         double *d_cur = L.d.p, *d_next = L.q.p; // full-storage levels: the direction alternates between the two vectors
         for (size_t k = 0; k < L.cheb_a.size(); k++) {
             if (l == 0 && dist(0)) {
-                product0(L.d.p, L.q.p, A.symmetric != 0, A.vals32);
-                launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, A.symmetric != 0);
+                product0(L.d.p, L.q.p, A.symmetric != 0, A.vals32, v32);
+                launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, A.symmetric != 0, v32);
             } else if (A.symmetric) { // first phase of the product; the step kernel collects the transposed products
                 halo(l, L.d.p);
                 launch_spmv_direct(A, L.d.p, L.q.p, nullptr, gate, st, A.vals32 != nullptr);
-                launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, true);
+                launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, true, v32);
             } else if (fused_cheb()) { // product and step in one launch (the small levels are bound by launch latency)
                 halo(l, d_cur);
                 launch_spmv_cheb(A, d_cur, rcur, L.r.p, d_next, x, L.cheb_a[k], L.cheb_c[k], gate, st);
@@ -704,9 +719,16 @@ struct Cycle {
     {
         AmgLevel &L = *H.levels[(size_t)l];
         const DeviceMatrix &A = L.smooth_ready ? L.smooth_dm : amg_level_matrix(c, l);
+        // (a product that left its results in single precision -- DeviceMatrix::vec32 -- is collected into L.r, FP64: last_r
+        //  is L.r itself after a Chebyshev step, or the right-hand side of the level when the smoother has degree one)
+        const bool q32 = A.symmetric && A.vals32 != nullptr && A.vec32 >= 1;
         if (l == 0 && dist(0)) {
             if (A.symmetric) {
-                product0(last_d, L.q.p, true, A.vals32);
+                product0(last_d, L.q.p, true, A.vals32, A.vec32);
+                if (q32) {
+                    launch_sym_gather(A, L.q.p, last_r, -1.0, gate, st, true, L.r.p);
+                    return L.r.p;
+                }
                 launch_sym_gather(A, L.q.p, last_r, -1.0, gate, st);
                 return L.q.p;
             }
@@ -717,6 +739,10 @@ struct Cycle {
         halo(l, last_d);
         if (A.symmetric) {
             launch_spmv_direct(A, last_d, L.q.p, nullptr, gate, st, A.vals32 != nullptr);
+            if (q32) {
+                launch_sym_gather(A, L.q.p, last_r, -1.0, gate, st, true, L.r.p);
+                return L.r.p;
+            }
             launch_sym_gather(A, L.q.p, last_r, -1.0, gate, st);
             return L.q.p;
         }

@@ -30,13 +30,14 @@ int halo_exchange(femshell_ctx *c, double *p, hipStream_t st)
 // (xin: input vector with ghost space, yout = K xin, partial sums of xin.yout from partials[0] on)
 // (defer_gather: symmetric storage, the caller's next kernel collects the transposed products -- k_cg_update<true>)
 int spmv_with_halo(femshell_ctx *c, const CgVectors &v, double *xin, double *yout, double *partials, int *n_partials,
-                   bool defer_gather, const float *vals32)
+                   bool defer_gather, const float *vals32, int vec32)
 {
     hipStream_t st = c->stream;
     *n_partials = 0;
     defer_gather = defer_gather && c->dm.symmetric;
     DeviceMatrix dm = c->dm;
     dm.vals32 = (defer_gather && c->dm.symmetric) ? vals32 : nullptr; // (the single-precision copy serves the symmetric first phase)
+    dm.vec32 = dm.vals32 != nullptr ? vec32 : 0; // (what such a product keeps in single precision besides: DeviceMatrix::vec32)
     if (!c->halo_overlap) {
         int rc = halo_exchange(c, xin, st);
         if (rc) return rc;

@@ -143,7 +143,7 @@ int halo_exchange(femshell_ctx *c, double *vec, hipStream_t st);
 // collects the transposed products
 // (vals32: the products read this single-precision copy of K's values -- smoothing products of the multigrid cycle)
 int spmv_with_halo(femshell_ctx *c, const CgVectors &v, double *xin, double *yout, double *partials, int *n_partials,
-                   bool defer_gather = false, const float *vals32 = nullptr);
+                   bool defer_gather = false, const float *vals32 = nullptr, int vec32 = 0);
 // the two recurrences (cg_driver.cpp); the CG state is left in the context's vectors and scalars
 int cg_classic(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it);
 int cg_single_reduction(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it);

@@ -476,14 +476,26 @@ template <bool kF32> __device__ __forceinline__ v2d load_word(const double2 *v, 
 }
 
 // kF32: the blocks come from m.vals32 (single precision, same layout), the arithmetic stays FP64
-template <bool kF32>
+// kVec (with kF32 only; DeviceMatrix::vec32): 1 = y and the transposed products are stored as floats, 2 = x is read as floats too
+__device__ __forceinline__ void load_node6(const double *x, int64_t node, bool as_float, double out[6])
+{
+    if (as_float) {
+        const float2 *xf = reinterpret_cast<const float2 *>(x) + 3 * node;
+        const float2 a0 = xf[0], a1 = xf[1], a2 = xf[2];
+        out[0] = a0.x; out[1] = a0.y; out[2] = a1.x; out[3] = a1.y; out[4] = a2.x; out[5] = a2.y;
+    } else {
+        const double2 *xd = reinterpret_cast<const double2 *>(x) + 3 * node;
+        const double2 a0 = xd[0], a1 = xd[1], a2 = xd[2];
+        out[0] = a0.x; out[1] = a0.y; out[2] = a1.x; out[3] = a1.y; out[4] = a2.x; out[5] = a2.y;
+    }
+}
+template <bool kF32, int kVec>
 __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *__restrict__ x, double *__restrict__ y,
                                                  double *__restrict__ partials, const CgScalars *s,
                                                  const int32_t *__restrict__ order, int count)
 {
     if (s != nullptr && s->done != 0) return;
     const int lane = threadIdx.x, half = lane >> 5, n = lane & 31;
-    const double2 *x2 = reinterpret_cast<const double2 *>(x);
     double dotv = 0.0;
     extern __shared__ double2 lds_products[]; // [half][max_loc][3]: transposed products that stay inside a slice
     const bool has_local = m.loc_index != nullptr;
@@ -497,15 +509,13 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
         const int W = live ? m.slice_width[sl] : 0;
         const int a = sl * kSliceNodes + n;
         double xa[6], ya[6];
-        {
-            const double2 a0 = x2[3 * (int64_t)a], a1 = x2[3 * (int64_t)a + 1], a2 = x2[3 * (int64_t)a + 2];
-            xa[0] = a0.x; xa[1] = a0.y; xa[2] = a1.x; xa[3] = a1.y; xa[4] = a2.x; xa[5] = a2.y;
-        }
+        load_node6(x, a, kVec == 2, xa);
 #pragma unroll
         for (int i = 0; i < 6; i++) ya[i] = 0.0;
         const double2 *v = reinterpret_cast<const double2 *>(m.vals + base * 36) + n;
         const float2 *v32 = kF32 ? reinterpret_cast<const float2 *>(m.vals32 + base * 36) + n : nullptr;
         double2 *tb = reinterpret_cast<double2 *>(m.tbuf + base * 6);
+        float2 *tbf = reinterpret_cast<float2 *>(m.tbuf) + base * 3; // (kVec >= 1: float (slot * 6 + j) of the same buffer)
         const uint8_t *li = has_local ? m.loc_index + base + n : nullptr;
         if (W > 0) {
             // slot 0 is the diagonal block K_aa, which is symmetric: only the 12 of its 18 words that hold the upper
@@ -531,10 +541,7 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
 #pragma unroll
             for (int e = 0; e < 18; e++) wd[e] = load_word<kF32>(v, v32, ((size_t)k * 18 + e) * kSliceNodes); // word (jp = e/6, i = e%6)
             double xc[6];
-            {
-                const double2 c0 = x2[3 * (int64_t)c], c1 = x2[3 * (int64_t)c + 1], c2 = x2[3 * (int64_t)c + 2];
-                xc[0] = c0.x; xc[1] = c0.y; xc[2] = c1.x; xc[3] = c1.y; xc[4] = c2.x; xc[5] = c2.y;
-            }
+            load_node6(x, c, kVec == 2, xc);
             double u[6];
 #pragma unroll
             for (int j = 0; j < 6; j++) u[j] = 0.0;
@@ -553,10 +560,17 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
             if (c != a && c < m.n_pad) {
                 const int local = has_local ? (int)li[(size_t)k * kSliceNodes] : 255;
                 // (row c is a row of this slice: the product waits in LDS for the end of the slice, else next to the slot)
-                double2 *t = local != 255 ? lu + local * 3 : tb + ((size_t)k * kSliceNodes + n) * 3;
-                t[0] = make_double2(u[0], u[1]);
-                t[1] = make_double2(u[2], u[3]);
-                t[2] = make_double2(u[4], u[5]);
+                if (kVec >= 1 && local == 255) {
+                    float2 *t = tbf + ((size_t)k * kSliceNodes + n) * 3;
+                    t[0] = make_float2((float)u[0], (float)u[1]);
+                    t[1] = make_float2((float)u[2], (float)u[3]);
+                    t[2] = make_float2((float)u[4], (float)u[5]);
+                } else {
+                    double2 *t = local != 255 ? lu + local * 3 : tb + ((size_t)k * kSliceNodes + n) * 3;
+                    t[0] = make_double2(u[0], u[1]);
+                    t[1] = make_double2(u[2], u[3]);
+                    t[2] = make_double2(u[4], u[5]);
+                }
                 if (partials != nullptr)
                     dotv += xc[0] * u[0] + xc[1] * u[1] + xc[2] * u[2] + xc[3] * u[3] + xc[4] * u[4] + xc[5] * u[5];
             }
@@ -578,10 +592,17 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
             __syncthreads(); // the next slice overwrites the products
         }
         if (live) {
-            double2 *yo = reinterpret_cast<double2 *>(y) + 3 * (int64_t)a;
-            yo[0] = make_double2(ya[0], ya[1]);
-            yo[1] = make_double2(ya[2], ya[3]);
-            yo[2] = make_double2(ya[4], ya[5]);
+            if (kVec >= 1) {
+                float2 *yo = reinterpret_cast<float2 *>(y) + 3 * (int64_t)a;
+                yo[0] = make_float2((float)ya[0], (float)ya[1]);
+                yo[1] = make_float2((float)ya[2], (float)ya[3]);
+                yo[2] = make_float2((float)ya[4], (float)ya[5]);
+            } else {
+                double2 *yo = reinterpret_cast<double2 *>(y) + 3 * (int64_t)a;
+                yo[0] = make_double2(ya[0], ya[1]);
+                yo[1] = make_double2(ya[2], ya[3]);
+                yo[2] = make_double2(ya[4], ya[5]);
+            }
         }
     }
     if (partials != nullptr) {
@@ -590,22 +611,25 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
     }
 }
 
-__global__ __launch_bounds__(192) void k_sym_gather(DeviceMatrix m, double *y, const double *base_vec, double sign,
+// (kQ32: y and the transposed products were stored as floats by a smoothing product, DeviceMatrix::vec32; out is FP64)
+template <bool kQ32>
+__global__ __launch_bounds__(192) void k_sym_gather(DeviceMatrix m, const double *y, double *out, const double *base_vec, double sign,
                                                     const CgScalars *s)
 {
     if (s != nullptr && s->done != 0) return;
     const int t = threadIdx.x, n = t / 6, j = t % 6;
+    const float *yf = reinterpret_cast<const float *>(y), *tf = reinterpret_cast<const float *>(m.tbuf);
     for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
         const int sl = w.s;
         const int Wi = m.in_width[sl];
         const int64_t ib = m.in_base[sl];
         const int64_t row = (int64_t)sl * kSliceRows + t;
-        double acc = y[row];
+        double acc = kQ32 ? (double)yf[row] : y[row];
         for (int k = 0; k < Wi; k++) {
             const int32_t slot = m.gat_slots[ib + (int64_t)k * kSliceNodes + n];
-            if (slot >= 0) acc += m.tbuf[(int64_t)slot * 6 + j];
+            if (slot >= 0) acc += kQ32 ? (double)tf[(int64_t)slot * 6 + j] : m.tbuf[(int64_t)slot * 6 + j];
         }
-        y[row] = base_vec != nullptr ? base_vec[row] + sign * acc : acc;
+        out[row] = base_vec != nullptr ? base_vec[row] + sign * acc : acc;
     }
 }
 
@@ -613,10 +637,13 @@ static void spmv_sym_phase1(const DeviceMatrix &m, const double *x, double *y, d
                             const int32_t *order, int count, int grid, hipStream_t st, bool f32 = false)
 {
     const size_t lds = m.loc_index != nullptr ? (size_t)2 * m.max_loc * 48 : 0;
-    if (f32 && m.vals32 != nullptr)
-        hipLaunchKernelGGL(k_spmv_sym<true>, dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
-    else
-        hipLaunchKernelGGL(k_spmv_sym<false>, dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
+    if (f32 && m.vals32 != nullptr) {
+        if (m.vec32 == 2) hipLaunchKernelGGL((k_spmv_sym<true, 2>), dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
+        else if (m.vec32 == 1) hipLaunchKernelGGL((k_spmv_sym<true, 1>), dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
+        else hipLaunchKernelGGL((k_spmv_sym<true, 0>), dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
+    } else {
+        hipLaunchKernelGGL((k_spmv_sym<false, 0>), dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_to_f32(const double *__restrict__ src, float *__restrict__ dst, int64_t n)
@@ -629,9 +656,12 @@ void launch_to_f32(const double *src, float *dst, int64_t n, hipStream_t st)
     if (n > 0) hipLaunchKernelGGL(k_to_f32, dim3(4096), dim3(256), 0, st, src, dst, n);
 }
 
-void launch_sym_gather(const DeviceMatrix &m, double *y, const double *base_vec, double sign, const CgScalars *s, hipStream_t st)
+void launch_sym_gather(const DeviceMatrix &m, double *y, const double *base_vec, double sign, const CgScalars *s, hipStream_t st,
+                       bool q32, double *out)
 {
-    hipLaunchKernelGGL(k_sym_gather, dim3(slice_grid(m)), dim3(192), 0, st, m, y, base_vec, sign, s);
+    if (out == nullptr) out = y;
+    if (q32) hipLaunchKernelGGL(k_sym_gather<true>, dim3(slice_grid(m)), dim3(192), 0, st, m, y, out, base_vec, sign, s);
+    else hipLaunchKernelGGL(k_sym_gather<false>, dim3(slice_grid(m)), dim3(192), 0, st, m, y, out, base_vec, sign, s);
 }
 
 // Double-double residual with symmetric storage: a lane per scalar row walks the blocks of its own row (row i of the

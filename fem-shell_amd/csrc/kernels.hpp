@@ -41,6 +41,11 @@ struct DeviceMatrix {
     const uint8_t *dmask = nullptr;     // per local node (owned, padding, ghosts)
     double *vals = nullptr;             // total_slots x 36, sliced layout
     const float *vals32 = nullptr;      // the same in single precision (smoothing products of the multigrid cycle only)
+    // ... and what such a product (symmetric storage) keeps in single precision besides: 1 = its results -- the direct part
+    // y and the transposed products in tbuf, six floats where the FP64 product writes six doubles, in the same buffers --,
+    // 2 = its input vector as well.  The arithmetic stays FP64.  k_cheb_start / k_cheb_step / k_sym_gather are told the
+    // same number (amg_solve.cpp Cycle::smooth).
+    int32_t vec32 = 0;
     const double *rhs_loads = nullptr;  // n_pad x 6 nodal loads and
     double *rhs_F = nullptr;            // the right-hand side k_assemble fills beside K (nullptr: K only)
     // symmetric storage (plan.hpp): transposed products K_ac^T x_a next to every slot, collected per row
@@ -175,7 +180,10 @@ void launch_spmv_axpy(const DeviceMatrix &m, const double *x, double *y, const d
                       const CgScalars *s, hipStream_t st);
 // symmetric storage only: second phase of a product whose first phase ran through launch_spmv_span (the transposed
 // products of all slices must be in place): y = base_vec + sign * (y + sum of the row's transposed products)
-void launch_sym_gather(const DeviceMatrix &m, double *y, const double *base_vec, double sign, const CgScalars *s, hipStream_t st);
+// (q32: y and the transposed products come from a smoothing product that stored them in single precision -- DeviceMatrix::vec32 --
+//  and the result goes to `out`, FP64, which may be base_vec)
+void launch_sym_gather(const DeviceMatrix &m, double *y, const double *base_vec, double sign, const CgScalars *s, hipStream_t st,
+                       bool q32 = false, double *out = nullptr);
 // r = b - K x with double-double products and row sums (accurate residual for the residual replacement; r != x)
 void launch_residual_dd(const DeviceMatrix &m, const double *x, const double *b, double *r, hipStream_t st);
 // the same over the slices order[begin, begin+count) only (interior / boundary halves of an overlapped

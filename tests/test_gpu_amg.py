@@ -118,15 +118,21 @@ def test_single_precision_smoothing_products_leave_the_solution_alone(monkeypatc
     fs.set_preconditioner("amg", coarsest_nodes=60)
     u, info = fs.solve(rtol=1e-12, max_it=500)
     fs.close()
-    for mode in ("3", "2"):
+    # FEMSHELL_AMG_VEC_F32: what such a product keeps in single precision besides the values -- 0 nothing, 1 its results (direct
+    # part and transposed products), 2 (default) its input, the Chebyshev direction, as well
+    seen = []
+    for mode, vec in (("3", "2"), ("3", "1"), ("3", "0"), ("2", "2")):
         monkeypatch.setenv("FEMSHELL_AMG_SMOOTH_F32", mode)
+        monkeypatch.setenv("FEMSHELL_AMG_VEC_F32", vec)
         fs = _context(m, mat)
         fs.set_preconditioner("amg", coarsest_nodes=60)
         u32, info32 = fs.solve(rtol=1e-12, max_it=500)
         assert info32["converged"] == 1 and info32["amg_levels"] >= 3
-        assert abs(info32["iterations"] - info["iterations"]) <= 3, (mode, info["iterations"], info32["iterations"])
+        assert abs(info32["iterations"] - info["iterations"]) <= 3, (mode, vec, info["iterations"], info32["iterations"])
         assert not np.array_equal(u32, u)  # (the knob did something)
         assert np.linalg.norm(u32 - u) / np.linalg.norm(u) < 1e-10
+        assert all(not np.array_equal(u32, other) for other in seen)  # (... and every setting something of its own)
+        seen.append(u32)
         fs.close()
 
 
