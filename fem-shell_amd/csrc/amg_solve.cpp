@@ -621,6 +621,14 @@ bool fused_cheb()
     return !(e && atoi(e) == 0);
 }
 
+// FEMSHELL_AMG_POST_INCREMENT=0: the residual the post-smoothing starts from as b - A x, an FP64 product with the iterate, instead
+// of (restricted residual) - A (P x_c) on the smoother's copy of the operator (A/B runs)
+bool post_increment()
+{
+    const char *e = getenv("FEMSHELL_AMG_POST_INCREMENT");
+    return !(e && atoi(e) == 0);
+}
+
 // FEMSHELL_AMG_RESIDUAL_INCREMENT=0: the residual in front of a restriction as b - A x, a product of its own in FP64 (A/B runs)
 bool residual_increment()
 {
@@ -671,7 +679,8 @@ struct Cycle {
         launch_spmv_axpy(A, x, out, b, -1.0, gate, st);
     }
 
-    void smooth(int l, const double *b, double *x, bool zero_guess)
+    // (r_given: the residual of x, where the caller has it -- in L.r or a vector of its own, never L.q or L.d)
+    void smooth(int l, const double *b, double *x, bool zero_guess, const double *r_given = nullptr)
     {
         AmgLevel &L = *H.levels[(size_t)l];
         // (the operator as the smoother sees it: single-precision copies of the values and of D^-1 where the level has them)
@@ -680,8 +689,8 @@ struct Cycle {
         const int v32 = (A.symmetric && A.vals32 != nullptr) ? A.vec32 : 0;
         const double *rcur = b;
         if (!zero_guess) {
-            residual(l, b, x, L.r.p);
-            rcur = L.r.p;
+            if (r_given == nullptr) residual(l, b, x, L.r.p);
+            rcur = r_given != nullptr ? r_given : L.r.p;
         }
         launch_cheb_start(A, rcur, L.d.p, x, L.inv_theta, !zero_guess, gate, st, v32);
         double *d_cur = L.d.p, *d_next = L.q.p; // full-storage levels: the direction alternates between the two vectors
@@ -711,42 +720,46 @@ struct Cycle {
     const double *last_r = nullptr;
     double *last_d = nullptr;
 
-    // r = b - A x right behind a pre-smoothing from a zero guess, without a product with x: the smoother carries the
-    // residual of its iterate up to the last direction d it added, so r = last_r - A d, and since ||A d|| is of the size of
-    // the residual itself -- not of ||A|| ||x||, seven to nine decades above it -- the single-precision copy of the values
-    // serves (relative error 1e-7 of the increment).  Returns where the residual is (L.r or L.q).
-    double *residual_after_presmoothing(int l)
+    // r_base - A dvec without a product with the iterate.  Right behind a pre-smoothing from a zero guess the smoother carries
+    // the residual of its iterate up to the last direction d it added, so b - A x = last_r - A d; behind the coarse-grid
+    // correction e = P x_c the residual is the one that was restricted minus A e.  Either way the product is with an
+    // INCREMENT of the iterate, its result of the size of the residual itself -- not of ||A|| ||x||, seven to nine decades
+    // above it -- and the single-precision copy of the values serves (relative error 1e-7 of the increment; the numpy
+    // restatement with these products rounded needs the same iterations, tools/lab/f32_vectors_experiment.py).
+    // Returns where the result is: L.r, or L.q for the first of the two on a symmetric-storage level in FP64.
+    double *residual_minus_product(int l, const double *r_base, double *dvec)
     {
         AmgLevel &L = *H.levels[(size_t)l];
         const DeviceMatrix &A = L.smooth_ready ? L.smooth_dm : amg_level_matrix(c, l);
-        // (a product that left its results in single precision -- DeviceMatrix::vec32 -- is collected into L.r, FP64: last_r
-        //  is L.r itself after a Chebyshev step, or the right-hand side of the level when the smoother has degree one)
+        // (a product that left its results in single precision -- DeviceMatrix::vec32 -- is collected into L.r, FP64)
         const bool q32 = A.symmetric && A.vals32 != nullptr && A.vec32 >= 1;
+        // the buffer the direct part of a symmetric product lands in: not the one the base vector lives in
+        double *pb = (!q32 && r_base == L.q.p) ? L.r.p : L.q.p;
         if (l == 0 && dist(0)) {
             if (A.symmetric) {
-                product0(last_d, L.q.p, true, A.vals32, A.vec32);
+                product0(dvec, pb, true, A.vals32, A.vec32);
                 if (q32) {
-                    launch_sym_gather(A, L.q.p, last_r, -1.0, gate, st, true, L.r.p);
+                    launch_sym_gather(A, pb, r_base, -1.0, gate, st, true, L.r.p);
                     return L.r.p;
                 }
-                launch_sym_gather(A, L.q.p, last_r, -1.0, gate, st);
-                return L.q.p;
+                launch_sym_gather(A, pb, r_base, -1.0, gate, st);
+                return pb;
             }
-            product0(last_d, L.q.p, false);
-            launch_sub(last_r, L.q.p, L.r.p, 6ll * A.n_pad, st);
+            product0(dvec, L.q.p, false);
+            launch_sub(r_base, L.q.p, L.r.p, 6ll * A.n_pad, st);
             return L.r.p;
         }
-        halo(l, last_d);
+        halo(l, dvec);
         if (A.symmetric) {
-            launch_spmv_direct(A, last_d, L.q.p, nullptr, gate, st, A.vals32 != nullptr);
+            launch_spmv_direct(A, dvec, pb, nullptr, gate, st, A.vals32 != nullptr);
             if (q32) {
-                launch_sym_gather(A, L.q.p, last_r, -1.0, gate, st, true, L.r.p);
+                launch_sym_gather(A, pb, r_base, -1.0, gate, st, true, L.r.p);
                 return L.r.p;
             }
-            launch_sym_gather(A, L.q.p, last_r, -1.0, gate, st);
-            return L.q.p;
+            launch_sym_gather(A, pb, r_base, -1.0, gate, st);
+            return pb;
         }
-        launch_spmv_axpy(A, last_d, L.r.p, last_r, -1.0, gate, st); // (last_d is L.d or L.q, never L.r)
+        launch_spmv_axpy(A, dvec, L.r.p, r_base, -1.0, gate, st); // (dvec is L.d or L.q, never L.r; r_base may be L.r)
         return L.r.p;
     }
 
@@ -762,7 +775,8 @@ struct Cycle {
         AmgLevel &N = *H.levels[(size_t)l + 1];
         smooth(l, b, x, true);
         double *rf = L.r.p; // r = b - A x
-        if (residual_increment()) rf = residual_after_presmoothing(l);
+        const bool increments = residual_increment();
+        if (increments) rf = residual_minus_product(l, last_r, last_d);
         else residual(l, b, x, L.r.p);
         // b_c = R r
         if (dist(l)) {
@@ -783,6 +797,16 @@ struct Cycle {
         if (H.opt.cycle == FEMSHELL_CYCLE_K && !next_is_coarsest) kcycle(l + 1);
         else cycle(l + 1, N.b.p, N.x.p);
         if (N.dist) halo(l + 1, N.x.p);
+        if (increments && post_increment()) {
+            // x += e, e = P x_c kept in the direction vector -- as floats where the smoothing products read theirs as floats --
+            // and the residual the post-smoothing starts from is the restricted one minus A e
+            const DeviceMatrix &A = L.smooth_ready ? L.smooth_dm : amg_level_matrix(c, l);
+            const bool e32 = A.symmetric && A.vals32 != nullptr && A.vec32 == 2;
+            launch_spmv_axpy_keep(L.P.dm, N.x.p, x, x, 1.0, L.d.p, e32, gate, st);
+            const double *r2 = residual_minus_product(l, rf, L.d.p);
+            smooth(l, b, x, false, r2);
+            return;
+        }
         launch_spmv_axpy(L.P.dm, N.x.p, x, x, 1.0, gate, st); // x += P x_c
         smooth(l, b, x, false);
     }

@@ -363,6 +363,9 @@ struct ChebEpilogue {
     double *d_out = nullptr; // nullptr: plain product
     double *xsol = nullptr;
     double a = 0.0, c = 0.0;
+    // launch_spmv_axpy_keep: the product itself, K x without the base vector, is stored as well (as floats: prod_float)
+    double *prod_out = nullptr;
+    int prod_float = 0;
 };
 
 template <int kChunk, bool kF32 = false>
@@ -415,6 +418,10 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
         // base_vec: y = base + sign * K x (residual b - K x, prolongation x + P x_c); may alias y
         const double yv = base_vec != nullptr ? base_vec[row] + sign * acc : acc;
         y[row] = yv;
+        if (cheb.prod_out != nullptr) {
+            if (cheb.prod_float) reinterpret_cast<float *>(cheb.prod_out)[row] = (float)acc;
+            else cheb.prod_out[row] = acc;
+        }
         if (cheb.d_out != nullptr) {
             // d_out = a d_in + c D^-1 r_out on the lane's row; the six residual entries of its node sit in six lanes of
             // three waves (lane = node + 32 dof): exchanged through LDS
@@ -868,6 +875,15 @@ void launch_spmv_axpy(const DeviceMatrix &m, const double *x, double *y, const d
         return;
     }
     spmv_dispatch(m, x, y, nullptr, s, nullptr, m.n_slices, slice_grid(m), st, base_vec, sign);
+}
+
+void launch_spmv_axpy_keep(const DeviceMatrix &m, const double *x, double *y, const double *base_vec, double sign, double *prod_out,
+                           bool prod_float, const CgScalars *s, hipStream_t st)
+{
+    ChebEpilogue e;
+    e.prod_out = prod_out;
+    e.prod_float = prod_float ? 1 : 0;
+    spmv_dispatch(m, x, y, nullptr, s, nullptr, m.n_slices, slice_grid(m), st, base_vec, sign, e);
 }
 
 int span_grid(const DeviceMatrix &m, int count)

@@ -178,6 +178,10 @@ void launch_spmv_cheb(const DeviceMatrix &m, const double *d_in, const double *r
                       double a, double c, const CgScalars *s, hipStream_t st);
 void launch_spmv_axpy(const DeviceMatrix &m, const double *x, double *y, const double *base_vec, double sign,
                       const CgScalars *s, hipStream_t st);
+// full storage only: the same, and the product itself (K x, without the base vector) into prod_out -- as floats in that buffer
+// when prod_float (the coarse correction P x_c, which the cycle adds to its iterate and then multiplies with the level operator)
+void launch_spmv_axpy_keep(const DeviceMatrix &m, const double *x, double *y, const double *base_vec, double sign, double *prod_out,
+                           bool prod_float, const CgScalars *s, hipStream_t st);
 // symmetric storage only: second phase of a product whose first phase ran through launch_spmv_span (the transposed
 // products of all slices must be in place): y = base_vec + sign * (y + sum of the row's transposed products)
 // (q32: y and the transposed products come from a smoothing product that stored them in single precision -- DeviceMatrix::vec32 --
