@@ -663,6 +663,10 @@ def main():
         _, ic = fs.solve(rtol=1e-10, max_it=3000, fetch=False)
         tts = {"preconditioner": "smoothed-aggregation multigrid (rigid-body modes, Chebyshev/block-Jacobi smoothing, K cycle), "
                                  "flexible CG, 1 refinement pass with a double-double residual",
+               "precision": "FP64 arithmetic throughout; the Krylov method, the K cycle's products, the Galerkin operators, residuals and "
+                            "iterates are FP64 data; what the cycle only smooths or transfers with is read from single-precision copies "
+                            "(level operators, D^-1, P, R on levels of >= 4096 nodes; products, transposed products and directions of "
+                            "the smoother), the cycle's two residuals are increments on those copies (DESIGN section 5)",
                "rtol": 1e-10, "iterations": ia["iterations"], "converged": ia["converged"],
                "solve_seconds": ia["solve_seconds"], "pc_setup_seconds": ia["pc_setup_seconds"], "wall_seconds_first_solve": wall,
                "solve_seconds_hierarchy_reused": ib["solve_seconds"], "levels": ia["amg_levels"],
