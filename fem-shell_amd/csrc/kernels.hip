@@ -423,6 +423,9 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
             else cheb.prod_out[row] = acc;
         }
         if (cheb.d_out != nullptr) {
+            // (MEASURED, round 4: fetching the epilogue's operands -- D^-1 row, d, x, base vector -- ahead of the product, in an
+            //  instantiation of its own, costs 24 registers and a wave per SIMD there and was 2 % SLOWER on the 4M solves
+            //  although the small levels are latency chains: profiles/r04_spmv_epilogue_prefetch_ab.txt.  Left as it is.)
             // d_out = a d_in + c D^-1 r_out on the lane's row; the six residual entries of its node sit in six lanes of
             // three waves (lane = node + 32 dof): exchanged through LDS
             const int n = t & 31, i = t >> 5;
