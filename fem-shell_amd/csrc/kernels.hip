@@ -635,11 +635,24 @@ __global__ __launch_bounds__(192) void k_sym_gather(DeviceMatrix m, const double
         const int64_t ib = m.in_base[sl];
         const int64_t row = (int64_t)sl * kSliceRows + t;
         double acc = kQ32 ? (double)yf[row] : y[row];
-        for (int k = 0; k < Wi; k++) {
+        const double bv = base_vec != nullptr ? base_vec[row] : 0.0;
+        // the slot indices of the first entries together, then their products together (as in k_cg_update): one entry at a
+        // time is two dependent memory round trips per entry; the order of the additions is the same
+        int32_t slot4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) slot4[k] = (k < Wi) ? m.gat_slots[ib + (int64_t)k * kSliceNodes + n] : -1;
+        double t4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            t4[k] = slot4[k] < 0 ? 0.0 : (kQ32 ? (double)tf[(int64_t)slot4[k] * 6 + j] : m.tbuf[(int64_t)slot4[k] * 6 + j]);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (slot4[k] >= 0) acc += t4[k];
+        for (int k = 4; k < Wi; k++) {
             const int32_t slot = m.gat_slots[ib + (int64_t)k * kSliceNodes + n];
             if (slot >= 0) acc += kQ32 ? (double)tf[(int64_t)slot * 6 + j] : m.tbuf[(int64_t)slot * 6 + j];
         }
-        out[row] = base_vec != nullptr ? base_vec[row] + sign * acc : acc;
+        out[row] = base_vec != nullptr ? bv + sign * acc : acc;
     }
 }
 
