@@ -487,6 +487,9 @@ template <bool kF32> __device__ __forceinline__ v2d load_word(const double2 *v, 
 
 // kF32: the blocks come from m.vals32 (single precision, same layout), the arithmetic stays FP64
 // kVec (with kF32 only; DeviceMatrix::vec32): 1 = y and the transposed products are stored as floats, 2 = x is read as floats too
+// (The float-storing variants compile to 182-194 registers, two waves per SIMD where the FP64 product has three.  MEASURED, round
+//  4: held to three waves -- amdgpu_waves_per_eu(3, 3), 168 registers, five dwords spilled -- the 4M solves take the same time
+//  within the run-to-run scatter of 1 %: profiles/r04_spmv_sym_waves_ab.txt, four alternating rounds.  Left to the compiler.)
 __device__ __forceinline__ void load_node6(const double *x, int64_t node, bool as_float, double out[6])
 {
     if (as_float) {
