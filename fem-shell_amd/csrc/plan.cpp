@@ -333,48 +333,89 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     //      element = combined id (triangles first), ascending per node
     const int32_t n_own = p.n_own;
     std::vector<int64_t> adj_ptr((size_t)n_own + 1, 0);
-    auto count = [&](const int32_t *conn, int nn, int32_t ne) {
-        for (int64_t q = 0; q < (int64_t)nn * ne; q++) {
-            const int32_t a = conn[q];
-            if (a >= g0 && a < g1) adj_ptr[a - g0 + 1]++;
-        }
+    // Ranges of owned nodes on the host threads: every thread walks the whole connectivity and keeps what falls into its
+    // range, once to count and once to fill -- the entries of a node in ascending element order, as a serial counting
+    // sort leaves them.
+    const int n_ranges = plan_chunks(n_own, 32768);
+    auto range_of = [&](int64_t t, int32_t *a0, int32_t *a1) {
+        *a0 = (int32_t)((int64_t)n_own * t / n_ranges);
+        *a1 = (int32_t)((int64_t)n_own * (t + 1) / n_ranges);
     };
-    count(tri, 3, n_tri);
-    count(quad, 4, n_quad);
+    plan_parallel(n_ranges, 1, [&](int, int64_t t0, int64_t t1) {
+        for (int64_t t = t0; t < t1; t++) {
+            int32_t a0, a1;
+            range_of(t, &a0, &a1);
+            const uint32_t span = (uint32_t)(a1 - a0);
+            const int32_t first = g0 + a0;
+            auto count = [&](const int32_t *conn, int64_t n) {
+                for (int64_t q = 0; q < n; q++) {
+                    const uint32_t d = (uint32_t)(conn[q] - first);
+                    if (d < span) adj_ptr[(size_t)a0 + d + 1]++;
+                }
+            };
+            count(tri, 3ll * n_tri);
+            count(quad, 4ll * n_quad);
+        }
+    });
     for (int32_t a = 0; a < n_own; a++) {
         if (adj_ptr[a + 1] == 0) return fail("node " + std::to_string(g0 + a) + " is not attached to any element");
         adj_ptr[a + 1] += adj_ptr[a];
     }
     RawVec<uint32_t> adj((size_t)adj_ptr[n_own]);
-    {
-        std::vector<int64_t> fill(adj_ptr.begin(), adj_ptr.end() - 1);
-        for (int32_t e = 0; e < n_tri; e++)
-            for (int i = 0; i < 3; i++) {
-                const int32_t a = tri[3ll * e + i];
-                if (a >= g0 && a < g1) adj[fill[a - g0]++] = ((uint32_t)e << 2) | (uint32_t)i;
-            }
-        for (int32_t e = 0; e < n_quad; e++)
-            for (int i = 0; i < 4; i++) {
-                const int32_t a = quad[4ll * e + i];
-                if (a >= g0 && a < g1) adj[fill[a - g0]++] = ((uint32_t)(n_tri + e) << 2) | (uint32_t)i;
-            }
-    }
+    plan_parallel(n_ranges, 1, [&](int, int64_t t0, int64_t t1) {
+        for (int64_t t = t0; t < t1; t++) {
+            int32_t a0, a1;
+            range_of(t, &a0, &a1);
+            const uint32_t span = (uint32_t)(a1 - a0);
+            const int32_t first = g0 + a0;
+            std::vector<int64_t> fill(adj_ptr.begin() + a0, adj_ptr.begin() + a1);
+            for (int32_t e = 0; e < n_tri; e++)
+                for (int i = 0; i < 3; i++) {
+                    const uint32_t d = (uint32_t)(tri[3ll * e + i] - first);
+                    if (d < span) adj[(size_t)fill[d]++] = ((uint32_t)e << 2) | (uint32_t)i;
+                }
+            for (int32_t e = 0; e < n_quad; e++)
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t d = (uint32_t)(quad[4ll * e + i] - first);
+                    if (d < span) adj[(size_t)fill[d]++] = ((uint32_t)(n_tri + e) << 2) | (uint32_t)i;
+                }
+        }
+    });
 
     lap("local elements");
-    // ---- local elements: every element touching an owned node
-    std::vector<int32_t> elem_local((size_t)n_tri + n_quad, -1);
-    for (uint32_t v : adj) elem_local[v >> 2] = 0;
-    for (int32_t e = 0; e < n_tri; e++)
-        if (elem_local[e] == 0) {
-            elem_local[e] = (int32_t)p.tri_global_id.size();
-            p.tri_global_id.push_back(e);
-        }
+    // ---- local elements: every element touching an owned node, numbered in input order (triangles, then quadrilaterals)
+    RawVec<int32_t> elem_local((size_t)n_tri + n_quad);
+    auto number_local = [&](const int32_t *conn, int nn, int32_t ne, int32_t id_offset, int32_t first_local, std::vector<int32_t> *global_ids) {
+        const int nch = plan_chunks(ne, 1 << 16);
+        std::vector<int32_t> chunk_count((size_t)nch + 1, 0);
+        plan_parallel(nch, 1, [&](int, int64_t c0, int64_t c1) {
+            for (int64_t c = c0; c < c1; c++) {
+                int32_t k = 0;
+                for (int64_t e = (int64_t)ne * c / nch; e < (int64_t)ne * (c + 1) / nch; e++) {
+                    bool touches = false;
+                    for (int i = 0; i < nn; i++) touches |= (uint32_t)(conn[nn * e + i] - g0) < (uint32_t)n_own;
+                    elem_local[(size_t)(id_offset + e)] = touches ? 0 : -1;
+                    k += touches ? 1 : 0;
+                }
+                chunk_count[(size_t)c + 1] = k;
+            }
+        });
+        for (int c = 0; c < nch; c++) chunk_count[(size_t)c + 1] += chunk_count[(size_t)c];
+        global_ids->resize((size_t)chunk_count[(size_t)nch]);
+        plan_parallel(nch, 1, [&](int, int64_t c0, int64_t c1) {
+            for (int64_t c = c0; c < c1; c++) {
+                int32_t at = chunk_count[(size_t)c];
+                for (int64_t e = (int64_t)ne * c / nch; e < (int64_t)ne * (c + 1) / nch; e++)
+                    if (elem_local[(size_t)(id_offset + e)] == 0) {
+                        elem_local[(size_t)(id_offset + e)] = first_local + at;
+                        (*global_ids)[(size_t)at++] = (int32_t)e;
+                    }
+            }
+        });
+    };
+    number_local(tri, 3, n_tri, 0, 0, &p.tri_global_id);
     const int32_t n_ltri = (int32_t)p.tri_global_id.size();
-    for (int32_t e = 0; e < n_quad; e++)
-        if (elem_local[n_tri + e] == 0) {
-            elem_local[n_tri + e] = n_ltri + (int32_t)p.quad_global_id.size();
-            p.quad_global_id.push_back(e);
-        }
+    number_local(quad, 4, n_quad, n_tri, n_ltri, &p.quad_global_id);
 
     lap("slot structures");
     // ---- per owned node: block slots (slot 0 = diagonal, then ascending global column) and
