@@ -28,12 +28,13 @@ struct EllPattern {
 template <class F> void build_rows(int32_t n, F row, std::vector<int64_t> *ptr_out, RawVec<int32_t> *col_out)
 {
     const int nchunks = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), ((int64_t)n + 1023) / 1024));
-    std::vector<std::vector<int32_t>> parts((size_t)nchunks);
+    std::vector<RawVec<int32_t>> parts((size_t)nchunks);
     std::vector<int32_t> cnt((size_t)std::max(n, 0), 0);
     parallel_chunks(nchunks, [&](int64_t t0, int64_t t1) {
         for (int64_t t = t0; t < t1; t++) {
             const int64_t a0 = (int64_t)n * t / nchunks, a1 = (int64_t)n * (t + 1) / nchunks;
-            std::vector<int32_t> tmp, mine;
+            std::vector<int32_t> tmp;
+            RawVec<int32_t> mine;
             mine.reserve((size_t)(a1 - a0) * 8);
             for (int64_t a = a0; a < a1; a++) {
                 tmp.clear();

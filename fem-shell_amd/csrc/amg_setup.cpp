@@ -107,14 +107,14 @@ void node_normals(int32_t n, const double *xyz, int64_t n_tri, const int32_t *tr
             };
             for (int64_t e = 0; e < n_tri; e++) {
                 const int32_t *c = tri + 3 * e;
-                if (!(mine(c[0]) | mine(c[1]) | mine(c[2]))) continue;
+                if (!(mine(c[0]) || mine(c[1]) || mine(c[2]))) continue;
                 double w[3];
                 cross_of(c[0], c[1], c[2], w);
                 for (int i = 0; i < 3; i++) add(c[i], w);
             }
             for (int64_t e = 0; e < n_quad; e++) {
                 const int32_t *c = quad + 4 * e;
-                if (!(mine(c[0]) | mine(c[1]) | mine(c[2]) | mine(c[3]))) continue;
+                if (!(mine(c[0]) || mine(c[1]) || mine(c[2]) || mine(c[3]))) continue;
                 double w[3], w2[3];
                 cross_of(c[0], c[1], c[2], w);
                 cross_of(c[0], c[2], c[3], w2);

@@ -2,6 +2,7 @@
 #include "plan.hpp"
 
 #include <sched.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <climits>
@@ -14,6 +15,26 @@
 #include <thread>
 
 namespace femshell {
+
+namespace {
+constexpr std::size_t kHugeAlign = (std::size_t)2 << 20, kHugeFrom = (std::size_t)4 << 20;
+}
+void *raw_allocate(std::size_t bytes)
+{
+    if (bytes < kHugeFrom) return ::operator new(bytes);
+    const std::size_t rounded = (bytes + kHugeAlign - 1) / kHugeAlign * kHugeAlign;
+    void *p = std::aligned_alloc(kHugeAlign, rounded);
+    if (p == nullptr) throw std::bad_alloc();
+    // FEMSHELL_HUGEPAGES=0: no advice (a host whose memory is so fragmented that the kernel compacts it inside the page faults)
+    static const bool advise = !(getenv("FEMSHELL_HUGEPAGES") && atoi(getenv("FEMSHELL_HUGEPAGES")) == 0);
+    if (advise) (void)madvise(p, rounded, MADV_HUGEPAGE); // (advice: refused or unavailable, the array is an ordinary one)
+    return p;
+}
+void raw_deallocate(void *p, std::size_t bytes) noexcept
+{
+    if (bytes < kHugeFrom) ::operator delete(p);
+    else std::free(p);
+}
 
 int available_cpus()
 {
@@ -570,8 +591,8 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         // chunks of rows on the host threads, each into lists of its own (slot_pair_ptr relative to the chunk), joined in
         // row order afterwards
         const int nchunks_r = plan_chunks(n_own, 4096);
-        std::vector<std::vector<int32_t>> part_col((size_t)nchunks_r), part_ptr((size_t)nchunks_r);
-        std::vector<std::vector<uint32_t>> part_pairs((size_t)nchunks_r);
+        std::vector<RawVec<int32_t>> part_col((size_t)nchunks_r), part_ptr((size_t)nchunks_r);
+        std::vector<RawVec<uint32_t>> part_pairs((size_t)nchunks_r);
         plan_parallel(n_own, 4096, [&](int t, int64_t a0, int64_t a1) {
             std::vector<Slot> slots;
             std::vector<uint32_t> tmp_pairs; // packed pair
@@ -579,8 +600,8 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             std::vector<int> order;
             // (lists of the thread's own, handed over at the end: the headers of part_col[t] and part_col[t + 1] share a cache
             //  line, and every push_back through them made the threads take turns -- this loop did not scale at all)
-            std::vector<int32_t> pc, pp;
-            std::vector<uint32_t> pairs_t;
+            RawVec<int32_t> pc, pp;
+            RawVec<uint32_t> pairs_t;
             pc.reserve((size_t)(a1 - a0) * 8);
             pp.reserve((size_t)(a1 - a0) * 8);
             pairs_t.reserve((size_t)(adj_ptr[a1] - adj_ptr[a0]) * 3);
@@ -648,8 +669,8 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                 std::copy(part_col[(size_t)t].begin(), part_col[(size_t)t].end(), slot_col.begin() + so);
                 for (size_t k = 0; k < part_ptr[(size_t)t].size(); k++) slot_pair_ptr[so + k + 1] = (int32_t)(po + (size_t)part_ptr[(size_t)t][k]);
                 std::copy(part_pairs[(size_t)t].begin(), part_pairs[(size_t)t].end(), slot_pairs.begin() + po);
-                std::vector<int32_t>().swap(part_col[(size_t)t]);
-                std::vector<uint32_t>().swap(part_pairs[(size_t)t]);
+                RawVec<int32_t>().swap(part_col[(size_t)t]);
+                RawVec<uint32_t>().swap(part_pairs[(size_t)t]);
             }
         });
     }
@@ -839,7 +860,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     p.pairs16.resize(p.pairs.size());
     {
         const int nchunks = plan_chunks(p.n_slices, 256);
-        std::vector<std::vector<int32_t>> part_elems((size_t)nchunks), part_nodes((size_t)nchunks);
+        std::vector<RawVec<int32_t>> part_elems((size_t)nchunks), part_nodes((size_t)nchunks);
         std::vector<int32_t> part_max((size_t)nchunks, 0), part_bad((size_t)nchunks, 0);
         plan_parallel(p.n_slices, 256, [&](int t, int64_t s0, int64_t s1) {
             // local element ids of a slice within this span: bitmap + rank table (FEMSHELL_PLAN_DENSE_SPAN: the tests set 0 to
@@ -849,7 +870,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             std::vector<int32_t> ids, placed;
             std::vector<uint64_t> bits;
             std::vector<uint16_t> pos_of;
-            std::vector<int32_t> elems, nodes; // (the thread's own; handed over at the end, see the slot loop above)
+            RawVec<int32_t> elems, nodes; // (the thread's own; handed over at the end, see the slot loop above)
             int32_t most = 0;
             elems.reserve((size_t)(s1 - s0) * 136);
             nodes.reserve((size_t)(s1 - s0) * 136 * 4);
@@ -941,8 +962,8 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
             for (int64_t t = t0; t < t1; t++) {
                 std::copy(part_elems[(size_t)t].begin(), part_elems[(size_t)t].end(), p.slice_elems.begin() + off[(size_t)t]);
                 std::copy(part_nodes[(size_t)t].begin(), part_nodes[(size_t)t].end(), p.slice_elem_nodes.begin() + 4 * off[(size_t)t]);
-                std::vector<int32_t>().swap(part_elems[(size_t)t]);
-                std::vector<int32_t>().swap(part_nodes[(size_t)t]);
+                RawVec<int32_t>().swap(part_elems[(size_t)t]);
+                RawVec<int32_t>().swap(part_nodes[(size_t)t]);
             }
         });
     }
@@ -1001,11 +1022,11 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     {
         // chunks of slices on the host threads, each into an item list of its own, joined in slice order afterwards
         const int nchunks_t = plan_chunks(p.n_slices, 256);
-        std::vector<std::vector<Plan::Item>> part_items((size_t)nchunks_t);
+        std::vector<RawVec<Plan::Item>> part_items((size_t)nchunks_t);
         std::vector<int32_t> part_stage((size_t)nchunks_t, 0), part_bad((size_t)nchunks_t, 0);
         plan_parallel(p.n_slices, 256, [&](int t, int64_t s0, int64_t s1) {
             std::vector<Plan::Item> tmp, sorted, packed;
-            std::vector<Plan::Item> out; // (the thread's own; handed over at the end)
+            RawVec<Plan::Item> out; // (the thread's own; handed over at the end)
             int32_t most_stage = 0;
             out.reserve((size_t)(s1 - s0) * 168);
             // stable order by decreasing number of contributions (0..kItemPairs): a bucket pass, no allocation
@@ -1094,7 +1115,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
         plan_parallel(nchunks_t, 1, [&](int, int64_t t0, int64_t t1) {
             for (int64_t t = t0; t < t1; t++) {
                 std::copy(part_items[(size_t)t].begin(), part_items[(size_t)t].end(), p.items.begin() + off[(size_t)t]);
-                std::vector<Plan::Item>().swap(part_items[(size_t)t]);
+                RawVec<Plan::Item>().swap(part_items[(size_t)t]);
             }
         });
     }

@@ -19,8 +19,10 @@
 //    writes every block exactly once, without atomics and in a fixed summation order.
 #pragma once
 
+#include <cstddef>
 #include <cstdint>
 #include <memory>
+#include <new>
 #include <string>
 #include <utility>
 #include <vector>
@@ -30,14 +32,24 @@ namespace femshell {
 // The large arrays of a plan (hundreds of MB at 4M triangles): resize() leaves new elements uninitialised instead of
 // zero-filling them on the calling thread, so that the host threads that write an array are also the ones that take its
 // page faults.  Every element is written before it is read (fills where a value is needed are explicit and parallel).
-template <class T> struct NoInitAlloc : std::allocator<T> {
+// Allocations of 4 MiB and more are aligned to 2 MiB and marked MADV_HUGEPAGE: where the kernel hands out transparent huge
+// pages on request (the usual "madvise" setting) the first touch of such an array takes one page fault per 2 MiB instead of
+// 512 -- the first femshell_set_mesh of a process, whose heap is cold, spent a third of its time in page faults.
+void *raw_allocate(std::size_t bytes);
+void raw_deallocate(void *p, std::size_t bytes) noexcept;
+template <class T> struct NoInitAlloc {
+    using value_type = T;
     template <class U> struct rebind {
         using other = NoInitAlloc<U>;
     };
     NoInitAlloc() = default;
     template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    T *allocate(std::size_t n) { return static_cast<T *>(raw_allocate(n * sizeof(T))); }
+    void deallocate(T *p, std::size_t n) noexcept { raw_deallocate(p, n * sizeof(T)); }
     template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
     template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+    template <class U> bool operator==(const NoInitAlloc<U> &) const { return true; }
+    template <class U> bool operator!=(const NoInitAlloc<U> &) const { return false; }
 };
 template <class T> using RawVec = std::vector<T, NoInitAlloc<T>>;
 
