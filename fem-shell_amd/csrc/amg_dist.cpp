@@ -776,9 +776,9 @@ int amg_setup_dist(femshell_ctx *c)
             src.normals = d_normals.p;
         }
         double ctr[3];
-        if (!c->mesh_xyz.empty()) mesh_centre((int32_t)(c->mesh_xyz.size() / 3), c->mesh_xyz.data(), ctr);
+        if (c->have_mesh_centre) std::copy(c->mesh_centre, c->mesh_centre + 3, ctr);
         else if (c->comm.world == 1) mesh_centre(pl.n_own, pl.xyz_local.data(), ctr); // (a one-rank communicator: tests)
-        else return set_err(FEMSHELL_ERR_INVALID, "multigrid setup: the context holds no copy of the mesh");
+        else return set_err(FEMSHELL_ERR_INVALID, "multigrid setup: the context does not know the centre of the mesh");
         src.cx = ctr[0];
         src.cy = ctr[1];
         src.cz = ctr[2];

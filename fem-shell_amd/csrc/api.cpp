@@ -586,10 +586,10 @@ static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double 
                     /* geometric orientation of the symmetric storage when the library chose the numbering: */ !c->perm.empty()))
         return set_err(FEMSHELL_ERR_MESH, "femshell_set_mesh: " + e);
     part_done("coordinate check, renumbering, plan");
-    if (c->cfg.world_size > 1 || c->comm.active()) { // the multigrid preconditioner of a row-partitioned context builds its hierarchy from the whole mesh
-        c->mesh_xyz.assign(xyz, xyz + 3ll * n_nodes);
-        c->mesh_tri.assign(tri, tri + 3ll * n_tri);
-        c->mesh_quad.assign(quad, quad + 4ll * n_quad);
+    c->have_mesh_centre = false;
+    if (c->cfg.world_size > 1 || c->comm.active()) { // (the row-partitioned multigrid: rigid-body modes about the centre of the whole mesh)
+        mesh_centre(n_nodes, xyz, c->mesh_centre);
+        c->have_mesh_centre = true;
     }
     const Plan &p = c->plan;
     hipStream_t st = c->stream;

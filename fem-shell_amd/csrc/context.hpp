@@ -115,10 +115,10 @@ struct femshell_ctx {
 
     femshell_pc_options pc{};           // preconditioner of femshell_solve (block-Jacobi unless set otherwise)
     std::shared_ptr<femshell::Amg> amg; // hierarchy of the multigrid preconditioner, rebuilt when K changes
-    // contexts with a communicator: the mesh as it was handed over (internal numbering; the row-partitioned multigrid
-    // takes the centre of the rigid-body modes from it, amg_dist.cpp)
-    std::vector<double> mesh_xyz;
-    std::vector<int32_t> mesh_tri, mesh_quad;
+    // contexts with a communicator: the centre of the WHOLE mesh, about which the rigid-body modes of the row-partitioned
+    // multigrid turn on every rank alike (amg_dist.cpp; a rank's plan holds its own rows and their ghosts only)
+    double mesh_centre[3] = {0.0, 0.0, 0.0};
+    bool have_mesh_centre = false;
 
     // error estimate of the last multigrid-preconditioned solve (femshell_solve_info, cg_amg)
     struct RefineStats {
