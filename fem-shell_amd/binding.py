@@ -44,7 +44,7 @@ class SolveInfo(C.Structure):
                 ("true_rel_residual", C.c_double), ("assemble_seconds", C.c_double), ("setup_seconds", C.c_double), ("solve_seconds", C.c_double),
                 ("bytes_per_iteration", C.c_double), ("pc_type", C.c_int32), ("amg_levels", C.c_int32),
                 ("pc_setup_seconds", C.c_double), ("operator_complexity", C.c_double),
-                ("refine_passes_done", C.c_int32), ("reserved0", C.c_int32), ("refine_correction_rel", C.c_double),
+                ("refine_passes_done", C.c_int32), ("pc_fp64_fallback", C.c_int32), ("refine_correction_rel", C.c_double),
                 ("refine_residual_reduction", C.c_double), ("error_estimate", C.c_double)]
 
 

@@ -106,6 +106,7 @@ struct AmgDist {
 struct AmgDenseStats {
     int n = 0, dropped = 0;
     double ms = 0.0, mfma_flops = 0.0, useful_flops = 0.0, bytes = 0.0;
+    double f32_defect = -1.0; // ||A (inv32 v) - v|| / ||v|| of the single-precision copy (-1: not taken); above 0.05 the FP64 one is kept
 };
 
 struct Amg {
@@ -142,6 +143,8 @@ int alloc_level_vectors(AmgLevel &L, bool top, bool kcycle, hipStream_t st);
 int level_halo_exchange(femshell_ctx *c, LevelHalo &H, double *vec, int width, hipStream_t st);
 // nodes above which a coarse level stays row-partitioned (FEMSHELL_AMG_DIST_MIN, default 60000)
 int32_t amg_dist_min();
+// does the hierarchy keep single-precision copies (level operators for the smoothers, coarsest inverse)?
+bool amg_uses_single_precision(const Amg &H);
 // the smoother's upper bound of the spectrum of D^-1 A: safety factor x the estimate of a power iteration of that many steps
 // (FEMSHELL_AMG_LAMBDA_SAFETY, FEMSHELL_AMG_POWER_ITS; read per setup)
 double amg_lambda_safety();

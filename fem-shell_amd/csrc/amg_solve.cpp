@@ -257,6 +257,41 @@ bool setup_verbose()
 
 } // namespace
 
+namespace {
+// ||A (inv32 v) - v|| / ||v|| for one vector v of mixed frequencies: what single precision did to the coarsest inverse
+int dense_inverse_defect(femshell_ctx *c, AmgLevel &L, const DeviceMatrix &A, Amg &H, double *rel_out)
+{
+    hipStream_t st = c->stream;
+    const int64_t n6 = 6ll * L.n_pad;
+    launch_fill_hash(L.r.p, 6ll * L.n, n6, st);
+    launch_dense_gemv_big(H.coarse_inv.p, H.coarse_inv32.p, H.coarse_lda, L.r.p, L.d.p, 6 * L.n, 6 * L.n_pad, nullptr, st);
+    launch_spmv(A, L.d.p, L.q.p, nullptr, nullptr, st);
+    launch_sub(L.q.p, L.r.p, L.q.p, n6, st);
+    DevBuf<double> scratch;
+    FS_HIP(scratch.alloc(3 * 128));
+    const int groups = launch_two_dots(L.q.p, L.q.p, L.r.p, L.r.p, n6, scratch.p, st);
+    double hp[2 * 128];
+    FS_HIP(hipMemcpyAsync(hp, scratch.p, sizeof hp, hipMemcpyDeviceToHost, st));
+    FS_HIP(hipStreamSynchronize(st));
+    FS_HIP(hipGetLastError());
+    double ee = 0.0, vv = 0.0;
+    for (int g = 0; g < groups; g++) {
+        ee += hp[g];
+        vv += hp[128 + g];
+    }
+    *rel_out = vv > 0.0 ? std::sqrt(ee / vv) : 0.0; // (NaN: the caller's test fails and the FP64 inverse is taken)
+    return FEMSHELL_OK;
+}
+} // namespace
+
+bool amg_uses_single_precision(const Amg &H)
+{
+    if (H.coarse_inv32.p != nullptr) return true;
+    for (const auto &L : H.levels)
+        if (L->A32.p != nullptr) return true;
+    return false;
+}
+
 int amg_setup(femshell_ctx *c)
 {
     TraceRange trace("femshell multigrid setup");
@@ -438,13 +473,29 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
             // (stored and applied in single precision unless FEMSHELL_AMG_DENSE_F32=0: the coarsest solve sits inside a K cycle
             //  inside a flexible Krylov method, 1e-7 there moves the iteration count by one or two and halves the 436 MB the
             //  four visits per iteration stream: panel 0.809 -> 0.785 s, cylinder 0.755 -> 0.744 s)
-            const bool dense_f32 = !(getenv("FEMSHELL_AMG_DENSE_F32") && atoi(getenv("FEMSHELL_AMG_DENSE_F32")) == 0);
+            const bool dense_f32 = !c->amg_fp64_only && !(getenv("FEMSHELL_AMG_DENSE_F32") && atoi(getenv("FEMSHELL_AMG_DENSE_F32")) == 0);
             H.coarse_lda = 0;
             H.dense = AmgDenseStats();
             H.coarse_inv32.release();
             if (L.n > dense_device_min) {
                 rc = amg_dense_inverse_device(c, A, dense_f32, &H.coarse_inv, &H.coarse_inv32, &H.coarse_lda, &H.dense);
                 if (rc) return rc;
+                if (dense_f32) {
+                    // Is the rounded inverse still an inverse?  Its entries are off by 6e-8 of the largest, the smallest
+                    // eigenvalue of A^-1 lies kappa(A) below that: beyond kappa ~ 1e6 the float copy is not positive definite
+                    // any more (a cantilever strip of t / L = 1 / 1600: CG breakdown).  ||A (inv32 v) - v|| / ||v|| on one
+                    // vector of mixed frequencies shows kappa eps; above 0.05 the inverse is computed again and kept FP64.
+                    double rel = 0.0;
+                    rc = dense_inverse_defect(c, L, Adev, H, &rel);
+                    if (rc) return rc;
+                    H.dense.f32_defect = rel;
+                    if (!(rel <= 0.05)) {
+                        H.coarse_inv32.release();
+                        rc = amg_dense_inverse_device(c, A, false, &H.coarse_inv, &H.coarse_inv32, &H.coarse_lda, &H.dense);
+                        if (rc) return rc;
+                        H.dense.f32_defect = rel;
+                    }
+                }
                 lap("dense inverse on the matrix cores", l);
             } else {
                 if (!dense_inverse(A, &inv))
@@ -562,7 +613,7 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
         // 1e-7, and the flexible Krylov method around the cycle does not care that the preconditioner moved a little.
         // 1 (default): levels of at least 4096 nodes; 2: level 0 only, 3: every level, whatever their size (A/B runs, tests); 0: off.
         const char *e = getenv("FEMSHELL_AMG_SMOOTH_F32");
-        const int mode = e ? atoi(e) : 1;
+        const int mode = c->amg_fp64_only ? 0 : (e ? atoi(e) : 1);
         for (size_t l = 0; l + 1 < H.levels.size(); l++) {
             AmgLevel &L = *H.levels[l];
             L.A32.release();

@@ -558,6 +558,7 @@ static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double 
     }
     std::string e;
     c->have_mesh = false;
+    c->amg_fp64_only = false;
     c->perm.clear();
     c->iperm.clear();
     std::vector<double> xyz_r;
@@ -837,8 +838,12 @@ int femshell_set_preconditioner(femshell_ctx *c, const femshell_pc_options *opt)
     a.reserved = b.reserved = 0;
     const bool same_hierarchy = std::memcmp(&a, &b, sizeof a) == 0;
     c->pc = *opt;
-    if (same_hierarchy && c->amg && c->amg->valid) c->amg->opt = *opt;
-    else c->amg.reset();
+    if (same_hierarchy && c->amg && c->amg->valid) {
+        c->amg->opt = *opt;
+    } else {
+        c->amg.reset();
+        c->amg_fp64_only = false;
+    }
     return FEMSHELL_OK;
 }
 
@@ -985,43 +990,57 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
     }
     double pc_setup_s = 0.0;
     const bool use_amg = c->pc.type == FEMSHELL_PC_AMG;
-    if (use_amg && (!c->amg || !c->amg->valid)) {
-        if (c->comm.active()) {
-            const double t0 = wall_s();
-            // row-partitioned hierarchy (amg_dist.cpp); a failure only one rank sees must reach the others
-            rc = agree_status(c, amg_setup_dist(c), "multigrid setup", true);
-            if (rc) {
-                c->amg.reset();
-                return rc;
-            }
-            pc_setup_s = wall_s() - t0;
-        } else {
-            rc = amg_setup(c);
-            if (rc) {
-                c->amg.reset();
-                return rc;
-            }
-            pc_setup_s = c->amg->setup_seconds;
-        }
-    }
     hipStream_t st = c->stream;
     TraceRange trace_cg(use_amg ? "femshell_solve: multigrid-preconditioned CG" : "femshell_solve: block-Jacobi CG");
     FS_HIP(c->hist.alloc((size_t)std::min<int64_t>(std::max(max_it, 1), 1 << 22))); // history of the first 4M iterations
     CgVectors v = cg_vectors(c);
     const DeviceMatrix &m = c->dm;
-
-    FS_HIP(hipEventRecord(c->ev0, st));
-    // a previous solve leaves done = 1 behind; the reduction launch in front of an all-reduce carries no phase and
-    // would skip its work on it (multi-rank re-solves, e.g. every coupling iteration)
-    FS_HIP(c->scal.zero(st));
     const bool single_reduction = !use_amg && use_single_reduction(c);
     double amg_true_rr = -1.0, amg_rec_rr = -1.0;
-    rc = use_amg ? cg_amg(c, v, rtol, max_it, &amg_true_rr, &amg_rec_rr)
-                 : single_reduction ? cg_single_reduction(c, v, rtol, max_it) : cg_classic(c, v, rtol, max_it);
-    if (rc) return rc;
     CgScalars hs{};
-    FS_HIP(hipMemcpyAsync(&hs, v.s, sizeof hs, hipMemcpyDeviceToHost, st));
-    FS_HIP(hipStreamSynchronize(st));
+    bool fp64_fallback = false;
+    FS_HIP(hipEventRecord(c->ev0, st));
+    for (int attempt = 0;; attempt++) {
+        if (use_amg && (!c->amg || !c->amg->valid)) {
+            if (c->comm.active()) {
+                const double t0 = wall_s();
+                // row-partitioned hierarchy (amg_dist.cpp); a failure only one rank sees must reach the others
+                rc = agree_status(c, amg_setup_dist(c), "multigrid setup", true);
+                if (rc) {
+                    c->amg.reset();
+                    return rc;
+                }
+                pc_setup_s += wall_s() - t0;
+            } else {
+                rc = amg_setup(c);
+                if (rc) {
+                    c->amg.reset();
+                    return rc;
+                }
+                pc_setup_s += c->amg->setup_seconds;
+            }
+        }
+        // a previous solve leaves done = 1 behind; the reduction launch in front of an all-reduce carries no phase and
+        // would skip its work on it (multi-rank re-solves, e.g. every coupling iteration)
+        FS_HIP(c->scal.zero(st));
+        amg_true_rr = amg_rec_rr = -1.0;
+        rc = use_amg ? cg_amg(c, v, rtol, max_it, &amg_true_rr, &amg_rec_rr)
+                     : single_reduction ? cg_single_reduction(c, v, rtol, max_it) : cg_classic(c, v, rtol, max_it);
+        if (rc) return rc;
+        FS_HIP(hipMemcpyAsync(&hs, v.s, sizeof hs, hipMemcpyDeviceToHost, st));
+        FS_HIP(hipStreamSynchronize(st));
+        // A breakdown of the flexible CG (p.Ap <= 0, the same all-reduced number on every rank) under a hierarchy that keeps
+        // single-precision copies: on very thin shells the rounded preconditioner is not positive definite any more.  Once:
+        // the hierarchy again, everything FP64, and the solve from the start.  The context stays that way until a new mesh
+        // or preconditioner is set; femshell_solve_info::pc_fp64_fallback says it happened.
+        if (use_amg && hs.done < 0 && attempt == 0 && !c->amg_fp64_only && amg_uses_single_precision(*c->amg)) {
+            c->amg_fp64_only = true;
+            c->amg.reset();
+            fp64_fallback = true;
+            continue;
+        }
+        break;
+    }
     const bool recurrence_converged = hs.done == 1;
     const double recurrence_rr = (use_amg && amg_rec_rr >= 0.0) ? amg_rec_rr : hs.rr;
     double true_rel = -1.0;
@@ -1069,7 +1088,7 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
         info->pc_setup_seconds = pc_setup_s;
         info->operator_complexity = 0.0;
         info->refine_passes_done = use_amg ? c->refine.passes : 0;
-        info->reserved0 = 0;
+        info->pc_fp64_fallback = fp64_fallback ? 1 : 0;
         info->refine_correction_rel = use_amg ? c->refine.correction_rel : -1.0;
         info->refine_residual_reduction = use_amg ? c->refine.residual_reduction : 0.0;
         info->error_estimate = (use_amg && c->refine.passes > 0) ? c->refine.correction_rel * c->refine.residual_reduction : -1.0;

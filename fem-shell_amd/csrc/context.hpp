@@ -114,6 +114,10 @@ struct femshell_ctx {
     std::vector<int32_t> all_begin, all_end;
 
     femshell_pc_options pc{};           // preconditioner of femshell_solve (block-Jacobi unless set otherwise)
+    // the multigrid hierarchy keeps everything FP64 (no single-precision copies, vectors or coarsest inverse): set by
+    // femshell_solve after a breakdown of the flexible CG with a hierarchy that used them -- the rounded preconditioner of a
+    // very thin shell is not positive definite any more --, cleared by femshell_set_mesh / femshell_set_preconditioner
+    bool amg_fp64_only = false;
     std::shared_ptr<femshell::Amg> amg; // hierarchy of the multigrid preconditioner, rebuilt when K changes
     // contexts with a communicator: the centre of the WHOLE mesh, about which the rigid-body modes of the row-partitioned
     // multigrid turn on every rank alike (amg_dist.cpp; a rank's plan holds its own rows and their ghosts only)

@@ -129,7 +129,10 @@ typedef struct femshell_solve_info {
      * that times the factor by which it reduced the residual of its correction equation.  Checked against manufactured
      * solutions at the 4M-triangle sizes (tests/test_gpu_fullsize.py, bench.py time_to_solution.manufactured). */
     int32_t refine_passes_done;       /* refinement passes that ran (<= femshell_pc_options::refine_passes + 1) */
-    int32_t reserved0;
+    int32_t pc_fp64_fallback;         /* 1: the flexible CG broke down (p.Ap <= 0) under a multigrid hierarchy that keeps
+                                         single-precision copies, and the solve ran again from the start with an all-FP64
+                                         hierarchy (very thin shells); the context keeps that choice until a new mesh or
+                                         preconditioner is set.  (the reserved word of version 2 of this struct) */
     double refine_correction_rel;     /* ||e||_2 / ||x||_2 of the last pass */
     double refine_residual_reduction; /* ||rhs - K e|| / ||rhs|| (recurrence) the last pass stopped at */
     double error_estimate;            /* refine_correction_rel * refine_residual_reduction: estimated relative error of u */
@@ -143,9 +146,12 @@ typedef struct femshell_solve_info {
  * count grows with the element count.  FEMSHELL_PC_AMG is a smoothed-aggregation multigrid
  * (rigid-body modes, Chebyshev/block-Jacobi smoothing, V or K cycle) around which the solve
  * runs a flexible CG: the answer a user of `-pc_type gamg` expects, with iteration counts
- * that stay near 100 up to the 4M-triangle meshes.  On row-partitioned contexts every rank
- * holds the single-rank hierarchy (built on its own GPU from the whole K) and smooths its own
- * rows: same iteration counts as on one rank, one all-reduce of a coarse vector per cycle.
+ * that stay near 100 up to the 4M-triangle meshes.  On row-partitioned contexts the hierarchy is
+ * row-partitioned like K (aggregates never span ranks; levels above 60,000 nodes split over the
+ * ranks, the rest replicated): iteration counts within a few of the single-rank ones.  What the
+ * cycle only smooths or transfers with is kept in single precision (FP64 arithmetic); should the
+ * flexible CG break down under it, the solve runs again with an all-FP64 hierarchy
+ * (femshell_solve_info::pc_fp64_fallback).
  * The environment variable FEMSHELL_PC=amg|jacobi sets the default of new contexts. */
 typedef enum femshell_pc_type { FEMSHELL_PC_BLOCK_JACOBI = 0, FEMSHELL_PC_AMG = 1 } femshell_pc_type;
 typedef enum femshell_cycle { FEMSHELL_CYCLE_V = 0, FEMSHELL_CYCLE_K = 1 } femshell_cycle;

@@ -136,6 +136,49 @@ def test_single_precision_smoothing_products_leave_the_solution_alone(monkeypatc
         fs.close()
 
 
+def test_very_thin_strip_keeps_its_coarsest_inverse_in_double_precision(monkeypatch):
+    # a cantilever strip of t / L = 1 / 1600: the coarsest operator (485 nodes) is so ill-conditioned that its inverse rounded
+    # to float is not positive definite any more -- the flexible CG broke down on it.  The setup measures what rounding did
+    # (||A inv32 v - v|| / ||v||) and keeps the FP64 inverse; the solve converges to the direct solution without a fallback
+    m = meshes.structured(256, 16, 0, 0, 16.0, 1.0, kind="t", ul_lr=True, bcids=(-1, -1, 1, -1), factor=300.0, loading=2)
+    mat = (0.3, 1e7, 0.01)
+    fs = _context(m, mat)
+    fs.set_preconditioner("amg")
+    u, info = fs.solve(rtol=1e-10, max_it=1000)
+    assert info["converged"] == 1 and info["amg_levels"] == 2 and info["pc_fp64_fallback"] == 0, info
+    rg, cg, vg, Fg = fs.export_bsr()
+    ug = oracle.refined_solve(rg, cg, vg, Fg)
+    assert np.linalg.norm(u.ravel() - ug) / np.linalg.norm(ug) < 1e-8  # (kappa ~ 1e13: 1.3e-10 measured)
+    fs.close()
+
+
+def test_breakdown_under_single_precision_copies_runs_again_in_double_precision():
+    # an unstructured Delaunay shell of poor element quality (the mesh of tests/test_gpu_parity.py): the multigrid does not
+    # converge on it in either precision, but with the single-precision copies the flexible CG breaks
+    # down early (p.Ap <= 0).  femshell_solve then builds the hierarchy again, all FP64, runs the solve from the start and
+    # says so; the context stays with that choice
+    from tests.test_gpu_parity import delaunay_shell
+
+    ensure_built()
+    xyz, tri = delaunay_shell(20000, 3)
+    dmask = np.zeros(len(xyz), dtype=np.uint8)
+    dmask[xyz[:, 0] < 0.15] = 0x3F
+    loads = np.zeros((len(xyz), 6))
+    loads[:, 2] = 1.0
+    fs = pkg.FemShell(0.3, 7.0e4, 0.03, device=0)
+    fs.set_mesh(xyz, tri, None)
+    fs.set_dirichlet(dmask)
+    fs.set_loads(loads)
+    fs.set_preconditioner("amg")
+    u, info = fs.solve(rtol=1e-10, max_it=150)  # (no exception: the second attempt ends at the iteration limit)
+    assert info["pc_fp64_fallback"] == 1 and info["converged"] == 0 and info["iterations"] == 150, info
+    assert np.all(np.isfinite(u))
+    u2, info2 = fs.solve(rtol=1e-10, max_it=150)  # the hierarchy is FP64 now: no second fallback, the same iterate
+    assert info2["pc_fp64_fallback"] == 0 and info2["pc_setup_seconds"] == 0.0
+    np.testing.assert_array_equal(u2, u)
+    fs.close()
+
+
 def test_tentative_prolongator_with_the_rows_in_memory(monkeypatch):
     # aggregates of more than 42 nodes keep the rows of their QR factorisation in HBM instead of registers; no test mesh
     # has one, so the knob sends every aggregate down that path
