@@ -999,7 +999,7 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
     double amg_true_rr = -1.0, amg_rec_rr = -1.0;
     CgScalars hs{};
     bool fp64_fallback = false;
-    FS_HIP(hipEventRecord(c->ev0, st));
+    float ms_abandoned = 0.f; // device time of an attempt that ended in the breakdown below: part of solve_seconds
     for (int attempt = 0;; attempt++) {
         if (use_amg && (!c->amg || !c->amg->valid)) {
             if (c->comm.active()) {
@@ -1022,6 +1022,7 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
         }
         // a previous solve leaves done = 1 behind; the reduction launch in front of an all-reduce carries no phase and
         // would skip its work on it (multi-rank re-solves, e.g. every coupling iteration)
+        FS_HIP(hipEventRecord(c->ev0, st)); // (behind the multigrid setup: solve_seconds is the time of the Krylov loop)
         FS_HIP(c->scal.zero(st));
         amg_true_rr = amg_rec_rr = -1.0;
         rc = use_amg ? cg_amg(c, v, rtol, max_it, &amg_true_rr, &amg_rec_rr)
@@ -1034,6 +1035,9 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
         // the hierarchy again, everything FP64, and the solve from the start.  The context stays that way until a new mesh
         // or preconditioner is set; femshell_solve_info::pc_fp64_fallback says it happened.
         if (use_amg && hs.done < 0 && attempt == 0 && !c->amg_fp64_only && amg_uses_single_precision(*c->amg)) {
+            FS_HIP(hipEventRecord(c->ev1, st));
+            FS_HIP(hipEventSynchronize(c->ev1));
+            FS_HIP(hipEventElapsedTime(&ms_abandoned, c->ev0, c->ev1));
             c->amg_fp64_only = true;
             c->amg.reset();
             fp64_fallback = true;
@@ -1067,6 +1071,7 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
     FS_HIP(hipGetLastError());
     float ms = 0.f;
     FS_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    ms += ms_abandoned;
     c->last_iters = hs.iters;
     c->hist_host.assign((size_t)std::min<int64_t>(hs.iters, (int64_t)c->hist.n), 0.0);
     if (!c->hist_host.empty())

@@ -136,6 +136,21 @@ def test_single_precision_smoothing_products_leave_the_solution_alone(monkeypatc
         fs.close()
 
 
+def test_solve_seconds_is_the_krylov_loop_without_the_setup():
+    # femshell_solve_info: pc_setup_seconds and solve_seconds are separate figures (bench.py's time to solution is the second);
+    # the first solve of a context builds the hierarchy, the second reuses it, and both report the same loop time
+    m, mat = _make("panel", 160)
+    fs = _context(m, mat)
+    fs.set_preconditioner("amg")
+    u1, i1 = fs.solve(rtol=1e-10, max_it=500)
+    u2, i2 = fs.solve(rtol=1e-10, max_it=500)
+    assert i1["pc_setup_seconds"] > 0.0 and i2["pc_setup_seconds"] == 0.0
+    assert i1["iterations"] == i2["iterations"]
+    assert i1["solve_seconds"] < 1.3 * i2["solve_seconds"] + 0.005, (i1["solve_seconds"], i2["solve_seconds"], i1["pc_setup_seconds"])
+    assert i1["pc_setup_seconds"] > 0.3 * i2["solve_seconds"]  # (a setup inside solve_seconds would have shown above)
+    fs.close()
+
+
 def test_very_thin_strip_keeps_its_coarsest_inverse_in_double_precision(monkeypatch):
     # a cantilever strip of t / L = 1 / 1600: the coarsest operator (485 nodes) is so ill-conditioned that its inverse rounded
     # to float is not positive definite any more -- the flexible CG broke down on it.  The setup measures what rounding did
