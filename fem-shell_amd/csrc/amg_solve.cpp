@@ -466,10 +466,11 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
             std::vector<double> inv;
             if (L.n > 4096) return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: coarsest level too large for a dense inverse");
             if (!have_host) return set_err(FEMSHELL_ERR_INVALID, "multigrid setup: the coarsest operator was not brought to the host");
-            // small operators are inverted on the host (a few GFLOP); beyond FEMSHELL_AMG_DENSE_DEVICE_MIN nodes (default
-            // 250) the inverse is computed on the matrix cores (amg_dense.hip: n^3 flops, 0.4 TFLOP at 1231 nodes)
+            // the smallest operators are inverted on the host; beyond FEMSHELL_AMG_DENSE_DEVICE_MIN nodes (default 64; 250
+            // until the host's 0.19 s at 145 nodes and 0.35 s at 204 showed up as most of the setup of the small coupled
+            // examples) the inverse is computed on the matrix cores (amg_dense.hip: n^3 flops, 0.4 TFLOP at 1231 nodes)
             // (read per setup: the tests switch them inside one process)
-            const long dense_device_min = getenv("FEMSHELL_AMG_DENSE_DEVICE_MIN") ? atol(getenv("FEMSHELL_AMG_DENSE_DEVICE_MIN")) : 250l;
+            const long dense_device_min = getenv("FEMSHELL_AMG_DENSE_DEVICE_MIN") ? atol(getenv("FEMSHELL_AMG_DENSE_DEVICE_MIN")) : 64l;
             // (stored and applied in single precision unless FEMSHELL_AMG_DENSE_F32=0: the coarsest solve sits inside a K cycle
             //  inside a flexible Krylov method, 1e-7 there moves the iteration count by one or two and halves the 436 MB the
             //  four visits per iteration stream: panel 0.809 -> 0.785 s, cylinder 0.755 -> 0.744 s)

@@ -163,7 +163,7 @@ typedef struct femshell_pc_options {
     int32_t coarsest_nodes;  /* coarsening stops at the first level of at most this many nodes; dense inverse there (default
                                 and maximum 1400: the K cycle visits its last levels 8-16 times per iteration and each
                                 visit is a chain of launches, so an exact solve of 8400 dofs -- one dense matrix-vector
-                                product -- is cheaper than two more levels; inverses beyond 250 nodes are computed on the
+                                product -- is cheaper than two more levels; inverses beyond 64 nodes are computed on the
                                 matrix cores) */
     int32_t max_levels;      /* default 12 */
     int32_t refine_passes;   /* iterative refinement after convergence, at most this many passes (default 1; 0 = off):
