@@ -143,6 +143,10 @@ int alloc_level_vectors(AmgLevel &L, bool top, bool kcycle, hipStream_t st);
 int level_halo_exchange(femshell_ctx *c, LevelHalo &H, double *vec, int width, hipStream_t st);
 // nodes above which a coarse level stays row-partitioned (FEMSHELL_AMG_DIST_MIN, default 60000)
 int32_t amg_dist_min();
+// host copies of the level operators for femshell_amg_export: problems of up to 300,000 blocks (40k triangles: the tests), or
+// FEMSHELL_AMG_KEEP_HOST=1 (up to 2,000,000 blocks).  Until round 4 every problem of up to 2,000,000 blocks paid for them: a
+// quarter of the multigrid setup of the 250k-triangle roof went into downloads nobody read.
+bool amg_keep_host(int64_t nnz_blocks);
 // does the hierarchy keep single-precision copies (level operators for the smoothers, coarsest inverse)?
 bool amg_uses_single_precision(const Amg &H);
 // the smoother's upper bound of the spectrum of D^-1 A: safety factor x the estimate of a power iteration of that many steps

@@ -728,7 +728,7 @@ int amg_setup_dist(femshell_ctx *c)
         if (verbose) fprintf(stderr, "[femshell amg setup, rank %d] level %d %-32s %.3f s\n", c->comm.rank, lap_level, what, t - tl);
         tl = t;
     };
-    const bool keep_host = pl.nnz_blocks <= (int64_t)2000000; // inspection exports (tests) on small problems only
+    const bool keep_host = amg_keep_host(pl.nnz_blocks); // inspection exports (tests)
     static const bool plain = getenv("FEMSHELL_AMG_PLAIN_RBM") && atoi(getenv("FEMSHELL_AMG_PLAIN_RBM")) != 0;
 
     // ---- level 0: the rank's rows of K

@@ -284,6 +284,13 @@ int dense_inverse_defect(femshell_ctx *c, AmgLevel &L, const DeviceMatrix &A, Am
 }
 } // namespace
 
+bool amg_keep_host(int64_t nnz_blocks)
+{
+    const char *e = getenv("FEMSHELL_AMG_KEEP_HOST"); // (read per setup)
+    if (e && atoi(e) != 0) return nnz_blocks <= (int64_t)2000000;
+    return nnz_blocks <= (int64_t)300000;
+}
+
 bool amg_uses_single_precision(const Amg &H)
 {
     if (H.coarse_inv32.p != nullptr) return true;
@@ -312,7 +319,7 @@ int amg_setup(femshell_ctx *c)
     };
     const SetupRules rules = setup_rules(opt);
     const bool host_only = rules.host_only;
-    const bool keep_host = pl.nnz_blocks <= (int64_t)2000000; // inspection exports (tests) on small problems only
+    const bool keep_host = amg_keep_host(pl.nnz_blocks); // inspection exports (tests)
     Bsr A;
     std::vector<double> B;  // near-null space of the current level on the host (levels coarsened on the host) ...
     DevBuf<double> Bdev;    // ... and in HBM (levels coarsened on the device, from the second one on)
@@ -407,7 +414,7 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
     auto want_host_matrix = [&](int next_level) {
         return std::function<bool(int32_t)>([&, next_level](int32_t na) { return !device_step(next_level, na); });
     };
-    const bool keep_host = pl.nnz_blocks <= (int64_t)2000000; // inspection exports (tests) on small problems only
+    const bool keep_host = amg_keep_host(pl.nnz_blocks); // inspection exports (tests)
     double tl = now_s();
     auto lap = [&](const char *what, int level) {
         const double t = now_s();

@@ -204,7 +204,9 @@ enum { FEMSHELL_AMG_AGGREGATES = 0, /* int32 [n_nodes] */
        /* the coarsest level only: the dense inverse the cycle multiplies with, double [n][n] row-major (n = 6 x its nodes;
         * the operator it inverts is that level's FEMSHELL_AMG_A_*, kept at every problem size) */
        FEMSHELL_AMG_COARSE_INVERSE };
-/* returns the element count of the array (-1: not available); copies it to out when out != NULL */
+/* returns the element count of the array (-1: not available); copies it to out when out != NULL.  The host copies behind
+ * the A_* / P_* / AGGREGATES arrays are kept for problems of up to 300,000 blocks of K (up to 2,000,000 with
+ * FEMSHELL_AMG_KEEP_HOST=1 in the environment at setup): an inspection interface, not part of the solve */
 int64_t femshell_amg_export(femshell_ctx *ctx, int32_t level, int32_t which, void *out);
 /* device timings of the first coarsening step of the last setup: out[0..3] = milliseconds of the prolongator, A P,
  * restriction and Galerkin kernels, out[4] = useful flops of the Galerkin product, out[5] = flops issued on the
