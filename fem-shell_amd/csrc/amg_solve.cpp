@@ -626,7 +626,10 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
             AmgLevel &L = *H.levels[l];
             L.A32.release();
             const DeviceMatrix &A = amg_level_matrix(c, (int)l);
-            if (mode == 0 || (mode == 2 && l > 0) || (mode == 1 && L.n < 4096) || A.vals == nullptr) continue;
+            // (the size of the WHOLE level decides on a row-partitioned one: every rank takes the same decision, which the
+            //  fallback of femshell_solve -- a collective rebuild -- relies on)
+            const int32_t level_nodes = L.dist ? std::max(L.n, L.n_global) : L.n;
+            if (mode == 0 || (mode == 2 && l > 0) || (mode == 1 && level_nodes < 4096) || A.vals == nullptr) continue;
             const int64_t nv = (l == 0 ? (int64_t)pl.total_slots() : (int64_t)L.A.vals.n / 36) * 36;
             FS_HIP(L.A32.alloc((size_t)nv));
             launch_to_f32(A.vals, L.A32.p, nv, st);

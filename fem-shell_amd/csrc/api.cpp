@@ -1034,7 +1034,10 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
         // single-precision copies: on very thin shells the rounded preconditioner is not positive definite any more.  Once:
         // the hierarchy again, everything FP64, and the solve from the start.  The context stays that way until a new mesh
         // or preconditioner is set; femshell_solve_info::pc_fp64_fallback says it happened.
-        if (use_amg && hs.done < 0 && attempt == 0 && !c->amg_fp64_only && amg_uses_single_precision(*c->amg)) {
+        // (row-partitioned contexts decide by what every rank knows alike -- the rebuild is collective --, not by what this
+        //  rank's part of the hierarchy happens to hold: a rank without rows on a split level keeps no copies)
+        const bool had_copies = use_amg && (c->comm.active() || amg_uses_single_precision(*c->amg));
+        if (use_amg && hs.done < 0 && attempt == 0 && !c->amg_fp64_only && had_copies) {
             FS_HIP(hipEventRecord(c->ev1, st));
             FS_HIP(hipEventSynchronize(c->ev1));
             FS_HIP(hipEventElapsedTime(&ms_abandoned, c->ev0, c->ev1));
