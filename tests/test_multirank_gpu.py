@@ -42,8 +42,8 @@ def run_ranks(world, kind, tmp_path, overlap=True, single_reduction=None, pc=Non
                 q.kill()
             raise
         logs.append(out.decode(errors="replace"))
-    for r, p in enumerate(procs):
-        assert p.returncode == 0, "rank %d failed:\n%s" % (r, logs[r][-2000:])
+    for r, p in enumerate(procs):  # (a rank that failed first usually explains the others' communication errors: show all)
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, "\n".join("--- rank %d\n%s" % (q, logs[q][-1500:]) for q in range(world)))
     return [np.load(o) for o in outs]
 
 
@@ -324,3 +324,13 @@ def test_bench_runs_row_partitioned_under_the_launcher_the_driver_uses(tmp_path)
     assert d["scaling"] == "strong" and d["config"]["parallelism"] == "row-partition x2"
     tts = d["time_to_solution"]
     assert tts["converged"] == 1 and tts["levels"] >= 2 and tts["iterations"] < 200
+
+
+def test_fp64_fallback_of_the_multigrid_is_taken_by_all_ranks_together(tmp_path):
+    """A breakdown of the flexible CG under the single-precision copies of the hierarchy (tests/test_gpu_amg.py has the
+    one-rank form) makes femshell_solve rebuild the hierarchy in FP64 and solve again; on a row-partitioned context that
+    rebuild is collective, so the ranks must decide alike -- they do, from the all-reduced p.Ap."""
+    ranks = run_ranks(2, "delaunay_hard", tmp_path)
+    for r in ranks:
+        assert int(r["fallback"]) == 1 and int(r["iterations"]) == 120 and int(r["converged"]) == 0 and bool(r["finite"]), dict(r)
+
