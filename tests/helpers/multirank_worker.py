@@ -26,6 +26,26 @@ def build_problem(kind):
     if kind == "cylinder":
         m = meshes.pinched_cylinder(48, 40)
         return m, m.material
+    if kind == "jittered":
+        # an unstructured mesh of good element quality (Delaunay triangulation of a jittered grid on a curved shell: irregular
+        # valence, no slivers), numbered along x as a mesh prepared for several ranks would be
+        from tests.test_gpu_parity import delaunay_shell
+
+        class M:
+            pass
+        m = M()
+        xyz, tri = delaunay_shell(4000, 3, jittered=True)
+        order = np.argsort(xyz[:, 0], kind="stable")
+        inv = np.empty_like(order)
+        inv[order] = np.arange(len(order))
+        m.xyz, m.tri = np.ascontiguousarray(xyz[order]), inv[tri].astype(np.int32)
+        m.quad = None
+        mask = np.zeros(len(m.xyz), dtype=np.uint8)
+        mask[m.xyz[:, 0] < 0.15] = 0x3F
+        m.loads = np.zeros((len(m.xyz), 6))
+        m.loads[:, 2] = 1.0
+        m.dirichlet_mask = lambda: mask
+        return m, (0.3, 7.0e4, 0.03)
     if kind == "delaunay_hard":
         # the Delaunay shell of poor element quality of tests/test_gpu_parity.py: the flexible CG breaks down under the
         # single-precision copies of the multigrid hierarchy

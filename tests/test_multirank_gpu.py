@@ -109,7 +109,8 @@ def test_row_partitioned_assembly_and_solve_against_the_oracle(world, kind, tmp_
 
 
 @pytest.mark.parametrize("world,kind,dist_min", [(2, "panel", 60000), (3, "cylinder", 60000), (4, "panel", 60000),
-                                                  (2, "cylinder", 100), (3, "panel", 100), (4, "cylinder", 100)])
+                                                  (2, "cylinder", 100), (3, "panel", 100), (4, "cylinder", 100),
+                                                  (2, "jittered", 60000), (3, "jittered", 100)])
 def test_multigrid_on_a_row_partitioned_context(world, kind, dist_min, tmp_path):
     """The hierarchy of a row-partitioned context is row-partitioned itself (csrc/amg_dist.cpp): aggregates never span ranks,
     everything else is the single-rank method, so the iteration count stays within 15 % of the single-rank count and the
@@ -136,7 +137,9 @@ def test_multigrid_on_a_row_partitioned_context(world, kind, dist_min, tmp_path)
         assert float(r["true_res"]) == float(ranks[0]["true_res"])
     assert covered.all()
     err = np.linalg.norm(ranks[0]["u"] - single["u"]) / np.linalg.norm(single["u"])
-    assert err < 1e-10, err  # both went through the refinement pass with the double-double residual
+    # both went through the refinement pass with the double-double residual (the thin unstructured shell, E t^3 five orders of
+    # magnitude softer in bending than in its plane, leaves 1.7e-10 between two such solves)
+    assert err < (5e-10 if kind == "jittered" else 1e-10), err
     errj = np.linalg.norm(ranks[0]["u"] - jacobi["u"]) / np.linalg.norm(jacobi["u"])
     assert errj < 1e-8, errj
     # no whole-K shadow: what a rank holds of the partitioned levels is its share
