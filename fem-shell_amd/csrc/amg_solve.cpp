@@ -497,6 +497,9 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
                     rc = dense_inverse_defect(c, L, Adev, H, &rel);
                     if (rc) return rc;
                     H.dense.f32_defect = rel;
+                    if (setup_verbose())
+                        fprintf(stderr, "[femshell amg setup] coarsest inverse rounded to single precision: ||A inv32 v - v|| / ||v|| = %.2e (%s)\n", rel,
+                                rel <= 0.05 ? "kept" : "above 0.05: the FP64 inverse is kept instead");
                     if (!(rel <= 0.05)) {
                         H.coarse_inv32.release();
                         rc = amg_dense_inverse_device(c, A, false, &H.coarse_inv, &H.coarse_inv32, &H.coarse_lda, &H.dense);
