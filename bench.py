@@ -537,6 +537,20 @@ def main():
         torch.cuda.empty_cache()
         return rate
     copy_gbs = device_copy_rate()
+
+    def device_alloc_ms():
+        """Wall time of hipMalloc + hipFree of 4 GiB: a few ms on a fresh box, a hundred and more right after a run that
+        churned the card's memory (the GPU test-suite: 138 contexts) -- the multigrid setup allocates and frees about 10 GB
+        of transient buffers, and `pc_setup_seconds` was 0.5 s instead of 0.18 s in bench runs that followed the test-suite
+        on the same box (the lap "uploads" of FEMSHELL_AMG_VERBOSE=1: 0.20 s instead of 0.005 s)."""
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        x = torch.empty(1 << 32, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        del x
+        torch.cuda.empty_cache()
+        return 1e3 * (time.perf_counter() - t)
+    alloc_ms = device_alloc_ms()
     t0 = time.perf_counter()
     fs.set_mesh(m.xyz, m.tri)
     setup_s = time.perf_counter() - t0
@@ -761,7 +775,8 @@ def main():
                                                          "(clocks, TLBs), then the --warmup steps of the contract",
                        "preconditioner": "6x6 block-Jacobi", "symbolic_setup_s": setup_s,
                        "matrix_storage": "symmetric (upper triangles of the diagonal blocks + the blocks of the lower-numbered row)" if symmetric else "full",
-                       "rccl_ranks_seen": rccl_ranks, "box_streaming_copy_gb_per_s": copy_gbs},
+                       "rccl_ranks_seen": rccl_ranks, "box_streaming_copy_gb_per_s": copy_gbs,
+                       "box_hipmalloc_plus_free_of_4GiB_ms": alloc_ms},
             # `roofline` belongs to `value`: the kernel the timed assembly steps consist of
             "roofline": dict(roof(asm_ms, asm_bytes, asm_kernel), kernel=asm_kernel + " (element records -> block slots -> K and F; the kernel "
                              "`value` / `ms_per_step` time; not HBM-bound: see fp64_* and DESIGN.md section 4)"),
