@@ -26,7 +26,9 @@ void *raw_allocate(std::size_t bytes)
     void *p = std::aligned_alloc(kHugeAlign, rounded);
     if (p == nullptr) throw std::bad_alloc();
     // FEMSHELL_HUGEPAGES=0: no advice (a host whose memory is so fragmented that the kernel compacts it inside the page faults)
-    static const bool advise = !(getenv("FEMSHELL_HUGEPAGES") && atoi(getenv("FEMSHELL_HUGEPAGES")) == 0);
+    // (read per allocation -- these are at least 4 MiB each --: the tests switch it inside one process)
+    const char *env = getenv("FEMSHELL_HUGEPAGES");
+    const bool advise = !(env && atoi(env) == 0);
     if (advise) (void)madvise(p, rounded, MADV_HUGEPAGE); // (advice: refused or unavailable, the array is an ordinary one)
     return p;
 }

@@ -300,6 +300,11 @@ def _host_side_digest():
             for k in sorted(p):
                 h.update(k.encode())
                 h.update(np.ascontiguousarray(p[k]).tobytes())
+    # (a mesh whose plan arrays exceed 4 MiB: the allocations that are 2 MiB-aligned and ask for transparent huge pages)
+    big = meshes.structured(330, 300, 0, 0, 11, 10, kind="t", ul_lr=True, bcids=(0, 0, 1, 1), factor=1.0, loading=2)
+    pb = b.build_plan(big.xyz, big.tri, None)
+    for k in sorted(pb):
+        h.update(np.ascontiguousarray(pb[k]).tobytes())
     for kind in ("morton", "rcm"):
         h.update(np.ascontiguousarray(b.reorder_host(kind, xyz, tri)).tobytes())
     q = meshes.structured(40, 40, 0, 0, 10, 10, kind="q", bcids=(1, 1, 1, 1), factor=1.0, loading=2)
@@ -368,6 +373,10 @@ def test_host_threads_do_not_change_the_plan(monkeypatch):
     # ... and the two ways a slice's element list is built (bitmap + rank table for element ids that lie close together,
     # sort + search otherwise) give the same plan
     monkeypatch.setenv("FEMSHELL_PLAN_DENSE_SPAN", "0")
+    assert _host_side_digest() == digests[0]
+    # ... and ordinary pages instead of the transparent huge pages the large arrays ask for
+    monkeypatch.delenv("FEMSHELL_PLAN_DENSE_SPAN")
+    monkeypatch.setenv("FEMSHELL_HUGEPAGES", "0")
     assert _host_side_digest() == digests[0]
 
 
