@@ -921,7 +921,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
                 // triangles of a cell back to back, so in ascending order those records are two apart and a
                 // wave's LDS reads fall on half of the banks; de-interleaved they are adjacent.
                 const int32_t n_even = ((int32_t)ids.size() + 1) / 2;
-                auto lds_pos = [&](int32_t rank) { return (rank & 1) ? n_even + (rank >> 1) : (rank >> 1); };
+                auto lds_pos = [&](int32_t sorted_pos) { return (sorted_pos & 1) ? n_even + (sorted_pos >> 1) : (sorted_pos >> 1); };
                 if (dense) {
                     if (pos_of.size() < (size_t)(hi - lo + 1)) pos_of.resize((size_t)(hi - lo + 1));
                     for (size_t r = 0; r < ids.size(); r++) pos_of[(size_t)(ids[r] - lo)] = (uint16_t)lds_pos((int32_t)r);
