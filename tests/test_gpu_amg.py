@@ -136,6 +136,28 @@ def test_single_precision_smoothing_products_leave_the_solution_alone(monkeypatc
         fs.close()
 
 
+def test_inspection_copies_of_the_hierarchy_are_kept_for_small_problems_only(monkeypatch):
+    # femshell_amg_export reads host copies of the level operators that the setup keeps for problems of up to 300,000 blocks
+    # of K -- every test above -- or, with FEMSHELL_AMG_KEEP_HOST=1, up to 2,000,000; beyond that the solve does not pay for them
+    m, mat = _make("panel", 224)  # 100,352 triangles, 50,625 nodes, 352,801 blocks
+    for keep in (False, True):
+        if keep:
+            monkeypatch.setenv("FEMSHELL_AMG_KEEP_HOST", "1")
+        fs = _context(m, mat)
+        fs.set_preconditioner("amg")
+        u, info = fs.solve(rtol=1e-8, max_it=500)
+        assert info["converged"] == 1 and info["amg_levels"] >= 3
+        ex = fs.amg_export(0)
+        if keep:
+            assert ex["P_vals"] is not None and len(ex["P_cols"]) == fs.amg_levels()[0]["p_blocks"]
+            assert len(ex["A_cols"]) == fs.amg_levels()[0]["nnz_blocks"]
+        else:
+            assert ex["P_vals"] is None or len(ex["P_vals"]) == 0
+        last = fs.amg_export(info["amg_levels"] - 1)  # the coarsest operator and its inverse: at every size
+        assert last["A_vals"] is not None and len(last["A_vals"]) > 0 and last["coarse_inverse"] is not None
+        fs.close()
+
+
 def test_solve_seconds_is_the_krylov_loop_without_the_setup():
     # femshell_solve_info: pc_setup_seconds and solve_seconds are separate figures (bench.py's time to solution is the second);
     # the first solve of a context builds the hierarchy, the second reuses it, and both report the same loop time
