@@ -645,6 +645,7 @@ struct DenseLookAhead {
     double *B_next = nullptr, *scratch = nullptr;
     int32_t *status = nullptr;
     unsigned int *flag = nullptr; // one counter per sweep, zero-initialised
+    int spin_limit = 1 << 24;     // polls of the pivot workgroup before it gives up (FEMSHELL_AMG_DENSE_LOOKAHEAD_SPINS: tests)
 };
 
 // one workgroup per lower 64 x 64 tile (i >= j): the sweep of the 128-wide block K
@@ -670,12 +671,14 @@ __global__ __launch_bounds__(256, 4) void k_dense_update(double *__restrict__ D,
             __shared__ int ok;
             if (tid == 0) {
                 int spins = 0;
-                while (__hip_atomic_load(la.flag + K, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < 3u && spins < (1 << 24)) {
+                while (spins < la.spin_limit && __hip_atomic_load(la.flag + K, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < 3u) {
                     __builtin_amdgcn_s_sleep(8);
                     spins++;
                 }
-                ok = spins < (1 << 24) ? 1 : 0;
-                if (!ok) la.status[0] = 2; // (never seen: the three tile workgroups precede this one in dispatch order)
+                ok = spins < la.spin_limit ? 1 : 0;
+                // (not seen on a card of its own: the three tile workgroups precede this one in dispatch order.  The host runs the
+                //  inverse again without the look-ahead: amg_dense_inverse_device)
+                if (!ok) la.status[0] = 2;
             }
             __syncthreads();
             if (!ok) return;
@@ -818,10 +821,14 @@ __global__ __launch_bounds__(256) void k_dense_gemv_big(const T *__restrict__ A,
 
 } // namespace
 
-int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precision, DevBuf<double> *inv64, DevBuf<float> *inv32,
-                             int64_t *lda_out, AmgDenseStats *stats)
+namespace {
+
+// (*timed_out: the look-ahead's bounded wait expired -- the caller runs the inverse again without it)
+int dense_inverse_once(femshell_ctx *c, const Bsr &A, bool single_precision, DevBuf<double> *inv64, DevBuf<float> *inv32,
+                       int64_t *lda_out, AmgDenseStats *stats, bool lookahead, bool *timed_out)
 {
     hipStream_t st = c->stream;
+    *timed_out = false;
     const int n = 6 * A.nr, n_pad = (n + kSW - 1) / kSW * kSW, nt = n_pad / kNB, ns = n_pad / kSW;
     const int64_t ld = n_pad;
     DevBuf<double> D, diag0, B, Cp, Wp, pivot_scratch;
@@ -863,8 +870,11 @@ int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precisio
     // (the pivot kernel is one workgroup and 70 us of dependent steps; running it on a second stream beside the previous
     //  sweep's update, after bringing its three tiles up to date first, was measured: the two event waits per sweep cost more
     //  than the overlap gains, 17.3 -> 29.7 ms)
-    // FEMSHELL_AMG_DENSE_LOOKAHEAD=0: the pivot inverse as a launch of its own in front of every sweep (A/B runs)
-    const bool lookahead = !(getenv("FEMSHELL_AMG_DENSE_LOOKAHEAD") && atoi(getenv("FEMSHELL_AMG_DENSE_LOOKAHEAD")) == 0);
+    // Look-ahead: workgroup `tiles` of the update's grid waits (bounded spin) for workgroups 0-2 of the SAME grid.  That makes
+    // progress because workgroups are dispatched in index order and the three it waits for never wait themselves -- an
+    // observed property of the dispatcher, not a contract: on a card shared with other processes, or under a CU mask, the
+    // bound can expire.  The kernel then marks status 2 and amg_dense_inverse_device runs the whole inverse again with the
+    // pivot as a launch of its own (slower, same numbers).
     const bool panel_split = !(getenv("FEMSHELL_AMG_DENSE_PANEL_SPLIT") && atoi(getenv("FEMSHELL_AMG_DENSE_PANEL_SPLIT")) == 0);
     for (int K = 0; K < ns; K++) {
         double *Bk = B.p + (size_t)(K & 1) * kSW * kSW;
@@ -880,6 +890,7 @@ int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precisio
             la.scratch = pivot_scratch.p;
             la.status = dstatus.p;
             la.flag = la_flags.p;
+            if (const char *e = getenv("FEMSHELL_AMG_DENSE_LOOKAHEAD_SPINS")) la.spin_limit = atoi(e);
         }
         if (la.on) hipLaunchKernelGGL(k_dense_update<true>, dim3(tiles + 1), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p, tiles, la);
         else hipLaunchKernelGGL(k_dense_update<false>, dim3(tiles), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p, tiles, la);
@@ -913,9 +924,32 @@ int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precisio
         stats->dropped = hstatus[1];
         stats->bytes = (double)ns * (double)tiles * 2.0 * kNB * kNB * 8.0; // lower triangle read + written per sweep
     }
-    if (hstatus[0] == 2) return set_err(FEMSHELL_ERR_HIP, "multigrid setup: the look-ahead of the dense inverse timed out");
+    if (hstatus[0] == 2) {
+        *timed_out = true;
+        return set_err(FEMSHELL_ERR_HIP, "multigrid setup: the look-ahead of the dense inverse timed out");
+    }
     if (hstatus[0] != 0) return set_err(FEMSHELL_ERR_BREAKDOWN, "multigrid setup: coarsest operator is not positive definite");
     return FEMSHELL_OK;
+}
+
+} // namespace
+
+int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precision, DevBuf<double> *inv64, DevBuf<float> *inv32,
+                             int64_t *lda_out, AmgDenseStats *stats)
+{
+    // FEMSHELL_AMG_DENSE_LOOKAHEAD=0: the pivot inverse as a launch of its own in front of every sweep (A/B runs)
+    const bool lookahead = !(getenv("FEMSHELL_AMG_DENSE_LOOKAHEAD") && atoi(getenv("FEMSHELL_AMG_DENSE_LOOKAHEAD")) == 0);
+    bool timed_out = false;
+    int rc = dense_inverse_once(c, A, single_precision, inv64, inv32, lda_out, stats, lookahead, &timed_out);
+    if (rc && timed_out && lookahead) {
+        // the look-ahead's workgroup was not scheduled beside the three it waits for (shared card, CU mask): once more, without it
+        if (getenv("FEMSHELL_AMG_VERBOSE") && atoi(getenv("FEMSHELL_AMG_VERBOSE")) != 0)
+            fprintf(stderr, "[femshell amg setup] the look-ahead of the dense inverse timed out: running it again without\n");
+        inv64->release();
+        inv32->release();
+        rc = dense_inverse_once(c, A, single_precision, inv64, inv32, lda_out, stats, false, &timed_out);
+    }
+    return rc;
 }
 
 void launch_dense_gemv_big(const double *A64, const float *A32, int64_t lda, const double *b, double *y, int32_t n, int32_t n_pad6,

@@ -154,7 +154,11 @@ bool amg_uses_single_precision(const Amg &H);
 double amg_lambda_safety();
 int amg_power_iterations();
 // z = M(r): one multigrid cycle on the context's stream (all launches are no-ops once gate->done != 0)
-int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate);
+// (pre_started: the caller's kernel took the first step of the pre-smoothing on level 0 already -- k_pcg_update_start: the
+//  direction in the level's d vector, the iterate = that direction in amg_apply_iterate(c, z))
+int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate, bool pre_started = false);
+// the vector the cycle on level 0 iterates in: z itself, or -- row-partitioned contexts -- the work vector with ghost space
+double *amg_apply_iterate(femshell_ctx *c, double *z);
 // *true_rr_out: ||b - K x||^2 of the returned iterate when the residual replacement computed it, else -1
 // *rec_rr_out: recurrence ||r||^2 the stopping rule saw last
 int cg_amg(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it, double *true_rr_out, double *rec_rr_out);

@@ -52,6 +52,7 @@ int allgather_i64(femshell_ctx *c, int64_t mine, std::vector<int64_t> *all)
     if (!comm_allreduce_sum(c->comm, d.p, world, c->stream, &e)) return set_err(FEMSHELL_ERR_COMM, e);
     FS_HIP(hipMemcpyAsync(h.data(), d.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     FS_HIP(hipStreamSynchronize(c->stream));
+    CommWatch::heartbeat(); // (every rank got here: progress of the phase the watchdog times)
     all->resize((size_t)world);
     for (int r = 0; r < world; r++) (*all)[(size_t)r] = (int64_t)std::llround(h[(size_t)r]);
     return FEMSHELL_OK;
@@ -202,6 +203,21 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
     const int world = c->comm.world, me = c->comm.rank;
     LevelHalo &FH = *L.halo;
     const int32_t n = pat.n, n_pad = FH.n_pad, n_ghost = FH.n_ghost, n_local = n_pad + n_ghost;
+    // A failure only this rank sees (an allocation, an upload, a launch) must not send it home while its peers sit in the next
+    // exchange -- a mismatched collective that only the watchdog would end.  The local work between two collectives therefore
+    // runs as blocks whose first failure is kept in `pending` (its text in last_err()), and every collective of this step is
+    // preceded by an agreement of the ranks on it: all of them leave with an error, or all of them go on.
+    int pending = FEMSHELL_OK;
+    auto local = [&](const std::function<int()> &block) {
+        if (pending) return;
+        pending = block();
+    };
+    auto agree = [&](const char *what) -> int {
+        int64_t unused = 0;
+        const int r = global_max(c, pending ? -1 : 0, &unused, what);
+        pending = FEMSHELL_OK;
+        return r;
+    };
     // ---- rank-local aggregation
     Bsr G; // rows: own nodes; columns: local ids, ghosts included
     graph_of_pattern(pat, &G);
@@ -254,28 +270,39 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
             for (int32_t i = 0; i < n; i++) order[(size_t)fill[(size_t)agg[(size_t)i]]++] = i;
         }
         DevBuf<int32_t> d_gptr, d_order;
-        FS_HIP(d_gptr.upload(gptr, st));
-        FS_HIP(d_order.upload(order, st));
-        FS_HIP(d_Q.alloc((size_t)n_local * 36));
-        FS_HIP(d_Q.zero(st));
-        FS_HIP(res->Bc_dev.alloc((size_t)std::max(na, 1) * 36));
-        const bool in_memory = getenv("FEMSHELL_AMG_QR") && std::string(getenv("FEMSHELL_AMG_QR")) == "memory";
-        launch_amg_tentative_qr(Bsrc, d_gptr.p, d_order.p, na, largest, d_Q.p, res->Bc_dev.p, in_memory, st);
-        FS_HIP(hipGetLastError());
-        rc = exchange_rows(c, FH, d_Q.p, 36);
-        if (rc) return rc;
         std::vector<double> keyf((size_t)n_local, -1.0);
         for (int32_t i = 0; i < n; i++) keyf[(size_t)i] = (double)(key[(size_t)i] = key0 + agg[(size_t)i]);
-        FS_HIP(d_keyf.upload(keyf, st));
+        local([&]() -> int {
+            FS_HIP(d_gptr.upload(gptr, st));
+            FS_HIP(d_order.upload(order, st));
+            FS_HIP(d_Q.alloc((size_t)n_local * 36));
+            FS_HIP(d_Q.zero(st));
+            FS_HIP(res->Bc_dev.alloc((size_t)std::max(na, 1) * 36));
+            const bool in_memory = getenv("FEMSHELL_AMG_QR") && std::string(getenv("FEMSHELL_AMG_QR")) == "memory";
+            launch_amg_tentative_qr(Bsrc, d_gptr.p, d_order.p, na, largest, d_Q.p, res->Bc_dev.p, in_memory, st);
+            FS_HIP(hipGetLastError());
+            FS_HIP(d_keyf.upload(keyf, st));
+            return FEMSHELL_OK;
+        });
+        rc = agree("the tentative prolongator");
+        if (rc) return rc;
+        rc = exchange_rows(c, FH, d_Q.p, 36);
+        if (rc) return rc;
         rc = exchange_rows(c, FH, d_keyf.p, 1);
         if (rc) return rc;
-        FS_HIP(hipMemcpyAsync(keyf.data() + n_pad, d_keyf.p + n_pad, (size_t)n_ghost * sizeof(double), hipMemcpyDeviceToHost, st));
-        FS_HIP(hipStreamSynchronize(st));
-        for (int32_t g = 0; g < n_ghost; g++) key[(size_t)n_pad + g] = (int32_t)keyf[(size_t)n_pad + g];
-        std::vector<int32_t> keyd(key);
-        for (int32_t &k : keyd) k = std::max(k, 0); // (padding rows)
-        FS_HIP(d_key.upload(keyd, st));
-        FS_HIP(hipStreamSynchronize(st));
+        local([&]() -> int {
+            FS_HIP(hipMemcpyAsync(keyf.data() + n_pad, d_keyf.p + n_pad, (size_t)n_ghost * sizeof(double), hipMemcpyDeviceToHost, st));
+            FS_HIP(hipStreamSynchronize(st));
+            for (int32_t g = 0; g < n_ghost; g++) key[(size_t)n_pad + g] = (int32_t)keyf[(size_t)n_pad + g];
+            std::vector<int32_t> keyd(key);
+            for (int32_t &k : keyd) k = std::max(k, 0); // (padding rows)
+            FS_HIP(d_key.upload(keyd, st));
+            FS_HIP(hipStreamSynchronize(st));
+            return FEMSHELL_OK;
+        });
+        // (the keys of the ghost rows are read on the host below: the ranks agree on their arrival first)
+        rc = agree("the aggregate keys of the ghost rows");
+        if (rc) return rc;
     }
     lap("tentative P, ghost rows of Q");
 
@@ -331,53 +358,67 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
     DevBuf<double> vP, vAP, vR, vAc;
     DevPattern dP, dAP, dR, dAc;
     EllView wP, wAP, wR, wAc;
-    FS_HIP(vP.alloc((size_t)eP.total() * 36));
-    rc = upload_pattern(eP, dP, vP.p, &wP, st);
-    if (rc) return rc;
     DevBuf<uint8_t> d_pmap_own, d_pmap_in;
-    FS_HIP(d_pmap_own.upload(pmap_own, st));
-    FS_HIP(d_pmap_in.upload(pmap_in, st));
-    {
+    local([&]() -> int {
+        FS_HIP(vP.alloc((size_t)eP.total() * 36));
+        const int r = upload_pattern(eP, dP, vP.p, &wP, st);
+        if (r) return r;
+        FS_HIP(d_pmap_own.upload(pmap_own, st));
+        FS_HIP(d_pmap_in.upload(pmap_in, st));
         EllView own = wP; // the kernel writes the own rows: one lane per slot
         own.n_rows = n;
         own.n_slices = n_pad / kSliceNodes;
         own.total = own_total_P;
         launch_amg_prolongator(Adev, d_key.p, d_Q.p, (4.0 / 3.0) / L.lam, d_pmap_own.p, d_pmap_in.p, own, st);
         FS_HIP(hipGetLastError());
-    }
+        return FEMSHELL_OK;
+    });
     // ---- the rows of P of the ghost nodes
     DevBuf<double> rowbuf; // received rows (reused for A P)
     DevBuf<int32_t> d_keys;
     std::vector<int32_t> hkeys;
-    auto fetch_ghost_rows = [&](const EllView &M, bool contig, EllPattern &E, DevPattern &D, int W) -> int {
+    // (local work in front of the exchange, agreement, the exchange, local work behind it -- whose failure the next
+    //  agreement of this step picks up)
+    auto fetch_ghost_rows = [&](const EllView &M, bool contig, EllPattern &E, DevPattern &D, int W, const char *what) -> int {
         // send: W x 37 doubles per node of the send lists; receive the same per ghost node
         const size_t per = (size_t)W * 37;
-        if ((size_t)FH.sendbuf_width < per) {
-            FS_HIP(FH.sendbuf.alloc((size_t)std::max(FH.total_send, 1) * per));
-            FH.sendbuf_width = (int)per;
-        }
-        launch_pack_ell_rows(M, contig, FH.send_nodes.p, FH.total_send, W, FH.sendbuf.p, st);
-        FS_HIP(hipGetLastError());
-        FS_HIP(rowbuf.alloc((size_t)std::max(n_ghost, 1) * per));
+        local([&]() -> int {
+            if ((size_t)FH.sendbuf_width < per) {
+                FS_HIP(FH.sendbuf.alloc((size_t)std::max(FH.total_send, 1) * per));
+                FH.sendbuf_width = (int)per;
+            }
+            launch_pack_ell_rows(M, contig, FH.send_nodes.p, FH.total_send, W, FH.sendbuf.p, st);
+            FS_HIP(hipGetLastError());
+            FS_HIP(rowbuf.alloc((size_t)std::max(n_ghost, 1) * per));
+            return FEMSHELL_OK;
+        });
+        const int arc = agree(what);
+        if (arc) return arc;
         std::string e;
         if (!comm_halo(c->comm, FH.peers, FH.send_offsets, FH.sendbuf.p, rowbuf.p, st, &e, (int)per)) return set_err(FEMSHELL_ERR_COMM, e);
-        const int64_t entries = (int64_t)n_ghost * W;
-        FS_HIP(d_keys.alloc((size_t)std::max<int64_t>(entries, 1)));
-        launch_extract_keys(rowbuf.p, entries, d_keys.p, st);
-        FS_HIP(hipGetLastError());
-        hkeys.assign((size_t)entries, -1);
-        if (entries) FS_HIP(hipMemcpyAsync(hkeys.data(), d_keys.p, (size_t)entries * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        FS_HIP(hipStreamSynchronize(st));
-        fill_ghost_rows(E, n_pad, n_ghost, W, hkeys);
-        // cols / count of the ghost rows into the device copy of the pattern, then the values
-        FS_HIP(hipMemcpyAsync(D.cols.p, E.cols.data(), E.cols.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        FS_HIP(hipMemcpyAsync(D.count.p, E.count.data(), E.count.size() * sizeof(uint8_t), hipMemcpyHostToDevice, st));
-        launch_unpack_ell_rows(rowbuf.p, n_ghost, W, M, contig, n_pad, st);
-        FS_HIP(hipGetLastError());
-        FS_HIP(hipStreamSynchronize(st));
+        local([&]() -> int {
+            const int64_t entries = (int64_t)n_ghost * W;
+            FS_HIP(d_keys.alloc((size_t)std::max<int64_t>(entries, 1)));
+            launch_extract_keys(rowbuf.p, entries, d_keys.p, st);
+            FS_HIP(hipGetLastError());
+            hkeys.assign((size_t)entries, -1);
+            if (entries) FS_HIP(hipMemcpyAsync(hkeys.data(), d_keys.p, (size_t)entries * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            FS_HIP(hipStreamSynchronize(st));
+            fill_ghost_rows(E, n_pad, n_ghost, W, hkeys);
+            // cols / count of the ghost rows into the device copy of the pattern, then the values
+            FS_HIP(hipMemcpyAsync(D.cols.p, E.cols.data(), E.cols.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            FS_HIP(hipMemcpyAsync(D.count.p, E.count.data(), E.count.size() * sizeof(uint8_t), hipMemcpyHostToDevice, st));
+            launch_unpack_ell_rows(rowbuf.p, n_ghost, W, M, contig, n_pad, st);
+            FS_HIP(hipGetLastError());
+            FS_HIP(hipStreamSynchronize(st));
+            return FEMSHELL_OK;
+        });
         return FEMSHELL_OK;
     };
-    rc = fetch_ghost_rows(wP, false, eP, dP, (int)Wp);
+    rc = fetch_ghost_rows(wP, false, eP, dP, (int)Wp, "the rank's rows of the prolongator");
+    if (rc) return rc;
+    // (the host reads the ghost rows' keys next: agreement on their arrival)
+    rc = agree("the ghost rows of the prolongator");
     if (rc) return rc;
     lap("P and its ghost rows");
 
@@ -400,18 +441,21 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
     if (rc) return rc;
     const int64_t own_total_AP = eAP.total();
     append_ghost_rows(eAP, n_ghost, (int)Wap);
-    FS_HIP(vAP.alloc((size_t)eAP.total() * 36));
-    rc = upload_pattern(eAP, dAP, vAP.p, &wAP, st);
-    if (rc) return rc;
-    {
+    local([&]() -> int {
+        FS_HIP(vAP.alloc((size_t)eAP.total() * 36));
+        const int r = upload_pattern(eAP, dAP, vAP.p, &wAP, st);
+        if (r) return r;
         EllView own = wAP;
         own.n_rows = n;
         own.n_slices = n_pad / kSliceNodes;
         own.total = own_total_AP;
         launch_amg_ap(Adev, wP, own, st);
         FS_HIP(hipGetLastError());
-    }
-    rc = fetch_ghost_rows(wAP, true, eAP, dAP, (int)Wap);
+        return FEMSHELL_OK;
+    });
+    rc = fetch_ghost_rows(wAP, true, eAP, dAP, (int)Wap, "the rank's rows of A P");
+    if (rc) return rc;
+    rc = agree("the ghost rows of A P");
     if (rc) return rc;
     lap("A P and its ghost rows");
 
@@ -475,7 +519,10 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
     DevBuf<int64_t> d_rptr;
     DevBuf<int32_t> d_rrow;
     DevBuf<uint8_t> d_rk;
-    {
+    ValueArray h;
+    L.agg.assign((size_t)n, 0);
+    for (int32_t i = 0; i < n; i++) L.agg[(size_t)i] = key[(size_t)i];
+    local([&]() -> int {
         std::vector<int32_t> rr(rrow);
         std::vector<uint8_t> kk(rk);
         if (rr.empty()) {
@@ -485,30 +532,27 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
         FS_HIP(d_rptr.upload(rptr, st));
         FS_HIP(d_rrow.upload(rr, st));
         FS_HIP(d_rk.upload(kk, st));
-    }
-    FS_HIP(vR.alloc((size_t)std::max<int64_t>(eR.total(), 1) * 36));
-    FS_HIP(vAc.alloc((size_t)std::max<int64_t>(eAc.total(), 1) * 36));
-    rc = upload_pattern(eR, dR, vR.p, &wR, st);
-    if (!rc) rc = upload_pattern(eAc, dAc, vAc.p, &wAc, st);
-    if (rc) return rc;
-    launch_amg_restriction(wP, d_rptr.p, d_rrow.p, d_rk.p, wR, st);
-    launch_amg_galerkin(wP, wAP, d_rptr.p, d_rrow.p, d_rk.p, wAc, st, false, key0);
-    FS_HIP(hipGetLastError());
-    FS_HIP(hipStreamSynchronize(st));
-    vAP.release();
+        FS_HIP(vR.alloc((size_t)std::max<int64_t>(eR.total(), 1) * 36));
+        FS_HIP(vAc.alloc((size_t)std::max<int64_t>(eAc.total(), 1) * 36));
+        int r = upload_pattern(eR, dR, vR.p, &wR, st);
+        if (!r) r = upload_pattern(eAc, dAc, vAc.p, &wAc, st);
+        if (r) return r;
+        launch_amg_restriction(wP, d_rptr.p, d_rrow.p, d_rk.p, wR, st);
+        launch_amg_galerkin(wP, wAP, d_rptr.p, d_rrow.p, d_rk.p, wAc, st, false, key0);
+        FS_HIP(hipGetLastError());
+        FS_HIP(hipStreamSynchronize(st));
+        vAP.release();
+        // ---- exports for the tests (small problems): the rank's rows with global column keys
+        if (keep_host) {
+            r = download_vals(vP, &h, st);
+            if (r) return r;
+            EllPattern own = eP; // own rows only
+            own.n_rows = n;
+            ell_to_bsr(own, h.data(), na_global, &L.hP);
+        }
+        return FEMSHELL_OK;
+    });
     lap("R, A_c on the device");
-
-    // ---- exports for the tests (small problems): the rank's rows with global column keys
-    L.agg.assign((size_t)n, 0);
-    for (int32_t i = 0; i < n; i++) L.agg[(size_t)i] = key[(size_t)i];
-    ValueArray h;
-    if (keep_host) {
-        rc = download_vals(vP, &h, st);
-        if (rc) return rc;
-        EllPattern own = eP; // own rows only
-        own.n_rows = n;
-        ell_to_bsr(own, h.data(), na_global, &L.hP);
-    }
 
     // ---- the coarse level
     N.n_global = na_global;
@@ -517,18 +561,24 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
         // all-gather: every rank gets the whole coarse operator (host BSR, global ids) and its near-null space; P keeps
         // global column ids (the correction it prolongates is replicated), R writes the rank's rows of the restricted
         // residual, which the cycle all-gathers
-        rc = download_vals(vAc, &h, st);
-        if (rc) return rc;
         Bsr mine;
-        ell_to_bsr(eAc, h.data(), na_global, &mine); // (columns ascending: the keys are global ids)
-        std::vector<double> cntf((size_t)na), colf(mine.col.begin(), mine.col.end()), allc, allcol, allval, bc((size_t)na * 36), allb;
-        for (int32_t I = 0; I < na; I++) cntf[(size_t)I] = (double)(mine.ptr[(size_t)I + 1] - mine.ptr[(size_t)I]);
+        std::vector<double> cntf((size_t)na), colf, allc, allcol, allval, bc((size_t)na * 36), allb;
+        local([&]() -> int {
+            const int r = download_vals(vAc, &h, st);
+            if (r) return r;
+            ell_to_bsr(eAc, h.data(), na_global, &mine); // (columns ascending: the keys are global ids)
+            colf.assign(mine.col.begin(), mine.col.end());
+            for (int32_t I = 0; I < na; I++) cntf[(size_t)I] = (double)(mine.ptr[(size_t)I + 1] - mine.ptr[(size_t)I]);
+            if (na) FS_HIP(hipMemcpy(bc.data(), res->Bc_dev.p, bc.size() * sizeof(double), hipMemcpyDeviceToHost));
+            return FEMSHELL_OK;
+        });
+        rc = agree("the rank's rows of the coarse operator");
+        if (rc) return rc;
         std::vector<int64_t> off;
         rc = allgather_doubles(c, cntf.data(), na, &allc, &off);
         if (!rc) rc = allgather_doubles(c, colf.data(), (int64_t)colf.size(), &allcol, &off);
         if (!rc) rc = allgather_doubles(c, mine.val.data(), (int64_t)mine.val.size(), &allval, &off);
         if (rc) return rc;
-        if (na) FS_HIP(hipMemcpy(bc.data(), res->Bc_dev.p, bc.size() * sizeof(double), hipMemcpyDeviceToHost));
         rc = allgather_doubles(c, bc.data(), (int64_t)bc.size(), &allb, &off);
         if (rc) return rc;
         Bsr &A = res->A_global;
@@ -547,9 +597,14 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
         L.P.dm.n_pad = n_pad;
         L.P.dm.n_slices = n_pad / kSliceNodes;
         adopt(L.R, eR, dR, vR, n_local);
-        FS_HIP(L.bown.alloc((size_t)na_pad * 6));
-        FS_HIP(L.bown.zero(st));
-        FS_HIP(hipStreamSynchronize(st));
+        local([&]() -> int {
+            FS_HIP(L.bown.alloc((size_t)na_pad * 6));
+            FS_HIP(L.bown.zero(st));
+            FS_HIP(hipStreamSynchronize(st));
+            return FEMSHELL_OK;
+        });
+        rc = agree("the buffers of the replicated level");
+        if (rc) return rc;
         lap("all-gather of the coarse operator");
         return FEMSHELL_OK;
     }
@@ -583,9 +638,14 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
     // (the ghost rows of P are setup intermediates: the cycle's P covers the own rows)
     to_local(eP, n);
     to_local(eAc, na);
-    FS_HIP(hipMemcpyAsync(dP.cols.p, eP.cols.data(), eP.cols.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    FS_HIP(hipMemcpyAsync(dAc.cols.p, eAc.cols.data(), eAc.cols.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    FS_HIP(hipStreamSynchronize(st));
+    local([&]() -> int {
+        FS_HIP(hipMemcpyAsync(dP.cols.p, eP.cols.data(), eP.cols.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        FS_HIP(hipMemcpyAsync(dAc.cols.p, eAc.cols.data(), eAc.cols.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        FS_HIP(hipStreamSynchronize(st));
+        return FEMSHELL_OK;
+    });
+    rc = agree("the rank's rows of R and of the coarse operator"); // (build_level_halo is collective)
+    if (rc) return rc;
     N.halo.reset(new LevelHalo());
     rc = build_level_halo(c, cpart, na_pad, ghost_keys, N.halo.get());
     if (rc) return rc;
@@ -600,8 +660,7 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
     L.P.dm.n_slices = n_pad / kSliceNodes;
     adopt(L.R, eR, dR, vR, n_local);
     if (keep_host) { // own rows of the coarse operator with global column ids, before the pattern arrays move on
-        rc = download_vals(vAc, &h, st);
-        if (rc) return rc;
+        local([&]() -> int { return download_vals(vAc, &h, st); });
         EllPattern g = eAc;
         for (int32_t r = 0; r < na; r++) {
             const int s = r / kSliceNodes, nn = r % kSliceNodes;
@@ -610,7 +669,7 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
                 kk = kk < na_pad ? key0 + kk : ghost_keys[(size_t)(kk - na_pad)];
             }
         }
-        ell_to_bsr(g, h.data(), na_global, &N.hA);
+        if (!pending) ell_to_bsr(g, h.data(), na_global, &N.hA);
     }
     adopt(N.A, eAc, dAc, vAc, nc_local);
     N.A.dm.n_ghost = N.n_ghost;
@@ -620,8 +679,7 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
     if (sym_coarse) {
         SlicedEllSym S;
         build_in_lists(na, eAc.slice_width, eAc.slice_base, eAc.cols.data(), eAc.count, &S);
-        rc = attach_in_lists(N.A, S, eAc.total(), st);
-        if (rc) return rc;
+        local([&]() -> int { return attach_in_lists(N.A, S, eAc.total(), st); });
         N.pattern.in_width.swap(S.in_width);
         N.pattern.in_base.swap(S.in_base);
         N.pattern.in_slots.swap(S.in_slots);
@@ -632,6 +690,8 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
     N.pattern.cols.swap(eAc.cols);
     N.pattern.count.swap(eAc.count);
     N.A_on_device = true;
+    rc = agree("the coarse level's halo and in-lists"); // (the caller's next step is collective again)
+    if (rc) return rc;
     lap("coarse halo");
     return FEMSHELL_OK;
 }
@@ -727,6 +787,7 @@ int amg_setup_dist(femshell_ctx *c)
         const double t = now_s();
         if (verbose) fprintf(stderr, "[femshell amg setup, rank %d] level %d %-32s %.3f s\n", c->comm.rank, lap_level, what, t - tl);
         tl = t;
+        CommWatch::heartbeat(); // (progress of the phase the watchdog times)
     };
     const bool keep_host = amg_keep_host(pl.nnz_blocks); // inspection exports (tests)
     static const bool plain = getenv("FEMSHELL_AMG_PLAIN_RBM") && atoi(getenv("FEMSHELL_AMG_PLAIN_RBM")) != 0;

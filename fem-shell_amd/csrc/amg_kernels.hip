@@ -33,9 +33,24 @@ __global__ __launch_bounds__(192) void k_cheb_start(DeviceMatrix m, const double
     }
 }
 
+bool node_kernels();
+int node_grid(const DeviceMatrix &m);
+template <bool kD32>
+__global__ void k_cheb_start_node(DeviceMatrix m, const double *__restrict__ rin, double *__restrict__ d, double *x, double inv_theta,
+                                  int accumulate, const CgScalars *gate);
+template <bool kGather, int kVec>
+__global__ void k_cheb_step_node(DeviceMatrix m, const double *rin, const double *__restrict__ q, double *rout, double *__restrict__ d,
+                                 double *__restrict__ x, double a, double c, const CgScalars *gate);
+
 void launch_cheb_start(const DeviceMatrix &m, const double *rin, double *d, double *x, double inv_theta, bool accumulate,
                        const CgScalars *gate, hipStream_t st, int vec32)
 {
+    if (node_kernels()) {
+        const dim3 g(node_grid(m)), b(64);
+        if (vec32 == 2) hipLaunchKernelGGL(k_cheb_start_node<true>, g, b, 0, st, m, rin, d, x, inv_theta, accumulate ? 1 : 0, gate);
+        else hipLaunchKernelGGL(k_cheb_start_node<false>, g, b, 0, st, m, rin, d, x, inv_theta, accumulate ? 1 : 0, gate);
+        return;
+    }
     if (vec32 == 2) hipLaunchKernelGGL(k_cheb_start<true>, dim3(slice_grid(m)), dim3(192), 0, st, m, rin, d, x, inv_theta, accumulate ? 1 : 0, gate);
     else hipLaunchKernelGGL(k_cheb_start<false>, dim3(slice_grid(m)), dim3(192), 0, st, m, rin, d, x, inv_theta, accumulate ? 1 : 0, gate);
 }
@@ -95,11 +110,279 @@ __global__ __launch_bounds__(192) void k_cheb_step(DeviceMatrix m, const double 
 void launch_cheb_step(const DeviceMatrix &m, const double *rin, const double *q, double *rout, double *d, double *x,
                       double a, double c, const CgScalars *gate, hipStream_t st, bool gather, int vec32)
 {
+    if (node_kernels()) {
+        const dim3 g(node_grid(m)), b(64);
+        if (gather && vec32 == 2) hipLaunchKernelGGL((k_cheb_step_node<true, 2>), g, b, 0, st, m, rin, q, rout, d, x, a, c, gate);
+        else if (gather && vec32 == 1) hipLaunchKernelGGL((k_cheb_step_node<true, 1>), g, b, 0, st, m, rin, q, rout, d, x, a, c, gate);
+        else if (gather) hipLaunchKernelGGL((k_cheb_step_node<true, 0>), g, b, 0, st, m, rin, q, rout, d, x, a, c, gate);
+        else hipLaunchKernelGGL((k_cheb_step_node<false, 0>), g, b, 0, st, m, rin, q, rout, d, x, a, c, gate);
+        return;
+    }
     const dim3 grid(slice_grid(m)), block(192);
     if (gather && vec32 == 2) hipLaunchKernelGGL((k_cheb_step<true, 2>), grid, block, 0, st, m, rin, q, rout, d, x, a, c, gate);
     else if (gather && vec32 == 1) hipLaunchKernelGGL((k_cheb_step<true, 1>), grid, block, 0, st, m, rin, q, rout, d, x, a, c, gate);
     else if (gather) hipLaunchKernelGGL((k_cheb_step<true, 0>), grid, block, 0, st, m, rin, q, rout, d, x, a, c, gate);
     else hipLaunchKernelGGL((k_cheb_step<false, 0>), grid, block, 0, st, m, rin, q, rout, d, x, a, c, gate);
+}
+
+// ---- one lane per node (device_common.hpp): the smoother's vector kernels without LDS and barriers -------------------------
+// FEMSHELL_NODE_KERNELS=0: the one-lane-per-scalar-row kernels of rounds 1-4 (A/B runs)
+bool node_kernels()
+{
+    static const bool on = [] {
+        const char *e = getenv("FEMSHELL_NODE_KERNELS");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+// workgroups of a node kernel: 64 lanes = two slices; never more than the per-slice kernels of the same matrix launch
+int node_grid(const DeviceMatrix &m)
+{
+    const int g = 8 * ((node_pairs(m.n_slices) + 7) / 8), cap = slice_grid(m);
+    return g < cap ? g : cap;
+}
+
+template <bool kD32>
+__global__ __launch_bounds__(64) void k_cheb_start_node(DeviceMatrix m, const double *__restrict__ rin, double *__restrict__ d, double *x,
+                                                        double inv_theta, int accumulate, const CgScalars *gate)
+{
+    if (gate != nullptr && gate->done != 0) return;
+    const int half = threadIdx.x >> 5, n = threadIdx.x & 31;
+    for (SliceWalk w(node_pairs(m.n_slices)); w.valid(); w.next()) {
+        const int sl = 2 * w.s + half;
+        if (sl >= m.n_slices) continue;
+        const int64_t node = (int64_t)sl * kSliceNodes + n;
+        double mv[kMinvWords], rv[6], xv[6], z[6];
+        node_minv(m, sl, n, true, mv);
+        load_node6(rin, node, false, rv);
+        if (accumulate) load_node6(x, node, false, xv);
+        node_minv_apply(mv, rv, z);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const double dv = inv_theta * z[j];
+            z[j] = dv;
+            xv[j] = accumulate ? xv[j] + dv : dv;
+        }
+        store_node6(d, node, kD32, z);
+        store_node6(x, node, false, xv);
+    }
+}
+
+template <bool kGather, int kVec>
+__global__ __launch_bounds__(64) void k_cheb_step_node(DeviceMatrix m, const double *rin, const double *__restrict__ q, double *rout,
+                                                       double *__restrict__ d, double *__restrict__ x, double a, double c,
+                                                       const CgScalars *gate)
+{
+    if (gate != nullptr && gate->done != 0) return;
+    const int half = threadIdx.x >> 5, n = threadIdx.x & 31;
+    for (SliceWalk w(node_pairs(m.n_slices)); w.valid(); w.next()) {
+        const int sl = 2 * w.s + half;
+        if (sl >= m.n_slices) continue;
+        const int64_t node = (int64_t)sl * kSliceNodes + n;
+        double mv[kMinvWords], qv[6], rv[6], dv[6], xv[6], z[6];
+        node_minv(m, sl, n, true, mv);
+        load_node6(q, node, kVec >= 1, qv);
+        load_node6(rin, node, false, rv);
+        load_node6(d, node, kVec == 2, dv);
+        load_node6(x, node, false, xv);
+        if (kGather) node_gather<(kVec >= 1)>(m, sl, n, qv);
+#pragma unroll
+        for (int j = 0; j < 6; j++) rv[j] = rv[j] - qv[j];
+        store_node6(rout, node, false, rv);
+        node_minv_apply(mv, rv, z);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const double dn = a * dv[j] + c * z[j];
+            dv[j] = dn;
+            xv[j] = xv[j] + dn;
+        }
+        store_node6(d, node, kVec == 2, dv);
+        store_node6(x, node, false, xv);
+    }
+}
+
+// ---- fused passes of the cycle (round 5) ---------------------------------------------------------------------
+// The first step of a Chebyshev smoothing -- d = inv_theta D^-1 r, x (+)= d -- is a block-diagonal operation on the residual it
+// starts from: it belongs in the epilogue of the kernel that PRODUCES that residual, not in a pass of its own that reads the
+// residual back (k_cheb_start: 0.41 GB and 106 us per call on level 0 of the 4M-triangle panel).  Same arithmetic, same bits.
+
+// second phase of a symmetric-storage product (k_sym_gather) + the start of the post-smoothing:
+//   out = base_vec + sign (y + transposed products);  d = inv_theta D^-1 out;  x += d
+// (kQ32: y and the transposed products are floats; kD32: d is stored as floats -- DeviceMatrix::vec32 of the smoother's matrix m)
+template <bool kQ32, bool kD32>
+__global__ __launch_bounds__(192) void k_sym_gather_start(DeviceMatrix m, const double *y, double *out, const double *base_vec, double sign,
+                                                          double *__restrict__ d, double *__restrict__ x, double inv_theta, const CgScalars *s)
+{
+    __shared__ double rs[kSliceRows];
+    if (s != nullptr && s->done != 0) return;
+    const int t = threadIdx.x, n = t / 6, j = t % 6;
+    const float *yf = reinterpret_cast<const float *>(y);
+    for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
+        const int sl = w.s;
+        const int64_t row = (int64_t)sl * kSliceRows + t;
+        const MinvRow mr = load_minv_smoother(m, sl, t);
+        const double bv = base_vec[row], xv = x[row];
+        const double acc = gather_transposed<kQ32>(m, sl, n, j, kQ32 ? (double)yf[row] : y[row]);
+        const double rn = bv + sign * acc;
+        out[row] = rn;
+        __syncthreads();
+        rs[t] = rn;
+        __syncthreads();
+        const double dv = inv_theta * apply_minv(mr, t, rs);
+        if (kD32) reinterpret_cast<float *>(d)[row] = (float)dv;
+        else d[row] = dv;
+        x[row] = xv + dv;
+    }
+}
+
+template <bool kQ32, bool kD32>
+__global__ __launch_bounds__(64) void k_sym_gather_start_node(DeviceMatrix m, const double *y, double *out, const double *base_vec, double sign,
+                                                              double *__restrict__ d, double *__restrict__ x, double inv_theta,
+                                                              const CgScalars *s)
+{
+    if (s != nullptr && s->done != 0) return;
+    const int half = threadIdx.x >> 5, n = threadIdx.x & 31;
+    for (SliceWalk w(node_pairs(m.n_slices)); w.valid(); w.next()) {
+        const int sl = 2 * w.s + half;
+        if (sl >= m.n_slices) continue;
+        const int64_t node = (int64_t)sl * kSliceNodes + n;
+        double mv[kMinvWords], acc[6], bv[6], xv[6], z[6];
+        node_minv(m, sl, n, true, mv);
+        load_node6(y, node, kQ32, acc);
+        load_node6(base_vec, node, false, bv);
+        load_node6(x, node, false, xv);
+        node_gather<kQ32>(m, sl, n, acc);
+#pragma unroll
+        for (int j = 0; j < 6; j++) bv[j] = bv[j] + sign * acc[j];
+        store_node6(out, node, false, bv);
+        node_minv_apply(mv, bv, z);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const double dv = inv_theta * z[j];
+            z[j] = dv;
+            xv[j] = xv[j] + dv;
+        }
+        store_node6(d, node, kD32, z);
+        store_node6(x, node, false, xv);
+    }
+}
+
+void launch_sym_gather_start(const DeviceMatrix &m, const double *y, double *out, const double *base_vec, double sign, double *d, double *x,
+                             double inv_theta, bool q32, bool d32, const CgScalars *s, hipStream_t st)
+{
+    if (node_kernels()) {
+        const dim3 g(node_grid(m)), b(64);
+        if (q32 && d32) hipLaunchKernelGGL((k_sym_gather_start_node<true, true>), g, b, 0, st, m, y, out, base_vec, sign, d, x, inv_theta, s);
+        else if (q32) hipLaunchKernelGGL((k_sym_gather_start_node<true, false>), g, b, 0, st, m, y, out, base_vec, sign, d, x, inv_theta, s);
+        else if (d32) hipLaunchKernelGGL((k_sym_gather_start_node<false, true>), g, b, 0, st, m, y, out, base_vec, sign, d, x, inv_theta, s);
+        else hipLaunchKernelGGL((k_sym_gather_start_node<false, false>), g, b, 0, st, m, y, out, base_vec, sign, d, x, inv_theta, s);
+        return;
+    }
+    const dim3 grid(slice_grid(m)), block(192);
+    if (q32 && d32) hipLaunchKernelGGL((k_sym_gather_start<true, true>), grid, block, 0, st, m, y, out, base_vec, sign, d, x, inv_theta, s);
+    else if (q32) hipLaunchKernelGGL((k_sym_gather_start<true, false>), grid, block, 0, st, m, y, out, base_vec, sign, d, x, inv_theta, s);
+    else if (d32) hipLaunchKernelGGL((k_sym_gather_start<false, true>), grid, block, 0, st, m, y, out, base_vec, sign, d, x, inv_theta, s);
+    else hipLaunchKernelGGL((k_sym_gather_start<false, false>), grid, block, 0, st, m, y, out, base_vec, sign, d, x, inv_theta, s);
+}
+
+// the update of the flexible PCG (k_pcg_update: x += alpha p, r -= alpha q, partial sums of r.r) + what stands on both sides
+// of it: in front, the second phase of q = K p on symmetric storage (kGather: q arrives as the direct part, the row adds the
+// transposed products of its in-list as k_sym_gather does, and stores the whole q for the z.q of k_pcg_dots); behind, the start
+// of the cycle's pre-smoothing on the new residual: d = inv_theta D^-1 r, z = d (m: level 0 as the smoother sees it)
+template <bool kGather, bool kD32>
+__global__ __launch_bounds__(192) void k_pcg_update_start(DeviceMatrix m, CgVectors v, double *__restrict__ d, double *__restrict__ z,
+                                                          double inv_theta)
+{
+    __shared__ double rs[kSliceRows];
+    __shared__ double sh[3];
+    if (v.s->done != 0) return;
+    const int t = threadIdx.x, n = t / 6, j = t % 6;
+    const double alpha = v.s->alpha;
+    double d1 = 0.0;
+    for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
+        const int sl = w.s;
+        const int64_t row = (int64_t)sl * kSliceRows + t;
+        const MinvRow mr = load_minv_smoother(m, sl, t);
+        const double pv = v.p[row], xv = v.x[row], rv = v.r[row];
+        double qv = v.q[row];
+        if (kGather) {
+            qv = gather_transposed<false>(m, sl, n, j, qv);
+            v.q[row] = qv;
+        }
+        v.x[row] = xv + alpha * pv;
+        const double rn = rv - alpha * qv;
+        v.r[row] = rn;
+        d1 += rn * rn;
+        __syncthreads();
+        rs[t] = rn;
+        __syncthreads();
+        const double dv = inv_theta * apply_minv(mr, t, rs);
+        if (kD32) reinterpret_cast<float *>(d)[row] = (float)dv;
+        else d[row] = dv;
+        z[row] = dv;
+    }
+    const double t1 = block_sum(d1, sh);
+    if (threadIdx.x == 0) v.partials[blockIdx.x] = t1;
+}
+
+// (launched with the grid of the per-slice kernels, slice_grid(m): the scalar step reduces that many partial sums)
+template <bool kGather, bool kD32>
+__global__ __launch_bounds__(64) void k_pcg_update_start_node(DeviceMatrix m, CgVectors v, double *__restrict__ d, double *__restrict__ z,
+                                                              double inv_theta)
+{
+    if (v.s->done != 0) return;
+    const int half = threadIdx.x >> 5, n = threadIdx.x & 31;
+    const double alpha = v.s->alpha;
+    double d1 = 0.0;
+    for (SliceWalk w(node_pairs(m.n_slices)); w.valid(); w.next()) {
+        const int sl = 2 * w.s + half;
+        if (sl >= m.n_slices) continue;
+        const int64_t node = (int64_t)sl * kSliceNodes + n;
+        double mv[kMinvWords], pv[6], xv[6], rv[6], qv[6], zz[6];
+        node_minv(m, sl, n, true, mv);
+        load_node6(v.p, node, false, pv);
+        load_node6(v.x, node, false, xv);
+        load_node6(v.r, node, false, rv);
+        load_node6(v.q, node, false, qv);
+        if (kGather) {
+            node_gather<false>(m, sl, n, qv);
+            store_node6(v.q, node, false, qv);
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            xv[j] = xv[j] + alpha * pv[j];
+            const double rn = rv[j] - alpha * qv[j];
+            rv[j] = rn;
+            d1 += rn * rn;
+        }
+        store_node6(v.x, node, false, xv);
+        store_node6(v.r, node, false, rv);
+        node_minv_apply(mv, rv, zz);
+#pragma unroll
+        for (int j = 0; j < 6; j++) zz[j] = inv_theta * zz[j];
+        store_node6(d, node, kD32, zz);
+        store_node6(z, node, false, zz);
+    }
+    const double t1 = wave_sum(d1);
+    if (threadIdx.x == 0) v.partials[blockIdx.x] = t1;
+}
+
+void launch_pcg_update_start(const DeviceMatrix &m, const CgVectors &v, double *d, double *z, double inv_theta, bool gather, bool d32,
+                             hipStream_t st)
+{
+    if (node_kernels()) {
+        const dim3 g(slice_grid(m)), b(64);
+        if (gather && d32) hipLaunchKernelGGL((k_pcg_update_start_node<true, true>), g, b, 0, st, m, v, d, z, inv_theta);
+        else if (gather) hipLaunchKernelGGL((k_pcg_update_start_node<true, false>), g, b, 0, st, m, v, d, z, inv_theta);
+        else if (d32) hipLaunchKernelGGL((k_pcg_update_start_node<false, true>), g, b, 0, st, m, v, d, z, inv_theta);
+        else hipLaunchKernelGGL((k_pcg_update_start_node<false, false>), g, b, 0, st, m, v, d, z, inv_theta);
+        return;
+    }
+    const dim3 grid(slice_grid(m)), block(192);
+    if (gather && d32) hipLaunchKernelGGL((k_pcg_update_start<true, true>), grid, block, 0, st, m, v, d, z, inv_theta);
+    else if (gather) hipLaunchKernelGGL((k_pcg_update_start<true, false>), grid, block, 0, st, m, v, d, z, inv_theta);
+    else if (d32) hipLaunchKernelGGL((k_pcg_update_start<false, true>), grid, block, 0, st, m, v, d, z, inv_theta);
+    else hipLaunchKernelGGL((k_pcg_update_start<false, false>), grid, block, 0, st, m, v, d, z, inv_theta);
 }
 
 // ---- power iteration ---------------------------------------------------------------------------------------

@@ -22,6 +22,16 @@ void launch_cheb_start(const DeviceMatrix &m, const double *rin, double *d, doub
 void launch_cheb_step(const DeviceMatrix &m, const double *rin, const double *q, double *rout, double *d, double *x,
                       double a, double c, const CgScalars *gate, hipStream_t st, bool gather = false, int vec32 = 0);
 
+// ---- fused passes (round 5): the start of a Chebyshev smoothing in the epilogue of the kernel that produces its residual
+// second phase of a symmetric-storage product + start of the post-smoothing: out = base_vec + sign (y + transposed products),
+// d = inv_theta D^-1 out, x += d  (m: the level as the smoother sees it; q32 / d32: y and the transposed products / d are floats)
+void launch_sym_gather_start(const DeviceMatrix &m, const double *y, double *out, const double *base_vec, double sign, double *d, double *x,
+                             double inv_theta, bool q32, bool d32, const CgScalars *s, hipStream_t st);
+// update of the flexible PCG + (gather) the second phase of q = K p in front of it, q stored whole + the start of the cycle's
+// pre-smoothing on the new residual behind it: d = inv_theta D^-1 r, z = d  (m: level 0 as the smoother sees it)
+void launch_pcg_update_start(const DeviceMatrix &m, const CgVectors &v, double *d, double *z, double inv_theta, bool gather, bool d32,
+                             hipStream_t st);
+
 // power iteration for lambda_max(D^-1 A): z = D^-1 q with the partial sums of z.z (one per workgroup of slice_grid(m))
 void launch_minv_apply_norm(const DeviceMatrix &m, const double *q, double *z, double *partials, hipStream_t st);
 // x[i] = deterministic pseudo-random value in (-1,1) for rows of real nodes, 0 for padding rows

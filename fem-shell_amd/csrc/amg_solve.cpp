@@ -17,6 +17,8 @@ namespace femshell {
 
 namespace {
 
+bool has_lowp_copy(const AmgLevel &L) { return L.A32.p != nullptr; }
+
 // FEMSHELL_AMG_VEC_F32: what a smoothing product on the single-precision copy of a level operator (symmetric storage) keeps
 // in single precision besides the values -- 2 (default): its results (direct part, transposed products) and its input, the
 // Chebyshev direction; 1: the results only; 0: nothing.  Residuals and iterates stay FP64.  Read per setup.
@@ -316,6 +318,7 @@ int amg_setup(femshell_ctx *c)
         const double t = now_s();
         if (setup_verbose()) fprintf(stderr, "[femshell amg setup] level %d %-28s %.3f s\n", level, what, t - tl);
         tl = t;
+        CommWatch::heartbeat(); // (progress of the phase the watchdog of a multi-rank context times)
     };
     const SetupRules rules = setup_rules(opt);
     const bool host_only = rules.host_only;
@@ -420,6 +423,7 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
         const double t = now_s();
         if (setup_verbose()) fprintf(stderr, "[femshell amg setup] level %d %-28s %.3f s\n", level, what, t - tl);
         tl = t;
+        CommWatch::heartbeat(); // (progress of the phase the watchdog of a multi-rank context times)
     };
     int rc = FEMSHELL_OK;
     for (int l = first_level;; l++) {
@@ -634,8 +638,11 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
             const int32_t level_nodes = L.dist ? std::max(L.n, L.n_global) : L.n;
             if (mode == 0 || (mode == 2 && l > 0) || (mode == 1 && level_nodes < 4096) || A.vals == nullptr) continue;
             const int64_t nv = (l == 0 ? (int64_t)pl.total_slots() : (int64_t)L.A.vals.n / 36) * 36;
-            FS_HIP(L.A32.alloc((size_t)nv));
-            launch_to_f32(A.vals, L.A32.p, nv, st);
+            {
+                FS_HIP(L.A32.alloc((size_t)nv));
+                launch_to_f32(A.vals, L.A32.p, nv, st);
+                if (const char *sb = getenv("FEMSHELL_AMG_SMOOTH_SIGBITS")) launch_round_sig(L.A32.p, nv, atoi(sb), st); // (experiment)
+            }
             // the block-Jacobi inverse the smoothers apply, and the transfer operators (R = P^T value by value, so the
             // rounded pair is still a transposed pair and the cycle stays symmetric)
             const int64_t nm = (int64_t)A.n_slices * 21 * kSliceNodes;
@@ -659,7 +666,7 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
             L.smooth_dm.minv32 = L.minv32.p;
             // a level whose vectors are exchanged with the neighbour ranks keeps the input of its products FP64 (the halo
             // exchange moves six doubles per node)
-            L.smooth_dm.vec32 = L.A32.p == nullptr ? 0 : std::min(smooth_vectors_f32(), L.dist ? 1 : 2);
+            L.smooth_dm.vec32 = !has_lowp_copy(L) ? 0 : std::min(smooth_vectors_f32(), L.dist ? 1 : 2);
             L.P.dm.vals32 = L.P32.p;
             L.R.dm.vals32 = L.R32.p;
             L.smooth_ready = true;
@@ -701,12 +708,29 @@ bool residual_increment()
     return !(e && atoi(e) == 0);
 }
 
+// FEMSHELL_AMG_FUSE (bit mask; A/B runs and tests): the first step of a Chebyshev smoothing runs in the epilogue of the kernel that
+// produces its residual.  1: k_pcg_update_start (the update of the flexible PCG + the second phase of q = K p + the start of the
+// cycle's pre-smoothing on level 0); 2: k_sym_gather_start (second phase of the increment product in front of a post-smoothing,
+// symmetric-storage levels) -- both repeat the arithmetic of the passes they replace bit for bit; 4: the same in the epilogue of
+// k_spmv on full-storage levels (rounds x + c z as one multiply-add: not the same bits).  Default 3: measured on the 4M-triangle
+// panel, with the one-lane-per-node vector kernels the fused passes take as long as the passes they replace (147 against 65 + 81
+// us, 226 against 82 + 85 + 81 us: these kernels are bound by their load instructions, not by their bytes), so the gain is the
+// launches only; bit 2 changed the iteration count by rounding luck (104 -> 106) and stays off.
+int fuse_mask()
+{
+    const char *e = getenv("FEMSHELL_AMG_FUSE");
+    return e ? atoi(e) : 3;
+}
+
 struct Cycle {
     femshell_ctx *c;
     Amg &H;
     const CgScalars *gate;
     hipStream_t st;
     int rc = FEMSHELL_OK;
+    const int fuse = fuse_mask();
+    // level 0: the caller's kernel (k_pcg_update_start) has taken the first step of the pre-smoothing already -- d in L.d, x = d
+    bool pre_started0 = false;
 
     bool dist(int l) const { return H.levels[(size_t)l]->dist; }
     void halo(int l, double *x)
@@ -717,13 +741,14 @@ struct Cycle {
     // y = K x on level 0 of a row-partitioned context: the halo exchange beside the interior slices (symmetric storage with
     // defer: the direct part only, the consumer collects the transposed products)
     // (vals32: a smoothing product on the single-precision copy of K's values)
-    void product0(double *x, double *y, bool defer, const float *vals32 = nullptr, int vec32 = 0)
+    // (lowp: a smoothing product on the single-precision copy of K's values that matrix view carries)
+    void product0(double *x, double *y, bool defer, const DeviceMatrix *lowp = nullptr, int vec32 = 0)
     {
         if (rc) return;
         CgVectors vv;
         vv.s = const_cast<CgScalars *>(gate);
         int np = 0;
-        rc = spmv_with_halo(c, vv, x, y, nullptr, &np, defer, vals32, vec32);
+        rc = spmv_with_halo(c, vv, x, y, nullptr, &np, defer, lowp != nullptr ? lowp->vals32 : nullptr, vec32);
     }
     // out = b - A_l x
     void residual(int l, const double *b, double *x, double *out)
@@ -745,27 +770,30 @@ struct Cycle {
     }
 
     // (r_given: the residual of x, where the caller has it -- in L.r or a vector of its own, never L.q or L.d)
-    void smooth(int l, const double *b, double *x, bool zero_guess, const double *r_given = nullptr)
+    // (d_started: the kernel that produced the residual took the first step too -- d = inv_theta D^-1 r in this vector, L.d or, on a
+    //  full-storage level, L.q; x updated)
+    void smooth(int l, const double *b, double *x, bool zero_guess, const double *r_given = nullptr, double *d_started = nullptr)
     {
         AmgLevel &L = *H.levels[(size_t)l];
         // (the operator as the smoother sees it: single-precision copies of the values and of D^-1 where the level has them)
         const DeviceMatrix &A = L.smooth_ready ? L.smooth_dm : amg_level_matrix(c, l);
         // what the smoothing products keep in single precision besides the operator's values (DeviceMatrix::vec32)
-        const int v32 = (A.symmetric && A.vals32 != nullptr) ? A.vec32 : 0;
+        const int v32 = (A.symmetric && has_lowp(A)) ? A.vec32 : 0;
         const double *rcur = b;
         if (!zero_guess) {
             if (r_given == nullptr) residual(l, b, x, L.r.p);
             rcur = r_given != nullptr ? r_given : L.r.p;
         }
-        launch_cheb_start(A, rcur, L.d.p, x, L.inv_theta, !zero_guess, gate, st, v32);
-        double *d_cur = L.d.p, *d_next = L.q.p; // full-storage levels: the direction alternates between the two vectors
+        if (d_started == nullptr) launch_cheb_start(A, rcur, L.d.p, x, L.inv_theta, !zero_guess, gate, st, v32);
+        // full-storage levels: the direction alternates between the two vectors
+        double *d_cur = d_started != nullptr ? d_started : L.d.p, *d_next = d_cur == L.d.p ? L.q.p : L.d.p;
         for (size_t k = 0; k < L.cheb_a.size(); k++) {
             if (l == 0 && dist(0)) {
-                product0(L.d.p, L.q.p, A.symmetric != 0, A.vals32, v32);
+                product0(L.d.p, L.q.p, A.symmetric != 0, &A, v32);
                 launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, A.symmetric != 0, v32);
             } else if (A.symmetric) { // first phase of the product; the step kernel collects the transposed products
                 halo(l, L.d.p);
-                launch_spmv_direct(A, L.d.p, L.q.p, nullptr, gate, st, A.vals32 != nullptr);
+                launch_spmv_direct(A, L.d.p, L.q.p, nullptr, gate, st, has_lowp(A));
                 launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, true, v32);
             } else if (fused_cheb()) { // product and step in one launch (the small levels are bound by launch latency)
                 halo(l, d_cur);
@@ -792,23 +820,37 @@ struct Cycle {
     // above it -- and the single-precision copy of the values serves (relative error 1e-7 of the increment; the numpy
     // restatement with these products rounded needs the same iterations, tools/lab/f32_vectors_experiment.py).
     // Returns where the result is: L.r, or L.q for the first of the two on a symmetric-storage level in FP64.
-    double *residual_minus_product(int l, const double *r_base, double *dvec)
+    // (start_x: the result is the residual a post-smoothing of the iterate start_x begins with -- where the kernel that finishes
+    //  the product can take the smoothing's first step as well it does, d = inv_theta D^-1 r and start_x += d, and *d_started
+    //  receives the vector that holds d; else *d_started stays null)
+    double *residual_minus_product(int l, const double *r_base, double *dvec, double *start_x = nullptr, double **d_started = nullptr)
     {
         AmgLevel &L = *H.levels[(size_t)l];
         const DeviceMatrix &A = L.smooth_ready ? L.smooth_dm : amg_level_matrix(c, l);
         // (a product that left its results in single precision -- DeviceMatrix::vec32 -- is collected into L.r, FP64)
-        const bool q32 = A.symmetric && A.vals32 != nullptr && A.vec32 >= 1;
+        const bool q32 = A.symmetric && has_lowp(A) && A.vec32 >= 1;
+        const bool d32 = q32 && A.vec32 == 2;
+        const bool start = start_x != nullptr && d_started != nullptr && (fuse & (A.symmetric ? 2 : 4)) != 0;
         // the buffer the direct part of a symmetric product lands in: not the one the base vector lives in
         double *pb = (!q32 && r_base == L.q.p) ? L.r.p : L.q.p;
+        // second phase of a symmetric product, with the smoothing's first step where asked for (dvec has been read by then: d
+        // goes to L.d, where the step kernels of a symmetric-storage level expect it)
+        auto gather = [&]() -> double * {
+            double *out = q32 ? L.r.p : pb;
+            if (start) {
+                launch_sym_gather_start(A, pb, out, r_base, -1.0, L.d.p, start_x, L.inv_theta, q32, d32, gate, st);
+                *d_started = L.d.p;
+            } else if (q32) {
+                launch_sym_gather(A, pb, r_base, -1.0, gate, st, true, L.r.p);
+            } else {
+                launch_sym_gather(A, pb, r_base, -1.0, gate, st);
+            }
+            return out;
+        };
         if (l == 0 && dist(0)) {
             if (A.symmetric) {
-                product0(dvec, pb, true, A.vals32, A.vec32);
-                if (q32) {
-                    launch_sym_gather(A, pb, r_base, -1.0, gate, st, true, L.r.p);
-                    return L.r.p;
-                }
-                launch_sym_gather(A, pb, r_base, -1.0, gate, st);
-                return pb;
+                product0(dvec, pb, true, &A, A.vec32);
+                return gather();
             }
             product0(dvec, L.q.p, false);
             launch_sub(r_base, L.q.p, L.r.p, 6ll * A.n_pad, st);
@@ -816,15 +858,18 @@ struct Cycle {
         }
         halo(l, dvec);
         if (A.symmetric) {
-            launch_spmv_direct(A, dvec, pb, nullptr, gate, st, A.vals32 != nullptr);
-            if (q32) {
-                launch_sym_gather(A, pb, r_base, -1.0, gate, st, true, L.r.p);
-                return L.r.p;
-            }
-            launch_sym_gather(A, pb, r_base, -1.0, gate, st);
-            return pb;
+            launch_spmv_direct(A, dvec, pb, nullptr, gate, st, has_lowp(A));
+            return gather();
         }
-        launch_spmv_axpy(A, dvec, L.r.p, r_base, -1.0, gate, st); // (dvec is L.d or L.q, never L.r; r_base may be L.r)
+        // (dvec is L.d or L.q, never L.r; r_base may be L.r)
+        if (start) {
+            // the product's Chebyshev epilogue as a first step: r = r_base - A dvec, d = inv_theta D^-1 r into the other direction vector
+            double *d_out = dvec == L.d.p ? L.q.p : L.d.p;
+            launch_spmv_start(A, dvec, r_base, L.r.p, d_out, start_x, L.inv_theta, gate, st);
+            *d_started = d_out;
+        } else {
+            launch_spmv_axpy(A, dvec, L.r.p, r_base, -1.0, gate, st);
+        }
         return L.r.p;
     }
 
@@ -838,7 +883,12 @@ struct Cycle {
             return;
         }
         AmgLevel &N = *H.levels[(size_t)l + 1];
-        smooth(l, b, x, true);
+        if (l == 0 && pre_started0) {
+            pre_started0 = false;
+            smooth(l, b, x, true, nullptr, L.d.p);
+        } else {
+            smooth(l, b, x, true);
+        }
         double *rf = L.r.p; // r = b - A x
         const bool increments = residual_increment();
         if (increments) rf = residual_minus_product(l, last_r, last_d);
@@ -866,10 +916,11 @@ struct Cycle {
             // x += e, e = P x_c kept in the direction vector -- as floats where the smoothing products read theirs as floats --
             // and the residual the post-smoothing starts from is the restricted one minus A e
             const DeviceMatrix &A = L.smooth_ready ? L.smooth_dm : amg_level_matrix(c, l);
-            const bool e32 = A.symmetric && A.vals32 != nullptr && A.vec32 == 2;
+            const bool e32 = A.symmetric && has_lowp(A) && A.vec32 == 2;
             launch_spmv_axpy_keep(L.P.dm, N.x.p, x, x, 1.0, L.d.p, e32, gate, st);
-            const double *r2 = residual_minus_product(l, rf, L.d.p);
-            smooth(l, b, x, false, r2);
+            double *d_started = nullptr;
+            const double *r2 = residual_minus_product(l, rf, L.d.p, x, &d_started);
+            smooth(l, b, x, false, r2, d_started);
             return;
         }
         launch_spmv_axpy(L.P.dm, N.x.p, x, x, 1.0, gate, st); // x += P x_c
@@ -937,9 +988,12 @@ struct AmgPoll {
 
 } // namespace
 
-int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate)
+double *amg_apply_iterate(femshell_ctx *c, double *z) { return c->amg->dist ? c->amg->dist->x0.p : z; }
+
+int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate, bool pre_started)
 {
     Cycle cy{c, *c->amg, gate, c->stream};
+    cy.pre_started0 = pre_started;
     if (c->amg->dist) {
         // the iterate of level 0 is an input of the halo product: it needs ghost space, which the CG's z does not have
         double *x = c->amg->dist->x0.p;
@@ -1034,17 +1088,26 @@ int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, do
         AmgPoll poll;
         poll.next_check = it + 1;
         bool finished = false;
+        // FEMSHELL_AMG_FUSE bit 0: the update kernel also finishes q = K p (second phase of the symmetric-storage product) and
+        // takes the first step of the cycle's pre-smoothing on the new residual (k_pcg_update_start: three passes become one)
+        AmgLevel &L0 = *c->amg->levels[0];
+        const bool fused_update = (fuse_mask() & 1) != 0 && c->amg->levels.size() > 1;
+        const DeviceMatrix &S0 = L0.smooth_ready ? L0.smooth_dm : m;
+        const bool d32_0 = S0.symmetric && has_lowp(S0) && S0.vec32 == 2;
         for (; it < max_it; it++) {
             int n_partials = 0;
-            if (c->comm.active()) rc = spmv_with_halo(c, v, v.p, v.q, v.partials, &n_partials, false);
+            const bool defer = fused_update && m.symmetric != 0;
+            if (c->comm.active()) rc = spmv_with_halo(c, v, v.p, v.q, v.partials, &n_partials, defer);
+            else if (defer) launch_spmv_direct(m, v.p, v.q, v.partials, v.s, st);
             else launch_spmv(m, v.p, v.q, v.partials, v.s, st);
             if (rc) return rc;
             rc = scalar_step(c, v, 1, CG_PHASE_ALPHA, rtol, n_partials);
             if (rc) return rc;
-            launch_pcg_update(m, v, st);
+            if (fused_update) launch_pcg_update_start(S0, v, L0.d.p, amg_apply_iterate(c, v.z), L0.inv_theta, defer, d32_0, st);
+            else launch_pcg_update(m, v, st);
             rc = scalar_step(c, v, 1, CG_PHASE_FLEX_CONV, rtol);
             if (rc) return rc;
-            rc = amg_apply(c, v.r, v.z, v.s);
+            rc = amg_apply(c, v.r, v.z, v.s, fused_update);
             if (rc) return rc;
             launch_pcg_dots(m, v, st);
             rc = scalar_step(c, v, 2, CG_PHASE_FLEX_BETA, rtol);

@@ -409,6 +409,7 @@ int femshell_create(const femshell_config *cfg, femshell_ctx **out)
     femshell_ctx *c = new femshell_ctx();
     c->cfg = *cfg;
     c->device = dev;
+    plan_progress_hook = &CommWatch::heartbeat; // (the phases of the symbolic plan are progress in the eyes of the watchdog)
     hipError_t e = hipSetDevice(dev);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);

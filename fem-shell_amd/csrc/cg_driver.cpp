@@ -37,11 +37,12 @@ int spmv_with_halo(femshell_ctx *c, const CgVectors &v, double *xin, double *you
     defer_gather = defer_gather && c->dm.symmetric;
     DeviceMatrix dm = c->dm;
     dm.vals32 = (defer_gather && c->dm.symmetric) ? vals32 : nullptr; // (the single-precision copy serves the symmetric first phase)
-    dm.vec32 = dm.vals32 != nullptr ? vec32 : 0; // (what such a product keeps in single precision besides: DeviceMatrix::vec32)
+    const bool lowp = dm.vals32 != nullptr;
+    dm.vec32 = lowp ? vec32 : 0; // (what such a product keeps in single precision besides: DeviceMatrix::vec32)
     if (!c->halo_overlap) {
         int rc = halo_exchange(c, xin, st);
         if (rc) return rc;
-        if (defer_gather) launch_spmv_direct(dm, xin, yout, partials, v.s, st, dm.vals32 != nullptr);
+        if (defer_gather) launch_spmv_direct(dm, xin, yout, partials, v.s, st, lowp);
         else launch_spmv(c->dm, xin, yout, partials, v.s, st);
         return FEMSHELL_OK;
     }

@@ -88,66 +88,94 @@ bool check(ncclResult_t r, const char *what, std::string *err)
 } // namespace
 
 // ---- watchdog (comm.hpp) ---------------------------------------------------------------------------------------
+// Every live CommWatch is an entry of a registry the monitor thread walks: contexts on different threads have their own
+// phases and timers (distinct contexts are thread-safe, include/femshell.h).  The time limit is read once, by the thread that
+// opens the watch -- the monitor thread never calls getenv, which would race with a host that changes its environment.
 namespace {
-
-std::atomic<const char *> g_watch_phase{nullptr};
-std::atomic<int64_t> g_watch_since_ms{0};
-std::atomic<int> g_watch_rank{0}, g_watch_world{1};
-std::once_flag g_watch_once;
 
 int64_t now_ms()
 {
     return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-double watch_timeout_s()
-{
-    const char *e = getenv("FEMSHELL_COMM_TIMEOUT"); // read per check: tests shorten it inside one process
-    return e ? atof(e) : 120.0;
-}
+struct WatchEntry {
+    const char *phase = nullptr;
+    int rank = 0, world = 1;
+    double limit_s = 0.0;
+    std::atomic<int64_t> since_ms{0};
+    WatchEntry *parent = nullptr; // the watch that was open on this thread when this one began
+};
+
+std::mutex g_watch_mutex;
+std::vector<WatchEntry *> g_watch_live;
+std::once_flag g_watch_once;
+thread_local WatchEntry *t_watch_top = nullptr; // innermost watch of the calling thread
 
 void watch_loop()
 {
     for (;;) {
         std::this_thread::sleep_for(std::chrono::milliseconds(200));
-        const char *phase = g_watch_phase.load(std::memory_order_acquire);
-        const double limit = watch_timeout_s();
-        if (phase == nullptr || !(limit > 0.0)) continue;
-        const double waited = 1e-3 * (double)(now_ms() - g_watch_since_ms.load(std::memory_order_acquire));
-        if (waited < limit) continue;
-        fprintf(stderr,
-                "[femshell watchdog] rank %d of %d: no progress for %.0f s in \"%s\" -- a peer rank never joined or stalled in a "
-                "collective.  Exiting with status 86 so that the launcher ends the rank group.  To look further: NCCL_DEBUG=WARN for "
-                "RCCL's own diagnostics, FEMSHELL_HALO_OVERLAP=0 to take the halo exchange off its second stream, "
-                "FEMSHELL_COMM_TIMEOUT=<seconds> (0 = wait forever).\n",
-                g_watch_rank.load(), g_watch_world.load(), waited, phase);
-        fflush(stderr);
-        _exit(86);
+        const int64_t now = now_ms();
+        std::lock_guard<std::mutex> lock(g_watch_mutex);
+        for (const WatchEntry *w : g_watch_live) {
+            if (!(w->limit_s > 0.0)) continue;
+            const double waited = 1e-3 * (double)(now - w->since_ms.load(std::memory_order_acquire));
+            if (waited < w->limit_s) continue;
+            fprintf(stderr,
+                    "[femshell watchdog] rank %d of %d: no progress for %.0f s in \"%s\" -- a peer rank never joined or stalled in a "
+                    "collective.  Exiting with status 86 so that the launcher ends the rank group.  To look further: NCCL_DEBUG=WARN for "
+                    "RCCL's own diagnostics, FEMSHELL_HALO_OVERLAP=0 to take the halo exchange off its second stream, "
+                    "FEMSHELL_COMM_TIMEOUT=<seconds> (0 = wait forever).\n",
+                    w->rank, w->world, waited, w->phase);
+            fflush(stderr);
+            _exit(86);
+        }
     }
 }
 
 } // namespace
 
-CommWatch::CommWatch(int rank, int world, const char *phase) : prev_phase_(nullptr), active_(world > 1 || phase == nullptr)
+CommWatch::CommWatch(int rank, int world, const char *phase) : entry_(nullptr)
 {
-    active_ = world > 1;
-    if (!active_) return;
+    if (world <= 1) return;
+    const char *e = getenv("FEMSHELL_COMM_TIMEOUT"); // once per watch, on the caller's thread (tests shorten it between calls)
+    WatchEntry *w = new WatchEntry();
+    w->phase = phase;
+    w->rank = rank;
+    w->world = world;
+    w->limit_s = e ? atof(e) : 120.0;
+    w->since_ms.store(now_ms(), std::memory_order_release);
+    w->parent = t_watch_top;
+    t_watch_top = w;
+    entry_ = w;
     std::call_once(g_watch_once, [] { std::thread(watch_loop).detach(); });
-    g_watch_rank.store(rank);
-    g_watch_world.store(world);
-    prev_phase_ = g_watch_phase.load(std::memory_order_acquire);
-    g_watch_since_ms.store(now_ms(), std::memory_order_release);
-    g_watch_phase.store(phase, std::memory_order_release);
+    std::lock_guard<std::mutex> lock(g_watch_mutex);
+    g_watch_live.push_back(w);
 }
 
 CommWatch::~CommWatch()
 {
-    if (!active_) return;
-    g_watch_since_ms.store(now_ms(), std::memory_order_release); // (the outer phase starts over)
-    g_watch_phase.store(prev_phase_, std::memory_order_release);
+    WatchEntry *w = static_cast<WatchEntry *>(entry_);
+    if (w == nullptr) return;
+    {
+        std::lock_guard<std::mutex> lock(g_watch_mutex);
+        for (size_t i = 0; i < g_watch_live.size(); i++)
+            if (g_watch_live[i] == w) {
+                g_watch_live.erase(g_watch_live.begin() + (long)i);
+                break;
+            }
+    }
+    t_watch_top = w->parent;
+    delete w;
+    heartbeat(); // (the outer phases of this thread start over)
 }
 
-void CommWatch::heartbeat() { g_watch_since_ms.store(now_ms(), std::memory_order_release); }
+// progress inside a phase: every watch open on the calling thread counts from here again
+void CommWatch::heartbeat()
+{
+    const int64_t now = now_ms();
+    for (WatchEntry *w = t_watch_top; w != nullptr; w = w->parent) w->since_ms.store(now, std::memory_order_release);
+}
 
 bool comm_unique_id(uint8_t id_out[128], std::string *err)
 {

@@ -32,7 +32,9 @@ struct Comm {
 // cancelled.  The library's blocking phases are therefore watched: while a CommWatch is alive a monitor thread ends the
 // PROCESS (exit status 86, one line on stderr naming rank, phase and what to try) once the phase has made no progress for
 // FEMSHELL_COMM_TIMEOUT seconds (default 120; 0 switches the watch off).  A launcher that sees one rank exit tears the
-// group down; nothing is ever re-executed.  heartbeat(): progress inside a long phase (the CG loop's polls).
+// group down; nothing is ever re-executed.  heartbeat(): progress inside a long phase (the CG loops' polls, the laps of the
+// symbolic phase and of the multigrid setup, every host-side agreement of the ranks).  Watches are per thread: contexts on
+// different threads have their own phases and timers, and the time limit is read once when a watch opens, by its own thread.
 struct CommWatch {
     CommWatch(int rank, int world, const char *phase);
     ~CommWatch();
@@ -41,8 +43,7 @@ struct CommWatch {
     static void heartbeat();
 
   private:
-    const char *prev_phase_;
-    bool active_;
+    void *entry_; // this watch's slot in the registry the monitor thread walks (nullptr: single-rank context, nothing to watch)
 };
 
 bool comm_unique_id(uint8_t id_out[128], std::string *err);

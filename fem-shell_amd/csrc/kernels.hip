@@ -366,6 +366,9 @@ struct ChebEpilogue {
     // launch_spmv_axpy_keep: the product itself, K x without the base vector, is stored as well (as floats: prod_float)
     double *prod_out = nullptr;
     int prod_float = 0;
+    // the FIRST step of a smoothing instead of a later one: d_out = c D^-1 r_out (no previous direction: d_in is the vector the
+    // product multiplied, not a direction), x += d_out -- or x = d_out from a zero guess (start == 2)
+    int start = 0;
 };
 
 template <int kChunk, bool kF32 = false>
@@ -439,16 +442,24 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
 #pragma unroll
                 for (int j = 0; j < 6; j++) mrow[j] = mi[minv_word(i < j ? i : j, i < j ? j : i) * kSliceNodes];
             }
-            const double dv = x[row], xv = cheb.xsol[row];
+            const double dv = cheb.start ? 0.0 : x[row], xv = cheb.start == 2 ? 0.0 : cheb.xsol[row];
             __syncthreads();
             rs[n * 6 + i] = yv;
             __syncthreads();
             double z = 0.0;
 #pragma unroll
             for (int j = 0; j < 6; j++) z += mrow[j] * rs[n * 6 + j];
-            const double dn = cheb.a * dv + cheb.c * z;
-            cheb.d_out[row] = dn;
-            cheb.xsol[row] = xv + dn;
+            if (cheb.start) {
+                // (the expression of k_cheb_start, so that the compiler contracts it the same way -- x = fma(c, z, x) -- and the
+                //  fused start gives the bits of the separate pass)
+                const double dn = cheb.c * z;
+                cheb.d_out[row] = dn;
+                cheb.xsol[row] = xv + dn;
+            } else {
+                const double dn = cheb.a * dv + cheb.c * z;
+                cheb.d_out[row] = dn;
+                cheb.xsol[row] = xv + dn;
+            }
         }
         if (partials != nullptr) dotv += acc * (((t >> 5) & 1) ? xw.y : xw.x);
     }
@@ -485,24 +496,28 @@ template <bool kF32> __device__ __forceinline__ v2d load_word(const double2 *v, 
     return __builtin_nontemporal_load(reinterpret_cast<const v2d *>(v) + off);
 }
 
-// kF32: the blocks come from m.vals32 (single precision, same layout), the arithmetic stays FP64
-// kVec (with kF32 only; DeviceMatrix::vec32): 1 = y and the transposed products are stored as floats, 2 = x is read as floats too
+// the 18 words (jp, i) of block slot k: wd[jp * 6 + i] = columns 2jp, 2jp+1 of row i.  diag: only the words of the upper triangle
+// are needed (slot 0 of a symmetric-storage row); the others stay unset
+// kVal: 0 = FP64 values, 1 = the float copy (m.vals32)
+template <int kVal, bool kDiag>
+__device__ __forceinline__ void load_block_words(const double2 *v, const float2 *v32, int k, v2d wd[18])
+{
+#pragma unroll
+    for (int e = 0; e < 18; e++)
+        if (!kDiag || 2 * (e / 6) + 1 >= e % 6) wd[e] = load_word<(kVal == 1)>(v, v32, ((size_t)k * 18 + e) * kSliceNodes);
+}
+
+// kVal: the blocks come from m.vals (0) or from m.vals32 (1: single precision, same layout); the arithmetic stays FP64
+// (A bfloat16 copy -- 72 B per block -- was built and measured in round 5 and is gone again: the smoother's copy needs about 20
+//  significant bits.  The residuals a cycle restricts are increments of products with that copy, and an error of 2^-8 ||A|| ||d||
+//  in them is amplified by the coarse solves: the 4M-triangle panel did not converge at all, and the float copy rounded to 18 / 17 /
+//  16 bits takes 129 / 186 / 394 iterations on the cylinder instead of 97: profiles/r05_smoother_significant_bits.txt,
+//  FEMSHELL_AMG_SMOOTH_SIGBITS.)
+// kVec (with kVal >= 1 only; DeviceMatrix::vec32): 1 = y and the transposed products are stored as floats, 2 = x is read as floats too
 // (The float-storing variants compile to 182-194 registers, two waves per SIMD where the FP64 product has three.  MEASURED, round
 //  4: held to three waves -- amdgpu_waves_per_eu(3, 3), 168 registers, five dwords spilled -- the 4M solves take the same time
 //  within the run-to-run scatter of 1 %: profiles/r04_spmv_sym_waves_ab.txt, four alternating rounds.  Left to the compiler.)
-__device__ __forceinline__ void load_node6(const double *x, int64_t node, bool as_float, double out[6])
-{
-    if (as_float) {
-        const float2 *xf = reinterpret_cast<const float2 *>(x) + 3 * node;
-        const float2 a0 = xf[0], a1 = xf[1], a2 = xf[2];
-        out[0] = a0.x; out[1] = a0.y; out[2] = a1.x; out[3] = a1.y; out[4] = a2.x; out[5] = a2.y;
-    } else {
-        const double2 *xd = reinterpret_cast<const double2 *>(x) + 3 * node;
-        const double2 a0 = xd[0], a1 = xd[1], a2 = xd[2];
-        out[0] = a0.x; out[1] = a0.y; out[2] = a1.x; out[3] = a1.y; out[4] = a2.x; out[5] = a2.y;
-    }
-}
-template <bool kF32, int kVec>
+template <int kVal, int kVec>
 __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *__restrict__ x, double *__restrict__ y,
                                                  double *__restrict__ partials, const CgScalars *s,
                                                  const int32_t *__restrict__ order, int count)
@@ -526,7 +541,7 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
 #pragma unroll
         for (int i = 0; i < 6; i++) ya[i] = 0.0;
         const double2 *v = reinterpret_cast<const double2 *>(m.vals + base * 36) + n;
-        const float2 *v32 = kF32 ? reinterpret_cast<const float2 *>(m.vals32 + base * 36) + n : nullptr;
+        const float2 *v32 = kVal == 1 ? reinterpret_cast<const float2 *>(m.vals32 + base * 36) + n : nullptr;
         double2 *tb = reinterpret_cast<double2 *>(m.tbuf + base * 6);
         float2 *tbf = reinterpret_cast<float2 *>(m.tbuf) + base * 3; // (kVec >= 1: float (slot * 6 + j) of the same buffer)
         const uint8_t *li = has_local ? m.loc_index + base + n : nullptr;
@@ -536,9 +551,7 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
             // element (i, j) below the diagonal is taken from (j, i).  Same order of the sum over j as in the loop
             // below, so a block whose halves mirror each other exactly (k_assemble's do) gives the same bits.
             v2d wd[18];
-#pragma unroll
-            for (int e = 0; e < 18; e++)
-                if (2 * (e / 6) + 1 >= e % 6) wd[e] = load_word<kF32>(v, v32, e * kSliceNodes);
+            load_block_words<kVal, true>(v, v32, 0, wd);
 #pragma unroll
             for (int i = 0; i < 6; i++)
 #pragma unroll
@@ -551,8 +564,7 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
         for (int k = 1; k < W; k++) {
             const int c = m.cols[base + (int64_t)k * kSliceNodes + n];
             v2d wd[18];
-#pragma unroll
-            for (int e = 0; e < 18; e++) wd[e] = load_word<kF32>(v, v32, ((size_t)k * 18 + e) * kSliceNodes); // word (jp = e/6, i = e%6)
+            load_block_words<kVal, false>(v, v32, k, wd); // word (jp = e/6, i = e%6)
             double xc[6];
             load_node6(x, c, kVec == 2, xc);
             double u[6];
@@ -664,11 +676,11 @@ static void spmv_sym_phase1(const DeviceMatrix &m, const double *x, double *y, d
 {
     const size_t lds = m.loc_index != nullptr ? (size_t)2 * m.max_loc * 48 : 0;
     if (f32 && m.vals32 != nullptr) {
-        if (m.vec32 == 2) hipLaunchKernelGGL((k_spmv_sym<true, 2>), dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
-        else if (m.vec32 == 1) hipLaunchKernelGGL((k_spmv_sym<true, 1>), dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
-        else hipLaunchKernelGGL((k_spmv_sym<true, 0>), dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
+        if (m.vec32 == 2) hipLaunchKernelGGL((k_spmv_sym<1, 2>), dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
+        else if (m.vec32 == 1) hipLaunchKernelGGL((k_spmv_sym<1, 1>), dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
+        else hipLaunchKernelGGL((k_spmv_sym<1, 0>), dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
     } else {
-        hipLaunchKernelGGL((k_spmv_sym<false, 0>), dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
+        hipLaunchKernelGGL((k_spmv_sym<0, 0>), dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
     }
 }
 
@@ -682,10 +694,68 @@ void launch_to_f32(const double *src, float *dst, int64_t n, hipStream_t st)
     if (n > 0) hipLaunchKernelGGL(k_to_f32, dim3(4096), dim3(256), 0, st, src, dst, n);
 }
 
+// experiment knob (FEMSHELL_AMG_SMOOTH_SIGBITS): the float copy rounded to `sig` significant bits in place (round to nearest even on
+// the bit pattern) -- how many bits does the smoother's copy of a level operator need?
+__global__ __launch_bounds__(256) void k_round_sig(float *__restrict__ v, int64_t n, int sig)
+{
+    const int drop = 24 - sig;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint32_t b = __float_as_uint(v[i]);
+        const uint32_t half = (1u << (drop - 1)) - 1u;
+        v[i] = __uint_as_float(((b + half + ((b >> drop) & 1u)) >> drop) << drop);
+    }
+}
+void launch_round_sig(float *v, int64_t n, int sig, hipStream_t st)
+{
+    if (n > 0 && sig > 0 && sig < 24) hipLaunchKernelGGL(k_round_sig, dim3(4096), dim3(256), 0, st, v, n, sig);
+}
+
+// one lane per node (device_common.hpp; FEMSHELL_NODE_KERNELS=0: the kernels above)
+static bool node_kernels_on()
+{
+    static const bool on = [] {
+        const char *e = getenv("FEMSHELL_NODE_KERNELS");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+static int node_grid_of(const DeviceMatrix &m)
+{
+    const int g = 8 * ((node_pairs(m.n_slices) + 7) / 8), cap = slice_grid(m);
+    return g < cap ? g : cap;
+}
+
+template <bool kQ32>
+__global__ __launch_bounds__(64) void k_sym_gather_node(DeviceMatrix m, const double *y, double *out, const double *base_vec, double sign,
+                                                        const CgScalars *s)
+{
+    if (s != nullptr && s->done != 0) return;
+    const int half = threadIdx.x >> 5, n = threadIdx.x & 31;
+    for (SliceWalk w(node_pairs(m.n_slices)); w.valid(); w.next()) {
+        const int sl = 2 * w.s + half;
+        if (sl >= m.n_slices) continue;
+        const int64_t node = (int64_t)sl * kSliceNodes + n;
+        double acc[6], bv[6];
+        load_node6(y, node, kQ32, acc);
+        if (base_vec != nullptr) load_node6(base_vec, node, false, bv);
+        node_gather<kQ32>(m, sl, n, acc);
+        if (base_vec != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) acc[j] = bv[j] + sign * acc[j];
+        }
+        store_node6(out, node, false, acc);
+    }
+}
+
 void launch_sym_gather(const DeviceMatrix &m, double *y, const double *base_vec, double sign, const CgScalars *s, hipStream_t st,
                        bool q32, double *out)
 {
     if (out == nullptr) out = y;
+    if (node_kernels_on()) {
+        if (q32) hipLaunchKernelGGL(k_sym_gather_node<true>, dim3(node_grid_of(m)), dim3(64), 0, st, m, y, out, base_vec, sign, s);
+        else hipLaunchKernelGGL(k_sym_gather_node<false>, dim3(node_grid_of(m)), dim3(64), 0, st, m, y, out, base_vec, sign, s);
+        return;
+    }
     if (q32) hipLaunchKernelGGL(k_sym_gather<true>, dim3(slice_grid(m)), dim3(192), 0, st, m, y, out, base_vec, sign, s);
     else hipLaunchKernelGGL(k_sym_gather<false>, dim3(slice_grid(m)), dim3(192), 0, st, m, y, out, base_vec, sign, s);
 }
@@ -885,6 +955,17 @@ void launch_spmv_cheb(const DeviceMatrix &m, const double *d_in, const double *r
     spmv_dispatch(m, d_in, r_out, nullptr, s, nullptr, m.n_slices, slice_grid(m), st, r_in, -1.0, e);
 }
 
+void launch_spmv_start(const DeviceMatrix &m, const double *v_in, const double *r_in, double *r_out, double *d_out, double *x,
+                       double inv_theta, const CgScalars *s, hipStream_t st)
+{
+    ChebEpilogue e;
+    e.d_out = d_out;
+    e.xsol = x;
+    e.c = inv_theta;
+    e.start = 1;
+    spmv_dispatch(m, v_in, r_out, nullptr, s, nullptr, m.n_slices, slice_grid(m), st, r_in, -1.0, e);
+}
+
 void launch_spmv_axpy(const DeviceMatrix &m, const double *x, double *y, const double *base_vec, double sign,
                       const CgScalars *s, hipStream_t st)
 {
@@ -1035,8 +1116,55 @@ __global__ __launch_bounds__(192) void k_cg_update(DeviceMatrix m, CgVectors v)
     }
 }
 
+// the same with one lane per node: no LDS, no barrier (launched with the grid of the per-slice kernels: the scalar step
+// reduces slice_grid(m) partial sums per array)
+template <bool kGather>
+__global__ __launch_bounds__(64) void k_cg_update_node(DeviceMatrix m, CgVectors v)
+{
+    if (v.s->done != 0) return;
+    const int G = gridDim.x, half = threadIdx.x >> 5, n = threadIdx.x & 31;
+    const double alpha = v.s->alpha;
+    double d0 = 0.0, d1 = 0.0;
+    for (SliceWalk w(node_pairs(m.n_slices)); w.valid(); w.next()) {
+        const int sl = 2 * w.s + half;
+        if (sl >= m.n_slices) continue;
+        const int64_t node = (int64_t)sl * kSliceNodes + n;
+        double mv[kMinvWords], pv[6], xv[6], rv[6], qv[6], z[6];
+        node_minv(m, sl, n, false, mv);
+        load_node6(v.p, node, false, pv);
+        load_node6(v.x, node, false, xv);
+        load_node6(v.r, node, false, rv);
+        load_node6(v.q, node, false, qv);
+        if (kGather) node_gather<false>(m, sl, n, qv);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            xv[j] = xv[j] + alpha * pv[j];
+            rv[j] = rv[j] - alpha * qv[j];
+        }
+        store_node6(v.x, node, false, xv);
+        store_node6(v.r, node, false, rv);
+        node_minv_apply(mv, rv, z);
+        store_node6(v.z, node, false, z);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            d0 += rv[j] * z[j];
+            d1 += rv[j] * rv[j];
+        }
+    }
+    const double t0 = wave_sum(d0), t1 = wave_sum(d1);
+    if (threadIdx.x == 0) {
+        v.partials[blockIdx.x] = t0;
+        v.partials[G + blockIdx.x] = t1;
+    }
+}
+
 void launch_cg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st, bool gather)
 {
+    if (node_kernels_on()) {
+        if (gather) hipLaunchKernelGGL(k_cg_update_node<true>, dim3(slice_grid(m)), dim3(64), 0, st, m, v);
+        else hipLaunchKernelGGL(k_cg_update_node<false>, dim3(slice_grid(m)), dim3(64), 0, st, m, v);
+        return;
+    }
     if (gather) hipLaunchKernelGGL(k_cg_update<true>, dim3(slice_grid(m)), dim3(192), 0, st, m, v);
     else hipLaunchKernelGGL(k_cg_update<false>, dim3(slice_grid(m)), dim3(192), 0, st, m, v);
 }

@@ -176,6 +176,10 @@ void launch_spmv(const DeviceMatrix &m, const double *x, double *y, double *part
 // d_out must not be d_in (other workgroups still read d_in); r_out may be r_in.
 void launch_spmv_cheb(const DeviceMatrix &m, const double *d_in, const double *r_in, double *r_out, double *d_out, double *x,
                       double a, double c, const CgScalars *s, hipStream_t st);
+// The residual in front of a post-smoothing and the smoothing's FIRST step in one launch (full storage): r_out = r_in - A v_in;
+// d_out = inv_theta D^-1 r_out; x += d_out  (d_out must not be v_in; r_out may be r_in)
+void launch_spmv_start(const DeviceMatrix &m, const double *v_in, const double *r_in, double *r_out, double *d_out, double *x,
+                       double inv_theta, const CgScalars *s, hipStream_t st);
 void launch_spmv_axpy(const DeviceMatrix &m, const double *x, double *y, const double *base_vec, double sign,
                       const CgScalars *s, hipStream_t st);
 // full storage only: the same, and the product itself (K x, without the base vector) into prod_out -- as floats in that buffer
@@ -209,6 +213,9 @@ void launch_spmv_direct(const DeviceMatrix &m, const double *x, double *y, doubl
                         bool single_precision_values = false);
 // dst = (float)src
 void launch_to_f32(const double *src, float *dst, int64_t n, hipStream_t st);
+// v rounded to `sig` (< 24) significant bits in place: FEMSHELL_AMG_SMOOTH_SIGBITS, an experiment knob
+void launch_round_sig(float *v, int64_t n, int sig, hipStream_t st);
+
 void launch_cg_direction(const DeviceMatrix &m, const CgVectors &v, hipStream_t st); // p = z + beta p
 // single-workgroup scalar step: optional reduction of `nsums` partial arrays into s->red, then the
 // scalar update of `phase` (rtol only used by CG_PHASE_INIT)

@@ -16,6 +16,9 @@
 
 namespace femshell {
 
+void (*plan_progress_hook)() = nullptr;
+
+
 namespace {
 constexpr std::size_t kHugeAlign = (std::size_t)2 << 20, kHugeFrom = (std::size_t)4 << 20;
 }
@@ -329,6 +332,7 @@ bool build_plan(int32_t n_nodes, const double *xyz, int32_t n_tri, const int32_t
     auto t_lap = std::chrono::steady_clock::now();
     const char *open_phase = "input checks";
     auto lap = [&](const char *what) {
+        if (plan_progress_hook != nullptr) plan_progress_hook(); // (the watchdog of a multi-rank context counts from here again)
         if (!verbose) return;
         const auto t = std::chrono::steady_clock::now();
         fprintf(stderr, "[femshell plan] %-44s %.3f s\n", open_phase, std::chrono::duration<double>(t - t_lap).count());

@@ -29,6 +29,12 @@
 
 namespace femshell {
 
+// called between the phases of build_plan when set: libfemshell points it at CommWatch::heartbeat (comm.hpp), so that a long
+// symbolic phase on a large mesh or a busy host is progress in the eyes of the watchdog of a multi-rank context; the host-only
+// sanitizer builds leave it null
+extern void (*plan_progress_hook)();
+
+
 // The large arrays of a plan (hundreds of MB at 4M triangles): resize() leaves new elements uninitialised instead of
 // zero-filling them on the calling thread, so that the host threads that write an array are also the ones that take its
 // page faults.  Every element is written before it is read (fills where a value is needed are explicit and parallel).

@@ -38,7 +38,10 @@ struct TextFile {
             const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
             p = nl ? nl + 1 : e;
         }
-        starts.push_back(buf.size() + 1); // (as if a newline ended the last line)
+        // one past the newline of the last line: behind the buffer when the file does not end with one (as if it did).  A file
+        // that DOES end with a newline must not get the extra position: its last line would keep the newline character, and a
+        // libMesh >= 0.9.2 file with a blank line behind the boundary-condition section then failed with "bad nodeset count"
+        starts.push_back(buf.size() + (buf.empty() || buf.back() != '\n' ? 1 : 0));
     }
     size_t n_lines() const { return starts.size() - 1; }
     // line i without its newline and without a trailing comment
@@ -180,7 +183,7 @@ ShellMesh read_xda(const std::string &path)
                                      " of an element with " + std::to_string(m.element_nodes(bc.elem).size()) + " sides");
         m.bcs.push_back(bc);
     }
-    if (header.rfind("libMesh-0.9.2+", 0) == 0 && pos < F.n_lines() && F.line_text(pos).find_first_not_of(" \t\r") != std::string::npos) {
+    if (header.rfind("libMesh-0.9.2+", 0) == 0 && pos < F.n_lines() && F.line_text(pos).find_first_not_of(" \t\r\n") != std::string::npos) {
         const long n_ns = count_of(F.line_text(pos++), "nodeset count"); // nodesets: (node, boundary id)
         for (long b = 0; b < n_ns && pos < F.n_lines(); b++, pos++) {
             F.line(pos, &c.p, &c.e);

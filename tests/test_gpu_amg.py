@@ -136,6 +136,32 @@ def test_single_precision_smoothing_products_leave_the_solution_alone(monkeypatc
         fs.close()
 
 
+@pytest.mark.parametrize("f32,vec", [("0", "0"), ("3", "2"), ("3", "1"), ("1", "2")])
+def test_fused_smoother_starts_give_the_same_bits_as_the_separate_passes(monkeypatch, f32, vec):
+    """FEMSHELL_AMG_FUSE (csrc/amg_solve.cpp): the first step of every Chebyshev smoothing runs in the epilogue of the kernel
+    that produces its residual -- k_pcg_update_start on level 0 (bit 0), k_sym_gather_start in front of the post-smoothing of a
+    symmetric-storage level (bit 1), the epilogue of k_spmv on a full-storage level (bit 2) -- instead of a k_cheb_start pass
+    of its own.  The first two repeat the expressions of the kernels they replace: solution and iteration count are those of
+    the unfused sequence bit for bit, on FP64 levels and on levels with single-precision copies.  The epilogue of k_spmv rounds
+    x + c z differently from k_cheb_start (a contracted multiply-add): same iterations, solution equal to rounding."""
+    m, mat = _make("roof", 64)
+    monkeypatch.setenv("FEMSHELL_AMG_SMOOTH_F32", f32)
+    monkeypatch.setenv("FEMSHELL_AMG_VEC_F32", vec)
+    got = {}
+    for fuse in ("0", "3", "-1"):
+        monkeypatch.setenv("FEMSHELL_AMG_FUSE", fuse)
+        fs = _context(m, mat)
+        fs.set_preconditioner("amg", coarsest_nodes=60)
+        u, info = fs.solve(rtol=1e-12, max_it=500)
+        assert info["converged"] == 1 and info["amg_levels"] >= 3
+        got[fuse] = (u, info["iterations"])
+        fs.close()
+    assert got["0"][1] == got["3"][1]
+    np.testing.assert_array_equal(got["0"][0], got["3"][0])
+    assert abs(got["0"][1] - got["-1"][1]) <= 1
+    assert np.linalg.norm(got["0"][0] - got["-1"][0]) <= 1e-11 * np.linalg.norm(got["0"][0])
+
+
 def test_inspection_copies_of_the_hierarchy_are_kept_for_small_problems_only(monkeypatch):
     # femshell_amg_export reads host copies of the level operators that the setup keeps for problems of up to 300,000 blocks
     # of K -- every test above -- or, with FEMSHELL_AMG_KEEP_HOST=1, up to 2,000,000; beyond that the solve does not pay for them
@@ -485,6 +511,28 @@ def test_dense_inverse_on_the_matrix_cores_equals_the_host_inverse(monkeypatch, 
     assert out["device"][2]["dropped_directions"] == 0 and out["device"][2]["mfma_flops_issued"] > 0
     assert abs(out["host"][1] - out["device"][1]) <= (2 if f32 else 1), (out["host"][1], out["device"][1])
     assert np.linalg.norm(out["host"][0] - out["device"][0]) <= 1e-10 * np.linalg.norm(out["host"][0])
+
+
+def test_dense_inverse_runs_again_without_the_look_ahead_when_its_wait_expires(monkeypatch):
+    """The pivot workgroup of the look-ahead waits, bounded, for three workgroups of its own launch (csrc/amg_dense.hip).  On a
+    card shared with other processes that wait can expire: the setup then runs the inverse again with the pivot as a launch
+    of its own instead of failing.  Forced here by a spin limit of zero; same solution as with the look-ahead."""
+    m, mat = _make("panel", 48)
+    sols = {}
+    for spins in (None, "0"):
+        monkeypatch.setenv("FEMSHELL_AMG_DENSE_DEVICE_MIN", "0")
+        if spins is None:
+            monkeypatch.delenv("FEMSHELL_AMG_DENSE_LOOKAHEAD_SPINS", raising=False)
+        else:
+            monkeypatch.setenv("FEMSHELL_AMG_DENSE_LOOKAHEAD_SPINS", spins)
+        fs = _context(m, mat)
+        fs.set_preconditioner("amg", coarsest_nodes=300)
+        u, info = fs.solve(rtol=1e-12, max_it=500)
+        assert info["converged"] == 1 and fs.amg_dense_stats()["n"] > 1200
+        sols[spins] = (u, info["iterations"])
+        fs.close()
+    assert sols[None][1] == sols["0"][1]
+    np.testing.assert_array_equal(sols[None][0], sols["0"][0])
 
 
 def test_dense_inverse_on_the_matrix_cores_drops_semi_definite_directions(monkeypatch):

@@ -332,6 +332,19 @@ def test_ascii_xda_reader_takes_what_a_stream_would_take(tools, tmp_path):
         np.testing.assert_array_equal(m.xyz, want_xyz)
         np.testing.assert_array_equal(m.tri, [[0, 1, 2], [1, 3, 2]])
         assert m.bcs == [(0, 0, 1), (1, 1, 0)]
+    # a libMesh >= 0.9.2 file: blank lines behind the boundary-condition section (with and without a newline at the very end of
+    # the file) are not a nodeset record; a real nodeset record behind them is read
+    new_header = text.replace("libMesh-0.7.0+", "libMesh-0.9.2+")
+    for name, tail, want_nodesets in (("blank_nl", "\n", 0), ("blank_nl_nl", "\n\n", 0), ("blank_no_nl", "\n  ", 0), ("none", "", 0),
+                                      ("nodeset", "1 # nodesets\n3 21\n", 1), ("nodeset_blank", "1\n3 21\n\n", 1)):
+        src = tmp_path / (name + ".xda")
+        src.write_bytes((new_header + tail).encode())
+        out = str(tmp_path / (name + "_out.xda"))
+        subprocess.check_call([conv, str(src), out])
+        m = meshes.read_xda(out)
+        np.testing.assert_array_equal(m.tri, [[0, 1, 2], [1, 3, 2]])
+        assert m.bcs == [(0, 0, 1), (1, 1, 0)]
+        assert open(out).read().count("nodesets") == want_nodesets, name
     for broken, words in ((text.replace("3   1\t3 2", "3 1 x 2"), "bad element line 1"),
                           (text.replace("1e0 0 0.", "1e0 zero 0."), "bad node line 1"),
                           (text.replace("3 0 1 2 # a triangle", "4 0 1 2"), "unsupported element type 4"),
