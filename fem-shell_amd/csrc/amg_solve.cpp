@@ -708,6 +708,9 @@ bool residual_increment()
     return !(e && atoi(e) == 0);
 }
 
+// does the matrix view carry the single-precision copy of its values for the smoothing products?
+bool has_lowp(const DeviceMatrix &A) { return A.vals32 != nullptr; }
+
 // FEMSHELL_AMG_FUSE (bit mask; A/B runs and tests): the first step of a Chebyshev smoothing runs in the epilogue of the kernel that
 // produces its residual.  1: k_pcg_update_start (the update of the flexible PCG + the second phase of q = K p + the start of the
 // cycle's pre-smoothing on level 0); 2: k_sym_gather_start (second phase of the increment product in front of a post-smoothing,
