@@ -966,9 +966,17 @@ void launch_spmv_start(const DeviceMatrix &m, const double *v_in, const double *
     spmv_dispatch(m, v_in, r_out, nullptr, s, nullptr, m.n_slices, slice_grid(m), st, r_in, -1.0, e);
 }
 
+static bool spmv_node_applies(const DeviceMatrix &m);
+static void launch_spmv_node(const DeviceMatrix &m, const double *x, double *y, const double *base_vec, double sign, double *prod_out,
+                             bool prod_float, const CgScalars *s, hipStream_t st);
+
 void launch_spmv_axpy(const DeviceMatrix &m, const double *x, double *y, const double *base_vec, double sign,
                       const CgScalars *s, hipStream_t st)
 {
+    if (spmv_node_applies(m)) {
+        launch_spmv_node(m, x, y, base_vec, sign, nullptr, false, s, st);
+        return;
+    }
     if (m.symmetric) { // (base_vec must not be y here: phase 1 overwrites y with the direct part)
         spmv_sym_phase1(m, x, y, nullptr, s, nullptr, m.n_slices, slice_grid(m), st);
         launch_sym_gather(m, y, base_vec, sign, s, st);
@@ -977,9 +985,81 @@ void launch_spmv_axpy(const DeviceMatrix &m, const double *x, double *y, const d
     spmv_dispatch(m, x, y, nullptr, s, nullptr, m.n_slices, slice_grid(m), st, base_vec, sign);
 }
 
+// Full-storage product with one lane per NODE row (round 5): y = base_vec + sign * K x for operators with few blocks per row -- the
+// prolongations, 2.5 blocks per fine node.  k_spmv stages the x of a slice's block columns through LDS behind two barriers per
+// slice, which pays for wide rows; with two to four slots a slice is two barriers around a handful of loads, and the prolongation
+// onto level 0 of the 4M-triangle panel moved its 1.14 GB at 3.6 TB/s (312 us).  Here a lane streams the words of its blocks as
+// k_spmv_sym does and reads the six entries of each column node straight from the caches.  Per row the sum runs over the slots
+// in ascending order and inside a block over the columns in ascending order, as in k_spmv: same bits.
+template <bool kF32>
+__global__ __launch_bounds__(64) void k_spmv_node(DeviceMatrix m, const double *__restrict__ x, double *y, const CgScalars *s,
+                                                  const double *base_vec, double sign, double *prod_out, int prod_float)
+{
+    if (s != nullptr && s->done != 0) return;
+    const int half = threadIdx.x >> 5, n = threadIdx.x & 31;
+    for (SliceWalk w(node_pairs(m.n_slices)); w.valid(); w.next()) {
+        const int sl = 2 * w.s + half;
+        if (sl >= m.n_slices) continue;
+        const int64_t base = m.slice_base[sl];
+        const int W = m.slice_width[sl];
+        const int64_t node = (int64_t)sl * kSliceNodes + n;
+        const double2 *v = reinterpret_cast<const double2 *>(m.vals + base * 36) + n;
+        const float2 *v32 = kF32 ? reinterpret_cast<const float2 *>(m.vals32 + base * 36) + n : nullptr;
+        double ya[6], bv[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) ya[i] = 0.0;
+        if (base_vec != nullptr) load_node6(base_vec, node, false, bv);
+        for (int k = 0; k < W; k++) {
+            const int c = m.cols[base + (int64_t)k * kSliceNodes + n];
+            v2d wd[18];
+            load_block_words<(kF32 ? 1 : 0), false>(v, v32, k, wd);
+            double xc[6];
+            load_node6(x, c, false, xc);
+#pragma unroll
+            for (int jp = 0; jp < 3; jp++)
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const v2d kw = wd[jp * 6 + i];
+                    ya[i] += kw.x * xc[2 * jp];
+                    ya[i] += kw.y * xc[2 * jp + 1];
+                }
+        }
+        if (prod_out != nullptr) store_node6(prod_out, node, prod_float != 0, ya);
+        if (base_vec != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) ya[i] = bv[i] + sign * ya[i];
+        }
+        store_node6(y, node, false, ya);
+    }
+}
+
+// rows narrower than this go through k_spmv_node (FEMSHELL_SPMV_NODE_WIDTH; 0 = never)
+static int spmv_node_width()
+{
+    static const int w = [] {
+        const char *e = getenv("FEMSHELL_SPMV_NODE_WIDTH");
+        return e ? atoi(e) : 8;
+    }();
+    return w;
+}
+
+static bool spmv_node_applies(const DeviceMatrix &m) { return !m.symmetric && m.max_slice_width > 0 && m.max_slice_width <= spmv_node_width(); }
+
+static void launch_spmv_node(const DeviceMatrix &m, const double *x, double *y, const double *base_vec, double sign, double *prod_out,
+                             bool prod_float, const CgScalars *s, hipStream_t st)
+{
+    const dim3 g(node_grid_of(m)), b(64);
+    if (m.vals32 != nullptr) hipLaunchKernelGGL(k_spmv_node<true>, g, b, 0, st, m, x, y, s, base_vec, sign, prod_out, prod_float ? 1 : 0);
+    else hipLaunchKernelGGL(k_spmv_node<false>, g, b, 0, st, m, x, y, s, base_vec, sign, prod_out, prod_float ? 1 : 0);
+}
+
 void launch_spmv_axpy_keep(const DeviceMatrix &m, const double *x, double *y, const double *base_vec, double sign, double *prod_out,
                            bool prod_float, const CgScalars *s, hipStream_t st)
 {
+    if (spmv_node_applies(m)) {
+        launch_spmv_node(m, x, y, base_vec, sign, prod_out, prod_float, s, st);
+        return;
+    }
     ChebEpilogue e;
     e.prod_out = prod_out;
     e.prod_float = prod_float ? 1 : 0;
