@@ -36,12 +36,77 @@ def context(request):
 
 def test_full_size_matrix_equals_oracle(context):
     kind, m, mat, fs = context
-    out = fullsize.matrix_parity(fs, m, mat)
+    out = fullsize.matrix_parity(fs, m, mat, products=True, kind=kind)
     assert out["same_pattern"], out
     assert out["blocks"] > 14000000
     assert out["F_bitwise_equal"], out
     assert out["max_entry_diff_over_max_entry"] <= 1e-12, out   # measured: 2e-15
     assert out["frobenius_rel_diff"] <= 1e-13, out
+    # the device's products against the ORACLE's matrix at this size (the manufactured right-hand sides below are products of
+    # the device itself): femshell_spmv against fso_bsr_spmv, femshell_residual (double-double) against longdouble row sums
+    pr = out["products_vs_oracle_matrix"]
+    assert pr["spmv_rel_diff"] <= 1e-12, pr
+    assert pr["residual_dd_sampled_scalar_rows"] >= 200000, pr
+    # against the oracle's blocks: what two correct FP64 assemblies differ by (2e-15 of the largest entry) times u
+    assert pr["residual_dd_vs_oracle_blocks_max_err_over_largest_row_scale"] <= 1e-15, pr
+    assert pr["residual_dd_vs_oracle_blocks_max_err_over_row_scale"] <= 2e-14, pr
+    # against the blocks the device holds, by independent arithmetic (longdouble): one rounding of the double-double sum;
+    # plain FP64 row sums of the same blocks are several times worse
+    assert pr["residual_dd_vs_exported_blocks_max_err_over_row_scale"] <= 1.5e-16, pr
+    assert pr["plain_fp64_row_sums_max_err_over_row_scale"] > 1.5e-16, pr
+
+
+def test_headline_load_case_against_the_reference_held_plate_answer():
+    """The 4M-triangle panel IS the plate of the thesis' tests D and G (10 x 10, t 0.5, E 1e7, nu 0.3, q 300:
+    doc/validation.tex:283-295): w at the centre against Timoshenko's series value the thesis quotes (alpha = 0.00406 ->
+    0.1064045, validation.tex:270), the thesis' own Tri-3 figure at 64 x 64 (0.106413, validation.tex:518) and the full
+    Navier series -- an answer at the headline size that neither the solver's error estimate nor a manufactured right-hand
+    side supplies.  What it shows (profiles/r05_headline_load_case_vs_navier.txt): the discretisation error falls with h^2
+    (-5.0e-4, -1.2e-4, -3.1e-5, -8.9e-6 at 64^2 ... 512^2) and would be 1e-6 at 1414^2 -- where w_c is 1.2e-4 off instead,
+    and moves by as much when the SAME matrix is assembled with other roundings (the mesh translated, renumbered, split along
+    the other diagonal: -2e-5 ... -1.3e-4).  That is kappa(K) x the rounding of K's own FP64 entries -- the sensitivity term of
+    DESIGN section 2, grown with h^-4 to 1e-4 at 4M triangles -- and no solver can remove it (the solver term of these solves
+    is 1e-11).  The reference's assembly rounds the same entries."""
+    ensure_built()
+    navier = fullsize.navier_centre_deflection(300.0, 10.0, 1e7, 0.3, 0.5)
+    assert abs(navier - 0.106466) < 2e-6                  # alpha = 0.00406235
+    dev = {}
+    for n in (64, 128, 256, 512, N_FULL):
+        r = fullsize.panel_centre_deflection(n)
+        assert r["converged"] == 1, r["iterations"]
+        dev[n] = (r["w_centre"] - navier) / navier
+    assert abs(dev[64] * navier + navier - 0.106413) < 5e-7     # the thesis' six digits for Tri-3 at 64 x 64
+    # second-order convergence while the discretisation error dominates
+    for coarse, fine in ((64, 128), (128, 256), (256, 512)):
+        assert dev[coarse] < 0 and 3.3 < dev[coarse] / dev[fine] < 4.5, dev
+    # the headline size: within 1e-3 of the thesis' analytic reference (three-digit alpha), within 3e-4 of the series ...
+    w_full = navier * (1.0 + dev[N_FULL])
+    assert abs(w_full - 0.1064045) < 1e-3 * 0.1064045, dev
+    assert abs(dev[N_FULL]) < 3e-4, dev
+    # ... and what is left is the rounding of K's entries times its condition number: the same plate translated by (3, 7, 0)
+    # -- the same matrix in exact arithmetic -- gives another fifth digit
+    moved = fullsize.panel_centre_deflection(N_FULL, shift=(3.0, 7.0, 0.0))
+    assert moved["converged"] == 1 and moved["error_estimate"] < 1e-9
+    change = abs(moved["w_centre"] - w_full) / navier
+    assert 1e-7 < change < 3e-4, (change, dev)
+    assert abs(dev[N_FULL]) < 20.0 * change + 1e-5, (change, dev)
+
+
+def test_full_size_manufactured_solution_with_the_spectrum_of_the_load_case(context):
+    """A manufactured solve whose u* is the CONVERGED SOLUTION OF THE LOAD CASE (uniform pressure on the panel, the two pinch
+    loads on the cylinder) instead of a smooth analytic field: b = K u* has the spectrum of the real right-hand side (the
+    smooth field's ||b|| is six decades above the pressure load's), and the solve has to come back to u*."""
+    kind, m, mat, fs = context
+    fs.set_loads(m.loads)
+    fs.assemble()
+    fs.set_preconditioner("amg", refine_passes=1)
+    u_load, info = fs.solve(rtol=1e-10, max_it=3000)
+    assert info["converged"] == 1
+    out = fullsize.manufactured_solve(fs, m, kind, rtol=1e-10, passes=(1,), u_star=u_load)
+    r1 = out["runs"][1]
+    assert r1["converged"] == 1 and r1["refine_passes_done"] >= 1
+    assert r1["rel_err_vs_manufactured"] < 1e-10, out
+    fs.set_loads(m.loads)
 
 
 def test_full_size_manufactured_solution(context):
