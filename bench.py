@@ -19,6 +19,7 @@ import hashlib
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -277,7 +278,8 @@ def fullsize_parity(fs, m, mat, kind):
     returns.  Replaces the loads of the context."""
     from tests.helpers import fullsize
 
-    out = {"matrix_vs_oracle": fullsize.matrix_parity(fs, m, mat)}
+    # (products=True: femshell_spmv and the double-double femshell_residual of the device against the ORACLE's blocks as well)
+    out = {"matrix_vs_oracle": fullsize.matrix_parity(fs, m, mat, products=True, kind=kind)}
     man = fullsize.manufactured_solve(fs, m, kind, rtol=1e-10, passes=(0, 1))
     r0, r1 = man["runs"][0], man["runs"][1]
     out["manufactured_solution"] = {
@@ -292,6 +294,39 @@ def fullsize_parity(fs, m, mat, kind):
         "rounding_of_b": man.get("rounding_of_b"),
         "note": "u* smooth, zero on the fixed dofs; b = K u* evaluated in double-double on the device and rounded to double; "
                 "the reference is u* + K^-1 (fl(b) - K u*)"}
+    # the same with u* = the converged solution of the load case itself (the spectrum of the real right-hand side)
+    fs.set_loads(m.loads)
+    fs.assemble()
+    fs.set_preconditioner("amg", refine_passes=1)
+    u_load, il = fs.solve(rtol=1e-10, max_it=3000)
+    man2 = fullsize.manufactured_solve(fs, m, kind, rtol=1e-10, passes=(1,), u_star=u_load)
+    out["manufactured_solution_with_the_load_case_spectrum"] = {
+        "rel_err_manufactured": man2["runs"][1]["rel_err_vs_manufactured"], "iterations": man2["runs"][1]["iterations"],
+        "error_estimate_from_solve_info": man2["runs"][1]["error_estimate"],
+        "note": "u* = the converged solution of the load case (uniform pressure / the two pinch loads), b = K u* in double-double"}
+    fs.set_loads(m.loads)
+    return out
+
+
+def headline_load_case_witness():
+    """w at the centre of the headline panel (the plate of the thesis' tests D / G, doc/validation.tex:283-295, 518) against
+    Navier's series over mesh sizes, and at the headline size once more with the mesh translated -- the same matrix in exact
+    arithmetic: what is left of the deviation at 4M triangles is kappa(K) x the rounding of K's FP64 entries (tests/test_gpu_fullsize.py
+    test_headline_load_case_against_the_reference_held_plate_answer, profiles/r05_headline_load_case_vs_navier.txt)."""
+    from tests.helpers import fullsize
+
+    navier = fullsize.navier_centre_deflection(300.0, 10.0, 1e7, 0.3, 0.5)
+    out = {"navier_series_w_centre": navier, "thesis_timoshenko_alpha_0.00406": 0.1064045, "thesis_tri3_64x64": 0.106413, "by_mesh": []}
+    for n in (64, 256, 512, 1414):
+        r = fullsize.panel_centre_deflection(n)
+        out["by_mesh"].append({"squares_per_side": n, "w_centre": r["w_centre"], "rel_dev_from_navier": (r["w_centre"] - navier) / navier,
+                               "iterations": r["iterations"], "solver_error_estimate": r["error_estimate"]})
+    moved = fullsize.panel_centre_deflection(1414, shift=(3.0, 7.0, 0.0))
+    out["headline_mesh_translated_by_3_7_0"] = {"w_centre": moved["w_centre"], "rel_dev_from_navier": (moved["w_centre"] - navier) / navier,
+                                                "rel_change_against_the_untranslated_mesh": abs(moved["w_centre"] - out["by_mesh"][-1]["w_centre"]) / navier}
+    out["note"] = ("second-order convergence up to 512^2 (-5.0e-4, -3.1e-5, -8.9e-6); at 1414^2 the discretisation error would be 1e-6, the answer is "
+                   "1e-4 off and moves by as much under a translation of the mesh: the sensitivity of the solution to the rounding of K's own "
+                   "entries, kappa x eps (the solver term is the error estimate); the reference's FP64 assembly rounds the same entries")
     return out
 
 
@@ -363,6 +398,51 @@ def config2_cylinder(pkg, device, steps, warmup, nx, roof):
                                 "error_estimate": ia["error_estimate"], "refine_passes_done": ia["refine_passes_done"]}}
     out["parity"] = fullsize_parity(fs, m, mat, "cylinder")
     fs.close()
+    return out
+
+
+def amg_iteration_roofline(fs, info, n_nodes, args):
+    """Roofline of one multigrid-preconditioned iteration: the bytes the cycle streams as it is built (femshell_amg_cycle_bytes:
+    single-precision copies, increments, real product counts -- csrc/amg_solve.cpp) per level, over the solve's time per
+    iteration; per-level milliseconds from the committed kernel trace of the same solve (tools/amg_level_times.py) while the
+    kernel sources are the ones it was taken with."""
+    per_level = [float(b) for b in fs.amg_cycle_bytes()]
+    its, secs = max(info["iterations"], 1), info["solve_seconds"]
+    krylov = info["bytes_per_iteration"] - sum(per_level)
+    out = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+           "achieved": info["bytes_per_iteration"] * its / secs / 1e9,
+           "ms_per_iteration": 1e3 * secs / its,
+           "algorithmic_gb_per_iteration": info["bytes_per_iteration"] / 1e9,
+           "algorithmic_gb_krylov_passes_on_level_0": krylov / 1e9,
+           "algorithmic_gb_of_the_cycle_by_level": [b / 1e9 for b in per_level],
+           "nodes_by_level": [l["n_nodes"] for l in fs.amg_levels()]}
+    out["frac"] = out["achieved"] / HBM_PEAK_GBS
+    path = os.path.join(ROOT, "profiles", "r05_amg_by_level.json")
+    if args.workload == "panel" and args.nx == 1414 and os.path.exists(path):
+        with open(path) as f:
+            prof = json.load(f)
+        if prof.get("kernel_source_digest") == kernel_source_digest():
+            out["by_level_ms_from_committed_profile"] = prof["ms_per_iteration_by_level"]
+            out["by_level_ms_source"] = "profiles/r05_amg_by_level.json (rocprofv3 --kernel-trace of tools/amg_probe.py panel 1414)"
+            tot = sum(prof["ms_per_iteration_by_level"]) + prof.get("ms_per_iteration_unassigned", 0.0)
+            out["frac_from_committed_profile"] = info["bytes_per_iteration"] / (tot * 1e-3) / 1e9 / HBM_PEAK_GBS
+        else:
+            out["by_level_ms_from_committed_profile"] = None
+            out["by_level_ms_source"] = "stale: profiles/r05_amg_by_level.json was taken with other kernel sources"
+    return out
+
+
+def mfma_counter_summary():
+    path = os.path.join(ROOT, "profiles", "r05_pmc_mfma.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    out = dict(d.get("all_kernels_of_the_inverse", {}), source="profiles/r05_pmc_mfma.json")
+    upd = d.get("kernels", {}).get("k_dense_update<true>")
+    if upd:
+        out["k_dense_update"] = {"tflops_by_counter": upd["tflops_by_counter"], "mfma_busy_fraction": upd["mfma_busy_fraction"],
+                                 "launches": upd["launches"]}
     return out
 
 
@@ -538,6 +618,20 @@ def main():
         return rate
     copy_gbs = device_copy_rate()
 
+    def box_stream_rates():
+        """Streaming write / read / copy rates of this box by tools/lab/hbm_rw (plain 16-byte-per-lane kernels over 4.3 GB, a child
+        process; built by __graft_entry__.build()): the practical roofs a write-heavy kernel (the assembly: 82 % stores) and a
+        read-heavy one (the products) are to be held against -- HBM3E's 8 TB/s is reached by neither direction on these boxes."""
+        exe = os.path.join(ROOT, "tools", "lab", "hbm_rw")
+        if rank != 0 or not os.path.exists(exe):
+            return None
+        try:
+            r = subprocess.run([exe, "--json"], capture_output=True, text=True, timeout=120)
+            return json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:  # noqa: BLE001 (a yardstick, not a measurement the line depends on)
+            return {"error": repr(e)}
+    stream = box_stream_rates() if not args.profile else None
+
     def device_alloc_ms():
         """Wall time of hipMalloc + hipFree of 4 GiB: a few ms on a fresh box, a hundred and more right after a run that
         churned the card's memory (the GPU test-suite: 138 contexts) -- the multigrid setup allocates and frees about 10 GB
@@ -631,6 +725,8 @@ def main():
             if meta.get("kernel_source_digest") == kernel_source_digest():
                 for kname, v in pm.items():
                     traffic[kname.split("::")[-1].split("<")[0]] = v["read_bytes_x2_gfx950"] + v["write_bytes"]
+                    traffic[kname.split("::")[-1].split("<")[0] + ":read"] = v["read_bytes_x2_gfx950"]
+                    traffic[kname.split("::")[-1].split("<")[0] + ":write"] = v["write_bytes"]
                 traffic["_source"] = "profiles/" + cands[-1]
             else:
                 traffic_note = "stale: profiles/%s was taken with other kernel sources" % cands[-1]
@@ -653,6 +749,14 @@ def main():
             # (how fast the kernel moves the bytes it really moves, against what this box reaches with a plain device-to-device
             #  copy of 1 GiB -- the practical roof of a mixed read / write stream, 4.8-5.2 TB/s on the boxes of this pool)
             out["traffic_rate_over_box_streaming_copy_rate"] = out["traffic_gb_per_s"] / copy_gbs
+            if stream and "write_gb_per_s" in stream:
+                # the same against the box's plain streaming kernels (tools/lab/hbm_rw): the mix of this kernel's reads and writes
+                # at the box's read and write rates is the time a perfect stream of the same bytes would take
+                rd = traffic.get(kernel + ":read"), traffic.get(kernel + ":write")
+                if rd[0] is not None and rd[1] is not None:
+                    t_stream = rd[0] / (stream["read_gb_per_s"] * 1e9) + rd[1] / (stream["write_gb_per_s"] * 1e9)
+                    out["time_of_a_plain_stream_of_the_same_bytes_ms"] = 1e3 * t_stream
+                    out["frac_of_the_box_streaming_rates"] = 1e3 * t_stream / ms
         if kernel in fp64:  # FP64 vector peak 78.6 TFLOP/s (MI355X_MICROARCH.md)
             out["fp64_gflop_per_launch"] = fp64[kernel] / 1e9
             out["fp64_tflops"] = fp64[kernel] / (ms * 1e-3) / 1e12
@@ -691,6 +795,7 @@ def main():
                "refine_correction_rel": ia["refine_correction_rel"], "refine_residual_reduction": ia["refine_residual_reduction"],
                "algorithmic_gb_per_iteration": ia["bytes_per_iteration"] / 1e9,
                "achieved_gb_per_s": ia["bytes_per_iteration"] * ia["iterations"] / ia["solve_seconds"] / 1e9,
+               "roofline_amg_iteration": amg_iteration_roofline(fs, ia, n_nodes, args),
                "setup_first_coarsening_on_device": {
                    "prolongator_ms": sst["prolongator_ms"], "ap_ms": sst["ap_ms"], "restriction_ms": sst["restriction_ms"],
                    "galerkin_ms": sst["galerkin_ms"],
@@ -708,7 +813,10 @@ def main():
                                 "note": "FP64 matrix peak 78.6 TFLOP/s; 64x64 tiles, block sweeps of width 128: the lower triangle is read and "
                                         "written once per sweep (58 sweeps at 7386 dofs); the pivot block of the next sweep is inverted by a "
                                         "reserved workgroup inside the trailing update's launch (17.1 ms with a launch of its own in front of "
-                                        "every sweep, FEMSHELL_AMG_DENSE_LOOKAHEAD=0)"}},
+                                        "every sweep, FEMSHELL_AMG_DENSE_LOOKAHEAD=0)"},
+                   # the same by rocprofv3 counters (tools/pmc_mfma.py: SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 flops over the kernel times of an
+                   # unprofiled trace; SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMDs x GRBM_GUI_ACTIVE / 8), committed summary of the same solve
+                   "mfma_counters_from_committed_profile": mfma_counter_summary()},
                "block_jacobi_alone": jacobi_extrapolation(jacobi_hist)}
         free_b, total_b = torch.cuda.mem_get_info()
         tts["hbm_in_use_gb_max_over_ranks"] = max_over_ranks((total_b - free_b) / 1e9)
@@ -727,6 +835,19 @@ def main():
                         "product of a split level is preceded by a halo exchange, the K cycle's sums are all-reduced, the first "
                         "replicated level's right-hand side is all-gathered (DESIGN section 6)"}
         if world == 1:
+            # the same solve with every copy the cycle reads in FP64 (FEMSHELL_AMG_SMOOTH_F32=0: no single-precision operators,
+            # D^-1, transfers, vectors; coarsest inverse FP64): what the mixed-precision preconditioner buys
+            os.environ["FEMSHELL_AMG_SMOOTH_F32"] = "0"
+            os.environ["FEMSHELL_AMG_DENSE_F32"] = "0"
+            fs.assemble()
+            fs.set_preconditioner("amg")
+            _, i64 = fs.solve(rtol=1e-10, max_it=3000, fetch=False)
+            _, i64b = fs.solve(rtol=1e-10, max_it=3000, fetch=False)
+            del os.environ["FEMSHELL_AMG_SMOOTH_F32"], os.environ["FEMSHELL_AMG_DENSE_F32"]
+            tts["all_fp64_preconditioner"] = {"iterations": i64["iterations"], "converged": i64["converged"],
+                                              "solve_seconds": i64b["solve_seconds"], "pc_setup_seconds": i64["pc_setup_seconds"],
+                                              "algorithmic_gb_per_iteration": i64["bytes_per_iteration"] / 1e9,
+                                              "error_estimate": i64["error_estimate"]}
             # the Galerkin product on the matrix cores, the measured alternative to the default vector-ALU kernel: one more setup
             os.environ["FEMSHELL_AMG_GALERKIN"] = "mfma"
             fs.assemble()
@@ -776,6 +897,9 @@ def main():
                        "preconditioner": "6x6 block-Jacobi", "symbolic_setup_s": setup_s,
                        "matrix_storage": "symmetric (upper triangles of the diagonal blocks + the blocks of the lower-numbered row)" if symmetric else "full",
                        "rccl_ranks_seen": rccl_ranks, "box_streaming_copy_gb_per_s": copy_gbs,
+                       "box_stream_write_gb_per_s": stream.get("write_gb_per_s") if stream else None,
+                       "box_stream_read_gb_per_s": stream.get("read_gb_per_s") if stream else None,
+                       "box_stream_copy_gb_per_s": stream.get("copy_gb_per_s") if stream else None,
                        "box_hipmalloc_plus_free_of_4GiB_ms": alloc_ms},
             # `roofline` belongs to `value`: the kernel the timed assembly steps consist of
             "roofline": dict(roof(asm_ms, asm_bytes, asm_kernel), kernel=asm_kernel + " (element records -> block slots -> K and F; the kernel "
@@ -794,6 +918,7 @@ def main():
                 out["parity"]["config1_scordelis_lo_250k"] = parity_config1(pkg, local_rank)
             if not args.no_fullsize_parity and args.workload == "panel" and args.nx == 1414:
                 out["parity"]["config3_flat_panel_4M"] = fullsize_parity(fs, m, (nu, E, thick), "panel")
+                out["parity"]["headline_load_case_vs_plate_theory"] = headline_load_case_witness()
                 out["config2_pinched_cylinder_4M"] = config2_cylinder(pkg, local_rank, args.steps, args.warmup, 1414, roof)
                 out["config4_coupled_flap_1M"] = config4_coupled_flap()
             if not args.no_cpu_baseline:

@@ -25,6 +25,7 @@ SYMBOLS = [
     "femshell_row_end", "femshell_comm_unique_id", "femshell_comm_init", "femshell_time_kernel",
     "femshell_sync", "femshell_pc_defaults", "femshell_set_preconditioner", "femshell_amg_levels", "femshell_amg_level",
     "femshell_amg_export", "femshell_residual", "femshell_comm_ranks", "femshell_amg_setup_stats", "femshell_amg_dense_stats", "femshell_amg_partition_info", "femshell_assembly_kernel",
+    "femshell_amg_cycle_bytes",
 ]
 
 
@@ -137,6 +138,8 @@ def load_library():
     L.femshell_amg_dense_stats.argtypes = [vp, dp]
     L.femshell_amg_partition_info.argtypes = [vp, dp]
     L.femshell_assembly_kernel.argtypes = [vp]
+    L.femshell_amg_cycle_bytes.argtypes = [vp, dp, C.c_int32]
+    L.femshell_amg_cycle_bytes.restype = C.c_int32
     for name in SYMBOLS:
         if name != "femshell_last_error" and not name.startswith("femshell_nnz") and \
                 not name.startswith("femshell_row") and name != "femshell_residual_history" and \
@@ -303,6 +306,14 @@ class FemShell:
             _check(self._L.femshell_amg_level(self._h, l, C.byref(info)))
             out.append({f[0]: getattr(info, f[0]) for f in AmgLevelInfo._fields_})
         return out
+
+    def amg_cycle_bytes(self):
+        """Algorithmic HBM bytes of one multigrid cycle per level (femshell_amg_cycle_bytes)."""
+        out = np.zeros(32)
+        n = self._L.femshell_amg_cycle_bytes(self._h, _d(out), 32)
+        if n < 0:
+            _check(n)
+        return out[:n].copy()
 
     def amg_setup_stats(self):
         """Device timings of the first coarsening step of the last multigrid setup."""

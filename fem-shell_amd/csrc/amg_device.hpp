@@ -162,7 +162,8 @@ double *amg_apply_iterate(femshell_ctx *c, double *z);
 // *true_rr_out: ||b - K x||^2 of the returned iterate when the residual replacement computed it, else -1
 // *rec_rr_out: recurrence ||r||^2 the stopping rule saw last
 int cg_amg(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it, double *true_rr_out, double *rec_rr_out);
-double amg_bytes_per_iteration(const femshell_ctx *c);
+// algorithmic HBM bytes of one cycle as it is built (single-precision copies, increments, the real product counts), and per level
+double amg_cycle_bytes(const femshell_ctx *c, std::vector<double> *per_level = nullptr);
 // K of a single-rank context as host BSR with ascending columns (api.cpp)
 int download_matrix(femshell_ctx *c, Bsr *A, int32_t *col_out = nullptr, double *val_out = nullptr);
 // Dense inverse of the coarsest operator on the device (amg_dense.hip): symmetric block sweeps on v_mfma_f64_16x16x4_f64.

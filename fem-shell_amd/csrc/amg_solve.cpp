@@ -1170,33 +1170,63 @@ int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, do
     return FEMSHELL_OK;
 }
 
-// algorithmic HBM bytes of one preconditioned iteration: every operator product of the cycle streams its blocks
-// (292 B each) once, plus the vector passes
-double amg_bytes_per_iteration(const femshell_ctx *c)
+// Algorithmic HBM bytes of one multigrid cycle, level by level (per_level[l]: everything the cycle does ON level l over all its
+// visits per outer iteration: smoothing products and steps, the two residual increments, the transfers to and from level l+1,
+// the K cycle's own products and vector passes; the dense solve on the coarsest level).  Counted is what the kernels have to
+// stream as the cycle is built today (round 5) -- NOT 292 B per block for every product as rounds 2-4 counted:
+//   * a smoothing product or a residual increment reads the smoother's copy of the operator: 148 B per stored block where the
+//     level keeps the single-precision copy (144 B of values + 4 B column index), 292 B else; symmetric storage stores (and streams)
+//     the diagonal and one block per pair; its input and output vectors are floats where DeviceMatrix::vec32 says so
+//   * the K cycle's two products per coarse solve and nothing else of the cycle read the FP64 operator
+//   * the transposed-product buffers of symmetric storage are overhead of the method and are not counted (as for bytes_spmv)
+//   * vector passes: every vector a kernel reads or writes once, 48 B per node (24 B as floats), the block-Jacobi inverse 168 B
+//     per node (84 B from its single-precision copy)
+double amg_cycle_bytes(const femshell_ctx *c, std::vector<double> *per_level)
 {
     const Amg &H = *c->amg;
-    std::vector<double> visits(H.levels.size(), 0.0);
+    const size_t nl = H.levels.size();
+    std::vector<double> visits(nl, 0.0), bytes(nl, 0.0);
     visits[0] = 1.0;
-    double bytes = 0.0;
-    for (size_t l = 0; l + 1 < H.levels.size(); l++) {
-        const AmgLevel &L = *H.levels[l];
-        const double deg = (double)L.cheb_a.size() + 1.0;
-        // pre: deg-1 products, residual: 1, post: deg products; K cycle adds one product per visit on levels >= 1
-        double a_products = 2.0 * deg;
-        const bool k_here = H.opt.cycle == FEMSHELL_CYCLE_K && l >= 1;
-        const double vec = 48.0 * L.n;
+    const bool kcyc = H.opt.cycle == FEMSHELL_CYCLE_K;
+    for (size_t l = 0; l + 1 < nl; l++) {
+        const AmgLevel &L = *H.levels[l], &N = *H.levels[l + 1];
+        const DeviceMatrix &A = amg_level_matrix(c, (int)l);
+        const double n = (double)L.n;
+        const bool lowp = L.A32.p != nullptr;
+        const int v32 = (A.symmetric && lowp) ? L.smooth_dm.vec32 : 0;
         // blocks a product of the level operator streams (symmetric storage: the stored ones)
-        const double blocks = l == 0 ? (double)c->plan.stored_blocks : (double)L.A.nnzb;
-        double per_visit = a_products * (292.0 * blocks + 2.0 * vec) + 292.0 * (double)(L.P.nnzb + L.R.nnzb) + 4.0 * vec +
-                           (2.0 * deg) * (5.0 * vec + 168.0 * L.n);
-        if (k_here) per_visit += 292.0 * blocks + 8.0 * vec;
-        bytes += visits[l] * per_visit;
-        const bool next_k = H.opt.cycle == FEMSHELL_CYCLE_K && l + 2 < H.levels.size();
+        const double blocks = l == 0 ? (double)c->plan.stored_blocks : (A.symmetric ? 0.5 * ((double)L.nnzb + n) : (double)L.nnzb);
+        const double deg = (double)L.cheb_a.size() + 1.0;
+        const double vec = 48.0 * n, fvec = 24.0 * n;
+        const double minv = (lowp ? 84.0 : 168.0) * n;
+        const double in_vec = v32 == 2 ? fvec : vec, out_vec = v32 >= 1 ? fvec : vec;
+        const double smooth_product = blocks * (lowp ? 148.0 : 292.0) + in_vec + out_vec;
+        // per visit: 2 (deg - 1) products inside the two smoothings + the two increments
+        double per_visit = 2.0 * deg * smooth_product;
+        // Chebyshev steps (2 (deg - 1)): rin, q, d, x, D^-1 read; rout, d, x written
+        per_visit += 2.0 * (deg - 1.0) * (vec + out_vec + in_vec + vec + minv + vec + in_vec + vec);
+        // the two starts: r, D^-1 (and x behind the coarse correction) read; d, x written -- and the two second phases / axpys
+        // of the increments: product and base vector read, residual written
+        per_visit += 2.0 * (vec + minv + in_vec + vec) + vec + 2.0 * (out_vec + vec + vec);
+        // transfers: R (rows of level l+1) and P (rows of level l), single-precision copies where the setup made them
+        const double rp_block = L.P32.p != nullptr ? 148.0 : 292.0;
+        // (the prolongation is a product over the rows of this level; the restriction one over the rows of the next and is booked
+        //  there -- which is also where a kernel trace by grid size finds it, tools/amg_level_times.py)
+        per_visit += rp_block * (double)L.P.nnzb + (48.0 * N.n + 2.0 * vec + in_vec);
+        bytes[l + 1] += visits[l] * (rp_block * (double)L.R.nnzb + vec + 48.0 * N.n);
+        // the K cycle on this level (levels >= 1 that are not the coarsest): per coarse solve = per two visits, two FP64 products
+        // and the vector passes of the two coefficient steps
+        if (kcyc && l >= 1) per_visit += 0.5 * (2.0 * (292.0 * blocks + 2.0 * vec) + 14.0 * vec);
+        bytes[l] += visits[l] * per_visit;
+        const bool next_k = kcyc && l + 2 < nl;
         visits[l + 1] = visits[l] * (next_k ? 2.0 : 1.0);
     }
     const AmgLevel &C = *H.levels.back();
-    bytes += visits.back() * (H.coarse_inv32.p != nullptr ? 4.0 : 8.0) * 36.0 * (double)C.n * (double)C.n;
-    return bytes;
+    bytes[nl - 1] += visits.back() * ((H.coarse_inv32.p != nullptr ? 4.0 : 8.0) * 36.0 * (double)C.n * (double)C.n + 96.0 * C.n);
+    double total = 0.0;
+    for (double b : bytes) total += b;
+    if (per_level != nullptr) *per_level = bytes;
+    return total;
 }
 
 } // namespace femshell

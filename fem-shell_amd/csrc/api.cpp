@@ -899,6 +899,16 @@ int femshell_amg_partition_info(femshell_ctx *c, double out[6])
     return FEMSHELL_OK;
 }
 
+int32_t femshell_amg_cycle_bytes(femshell_ctx *c, double *per_level, int32_t cap)
+{
+    if (!c) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_cycle_bytes: null context");
+    if (!c->amg || !c->amg->valid) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_cycle_bytes: no multigrid hierarchy");
+    std::vector<double> b;
+    (void)amg_cycle_bytes(c, &b);
+    for (int32_t l = 0; per_level != nullptr && l < cap && l < (int32_t)b.size(); l++) per_level[l] = b[(size_t)l];
+    return (int32_t)b.size();
+}
+
 int femshell_assembly_kernel(femshell_ctx *c)
 {
     if (!c) return set_err(FEMSHELL_ERR_INVALID, "femshell_assembly_kernel: null context");
@@ -1089,7 +1099,9 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
         info->assemble_seconds = asm_s;
         info->setup_seconds = setup_s;
         info->solve_seconds = 1e-3 * ms;
-        info->bytes_per_iteration = use_amg ? bytes_spmv(c) + (6.0 + 5.0 + 3.0) * 48.0 * c->plan.n_own + amg_bytes_per_iteration(c)
+        // (multigrid: the Krylov product, the update with its start of the smoothing, the two dot products and the new direction
+        //  around the cycle: x, p, r, q read, x, r, q, z written, D^-1; z, r, q; z, p read, p written)
+        info->bytes_per_iteration = use_amg ? bytes_spmv(c) + (8.0 + 3.0 + 3.0) * 48.0 * c->plan.n_own + amg_cycle_bytes(c)
                                     : single_reduction ? bytes_spmv(c) + bytes_update_single_reduction(c)
                                                        : bytes_spmv(c) + bytes_update(c) + bytes_direction(c);
         info->pc_type = c->pc.type;

@@ -223,6 +223,13 @@ int femshell_amg_dense_stats(femshell_ctx *ctx, double out[6]);
  * which every rank holds in full (dense inverse included), out[3] / out[4] = this rank's rows / ghost rows on the last
  * row-partitioned level, out[5] = nodes of the first replicated level. */
 int femshell_amg_partition_info(femshell_ctx *ctx, double out[6]);
+/* Algorithmic HBM bytes of ONE multigrid cycle (one application of the preconditioner inside femshell_solve, which replaces the
+ * PETSc preconditioner behind equation_systems.solve(), fem-shell.cpp:138), level by level: per_level[l] = what the cycle streams on
+ * level l over all its visits per outer iteration -- smoothing products on the single-precision copies where the level keeps them,
+ * residual increments, transfers, the K cycle's FP64 products, the dense solve of the coarsest level (csrc/amg_solve.cpp
+ * amg_cycle_bytes spells the model out).  Returns the number of levels (< 0: error); at most `cap` entries are written.
+ * femshell_solve_info::bytes_per_iteration = their sum + the Krylov method's own passes on level 0. */
+int32_t femshell_amg_cycle_bytes(femshell_ctx *ctx, double *per_level, int32_t cap);
 /* which assembly kernel femshell_assemble launches for the mesh of this context (after femshell_set_mesh): 1 = the
  * pipelined one (k_assemble_pipe: meshes whose slices touch at most 150 elements -- 77 with quadrilaterals -- and whose
  * work items fit one round of its waves: structured meshes, unstructured ones numbered with locality), 0 = the two-phase
