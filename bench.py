@@ -896,7 +896,7 @@ def main():
                                                          "(clocks, TLBs), then the --warmup steps of the contract",
                        "preconditioner": "6x6 block-Jacobi", "symbolic_setup_s": setup_s,
                        "matrix_storage": "symmetric (upper triangles of the diagonal blocks + the blocks of the lower-numbered row)" if symmetric else "full",
-                       "rccl_ranks_seen": rccl_ranks, "box_streaming_copy_gb_per_s": copy_gbs,
+                       "rccl_ranks_seen": rccl_ranks, "rccl_selftest_us": fs.comm_selftest(), "box_streaming_copy_gb_per_s": copy_gbs,
                        "box_stream_write_gb_per_s": stream.get("write_gb_per_s") if stream else None,
                        "box_stream_read_gb_per_s": stream.get("read_gb_per_s") if stream else None,
                        "box_stream_copy_gb_per_s": stream.get("copy_gb_per_s") if stream else None,

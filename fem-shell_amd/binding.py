@@ -25,7 +25,7 @@ SYMBOLS = [
     "femshell_row_end", "femshell_comm_unique_id", "femshell_comm_init", "femshell_time_kernel",
     "femshell_sync", "femshell_pc_defaults", "femshell_set_preconditioner", "femshell_amg_levels", "femshell_amg_level",
     "femshell_amg_export", "femshell_residual", "femshell_comm_ranks", "femshell_amg_setup_stats", "femshell_amg_dense_stats", "femshell_amg_partition_info", "femshell_assembly_kernel",
-    "femshell_amg_cycle_bytes",
+    "femshell_amg_cycle_bytes", "femshell_comm_selftest",
 ]
 
 
@@ -138,6 +138,7 @@ def load_library():
     L.femshell_amg_dense_stats.argtypes = [vp, dp]
     L.femshell_amg_partition_info.argtypes = [vp, dp]
     L.femshell_assembly_kernel.argtypes = [vp]
+    L.femshell_comm_selftest.argtypes = [vp, dp]
     L.femshell_amg_cycle_bytes.argtypes = [vp, dp, C.c_int32]
     L.femshell_amg_cycle_bytes.restype = C.c_int32
     for name in SYMBOLS:
@@ -306,6 +307,15 @@ class FemShell:
             _check(self._L.femshell_amg_level(self._h, l, C.byref(info)))
             out.append({f[0]: getattr(info, f[0]) for f in AmgLevelInfo._fields_})
         return out
+
+    def comm_selftest(self):
+        """Microseconds of the three communication patterns femshell_comm_init checked on first contact (None: no communicator)."""
+        out = np.zeros(3)
+        rc = self._L.femshell_comm_selftest(self._h, _d(out))
+        if rc < 0:
+            _check(rc)
+        return None if rc == 0 else {"halo_send_recv_on_second_stream_beside_allreduce_us": float(out[0]),
+                                     "grouped_broadcast_row_gather_us": float(out[1]), "allreduce_3_words_us": float(out[2])}
 
     def amg_cycle_bytes(self):
         """Algorithmic HBM bytes of one multigrid cycle per level (femshell_amg_cycle_bytes)."""

@@ -507,7 +507,25 @@ int femshell_comm_init(femshell_ctx *c, const uint8_t id[128])
             return set_err(FEMSHELL_ERR_COMM, "femshell_comm_init: the first all-reduce returned " + std::to_string(got) + " instead of the rank count " +
                                                   std::to_string(c->cfg.world_size));
     }
+    {
+        // ... and the patterns the solves use, once each with a known answer (comm.cpp comm_selftest): the halo exchange's grouped
+        // send/recv on the second stream beside an all-reduce on the main one, the grouped broadcasts of the row gather.  The first
+        // real multi-GPU run either passes here or names the pattern that failed -- or, stalled, is ended by the watchdog with the
+        // pattern's name -- instead of hanging in its first solve.
+        if (!c->halo_stream) FS_HIP(hipStreamCreateWithFlags(&c->halo_stream, hipStreamNonBlocking));
+        DevBuf<double> scratch;
+        FS_HIP(scratch.alloc((size_t)16 + 2 * (size_t)c->cfg.world_size));
+        if (!comm_selftest(c->comm, c->stream, c->halo_stream, scratch.p, c->comm_selftest_us, &e)) return set_err(FEMSHELL_ERR_COMM, "femshell_comm_init: " + e);
+        c->comm_selftest_done = true;
+    }
     return FEMSHELL_OK;
+}
+
+int femshell_comm_selftest(femshell_ctx *c, double out_us[3])
+{
+    if (!c || !out_us) return set_err(FEMSHELL_ERR_INVALID, "femshell_comm_selftest: null argument");
+    for (int i = 0; i < 3; i++) out_us[i] = c->comm_selftest_done ? c->comm_selftest_us[i] : -1.0;
+    return c->comm_selftest_done ? 1 : 0;
 }
 
 int32_t femshell_comm_ranks(femshell_ctx *c) { return c ? comm_count(c->comm) : 0; }

@@ -205,6 +205,79 @@ bool comm_init(Comm &c, const uint8_t id_bytes[128], int rank, int world, std::s
     return true;
 }
 
+// First-contact self-test (comm.hpp): the communication patterns of a solve, once each with a known answer, each under its own
+// watch so that a transport that initialises but cannot carry one of them is named here and not as a hang in the first solve.
+//  1. a grouped ncclSend / ncclRecv ring on `second` (every rank to its successor: the halo pattern on the halo stream) while an
+//     ncclAllReduce of three words is enqueued on `main` (the CG's reduction on the main stream) -- two streams, one communicator
+//  2. grouped ncclBroadcast, one per rank (the pattern of comm_gather_rows: femshell_get_solution, the all-gather in front of the
+//     replicated levels of the multigrid)
+// scratch: device memory for 16 + 2 x world doubles.  us_out[0..2]: wall microseconds of the two patterns and of a lone
+// all-reduce of three words (enqueue to completion, host clock).
+bool comm_selftest(Comm &c, hipStream_t main, hipStream_t second, double *scratch, double us_out[3], std::string *err)
+{
+    ncclComm_t comm = static_cast<ncclComm_t>(c.comm);
+    const int W = c.world, me = c.rank;
+    auto fail = [&](const std::string &what) {
+        if (err) *err = what;
+        return false;
+    };
+    auto now_us = [] { return 1e-3 * (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    std::vector<double> h((size_t)16 + 2 * (size_t)W, 0.0);
+    // layout: [0..5] ring send, [6..11] ring recv, [12..14] all-reduce words, [16 + r] broadcast slots, [16 + W + r] their source
+    for (int i = 0; i < 6; i++) h[(size_t)i] = 100.0 * me + i;
+    for (int i = 0; i < 3; i++) h[(size_t)12 + i] = (double)(me + 1) * (i + 1);
+    h[(size_t)16 + W + me] = 7.0 + me;
+    if (hipMemcpy(scratch, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail("self-test: upload failed");
+    const int next = (me + 1) % W, prev = (me + W - 1) % W;
+    double t0 = now_us();
+    {
+        CommWatch watch(me, W, "self-test: grouped send/recv on the halo stream beside an all-reduce on the main stream");
+        if (W > 1) {
+            if (!check(g_api.GroupStart(), "ncclGroupStart", err)) return false;
+            bool ok = check(g_api.Send(scratch, 6, ncclDouble, next, comm, second), "ncclSend", err);
+            ok = ok && check(g_api.Recv(scratch + 6, 6, ncclDouble, prev, comm, second), "ncclRecv", err);
+            const bool ended = check(g_api.GroupEnd(), "ncclGroupEnd", ok ? err : nullptr);
+            if (!ok || !ended) return false;
+        }
+        if (!check(g_api.AllReduce(scratch + 12, scratch + 12, 3, ncclDouble, ncclSum, comm, main), "ncclAllReduce", err)) return false;
+        if (hipStreamSynchronize(second) != hipSuccess || hipStreamSynchronize(main) != hipSuccess) return fail("self-test: stream synchronisation failed");
+    }
+    us_out[0] = now_us() - t0;
+    t0 = now_us();
+    {
+        CommWatch watch(me, W, "self-test: grouped ncclBroadcast, one per rank (row gather)");
+        if (!check(g_api.GroupStart(), "ncclGroupStart", err)) return false;
+        bool ok = true;
+        for (int r = 0; r < W && ok; r++)
+            ok = check(g_api.Broadcast(r == me ? scratch + 16 + W + r : scratch + 16 + r, scratch + 16 + r, 1, ncclDouble, r, comm, main), "ncclBroadcast", err);
+        const bool ended = check(g_api.GroupEnd(), "ncclGroupEnd", ok ? err : nullptr);
+        if (!ok || !ended) return false;
+        if (hipStreamSynchronize(main) != hipSuccess) return fail("self-test: stream synchronisation failed");
+    }
+    us_out[1] = now_us() - t0;
+    t0 = now_us();
+    {
+        CommWatch watch(me, W, "self-test: all-reduce of three words");
+        if (!check(g_api.AllReduce(scratch + 12, scratch + 12, 3, ncclDouble, ncclSum, comm, main), "ncclAllReduce", err)) return false;
+        if (hipStreamSynchronize(main) != hipSuccess) return fail("self-test: stream synchronisation failed");
+    }
+    us_out[2] = now_us() - t0;
+    if (hipMemcpy(h.data(), scratch, h.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail("self-test: download failed");
+    const double tri = 0.5 * W * (W + 1.0);
+    if (W > 1)
+        for (int i = 0; i < 6; i++)
+            if (h[(size_t)6 + i] != 100.0 * prev + i)
+                return fail("self-test: the grouped send/recv on the second stream delivered " + std::to_string(h[(size_t)6 + i]) + " instead of " +
+                            std::to_string(100.0 * prev + i) + " from rank " + std::to_string(prev));
+    for (int i = 0; i < 3; i++)
+        if (h[(size_t)12 + i] != tri * (i + 1) * W) // (reduced twice: the second all-reduce sums the W copies of the first sum)
+            return fail("self-test: the all-reduces returned " + std::to_string(h[(size_t)12 + i]) + " instead of " + std::to_string(tri * (i + 1) * W));
+    for (int r = 0; r < W; r++)
+        if (h[(size_t)16 + r] != 7.0 + r)
+            return fail("self-test: the grouped broadcast of rank " + std::to_string(r) + " delivered " + std::to_string(h[(size_t)16 + r]));
+    return true;
+}
+
 int comm_count(const Comm &c)
 {
     int n = 0;

@@ -50,6 +50,10 @@ bool comm_unique_id(uint8_t id_out[128], std::string *err);
 bool comm_init(Comm &c, const uint8_t id[128], int rank, int world, std::string *err);
 void comm_destroy(Comm &c);
 int comm_count(const Comm &c); // ranks RCCL itself reports for the communicator (ncclCommCount); 0 without one
+// first-contact self-test of the patterns a solve uses (comm.cpp): grouped send/recv on a second stream beside an all-reduce on
+// the main one, grouped broadcasts, a lone all-reduce; each watched and timed (us_out[3], microseconds); scratch: 16 + 2 x world
+// doubles of device memory
+bool comm_selftest(Comm &c, hipStream_t main, hipStream_t second, double *scratch, double us_out[3], std::string *err);
 
 // in-place sum of `count` doubles across ranks, stream-ordered
 bool comm_allreduce_sum(Comm &c, double *buf, int count, hipStream_t st, std::string *err);

@@ -76,6 +76,9 @@ struct femshell_ctx {
     femshell::DevBuf<double> agree;
     // halo exchange beside the interior SpMV (multi-rank contexts): second stream + hand-off events
     hipStream_t halo_stream = nullptr;
+    // first-contact self-test of femshell_comm_init (comm.cpp comm_selftest): microseconds of its three patterns
+    double comm_selftest_us[3] = {-1.0, -1.0, -1.0};
+    bool comm_selftest_done = false;
     hipEvent_t ev_p_ready = nullptr, ev_halo_done = nullptr;
     bool halo_overlap = false;
     femshell::MatConst mc{};

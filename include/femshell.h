@@ -281,6 +281,13 @@ int femshell_comm_unique_id(uint8_t id_out[128]);
 int femshell_comm_init(femshell_ctx *ctx, const uint8_t id[128]);
 /* ranks RCCL reports for this context's communicator (ncclCommCount); 0 when the context has none */
 int32_t femshell_comm_ranks(femshell_ctx *ctx);
+/* What femshell_comm_init checked on first contact, beyond the communicator itself: the communication patterns of a solve, once
+ * each with a known answer and under the watchdog -- out_us[0]: a grouped ncclSend / ncclRecv ring on the halo stream beside an
+ * ncclAllReduce of three words on the main stream (the reference's counterparts: PETSc's VecScatter halo and the MPI_Allreduce
+ * inside KSPSolve, fem-shell.cpp:138); out_us[1]: grouped ncclBroadcast, one per rank (build_solution_vector + broadcast,
+ * fem-shell.cpp:141, fem-shell_precice.cpp:277-280); out_us[2]: a lone all-reduce of three words.  Wall microseconds, enqueue
+ * to completion.  Returns 1 when the self-test ran (a communicator exists), 0 when not (single-rank context), < 0 on error. */
+int femshell_comm_selftest(femshell_ctx *ctx, double out_us[3]);
 
 /* ---- measurement ----------------------------------------------------------------- */
 

@@ -91,6 +91,10 @@ def main():
                 time.sleep(0.01)
             uid = np.load(uid_file)
         fs.comm_init(uid)
+        # first contact (femshell_comm_init): the grouped send/recv ring beside an all-reduce, the grouped broadcasts and a lone
+        # all-reduce came back with their known answers on every rank, or comm_init would have raised
+        st = fs.comm_selftest()
+        assert st is not None and all(v > 0.0 for v in st.values()), st
     fs.set_mesh(m.xyz, m.tri, m.quad)
     fs.set_dirichlet(m.dirichlet_mask())
     fs.set_loads(m.loads)

@@ -391,6 +391,7 @@ def test_rccl_can_be_loaded_on_the_gpu_box():
     assert uid.shape == (128,) and uid.any()
     fs = pkg.FemShell(0.3, 1.0, 1.0, rank=0, world_size=1)
     fs.comm_init(uid)  # no-op for one rank
+    assert fs.comm_selftest() is None  # (no communicator, nothing to test)
 
 
 def test_solve_through_a_one_rank_rccl_communicator(monkeypatch):
@@ -399,6 +400,10 @@ def test_solve_through_a_one_rank_rccl_communicator(monkeypatch):
     m = meshes.load_example("test_C_w_tA16")
     fs = pkg.FemShell(0.3, 10.92, 1.0, rank=0, world_size=1)
     fs.comm_init(pkg.comm_unique_id())
+    # first contact: femshell_comm_init ran the patterns of a solve once each with a known answer (real librccl, one rank:
+    # all-reduce on the main stream, grouped broadcast; the send/recv ring needs a second rank -- tests/test_multirank_gpu.py)
+    st = fs.comm_selftest()
+    assert st is not None and all(v > 0.0 for v in st.values()), st
     fs.set_mesh(m.xyz, m.tri, m.quad)
     fs.set_dirichlet(m.dirichlet_mask())
     fs.set_loads(m.loads)
