@@ -36,10 +36,10 @@ __global__ __launch_bounds__(192) void k_cheb_start(DeviceMatrix m, const double
 bool node_kernels();
 int node_grid(const DeviceMatrix &m);
 template <bool kD32>
-__global__ void k_cheb_start_node(DeviceMatrix m, const double *__restrict__ rin, double *__restrict__ d, double *x, double inv_theta,
+__global__ __launch_bounds__(64) void k_cheb_start_node(DeviceMatrix m, const double *__restrict__ rin, double *__restrict__ d, double *x, double inv_theta,
                                   int accumulate, const CgScalars *gate);
 template <bool kGather, int kVec>
-__global__ void k_cheb_step_node(DeviceMatrix m, const double *rin, const double *__restrict__ q, double *rout, double *__restrict__ d,
+__global__ __launch_bounds__(64) void k_cheb_step_node(DeviceMatrix m, const double *rin, const double *__restrict__ q, double *rout, double *__restrict__ d,
                                  double *__restrict__ x, double a, double c, const CgScalars *gate);
 
 void launch_cheb_start(const DeviceMatrix &m, const double *rin, double *d, double *x, double inv_theta, bool accumulate,

@@ -189,6 +189,10 @@ template <bool kT32> __device__ __forceinline__ void node_gather(const DeviceMat
         }
     }
 }
+// (MEASURED, round 5, and dropped: the vectors of k_cheb_step_node moved by the whole wave -- fully coalesced 16-byte accesses of the
+//  3 KB two adjacent slices occupy, turned into the node-per-lane view through LDS -- instead of three 16-byte words per lane at a
+//  stride of 48 bytes: 0.6393 -> 0.6350 s and 0.6319 -> 0.6308 s per solve of the 4M-triangle panel, alternating on one box.  The
+//  partial-line stores the counters show -- 312 MB written where 240 MB are due -- are not what bounds these kernels.)
 // the slices a 64-lane workgroup of a node kernel walks: pairs of slices, one per half-wave (the walk of k_spmv_sym)
 __host__ __device__ __forceinline__ int node_pairs(int n_slices) { return (n_slices + 1) >> 1; }
 
