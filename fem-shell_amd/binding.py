@@ -25,7 +25,7 @@ SYMBOLS = [
     "femshell_row_end", "femshell_comm_unique_id", "femshell_comm_init", "femshell_time_kernel",
     "femshell_sync", "femshell_pc_defaults", "femshell_set_preconditioner", "femshell_amg_levels", "femshell_amg_level",
     "femshell_amg_export", "femshell_residual", "femshell_comm_ranks", "femshell_amg_setup_stats", "femshell_amg_dense_stats", "femshell_amg_partition_info", "femshell_assembly_kernel",
-    "femshell_amg_cycle_bytes", "femshell_comm_selftest",
+    "femshell_amg_cycle_bytes", "femshell_comm_selftest", "femshell_comm_counters",
 ]
 
 
@@ -139,6 +139,7 @@ def load_library():
     L.femshell_amg_partition_info.argtypes = [vp, dp]
     L.femshell_assembly_kernel.argtypes = [vp]
     L.femshell_comm_selftest.argtypes = [vp, dp]
+    L.femshell_comm_counters.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32]
     L.femshell_amg_cycle_bytes.argtypes = [vp, dp, C.c_int32]
     L.femshell_amg_cycle_bytes.restype = C.c_int32
     for name in SYMBOLS:
@@ -307,6 +308,15 @@ class FemShell:
             _check(self._L.femshell_amg_level(self._h, l, C.byref(info)))
             out.append({f[0]: getattr(info, f[0]) for f in AmgLevelInfo._fields_})
         return out
+
+    def comm_counters(self, clear=False):
+        """Communication enqueued since the counters were cleared (femshell_comm_counters)."""
+        out = (C.c_int64 * 4)()
+        rc = self._L.femshell_comm_counters(self._h, out, 1 if clear else 0)
+        if rc < 0:
+            _check(rc)
+        return {"halo_exchanges_on_the_halo_stream": int(out[0]), "halo_exchanges_on_the_main_stream": int(out[1]),
+                "allreduces": int(out[2]), "row_gathers": int(out[3])}
 
     def comm_selftest(self):
         """Microseconds of the three communication patterns femshell_comm_init checked on first contact (None: no communicator)."""

@@ -60,6 +60,10 @@ struct AmgLevel {
     int32_t n_ghost = 0, n_global = 0;
     std::vector<int32_t> part;
     std::shared_ptr<LevelHalo> halo;
+    // ... and, for levels >= 1, the slices of the level operator ordered for the overlap of its products with their halo
+    // exchange: the n_interior slices that read owned columns only first (level 0: the plan's spmv_order)
+    DevBuf<int32_t> order;
+    int32_t n_interior = -1;
     DevBuf<double> bown;      // last row-partitioned level: the rank's rows of the restricted residual, all-gathered into the
                               // replicated level below
     DevBuf<double> ksums;     // three words for the all-reduce of a K-cycle coefficient step

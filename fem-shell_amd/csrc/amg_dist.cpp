@@ -671,6 +671,27 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
         }
         if (!pending) ell_to_bsr(g, h.data(), na_global, &N.hA);
     }
+    {
+        // slices of the coarse operator that read owned columns only first: its products run those while their halo is in flight
+        const int32_t ns = na_pad / kSliceNodes;
+        std::vector<int32_t> interior, boundary;
+        for (int32_t sl = 0; sl < ns; sl++) {
+            bool ghost = false;
+            for (int32_t nn = 0; nn < kSliceNodes && !ghost; nn++) {
+                const int32_t r = sl * kSliceNodes + nn;
+                if (r >= na) break;
+                for (int k = 0; k < eAc.count[(size_t)r] && !ghost; k++)
+                    ghost = eAc.cols[(size_t)(eAc.slice_base[(size_t)sl] + (int64_t)k * kSliceNodes + nn)] >= na_pad;
+            }
+            (ghost ? boundary : interior).push_back(sl);
+        }
+        N.n_interior = (int32_t)interior.size();
+        interior.insert(interior.end(), boundary.begin(), boundary.end());
+        local([&]() -> int {
+            FS_HIP(N.order.upload(interior, st));
+            return FEMSHELL_OK;
+        });
+    }
     adopt(N.A, eAc, dAc, vAc, nc_local);
     N.A.dm.n_ghost = N.n_ghost;
     N.pattern = HostEllPattern();

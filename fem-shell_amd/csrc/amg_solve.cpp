@@ -741,6 +741,63 @@ struct Cycle {
         if (rc || !dist(l)) return;
         rc = level_halo_exchange(c, *H.levels[(size_t)l]->halo, x, 6, st);
     }
+    // Products of a row-partitioned level >= 1 with the halo exchange of their input BESIDE the slices that read owned columns only
+    // (round 5; level 0 has done so since round 2, cg_driver.cpp spmv_with_halo): pack and grouped send/recv on the halo stream,
+    // the interior slices on the main stream meanwhile, the slices with ghost columns behind the exchange.  FEMSHELL_HALO_OVERLAP=0,
+    // or a level without the slice order: the blocking sequence halo(l, x) + product.
+    bool overlap(int l) const
+    {
+        const AmgLevel &L = *H.levels[(size_t)l];
+        return L.dist && l >= 1 && c->halo_overlap && c->halo_stream != nullptr && L.order.p != nullptr && L.n_interior >= 0;
+    }
+    // span(begin, count): launches the product over the slices order[begin, begin + count) of level l on the main stream
+    template <class Span> void overlapped(int l, double *x, Span span)
+    {
+        if (rc) return;
+        AmgLevel &L = *H.levels[(size_t)l];
+        const int ns = L.n_pad / kSliceNodes;
+        hipError_t e = hipEventRecord(c->ev_p_ready, st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->halo_stream, c->ev_p_ready, 0);
+        if (e == hipSuccess) {
+            rc = level_halo_exchange(c, *L.halo, x, 6, c->halo_stream);
+            if (rc) return;
+            e = hipEventRecord(c->ev_halo_done, c->halo_stream);
+        }
+        if (e == hipSuccess) {
+            span(0, L.n_interior);
+            e = hipStreamWaitEvent(st, c->ev_halo_done, 0);
+        }
+        if (e != hipSuccess) {
+            rc = set_err(FEMSHELL_ERR_HIP, std::string("multigrid cycle, overlapped halo exchange: ") + hipGetErrorString(e));
+            return;
+        }
+        span(L.n_interior, ns - L.n_interior);
+    }
+    // y = op(A x) of level l (>= 1 row-partitioned: overlapped when possible): first phase of a symmetric-storage product, or a
+    // full-storage product with epilogue e
+    void sym_phase1(int l, const DeviceMatrix &A, double *x, double *y)
+    {
+        if (overlap(l)) {
+            const int32_t *order = H.levels[(size_t)l]->order.p;
+            overlapped(l, x, [&](int b, int n) { (void)launch_spmv_span(A, x, y, nullptr, gate, order, b, n, 0, st); });
+            return;
+        }
+        halo(l, x);
+        launch_spmv_direct(A, x, y, nullptr, gate, st, has_lowp(A));
+    }
+    void full_product(int l, const DeviceMatrix &A, double *x, double *y, const SpmvEpilogue &e)
+    {
+        if (overlap(l)) {
+            const int32_t *order = H.levels[(size_t)l]->order.p;
+            overlapped(l, x, [&](int b, int n) { launch_spmv_epilogue_span(A, x, y, e, order, b, n, gate, st); });
+            return;
+        }
+        halo(l, x);
+        if (e.d_out != nullptr && e.start) launch_spmv_start(A, x, e.base_vec, y, e.d_out, e.xsol, e.c, gate, st);
+        else if (e.d_out != nullptr) launch_spmv_cheb(A, x, e.base_vec, y, e.d_out, e.xsol, e.a, e.c, gate, st);
+        else if (e.base_vec != nullptr) launch_spmv_axpy(A, x, y, e.base_vec, e.sign, gate, st);
+        else launch_spmv(A, x, y, nullptr, gate, st);
+    }
     // y = K x on level 0 of a row-partitioned context: the halo exchange beside the interior slices (symmetric storage with
     // defer: the direct part only, the consumer collects the transposed products)
     // (vals32: a smoothing product on the single-precision copy of K's values)
@@ -795,12 +852,17 @@ struct Cycle {
                 product0(L.d.p, L.q.p, A.symmetric != 0, &A, v32);
                 launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, A.symmetric != 0, v32);
             } else if (A.symmetric) { // first phase of the product; the step kernel collects the transposed products
-                halo(l, L.d.p);
-                launch_spmv_direct(A, L.d.p, L.q.p, nullptr, gate, st, has_lowp(A));
+                sym_phase1(l, A, L.d.p, L.q.p);
                 launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, true, v32);
             } else if (fused_cheb()) { // product and step in one launch (the small levels are bound by launch latency)
-                halo(l, d_cur);
-                launch_spmv_cheb(A, d_cur, rcur, L.r.p, d_next, x, L.cheb_a[k], L.cheb_c[k], gate, st);
+                SpmvEpilogue e;
+                e.base_vec = rcur;
+                e.sign = -1.0;
+                e.d_out = d_next;
+                e.xsol = x;
+                e.a = L.cheb_a[k];
+                e.c = L.cheb_c[k];
+                full_product(l, A, d_cur, L.r.p, e);
                 std::swap(d_cur, d_next);
             } else {
                 halo(l, L.d.p);
@@ -859,20 +921,24 @@ struct Cycle {
             launch_sub(r_base, L.q.p, L.r.p, 6ll * A.n_pad, st);
             return L.r.p;
         }
-        halo(l, dvec);
         if (A.symmetric) {
-            launch_spmv_direct(A, dvec, pb, nullptr, gate, st, has_lowp(A));
+            sym_phase1(l, A, dvec, pb);
             return gather();
         }
         // (dvec is L.d or L.q, never L.r; r_base may be L.r)
+        SpmvEpilogue e;
+        e.base_vec = r_base;
+        e.sign = -1.0;
         if (start) {
             // the product's Chebyshev epilogue as a first step: r = r_base - A dvec, d = inv_theta D^-1 r into the other direction vector
             double *d_out = dvec == L.d.p ? L.q.p : L.d.p;
-            launch_spmv_start(A, dvec, r_base, L.r.p, d_out, start_x, L.inv_theta, gate, st);
+            e.d_out = d_out;
+            e.xsol = start_x;
+            e.c = L.inv_theta;
+            e.start = 1;
             *d_started = d_out;
-        } else {
-            launch_spmv_axpy(A, dvec, L.r.p, r_base, -1.0, gate, st);
         }
+        full_product(l, A, dvec, L.r.p, e);
         return L.r.p;
     }
 
@@ -930,6 +996,17 @@ struct Cycle {
         smooth(l, b, x, false);
     }
 
+    // y = A_l x on the FP64 operator of level l (the K cycle's own products)
+    void krylov_product(int l, const DeviceMatrix &A, double *x, double *y)
+    {
+        if (A.symmetric) {
+            sym_phase1(l, A, x, y);
+            launch_sym_gather(A, y, nullptr, 1.0, gate, st);
+        } else {
+            full_product(l, A, x, y, SpmvEpilogue());
+        }
+    }
+
     // two steps of flexible CG on A_l x = b_l preconditioned by the cycle (Notay & Vassilevski's K cycle)
     void kcycle(int l)
     {
@@ -943,8 +1020,7 @@ struct Cycle {
             launch_kcyc_coefficients(phase, L.ksums.p, L.ks.p, gate, st);
         };
         cycle(l, L.b.p, L.c1.p);
-        halo(l, L.c1.p);
-        launch_spmv(A, L.c1.p, L.v1.p, nullptr, gate, st);
+        krylov_product(l, A, L.c1.p, L.v1.p);
         if (small) {
             launch_kcyc_step1_small(L.c1.p, L.v1.p, L.b.p, L.r2.p, n6, L.ks.p, gate, st);
         } else {
@@ -957,8 +1033,7 @@ struct Cycle {
             launch_kcyc_r2(L.b.p, L.v1.p, L.r2.p, n6, L.ks.p, gate, st);
         }
         cycle(l, L.r2.p, L.c2.p);
-        halo(l, L.c2.p);
-        launch_spmv(A, L.c2.p, L.v2.p, nullptr, gate, st);
+        krylov_product(l, A, L.c2.p, L.v2.p);
         if (small) {
             launch_kcyc_step2_small(L.c1.p, L.c2.p, L.v1.p, L.v2.p, L.r2.p, L.x.p, n6, L.ks.p, gate, st);
         } else {

@@ -407,6 +407,7 @@ int femshell_create(const femshell_config *cfg, femshell_ctx **out)
     if (dev < 0) FS_HIP(hipGetDevice(&dev));
     if (dev >= ndev) return set_err(FEMSHELL_ERR_NO_DEVICE, "femshell_create: device ordinal out of range");
     femshell_ctx *c = new femshell_ctx();
+    DevPool::get().context_opened();
     c->cfg = *cfg;
     c->device = dev;
     plan_progress_hook = &CommWatch::heartbeat; // (the phases of the symbolic plan are progress in the eyes of the watchdog)
@@ -470,6 +471,7 @@ int femshell_destroy(femshell_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    DevPool::get().context_closed(); // (the last context of the process: the kept blocks go back to the driver)
     return FEMSHELL_OK;
 }
 
@@ -513,12 +515,24 @@ int femshell_comm_init(femshell_ctx *c, const uint8_t id[128])
         // real multi-GPU run either passes here or names the pattern that failed -- or, stalled, is ended by the watchdog with the
         // pattern's name -- instead of hanging in its first solve.
         if (!c->halo_stream) FS_HIP(hipStreamCreateWithFlags(&c->halo_stream, hipStreamNonBlocking));
+        c->comm.second = c->halo_stream;
         DevBuf<double> scratch;
         FS_HIP(scratch.alloc((size_t)16 + 2 * (size_t)c->cfg.world_size));
         if (!comm_selftest(c->comm, c->stream, c->halo_stream, scratch.p, c->comm_selftest_us, &e)) return set_err(FEMSHELL_ERR_COMM, "femshell_comm_init: " + e);
         c->comm_selftest_done = true;
     }
     return FEMSHELL_OK;
+}
+
+int femshell_comm_counters(femshell_ctx *c, int64_t out[4], int32_t clear)
+{
+    if (!c || !out) return set_err(FEMSHELL_ERR_INVALID, "femshell_comm_counters: null argument");
+    out[0] = c->comm.halo_groups_second;
+    out[1] = c->comm.halo_groups_main;
+    out[2] = c->comm.allreduces;
+    out[3] = c->comm.gathers;
+    if (clear) c->comm.halo_groups_second = c->comm.halo_groups_main = c->comm.allreduces = c->comm.gathers = 0;
+    return c->comm.active() ? 1 : 0;
 }
 
 int femshell_comm_selftest(femshell_ctx *c, double out_us[3])
@@ -719,11 +733,12 @@ static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double 
     c->halo_overlap = false;
     if (c->comm.active() && !p.peers.empty() && p.n_interior_slices > 0 &&
         !(getenv("FEMSHELL_HALO_OVERLAP") && atoi(getenv("FEMSHELL_HALO_OVERLAP")) == 0)) {
-        if (!c->halo_stream) {
+        if (!c->halo_stream) { // (femshell_comm_init creates it for its self-test)
             FS_HIP(hipStreamCreateWithFlags(&c->halo_stream, hipStreamNonBlocking));
-            FS_HIP(hipEventCreateWithFlags(&c->ev_p_ready, hipEventDisableTiming));
-            FS_HIP(hipEventCreateWithFlags(&c->ev_halo_done, hipEventDisableTiming));
+            c->comm.second = c->halo_stream;
         }
+        if (!c->ev_p_ready) FS_HIP(hipEventCreateWithFlags(&c->ev_p_ready, hipEventDisableTiming));
+        if (!c->ev_halo_done) FS_HIP(hipEventCreateWithFlags(&c->ev_halo_done, hipEventDisableTiming));
         FS_HIP(c->spmv_order.upload(p.spmv_order, st));
         c->halo_overlap = true;
     }

@@ -293,6 +293,7 @@ void comm_destroy(Comm &c)
 
 bool comm_allreduce_sum(Comm &c, double *buf, int count, hipStream_t st, std::string *err)
 {
+    c.allreduces++;
     return check(g_api.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, static_cast<ncclComm_t>(c.comm), st),
                  "ncclAllReduce", err);
 }
@@ -302,6 +303,7 @@ bool comm_halo(Comm &c, const std::vector<HaloPeer> &peers, const std::vector<in
 {
     const int64_t w = width;
     ncclComm_t comm = static_cast<ncclComm_t>(c.comm);
+    (st == c.second && st != nullptr ? c.halo_groups_second : c.halo_groups_main)++;
     if (!check(g_api.GroupStart(), "ncclGroupStart", err)) return false;
     bool ok = true;
     for (size_t i = 0; i < peers.size() && ok; i++) {
@@ -321,6 +323,7 @@ bool comm_gather_rows(Comm &c, const double *x_owned, double *full, const std::v
                       const std::vector<int32_t> &row_end, hipStream_t st, std::string *err)
 {
     ncclComm_t comm = static_cast<ncclComm_t>(c.comm);
+    c.gathers++;
     if (!check(g_api.GroupStart(), "ncclGroupStart", err)) return false;
     bool ok = true;
     for (int r = 0; r < c.world && ok; r++) {
@@ -337,6 +340,7 @@ bool comm_gather_pieces(Comm &c, const double *mine, double *full, const std::ve
                         const std::vector<int64_t> &end, hipStream_t st, std::string *err)
 {
     ncclComm_t comm = static_cast<ncclComm_t>(c.comm);
+    c.gathers++;
     if (!check(g_api.GroupStart(), "ncclGroupStart", err)) return false;
     bool ok = true;
     for (int r = 0; r < c.world && ok; r++) {

@@ -25,6 +25,11 @@ struct Comm {
     void *comm = nullptr; // ncclComm_t
     int rank = 0, world = 1;
     bool active() const { return comm != nullptr; }
+    // what has been enqueued on this communicator since the counters were last cleared (femshell_comm_counters): grouped send/recv
+    // exchanges on the stream registered as `second` (the halo stream: they run beside kernels of the main stream) and on any
+    // other stream (they sit in the main stream's dependency chain), all-reduces, grouped broadcasts (row gathers)
+    hipStream_t second = nullptr;
+    int64_t halo_groups_second = 0, halo_groups_main = 0, allreduces = 0, gathers = 0;
 };
 
 // Hang protection of multi-rank contexts.  A rank that waits for a peer that never joined (ncclCommInitRank), or for a

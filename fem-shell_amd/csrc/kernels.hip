@@ -1066,6 +1066,24 @@ void launch_spmv_axpy_keep(const DeviceMatrix &m, const double *x, double *y, co
     spmv_dispatch(m, x, y, nullptr, s, nullptr, m.n_slices, slice_grid(m), st, base_vec, sign, e);
 }
 
+// a full-storage product with any of the epilogues above over the slices order[begin, begin + count) only: the interior / boundary
+// halves of a product whose halo exchange runs beside the interior half (row-partitioned multigrid levels, amg_solve.cpp)
+void launch_spmv_epilogue_span(const DeviceMatrix &m, const double *x, double *y, const SpmvEpilogue &e, const int32_t *order, int begin,
+                               int count, const CgScalars *s, hipStream_t st)
+{
+    if (count <= 0) return;
+    ChebEpilogue c;
+    c.d_out = e.d_out;
+    c.xsol = e.xsol;
+    c.a = e.a;
+    c.c = e.c;
+    c.start = e.start;
+    c.prod_out = e.prod_out;
+    c.prod_float = e.prod_float ? 1 : 0;
+    const int g = 8 * ((count + 7) / 8), cap = slice_grid(m);
+    spmv_dispatch(m, x, y, nullptr, s, order + begin, count, g < cap ? g : cap, st, e.base_vec, e.sign, c);
+}
+
 int span_grid(const DeviceMatrix &m, int count)
 {
     const int g = 8 * ((count + 7) / 8), cap = slice_grid(m);

@@ -194,6 +194,20 @@ void launch_sym_gather(const DeviceMatrix &m, double *y, const double *base_vec,
                        bool q32 = false, double *out = nullptr);
 // r = b - K x with double-double products and row sums (accurate residual for the residual replacement; r != x)
 void launch_residual_dd(const DeviceMatrix &m, const double *x, const double *b, double *r, hipStream_t st);
+// what a full-storage product does with its result besides storing it (the epilogues of launch_spmv_axpy / _cheb / _start /
+// _axpy_keep as one description), for launch_spmv_epilogue_span
+struct SpmvEpilogue {
+    const double *base_vec = nullptr; // y = base_vec + sign * K x (nullptr: y = K x)
+    double sign = 1.0;
+    double *d_out = nullptr, *xsol = nullptr; // Chebyshev step: d_out = a x + c D^-1 y, xsol += d_out (start != 0: the first step)
+    double a = 0.0, c = 0.0;
+    int start = 0;
+    double *prod_out = nullptr;       // K x itself as well (as floats: prod_float)
+    bool prod_float = false;
+};
+// the product with such an epilogue over the slices order[begin, begin + count) only
+void launch_spmv_epilogue_span(const DeviceMatrix &m, const double *x, double *y, const SpmvEpilogue &e, const int32_t *order, int begin,
+                               int count, const CgScalars *s, hipStream_t st);
 // the same over the slices order[begin, begin+count) only (interior / boundary halves of an overlapped
 // halo exchange); the partial sums go to partials[partial_offset ...]; returns the number written
 int launch_spmv_span(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,

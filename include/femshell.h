@@ -288,6 +288,13 @@ int32_t femshell_comm_ranks(femshell_ctx *ctx);
  * fem-shell.cpp:141, fem-shell_precice.cpp:277-280); out_us[2]: a lone all-reduce of three words.  Wall microseconds, enqueue
  * to completion.  Returns 1 when the self-test ran (a communicator exists), 0 when not (single-rank context), < 0 on error. */
 int femshell_comm_selftest(femshell_ctx *ctx, double out_us[3]);
+/* Communication this context has enqueued since the counters were last cleared: out[0] = grouped send/recv exchanges on the halo
+ * stream (they run beside the interior slices of the product that needs them), out[1] = such exchanges on the main stream (in
+ * the dependency chain: restrictions, prolongations, setup), out[2] = all-reduces, out[3] = grouped broadcasts (row gathers).
+ * clear != 0 resets them.  What the reference leaves to PETSc (VecScatter, MPI_Allreduce inside KSPSolve, fem-shell.cpp:138) is
+ * countable here: tests hold the per-iteration budget of the row-partitioned multigrid to these numbers.  Returns 1 with a
+ * communicator, 0 without, < 0 on error. */
+int femshell_comm_counters(femshell_ctx *ctx, int64_t out[4], int32_t clear);
 
 /* ---- measurement ----------------------------------------------------------------- */
 

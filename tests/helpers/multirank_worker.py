@@ -144,7 +144,13 @@ def main():
         extra["residual_history"] = fs.residual_history()
     # a second solve on the same context with doubled loads (the coupled program re-solves every coupling iteration)
     fs.set_loads(2.0 * m.loads)
+    if world > 1:
+        fs.comm_counters(clear=True)  # (the second solve reuses the hierarchy: what it enqueues is the solve alone, no setup)
     u2, info2 = fs.solve(rtol=1e-11, max_it=100000)
+    if world > 1:
+        cc = fs.comm_counters()
+        extra["comm_solve2"] = np.array([cc["halo_exchanges_on_the_halo_stream"], cc["halo_exchanges_on_the_main_stream"],
+                                         cc["allreduces"], cc["row_gathers"]])
     np.savez(out_file, u=u, iterations=info["iterations"], converged=info["converged"], begin=b, end=e,
              true_res=info["true_rel_residual"], u2=u2, converged2=info2["converged"], iterations2=info2["iterations"],
              levels=info["amg_levels"], **extra)

@@ -282,6 +282,36 @@ def test_halo_overlap_and_single_stream_exchange_agree(tmp_path):
     assert err < 1e-8, err
 
 
+@pytest.mark.parametrize("world,dist_min", [(2, 100), (3, 100)])
+def test_multigrid_halo_exchanges_of_split_coarse_levels_run_beside_the_interior_slices(world, dist_min, tmp_path):
+    """Round 5 (csrc/amg_solve.cpp Cycle::overlapped): the products of a row-partitioned level >= 1 -- smoothing products,
+    residual increments, the K cycle's own products -- send the ghost entries of their input on the halo stream while the
+    slices that read owned columns only are multiplied, as level 0 has done since round 2.  Same rows times the same numbers:
+    the solution is the one of the blocking exchange (FEMSHELL_HALO_OVERLAP=0) up to the order of level 0's partial sums.  The counters of the second solve
+    (hierarchy reused: the solve alone) show where the exchanges went: with the overlap only the transfers' exchanges (a
+    restriction needs the residual, a prolongation the coarse correction of the neighbours' nodes along the cut) stay in the
+    main stream's dependency chain."""
+    (tmp_path / "on").mkdir()
+    (tmp_path / "off").mkdir()
+    env = {"FEMSHELL_AMG_DIST_MIN": str(dist_min)}
+    on = run_ranks(world, "panel", tmp_path / "on", pc="amg", overlap=True, extra_env=env)
+    off = run_ranks(world, "panel", tmp_path / "off", pc="amg", overlap=False, extra_env=env)
+    for a, b in zip(on, off):
+        assert a["converged"] == 1 and b["converged"] == 1
+        assert abs(int(a["iterations"]) - int(b["iterations"])) <= 1 and abs(int(a["iterations2"]) - int(b["iterations2"])) <= 1
+        # (the p.q partial sums of level 0 are added in another order when its slices run as two spans: rounding, nothing else)
+        assert np.linalg.norm(a["u"] - b["u"]) <= 1e-10 * np.linalg.norm(b["u"])
+        assert np.linalg.norm(a["u2"] - b["u2"]) <= 1e-10 * np.linalg.norm(b["u2"])
+    second, main, allred, gathers = [float(v) / int(on[0]["iterations2"]) for v in on[0]["comm_solve2"]]
+    second_off, main_off, allred_off, gathers_off = [float(v) / int(off[0]["iterations2"]) for v in off[0]["comm_solve2"]]
+    assert second_off == 0.0 and main_off > 20.0, off[0]["comm_solve2"]    # (two split levels: every exchange blocks)
+    assert abs((second + main) - main_off) < 0.5                            # the same exchanges ...
+    assert main <= 12.5 and second >= 2.0 * main, on[0]["comm_solve2"]      # ... of which the products' now travel beside kernels
+    assert abs(allred - allred_off) < 0.5 and abs(gathers - gathers_off) < 0.5
+    print("per outer iteration on %d ranks: %.1f halo exchanges on the halo stream, %.1f on the main stream, %.1f all-reduces, %.1f row gathers"
+          % (world, second, main, allred, gathers))
+
+
 def test_classic_and_single_reduction_recurrences_agree_across_ranks(tmp_path):
     # multi-rank solves default to the single-reduction recurrence (one all-reduce of three sums per iteration);
     # the classic two-reduction recurrence stays available and must give the same answer
