@@ -745,6 +745,9 @@ __global__ __launch_bounds__(256, 4) void k_dense_update(double *__restrict__ D,
             }
     // K = 128 in four chunks of 32 (row stride 34 doubles: conflict-free): 35 KB of LDS per workgroup, four per CU
     const double *wsrc = Wp + (int64_t)(i * kNB) * kSW, *csrc = Cp + (int64_t)(j * kNB) * kSW;
+    // (MEASURED, round 5, and dropped: the next chunk's operands fetched into registers while the matrix cores work on this chunk's
+    //  -- eight 16-byte words per thread.  With the look-ahead's pivot code in the same kernel the 128 registers of four workgroups
+    //  per CU do not hold them: 480 bytes of scratch per lane, 25.0 ms instead of 13.7 ms.)
     for (int h = 0; h < kSW / kHalf; h++) {
         if (h) __syncthreads(); // the previous chunk's readers are through
         for (int e = tid; e < kNB * kHalf / 2; e += 256) { // 16-byte words: 16 per row and chunk
@@ -767,6 +770,143 @@ __global__ __launch_bounds__(256, 4) void k_dense_update(double *__restrict__ D,
                 tile[(int64_t)r * ld + c] = -acc[ti][tj][g];
             }
     done();
+}
+
+// ---- the trailing update on 128 x 128 tiles (round 5) ---------------------------------------------------------------------------
+// One workgroup per lower 128 x 128 tile of the triangle (= 2 x 2 of the 64-tiles above; the sweep's pivot block is exactly one
+// such tile), every wave a 64 x 64 quadrant = 4 x 4 matrix-core tiles: per step of four columns of K a wave reads eight operands
+// from LDS and issues sixteen v_mfma_f64_16x16x4_f64 where the 64 x 64 kernel reads four for four, and the workgroup reads its
+// two 128 x 128 operand panels and its tile once for 4.2 MFLOP -- 8.2 flop per byte where the 64-tiles have 5.5.  70 KB of LDS
+// per workgroup (operands in chunks of 32 columns, row stride 34), two workgroups per CU, 128 accumulator registers.
+// Diagonal tiles compute the three quadrants of the lower triangle (the wave of the upper right one stages and waits).
+// Look-ahead: workgroup 0 takes the next pivot block's tile -- ONE tile now -- and workgroup 1 inverts it once it is in place.
+template <int kDepth, int kStride>
+__device__ __forceinline__ void quadrant64_xyt(const double *Xs, const double *Ys, int r0, int c0, int lane, v4d acc[4][4])
+{
+    const int rr = lane & 15, kq = lane >> 4;
+#pragma unroll 2
+    for (int k = 0; k < kDepth; k += 4) {
+        double a[4], b[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            a[t] = Xs[(r0 + 16 * t + rr) * kStride + k + kq];
+            b[t] = Ys[(c0 + 16 * t + rr) * kStride + k + kq];
+        }
+#pragma unroll
+        for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+            for (int tj = 0; tj < 4; tj++) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+    }
+}
+
+template <bool kLookAhead>
+__global__ __launch_bounds__(256, 2) void k_dense_update128(double *__restrict__ D, int64_t ld, int K, const double *__restrict__ B,
+                                                            const double *__restrict__ Cp, const double *__restrict__ Wp, int stiles,
+                                                            DenseLookAhead la)
+{
+    extern __shared__ double lds_big[]; // 2 x 128 x 34 doubles
+    double *Ws = lds_big, *Cs = lds_big + kSW * kLdh;
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    bool ahead_tile = false;
+    if (kLookAhead && la.on) {
+        const int K1 = K + 1, t_a = K1 * (K1 + 1) / 2 + K1; // the next pivot block's tile
+        if (blockIdx.x == 1) {
+            // ---- the pivot workgroup (see k_dense_update: bounded wait for the workgroup that precedes it in dispatch order)
+            __shared__ int ok;
+            if (tid == 0) {
+                int spins = 0;
+                while (spins < la.spin_limit && __hip_atomic_load(la.flag + K, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < 1u) {
+                    __builtin_amdgcn_s_sleep(8);
+                    spins++;
+                }
+                ok = spins < la.spin_limit ? 1 : 0;
+                if (!ok) la.status[0] = 2;
+            }
+            __syncthreads();
+            if (!ok) return;
+            __threadfence();
+            pivot_block_lean(D, ld, K + 1, la.diag0, la.B_next, la.status, la.scratch, lds_big);
+            return;
+        }
+        if (blockIdx.x == 0) {
+            t = t_a;
+            ahead_tile = true;
+        } else {
+            t = blockIdx.x - 1; // 1 .. stiles-1; whoever lands on t_a takes the tile of the workgroup that left (0)
+            if (t == t_a) t = 0;
+        }
+        if (t >= stiles) return;
+    }
+    int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= t) I++;
+    while (I * (I + 1) / 2 > t) I--;
+    const int J = t - I * (I + 1) / 2;
+    double *tile = D + (int64_t)(I * kSW) * ld + J * kSW;
+    const bool ki = I == K, kj = J == K;
+    if (ki && kj) { // the pivot block: -B
+        for (int e = tid; e < kSW * kSW; e += 256) tile[(int64_t)(e / kSW) * ld + e % kSW] = -B[e];
+        return;
+    }
+    if (kj) { // below the pivot block: A_I,K <- W_I
+        for (int e = tid; e < kSW * kSW; e += 256) tile[(int64_t)(e / kSW) * ld + e % kSW] = Wp[((int64_t)I * kSW + e / kSW) * kSW + e % kSW];
+        return;
+    }
+    if (ki) { // left of the pivot block: A_K,J <- W_J^T, 64 rows of W_J at a time through LDS (row stride 65)
+        constexpr int L = kNB + 1;
+        for (int half = 0; half < 2; half++) {
+            if (half) __syncthreads();
+            for (int e = tid; e < kNB * kSW; e += 256) // rows [64 half, 64 half + 64) of W_J, all 128 columns
+                lds_big[(e % kSW) * L + e / kSW] = Wp[((int64_t)J * kSW + kNB * half + e / kSW) * kSW + e % kSW];
+            __syncthreads();
+            for (int e = tid; e < kSW * kNB; e += 256) // tile row r (= column of W), columns [64 half, 64 half + 64)
+                tile[(int64_t)(e / kNB) * ld + kNB * half + e % kNB] = lds_big[(e / kNB) * L + e % kNB];
+        }
+        return;
+    }
+    const int wave = tid >> 6, lane = tid & 63, r0 = kNB * (wave >> 1), c0 = kNB * (wave & 1);
+    const bool idle = I == J && wave == 1; // the quadrant above the diagonal of a diagonal tile
+    v4d acc[4][4];
+    if (!idle) {
+#pragma unroll
+        for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+            for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int r = r0 + 16 * ti + (lane >> 4) + 4 * g, c = c0 + 16 * tj + (lane & 15);
+                    acc[ti][tj][g] = -tile[(int64_t)r * ld + c]; // accumulate W C^T - A, store its negative
+                }
+    }
+    const double *wsrc = Wp + (int64_t)(I * kSW) * kSW, *csrc = Cp + (int64_t)(J * kSW) * kSW;
+    for (int h = 0; h < kSW / kHalf; h++) {
+        if (h) __syncthreads(); // the previous chunk's readers are through
+        for (int e = tid; e < kSW * kHalf / 2; e += 256) { // 16-byte words: 16 per row and chunk, 128 rows
+            const int r = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));
+            const double2 wv = *reinterpret_cast<const double2 *>(wsrc + r * kSW + h * kHalf + k);
+            const double2 cv = *reinterpret_cast<const double2 *>(csrc + r * kSW + h * kHalf + k);
+            *reinterpret_cast<double2 *>(Ws + r * kLdh + k) = wv;
+            *reinterpret_cast<double2 *>(Cs + r * kLdh + k) = cv;
+        }
+        __syncthreads();
+        if (!idle) quadrant64_xyt<kHalf, kLdh>(Ws, Cs, r0, c0, lane, acc);
+    }
+    if (!idle) {
+#pragma unroll
+        for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+            for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int r = r0 + 16 * ti + (lane >> 4) + 4 * g, c = c0 + 16 * tj + (lane & 15);
+                    tile[(int64_t)r * ld + c] = -acc[ti][tj][g];
+                }
+    }
+    if (ahead_tile) {
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(la.flag + K, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // out (n x ldo, both triangles) <- -(lower triangle of D)
@@ -876,6 +1016,18 @@ int dense_inverse_once(femshell_ctx *c, const Bsr &A, bool single_precision, Dev
     // bound can expire.  The kernel then marks status 2 and amg_dense_inverse_device runs the whole inverse again with the
     // pivot as a launch of its own (slower, same numbers).
     const bool panel_split = !(getenv("FEMSHELL_AMG_DENSE_PANEL_SPLIT") && atoi(getenv("FEMSHELL_AMG_DENSE_PANEL_SPLIT")) == 0);
+    // FEMSHELL_AMG_DENSE_TILE=128: the trailing update on 128 x 128 tiles (k_dense_update128; default: 64 x 64, four workgroups
+    // per CU).  MEASURED, round 5, 7386 dofs, alternating on one box: 14.1 ms against 13.7 ms, 192 against 177 us per sweep --
+    // half the operand traffic and four times the matrix instructions per LDS read buy nothing: both kernels leave the matrix
+    // pipe idle half of the time (SQ_VALU_MFMA_BUSY_CYCLES 0.48, profiles/r05_pmc_mfma.json) behind their synchronous operand
+    // staging, and the larger tile has 1711 workgroups for 512 slots (a fourth, nearly empty round).  The measured alternative stays.
+    const bool big_tiles = getenv("FEMSHELL_AMG_DENSE_TILE") && atoi(getenv("FEMSHELL_AMG_DENSE_TILE")) == 128;
+    const int stiles = ns * (ns + 1) / 2;
+    const size_t lds_big_bytes = 2 * (size_t)kSW * kLdh * sizeof(double);
+    if (big_tiles) {
+        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_update128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big_bytes));
+        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_update128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big_bytes));
+    }
     for (int K = 0; K < ns; K++) {
         double *Bk = B.p + (size_t)(K & 1) * kSW * kSW;
         if (K == 0 || !lookahead)
@@ -892,8 +1044,14 @@ int dense_inverse_once(femshell_ctx *c, const Bsr &A, bool single_precision, Dev
             la.flag = la_flags.p;
             if (const char *e = getenv("FEMSHELL_AMG_DENSE_LOOKAHEAD_SPINS")) la.spin_limit = atoi(e);
         }
-        if (la.on) hipLaunchKernelGGL(k_dense_update<true>, dim3(tiles + 1), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p, tiles, la);
-        else hipLaunchKernelGGL(k_dense_update<false>, dim3(tiles), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p, tiles, la);
+        if (big_tiles) {
+            if (la.on) hipLaunchKernelGGL(k_dense_update128<true>, dim3(stiles + 1), dim3(256), lds_big_bytes, st, D.p, ld, K, Bk, Cp.p, Wp.p, stiles, la);
+            else hipLaunchKernelGGL(k_dense_update128<false>, dim3(stiles), dim3(256), lds_big_bytes, st, D.p, ld, K, Bk, Cp.p, Wp.p, stiles, la);
+        } else if (la.on) {
+            hipLaunchKernelGGL(k_dense_update<true>, dim3(tiles + 1), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p, tiles, la);
+        } else {
+            hipLaunchKernelGGL(k_dense_update<false>, dim3(tiles), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p, tiles, la);
+        }
     }
     const int64_t ldo = (n + 1) / 2 * 2;
     const unsigned gfin = (unsigned)(((int64_t)n * ldo + 255) / 256);

@@ -485,9 +485,11 @@ def test_dense_inverse_on_the_matrix_cores_equals_the_host_inverse(monkeypatch, 
     precision (FEMSHELL_AMG_DENSE_F32=1) the preconditioner changes in the 8th digit and the iteration count by a step."""
     m, mat = _make("panel", 48)
     out = {}
-    for path, dmin in (("host", "100000"), ("device", "0")):
+    for path, dmin in (("host", "100000"), ("device", "0"), ("device128", "0")):
         monkeypatch.setenv("FEMSHELL_AMG_DENSE_DEVICE_MIN", dmin)
         monkeypatch.setenv("FEMSHELL_AMG_DENSE_F32", str(f32))
+        # (device128: the trailing update on 128 x 128 tiles, the measured alternative of round 5 -- same inverse)
+        monkeypatch.setenv("FEMSHELL_AMG_DENSE_TILE", "128" if path == "device128" else "64")
         fs = _context(m, mat)
         fs.set_preconditioner("amg", coarsest_nodes=300)
         u, info = fs.solve(rtol=1e-12, max_it=500)
@@ -495,7 +497,7 @@ def test_dense_inverse_on_the_matrix_cores_equals_the_host_inverse(monkeypatch, 
         st = fs.amg_dense_stats()
         assert info["converged"] == 1 and len(lv) == 2 and 200 < lv[-1]["n_nodes"] <= 300
         out[path] = (u, info["iterations"], st, lv[-1]["n_nodes"])
-        if path == "device":
+        if path.startswith("device"):
             # the inverse the matrix cores computed against the CHECKER's coarsest operator (oracle/amg_oracle.py builds its own
             # hierarchy from the exported K), not only against the product's host inverse
             rg, cg, vg, Fg = fs.export_bsr()
@@ -507,6 +509,7 @@ def test_dense_inverse_on_the_matrix_cores_equals_the_host_inverse(monkeypatch, 
             defect = np.abs(Ac @ inv - np.eye(len(Ac))).max()
             assert defect <= (1e-9 if not f32 else 2e-4), defect
         fs.close()
+    assert out["device128"][1] == out["device"][1] and np.linalg.norm(out["device128"][0] - out["device"][0]) <= 1e-12 * np.linalg.norm(out["device"][0])
     assert out["host"][2]["n"] == 0 and out["device"][2]["n"] == 6 * out["device"][3]
     assert out["device"][2]["dropped_directions"] == 0 and out["device"][2]["mfma_flops_issued"] > 0
     assert abs(out["host"][1] - out["device"][1]) <= (2 if f32 else 1), (out["host"][1], out["device"][1])
