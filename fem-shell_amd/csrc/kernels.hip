@@ -11,6 +11,8 @@
 #include "kernels.hpp"
 #include "plan.hpp"
 #include "device_common.hpp"
+
+#include <type_traits>
 #include "assemble_kernel.hpp"
 
 #include <cstdlib>
@@ -305,54 +307,50 @@ void launch_block_jacobi(const DeviceMatrix &m, hipStream_t st)
 // =====================================================================================
 // kChunk block slots are handled together: all their K loads are issued back to back; the loads of the first
 // chunk are issued before the x staging (spmv_load), so that their latency overlaps it.
-template <int kChunk> struct SpmvChunk {
-    double2 a[kChunk][3];
-};
 // (kF32: the words come from a single-precision copy of the values in the same layout, v32 -- smoothing products of the
-//  multigrid cycle only; the arithmetic stays FP64)
+//  multigrid cycle only; the arithmetic stays FP64.  The chunk keeps the words AS LOADED and converts them where they are used:
+//  until round 5 spmv_load converted to double on the spot, so the wave waited for its loads before it began to stage x -- the
+//  float variant of the product took 16.3 us on the 584-slice level of the 4M hierarchy where the FP64 one took 11.4.)
+template <int kChunk, bool kF32 = false> struct SpmvChunk {
+    typedef float v2f_ __attribute__((ext_vector_type(2)));
+    typedef double v2d_ __attribute__((ext_vector_type(2)));
+    typedef typename std::conditional<kF32, v2f_, v2d_>::type Word;
+    Word a[kChunk][3];
+};
 template <int kChunk, bool kF32 = false>
-__device__ __forceinline__ void spmv_load(SpmvChunk<kChunk> &c, const double2 *__restrict__ v, int k0, int W,
+__device__ __forceinline__ void spmv_load(SpmvChunk<kChunk, kF32> &c, const double2 *__restrict__ v, int k0, int W,
                                           const float2 *__restrict__ v32 = nullptr)
 {
+    typedef typename SpmvChunk<kChunk, kF32>::Word Word;
 #pragma unroll
     for (int q = 0; q < kChunk; q++) {
-        if (kF32 && k0 + q < W) {
-            typedef float v2f_ __attribute__((ext_vector_type(2)));
-            const v2f_ *vv = reinterpret_cast<const v2f_ *>(v32 + (size_t)(k0 + q) * 3 * kSliceRows);
-            const v2f_ w0 = __builtin_nontemporal_load(vv), w1 = __builtin_nontemporal_load(vv + kSliceRows),
-                       w2 = __builtin_nontemporal_load(vv + 2 * kSliceRows);
-            c.a[q][0] = make_double2((double)w0.x, (double)w0.y);
-            c.a[q][1] = make_double2((double)w1.x, (double)w1.y);
-            c.a[q][2] = make_double2((double)w2.x, (double)w2.y);
-        } else if (k0 + q < W) {
-            typedef double v2d __attribute__((ext_vector_type(2)));
-            const v2d *vv = reinterpret_cast<const v2d *>(v + (size_t)(k0 + q) * 3 * kSliceRows);
+        if (k0 + q < W) {
             // K is read once per launch: non-temporal loads leave the caches to x
-            const v2d w0 = __builtin_nontemporal_load(vv), w1 = __builtin_nontemporal_load(vv + kSliceRows),
-                      w2 = __builtin_nontemporal_load(vv + 2 * kSliceRows);
-            c.a[q][0] = make_double2(w0.x, w0.y);
-            c.a[q][1] = make_double2(w1.x, w1.y);
-            c.a[q][2] = make_double2(w2.x, w2.y);
+            const Word *vv = kF32 ? reinterpret_cast<const Word *>(v32 + (size_t)(k0 + q) * 3 * kSliceRows)
+                                  : reinterpret_cast<const Word *>(v + (size_t)(k0 + q) * 3 * kSliceRows);
+            c.a[q][0] = __builtin_nontemporal_load(vv);
+            c.a[q][1] = __builtin_nontemporal_load(vv + kSliceRows);
+            c.a[q][2] = __builtin_nontemporal_load(vv + 2 * kSliceRows);
         } else {
 #pragma unroll
-            for (int t = 0; t < 3; t++) c.a[q][t] = make_double2(0.0, 0.0);
+            for (int t = 0; t < 3; t++) c.a[q][t] = (Word){0, 0};
         }
     }
 }
-template <int kChunk>
-__device__ __forceinline__ double spmv_fma(const SpmvChunk<kChunk> &c, const double2 *__restrict__ xs, int k0, int W, double acc)
+template <int kChunk, bool kF32>
+__device__ __forceinline__ double spmv_fma(const SpmvChunk<kChunk, kF32> &c, const double2 *__restrict__ xs, int k0, int W, double acc)
 {
 #pragma unroll
     for (int q = 0; q < kChunk; q++) {
         if (k0 + q < W) {
             const double2 *xx = xs + (size_t)(k0 + q) * 3 * kSliceNodes;
             const double2 x0 = xx[0], x1 = xx[1], x2 = xx[2];
-            acc += c.a[q][0].x * x0.x;
-            acc += c.a[q][0].y * x0.y;
-            acc += c.a[q][1].x * x1.x;
-            acc += c.a[q][1].y * x1.y;
-            acc += c.a[q][2].x * x2.x;
-            acc += c.a[q][2].y * x2.y;
+            acc += (double)c.a[q][0].x * x0.x;
+            acc += (double)c.a[q][0].y * x0.y;
+            acc += (double)c.a[q][1].x * x1.x;
+            acc += (double)c.a[q][1].y * x1.y;
+            acc += (double)c.a[q][2].x * x2.x;
+            acc += (double)c.a[q][2].y * x2.y;
         }
     }
     return acc;
@@ -398,8 +396,11 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
             const double2 *v = reinterpret_cast<const double2 *>(m.vals + base * 36) + (size_t)p0 * 3 * kSliceRows + t;
             const int32_t *cols = m.cols + base + (int64_t)p0 * kSliceNodes;
             const float2 *v32 = kF32 ? reinterpret_cast<const float2 *>(m.vals32 + base * 36) + (size_t)p0 * 3 * kSliceRows + t : nullptr;
-            SpmvChunk<kChunk> ch;
+            // (the float variant keeps two chunks in flight: the second chunk's words travel during the staging of x as well, every
+            //  later chunk while its predecessor is multiplied -- 96 registers of words; the FP64 variant has room for one)
+            SpmvChunk<kChunk, kF32> ch, ch2;
             spmv_load<kChunk, kF32>(ch, v, 0, Wp, v32);
+            if (kF32 && kChunk < Wp) spmv_load<kChunk, kF32>(ch2, v, kChunk, Wp, v32);
             __syncthreads(); // the previous panel's readers are done with xs_all
             for (int e = t; e < Wp * kSliceNodes; e += kSliceRows) {
                 const double2 *xv = x2 + 3 * (int64_t)cols[e];
@@ -409,10 +410,22 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
                 xs_all[3 * e + 2] = x2w;
             }
             __syncthreads();
-            acc = spmv_fma<kChunk>(ch, xs, 0, Wp, acc);
-            for (int k0 = kChunk; k0 < Wp; k0 += kChunk) {
-                spmv_load<kChunk, kF32>(ch, v, k0, Wp, v32);
-                acc = spmv_fma<kChunk>(ch, xs, k0, Wp, acc);
+            acc = spmv_fma<kChunk, kF32>(ch, xs, 0, Wp, acc);
+            if (kF32) {
+                // slots in ascending order as before: ch (0), ch2 (kChunk), ch (2 kChunk), ch2 (3 kChunk), ...
+                for (int k0 = kChunk; k0 < Wp; k0 += 2 * kChunk) {
+                    if (k0 + kChunk < Wp) spmv_load<kChunk, kF32>(ch, v, k0 + kChunk, Wp, v32);
+                    acc = spmv_fma<kChunk, kF32>(ch2, xs, k0, Wp, acc);
+                    if (k0 + kChunk < Wp) {
+                        if (k0 + 2 * kChunk < Wp) spmv_load<kChunk, kF32>(ch2, v, k0 + 2 * kChunk, Wp, v32);
+                        acc = spmv_fma<kChunk, kF32>(ch, xs, k0 + kChunk, Wp, acc);
+                    }
+                }
+            } else {
+                for (int k0 = kChunk; k0 < Wp; k0 += kChunk) {
+                    spmv_load<kChunk, kF32>(ch, v, k0, Wp, v32);
+                    acc = spmv_fma<kChunk, kF32>(ch, xs, k0, Wp, acc);
+                }
             }
             // x[row] is in LDS during the first panel: slot 0 is the diagonal block, its column is the lane's own node
             if (p0 == 0 && partials != nullptr) xw = xs[t >> 6]; // word (t / 32) / 2 of the node's six entries
