@@ -317,7 +317,7 @@ template <int kChunk, bool kF32 = false> struct SpmvChunk {
     typedef typename std::conditional<kF32, v2f_, v2d_>::type Word;
     Word a[kChunk][3];
 };
-template <int kChunk, bool kF32 = false>
+template <int kChunk, bool kF32 = false, bool kNT = true>
 __device__ __forceinline__ void spmv_load(SpmvChunk<kChunk, kF32> &c, const double2 *__restrict__ v, int k0, int W,
                                           const float2 *__restrict__ v32 = nullptr)
 {
@@ -325,12 +325,20 @@ __device__ __forceinline__ void spmv_load(SpmvChunk<kChunk, kF32> &c, const doub
 #pragma unroll
     for (int q = 0; q < kChunk; q++) {
         if (k0 + q < W) {
-            // K is read once per launch: non-temporal loads leave the caches to x
+            // an operator that is read once per launch and does not fit the caches: non-temporal loads leave them to x (kNT);
+            // operators of a few ten megabytes -- the coarse levels of the cycle, multiplied again a few microseconds later --
+            // are read with plain loads and found in the L2 / the Infinity Cache by the next product
             const Word *vv = kF32 ? reinterpret_cast<const Word *>(v32 + (size_t)(k0 + q) * 3 * kSliceRows)
                                   : reinterpret_cast<const Word *>(v + (size_t)(k0 + q) * 3 * kSliceRows);
-            c.a[q][0] = __builtin_nontemporal_load(vv);
-            c.a[q][1] = __builtin_nontemporal_load(vv + kSliceRows);
-            c.a[q][2] = __builtin_nontemporal_load(vv + 2 * kSliceRows);
+            if (kNT) {
+                c.a[q][0] = __builtin_nontemporal_load(vv);
+                c.a[q][1] = __builtin_nontemporal_load(vv + kSliceRows);
+                c.a[q][2] = __builtin_nontemporal_load(vv + 2 * kSliceRows);
+            } else {
+                c.a[q][0] = vv[0];
+                c.a[q][1] = vv[kSliceRows];
+                c.a[q][2] = vv[2 * kSliceRows];
+            }
         } else {
 #pragma unroll
             for (int t = 0; t < 3; t++) c.a[q][t] = (Word){0, 0};
@@ -369,7 +377,7 @@ struct ChebEpilogue {
     int start = 0;
 };
 
-template <int kChunk, bool kF32 = false>
+template <int kChunk, bool kF32 = false, bool kNT = true>
 __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__restrict__ x,
                                               double *__restrict__ y, double *__restrict__ partials,
                                               const CgScalars *s, const int32_t *__restrict__ order, int count,
@@ -399,8 +407,8 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
             // (the float variant keeps two chunks in flight: the second chunk's words travel during the staging of x as well, every
             //  later chunk while its predecessor is multiplied -- 96 registers of words; the FP64 variant has room for one)
             SpmvChunk<kChunk, kF32> ch, ch2;
-            spmv_load<kChunk, kF32>(ch, v, 0, Wp, v32);
-            if (kF32 && kChunk < Wp) spmv_load<kChunk, kF32>(ch2, v, kChunk, Wp, v32);
+            spmv_load<kChunk, kF32, kNT>(ch, v, 0, Wp, v32);
+            if (kF32 && kChunk < Wp) spmv_load<kChunk, kF32, kNT>(ch2, v, kChunk, Wp, v32);
             __syncthreads(); // the previous panel's readers are done with xs_all
             for (int e = t; e < Wp * kSliceNodes; e += kSliceRows) {
                 const double2 *xv = x2 + 3 * (int64_t)cols[e];
@@ -414,16 +422,16 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
             if (kF32) {
                 // slots in ascending order as before: ch (0), ch2 (kChunk), ch (2 kChunk), ch2 (3 kChunk), ...
                 for (int k0 = kChunk; k0 < Wp; k0 += 2 * kChunk) {
-                    if (k0 + kChunk < Wp) spmv_load<kChunk, kF32>(ch, v, k0 + kChunk, Wp, v32);
+                    if (k0 + kChunk < Wp) spmv_load<kChunk, kF32, kNT>(ch, v, k0 + kChunk, Wp, v32);
                     acc = spmv_fma<kChunk, kF32>(ch2, xs, k0, Wp, acc);
                     if (k0 + kChunk < Wp) {
-                        if (k0 + 2 * kChunk < Wp) spmv_load<kChunk, kF32>(ch2, v, k0 + 2 * kChunk, Wp, v32);
+                        if (k0 + 2 * kChunk < Wp) spmv_load<kChunk, kF32, kNT>(ch2, v, k0 + 2 * kChunk, Wp, v32);
                         acc = spmv_fma<kChunk, kF32>(ch, xs, k0 + kChunk, Wp, acc);
                     }
                 }
             } else {
                 for (int k0 = kChunk; k0 < Wp; k0 += kChunk) {
-                    spmv_load<kChunk, kF32>(ch, v, k0, Wp, v32);
+                    spmv_load<kChunk, kF32, kNT>(ch, v, k0, Wp, v32);
                     acc = spmv_fma<kChunk, kF32>(ch, xs, k0, Wp, acc);
                 }
             }
@@ -497,27 +505,32 @@ __global__ __launch_bounds__(192) void k_spmv(DeviceMatrix m, const double *__re
 // =====================================================================================
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef float v2f __attribute__((ext_vector_type(2)));
-template <bool kF32> __device__ __forceinline__ v2d load_word(const double2 *v, const float2 *v32, size_t off)
+// (kNT: non-temporal loads -- an operator that is streamed once per launch and larger than the caches leaves them to the vectors;
+//  kNT = false, plain loads: operators small enough for the 256 MB Infinity Cache to serve the NEXT product of the same cycle --
+//  a level-1 operator of the 4M hierarchy is multiplied sixteen times per outer iteration)
+template <bool kF32, bool kNT = true> __device__ __forceinline__ v2d load_word(const double2 *v, const float2 *v32, size_t off)
 {
     if (kF32) {
-        const v2f w = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(v32) + off);
+        const v2f *p = reinterpret_cast<const v2f *>(v32) + off;
+        const v2f w = kNT ? __builtin_nontemporal_load(p) : *p;
         v2d r;
         r.x = (double)w.x;
         r.y = (double)w.y;
         return r;
     }
-    return __builtin_nontemporal_load(reinterpret_cast<const v2d *>(v) + off);
+    const v2d *p = reinterpret_cast<const v2d *>(v) + off;
+    return kNT ? __builtin_nontemporal_load(p) : *p;
 }
 
 // the 18 words (jp, i) of block slot k: wd[jp * 6 + i] = columns 2jp, 2jp+1 of row i.  diag: only the words of the upper triangle
 // are needed (slot 0 of a symmetric-storage row); the others stay unset
 // kVal: 0 = FP64 values, 1 = the float copy (m.vals32)
-template <int kVal, bool kDiag>
+template <int kVal, bool kDiag, bool kNT = true>
 __device__ __forceinline__ void load_block_words(const double2 *v, const float2 *v32, int k, v2d wd[18])
 {
 #pragma unroll
     for (int e = 0; e < 18; e++)
-        if (!kDiag || 2 * (e / 6) + 1 >= e % 6) wd[e] = load_word<(kVal == 1)>(v, v32, ((size_t)k * 18 + e) * kSliceNodes);
+        if (!kDiag || 2 * (e / 6) + 1 >= e % 6) wd[e] = load_word<(kVal == 1), kNT>(v, v32, ((size_t)k * 18 + e) * kSliceNodes);
 }
 
 // kVal: the blocks come from m.vals (0) or from m.vals32 (1: single precision, same layout); the arithmetic stays FP64
@@ -530,7 +543,7 @@ __device__ __forceinline__ void load_block_words(const double2 *v, const float2 
 // (The float-storing variants compile to 182-194 registers, two waves per SIMD where the FP64 product has three.  MEASURED, round
 //  4: held to three waves -- amdgpu_waves_per_eu(3, 3), 168 registers, five dwords spilled -- the 4M solves take the same time
 //  within the run-to-run scatter of 1 %: profiles/r04_spmv_sym_waves_ab.txt, four alternating rounds.  Left to the compiler.)
-template <int kVal, int kVec>
+template <int kVal, int kVec, bool kNT = true>
 __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *__restrict__ x, double *__restrict__ y,
                                                  double *__restrict__ partials, const CgScalars *s,
                                                  const int32_t *__restrict__ order, int count)
@@ -564,7 +577,7 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
             // element (i, j) below the diagonal is taken from (j, i).  Same order of the sum over j as in the loop
             // below, so a block whose halves mirror each other exactly (k_assemble's do) gives the same bits.
             v2d wd[18];
-            load_block_words<kVal, true>(v, v32, 0, wd);
+            load_block_words<kVal, true, kNT>(v, v32, 0, wd);
 #pragma unroll
             for (int i = 0; i < 6; i++)
 #pragma unroll
@@ -577,7 +590,7 @@ __global__ __launch_bounds__(64) void k_spmv_sym(DeviceMatrix m, const double *_
         for (int k = 1; k < W; k++) {
             const int c = m.cols[base + (int64_t)k * kSliceNodes + n];
             v2d wd[18];
-            load_block_words<kVal, false>(v, v32, k, wd); // word (jp = e/6, i = e%6)
+            load_block_words<kVal, false, kNT>(v, v32, k, wd); // word (jp = e/6, i = e%6)
             double xc[6];
             load_node6(x, c, kVec == 2, xc);
             double u[6];
@@ -684,10 +697,18 @@ __global__ __launch_bounds__(192) void k_sym_gather(DeviceMatrix m, const double
     }
 }
 
+static bool operator_fits_the_caches(const DeviceMatrix &m);
+
 static void spmv_sym_phase1(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
                             const int32_t *order, int count, int grid, hipStream_t st, bool f32 = false)
 {
     const size_t lds = m.loc_index != nullptr ? (size_t)2 * m.max_loc * 48 : 0;
+    // operators whose single-precision values fit the Infinity Cache are read with plain loads: the next smoothing product of the
+    // same visit finds them there (operator_fits_the_caches, below)
+    if (f32 && m.vals32 != nullptr && m.vec32 == 2 && operator_fits_the_caches(m)) {
+        hipLaunchKernelGGL((k_spmv_sym<1, 2, false>), dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
+        return;
+    }
     if (f32 && m.vals32 != nullptr) {
         if (m.vec32 == 2) hipLaunchKernelGGL((k_spmv_sym<1, 2>), dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
         else if (m.vec32 == 1) hipLaunchKernelGGL((k_spmv_sym<1, 1>), dim3(grid), dim3(64), lds, st, m, x, y, partials, s, order, count);
@@ -915,6 +936,28 @@ void launch_residual_dd(const DeviceMatrix &m, const double *x, const double *b,
     hipLaunchKernelGGL(k_residual_dd, dim3(slice_grid(m)), dim3(192), lds, st, m, x, b, r);
 }
 
+// Is the operator of a size at which the next product of the same cycle finds it in the 256 MB Infinity Cache -- and at which that
+// pays?  Upper bound of the bytes of its values from the padded slot count; plain loads between FEMSHELL_SPMV_CACHED_MIN_MB and
+// FEMSHELL_SPMV_CACHED_MB (defaults 128 and 300; CACHED_MB=0: every operator is streamed with non-temporal loads as in rounds 1-4).
+// MEASURED, round 5, alternating on one box (symmetric-storage smoothing products only): the level-1 operator of the 4M hierarchies
+// (197 MB of floats, sixteen smoothing products per outer iteration) with plain loads: panel 0.6454 -> 0.6372 s, cylinder 0.6031 ->
+// 0.5945 s; level 0 as well (1.2 GB): 0.6002 s -- it does not fit, and its lines evict the vectors; the 250k-triangle roof, whose
+// level 0 is 72 MB: 0.0603 -> 0.0614 s -- an operator that small is gone from the L2s anyway and costs the vectors their place.
+static bool operator_fits_the_caches(const DeviceMatrix &m)
+{
+    static const double max_mb = [] {
+        const char *e = getenv("FEMSHELL_SPMV_CACHED_MB");
+        return e ? atof(e) : 300.0;
+    }();
+    static const double min_mb = [] {
+        const char *e = getenv("FEMSHELL_SPMV_CACHED_MIN_MB");
+        return e ? atof(e) : 128.0;
+    }();
+    const double bytes_per_value = m.vals32 != nullptr ? 4.0 : 8.0;
+    const double mb = (double)m.n_slices * m.max_slice_width * kSliceNodes * 36.0 * bytes_per_value * 1e-6;
+    return mb <= max_mb && mb >= min_mb;
+}
+
 constexpr int kSpmvPanel = 64; // block slots of x staged in LDS at a time by k_spmv
 
 static void spmv_dispatch(const DeviceMatrix &m, const double *x, double *y, double *partials, const CgScalars *s,
@@ -934,8 +977,18 @@ static void spmv_dispatch(const DeviceMatrix &m, const double *x, double *y, dou
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kernel, g, b, lds, st, m, x, y, partials, s, order, count, base_vec, sign, panel, cheb);
     };
+    // (MEASURED, round 5: plain loads here -- the latency-bound products of the small levels -- LOSE: with them the 4M panel keeps
+    //  0.5 % of the 1.3 % the symmetric-storage products gain, and the 250k-triangle roof, all of whose operators fit, takes 0.0609 s
+    //  instead of 0.0594 s.  FEMSHELL_SPMV_CACHED_FULL=1 selects them for A/B runs.)
+    static const bool cached_full = getenv("FEMSHELL_SPMV_CACHED_FULL") && atoi(getenv("FEMSHELL_SPMV_CACHED_FULL")) == 1;
+    const bool cached = cached_full && operator_fits_the_caches(m);
     if (m.vals32 != nullptr) { // a product of the multigrid cycle on a single-precision copy of the values (amg_solve.cpp)
-        launch(k_spmv<8, true>);
+        if (cached) launch(k_spmv<8, true, false>);
+        else launch(k_spmv<8, true>);
+        return;
+    }
+    if (cached && chunk == 8) {
+        launch(k_spmv<8, false, false>);
         return;
     }
     switch (chunk) {
