@@ -1110,6 +1110,10 @@ int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precisio
     return rc;
 }
 
+// (MEASURED, round 5, and dropped: the product from the lower triangle of the symmetric inverse alone -- one workgroup per 64 x 64
+//  tile, the tile used for its block row and, through lane shuffles and LDS, for its block column, two-stage sums in a fixed
+//  order: 109 MB + 14 MB of partial sums instead of 218 MB, and 5 % MORE time per solve of the 4M panel (0.632 against 0.600 s): the
+//  sixty-four shuffles a thread spends on the transposed sums and 6786 workgroups of 16 KB cost more than the bytes they save.)
 void launch_dense_gemv_big(const double *A64, const float *A32, int64_t lda, const double *b, double *y, int32_t n, int32_t n_pad6,
                            const CgScalars *gate, hipStream_t st)
 {
