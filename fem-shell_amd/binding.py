@@ -25,7 +25,7 @@ SYMBOLS = [
     "femshell_row_end", "femshell_comm_unique_id", "femshell_comm_init", "femshell_time_kernel",
     "femshell_sync", "femshell_pc_defaults", "femshell_set_preconditioner", "femshell_amg_levels", "femshell_amg_level",
     "femshell_amg_export", "femshell_residual", "femshell_comm_ranks", "femshell_amg_setup_stats", "femshell_amg_dense_stats", "femshell_amg_partition_info", "femshell_assembly_kernel",
-    "femshell_amg_cycle_bytes", "femshell_comm_selftest", "femshell_comm_counters",
+    "femshell_amg_cycle_bytes", "femshell_comm_selftest", "femshell_comm_counters", "femshell_owned_nodes", "femshell_comm_bytes",
 ]
 
 
@@ -121,6 +121,8 @@ def load_library():
     L.femshell_row_begin.restype = C.c_int32
     L.femshell_row_end.argtypes = [vp]
     L.femshell_row_end.restype = C.c_int32
+    L.femshell_owned_nodes.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.femshell_owned_nodes.restype = C.c_int32
     L.femshell_comm_unique_id.argtypes = [bp]
     L.femshell_comm_init.argtypes = [vp, bp]
     L.femshell_comm_ranks.argtypes = [vp]
@@ -140,6 +142,7 @@ def load_library():
     L.femshell_assembly_kernel.argtypes = [vp]
     L.femshell_comm_selftest.argtypes = [vp, dp]
     L.femshell_comm_counters.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32]
+    L.femshell_comm_bytes.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32]
     L.femshell_amg_cycle_bytes.argtypes = [vp, dp, C.c_int32]
     L.femshell_amg_cycle_bytes.restype = C.c_int32
     for name in SYMBOLS:
@@ -278,6 +281,13 @@ class FemShell:
     def row_range(self):
         return int(self._L.femshell_row_begin(self._h)), int(self._L.femshell_row_end(self._h))
 
+    def owned_nodes(self):
+        """the caller's ids of the node rows this rank owns, in the order export_bsr gives them"""
+        n = int(self._L.femshell_owned_nodes(self._h, None))
+        ids = np.zeros(n, dtype=np.int32)
+        self._L.femshell_owned_nodes(self._h, _i(ids))
+        return ids
+
     def time_kernel(self, which, reps=10):
         ms = C.c_double()
         by = C.c_double()
@@ -308,6 +318,14 @@ class FemShell:
             _check(self._L.femshell_amg_level(self._h, l, C.byref(info)))
             out.append({f[0]: getattr(info, f[0]) for f in AmgLevelInfo._fields_})
         return out
+
+    def comm_bytes(self, clear=False):
+        """(bytes handed to the sends of halo exchanges, bytes contributed to all-reduces and broadcasts) since the last clear"""
+        out = (C.c_int64 * 2)()
+        rc = self._L.femshell_comm_bytes(self._h, out, 1 if clear else 0)
+        if rc < 0:
+            _check(rc)
+        return int(out[0]), int(out[1])
 
     def comm_counters(self, clear=False):
         """Communication enqueued since the counters were cleared (femshell_comm_counters)."""

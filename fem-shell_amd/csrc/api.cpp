@@ -535,6 +535,15 @@ int femshell_comm_counters(femshell_ctx *c, int64_t out[4], int32_t clear)
     return c->comm.active() ? 1 : 0;
 }
 
+int femshell_comm_bytes(femshell_ctx *c, int64_t out[2], int32_t clear)
+{
+    if (!c || !out) return set_err(FEMSHELL_ERR_INVALID, "femshell_comm_bytes: null argument");
+    out[0] = c->comm.halo_bytes_sent;
+    out[1] = c->comm.collective_bytes;
+    if (clear) c->comm.halo_bytes_sent = c->comm.collective_bytes = 0;
+    return c->comm.active() ? 1 : 0;
+}
+
 int femshell_comm_selftest(femshell_ctx *c, double out_us[3])
 {
     if (!c || !out_us) return set_err(FEMSHELL_ERR_INVALID, "femshell_comm_selftest: null argument");
@@ -596,7 +605,10 @@ static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double 
     c->iperm.clear();
     std::vector<double> xyz_r;
     std::vector<int32_t> tri_r, quad_r;
-    if ((c->cfg.flags & (FEMSHELL_REORDER_MORTON | FEMSHELL_REORDER_RCM)) && c->cfg.world_size == 1 && n_nodes > 0) {
+    // (row-partitioned contexts: every rank holds the whole mesh and computes the same permutation -- both orderings are
+    //  serial and deterministic -- BEFORE the slice partition, so a rank's rows are a stretch of the curve / of the level
+    //  structure: compact in space whatever the caller's numbering is, ghosts along its two ends only)
+    if ((c->cfg.flags & (FEMSHELL_REORDER_MORTON | FEMSHELL_REORDER_RCM)) && n_nodes > 0) {
         for (int64_t q = 0; q < 3ll * n_tri; q++)
             if (tri[q] < 0 || tri[q] >= n_nodes) return set_err(FEMSHELL_ERR_MESH, "femshell_set_mesh: triangle " + std::to_string(q / 3) + " references a node out of range");
         for (int64_t q = 0; q < 4ll * n_quad; q++)
@@ -1181,8 +1193,17 @@ int femshell_get_solution(femshell_ctx *c, double *u_out)
     std::string e;
     if (!comm_gather_rows(c->comm, c->x.p, c->ufull.p, c->all_begin, c->all_end, c->stream, &e))
         return set_err(FEMSHELL_ERR_COMM, e);
-    FS_HIP(hipMemcpyAsync(u_out, c->ufull.p, (size_t)p.n_nodes * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (c->perm.empty()) {
+        FS_HIP(hipMemcpyAsync(u_out, c->ufull.p, (size_t)p.n_nodes * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        FS_HIP(hipStreamSynchronize(c->stream));
+        return FEMSHELL_OK;
+    }
+    std::vector<double> h((size_t)p.n_nodes * 6); // internal numbering -> the caller's
+    FS_HIP(hipMemcpyAsync(h.data(), c->ufull.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     FS_HIP(hipStreamSynchronize(c->stream));
+    parallel_chunks(p.n_nodes, [&](int64_t b, int64_t e) {
+        for (int64_t i = b; i < e; i++) std::memcpy(u_out + 6ull * c->perm[(size_t)i], &h[6ull * (size_t)i], 6 * sizeof(double));
+    }, 1 << 16);
     return FEMSHELL_OK;
 }
 
@@ -1252,6 +1273,27 @@ int femshell_export_bsr(femshell_ctx *c, int32_t *rowptr, int32_t *colidx, doubl
     }
     rc = download_matrix(c, &A);
     if (rc) return rc;
+    if (c->cfg.world_size > 1) {
+        // a renumbered row partition: the rank's rows in the order of femshell_owned_nodes (the stretch of the internal
+        // numbering it owns), columns ascending in the caller's ids; F already is in that order
+        FS_HIP(hipStreamSynchronize(c->stream));
+        for (int32_t a = 0; a <= p.n_own; a++) rowptr[a] = (int32_t)A.ptr[a];
+        parallel_chunks(p.n_own, [&](int64_t a0, int64_t a1) {
+            std::vector<std::pair<int32_t, int64_t>> order;
+            for (int64_t a = a0; a < a1; a++) {
+                order.clear();
+                for (int64_t q = A.ptr[a]; q < A.ptr[a + 1]; q++) order.push_back({c->perm[A.col[(size_t)q]], q});
+                std::sort(order.begin(), order.end());
+                int64_t w = A.ptr[a];
+                for (auto &o : order) {
+                    colidx[w] = o.first;
+                    std::memcpy(vals + 36 * w, &A.val[(size_t)o.second * 36], 36 * sizeof(double));
+                    w++;
+                }
+            }
+        });
+        return FEMSHELL_OK;
+    }
     // internal numbering -> the caller's: rows in the caller's order, columns ascending in the caller's ids
     if (F) {
         std::vector<double> Fi(F, F + (size_t)p.n_own * 6);
@@ -1344,6 +1386,19 @@ int femshell_residual(femshell_ctx *c, const double *x, double *r)
     FS_HIP(hipStreamSynchronize(c->stream));
     for (int32_t i = 0; i < p.n_own && !ri.empty(); i++) std::memcpy(r + 6ull * c->perm[i], &ri[6ull * i], 6 * sizeof(double));
     return FEMSHELL_OK;
+}
+
+int32_t femshell_owned_nodes(femshell_ctx *c, int32_t *ids_out)
+{
+    if (!c || !c->have_mesh) return 0;
+    const Plan &p = c->plan;
+    if (ids_out)
+        for (int32_t i = 0; i < p.n_own; i++) {
+            // (one rank with a renumbering: femshell_export_bsr gives the rows in the caller's order)
+            const int32_t row = p.row_begin + i;
+            ids_out[i] = (c->perm.empty() || c->cfg.world_size == 1) ? row : c->perm[(size_t)row];
+        }
+    return p.n_own;
 }
 
 int32_t femshell_row_begin(femshell_ctx *c) { return (c && c->have_mesh) ? c->plan.row_begin : 0; }

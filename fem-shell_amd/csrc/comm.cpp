@@ -294,6 +294,7 @@ void comm_destroy(Comm &c)
 bool comm_allreduce_sum(Comm &c, double *buf, int count, hipStream_t st, std::string *err)
 {
     c.allreduces++;
+    c.collective_bytes += 8ll * count;
     return check(g_api.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, static_cast<ncclComm_t>(c.comm), st),
                  "ncclAllReduce", err);
 }
@@ -308,6 +309,7 @@ bool comm_halo(Comm &c, const std::vector<HaloPeer> &peers, const std::vector<in
     bool ok = true;
     for (size_t i = 0; i < peers.size() && ok; i++) {
         const HaloPeer &h = peers[i];
+        c.halo_bytes_sent += 8ll * w * (int64_t)h.send_nodes.size();
         if (!h.send_nodes.empty())
             ok = check(g_api.Send(sendbuf + w * send_offsets[i], (size_t)w * h.send_nodes.size(), ncclDouble, h.rank, comm, st),
                        "ncclSend", err);
@@ -329,6 +331,7 @@ bool comm_gather_rows(Comm &c, const double *x_owned, double *full, const std::v
     for (int r = 0; r < c.world && ok; r++) {
         const size_t cnt = 6 * (size_t)(row_end[r] - row_begin[r]);
         if (cnt == 0) continue;
+        if (r == c.rank) c.collective_bytes += 8ll * (int64_t)cnt;
         double *dst = full + 6ll * row_begin[r];
         ok = check(g_api.Broadcast(r == c.rank ? x_owned : dst, dst, cnt, ncclDouble, r, comm, st), "ncclBroadcast", err);
     }
@@ -346,6 +349,7 @@ bool comm_gather_pieces(Comm &c, const double *mine, double *full, const std::ve
     for (int r = 0; r < c.world && ok; r++) {
         const size_t cnt = (size_t)(end[r] - begin[r]);
         if (cnt == 0) continue;
+        if (r == c.rank) c.collective_bytes += 8ll * (int64_t)cnt;
         double *dst = full + begin[r];
         ok = check(g_api.Broadcast(r == c.rank ? mine : dst, dst, cnt, ncclDouble, r, comm, st), "ncclBroadcast", err);
     }

@@ -30,6 +30,7 @@ struct Comm {
     // other stream (they sit in the main stream's dependency chain), all-reduces, grouped broadcasts (row gathers)
     hipStream_t second = nullptr;
     int64_t halo_groups_second = 0, halo_groups_main = 0, allreduces = 0, gathers = 0;
+    int64_t halo_bytes_sent = 0, collective_bytes = 0; // (femshell_comm_bytes: what this rank handed to sends / to all-reduces and broadcasts)
 };
 
 // Hang protection of multi-rank contexts.  A rank that waits for a peer that never joined (ncclCommInitRank), or for a

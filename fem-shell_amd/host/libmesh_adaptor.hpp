@@ -141,10 +141,13 @@ inline void femshell_assemble_elasticity(EquationSystems &es, const std::string 
     check(femshell_assemble(b.ctx));
     if (!b.compat_copy_back) return; // K and F stay in HBM for FemShellLinearSolver
     // compat mode: hand the assembled block rows to libMesh (ADD semantics, fem-shell.cpp:1230-1231).  Every rank
-    // exports the node rows [row_begin, row_end) it assembled (global column ids); libMesh/PETSc route the entries to
-    // the owner of each dof when the matrix is closed, as they do for the reference's own add_matrix calls.
+    // exports the node rows it assembled (femshell_owned_nodes: [row_begin, row_end) unless the library renumbered the
+    // nodes; global column ids); libMesh/PETSc route the entries to the owner of each dof when the matrix is closed, as
+    // they do for the reference's own add_matrix calls.
     const int64_t nb = femshell_nnz_blocks(b.ctx);
-    const int32_t row0 = femshell_row_begin(b.ctx), n_rows = femshell_row_end(b.ctx) - row0;
+    const int32_t n_rows = femshell_owned_nodes(b.ctx, nullptr);
+    std::vector<int32_t> own((size_t)n_rows);
+    femshell_owned_nodes(b.ctx, own.data());
     std::vector<int32_t> rowptr(n_rows + 1), colidx(nb);
     std::vector<double> vals(36 * nb), F(6 * (size_t)n_rows);
     check(femshell_export_bsr(b.ctx, rowptr.data(), colidx.data(), vals.data(), F.data()));
@@ -152,7 +155,7 @@ inline void femshell_assemble_elasticity(EquationSystems &es, const std::string 
     DenseMatrix<Number> blk(6, 6);
     std::vector<dof_id_type> rows(6), cols(6);
     for (int32_t a = 0; a < n_rows; a++) {
-        for (unsigned v = 0; v < 6; v++) rows[v] = dof(row0 + a, v);
+        for (unsigned v = 0; v < 6; v++) rows[v] = dof(own[(size_t)a], v);
         for (int32_t q = rowptr[a]; q < rowptr[a + 1]; q++) {
             for (unsigned v = 0; v < 6; v++) cols[v] = dof(colidx[q], v);
             for (int i = 0; i < 6; i++)

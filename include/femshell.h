@@ -49,7 +49,7 @@ typedef enum femshell_status {
 #define FEMSHELL_REF_DRILL_MAX  0x2u /* SA:1035-1052: drilling stiffness max(..)/1000 on every node block */
 #define FEMSHELL_REASSEMBLE_EACH_SOLVE 0x4u /* PC:271: rebuild K on every solve (the reference does; K is constant) */
 #define FEMSHELL_REF_DEFAULT    (FEMSHELL_REF_Y21 | FEMSHELL_REF_DRILL_MAX)
-/* node renumbering inside the library (single-rank contexts): rows are stored along a Morton curve through the mesh /
+/* node renumbering inside the library (any number of ranks): rows are stored along a Morton curve through the mesh /
  * in reverse Cuthill-McKee order, so that the x entries a 32-node slice gathers are close together whatever the caller's
  * numbering is.  libMesh renumbers for locality by default; the reference switches it off only because its force file is
  * indexed by the original ids (SA:36).  Every node-indexed argument of this ABI keeps the caller's numbering.
@@ -274,6 +274,14 @@ int femshell_residual(femshell_ctx *ctx, const double *x, double *r);
 
 int32_t femshell_row_begin(femshell_ctx *ctx); /* first owned node row */
 int32_t femshell_row_end(femshell_ctx *ctx);   /* one past the last owned node row */
+/* The caller's ids of the node rows this rank owns, in the order femshell_export_bsr gives them; returns their number
+ * (ids_out may be NULL).  Without a renumbering flag: row_begin .. row_end - 1.  With FEMSHELL_REORDER_MORTON / _RCM on a
+ * row-partitioned context the library partitions the RENUMBERED rows (every rank computes the same permutation of the whole
+ * mesh, then takes its stretch: a compact patch of the mesh whatever the caller's numbering is -- libMesh partitions its
+ * elements for locality the same way, doc/implementation.tex:103-124), so the owned nodes are not a range of the caller's ids:
+ * this list names them.  Node-indexed arguments (femshell_set_dirichlet, femshell_set_loads, the solution) keep the caller's
+ * numbering on every rank. */
+int32_t femshell_owned_nodes(femshell_ctx *ctx, int32_t *ids_out);
 /* rank 0 creates the id, the host program distributes it (e.g. a torch.distributed or MPI
  * broadcast), every rank then calls femshell_comm_init before femshell_set_mesh.
  * replaces: LibMeshInit / init.comm() (SA:28, 35) */
@@ -295,6 +303,10 @@ int femshell_comm_selftest(femshell_ctx *ctx, double out_us[3]);
  * countable here: tests hold the per-iteration budget of the row-partitioned multigrid to these numbers.  Returns 1 with a
  * communicator, 0 without, < 0 on error. */
 int femshell_comm_counters(femshell_ctx *ctx, int64_t out[4], int32_t clear);
+/* ... and its volume: out[0] = bytes this rank handed to the sends of grouped exchanges (vector halos: 48 bytes per node another
+ * rank reads; the multigrid setup: the rows of Q, P and A P of those nodes), out[1] = bytes it contributed to all-reduces and
+ * broadcasts.  Same clearing and return values. */
+int femshell_comm_bytes(femshell_ctx *ctx, int64_t out[2], int32_t clear);
 
 /* ---- measurement ----------------------------------------------------------------- */
 

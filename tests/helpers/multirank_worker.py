@@ -26,6 +26,24 @@ def build_problem(kind):
     if kind == "cylinder":
         m = meshes.pinched_cylinder(48, 40)
         return m, m.material
+    if kind in ("jittered_random", "delaunay_hard_random"):
+        # the same shells in the numbering the generator gives them -- random: a rank's range of the caller's ids is scattered
+        # over the whole shell (half of all nodes are ghosts of the other rank).  For FEMSHELL_REORDER=morton|rcm, which
+        # partitions the renumbered rows.
+        from tests.test_gpu_parity import delaunay_shell
+
+        class M:
+            pass
+        m = M()
+        xyz, tri = delaunay_shell(20000, 3, jittered=(kind == "jittered_random"))
+        m.xyz, m.tri, m.quad = np.ascontiguousarray(xyz), tri.astype(np.int32), None
+        mask = np.zeros(len(m.xyz), dtype=np.uint8)
+        mask[m.xyz[:, 0] < 0.15] = 0x3F
+        m.loads = np.zeros((len(m.xyz), 6))
+        m.loads[:, 2] = 1.0
+        m.dirichlet_mask = lambda: mask
+        m.n_nodes = len(m.xyz)
+        return m, (0.3, 7.0e4, 0.03)
     if kind == "jittered":
         # an unstructured mesh of good element quality (Delaunay triangulation of a jittered grid on a curved shell: irregular
         # valence, no slivers), numbered along x as a mesh prepared for several ranks would be
@@ -114,6 +132,16 @@ def main():
         np.savez(out_file, code=code, msg=msg)
         fs.close()
         return
+    if kind == "delaunay_hard_random":
+        # the multigrid setup alone (one iteration): what it sends, and which assembly kernel the renumbered mesh gets
+        fs.set_preconditioner("amg")
+        fs.comm_bytes(clear=True)
+        fs.assemble()
+        _, info = fs.solve(rtol=1e-10, max_it=1)
+        np.savez(out_file, setup_bytes=np.array(fs.comm_bytes()), assembly_kernel=fs.assembly_kernel(), levels=info["amg_levels"],
+                 own=fs.owned_nodes())
+        fs.close()
+        return
     if kind == "delaunay_hard":
         # every rank takes the fallback together (the rebuild of the hierarchy is collective) and ends at the iteration limit
         fs.set_preconditioner("amg")
@@ -122,13 +150,17 @@ def main():
                  finite=bool(np.all(np.isfinite(u))), levels=info["amg_levels"])
         fs.close()
         return
+    if world > 1:
+        fs.comm_bytes(clear=True)
     u, info = fs.solve(rtol=1e-11, max_it=100000)
     b, e = fs.row_range()
-    extra = {}
+    extra = {"own": fs.owned_nodes(), "assembly_kernel": fs.assembly_kernel()}
+    if world > 1:
+        extra["first_solve_bytes"] = np.array(fs.comm_bytes())
     if os.environ.get("FEMSHELL_TEST_EXPORT") == "1":
         # the rows of K and F this rank assembled (global column ids), for the comparison with the oracle's assembly
         rp, ci, vals, F = fs.export_bsr()
-        extra = dict(k_rowptr=rp[:e - b + 1], k_cols=ci, k_vals=vals, k_F=F[:6 * (e - b)])
+        extra.update(k_rowptr=rp[:e - b + 1], k_cols=ci, k_vals=vals, k_F=F[:6 * (e - b)])
     if os.environ.get("FEMSHELL_TEST_AMG_EXPORT") == "1":
         # the rank's part of the multigrid hierarchy (row-partitioned levels: its rows, global column ids)
         lv = fs.amg_levels()

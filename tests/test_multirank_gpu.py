@@ -108,6 +108,56 @@ def test_row_partitioned_assembly_and_solve_against_the_oracle(world, kind, tmp_
     assert err < 1e-8, err  # solver term ~1e-13 + kappa x (1e-16 rounding differences of the two assemblies)
 
 
+@pytest.mark.parametrize("world,order", [(2, "morton"), (3, "rcm")])
+def test_renumbered_row_partition_of_a_randomly_numbered_mesh_against_the_oracle(world, order, tmp_path, monkeypatch):
+    """FEMSHELL_REORDER on a row-partitioned context (doc/implementation.tex:103-124: libMesh partitions for locality whatever the
+    file's numbering is): every rank computes the same permutation and owns a stretch of it.  A 20k-node Delaunay shell in
+    the generator's random numbering: the ranks' owned nodes (femshell_owned_nodes) tile the mesh, their rows of K and F equal
+    the oracle's assembly in the CALLER's numbering, the gathered solution (caller's numbering on every rank) equals the
+    oracle's solve, and the renumbered mesh gets the pipelined assembly kernel."""
+    from tests.helpers import oracle
+    from tests.helpers.multirank_worker import build_problem
+
+    monkeypatch.setenv("FEMSHELL_TEST_EXPORT", "1")
+    ranks = run_ranks(world, "jittered_random", tmp_path, pc="amg", extra_env={"FEMSHELL_REORDER": order})
+    m, mat = build_problem("jittered_random")
+    r0, c0, v0, F0 = oracle.assemble(m.xyz, m.tri, np.zeros((0, 4), np.int32), oracle.material(*mat), m.dirichlet_mask(), m.loads)
+    scale = np.abs(v0).max()
+    seen = np.zeros(m.n_nodes, dtype=np.int32)
+    for r in ranks:
+        own = np.asarray(r["own"], dtype=np.int64)
+        assert len(own) == int(r["end"]) - int(r["begin"])
+        seen[own] += 1
+        rp = np.asarray(r["k_rowptr"], dtype=np.int64)
+        np.testing.assert_array_equal(np.diff(rp), (r0[own + 1] - r0[own]))
+        idx = np.concatenate([np.arange(r0[a], r0[a + 1]) for a in own])  # the oracle's blocks of these rows, row after row
+        np.testing.assert_array_equal(r["k_cols"][:len(idx)], c0[idx])
+        assert np.abs(r["k_vals"][:len(idx)] - v0[idx]).max() <= 1e-12 * scale
+        np.testing.assert_array_equal(r["k_F"].reshape(-1, 6), F0.reshape(-1, 6)[own])
+        assert str(r["assembly_kernel"]) == "k_assemble_pipe"
+        # a compact patch each: what a rank sends in the first solve (setup of the hierarchy included) stays far below the
+        # 180 MB the setup alone moved when a rank's rows were scattered over the shell
+        assert int(r["first_solve_bytes"][0]) < 40e6, r["first_solve_bytes"]
+        np.testing.assert_array_equal(r["u"], ranks[0]["u"])
+        assert int(r["converged"]) == 1
+    assert (seen == 1).all()
+    u0 = oracle.refined_solve(r0, c0, v0, F0)
+    err = np.linalg.norm(ranks[0]["u"].ravel() - u0) / np.linalg.norm(u0)
+    assert err < 1e-8, err
+
+
+def test_multigrid_setup_traffic_of_a_randomly_numbered_mesh_with_and_without_renumbering(tmp_path):
+    """What the setup of the row-partitioned hierarchy sends per rank on the 20k-node Delaunay shell of poor element quality in
+    random numbering: the rows of Q, P and A P of every node another rank reads.  In the caller's numbering half of all nodes are
+    such nodes; after renumbering only those along the cut."""
+    (tmp_path / "m").mkdir()
+    ranks = run_ranks(2, "delaunay_hard_random", tmp_path / "m", extra_env={"FEMSHELL_REORDER": "morton"})
+    for r in ranks:
+        assert str(r["assembly_kernel"]) == "k_assemble_pipe"
+        assert int(r["setup_bytes"][0]) <= 20e6, r["setup_bytes"]
+    print("setup bytes per rank (renumbered):", [int(r["setup_bytes"][0]) for r in ranks])
+
+
 @pytest.mark.parametrize("world,kind,dist_min", [(2, "panel", 60000), (3, "cylinder", 60000), (4, "panel", 60000),
                                                   (2, "cylinder", 100), (3, "panel", 100), (4, "cylinder", 100),
                                                   (2, "jittered", 60000), (3, "jittered", 100)])
