@@ -363,212 +363,48 @@ __device__ __forceinline__ void pivot_block(const double *__restrict__ D, int64_
     }
 }
 
+// Bounded wait of one workgroup for a counter another launch raises (the look-ahead of the block sweep, below): thread 0 polls
+// with acquire semantics, the others join at the barrier; false when the bound expired (status[0] = 2: the host runs the inverse
+// again without the look-ahead).
+// kFenceAlways = false: for a consumer that has not touched the announced bytes since its launch began and whose producer is
+// a launch that (nearly always) ended before this one began -- the panel kernel waiting for B.  A launch begins with its caches
+// invalidated, so what the producer wrote back before it raised the counter is what the first loads see; the agent-scope
+// acquire is then only paid when the counter was NOT yet up at the first look.  (Paid always, by all 244 workgroups of the panel
+// kernel at once, it cost 15 us per sweep: every one of them an L2 write-back and invalidate.)
+template <bool kFenceAlways = true>
+__device__ __forceinline__ bool wait_for_counter(const unsigned int *counter, unsigned int need, int spin_limit, int32_t *status)
+{
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while (spins < spin_limit && __hip_atomic_load(counter, kFenceAlways ? __ATOMIC_ACQUIRE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            // (somebody else's bound has expired already: the inverse runs again anyway, nobody waits out a bound of his own)
+            if ((spins & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2) spins = spin_limit - 1;
+            __builtin_amdgcn_s_sleep(8);
+            spins++;
+        }
+        ok = spins >= spin_limit ? 0 : (spins == 0 ? 1 : 2);
+        if (!ok) __hip_atomic_store(status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (kFenceAlways || ok == 2) __threadfence(); // (acquire for every thread's loads of what the counter announces)
+    return ok != 0;
+}
+
+// wait_tiles != nullptr: the look-ahead's launch on the second stream -- the inverse of pivot block K starts when the update of
+// sweep K - 1 (first stream, same time) has counted its `need` tiles in place, and `done` announces B to the panel kernel.
 __global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ D, int64_t ld, int K, const double *__restrict__ diag0,
-                                                     double *__restrict__ B, int32_t *status)
+                                                     double *__restrict__ B, int32_t *status, const unsigned int *wait_tiles,
+                                                     unsigned int need, int spin_limit, unsigned int *done)
 {
     extern __shared__ double lds_dense[];
-    pivot_block(D, ld, K, diag0, B, status, lds_dense, lds_dense + 4 * kNB * kLdp);
-}
+    const bool go = wait_tiles == nullptr || wait_for_counter(wait_tiles, need, spin_limit, status);
+    if (go) pivot_block(D, ld, K, diag0, B, status, lds_dense, lds_dense + 4 * kNB * kLdp);
 
-// ---- the same pivot inverse for a workgroup that has 35 KB of LDS and 128 VGPRs (the look-ahead inside k_dense_update) --------
-// sweep64 with the row panel consumed as it is read: s, the 4 x 4 pivot sub-block and one 4 x 4 product live in registers
-// (52 doubles instead of 100), the rows of the step come from LDS a row of four at a time
-__device__ __forceinline__ void sweep64_lean(double s[4][4], const double *a0, double (*rowbuf)[4][kNB], int bi, int bj, int &n_dead,
-                                             int &n_failed)
-{
-    for (int g = 0; g < kNB / 4; g++) {
-        const int cur = g & 1;
-        if (bi == g) {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int b = 0; b < 4; b++) rowbuf[cur][k][4 * bj + b] = s[k][b];
-        }
+    if (done != nullptr) { // (raised on a failed wait as well: nobody behind this launch waits for its full bound too)
+        __threadfence();
         __syncthreads();
-        double m[4][4];
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-#pragma unroll
-            for (int l = 0; l < 4; l++) m[k][l] = rowbuf[cur][k][4 * g + l];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const double d = m[k][k], a = a0[4 * g + k];
-            const bool failed = !(a > 0.0) || d < -1e-4 * fabs(a);
-            const bool dead = failed || d <= 1e-11 * a;
-            n_failed += failed ? 1 : 0;
-            n_dead += dead ? 1 : 0;
-            double inv = 0.0;
-            if (!dead) {
-                inv = __builtin_amdgcn_rcp(d);
-                inv = inv * (2.0 - d * inv);
-                inv = inv * (2.0 - d * inv);
-            }
-            double col[4];
-#pragma unroll
-            for (int l = 0; l < 4; l++) col[l] = m[l][k];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (i == k || j == k) continue;
-                    m[i][j] -= col[i] * col[j] * inv;
-                }
-#pragma unroll
-            for (int l = 0; l < 4; l++) {
-                if (l == k) continue;
-                const double v = col[l] * inv;
-                m[l][k] = v;
-                m[k][l] = v;
-            }
-            m[k][k] = -inv;
-        }
-        // ti = -R_i^T m, one row of the panel at a time
-        double ti[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int l = 0; l < 4; l++) ti[a][l] = 0.0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            double ri[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) ri[q] = rowbuf[cur][k][4 * bi + q];
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int l = 0; l < 4; l++) ti[a][l] -= ri[a] * m[k][l];
-        }
-        if (bi == g && bj == g) {
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = 0; b < 4; b++) s[a][b] = m[a][b];
-        } else if (bj == g) {
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = 0; b < 4; b++) s[a][b] = ti[a][b];
-        } else {
-            const bool row_of_step = bi == g;
-            if (row_of_step) {
-#pragma unroll
-                for (int a = 0; a < 4; a++)
-#pragma unroll
-                    for (int b = 0; b < 4; b++) s[a][b] = 0.0;
-            }
-#pragma unroll
-            for (int l = 0; l < 4; l++) {
-                double rj[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) rj[q] = rowbuf[cur][l][4 * bj + q];
-#pragma unroll
-                for (int a = 0; a < 4; a++)
-#pragma unroll
-                    for (int b = 0; b < 4; b++) s[a][b] -= (row_of_step ? m[a][l] : ti[a][l]) * rj[b];
-            }
-        }
-    }
-    __syncthreads(); // rowbuf may be reused
-}
-
-// acc += X Y^T for two 64 x 64 blocks in HBM (row stride kLdp), staged through LDS in two chunks of 32 columns of K (two
-// 64 x 34 panels = the 35 KB of an update workgroup), the wave's 32 x 32 quadrant on the matrix cores
-__device__ __forceinline__ void staged_xyt(const double *__restrict__ Xg, const double *__restrict__ Yg, double *lds, int r0, int c0,
-                                           int lane, int tid, v4d acc[2][2])
-{
-    double *Xs = lds, *Ys = lds + kNB * kLdh;
-    for (int ch = 0; ch < kNB / kHalf; ch++) {
-        __syncthreads(); // the previous readers of the panels are through; the blocks in HBM are complete
-        for (int e = tid; e < kNB * kHalf / 2; e += 256) {
-            const int r = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));
-            *reinterpret_cast<double2 *>(Xs + r * kLdh + k) = *reinterpret_cast<const double2 *>(Xg + r * kLdp + ch * kHalf + k);
-            *reinterpret_cast<double2 *>(Ys + r * kLdh + k) = *reinterpret_cast<const double2 *>(Yg + r * kLdp + ch * kHalf + k);
-        }
-        __syncthreads();
-        quadrant_xyt<kHalf, kLdh>(Xs, Ys, r0, c0, lane, acc);
-    }
-}
-
-// pivot_block for such a workgroup: P0 .. P3 in HBM scratch (cache resident), lds = 2 x 64 x 34 doubles, used as the row
-// panel + diagonal entries during the sweeps and as the two operand panels during the products
-__device__ __forceinline__ void pivot_block_lean(const double *__restrict__ D, int64_t ld, int K, const double *__restrict__ diag0,
-                                                 double *__restrict__ B, int32_t *status, double *panels, double *lds)
-{
-    constexpr int L = kLdp;
-    double *P0 = panels, *P1 = P0 + kNB * L, *P2 = P1 + kNB * L, *P3 = P2 + kNB * L;
-    double (*rowbuf)[4][kNB] = reinterpret_cast<double (*)[4][kNB]>(lds);
-    double *a0 = lds + 2 * 4 * kNB;
-    const int tid = threadIdx.x, k0 = 2 * K * kNB, bi = tid >> 4, bj = tid & 15;
-    const int wave = tid >> 6, lane = tid & 63, r0 = 32 * (wave >> 1), c0 = 32 * (wave & 1);
-    double s[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int r = 4 * bi + a, c = 4 * bj + b;
-            s[a][b] = r >= c ? D[(int64_t)(k0 + r) * ld + k0 + c] : D[(int64_t)(k0 + c) * ld + k0 + r];
-            P1[r * L + c] = D[(int64_t)(k0 + kNB + r) * ld + k0 + c]; // C
-        }
-    if (tid < 2 * kNB) a0[tid] = diag0[k0 + tid];
-    __syncthreads();
-    int n_dead = 0, n_failed = 0;
-    sweep64_lean(s, a0, rowbuf, bi, bj, n_dead, n_failed); // s = -B_A
-    double a0_second = tid < kNB ? a0[kNB + tid] : 0.0;     // (the products take the LDS: the second block's diagonal rides in registers)
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) P0[(4 * bi + a) * L + 4 * bj + b] = -s[a][b];
-    v4d w[2][2];
-    auto zero = [&]() {
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++) w[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-    };
-    zero();
-    staged_xyt(P1, P0, lds, r0, c0, lane, tid, w); // W = C B_A
-    for_quadrant(r0, c0, lane, [&](int ti, int tj, int g, int r, int c) {
-        P2[r * L + c] = w[ti][tj][g];
-        P3[c * L + r] = w[ti][tj][g];
-    });
-    // S = D22 - W C^T: the accumulator starts from -D22
-    for_quadrant(r0, c0, lane, [&](int ti, int tj, int g, int r, int c) {
-        w[ti][tj][g] = -(r >= c ? D[(int64_t)(k0 + kNB + r) * ld + k0 + kNB + c] : D[(int64_t)(k0 + kNB + c) * ld + k0 + kNB + r]);
-    });
-    staged_xyt(P2, P1, lds, r0, c0, lane, tid, w); // W C^T - D22
-    __syncthreads();                                // every wave is through with C
-    for_quadrant(r0, c0, lane, [&](int ti, int tj, int g, int r, int c) { P1[r * L + c] = -w[ti][tj][g]; }); // S
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) s[a][b] = P1[(4 * bi + a) * L + 4 * bj + b];
-    if (tid < kNB) a0[tid] = a0_second;
-    __syncthreads();
-    sweep64_lean(s, a0, rowbuf, bi, bj, n_dead, n_failed); // s = -B_S
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int r = 4 * bi + a, c = 4 * bj + b;
-            P1[r * L + c] = -s[a][b];
-            B[(kNB + r) * kSW + kNB + c] = -s[a][b]; // X22 = B_S
-        }
-    zero();
-    staged_xyt(P1, P3, lds, r0, c0, lane, tid, w); // B_S W = B_S (W^T)^T
-    __syncthreads();                                // every wave is through with W^T ... and nobody reads W any more
-    for_quadrant(r0, c0, lane, [&](int ti, int tj, int g, int r, int c) {
-        const double v = -w[ti][tj][g]; // X21 = -B_S W
-        B[(kNB + r) * kSW + c] = v;
-        B[c * kSW + kNB + r] = v;       // X12 = X21^T
-        P2[c * L + r] = v;              // X21^T for the last product
-    });
-    zero();
-    staged_xyt(P3, P2, lds, r0, c0, lane, tid, w); // W^T X21 = W^T (X21^T)^T
-    for_quadrant(r0, c0, lane, [&](int ti, int tj, int g, int r, int c) { B[r * kSW + c] = P0[r * L + c] - w[ti][tj][g]; }); // X11
-    if (tid == 0 && n_dead) {
-        if (n_failed) status[0] = 1;
-        atomicAdd(&status[1], n_dead);
+        if (threadIdx.x == 0) __hip_atomic_store(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -579,15 +415,17 @@ __device__ __forceinline__ void pivot_block_lean(const double *__restrict__ D, i
 // both operands are read the same way.  Wave w computes the output columns [32 w, 32 w + 32) of all 64 rows.
 // (kSplit: two workgroups per 64-row block, 32 rows each -- 2 x 116 workgroups instead of 116 on 256 CUs; the panel product
 //  sits between the pivot inverse and the trailing update of every sweep, on the critical path)
+// (ready != nullptr: B comes from the look-ahead's launch on the second stream, which raises *ready when it is complete)
 template <bool kSplit>
-__global__ __launch_bounds__(256) void k_dense_panels(const double *__restrict__ D, int64_t ld, int K, const double *__restrict__ B,
-                                                      double *__restrict__ Cp, double *__restrict__ Wp)
+__global__ __launch_bounds__(256) void k_dense_panels(const double *D, int64_t ld, int K, const double *B, double *__restrict__ Cp,
+                                                      double *__restrict__ Wp, const unsigned int *ready, int spin_limit, int32_t *status)
 {
     constexpr int kRows = kSplit ? kNB / 2 : kNB; // rows of C_i this workgroup takes
     __shared__ double Cs[kRows * kLdh];
     __shared__ double Bs[kSW * kLdh];
     const int i = kSplit ? blockIdx.x >> 1 : blockIdx.x, row0 = kSplit ? (blockIdx.x & 1) * kRows : 0, tid = threadIdx.x;
     if ((i >> 1) == K) return;
+    if (ready != nullptr && !wait_for_counter<false>(ready, 1u, spin_limit, status)) return;
     const int wave = tid >> 6, lane = tid & 63;
     v4d acc[kRows / 32][2][2]; // [row half][ti][tj]
 #pragma unroll
@@ -627,78 +465,119 @@ __global__ __launch_bounds__(256) void k_dense_panels(const double *__restrict__
                 }
 }
 
-// Look-ahead of the block sweep (la.on; FEMSHELL_AMG_DENSE_LOOKAHEAD=0 switches it off): the three tiles of the NEXT pivot
-// block are the first workgroups of the grid; they count themselves done in la.flag (release), and workgroup 3 -- which has
-// no tile -- waits for them (acquire, bounded) and inverts that block into la.B_next while the other workgroups update the
-// rest of the triangle.  The one-workgroup pivot inverse (71 us of dependent steps per sweep, 4.1 of 17.2 ms at 7386 dofs)
-// thereby leaves the critical path without a second stream and its event waits (round 3: 29.7 ms that way).  A workgroup of
-// this kernel has 35 KB of LDS and 128 VGPRs where k_dense_pivot takes 138 KB and 194, so the look-ahead runs
-// pivot_block_lean: the 64 x 66 work blocks in la.scratch (HBM, cache resident), every product staged through the 35 KB
-// in two chunks of 32 columns like the update's own operands, and a sweep that consumes its row panel as it reads it.
-// MEASURED (round 4, 7386 dofs, alternating on one box): 17.1 ms without -> 14.2 ms -> 13.2 ms with the panel kernel's rows
-// split over two workgroups and the symmetrisation pass dropped = 32.2 TFLOP/s issued = 41 % of the FP64 matrix peak.  (The
-// first version ran the unchanged pivot_block with its blocks in HBM: its products behind global loads and 68 spilled
-// doubles took 290 us per sweep, longer than the 161 us update -- 19.2 ms.)
+// Look-ahead of the block sweep (la.on; FEMSHELL_AMG_DENSE_LOOKAHEAD=0 switches it off).  The one-workgroup pivot inverse is 71 us
+// of dependent steps per sweep (4.1 of 17.2 ms at 7386 dofs) in front of everything else.  The tiles of the NEXT pivot block are
+// therefore the first workgroups of the update's grid; they count themselves done in la.flag (release), and the inverse of that
+// block -- k_dense_pivot, launched on a SECOND stream before the update it belongs to -- waits for that count (acquire, bounded),
+// runs beside the rest of the update and raises a second flag the next sweep's panel kernel waits for.  No events: the two
+// streams meet through the two counters only (round 3's version with two event waits per sweep: 29.7 ms).
+// History.  Rounds 4-5 ran the inverse INSIDE the update kernel (a fourth special workgroup, pivot_block_lean: work blocks in HBM
+// scratch, products staged through the update's 35 KB): 17.1 -> 13.2 ms.  Measured in round 5 (rocprofv3, 7776 dofs): that code
+// costs the update itself -- 194 registers wanted, 128 granted at four workgroups per CU, 348 bytes of scratch per lane: 171 us
+// per sweep for the plain instantiation, 194 us for the one that carries the pivot code with the look-ahead switched off, 215 us
+// with it on -- whatever the pivot workgroup did (skipping its work altogether: 205 us).  A launch of its own gives the inverse
+// 138 KB of LDS and its registers without taking either from the 7503 tile workgroups.
 struct DenseLookAhead {
     int on = 0;
-    const double *diag0 = nullptr;
-    double *B_next = nullptr, *scratch = nullptr;
-    int32_t *status = nullptr;
-    unsigned int *flag = nullptr; // one counter per sweep, zero-initialised
-    int spin_limit = 1 << 24;     // polls of the pivot workgroup before it gives up (FEMSHELL_AMG_DENSE_LOOKAHEAD_SPINS: tests)
+    unsigned int *flag = nullptr; // one counter per sweep, zero-initialised: tiles of the next pivot block in place
 };
 
+// Workgroup -> tile of the trailing update, by XCD.  A tile (i, j) reads the operand panels W_i and C_j (64 KB each) besides its
+// own 32 KB, and the two panel arrays (15 MB at 7.4k dofs) do not fit the 4 MB L2 of an XCD: with tiles handed out in linear
+// order -- consecutive workgroups on eight different XCDs -- every XCD streams every panel from the Infinity Cache over and over,
+// 870 MB per sweep beside the 436 MB of the tiles themselves, and the update runs at the rate of that traffic (8 TB/s), not of
+// the matrix cores.  Here the triangle is cut into super-blocks of 8 x 8 tiles; a super-block belongs to ONE XCD (the workgroups
+// with the same blockIdx % 8 share one: cdna_hip_programming.md T1), whose 128 resident workgroups are then two super-blocks:
+// 16 + 16 panels = 2 MB in its L2, each fetched once per super-block.  The host deals the super-blocks out by weight (diagonal
+// and last-row blocks have fewer tiles) and lists them per XCD in row-major order (DenseTileMap::list: (I << 16) | J, -1 = none).
+struct DenseTileMap {
+    const int32_t *list = nullptr; // [8][per_xcd]
+    int per_xcd = 0;               // super-blocks per XCD (the longest list)
+    int nt = 0;                    // 64-tiles per side
+    int linear = 0;                // FEMSHELL_AMG_DENSE_XCD_MAP=0: tiles in linear order of the triangle (A/B runs)
+};
+constexpr int kSb = 8; // tiles per side of a super-block
+
+constexpr int kUpdLds = 2 * kNB * kLdh > kNB * kLdp ? 2 * kNB * kLdh : kNB * kLdp; // doubles of one operand buffer pair
+
+// Columns [32 h, 32 h + 32) of the rows of W_i and C_j into their LDS panels (row stride 34 doubles): kRows x 16 words of 16 bytes
+// per operand, kRows / 16 per thread and operand -- ALL of them in flight before the first is waited for.  The loads are inline
+// assembly because nothing else kept them together: written as plain loads in front of the LDS writes (a loop, unrolled, arrays
+// of registers, sched_group_barrier, amdgpu_waves_per_eu) the compiler's scheduler turns them into load, wait, LDS write, eight
+// times over -- eight memory round trips per chunk instead of one.  One box, 7776 dofs, alternating: 13.5 ms (loop) / 13.2 ms
+// (unrolled, compiler's order) / 12.1 ms (this) for the whole inverse.
+// (The compiler does not count these loads in its own s_waitcnt bookkeeping; they are waited for, all of them, before this function
+//  returns, and loads the compiler issued earlier only complete earlier than it assumes.)
+// MEASURED besides (round 5, per-phase clocks inside the workgroups): a tile workgroup lives 24 us, of which its four matrix
+// phases are 10.6 (2.6 each: 0.85 alone, the rest is the pipe shared with the three other workgroups of the CU), staging 7.2,
+// barriers 2.7, the tile's own values 3.0 before and 0.75 behind.  Built, timed and dropped: global_load_lds_dword straight into the
+// padded rows (13.6 ms against 11.6 on that box: 4-byte transfers), the next chunk travelling behind the matrix instructions
+// into a second LDS buffer at two workgroups per CU (14.0 ms), the same on 128 x 128 tiles (13.9 ms), and a fixed order of
+// precedence (s_setprio) among the four workgroups of a CU against their running in step (12.4 against 12.0 ms).  Memory latency
+// under load (1.5 - 2.5 us per 32 KB chunk) against 0.85 us of matrix work per chunk and wave is the shape of the problem:
+// hiding it takes three or four chunks in flight per workgroup, a ring this kernel does not have.
+typedef double word16 __attribute__((ext_vector_type(2)));
+template <int kRows = kNB>
+__device__ __forceinline__ void stage_chunk(double *Ws, double *Cs, const double *__restrict__ wsrc, const double *__restrict__ csrc,
+                                            int h, int tid)
+{
+    constexpr int kWords = kRows * (kHalf / 2) / 256; // per thread and operand
+    word16 wv[kWords], cv[kWords];
+#pragma unroll
+    for (int q = 0; q < kWords; q++) {
+        const int e = tid + 256 * q, r = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wv[q]) : "v"(wsrc + r * kSW + h * kHalf + k));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cv[q]) : "v"(csrc + r * kSW + h * kHalf + k));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < kWords; q++) {
+        const int e = tid + 256 * q, r = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));
+        *reinterpret_cast<word16 *>(Ws + r * kLdh + k) = wv[q];
+        *reinterpret_cast<word16 *>(Cs + r * kLdh + k) = cv[q];
+    }
+}
+
 // one workgroup per lower 64 x 64 tile (i >= j): the sweep of the 128-wide block K
-// (kLookAhead = false: the kernel without the pivot workgroup's code -- the last sweep, and FEMSHELL_AMG_DENSE_LOOKAHEAD=0)
+// (kLookAhead: the first three workgroups take the tiles of the next pivot block and count themselves done)
 template <bool kLookAhead>
 __global__ __launch_bounds__(256, 4) void k_dense_update(double *__restrict__ D, int64_t ld, int K, const double *__restrict__ B,
-                                                         const double *__restrict__ Cp, const double *__restrict__ Wp, int tiles,
-                                                         DenseLookAhead la)
+                                                                     const double *__restrict__ Cp, const double *__restrict__ Wp,
+                                                                     DenseTileMap map, DenseLookAhead la)
 {
-    __shared__ double lds_upd[2 * kNB * kLdh > kNB * kLdp ? 2 * kNB * kLdh : kNB * kLdp];
+    extern __shared__ double lds_upd[]; // kUpdLds doubles
     double *Ws = lds_upd, *Cs = lds_upd + kNB * kLdh;
     const int tid = threadIdx.x;
     // workgroup -> tile.  With the look-ahead: workgroups 0, 1, 2 take the tiles (2K+2, 2K+2), (2K+3, 2K+2), (2K+3, 2K+3) of the
-    // next pivot block, workgroup 3 is the pivot workgroup, and the tiles those three took are handed to the workgroups that
-    // would have had the indices 0 .. 2 (a swap: every tile still has exactly one workgroup)
-    int t = blockIdx.x;
+    // next pivot block, the map starts at workgroup 3 and whoever it sends to one of the three tiles leaves (every tile still
+    // has exactly one workgroup)
+    int m = blockIdx.x, i = 0, j = 0;
     bool ahead_tile = false;
     if (kLookAhead && la.on) {
         const int i2 = 2 * K + 2;
-        const int t_a = i2 * (i2 + 1) / 2 + i2, t_b = (i2 + 1) * (i2 + 2) / 2 + i2, t_c = t_b + 1; // linear indices of the three tiles
-        if (blockIdx.x == 3) {
-            // ---- the pivot workgroup
-            __shared__ int ok;
-            if (tid == 0) {
-                int spins = 0;
-                while (spins < la.spin_limit && __hip_atomic_load(la.flag + K, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < 3u) {
-                    __builtin_amdgcn_s_sleep(8);
-                    spins++;
-                }
-                ok = spins < la.spin_limit ? 1 : 0;
-                // (not seen on a card of its own: the three tile workgroups precede this one in dispatch order.  The host runs the
-                //  inverse again without the look-ahead: amg_dense_inverse_device)
-                if (!ok) la.status[0] = 2;
-            }
-            __syncthreads();
-            if (!ok) return;
-            __threadfence(); // (acquire for every thread's loads of the three tiles)
-            pivot_block_lean(D, ld, K + 1, la.diag0, la.B_next, la.status, la.scratch, lds_upd);
-            return;
-        }
-        // blockIdx 0..2 -> t_a, t_b, t_c; blockIdx 4.. -> its own index shifted by one, and whoever lands on t_a / t_b / t_c
-        // takes the tile of the workgroup that left (0, 1, 2)
         if (blockIdx.x < 3) {
-            t = blockIdx.x == 0 ? t_a : (blockIdx.x == 1 ? t_b : t_c);
+            i = blockIdx.x == 0 ? i2 : i2 + 1;
+            j = blockIdx.x == 2 ? i2 + 1 : i2;
             ahead_tile = true;
-        } else {
-            t = blockIdx.x - 1;                 // 3 .. tiles-1 (the pivot workgroup took index 3)
-            if (t == t_a) t = 0;
-            else if (t == t_b) t = 1;
-            else if (t == t_c) t = 2;
-            // (t = 3 .. tiles-1 covers every tile but 0, 1, 2 and, through the swap, t_a, t_b, t_c are replaced by them)
         }
-        if (t >= tiles) return;
+        m = (int)blockIdx.x - 3;
+    }
+    if (!ahead_tile) {
+        // (m & 7 labels the workgroups that share an XCD as blockIdx & 7 does: the offset of 3 permutes the labels)
+        if (map.linear) {
+            if (m >= map.nt * (map.nt + 1) / 2) return;
+            i = (int)((sqrt(8.0 * m + 1.0) - 1.0) * 0.5);
+            while ((i + 1) * (i + 2) / 2 <= m) i++;
+            while (i * (i + 1) / 2 > m) i--;
+            j = m - i * (i + 1) / 2;
+        } else {
+            const int idx = m >> 3, sb = map.list[(m & 7) * map.per_xcd + idx / (kSb * kSb)], tin = idx % (kSb * kSb);
+            if (sb < 0) return;
+            i = kSb * (sb >> 16) + tin / kSb;
+            j = kSb * (sb & 0xffff) + tin % kSb;
+            if (i >= map.nt || j > i) return;
+        }
+        if (kLookAhead && la.on && (i >> 1) == K + 1 && (j >> 1) == K + 1) return; // (the first three workgroups took these)
     }
     auto done = [&]() { // a tile of the next pivot block is in place
         if (ahead_tile) {
@@ -707,11 +586,6 @@ __global__ __launch_bounds__(256, 4) void k_dense_update(double *__restrict__ D,
             if (tid == 0) __hip_atomic_fetch_add(la.flag + K, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-    // linear tile index -> (i, j), i >= j
-    int i = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-    while ((i + 1) * (i + 2) / 2 <= t) i++;
-    while (i * (i + 1) / 2 > t) i--;
-    const int j = t - i * (i + 1) / 2;
     double *tile = D + (int64_t)(i * kNB) * ld + j * kNB;
     const bool ki = (i >> 1) == K, kj = (j >> 1) == K;
     if (ki && kj) { // inside the pivot block: -B
@@ -745,20 +619,13 @@ __global__ __launch_bounds__(256, 4) void k_dense_update(double *__restrict__ D,
             }
     // K = 128 in four chunks of 32 (row stride 34 doubles: conflict-free): 35 KB of LDS per workgroup, four per CU
     const double *wsrc = Wp + (int64_t)(i * kNB) * kSW, *csrc = Cp + (int64_t)(j * kNB) * kSW;
-    // (MEASURED, round 5, and dropped: the next chunk's operands fetched into registers while the matrix cores work on this chunk's
-    //  -- eight 16-byte words per thread.  With the look-ahead's pivot code in the same kernel the 128 registers of four workgroups
-    //  per CU do not hold them: 480 bytes of scratch per lane, 25.0 ms instead of 13.7 ms.)
-    for (int h = 0; h < kSW / kHalf; h++) {
-        if (h) __syncthreads(); // the previous chunk's readers are through
-        for (int e = tid; e < kNB * kHalf / 2; e += 256) { // 16-byte words: 16 per row and chunk
-            const int r = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));
-            const double2 wv = *reinterpret_cast<const double2 *>(wsrc + r * kSW + h * kHalf + k);
-            const double2 cv = *reinterpret_cast<const double2 *>(csrc + r * kSW + h * kHalf + k);
-            *reinterpret_cast<double2 *>(Ws + r * kLdh + k) = wv;
-            *reinterpret_cast<double2 *>(Cs + r * kLdh + k) = cv;
+    {
+        for (int h = 0; h < kSW / kHalf; h++) {
+            if (h) __syncthreads(); // the previous chunk's readers are through
+            stage_chunk(Ws, Cs, wsrc, csrc, h, tid);
+            __syncthreads();
+            quadrant_xyt<kHalf, kLdh>(Ws, Cs, r0, c0, lane, acc);
         }
-        __syncthreads();
-        quadrant_xyt<kHalf, kLdh>(Ws, Cs, r0, c0, lane, acc);
     }
 #pragma unroll
     for (int ti = 0; ti < 2; ti++)
@@ -779,7 +646,7 @@ __global__ __launch_bounds__(256, 4) void k_dense_update(double *__restrict__ D,
 // two 128 x 128 operand panels and its tile once for 4.2 MFLOP -- 8.2 flop per byte where the 64-tiles have 5.5.  70 KB of LDS
 // per workgroup (operands in chunks of 32 columns, row stride 34), two workgroups per CU, 128 accumulator registers.
 // Diagonal tiles compute the three quadrants of the lower triangle (the wave of the upper right one stages and waits).
-// Look-ahead: workgroup 0 takes the next pivot block's tile -- ONE tile now -- and workgroup 1 inverts it once it is in place.
+// Look-ahead: workgroup 0 takes the next pivot block's tile -- ONE tile now.
 template <int kDepth, int kStride>
 __device__ __forceinline__ void quadrant64_xyt(const double *Xs, const double *Ys, int r0, int c0, int lane, v4d acc[4][4])
 {
@@ -810,33 +677,13 @@ __global__ __launch_bounds__(256, 2) void k_dense_update128(double *__restrict__
     int t = blockIdx.x;
     bool ahead_tile = false;
     if (kLookAhead && la.on) {
-        const int K1 = K + 1, t_a = K1 * (K1 + 1) / 2 + K1; // the next pivot block's tile
-        if (blockIdx.x == 1) {
-            // ---- the pivot workgroup (see k_dense_update: bounded wait for the workgroup that precedes it in dispatch order)
-            __shared__ int ok;
-            if (tid == 0) {
-                int spins = 0;
-                while (spins < la.spin_limit && __hip_atomic_load(la.flag + K, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < 1u) {
-                    __builtin_amdgcn_s_sleep(8);
-                    spins++;
-                }
-                ok = spins < la.spin_limit ? 1 : 0;
-                if (!ok) la.status[0] = 2;
-            }
-            __syncthreads();
-            if (!ok) return;
-            __threadfence();
-            pivot_block_lean(D, ld, K + 1, la.diag0, la.B_next, la.status, la.scratch, lds_big);
-            return;
-        }
-        if (blockIdx.x == 0) {
+        const int K1 = K + 1, t_a = K1 * (K1 + 1) / 2 + K1; // the next pivot block's tile: workgroup 0 takes it, and whoever
+        if (blockIdx.x == 0) {                              // lands on it takes the tile of the workgroup that left (0)
             t = t_a;
             ahead_tile = true;
-        } else {
-            t = blockIdx.x - 1; // 1 .. stiles-1; whoever lands on t_a takes the tile of the workgroup that left (0)
-            if (t == t_a) t = 0;
+        } else if (t == t_a) {
+            t = 0;
         }
-        if (t >= stiles) return;
     }
     int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
     while ((I + 1) * (I + 2) / 2 <= t) I++;
@@ -881,13 +728,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_update128(double *__restrict__
     const double *wsrc = Wp + (int64_t)(I * kSW) * kSW, *csrc = Cp + (int64_t)(J * kSW) * kSW;
     for (int h = 0; h < kSW / kHalf; h++) {
         if (h) __syncthreads(); // the previous chunk's readers are through
-        for (int e = tid; e < kSW * kHalf / 2; e += 256) { // 16-byte words: 16 per row and chunk, 128 rows
-            const int r = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));
-            const double2 wv = *reinterpret_cast<const double2 *>(wsrc + r * kSW + h * kHalf + k);
-            const double2 cv = *reinterpret_cast<const double2 *>(csrc + r * kSW + h * kHalf + k);
-            *reinterpret_cast<double2 *>(Ws + r * kLdh + k) = wv;
-            *reinterpret_cast<double2 *>(Cs + r * kLdh + k) = cv;
-        }
+        stage_chunk<kSW>(Ws, Cs, wsrc, csrc, h, tid);
         __syncthreads();
         if (!idle) quadrant64_xyt<kHalf, kLdh>(Ws, Cs, r0, c0, lane, acc);
     }
@@ -971,7 +812,7 @@ int dense_inverse_once(femshell_ctx *c, const Bsr &A, bool single_precision, Dev
     *timed_out = false;
     const int n = 6 * A.nr, n_pad = (n + kSW - 1) / kSW * kSW, nt = n_pad / kNB, ns = n_pad / kSW;
     const int64_t ld = n_pad;
-    DevBuf<double> D, diag0, B, Cp, Wp, pivot_scratch;
+    DevBuf<double> D, diag0, B, Cp, Wp;
     DevBuf<unsigned int> la_flags;
     DevBuf<int64_t> dptr;
     DevBuf<int32_t> dcol, dstatus;
@@ -980,8 +821,8 @@ int dense_inverse_once(femshell_ctx *c, const Bsr &A, bool single_precision, Dev
     FS_HIP(D.zero(st));
     FS_HIP(diag0.alloc(n_pad));
     FS_HIP(B.alloc(2 * kSW * kSW)); // (two: the look-ahead writes the next sweep's while this sweep's is read)
-    FS_HIP(pivot_scratch.alloc(4 * (size_t)kNB * kLdp));
-    FS_HIP(la_flags.alloc((size_t)ns + 1));
+    // counters of the look-ahead: [0, ns] tiles of the next pivot block in place (per sweep), [ns + 1, 2 ns + 1] B of a sweep complete
+    FS_HIP(la_flags.alloc(2 * (size_t)ns + 2));
     FS_HIP(la_flags.zero(st));
     FS_HIP(Cp.alloc((size_t)n_pad * kSW));
     FS_HIP(Wp.alloc((size_t)n_pad * kSW));
@@ -1004,23 +845,59 @@ int dense_inverse_once(femshell_ctx *c, const Bsr &A, bool single_precision, Dev
         hipLaunchKernelGGL(k_dense_prepare, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, D.p, ld, n, n_pad, diag0.p);
     }
     const int tiles = nt * (nt + 1) / 2;
+    // super-blocks of the trailing update, dealt out to the eight XCDs by weight (DenseTileMap)
+    DevBuf<int32_t> d_sb_list;
+    DenseTileMap tmap;
+    {
+        const int nsbr = (nt + kSb - 1) / kSb;
+        struct Sb { int I, J, weight; };
+        std::vector<Sb> sbs;
+        for (int I = 0; I < nsbr; I++)
+            for (int J = 0; J <= I; J++) {
+                int w = 0;
+                for (int a = 0; a < kSb; a++)
+                    for (int b = 0; b < kSb; b++) w += (kSb * I + a < nt && kSb * J + b <= kSb * I + a) ? 1 : 0;
+                sbs.push_back({I, J, w});
+            }
+        std::stable_sort(sbs.begin(), sbs.end(), [](const Sb &x, const Sb &y) { return x.weight > y.weight; });
+        std::vector<std::vector<Sb>> lists(8);
+        int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (const Sb &b : sbs) {
+            const int x = (int)(std::min_element(load, load + 8) - load);
+            lists[(size_t)x].push_back(b);
+            load[x] += b.weight;
+        }
+        size_t longest = 1;
+        for (auto &l : lists) {
+            std::sort(l.begin(), l.end(), [](const Sb &x, const Sb &y) { return x.I != y.I ? x.I < y.I : x.J < y.J; });
+            longest = std::max(longest, l.size());
+        }
+        std::vector<int32_t> flat(8 * longest, -1);
+        for (int x = 0; x < 8; x++)
+            for (size_t k = 0; k < lists[(size_t)x].size(); k++) flat[(size_t)x * longest + k] = (lists[(size_t)x][k].I << 16) | lists[(size_t)x][k].J;
+        FS_HIP(d_sb_list.upload(flat, st));
+        tmap.list = d_sb_list.p;
+        tmap.per_xcd = (int)longest;
+        tmap.nt = nt;
+        tmap.linear = (getenv("FEMSHELL_AMG_DENSE_XCD_MAP") && atoi(getenv("FEMSHELL_AMG_DENSE_XCD_MAP")) == 0) ? 1 : 0;
+    }
+    const unsigned update_grid = 8u * (unsigned)tmap.per_xcd * kSb * kSb;
+    const size_t lds_upd_bytes = (size_t)kUpdLds * sizeof(double);
     // LDS of the pivot kernel: four 64 x 66 blocks, the row panel of the sweeps, 128 diagonal entries
     const size_t lds_pivot = (4 * (size_t)kNB * kLdp + 2 * 4 * kNB + 2 * kNB) * sizeof(double);
     FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_pivot), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pivot));
-    // (the pivot kernel is one workgroup and 70 us of dependent steps; running it on a second stream beside the previous
-    //  sweep's update, after bringing its three tiles up to date first, was measured: the two event waits per sweep cost more
-    //  than the overlap gains, 17.3 -> 29.7 ms)
-    // Look-ahead: workgroup `tiles` of the update's grid waits (bounded spin) for workgroups 0-2 of the SAME grid.  That makes
-    // progress because workgroups are dispatched in index order and the three it waits for never wait themselves -- an
-    // observed property of the dispatcher, not a contract: on a card shared with other processes, or under a CU mask, the
-    // bound can expire.  The kernel then marks status 2 and amg_dense_inverse_device runs the whole inverse again with the
-    // pivot as a launch of its own (slower, same numbers).
+    // Look-ahead: the pivot launch on the second stream waits (bounded) for three workgroups of the update on the first, and the
+    // next panel kernel for the pivot launch.  That makes progress because the pivot launch is enqueued in front of the update it
+    // waits for and the two streams run side by side -- how HIP maps streams to hardware queues, not a contract: if the streams
+    // were serialised, or on a card shared with other processes, a bound expires.  The waiting kernel then marks status 2 and
+    // amg_dense_inverse_device runs the whole inverse again with the pivot as a launch in front of every sweep (slower, same
+    // numbers).
     const bool panel_split = !(getenv("FEMSHELL_AMG_DENSE_PANEL_SPLIT") && atoi(getenv("FEMSHELL_AMG_DENSE_PANEL_SPLIT")) == 0);
     // FEMSHELL_AMG_DENSE_TILE=128: the trailing update on 128 x 128 tiles (k_dense_update128; default: 64 x 64, four workgroups
-    // per CU).  MEASURED, round 5, 7386 dofs, alternating on one box: 14.1 ms against 13.7 ms, 192 against 177 us per sweep --
-    // half the operand traffic and four times the matrix instructions per LDS read buy nothing: both kernels leave the matrix
-    // pipe idle half of the time (SQ_VALU_MFMA_BUSY_CYCLES 0.48, profiles/r05_pmc_mfma.json) behind their synchronous operand
-    // staging, and the larger tile has 1711 workgroups for 512 slots (a fourth, nearly empty round).  The measured alternative stays.
+    // per CU).  MEASURED, round 5, 7776 dofs, alternating on one box, both with the look-ahead on the second stream: 15.0 ms
+    // against 13.5 ms (before the loads of a chunk were kept together: stage_chunk) -- half the operand traffic and four times
+    // the matrix instructions per LDS read buy nothing where the workgroups wait for memory latency, and the larger tile has 1891
+    // workgroups for 512 slots (a fourth, nearly empty round).  The measured alternative stays, and stays under test.
     const bool big_tiles = getenv("FEMSHELL_AMG_DENSE_TILE") && atoi(getenv("FEMSHELL_AMG_DENSE_TILE")) == 128;
     const int stiles = ns * (ns + 1) / 2;
     const size_t lds_big_bytes = 2 * (size_t)kSW * kLdh * sizeof(double);
@@ -1028,29 +905,43 @@ int dense_inverse_once(femshell_ctx *c, const Bsr &A, bool single_precision, Dev
         FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_update128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big_bytes));
         FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_update128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big_bytes));
     }
+    // the look-ahead's second stream: made once per context; it meets the first through the counters (and one event, here: the
+    // counters are zero before anything polls them)
+    int spin_limit = 1 << 22; // polls before a waiting workgroup gives up (seconds) (FEMSHELL_AMG_DENSE_LOOKAHEAD_SPINS: tests)
+    if (const char *e = getenv("FEMSHELL_AMG_DENSE_LOOKAHEAD_SPINS")) spin_limit = atoi(e);
+    unsigned int *tiles_in_place = la_flags.p, *b_complete = la_flags.p + ns + 1;
+    if (lookahead && ns > 1) {
+        if (!c->aux_stream) FS_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking)); // (femshell_create made it)
+        hipEvent_t zeroed;
+        FS_HIP(hipEventCreateWithFlags(&zeroed, hipEventDisableTiming));
+        FS_HIP(hipEventRecord(zeroed, st));
+        FS_HIP(hipStreamWaitEvent(c->aux_stream, zeroed, 0));
+        (void)hipEventDestroy(zeroed);
+    }
+    const unsigned int need_tiles = big_tiles ? 1u : 3u;
     for (int K = 0; K < ns; K++) {
         double *Bk = B.p + (size_t)(K & 1) * kSW * kSW;
-        if (K == 0 || !lookahead)
-            hipLaunchKernelGGL(k_dense_pivot, dim3(1), dim3(256), lds_pivot, st, D.p, ld, K, diag0.p, Bk, dstatus.p);
-        if (panel_split) hipLaunchKernelGGL(k_dense_panels<true>, dim3(2 * nt), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p);
-        else hipLaunchKernelGGL(k_dense_panels<false>, dim3(nt), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p);
+        const bool b_from_aux = lookahead && K > 0; // (this sweep's B: by the launch on the second stream during the last sweep)
+        if (!b_from_aux)
+            hipLaunchKernelGGL(k_dense_pivot, dim3(1), dim3(256), lds_pivot, st, D.p, ld, K, diag0.p, Bk, dstatus.p, nullptr, 0u, 0, nullptr);
         DenseLookAhead la;
         if (lookahead && K + 1 < ns) {
             la.on = 1;
-            la.diag0 = diag0.p;
-            la.B_next = B.p + (size_t)((K + 1) & 1) * kSW * kSW;
-            la.scratch = pivot_scratch.p;
-            la.status = dstatus.p;
-            la.flag = la_flags.p;
-            if (const char *e = getenv("FEMSHELL_AMG_DENSE_LOOKAHEAD_SPINS")) la.spin_limit = atoi(e);
+            la.flag = tiles_in_place;
+            // in front of the update it waits for, so that it is resident when the three tiles arrive
+            hipLaunchKernelGGL(k_dense_pivot, dim3(1), dim3(256), lds_pivot, c->aux_stream, D.p, ld, K + 1, diag0.p,
+                               B.p + (size_t)((K + 1) & 1) * kSW * kSW, dstatus.p, tiles_in_place + K, need_tiles, spin_limit, b_complete + K + 1);
         }
+        const unsigned int *ready = b_from_aux ? b_complete + K : nullptr;
+        if (panel_split) hipLaunchKernelGGL(k_dense_panels<true>, dim3(2 * nt), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p, ready, spin_limit, dstatus.p);
+        else hipLaunchKernelGGL(k_dense_panels<false>, dim3(nt), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p, ready, spin_limit, dstatus.p);
         if (big_tiles) {
-            if (la.on) hipLaunchKernelGGL(k_dense_update128<true>, dim3(stiles + 1), dim3(256), lds_big_bytes, st, D.p, ld, K, Bk, Cp.p, Wp.p, stiles, la);
+            if (la.on) hipLaunchKernelGGL(k_dense_update128<true>, dim3(stiles), dim3(256), lds_big_bytes, st, D.p, ld, K, Bk, Cp.p, Wp.p, stiles, la);
             else hipLaunchKernelGGL(k_dense_update128<false>, dim3(stiles), dim3(256), lds_big_bytes, st, D.p, ld, K, Bk, Cp.p, Wp.p, stiles, la);
         } else if (la.on) {
-            hipLaunchKernelGGL(k_dense_update<true>, dim3(tiles + 1), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p, tiles, la);
+            hipLaunchKernelGGL(k_dense_update<true>, dim3(update_grid + 3), dim3(256), lds_upd_bytes, st, D.p, ld, K, Bk, Cp.p, Wp.p, tmap, la);
         } else {
-            hipLaunchKernelGGL(k_dense_update<false>, dim3(tiles), dim3(256), 0, st, D.p, ld, K, Bk, Cp.p, Wp.p, tiles, la);
+            hipLaunchKernelGGL(k_dense_update<false>, dim3(update_grid), dim3(256), lds_upd_bytes, st, D.p, ld, K, Bk, Cp.p, Wp.p, tmap, la);
         }
     }
     const int64_t ldo = (n + 1) / 2 * 2;
@@ -1067,6 +958,7 @@ int dense_inverse_once(femshell_ctx *c, const Bsr &A, bool single_precision, Dev
     int32_t hstatus[2] = {0, 0};
     FS_HIP(hipMemcpyAsync(hstatus, dstatus.p, sizeof hstatus, hipMemcpyDeviceToHost, st));
     FS_HIP(hipStreamSynchronize(st));
+    if (lookahead && c->aux_stream) FS_HIP(hipStreamSynchronize(c->aux_stream)); // (its last launch raised its flag before it ended)
     FS_HIP(hipGetLastError());
     float ms = 0.f;
     FS_HIP(hipEventElapsedTime(&ms, e0, e1));

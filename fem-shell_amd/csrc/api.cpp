@@ -421,6 +421,11 @@ int femshell_create(const femshell_config *cfg, femshell_ctx **out)
     if (e == hipSuccess) e = c->status.zero(c->stream);
     if (e == hipSuccess) e = c->scal.alloc(1);
     if (e == hipSuccess) e = c->scal.zero(c->stream);
+    // the second stream of the dense inverse's look-ahead (amg_dense.hip): made, and used once, here -- the first launch on a new
+    // stream pays for its hardware queue (5 ms), which has no place inside the multigrid setup
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemsetAsync(c->scal.p, 0, sizeof(*c->scal.p), c->aux_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->aux_stream);
     if (e != hipSuccess) {
         (void)femshell_destroy(c); // releases whatever was created
         return set_err(FEMSHELL_ERR_HIP, std::string("femshell_create: ") + hipGetErrorString(e));
@@ -465,6 +470,7 @@ int femshell_destroy(femshell_ctx *c)
     if (c->ev_p_ready) (void)hipEventDestroy(c->ev_p_ready);
     if (c->ev_halo_done) (void)hipEventDestroy(c->ev_halo_done);
     if (c->halo_stream) (void)hipStreamDestroy(c->halo_stream);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->status_host) (void)hipHostFree(c->status_host);
     if (c->agree_host) (void)hipHostFree(c->agree_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
