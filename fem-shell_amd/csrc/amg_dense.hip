@@ -415,6 +415,19 @@ __global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ 
 // both operands are read the same way.  Wave w computes the output columns [32 w, 32 w + 32) of all 64 rows.
 // (kSplit: two workgroups per 64-row block, 32 rows each -- 2 x 116 workgroups instead of 116 on 256 CUs; the panel product
 //  sits between the pivot inverse and the trailing update of every sweep, on the critical path)
+typedef double word16 __attribute__((ext_vector_type(2)));
+// kWords 16-byte loads of one thread, all in flight before the first is waited for (see stage_chunk for why this is assembly)
+template <int kWords> struct WordsInFlight {
+    word16 v[kWords];
+    __device__ __forceinline__ void issue(int q, const double *p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[q]) : "v"(p)); }
+    __device__ __forceinline__ void wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+template <int kCount> struct DoublesInFlight {
+    double v[kCount];
+    __device__ __forceinline__ void issue(int q, const double *p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v[q]) : "v"(p)); }
+    __device__ __forceinline__ void wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
 // (ready != nullptr: B comes from the look-ahead's launch on the second stream, which raises *ready when it is complete)
 template <bool kSplit>
 __global__ __launch_bounds__(256) void k_dense_panels(const double *D, int64_t ld, int K, const double *B, double *__restrict__ Cp,
@@ -437,16 +450,51 @@ __global__ __launch_bounds__(256) void k_dense_panels(const double *D, int64_t l
     const bool below = i > 2 * K + 1;
     for (int ch = 0; ch < kSW / kHalf; ch++) { // columns [32 ch, 32 ch + 32) of C_i = K range of the product
         if (ch) __syncthreads();
-        for (int e = tid; e < kRows * kHalf; e += 256) {
-            const int r = e / kHalf, k = e % kHalf, col = kHalf * ch + k; // column of the sweep block
-            const int64_t gr = (int64_t)i * kNB + row0 + r, gc = (int64_t)2 * K * kNB + col;
-            const double v = below ? D[gr * ld + gc] : D[gc * ld + gr]; // (above: a transposed, column-wise read)
-            Cs[r * kLdh + k] = v;
-            Cp[gr * kSW + col] = v;
+        // B^T[k][n] = B[n][k]: 128 rows x 16 words of 16 bytes, eight per thread, all in flight at once (as scalar loads in a loop
+        // they were sixteen round trips to memory per chunk -- the whole 31 us of this kernel)
+        constexpr int kBWords = kSW * (kHalf / 2) / 256;
+        WordsInFlight<kBWords> bw;
+#pragma unroll
+        for (int q = 0; q < kBWords; q++) {
+            const int e = tid + 256 * q, n = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));
+            bw.issue(q, B + n * kSW + kHalf * ch + k);
         }
-        for (int e = tid; e < kSW * kHalf; e += 256) {
-            const int n = e / kHalf, k = e % kHalf;
-            Bs[n * kLdh + k] = B[n * kSW + kHalf * ch + k]; // B^T[k][n] = B[n][k]
+        if (below) { // rows of the tile: 16 words per row
+            constexpr int kCWords = kRows * (kHalf / 2) / 256;
+            WordsInFlight<kCWords> cw;
+#pragma unroll
+            for (int q = 0; q < kCWords; q++) {
+                const int e = tid + 256 * q, r = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));
+                cw.issue(q, D + ((int64_t)i * kNB + row0 + r) * ld + (int64_t)2 * K * kNB + kHalf * ch + k);
+            }
+            cw.wait();
+#pragma unroll
+            for (int q = 0; q < kCWords; q++) {
+                const int e = tid + 256 * q, r = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));
+                *reinterpret_cast<word16 *>(Cs + r * kLdh + k) = cw.v[q];
+                *reinterpret_cast<word16 *>(Cp + ((int64_t)i * kNB + row0 + r) * kSW + kHalf * ch + k) = cw.v[q];
+            }
+        } else { // above the pivot block: the transposed tiles (2K, i), (2K+1, i), read along their rows (consecutive threads:
+                 // consecutive addresses), eight bytes at a time
+            constexpr int kCount = kRows * kHalf / 256;
+            DoublesInFlight<kCount> cd;
+#pragma unroll
+            for (int q = 0; q < kCount; q++) {
+                const int e = tid + 256 * q, r = e % kRows, k = e / kRows;
+                cd.issue(q, D + ((int64_t)2 * K * kNB + kHalf * ch + k) * ld + (int64_t)i * kNB + row0 + r);
+            }
+            cd.wait();
+#pragma unroll
+            for (int q = 0; q < kCount; q++) {
+                const int e = tid + 256 * q, r = e % kRows, k = e / kRows;
+                Cs[r * kLdh + k] = cd.v[q];
+                Cp[((int64_t)i * kNB + row0 + r) * kSW + kHalf * ch + k] = cd.v[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kBWords; q++) {
+            const int e = tid + 256 * q, n = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));
+            *reinterpret_cast<word16 *>(Bs + n * kLdh + k) = bw.v[q];
         }
         __syncthreads();
 #pragma unroll
@@ -516,7 +564,6 @@ constexpr int kUpdLds = 2 * kNB * kLdh > kNB * kLdp ? 2 * kNB * kLdh : kNB * kLd
 // precedence (s_setprio) among the four workgroups of a CU against their running in step (12.4 against 12.0 ms).  Memory latency
 // under load (1.5 - 2.5 us per 32 KB chunk) against 0.85 us of matrix work per chunk and wave is the shape of the problem:
 // hiding it takes three or four chunks in flight per workgroup, a ring this kernel does not have.
-typedef double word16 __attribute__((ext_vector_type(2)));
 template <int kRows = kNB>
 __device__ __forceinline__ void stage_chunk(double *Ws, double *Cs, const double *__restrict__ wsrc, const double *__restrict__ csrc,
                                             int h, int tid)
@@ -615,6 +662,8 @@ __global__ __launch_bounds__(256, 4) void k_dense_update(double *__restrict__ D,
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int r = r0 + 16 * ti + (lane >> 4) + 4 * g, c = c0 + 16 * tj + (lane & 15);
+                // (kept in registers of their own until the end -- A - W C^T -- they would not be waited for before the first operand
+                //  loads go out, 3 us per tile; measured: 32 more registers spill at four workgroups per CU, 202 against 180 us per sweep)
                 acc[ti][tj][g] = -tile[(int64_t)r * ld + c]; // accumulate W C^T - A, store its negative
             }
     // K = 128 in four chunks of 32 (row stride 34 doubles: conflict-free): 35 KB of LDS per workgroup, four per CU
