@@ -811,9 +811,9 @@ def main():
                    "roofline": {"bound": "mfma", "achieved": dst["mfma_flops_issued"] / max(dst["ms"], 1e-9) / 1e9, "peak": 78.6,
                                 "unit": "TFLOP/s", "frac": dst["mfma_flops_issued"] / max(dst["ms"], 1e-9) / 1e9 / 78.6,
                                 "note": "FP64 matrix peak 78.6 TFLOP/s; 64x64 tiles, block sweeps of width 128: the lower triangle is read and "
-                                        "written once per sweep (58 sweeps at 7386 dofs); the pivot block of the next sweep is inverted by a "
-                                        "reserved workgroup inside the trailing update's launch (17.1 ms with a launch of its own in front of "
-                                        "every sweep, FEMSHELL_AMG_DENSE_LOOKAHEAD=0)"},
+                                        "written once per sweep (58 sweeps at 7386 dofs); the pivot block of the next sweep is inverted by a launch of "
+                                        "its own on a second stream beside the trailing update, the two meeting through device-side counters "
+                                        "(FEMSHELL_AMG_DENSE_LOOKAHEAD=0: in front of every sweep instead, 1.4 times the time)"},
                    # the same by rocprofv3 counters (tools/pmc_mfma.py: SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 flops over the kernel times of an
                    # unprofiled trace; SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMDs x GRBM_GUI_ACTIVE / 8), committed summary of the same solve
                    "mfma_counters_from_committed_profile": mfma_counter_summary()},

@@ -517,9 +517,10 @@ def test_dense_inverse_on_the_matrix_cores_equals_the_host_inverse(monkeypatch, 
 
 
 def test_dense_inverse_runs_again_without_the_look_ahead_when_its_wait_expires(monkeypatch):
-    """The pivot workgroup of the look-ahead waits, bounded, for three workgroups of its own launch (csrc/amg_dense.hip).  On a
-    card shared with other processes that wait can expire: the setup then runs the inverse again with the pivot as a launch
-    of its own instead of failing.  Forced here by a spin limit of zero; same solution as with the look-ahead."""
+    """The look-ahead's pivot launch (second stream) waits, bounded, for three workgroups of the update on the first stream, and
+    the next panel kernel for the pivot launch (csrc/amg_dense.hip).  If the two streams do not run side by side, or on a card
+    shared with other processes, a wait can expire: the setup then runs the inverse again with the pivot as a launch in front of
+    every sweep instead of failing.  Forced here by a spin limit of zero; same solution as with the look-ahead."""
     m, mat = _make("panel", 48)
     sols = {}
     for spins in (None, "0"):
