@@ -439,7 +439,7 @@ def mfma_counter_summary():
     with open(path) as f:
         d = json.load(f)
     out = dict(d.get("all_kernels_of_the_inverse", {}), source="profiles/r05_pmc_mfma.json")
-    upd = d.get("kernels", {}).get("k_dense_update<true>")
+    upd = d.get("kernels", {}).get("k_dense_update") or d.get("kernels", {}).get("k_dense_update<true>")
     if upd:
         out["k_dense_update"] = {"tflops_by_counter": upd["tflops_by_counter"], "mfma_busy_fraction": upd["mfma_busy_fraction"],
                                  "launches": upd["launches"]}

@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Matrix-core counters of the dense inverse of the coarsest operator (csrc/amg_dense.hip), from rocprofv3 counter passes over
-tools/amg_probe.py:   pmc_mfma.py <busy_pass.csv> <mops_pass.csv> <kernel_trace.csv> <out.json>
+tools/amg_probe.py:   pmc_mfma.py <busy_pass.csv> <mops_pass.csv> <kernel_trace.csv> <out.json> [<probe.txt of the trace pass>]
+The counter passes run with FEMSHELL_AMG_DENSE_LOOKAHEAD=0 (rocprofv3 serialises launches while it collects counters; the look-ahead's
+launch on the second stream would wait for a launch that cannot start): same kernels, same flops, kernel names without the
+template arguments.  Time base of the whole inverse: the wall time the library measured in the trace pass (probe.txt; the pivot
+launches overlap the updates there, so kernel durations do not add up to it); per kernel: durations of the trace pass.
   pass 1: --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE      pass 2: --pmc SQ_INSTS_VALU_MFMA_MOPS_F64
 Derived, per kernel and over all kernels of the inverse:
   flops_by_counter      = SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 (the counter's unit)  -- against the flops the host counts as issued
@@ -15,7 +19,8 @@ from collections import defaultdict
 
 
 def clean(name):
-    return re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", "")).replace("void ", "").replace("femshell::", "")
+    name = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", "")).replace("void ", "").replace("femshell::", "")
+    return re.sub(r"<.*", "", name) if name.startswith("k_dense_") and not name.startswith("k_dense_gemv") else name
 
 
 def counters(path):
@@ -58,7 +63,14 @@ def main():
         out["kernels"][k] = e
         for key in ("seconds_unprofiled_trace", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "flops_by_counter"):
             tot[key] += e[key]
+    wall = None
+    if len(sys.argv) > 5:
+        m = re.search(r"dense inverse of the coarsest operator on the matrix cores: n = \d+, ([0-9.]+) ms", open(sys.argv[5]).read())
+        wall = float(m.group(1)) * 1e-3 if m else None
+    if wall:  # (one inverse per probe run)
+        tot["seconds_unprofiled_trace"] = wall
     out["all_kernels_of_the_inverse"] = {
+        "time_base": "wall time of the inverse as the library measured it in the trace pass" if wall else "sum of kernel durations",
         "seconds_unprofiled_trace": tot["seconds_unprofiled_trace"], "flops_by_counter": tot["flops_by_counter"],
         "tflops_by_counter": tot["flops_by_counter"] / tot["seconds_unprofiled_trace"] / 1e12 if tot["seconds_unprofiled_trace"] else None,
         "frac_of_78.6_tflops_by_counter": tot["flops_by_counter"] / tot["seconds_unprofiled_trace"] / 1e12 / 78.6 if tot["seconds_unprofiled_trace"] else None,

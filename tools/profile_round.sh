@@ -32,12 +32,14 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_
 cp $(one $out/${tag}_amg_stats "*kernel_stats.csv") $out/${tag}_amg_kernel_stats.csv 2> /dev/null
 python3 tools/kernel_trace_by_grid.py $(one $out/${tag}_amg_stats "*kernel_trace.csv") $out/${tag}_amg_kernels_by_level.txt
 python3 tools/amg_level_times.py $out/${tag}_amg_kernels_by_level.txt $out/${tag}_amg_probe.txt $out/${tag}_amg_by_level.json
-timeout 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_amg_fetch -o f -- python3 tools/amg_probe.py panel 1414 > /dev/null 2> $out/${tag}_amg_fetch.err
-timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_amg_write -o w -- python3 tools/amg_probe.py panel 1414 > /dev/null 2> $out/${tag}_amg_write.err
+FEMSHELL_AMG_DENSE_LOOKAHEAD=0 timeout 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_amg_fetch -o f -- python3 tools/amg_probe.py panel 1414 > /dev/null 2> $out/${tag}_amg_fetch.err
+FEMSHELL_AMG_DENSE_LOOKAHEAD=0 timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_amg_write -o w -- python3 tools/amg_probe.py panel 1414 > /dev/null 2> $out/${tag}_amg_write.err
 python3 tools/pmc_by_grid.py $(one $out/${tag}_amg_fetch "*counter_collection.csv") $(one $out/${tag}_amg_write "*counter_collection.csv") $(one $out/${tag}_amg_stats "*kernel_trace.csv") > $out/${tag}_amg_traffic_by_level.txt
-timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/${tag}_mfma_busy -o b -- python3 tools/amg_probe.py panel 1414 > /dev/null 2> $out/${tag}_mfma_busy.err
-timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 --output-format csv -d $out/${tag}_mfma_mops -o m -- python3 tools/amg_probe.py panel 1414 > /dev/null 2> $out/${tag}_mfma_mops.err
-python3 tools/pmc_mfma.py $(one $out/${tag}_mfma_busy "*counter_collection.csv") $(one $out/${tag}_mfma_mops "*counter_collection.csv") $(one $out/${tag}_amg_stats "*kernel_trace.csv") $out/${tag}_pmc_mfma.json
+# (counter passes serialise launches: the look-ahead of the dense inverse, which waits across two streams, is switched off in them --
+#  in ALL counter passes over the multigrid solve, or each would first run into its bounded waits)
+FEMSHELL_AMG_DENSE_LOOKAHEAD=0 timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/${tag}_mfma_busy -o b -- python3 tools/amg_probe.py panel 1414 > /dev/null 2> $out/${tag}_mfma_busy.err
+FEMSHELL_AMG_DENSE_LOOKAHEAD=0 timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 --output-format csv -d $out/${tag}_mfma_mops -o m -- python3 tools/amg_probe.py panel 1414 > /dev/null 2> $out/${tag}_mfma_mops.err
+python3 tools/pmc_mfma.py $(one $out/${tag}_mfma_busy "*counter_collection.csv") $(one $out/${tag}_mfma_mops "*counter_collection.csv") $(one $out/${tag}_amg_stats "*kernel_trace.csv") $out/${tag}_pmc_mfma.json $out/${tag}_amg_probe.txt
 rm -rf $out/${tag}_amg_stats $out/${tag}_amg_fetch $out/${tag}_amg_write $out/${tag}_mfma_busy $out/${tag}_mfma_mops
 # ---- the default bench run comes last and sees the summaries (bench.py attaches `traffic` and the per-level times only from a
 # profile taken with the same kernel sources; on the box the copies under profiles/ are scratch -- commit them from gpurun_out/)
