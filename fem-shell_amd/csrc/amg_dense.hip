@@ -391,6 +391,21 @@ __device__ __forceinline__ bool wait_for_counter(const unsigned int *counter, un
     return ok != 0;
 }
 
+// Do the context's two streams run side by side?  HIP maps streams onto a handful of hardware queues (four by default): in a
+// process with many streams two of them can share one, and a launch that waits for a launch BEHIND it in the same queue waits
+// for its bound.  Asked once per context, with the question itself: a launch on the second stream that waits (briefly) for a
+// counter, a launch on the first that raises it.
+__global__ void k_streams_probe_wait(unsigned int *flag, int spins, int32_t *seen)
+{
+    int n = 0;
+    while (n < spins && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(8);
+        n++;
+    }
+    *seen = n < spins ? 1 : 0;
+}
+__global__ void k_streams_probe_raise(unsigned int *flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // wait_tiles != nullptr: the look-ahead's launch on the second stream -- the inverse of pivot block K starts when the update of
 // sweep K - 1 (first stream, same time) has counted its `need` tiles in place, and `done` announces B to the panel kernel.
 __global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ D, int64_t ld, int K, const double *__restrict__ diag0,
@@ -959,8 +974,27 @@ int dense_inverse_once(femshell_ctx *c, const Bsr &A, bool single_precision, Dev
     int spin_limit = 1 << 22; // polls before a waiting workgroup gives up (seconds) (FEMSHELL_AMG_DENSE_LOOKAHEAD_SPINS: tests)
     if (const char *e = getenv("FEMSHELL_AMG_DENSE_LOOKAHEAD_SPINS")) spin_limit = atoi(e);
     unsigned int *tiles_in_place = la_flags.p, *b_complete = la_flags.p + ns + 1;
-    if (lookahead && ns > 1) {
+    if (lookahead && ns > 1 && c->aux_streams_side_by_side == 0) {
         if (!c->aux_stream) FS_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking)); // (femshell_create made it)
+        DevBuf<unsigned int> flag;
+        DevBuf<int32_t> seen;
+        FS_HIP(flag.alloc(1));
+        FS_HIP(seen.alloc(1));
+        FS_HIP(flag.zero(st));
+        FS_HIP(seen.zero(st));
+        FS_HIP(hipStreamSynchronize(st));
+        hipLaunchKernelGGL(k_streams_probe_wait, dim3(1), dim3(1), 0, c->aux_stream, flag.p, 8000, seen.p); // (a few milliseconds at most)
+        hipLaunchKernelGGL(k_streams_probe_raise, dim3(1), dim3(1), 0, st, flag.p);
+        FS_HIP(hipStreamSynchronize(c->aux_stream));
+        FS_HIP(hipStreamSynchronize(st));
+        int32_t h = 0;
+        FS_HIP(hipMemcpy(&h, seen.p, sizeof h, hipMemcpyDeviceToHost));
+        c->aux_streams_side_by_side = h ? 1 : -1;
+        if (!h && getenv("FEMSHELL_AMG_VERBOSE") && atoi(getenv("FEMSHELL_AMG_VERBOSE")) != 0)
+            fprintf(stderr, "[femshell amg setup] the context's two streams share a hardware queue: dense inverse without its look-ahead\n");
+    }
+    if (lookahead && c->aux_streams_side_by_side < 0) lookahead = false;
+    if (lookahead && ns > 1) {
         hipEvent_t zeroed;
         FS_HIP(hipEventCreateWithFlags(&zeroed, hipEventDisableTiming));
         FS_HIP(hipEventRecord(zeroed, st));

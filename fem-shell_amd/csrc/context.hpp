@@ -194,7 +194,8 @@ struct femshell_ctx {
     femshell::DevBuf<double> agree;
     // halo exchange beside the interior SpMV (multi-rank contexts): second stream + hand-off events
     hipStream_t halo_stream = nullptr;
-    hipStream_t aux_stream = nullptr; // the look-ahead of the dense inverse (amg_dense.hip): made on first use
+    hipStream_t aux_stream = nullptr; // the look-ahead of the dense inverse (amg_dense.hip)
+    int aux_streams_side_by_side = 0; // 0: not asked yet, 1: stream and aux_stream run concurrently, -1: they share a hardware queue
     // first-contact self-test of femshell_comm_init (comm.cpp comm_selftest): microseconds of its three patterns
     double comm_selftest_us[3] = {-1.0, -1.0, -1.0};
     bool comm_selftest_done = false;

@@ -539,6 +539,31 @@ def test_dense_inverse_runs_again_without_the_look_ahead_when_its_wait_expires(m
     np.testing.assert_array_equal(sols[None][0], sols["0"][0])
 
 
+def test_dense_inverse_look_ahead_in_a_process_with_many_streams(monkeypatch):
+    """The look-ahead of the dense inverse runs on a second stream of the context and meets the first through device-side counters
+    (csrc/amg_dense.hip).  HIP maps streams onto a few hardware queues: in a process with many contexts the two streams of one
+    can share a queue, and the pivot launch would wait -- for its full bound -- for an update queued BEHIND it.  The context
+    asks once whether its streams run side by side and does without the look-ahead if not: setups stay in the tens of
+    milliseconds whatever the answer is, and the solution is the same."""
+    monkeypatch.setenv("FEMSHELL_AMG_DENSE_DEVICE_MIN", "0")
+    m, mat = _make("panel", 48)
+    keep, times, sols = [], [], []
+    for k in range(7):  # fourteen streams in the end
+        fs = _context(m, mat)
+        fs.set_preconditioner("amg", coarsest_nodes=300)
+        u, info = fs.solve(rtol=1e-12, max_it=500)
+        assert info["converged"] == 1 and fs.amg_dense_stats()["n"] > 1200
+        times.append(info["pc_setup_seconds"])
+        sols.append((u, info["iterations"]))
+        keep.append(fs)
+    for fs in keep:
+        fs.close()
+    assert max(times[1:]) < 0.25, times  # (a bound that expired cost more than a second; the first setup loads the code objects)
+    for u, its in sols[1:]:
+        assert abs(its - sols[0][1]) <= 1
+        assert np.linalg.norm(u - sols[0][0]) <= 1e-9 * np.linalg.norm(sols[0][0])
+
+
 def test_dense_inverse_on_the_matrix_cores_drops_semi_definite_directions(monkeypatch):
     """The reference's Test A fixes u, v, w at three collinear nodes only: the rotation about that line has no stiffness,
     and the inverse of the coarsest operator (here K itself, 27 nodes) has to drop it -- same rule on the device as on the
