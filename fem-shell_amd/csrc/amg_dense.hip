@@ -22,6 +22,7 @@
 #include "device_common.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -866,6 +867,47 @@ __global__ __launch_bounds__(256) void k_dense_gemv_big(const T *__restrict__ A,
 
 } // namespace
 
+int amg_dense_probe_streams(femshell_ctx *c)
+{
+    hipStream_t st = c->stream;
+    const bool verbose = getenv("FEMSHELL_AMG_VERBOSE") && atoi(getenv("FEMSHELL_AMG_VERBOSE")) != 0;
+    DevBuf<unsigned int> flag;
+    DevBuf<int32_t> seen;
+    FS_HIP(flag.alloc(1));
+    FS_HIP(seen.alloc(1));
+    // (a second stream that turns out to share the first one's hardware queue: three more are made, all alive at once so that they
+    //  sit on different queues, and the first that runs beside the main stream is kept)
+    hipStream_t candidates[4] = {c->aux_stream, nullptr, nullptr, nullptr};
+    int kept = -1;
+    for (int k = 0; k < 4 && kept < 0; k++) {
+        if (k == 1)
+            for (int q = 1; q < 4; q++) FS_HIP(hipStreamCreateWithFlags(&candidates[q], hipStreamNonBlocking));
+        if (!candidates[k]) FS_HIP(hipStreamCreateWithFlags(&candidates[k], hipStreamNonBlocking));
+        const double t_probe = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        FS_HIP(flag.zero(st));
+        FS_HIP(seen.zero(st));
+        FS_HIP(hipStreamSynchronize(st));
+        hipLaunchKernelGGL(k_streams_probe_wait, dim3(1), dim3(1), 0, candidates[k], flag.p, 8000, seen.p); // (a few milliseconds at most)
+        hipLaunchKernelGGL(k_streams_probe_raise, dim3(1), dim3(1), 0, st, flag.p);
+        FS_HIP(hipStreamSynchronize(candidates[k]));
+        FS_HIP(hipStreamSynchronize(st));
+        int32_t h = 0;
+        FS_HIP(hipMemcpy(&h, seen.p, sizeof h, hipMemcpyDeviceToHost));
+        if (verbose)
+            fprintf(stderr, "[femshell] do the context's two streams run side by side: %s (asked in %.3f ms)\n", h ? "yes" : "no",
+                    1e3 * (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_probe));
+        if (h) kept = k;
+    }
+    c->aux_streams_side_by_side = kept >= 0 ? 1 : -1;
+    c->aux_stream = candidates[kept >= 0 ? kept : 0];
+    for (int k = 0; k < 4; k++)
+        if (candidates[k] && candidates[k] != c->aux_stream) FS_HIP(hipStreamDestroy(candidates[k]));
+    if (c->aux_streams_side_by_side < 0) {
+        if (verbose) fprintf(stderr, "[femshell] no second stream on a hardware queue of its own: dense inverse without its look-ahead\n");
+    }
+    return FEMSHELL_OK;
+}
+
 namespace {
 
 // (*timed_out: the look-ahead's bounded wait expired -- the caller runs the inverse again without it)
@@ -876,6 +918,11 @@ int dense_inverse_once(femshell_ctx *c, const Bsr &A, bool single_precision, Dev
     *timed_out = false;
     const int n = 6 * A.nr, n_pad = (n + kSW - 1) / kSW * kSW, nt = n_pad / kNB, ns = n_pad / kSW;
     const int64_t ld = n_pad;
+    if (lookahead && ns > 1 && c->aux_streams_side_by_side == 0) { // (femshell_create asked; a context made some other way asks here)
+        const int rc = amg_dense_probe_streams(c);
+        if (rc) return rc;
+    }
+    if (lookahead && c->aux_streams_side_by_side < 0) lookahead = false;
     DevBuf<double> D, diag0, B, Cp, Wp;
     DevBuf<unsigned int> la_flags;
     DevBuf<int64_t> dptr;
@@ -974,25 +1021,6 @@ int dense_inverse_once(femshell_ctx *c, const Bsr &A, bool single_precision, Dev
     int spin_limit = 1 << 22; // polls before a waiting workgroup gives up (seconds) (FEMSHELL_AMG_DENSE_LOOKAHEAD_SPINS: tests)
     if (const char *e = getenv("FEMSHELL_AMG_DENSE_LOOKAHEAD_SPINS")) spin_limit = atoi(e);
     unsigned int *tiles_in_place = la_flags.p, *b_complete = la_flags.p + ns + 1;
-    if (lookahead && ns > 1 && c->aux_streams_side_by_side == 0) {
-        if (!c->aux_stream) FS_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking)); // (femshell_create made it)
-        DevBuf<unsigned int> flag;
-        DevBuf<int32_t> seen;
-        FS_HIP(flag.alloc(1));
-        FS_HIP(seen.alloc(1));
-        FS_HIP(flag.zero(st));
-        FS_HIP(seen.zero(st));
-        FS_HIP(hipStreamSynchronize(st));
-        hipLaunchKernelGGL(k_streams_probe_wait, dim3(1), dim3(1), 0, c->aux_stream, flag.p, 8000, seen.p); // (a few milliseconds at most)
-        hipLaunchKernelGGL(k_streams_probe_raise, dim3(1), dim3(1), 0, st, flag.p);
-        FS_HIP(hipStreamSynchronize(c->aux_stream));
-        FS_HIP(hipStreamSynchronize(st));
-        int32_t h = 0;
-        FS_HIP(hipMemcpy(&h, seen.p, sizeof h, hipMemcpyDeviceToHost));
-        c->aux_streams_side_by_side = h ? 1 : -1;
-        if (!h && getenv("FEMSHELL_AMG_VERBOSE") && atoi(getenv("FEMSHELL_AMG_VERBOSE")) != 0)
-            fprintf(stderr, "[femshell amg setup] the context's two streams share a hardware queue: dense inverse without its look-ahead\n");
-    }
     if (lookahead && c->aux_streams_side_by_side < 0) lookahead = false;
     if (lookahead && ns > 1) {
         hipEvent_t zeroed;

@@ -173,6 +173,9 @@ int download_matrix(femshell_ctx *c, Bsr *A, int32_t *col_out = nullptr, double 
 // Dense inverse of the coarsest operator on the device (amg_dense.hip): symmetric block sweeps on v_mfma_f64_16x16x4_f64.
 // Exactly one of inv64 / inv32 is filled (rows of *lda entries); FEMSHELL_ERR_BREAKDOWN for an operator that is not
 // positive semi-definite (same pivot rules as the host's dense_inverse)
+// Asks, once per context, whether c->stream and c->aux_stream run side by side (the look-ahead of the dense inverse needs that; a
+// process with many streams can have two of them on one hardware queue): c->aux_streams_side_by_side = 1 / -1.
+int amg_dense_probe_streams(femshell_ctx *c);
 int amg_dense_inverse_device(femshell_ctx *c, const Bsr &A, bool single_precision, DevBuf<double> *inv64, DevBuf<float> *inv32,
                              int64_t *lda_out, AmgDenseStats *stats);
 // y = Ainv b for such an inverse (one of A64 / A32 non-null); rows [n, n_pad6) of y are set to zero

@@ -426,6 +426,7 @@ int femshell_create(const femshell_config *cfg, femshell_ctx **out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMemsetAsync(c->scal.p, 0, sizeof(*c->scal.p), c->aux_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->aux_stream);
+    if (e == hipSuccess && amg_dense_probe_streams(c) != FEMSHELL_OK) e = hipErrorUnknown; // (do the two run side by side?  10 ms the first time)
     if (e != hipSuccess) {
         (void)femshell_destroy(c); // releases whatever was created
         return set_err(FEMSHELL_ERR_HIP, std::string("femshell_create: ") + hipGetErrorString(e));
