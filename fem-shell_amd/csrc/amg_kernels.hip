@@ -298,7 +298,7 @@ __global__ __launch_bounds__(192) void k_pcg_update_start(DeviceMatrix m, CgVect
     if (v.s->done != 0) return;
     const int t = threadIdx.x, n = t / 6, j = t % 6;
     const double alpha = v.s->alpha;
-    double d1 = 0.0;
+    double d1 = 0.0, d2 = 0.0; // r.r and x.x (the refinement pass's stopping rule: CG_PHASE_FLEX_CONV)
     for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
         const int sl = w.s;
         const int64_t row = (int64_t)sl * kSliceRows + t;
@@ -309,7 +309,9 @@ __global__ __launch_bounds__(192) void k_pcg_update_start(DeviceMatrix m, CgVect
             qv = gather_transposed<false>(m, sl, n, j, qv);
             v.q[row] = qv;
         }
-        v.x[row] = xv + alpha * pv;
+        const double xn = xv + alpha * pv;
+        v.x[row] = xn;
+        d2 += xn * xn;
         const double rn = rv - alpha * qv;
         v.r[row] = rn;
         d1 += rn * rn;
@@ -322,7 +324,12 @@ __global__ __launch_bounds__(192) void k_pcg_update_start(DeviceMatrix m, CgVect
         z[row] = dv;
     }
     const double t1 = block_sum(d1, sh);
-    if (threadIdx.x == 0) v.partials[blockIdx.x] = t1;
+    __syncthreads();
+    const double t2 = block_sum(d2, sh);
+    if (threadIdx.x == 0) {
+        v.partials[blockIdx.x] = t1;
+        v.partials[gridDim.x + blockIdx.x] = t2;
+    }
 }
 
 // (launched with the grid of the per-slice kernels, slice_grid(m): the scalar step reduces that many partial sums)
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(64) void k_pcg_update_start_node(DeviceMatrix m, Cg
     if (v.s->done != 0) return;
     const int half = threadIdx.x >> 5, n = threadIdx.x & 31;
     const double alpha = v.s->alpha;
-    double d1 = 0.0;
+    double d1 = 0.0, d2 = 0.0;
     for (SliceWalk w(node_pairs(m.n_slices)); w.valid(); w.next()) {
         const int sl = 2 * w.s + half;
         if (sl >= m.n_slices) continue;
@@ -351,6 +358,7 @@ __global__ __launch_bounds__(64) void k_pcg_update_start_node(DeviceMatrix m, Cg
 #pragma unroll
         for (int j = 0; j < 6; j++) {
             xv[j] = xv[j] + alpha * pv[j];
+            d2 += xv[j] * xv[j];
             const double rn = rv[j] - alpha * qv[j];
             rv[j] = rn;
             d1 += rn * rn;
@@ -363,8 +371,11 @@ __global__ __launch_bounds__(64) void k_pcg_update_start_node(DeviceMatrix m, Cg
         store_node6(d, node, kD32, zz);
         store_node6(z, node, false, zz);
     }
-    const double t1 = wave_sum(d1);
-    if (threadIdx.x == 0) v.partials[blockIdx.x] = t1;
+    const double t1 = wave_sum(d1), t2 = wave_sum(d2);
+    if (threadIdx.x == 0) {
+        v.partials[blockIdx.x] = t1;
+        v.partials[gridDim.x + blockIdx.x] = t2;
+    }
 }
 
 void launch_pcg_update_start(const DeviceMatrix &m, const CgVectors &v, double *d, double *z, double inv_theta, bool gather, bool d32,
@@ -487,17 +498,24 @@ __global__ __launch_bounds__(192) void k_pcg_update(DeviceMatrix m, CgVectors v)
     if (v.s->done != 0) return;
     const int t = threadIdx.x;
     const double alpha = v.s->alpha;
-    double d1 = 0.0;
+    double d1 = 0.0, d2 = 0.0;
     for (SliceWalk w(m.n_slices); w.valid(); w.next()) {
         const int64_t row = (int64_t)w.s * kSliceRows + t;
         const double pv = v.p[row], qv = v.q[row], xv = v.x[row], rv = v.r[row];
-        v.x[row] = xv + alpha * pv;
+        const double xn = xv + alpha * pv;
+        v.x[row] = xn;
+        d2 += xn * xn;
         const double rn = rv - alpha * qv;
         v.r[row] = rn;
         d1 += rn * rn;
     }
     const double t1 = block_sum(d1, sh);
-    if (threadIdx.x == 0) v.partials[blockIdx.x] = t1;
+    __syncthreads();
+    const double t2 = block_sum(d2, sh);
+    if (threadIdx.x == 0) {
+        v.partials[blockIdx.x] = t1;
+        v.partials[gridDim.x + blockIdx.x] = t2;
+    }
 }
 
 void launch_pcg_update(const DeviceMatrix &m, const CgVectors &v, hipStream_t st)

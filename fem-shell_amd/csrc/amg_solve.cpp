@@ -1085,6 +1085,39 @@ int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate
     return FEMSHELL_OK;
 }
 
+// ||a||^2 and ||b||^2 over the owned rows of all ranks (two partial arrays of 128 groups, room for a third, and behind them the
+// two-word staging slot of the all-reduce)
+static int two_squared_norms(femshell_ctx *c, const double *a, const double *b, int64_t n6, double sums[2])
+{
+    hipStream_t st = c->stream;
+    constexpr size_t kDotsStage = 3 * 128;
+    FS_HIP(c->dots_scratch.alloc(kDotsStage + 2));
+    const int groups = launch_two_dots(a, a, b, b, n6, c->dots_scratch.p, st);
+    double hp[2 * 128];
+    FS_HIP(hipMemcpyAsync(hp, c->dots_scratch.p, sizeof hp, hipMemcpyDeviceToHost, st));
+    FS_HIP(hipStreamSynchronize(st));
+    sums[0] = sums[1] = 0.0;
+    for (int g = 0; g < groups; g++) {
+        sums[0] += hp[g];
+        sums[1] += hp[128 + g];
+    }
+    if (c->comm.active()) { // every rank holds its own rows
+        FS_HIP(hipMemcpyAsync(c->dots_scratch.p + kDotsStage, sums, 2 * sizeof(double), hipMemcpyHostToDevice, st));
+        std::string e;
+        if (!comm_allreduce_sum(c->comm, c->dots_scratch.p + kDotsStage, 2, st, &e)) return set_err(FEMSHELL_ERR_COMM, e);
+        FS_HIP(hipMemcpyAsync(sums, c->dots_scratch.p + kDotsStage, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        FS_HIP(hipStreamSynchronize(st));
+    }
+    return FEMSHELL_OK;
+}
+static int squared_norm(femshell_ctx *c, const double *a, int64_t n6, double *out)
+{
+    double sums[2];
+    const int rc = two_squared_norms(c, a, a, n6, sums);
+    *out = sums[0];
+    return rc;
+}
+
 // Flexible preconditioned CG (beta = z.(r - r_old) / r_old.z_old, so that the K cycle's slightly varying operator
 // does not break the recurrence); stopping rule and scalars as in cg_classic.
 //
@@ -1096,10 +1129,11 @@ int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate
 // 2e-10 -> 2e-9) and the correction equation K e = b - K x is solved by the same method from e = 0 in a vector of
 // its own -- there the noise scales with ||e||, not ||x|| -- and added once: x += e.  (Continuing the recurrence on
 // x itself does not help: every update x += alpha p rounds at eps ||x||.)  Measured on the roof: 2e-10 -> 2e-13
-// with one pass.  femshell_pc_options::refine_passes passes at most (default 1; 0 = off).  A pass always runs to a drop
-// of 1e-4 of its own right-hand side, whatever the residual tolerance of the solve: ||e|| / ||x|| of the pass is the
-// displacement error of the iterate before it (manufactured solutions at 4M triangles: 4.8e-8 estimated, 4.8e-8 true)
-// and the pass leaves about that times its drop; passes after the first run while that product exceeds rtol.
+// with one pass.  femshell_pc_options::refine_passes passes at most (default 1; 0 = off).  A pass stops on the drop of its
+// own right-hand side, whatever the residual tolerance of the solve: ||e|| / ||x|| of the pass is the displacement error of
+// the iterate before it (manufactured solutions at 4M triangles: 4.8e-8 estimated, 4.8e-8 true) and the pass leaves about
+// that times its drop -- it runs until that product, with the ||e_k|| so far, is a fifth of rtol (kernels.hip: kRefineTarget;
+// 1e-4 flat with FEMSHELL_REFINE_ADAPTIVE=0); passes after the first run while the product exceeds rtol.
 // *true_rr_out = ||b - K x||^2 (double-double) of the returned iterate.
 int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, double *true_rr_out, double *rec_rr_out)
 {
@@ -1118,6 +1152,8 @@ int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, do
     const bool loosened = refine >= 1 && rtol > 0.0;
     const double rtol_first = loosened ? std::min(100.0 * rtol, 1e-2) : rtol;
     const int pass_limit = refine + (loosened ? 1 : 0);
+    // FEMSHELL_REFINE_ADAPTIVE=0: every pass to a drop of 1e-4 of its own right-hand side, as before round 5 (A/B runs)
+    const bool adaptive_pass = !(getenv("FEMSHELL_REFINE_ADAPTIVE") && atoi(getenv("FEMSHELL_REFINE_ADAPTIVE")) == 0);
     CgVectors v = v0;
     CgScalars hs{};
     int32_t it = 0;
@@ -1136,6 +1172,14 @@ int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, do
             if (rc) return rc;
             launch_residual_dd(m, c->xacc.p, v0.b, c->rres.p, st);
             v.b = c->rres.p;
+            if (adaptive_pass) {
+                // ||x||^2 of the iterate this pass corrects, for the pass's own stopping rule (kernels.hip: kRefineTarget)
+                double xx = 0.0;
+                rc = squared_norm(c, c->xacc.p, n6, &xx);
+                if (rc) return rc;
+                const double pass[3] = {xx, 0.0, rtol};
+                FS_HIP(hipMemcpyAsync(reinterpret_cast<char *>(v.s) + offsetof(CgScalars, pass_xx), pass, sizeof pass, hipMemcpyHostToDevice, st));
+            }
             launch_pcg_init(m, v, st); // x = 0, r = rhs, partial sums of r.r
             // (rtol = 0: the pass stops on the relative drop kRefineDrop of its own right-hand side alone -- the residual
             //  tolerance of the solve says little about the displacement error on these systems: at 4M triangles a
@@ -1183,7 +1227,7 @@ int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, do
             if (rc) return rc;
             if (fused_update) launch_pcg_update_start(S0, v, L0.d.p, amg_apply_iterate(c, v.z), L0.inv_theta, defer, d32_0, st);
             else launch_pcg_update(m, v, st);
-            rc = scalar_step(c, v, 1, CG_PHASE_FLEX_CONV, rtol);
+            rc = scalar_step(c, v, 2, CG_PHASE_FLEX_CONV, rtol); // (r.r and, for the stopping rule of a refinement pass, x.x)
             if (rc) return rc;
             rc = amg_apply(c, v.r, v.z, v.s, fused_update);
             if (rc) return rc;
@@ -1208,25 +1252,9 @@ int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, do
         if (pass > 0) {
             // error estimate of the solve: ||e|| / ||x|| of this pass (the error of the iterate before it) and the factor
             // by which the pass reduced the residual of its correction equation
-            // (two partial arrays of 128 groups, room for a third, and behind them the two-word staging slot of the all-reduce)
-            constexpr size_t kDotsStage = 3 * 128;
-            FS_HIP(c->dots_scratch.alloc(kDotsStage + 2));
-            const int groups = launch_two_dots(v.x, v.x, c->xacc.p, c->xacc.p, n6, c->dots_scratch.p, st);
-            double hp[2 * 128];
-            FS_HIP(hipMemcpyAsync(hp, c->dots_scratch.p, sizeof hp, hipMemcpyDeviceToHost, st));
-            FS_HIP(hipStreamSynchronize(st));
-            double sums[2] = {0.0, 0.0};
-            for (int g = 0; g < groups; g++) {
-                sums[0] += hp[g];
-                sums[1] += hp[128 + g];
-            }
-            if (c->comm.active()) { // every rank holds its own rows
-                FS_HIP(hipMemcpyAsync(c->dots_scratch.p + kDotsStage, sums, sizeof sums, hipMemcpyHostToDevice, st));
-                std::string e;
-                if (!comm_allreduce_sum(c->comm, c->dots_scratch.p + kDotsStage, 2, st, &e)) return set_err(FEMSHELL_ERR_COMM, e);
-                FS_HIP(hipMemcpyAsync(sums, c->dots_scratch.p + kDotsStage, sizeof sums, hipMemcpyDeviceToHost, st));
-                FS_HIP(hipStreamSynchronize(st));
-            }
+            double sums[2];
+            rc = two_squared_norms(c, v.x, c->xacc.p, n6, sums);
+            if (rc) return rc;
             c->refine.passes = pass;
             c->refine.correction_rel = sums[1] > 0.0 ? std::sqrt(sums[0] / sums[1]) : 0.0;
             c->refine.residual_reduction = pass_rhs_rr > 0.0 ? std::sqrt(hs.rr / pass_rhs_rr) : 0.0;

@@ -1498,7 +1498,14 @@ void launch_cg_direction(const DeviceMatrix &m, const CgVectors &v, hipStream_t 
 // does not change the result: the final sum runs over the stage-1 sums in a fixed tree.
 constexpr int kReduceGroups = 64;
 
-constexpr double kRefineDrop = 1.0e-4; // residual reduction asked of a refinement pass (relative to its right-hand side)
+constexpr double kRefineDrop = 1.0e-4; // residual reduction asked of a refinement pass (relative to its right-hand side) ...
+// ... unless the pass knows better.  Its correction e is the displacement error of the iterate x it started from, and what the
+// pass leaves of that error is about ||e|| / ||x|| times the drop of its residual (cg_amg).  With ||x||^2 at hand (pass_xx) the
+// pass therefore stops when that estimate, with the ||e_k|| of the correction so far, is kRefineTarget of the tolerance: on the
+// 4M panel (||e|| / ||x|| = 4.6e-8 behind a first phase to 1e-8) at a drop of 4.3e-4 instead of 1e-4 -- six iterations of 104 --
+// and where the first phase left a larger error, deeper than 1e-4 instead of a second pass.  Never less than two digits, never
+// more than six.
+constexpr double kRefineTarget = 0.2, kRefineDropMin = 1.0e-6, kRefineDropMax = 1.0e-2;
 
 __device__ __forceinline__ void cg_scalar_phase(const CgVectors &v, int phase, double rtol)
 {
@@ -1556,6 +1563,8 @@ __device__ __forceinline__ void cg_scalar_phase(const CgVectors &v, int phase, d
             }
         }
     } else if (phase == CG_PHASE_FLEX_INIT) {
+        s->pass_xx = 0.0;
+        s->pass_rhs_rr = 0.0;
         s->bb = s->red[0];
         s->rr = s->red[0];
         s->tol2 = rtol > 0.0 ? rtol * rtol * s->red[0] : 0.0;
@@ -1579,6 +1588,7 @@ __device__ __forceinline__ void cg_scalar_phase(const CgVectors &v, int phase, d
         // whose error it reduces by that factor (2e-10 -> 1e-13 and below on the shell systems), and every further
         // digit costs iterations of the whole method
         s->tol2 = fmax(tol2_solve, kRefineDrop * kRefineDrop * s->red[0]);
+        s->pass_rhs_rr = s->red[0];
     } else if (phase == CG_PHASE_FLEX_RZ0) {
         s->rz = s->red[0];
         if (!(s->red[0] > 0.0)) s->done = -1; // the preconditioner is not positive definite
@@ -1588,6 +1598,12 @@ __device__ __forceinline__ void cg_scalar_phase(const CgVectors &v, int phase, d
         const int it = s->iters + 1;
         s->iters = it;
         if (v.hist != nullptr && it <= v.hist_cap) v.hist[it - 1] = rr / s->bb;
+        if (s->pass_xx > 0.0 && s->pass_rhs_rr > 0.0 && s->red[1] > 0.0) {
+            // a refinement pass with the adaptive rule: red[1] = e.e of the correction so far
+            const double drop = kRefineTarget * s->pass_rtol * sqrt(s->pass_xx / s->red[1]);
+            const double d = fmin(fmax(drop, kRefineDropMin), kRefineDropMax);
+            s->tol2 = d * d * s->pass_rhs_rr;
+        }
         if (rr <= s->tol2) s->done = 1;
     } else if (phase == CG_PHASE_FLEX_BETA) {
         const double rzn = s->red[0], zq = s->red[1];

@@ -124,6 +124,9 @@ struct CgScalars {
     // derives alpha / beta from red[] and the previous (r.z, alpha); those are read from ring[parity] while workgroup 0
     // writes ring[parity ^ 1] and the fields above
     double ring_rz[2], ring_alpha[2];
+    // a refinement pass of the multigrid-preconditioned solve (cg_amg): ||x||^2 of the iterate the pass corrects (uploaded by the
+    // host in front of CG_PHASE_FLEX_RESTART; 0: no adaptive stopping), ||rhs||^2 of the pass, the tolerance of the solve
+    double pass_xx, pass_rhs_rr, pass_rtol;
 };
 
 struct CgVectors {

@@ -168,9 +168,11 @@ typedef struct femshell_pc_options {
     int32_t max_levels;      /* default 12 */
     int32_t refine_passes;   /* iterative refinement after convergence, at most this many passes (default 1; 0 = off):
                                 the residual of the iterate is evaluated in double-double and the correction equation
-                                solved by the same method to a drop of 1e-4, whatever rtol is -- rtol bounds the
-                                residual, and on these systems the displacement error sits one to two decades above
-                                it (4M triangles, manufactured solution: 4e-9 at a residual of 9e-11 ||b||).  The
+                                solved by the same method -- rtol bounds the residual, and on these systems the
+                                displacement error sits one to two decades above it (4M triangles, manufactured
+                                solution: 4e-9 at a residual of 9e-11 ||b||) -- until femshell_solve_info::error_estimate
+                                of the pass so far, ||e|| / ||x|| x the drop of its residual, is a fifth of rtol (a drop
+                                between 1e-2 and 1e-6; 1e-4 flat before round 5 and with FEMSHELL_REFINE_ADAPTIVE=0).  The
                                 first pass always runs, further ones (one more than this number at most) while
                                 femshell_solve_info::error_estimate exceeds rtol.  Plain FP64 CG stalls at a displacement
                                 error of kappa*eps -- 2e-10 on the 250k-triangle roof -- one pass brings it to 1e-13.

@@ -346,8 +346,10 @@ def kcycle_solve(levels, li, rc):
     return w1 * c1 + w2 * c2
 
 
-def flexible_pcg(A, b, M, rtol=1e-10, max_it=1000):
-    """beta = z.(r - r_old) / r_old.z_old = -alpha z.q / rz_old; stops at ||r|| <= rtol ||b||."""
+def flexible_pcg(A, b, M, rtol=1e-10, max_it=1000, pass_of=None):
+    """beta = z.(r - r_old) / r_old.z_old = -alpha z.q / rz_old; stops at ||r|| <= rtol ||b||.
+    pass_of = (||x||^2 of the iterate this solve corrects, tolerance of the whole solve): the stopping rule of a refinement pass
+    (csrc/kernels.hip kRefineTarget) -- the drop asked of the residual is 0.2 tol ||x|| / ||e_k||, within [1e-6, 1e-2]."""
     x = np.zeros_like(b)
     r = b.copy()
     bb = b @ b
@@ -364,6 +366,8 @@ def flexible_pcg(A, b, M, rtol=1e-10, max_it=1000):
         r -= alpha * q
         rr = r @ r
         hist.append(np.sqrt(rr / bb))
+        if pass_of is not None and x @ x > 0.0:
+            rtol = min(max(0.2 * pass_of[1] * np.sqrt(pass_of[0] / (x @ x)), 1.0e-6), 1.0e-2)
         if rr <= rtol * rtol * bb:
             break
         z = M(r)
@@ -382,9 +386,10 @@ def residual_extended(A, b, x):
     return (b.astype(ld) - np.add.reduceat(A.data.astype(ld) * x.astype(ld)[A.indices], A.indptr[:-1])).astype(np.float64)
 
 
-def solve(A, b, levels, kcycle=True, rtol=1e-10, max_it=1000, refine_passes=0):
+def solve(A, b, levels, kcycle=True, rtol=1e-10, max_it=1000, refine_passes=0, adaptive=True):
     """Flexible PCG around the cycle, then iterative refinement: residual of the iterate in extended precision, correction
-    equation solved by the same method until its residual has dropped by 1e-4, x += e.  With a pass to follow the first
+    equation solved by the same method until its residual has dropped by 1e-4 -- adaptive: by 0.2 rtol ||x|| / ||e_k||, the drop
+    that puts the estimate below at a fifth of the tolerance -- and x += e.  With a pass to follow the first
     phase stops a factor 100 above the tolerance.  ||e|| / ||x|| times the drop estimates the error the pass leaves; passes
     after the first -- at most `refine_passes`, and one more -- run while the estimate exceeds rtol
     (csrc/amg_solve.cpp cg_amg)."""
@@ -398,8 +403,9 @@ def solve(A, b, levels, kcycle=True, rtol=1e-10, max_it=1000, refine_passes=0):
         nr = np.linalg.norm(r)
         if nr == 0.0 or len(hist) >= max_it or (k >= 1 and est <= rtol):
             break
-        # the correction needs four digits, not the full tolerance again (csrc/kernels.hip: kRefineDrop)
-        e, h = flexible_pcg(A, r, M, 1.0e-4, max_it - len(hist))
+        # the correction needs about four digits, not the full tolerance again: as many as put the estimate of what it leaves,
+        # ||e|| / ||x|| x its drop, at a fifth of the tolerance (csrc/kernels.hip: kRefineDrop, kRefineTarget)
+        e, h = flexible_pcg(A, r, M, 1.0e-4, max_it - len(hist), pass_of=(x @ x, rtol) if adaptive else None)
         hist = hist + [v * nr / nb for v in h]
         est = np.linalg.norm(e) / np.linalg.norm(x) * (h[-1] if h else 1.0)
         x = x + e
