@@ -59,6 +59,7 @@ struct AmgLevel {
     bool dist = false;
     int32_t n_ghost = 0, n_global = 0;
     std::vector<int32_t> part;
+    std::vector<int32_t> part_begin, part_end; // the same as two lists of the ranks' first / one-past-last rows (comm_gather_rows)
     std::shared_ptr<LevelHalo> halo;
     // ... and, for levels >= 1, the slices of the level operator ordered for the overlap of its products with their halo
     // exchange: the n_interior slices that read owned columns only first (level 0: the plan's spmv_order)

@@ -970,9 +970,12 @@ struct Cycle {
             } else {
                 // the rank's rows of the restricted residual, all-gathered into the replicated level
                 launch_spmv(L.R.dm, rf, L.bown.p, nullptr, gate, st);
-                std::vector<int32_t> begin(N.part.begin(), N.part.end() - 1), end(N.part.begin() + 1, N.part.end());
+                if (N.part_begin.size() + 1 != N.part.size()) { // (once per hierarchy, not per restriction)
+                    N.part_begin.assign(N.part.begin(), N.part.end() - 1);
+                    N.part_end.assign(N.part.begin() + 1, N.part.end());
+                }
                 std::string e;
-                if (!rc && !comm_gather_rows(c->comm, L.bown.p, N.b.p, begin, end, st, &e)) rc = set_err(FEMSHELL_ERR_COMM, e);
+                if (!rc && !comm_gather_rows(c->comm, L.bown.p, N.b.p, N.part_begin, N.part_end, st, &e)) rc = set_err(FEMSHELL_ERR_COMM, e);
             }
         } else {
             launch_spmv(L.R.dm, rf, N.b.p, nullptr, gate, st);
