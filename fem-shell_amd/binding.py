@@ -25,7 +25,7 @@ SYMBOLS = [
     "femshell_row_end", "femshell_comm_unique_id", "femshell_comm_init", "femshell_time_kernel",
     "femshell_sync", "femshell_pc_defaults", "femshell_set_preconditioner", "femshell_amg_levels", "femshell_amg_level",
     "femshell_amg_export", "femshell_residual", "femshell_comm_ranks", "femshell_amg_setup_stats", "femshell_amg_dense_stats", "femshell_amg_partition_info", "femshell_assembly_kernel",
-    "femshell_amg_cycle_bytes", "femshell_comm_selftest", "femshell_comm_counters", "femshell_owned_nodes", "femshell_comm_bytes",
+    "femshell_amg_cycle_bytes", "femshell_comm_selftest", "femshell_comm_counters", "femshell_owned_nodes", "femshell_comm_bytes", "femshell_set_initial_guess",
 ]
 
 
@@ -121,6 +121,7 @@ def load_library():
     L.femshell_row_begin.restype = C.c_int32
     L.femshell_row_end.argtypes = [vp]
     L.femshell_row_end.restype = C.c_int32
+    L.femshell_set_initial_guess.argtypes = [vp, dp]
     L.femshell_owned_nodes.argtypes = [vp, C.POINTER(C.c_int32)]
     L.femshell_owned_nodes.restype = C.c_int32
     L.femshell_comm_unique_id.argtypes = [bp]
@@ -280,6 +281,14 @@ class FemShell:
 
     def row_range(self):
         return int(self._L.femshell_row_begin(self._h)), int(self._L.femshell_row_end(self._h))
+
+    def set_initial_guess(self, u0=None):
+        """The next solve starts from u0 (n_nodes x 6) -- None: from the previous solve's solution, where it lies in HBM."""
+        if u0 is not None:
+            u0 = np.ascontiguousarray(u0, dtype=np.float64).reshape(-1)
+            if len(u0) != 6 * self.n_nodes:
+                raise ValueError("u0 needs n_nodes x 6 entries")
+        _check(self._L.femshell_set_initial_guess(self._h, _d(u0)))
 
     def owned_nodes(self):
         """the caller's ids of the node rows this rank owns, in the order export_bsr gives them"""

@@ -166,7 +166,8 @@ int amg_apply(femshell_ctx *c, const double *r, double *z, const CgScalars *gate
 double *amg_apply_iterate(femshell_ctx *c, double *z);
 // *true_rr_out: ||b - K x||^2 of the returned iterate when the residual replacement computed it, else -1
 // *rec_rr_out: recurrence ||r||^2 the stopping rule saw last
-int cg_amg(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it, double *true_rr_out, double *rec_rr_out);
+// (x0: the iterate to start from -- owned rows, n_pad * 6 doubles in HBM -- or nullptr for zero)
+int cg_amg(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it, double *true_rr_out, double *rec_rr_out, const double *x0 = nullptr);
 // algorithmic HBM bytes of one cycle as it is built (single-precision copies, increments, the real product counts), and per level
 double amg_cycle_bytes(const femshell_ctx *c, std::vector<double> *per_level = nullptr);
 // K of a single-rank context as host BSR with ascending columns (api.cpp)

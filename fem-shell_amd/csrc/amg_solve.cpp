@@ -1138,7 +1138,7 @@ static int squared_norm(femshell_ctx *c, const double *a, int64_t n6, double *ou
 // that times its drop -- it runs until that product, with the ||e_k|| so far, is a fifth of rtol (kernels.hip: kRefineTarget;
 // 1e-4 flat with FEMSHELL_REFINE_ADAPTIVE=0); passes after the first run while the product exceeds rtol.
 // *true_rr_out = ||b - K x||^2 (double-double) of the returned iterate.
-int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, double *true_rr_out, double *rec_rr_out)
+int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, double *true_rr_out, double *rec_rr_out, const double *x0)
 {
     const DeviceMatrix &m = c->dm;
     hipStream_t st = c->stream;
@@ -1168,6 +1168,23 @@ int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, do
             launch_pcg_init(m, v, st);
             rc = scalar_step(c, v, 1, CG_PHASE_FLEX_INIT, rtol_first);
             if (rc) return rc;
+            if (x0 != nullptr) {
+                // A solve from an initial guess (femshell_set_initial_guess): x0 becomes the accumulated iterate and the first phase
+                // solves the correction equation K e = b - K x0 -- its right-hand side evaluated in double-double, as a refinement
+                // pass's -- down to the threshold the step above derived from b.  What follows is the solve from zero: x0 + e takes
+                // the place of the first phase's iterate, the refinement passes correct it.
+                FS_HIP(c->xacc.alloc((size_t)n6 + 6 * (size_t)m.n_ghost));
+                FS_HIP(c->xacc.zero(st));
+                FS_HIP(c->rres.alloc((size_t)n6));
+                launch_copy(x0, c->xacc.p, n6, nullptr, st);
+                rc = halo_exchange(c, c->xacc.p, st);
+                if (rc) return rc;
+                launch_residual_dd(m, c->xacc.p, v0.b, c->rres.p, st);
+                v.b = c->rres.p;
+                launch_pcg_init(m, v, st); // x = 0, r = b - K x0, partial sums of r.r
+                rc = scalar_step(c, v, 1, CG_PHASE_FLEX_WARM, rtol_first);
+                if (rc) return rc;
+            }
         } else {
             // correction equation: right-hand side = residual of the accumulated solution, evaluated in double-double
             TraceRange trace("femshell refinement pass: double-double residual");
@@ -1250,6 +1267,12 @@ int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, do
             FS_HIP(hipStreamSynchronize(st));
         }
         it = hs.iters;
+        if (pass == 0 && x0 != nullptr) {
+            // the iterate of the first phase is x0 + e, whatever ended the phase
+            launch_add(v.x, c->xacc.p, n6, st);
+            launch_copy(c->xacc.p, v.x, n6, nullptr, st);
+            v.b = v0.b;
+        }
         if (pass == 0) *rec_rr_out = hs.rr; // what the stopping rule of the first phase saw (a refinement pass stops on
                                             // the drop of its own right-hand side, see CG_PHASE_FLEX_RESTART)
         if (pass > 0) {

@@ -607,6 +607,7 @@ static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double 
     }
     std::string e;
     c->have_mesh = false;
+    c->warm_next = false;
     c->amg_fp64_only = false;
     c->perm.clear();
     c->iperm.clear();
@@ -1059,6 +1060,8 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
     CgVectors v = cg_vectors(c);
     const DeviceMatrix &m = c->dm;
     const bool single_reduction = !use_amg && use_single_reduction(c);
+    const double *x0 = c->warm_next ? c->x0.p : nullptr; // femshell_set_initial_guess: this solve's, and only this one's
+    c->warm_next = false;
     double amg_true_rr = -1.0, amg_rec_rr = -1.0;
     CgScalars hs{};
     bool fp64_fallback = false;
@@ -1088,8 +1091,9 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
         FS_HIP(hipEventRecord(c->ev0, st)); // (behind the multigrid setup: solve_seconds is the time of the Krylov loop)
         FS_HIP(c->scal.zero(st));
         amg_true_rr = amg_rec_rr = -1.0;
-        rc = use_amg ? cg_amg(c, v, rtol, max_it, &amg_true_rr, &amg_rec_rr)
-                     : single_reduction ? cg_single_reduction(c, v, rtol, max_it) : cg_classic(c, v, rtol, max_it);
+        // (from an initial guess the block-Jacobi method runs its classic recurrence: the single-reduction form has no such start)
+        rc = use_amg ? cg_amg(c, v, rtol, max_it, &amg_true_rr, &amg_rec_rr, x0)
+                     : (single_reduction && !x0) ? cg_single_reduction(c, v, rtol, max_it) : cg_classic(c, v, rtol, max_it, x0);
         if (rc) return rc;
         FS_HIP(hipMemcpyAsync(&hs, v.s, sizeof hs, hipMemcpyDeviceToHost, st));
         FS_HIP(hipStreamSynchronize(st));
@@ -1174,6 +1178,37 @@ int femshell_solve(femshell_ctx *c, double rtol, int32_t max_it, double *u_out, 
     if (hs.done < 0)
         return set_err(FEMSHELL_ERR_BREAKDOWN, "femshell_solve: CG breakdown, p.Ap <= 0 (matrix not positive definite)");
     if (u_out) return femshell_get_solution(c, u_out);
+    return FEMSHELL_OK;
+}
+
+int femshell_set_initial_guess(femshell_ctx *c, const double *u0)
+{
+    if (!c) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_initial_guess: null context");
+    if (!c->have_mesh) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_initial_guess: no mesh set");
+    int rc = select_device(c);
+    if (rc) return rc;
+    const Plan &p = c->plan;
+    const size_t n6 = (size_t)p.n_pad * 6;
+    if (u0 == nullptr) {
+        if (!c->have_solution) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_initial_guess: no previous solve to start from");
+        FS_HIP(c->x0.alloc(n6));
+        FS_HIP(hipMemcpyAsync(c->x0.p, c->x.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        // the rank's own rows, internal numbering
+        std::vector<double> h(n6, 0.0);
+        for (int32_t i = 0; i < p.n_own; i++) {
+            const int32_t row = p.row_begin + i, node = c->perm.empty() ? row : c->perm[(size_t)row];
+            for (int v = 0; v < 6; v++) {
+                const double val = u0[6ull * (size_t)node + v];
+                if (!std::isfinite(val)) return set_err(FEMSHELL_ERR_INVALID, "femshell_set_initial_guess: non-finite entry");
+                h[6ull * (size_t)i + v] = val;
+            }
+        }
+        FS_HIP(c->x0.alloc(n6));
+        FS_HIP(hipMemcpyAsync(c->x0.p, h.data(), n6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        FS_HIP(hipStreamSynchronize(c->stream)); // (h goes out of scope)
+    }
+    c->warm_next = true;
     return FEMSHELL_OK;
 }
 

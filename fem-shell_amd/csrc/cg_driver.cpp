@@ -99,13 +99,25 @@ struct DonePoll {
 
 // classic preconditioned CG: two reductions per iteration (p.q before the update, r.z and r.r after it); the
 // iterates are those of the oracle's fso_pcg_block_jacobi
-int cg_classic(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it)
+int cg_classic(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it, const double *x0)
 {
     const DeviceMatrix &m = c->dm;
     hipStream_t st = c->stream;
     launch_cg_init(m, v, false, st);
     int rc = scalar_step(c, v, 2, CG_PHASE_INIT, rtol);
     if (rc) return rc;
+    if (x0 != nullptr) {
+        // a solve from an initial guess (femshell_set_initial_guess): b.b and the threshold stand as derived from b above; the
+        // method starts from x0 with the explicit residual r = b - K x0 (q = K x through the product's own input vector p)
+        FS_HIP(hipMemcpyAsync(v.x, x0, (size_t)m.n_pad * 6 * sizeof(double), hipMemcpyDeviceToDevice, st));
+        launch_copy_x_to_p(m, v, st);
+        rc = halo_exchange(c, v.p, st);
+        if (rc) return rc;
+        launch_spmv(m, v.p, v.q, nullptr, nullptr, st);
+        launch_cg_init(m, v, true, st);
+        rc = scalar_step(c, v, 2, CG_PHASE_RESTART, rtol);
+        if (rc) return rc;
+    }
     CgScalars hs{};
     DonePoll poll;
     for (int32_t it = 0; it < max_it; it++) {

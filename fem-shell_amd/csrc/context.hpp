@@ -194,6 +194,9 @@ struct femshell_ctx {
     femshell::DevBuf<double> agree;
     // halo exchange beside the interior SpMV (multi-rank contexts): second stream + hand-off events
     hipStream_t halo_stream = nullptr;
+    // femshell_set_initial_guess: the iterate the NEXT femshell_solve starts from (owned rows, internal numbering), consumed by it
+    femshell::DevBuf<double> x0;
+    bool warm_next = false;
     hipStream_t aux_stream = nullptr; // the look-ahead of the dense inverse (amg_dense.hip)
     int aux_streams_side_by_side = 0; // 0: not asked yet, 1: stream and aux_stream run concurrently, -1: they share a hardware queue
     // first-contact self-test of femshell_comm_init (comm.cpp comm_selftest): microseconds of its three patterns
@@ -272,7 +275,7 @@ int halo_exchange(femshell_ctx *c, double *vec, hipStream_t st);
 int spmv_with_halo(femshell_ctx *c, const CgVectors &v, double *xin, double *yout, double *partials, int *n_partials,
                    bool defer_gather = false, const float *vals32 = nullptr, int vec32 = 0);
 // the two recurrences (cg_driver.cpp); the CG state is left in the context's vectors and scalars
-int cg_classic(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it);
+int cg_classic(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it, const double *x0 = nullptr);
 int cg_single_reduction(femshell_ctx *c, const CgVectors &v, double rtol, int32_t max_it);
 bool use_single_reduction(const femshell_ctx *c);
 // reduction of the partial sums [+ all-reduce on contexts with a communicator] + scalar step

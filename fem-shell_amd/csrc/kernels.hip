@@ -1589,6 +1589,9 @@ __device__ __forceinline__ void cg_scalar_phase(const CgVectors &v, int phase, d
         // digit costs iterations of the whole method
         s->tol2 = fmax(tol2_solve, kRefineDrop * kRefineDrop * s->red[0]);
         s->pass_rhs_rr = s->red[0];
+    } else if (phase == CG_PHASE_FLEX_WARM) {
+        s->rr = s->red[0];
+        s->done = (s->red[0] <= s->tol2) ? 1 : 0;
     } else if (phase == CG_PHASE_FLEX_RZ0) {
         s->rz = s->red[0];
         if (!(s->red[0] > 0.0)) s->done = -1; // the preconditioner is not positive definite
@@ -1634,7 +1637,7 @@ __global__ __launch_bounds__(256) void k_cg_scalar(CgVectors v, int G, int do_re
     // gate_phase: the phase this launch belongs to (a reduce-only launch in front of an all-reduce carries
     // phase NONE but must not be skipped when it serves an INIT / RESTART step on a finished solve)
     if (gate_phase != CG_PHASE_INIT && gate_phase != CG_PHASE_RESTART && gate_phase != CG_PHASE_FUSED_INIT &&
-        gate_phase != CG_PHASE_FLEX_INIT && gate_phase != CG_PHASE_FLEX_RESTART && s->done != 0)
+        gate_phase != CG_PHASE_FLEX_INIT && gate_phase != CG_PHASE_FLEX_RESTART && gate_phase != CG_PHASE_FLEX_WARM && s->done != 0)
         return; // same decision in every workgroup
     if (!do_reduce) {
         if (blockIdx.x == 0 && threadIdx.x == 0) cg_scalar_phase(v, phase, rtol);

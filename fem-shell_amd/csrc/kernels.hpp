@@ -151,8 +151,10 @@ enum CgPhase : int {
     CG_PHASE_FLEX_RZ0 = 8,  // red[0] = r.z of the initial residual
     CG_PHASE_FLEX_CONV = 9, // red[0] = r.r after the update: iteration count, history, stopping test
     CG_PHASE_FLEX_BETA = 10, // red[0] = r.z, red[1] = z.q: beta = z.(r - r_old) / rz_old = -alpha z.q / rz_old
-    CG_PHASE_FLEX_RESTART = 11 // red[0] = r.r of the right-hand side of a refinement pass (the double-double residual
-                               // of the accumulated solution); tolerance, iteration count and history carry on
+    CG_PHASE_FLEX_RESTART = 11, // red[0] = r.r of the right-hand side of a refinement pass (the double-double residual
+                                // of the accumulated solution); tolerance, iteration count and history carry on
+    CG_PHASE_FLEX_WARM = 12     // a solve from an initial guess: red[0] = r.r of b - K x0 (double-double), the first phase solves the
+                                // correction equation down to the threshold CG_PHASE_FLEX_INIT derived from b
 };
 
 int slice_grid(const DeviceMatrix &m); // workgroups of the per-slice kernels (multiple of 8, at most 2560)

@@ -181,6 +181,21 @@ class FemShellLinearSolver : public LinearSolver<Number> {
         const MeshBase &mesh = b.es->get_mesh();
         const unsigned sys = b.es->get_system<LinearImplicitSystem>("Elasticity").number();
         std::vector<double> u(6 * (size_t)mesh.n_nodes());
+        // `solution` arrives holding the initial guess, as it does for PETSc (PetscLinearSolver: KSPSetInitialGuessNonzero): zero on
+        // the first solve of a system, the last solution afterwards -- every rank gets the whole vector, as femshell_set_initial_guess
+        // takes it; an all-zero guess is the solve from zero
+        {
+            std::vector<Number> all;
+            solution.localize(all);
+            bool any = false;
+            for (const Node *nd : mesh.node_ptr_range())
+                for (unsigned var = 0; var < 6; var++) {
+                    const double v = all[nd->dof_number(sys, var, 0)];
+                    u[6 * (size_t)nd->id() + var] = v;
+                    any = any || v != 0.0;
+                }
+            if (any) check(femshell_set_initial_guess(b.ctx, u.data()));
+        }
         b.last_rc = femshell_solve(b.ctx, tol, (int32_t)m_its, u.data(), &info); // full vector on every rank, 6*node+var
         b.last_info = info;
         // a breakdown (K or the preconditioner not positive definite) is a solver outcome libMesh asks about through

@@ -258,6 +258,7 @@ void ShellSystem::comm_init(const unsigned char id[128]) { check(femshell_comm_i
 void ShellSystem::set_mesh(const ShellMesh &m)
 {
     n_nodes_ = m.n_nodes();
+    solved_once_ = false;
     check(femshell_set_mesh(ctx_, m.n_nodes(), m.xyz.data(), m.n_tri(), m.tri.data(), m.n_quad(), m.quad.data()),
           "femshell_set_mesh");
     const std::vector<uint8_t> mask = m.dirichlet_mask();
@@ -282,7 +283,13 @@ SolveResult ShellSystem::solve(double tol, int max_it)
 {
     SolveResult r;
     sols_.assign((size_t)n_nodes_ * 6, 0.0);
+    // libMesh hands system.solution to KSPSolve as the initial guess (PetscLinearSolver: KSPSetInitialGuessNonzero): the first
+    // solve of a system starts from zero, every later one -- the coupling iterations of fem-shell_precice.cpp:271 -- from the
+    // displacements of the solve before.  FEMSHELL_WARM_START=0: every solve from zero (A/B runs)
+    static const bool warm = !(std::getenv("FEMSHELL_WARM_START") && std::atoi(std::getenv("FEMSHELL_WARM_START")) == 0);
+    if (warm && solved_once_) check(femshell_set_initial_guess(ctx_, nullptr), "femshell_set_initial_guess");
     check(femshell_solve(ctx_, tol, max_it, sols_.data(), &r.info), "femshell_solve");
+    solved_once_ = true;
     r.iterations = (unsigned)r.info.iterations;
     r.final_residual = r.info.rel_residual;
     r.converged = r.info.converged == 1;

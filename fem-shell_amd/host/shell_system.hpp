@@ -116,6 +116,7 @@ class ShellSystem {
     void choose_preconditioner(const Parameters &p);
     femshell_ctx *ctx_ = nullptr;
     int n_nodes_ = 0, rank_ = 0;
+    bool solved_once_ = false; // later solves start from the solution before (libMesh's initial guess: ShellSystem::solve)
     std::vector<double> sols_;
 };
 

@@ -249,6 +249,16 @@ int femshell_assembly_kernel(femshell_ctx *ctx);
 int femshell_solve(femshell_ctx *ctx, double rtol, int32_t max_it, double *u_out,
                    femshell_solve_info *info);
 int femshell_get_solution(femshell_ctx *ctx, double *u_out);
+/* The NEXT femshell_solve of this context starts from u0 (n_nodes x 6, the caller's numbering; every rank passes the whole vector
+ * and keeps its own rows) instead of from zero; u0 == NULL: from the solution of the context's previous solve, where it lies in
+ * HBM (no transfer).  Consumed by that solve; femshell_set_mesh forgets it.
+ * replaces: libMesh hands system.solution to KSPSolve as the initial guess (PetscLinearSolver: KSPSetInitialGuessNonzero), so
+ * every equation_systems.solve() of the coupled adapter's loop (fem-shell_precice.cpp:271) starts from the displacements of the
+ * last coupling iteration; the stand-alone program's one solve (fem-shell.cpp:138) starts from zero either way.
+ * The stopping rule is unchanged (||r|| <= rtol ||b||, the refinement passes of the multigrid-preconditioned solve and their
+ * error estimate): the first phase solves the correction equation K e = b - K u0, its right-hand side evaluated in
+ * double-double, down to the threshold a solve from zero runs to.  Block-Jacobi: classic recurrence from r = b - K u0. */
+int femshell_set_initial_guess(femshell_ctx *ctx, const double *u0);
 /* ||r||/||b|| after each iteration of the last solve; returns the count written (<= cap) */
 int32_t femshell_residual_history(femshell_ctx *ctx, double *hist, int32_t cap);
 

@@ -386,17 +386,29 @@ def residual_extended(A, b, x):
     return (b.astype(ld) - np.add.reduceat(A.data.astype(ld) * x.astype(ld)[A.indices], A.indptr[:-1])).astype(np.float64)
 
 
-def solve(A, b, levels, kcycle=True, rtol=1e-10, max_it=1000, refine_passes=0, adaptive=True):
+def solve(A, b, levels, kcycle=True, rtol=1e-10, max_it=1000, refine_passes=0, adaptive=True, x0=None):
     """Flexible PCG around the cycle, then iterative refinement: residual of the iterate in extended precision, correction
     equation solved by the same method until its residual has dropped by 1e-4 -- adaptive: by 0.2 rtol ||x|| / ||e_k||, the drop
     that puts the estimate below at a fifth of the tolerance -- and x += e.  With a pass to follow the first
     phase stops a factor 100 above the tolerance.  ||e|| / ||x|| times the drop estimates the error the pass leaves; passes
     after the first -- at most `refine_passes`, and one more -- run while the estimate exceeds rtol
+    x0: an initial guess (femshell_set_initial_guess) -- the first phase solves K e = b - K x0, the right-hand side in extended
+    precision, down to the threshold it runs to from zero, and x0 + e takes the place of its iterate
     (csrc/amg_solve.cpp cg_amg)."""
     M = lambda r: cycle(levels, 0, r, kcycle)  # noqa: E731
     loosened = refine_passes >= 1 and rtol > 0
-    x, hist = flexible_pcg(A, b, M, min(100.0 * rtol, 1e-2) if loosened else rtol, max_it)
+    rtol_first = min(100.0 * rtol, 1e-2) if loosened else rtol
     nb = np.linalg.norm(b)
+    if x0 is None:
+        x, hist = flexible_pcg(A, b, M, rtol_first, max_it)
+    else:
+        r = residual_extended(A, b, x0)
+        nr = np.linalg.norm(r)
+        if nr > rtol_first * nb:
+            e, h = flexible_pcg(A, r, M, rtol_first * nb / nr, max_it)
+            x, hist = x0 + e, [v * nr / nb for v in h]
+        else:
+            x, hist = x0.copy(), []
     est = None
     for k in range(refine_passes + (1 if loosened else 0)):
         r = residual_extended(A, b, x)

@@ -40,6 +40,7 @@ struct MeshBase {
 template <class T> struct NumericVector {
     numeric_index_type size() const, first_local_index() const, last_local_index() const;
     void set(numeric_index_type, T); void add(numeric_index_type, T); void close();
+    void localize(std::vector<T> &v_local) const; // (libMesh: the whole vector on every processor)
 };
 template <class T> struct SparseMatrix { void add_matrix(const DenseMatrix<T> &, const std::vector<dof_id_type> &rows, const std::vector<dof_id_type> &cols); };
 template <class T> struct ShellMatrix {};

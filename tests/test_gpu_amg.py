@@ -606,3 +606,50 @@ def test_aggregates_do_not_depend_on_the_internal_numbering(flag):
     assert out["reordered"][2] == out["plain"][2], (out["plain"][2], out["reordered"][2])
     assert abs(out["reordered"][1] - out["plain"][1]) <= 0.1 * out["plain"][1] + 2, (out["plain"][1], out["reordered"][1])
     assert np.linalg.norm(out["reordered"][0] - out["plain"][0]) <= 1e-7 * np.linalg.norm(out["plain"][0])
+
+
+@pytest.mark.parametrize("pc", ["amg", "jacobi"])
+def test_solve_from_an_initial_guess(pc):
+    """femshell_set_initial_guess: what libMesh does for the reference -- system.solution goes to KSPSolve as the initial guess, so
+    the solves of the coupled adapter's loop (fem-shell_precice.cpp:271) start from the last coupling iteration's displacements.
+    From the previous solution and unchanged loads a solve needs a fraction of the iterations and returns the same displacements;
+    from a scaled copy (the dummy fluid's load factor moving between time steps) it saves the decades the guess is worth; the
+    guess is consumed by one solve; the multigrid path follows the restatement (oracle/amg_oracle.py solve x0)."""
+    m, mat = _make("panel", 40)
+    fs = _context(m, mat)
+    if pc == "amg":
+        fs.set_preconditioner("amg", coarsest_nodes=60)
+    # (block-Jacobi CG in plain FP64: the explicit residual of a converged iterate sits at kappa x eps = 1e-9 ||b|| on this panel,
+    #  whatever the recurrence reached -- a guess is worth something down to there, hence the tolerance of that leg)
+    rtol = 1e-10 if pc == "amg" else 1e-8
+    u_cold, cold = fs.solve(rtol=rtol, max_it=20000)
+    assert cold["converged"] == 1
+    # (1) from the previous solution where it lies
+    fs.set_initial_guess(None)
+    u1, i1 = fs.solve(rtol=rtol, max_it=20000)
+    assert i1["converged"] == 1 and i1["iterations"] <= 0.45 * cold["iterations"], (i1["iterations"], cold["iterations"])
+    assert np.linalg.norm(u1 - u_cold) <= (1e-9 if pc == "amg" else 1e-6) * np.linalg.norm(u_cold)
+    # (2) consumed: the next solve starts from zero again
+    u2, i2 = fs.solve(rtol=rtol, max_it=20000)
+    assert i2["iterations"] == cold["iterations"]
+    np.testing.assert_array_equal(u2, u_cold)
+    # (3) loads scaled by 1.04, guess = the old solution handed in from the host: the answer is 1.04 x, in fewer iterations
+    fs.set_loads(1.04 * m.loads)
+    fs.set_initial_guess(u_cold)
+    u3, i3 = fs.solve(rtol=rtol, max_it=20000)
+    assert i3["converged"] == 1 and i3["iterations"] < cold["iterations"]
+    assert np.linalg.norm(u3 - 1.04 * u_cold) <= (1e-8 if pc == "amg" else 1e-5) * np.linalg.norm(u_cold)
+    if pc == "amg":
+        lv = fs.amg_levels()
+        rg, cg, vg, Fg = fs.export_bsr()
+        A = _bsr(rg, cg, vg, m.n_nodes)
+        levels = amg_oracle.setup(A, m.xyz, m.dirichlet_mask(), lams=[l["lambda_max"] for l in lv], coarsest_nodes=60, tri=m.tri, quad=m.quad)
+        u0, hist = amg_oracle.solve(A, Fg, levels, rtol=rtol, max_it=400, refine_passes=1, x0=u_cold.ravel())
+        assert abs(len(hist) - i3["iterations"]) <= 2, (len(hist), i3["iterations"])
+        assert np.linalg.norm(u3.ravel() - u0) <= 1e-9 * np.linalg.norm(u0)
+    # (4) errors: before any solve of a fresh context there is nothing to start from
+    fs2 = _context(m, mat)
+    with pytest.raises(pkg.FemShellError):
+        fs2.set_initial_guess(None)
+    fs2.close()
+    fs.close()
