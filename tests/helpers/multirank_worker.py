@@ -183,6 +183,14 @@ def main():
         cc = fs.comm_counters()
         extra["comm_solve2"] = np.array([cc["halo_exchanges_on_the_halo_stream"], cc["halo_exchanges_on_the_main_stream"],
                                          cc["allreduces"], cc["row_gathers"]])
+    if os.environ.get("FEMSHELL_TEST_WARM") == "1":
+        # a third solve of the same loads from the second one's solution (femshell_set_initial_guess on a row-partitioned context)
+        fs.set_initial_guess(None)
+        u3, info3 = fs.solve(rtol=1e-11, max_it=100000)
+        extra.update(u3=u3, iterations3=info3["iterations"], converged3=info3["converged"])
+        fs.set_initial_guess(u)  # ... and one from a host vector: the first solve's solution, half the loads
+        u4, info4 = fs.solve(rtol=1e-11, max_it=100000)
+        extra.update(u4=u4, iterations4=info4["iterations"], converged4=info4["converged"])
     np.savez(out_file, u=u, iterations=info["iterations"], converged=info["converged"], begin=b, end=e,
              true_res=info["true_rel_residual"], u2=u2, converged2=info2["converged"], iterations2=info2["iterations"],
              levels=info["amg_levels"], **extra)

@@ -146,6 +146,23 @@ def test_renumbered_row_partition_of_a_randomly_numbered_mesh_against_the_oracle
     assert err < 1e-8, err
 
 
+@pytest.mark.parametrize("pc", ["amg", None])
+def test_solve_from_an_initial_guess_on_a_row_partitioned_context(pc, tmp_path):
+    """femshell_set_initial_guess with several ranks: every rank keeps its own rows of the guess (or of its previous solution), the
+    ghost entries travel as for any iterate; same answer on every rank, fewer iterations than from zero."""
+    ranks = run_ranks(2, "panel", tmp_path, pc=pc, extra_env={"FEMSHELL_TEST_WARM": "1"})
+    for r in ranks:
+        assert int(r["converged3"]) == 1 and int(r["converged4"]) == 1
+        np.testing.assert_array_equal(r["u3"], ranks[0]["u3"])
+        np.testing.assert_array_equal(r["u4"], ranks[0]["u4"])
+        scale = np.linalg.norm(r["u2"])
+        assert np.linalg.norm(r["u3"] - r["u2"]) <= 1e-8 * scale            # the same loads again
+        assert np.linalg.norm(r["u4"] - r["u2"]) <= 1e-8 * scale            # from u = u2 / 2: half way there
+        assert int(r["iterations4"]) < int(r["iterations2"])
+        if pc == "amg":  # (plain-FP64 block-Jacobi CG gains from a guess down to kappa x eps only: tests/test_gpu_amg.py)
+            assert int(r["iterations3"]) <= 0.5 * int(r["iterations2"]), (int(r["iterations3"]), int(r["iterations2"]))
+
+
 def test_multigrid_setup_traffic_of_a_randomly_numbered_mesh_with_and_without_renumbering(tmp_path):
     """What the setup of the row-partitioned hierarchy sends per rank on the 20k-node Delaunay shell of poor element quality in
     random numbering: the rows of Q, P and A P of every node another rank reads.  In the caller's numbering half of all nodes are
