@@ -240,7 +240,8 @@ int femshell_assembly_kernel(femshell_ctx *ctx);
 
 /* replaces: equation_systems.solve() -> PETSc KSPSolve (SA:138, PC:271) followed by
  * build_solution_vector (SA:141; PC:274-280 broadcast): 6x6-block-Jacobi preconditioned CG,
- * x0 = 0, stop at ||r||_2 <= rtol*||b||_2 or max_it.  rtol <= 0 runs exactly max_it iterations.
+ * x0 = 0 (or what femshell_set_initial_guess handed over for this solve), stop at ||r||_2 <= rtol*||b||_2 or max_it.
+ * rtol <= 0 runs exactly max_it iterations.
  * u_out[n_nodes][6] receives the full solution on every rank; NULL leaves it in HBM
  * (fetch with femshell_get_solution).  Assembles first if needed.
  * Contexts with a communicator (femshell_comm_init) run the single-reduction form of the same method
