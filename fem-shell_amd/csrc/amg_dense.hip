@@ -265,10 +265,7 @@ template <class F> __device__ __forceinline__ void for_quadrant(int r0, int c0, 
 // cores from LDS (row stride 66: conflict-free; a product with thread-per-4x4 FMAs from LDS took 98 us per sweep, more than
 // the trailing update it feeds).  LDS: P0 = B_A, P1 = C -> S -> B_S, P2 = W -> X21^T, P3 = W^T.
 // status[0] = 1 on a clearly negative pivot, status[1] counts the dropped directions.
-// (panels: the four 64 x 66 work blocks P0 .. P3 -- LDS in k_dense_pivot; in the look-ahead of k_dense_update, whose
-//  workgroups have 35 KB of LDS each, a scratch buffer in HBM that stays in the caches: the products then read their operands
-//  through global loads, slower than from LDS but beside the trailing update instead of in front of it.  small: 2 x 4 x 64
-//  doubles of row panel + 128 diagonal entries, LDS in both.)
+// (panels: the four 64 x 66 work blocks P0 .. P3; small: 2 x 4 x 64 doubles of row panel + 128 diagonal entries -- LDS, both.)
 __device__ __forceinline__ void pivot_block(const double *__restrict__ D, int64_t ld, int K, const double *__restrict__ diag0,
                                             double *__restrict__ B, int32_t *status, double *panels, double *small_lds)
 {
