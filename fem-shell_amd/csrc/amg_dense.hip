@@ -675,8 +675,10 @@ __global__ __launch_bounds__(256, 4) void k_dense_update(double *__restrict__ D,
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int r = r0 + 16 * ti + (lane >> 4) + 4 * g, c = c0 + 16 * tj + (lane & 15);
-                // (kept in registers of their own until the end -- A - W C^T -- they would not be waited for before the first operand
-                //  loads go out, 3 us per tile; measured: 32 more registers spill at four workgroups per CU, 202 against 180 us per sweep)
+                // (MEASURED, round 5: kept in registers of their own until the end -- A - W C^T -- they are not waited for before the
+                //  first operand loads go out; from the start that costs 32 registers beside the 32 of the words in flight and spills
+                //  at four workgroups per CU (202 against 180 us per sweep); fetched in front of the last chunk's matrix instructions
+                //  into the registers the staging has given back: no spill, and no gain either -- 11.07 against 11.07 - 11.10 ms)
                 acc[ti][tj][g] = -tile[(int64_t)r * ld + c]; // accumulate W C^T - A, store its negative
             }
     // K = 128 in four chunks of 32 (row stride 34 doubles: conflict-free): 35 KB of LDS per workgroup, four per CU
