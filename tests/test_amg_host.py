@@ -298,3 +298,24 @@ def test_rank_local_aggregation_of_the_restatement(world):
         u, h = amg_oracle.solve(A, F.ravel(), lv, rtol=1e-10, max_it=300, refine_passes=1)
         assert len(h) <= 1.2 * len(h1) + 2, (world, dist_min, len(h), len(h1))
         assert np.linalg.norm(u - u1) <= 1e-9 * np.linalg.norm(u1)
+
+
+def test_restatement_from_an_initial_guess_and_with_the_adaptive_pass():
+    """oracle/amg_oracle.py solve: (i) x0 -- the first phase solves the correction equation of the guess down to the threshold it runs
+    to from zero (csrc/amg_solve.cpp cg_amg, femshell_set_initial_guess): same answer, fewer iterations from a good guess, the
+    iterations of a solve from zero from a useless one; (ii) the refinement pass stops on its own error estimate (a fifth of the
+    tolerance) instead of at a flat drop of 1e-4: never more iterations, the estimate it leaves stays below the tolerance."""
+    m, dm, rp, ci, vals, F = _problem("panel")
+    A = _bsr(rp, ci, vals, m.n_nodes)
+    levels = amg_oracle.setup(A, m.xyz, dm, coarsest_nodes=60, tri=m.tri)
+    b = F.ravel()
+    x, h = amg_oracle.solve(A, b, levels, rtol=1e-10, max_it=300, refine_passes=1)
+    xf, hf = amg_oracle.solve(A, b, levels, rtol=1e-10, max_it=300, refine_passes=1, adaptive=False)
+    assert len(h) <= len(hf)
+    assert np.linalg.norm(x - xf) <= 1e-9 * np.linalg.norm(xf)
+    xw, hw = amg_oracle.solve(A, b, levels, rtol=1e-10, max_it=300, refine_passes=1, x0=0.96 * x)
+    assert len(hw) < len(h) and np.linalg.norm(xw - x) <= 1e-9 * np.linalg.norm(x)
+    xs, hs = amg_oracle.solve(A, b, levels, rtol=1e-10, max_it=300, refine_passes=1, x0=x)
+    assert len(hs) <= 0.5 * len(h) and np.linalg.norm(xs - x) <= 1e-9 * np.linalg.norm(x)
+    xz, hz = amg_oracle.solve(A, b, levels, rtol=1e-10, max_it=300, refine_passes=1, x0=np.zeros_like(b))
+    assert abs(len(hz) - len(h)) <= 1 and np.linalg.norm(xz - x) <= 1e-9 * np.linalg.norm(x)
