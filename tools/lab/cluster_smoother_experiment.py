@@ -89,5 +89,7 @@ dmask = np.zeros(n, dtype=np.uint8); dmask[xyz[:, 0] < 0.15] = 0x3F
 loads = np.zeros((n, 6)); loads[:, 2] = 1.0
 r0, c0, v0, F0 = oracle.assemble(xyz, tri, np.zeros((0, 4), np.int32), oracle.material(0.3, 7.0e4, 0.03), dmask, loads)
 A = oracle.to_scipy(r0, c0, v0).tobsr((6, 6)); A.sort_indices()
-for tau, mc in ((0.8, 3), (0.8, 6), (0.7, 6), (0.6, 8), (0.9, 6)):
+run(A, F0, xyz, tri, dmask, 0.0, False, False, "point blocks, plain aggregation")
+run(A, F0, xyz, tri, dmask, 0.9, False, True, "cluster blocks (sigma > 0.90, <= 3 nodes), plain aggregation")
+for tau, mc in ((0.9, 3), (0.8, 6), (0.6, 8)):
     run(A, F0, xyz, tri, dmask, tau, True, True, "cluster blocks (sigma > %.2f, <= %d nodes), glued aggregation" % (tau, mc), max_cluster=mc)
