@@ -223,8 +223,101 @@ void aggregation_order(const Bsr &A, std::vector<int32_t> *order)
     }
 }
 
-int32_t aggregate_nodes(const Bsr &A, std::vector<int32_t> *aggout, const std::vector<int32_t> *visit)
+// The graph the greedy passes see when rows have more than `keep` neighbours: per node the `keep` neighbours it shares most
+// neighbours with (ties: the lower column), an edge stays when either end keeps it.  Why: the Galerkin operators of a structured
+// mesh reach three fine couplings far, and depending on how the aggregates of level 1 happen to tile -- a matter of the row length
+// modulo the tile -- the graph of level 2 has 13 or 17 neighbours per node; with 17 the aggregates of levels 2 and 3 hold 20
+// nodes instead of 15 and the 10M-triangle pinched cylinder needs 164 iterations where the 9M-triangle one needs 89
+// (profiles/r05_aggregation_lottery.txt).  The far couplings are the ones that share few neighbours with the node.  Rows are
+// sorted (graph_of_pattern, the host operators' columns ascend); keep <= 0 or no row beyond it: the graph itself.
+static const Bsr *graph_for_aggregation(const Bsr &A, int keep, Bsr *store)
 {
+    const int32_t n = A.nr;
+    if (keep <= 0) return &A;
+    int64_t widest = 0;
+    for (int32_t i = 0; i < n; i++) widest = std::max<int64_t>(widest, A.ptr[(size_t)i + 1] - A.ptr[(size_t)i]);
+    if (widest <= (int64_t)keep + 1) return &A; // (the node itself is one of its columns)
+    RawVec<uint8_t> kept((size_t)A.ptr[n]);
+    parallel_chunks(n, [&](int64_t i0, int64_t i1) {
+        std::vector<std::pair<int32_t, int32_t>> cand; // (-common neighbours, column)
+        for (int64_t i = i0; i < i1; i++) {
+            const int64_t b = A.ptr[i], e = A.ptr[i + 1];
+            if (e - b <= (int64_t)keep + 1) {
+                for (int64_t q = b; q < e; q++) kept[(size_t)q] = 1;
+                continue;
+            }
+            cand.clear();
+            for (int64_t q = b; q < e; q++) {
+                const int32_t j = A.col[q];
+                kept[(size_t)q] = j == (int32_t)i ? 1 : 0;
+                if (j == (int32_t)i) continue;
+                int32_t common = 0;
+                int64_t x = b, y = A.ptr[j];
+                const int64_t ye = A.ptr[(size_t)j + 1];
+                while (x < e && y < ye) {
+                    const int32_t cx = A.col[x], cy = A.col[y];
+                    if (cx == cy) {
+                        common++;
+                        x++;
+                        y++;
+                    } else if (cx < cy) {
+                        x++;
+                    } else {
+                        y++;
+                    }
+                }
+                cand.emplace_back(-common, j);
+            }
+            std::sort(cand.begin(), cand.end());
+            for (int k = 0; k < keep && k < (int)cand.size(); k++) {
+                const int32_t j = cand[(size_t)k].second;
+                const int64_t q = std::lower_bound(A.col.begin() + b, A.col.begin() + e, j) - A.col.begin();
+                kept[(size_t)q] = 1;
+            }
+        }
+    }, 1 << 12);
+    Bsr &G = *store;
+    G = Bsr();
+    G.nr = G.nc = n;
+    G.ptr.assign((size_t)n + 1, 0);
+    auto stays = [&](int64_t i, int64_t q) {
+        if (kept[(size_t)q]) return true;
+        const int32_t j = A.col[q]; // the other end's opinion
+        const int64_t b = A.ptr[j], e = A.ptr[(size_t)j + 1];
+        const int64_t r = std::lower_bound(A.col.begin() + b, A.col.begin() + e, (int32_t)i) - A.col.begin();
+        return r < e && A.col[r] == (int32_t)i && kept[(size_t)r] != 0;
+    };
+    parallel_chunks(n, [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; i++) {
+            int64_t cnt = 0;
+            for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++) cnt += stays(i, q) ? 1 : 0;
+            G.ptr[(size_t)i + 1] = cnt;
+        }
+    }, 1 << 12);
+    for (int32_t i = 0; i < n; i++) G.ptr[(size_t)i + 1] += G.ptr[(size_t)i];
+    G.col.resize((size_t)G.ptr[n]);
+    parallel_chunks(n, [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; i++) {
+            int64_t w = G.ptr[i];
+            for (int64_t q = A.ptr[i]; q < A.ptr[i + 1]; q++)
+                if (stays(i, q)) G.col[(size_t)w++] = A.col[q];
+        }
+    }, 1 << 12);
+    return &G;
+}
+
+// FEMSHELL_AMG_AGG_KEEP: neighbours per node the aggregation looks at (default 12 -- the graphs of the 4M-triangle north-star
+// meshes, 11.9 neighbours per node on their coarse levels, keep their aggregates bit for bit; 0: all of them, as in rounds 2-4)
+static int aggregation_keep()
+{
+    const char *e = getenv("FEMSHELL_AMG_AGG_KEEP"); // (read per setup: the tests switch it inside one process)
+    return e && *e ? atoi(e) : 12;
+}
+
+int32_t aggregate_nodes(const Bsr &Afull, std::vector<int32_t> *aggout, const std::vector<int32_t> *visit)
+{
+    Bsr filtered;
+    const Bsr &A = *graph_for_aggregation(Afull, aggregation_keep(), &filtered);
     const int32_t n = A.nr;
     std::vector<int32_t> agg((size_t)n, -1);
     int32_t na = 0;

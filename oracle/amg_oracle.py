@@ -11,6 +11,8 @@ operator by operator.
 
 Conventions: matrices are scipy BSR with 6x6 blocks; B[n, dof, mode] is the near-null space.
 """
+import os
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -85,9 +87,50 @@ def aggregation_order(rowptr, colidx):
     return order
 
 
+def aggregation_keep():
+    """Neighbours per node the aggregation looks at (csrc/amg_setup.cpp aggregation_keep: FEMSHELL_AMG_AGG_KEEP, default 12)."""
+    e = os.environ.get("FEMSHELL_AMG_AGG_KEEP")
+    return int(e) if e not in (None, "") else 12
+
+
+def graph_for_aggregation(rowptr, colidx, keep=None):
+    """The graph the greedy passes see (csrc/amg_setup.cpp graph_for_aggregation): when a row has more than `keep` neighbours
+    besides the node itself, every such node keeps the `keep` neighbours it shares most neighbours with (ties: the lower
+    column), and an edge stays when either end keeps it.  Rows must be sorted.  Returns (rowptr, colidx)."""
+    keep = aggregation_keep() if keep is None else keep
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    colidx = np.asarray(colidx, dtype=np.int64)
+    n = len(rowptr) - 1
+    deg = np.diff(rowptr)
+    if keep <= 0 or n == 0 or deg.max() <= keep + 1:
+        return rowptr, colidx
+    kept = np.ones(len(colidx), dtype=bool)
+    for i in np.nonzero(deg > keep + 1)[0]:
+        b, e = rowptr[i], rowptr[i + 1]
+        nb = colidx[b:e]
+        kept[b:e] = nb == i
+        cand = []
+        for j in nb:
+            if j == i:
+                continue
+            common = len(np.intersect1d(nb, colidx[rowptr[j]:rowptr[j + 1]], assume_unique=True))
+            cand.append((-common, int(j)))
+        cand.sort()
+        for _, j in cand[:keep]:
+            kept[b + np.searchsorted(nb, j)] = True
+    rows = np.repeat(np.arange(n), deg)
+    pattern = sp.csr_matrix((np.ones(len(colidx), dtype=np.int64), (rows, colidx)), shape=(n, n))
+    mine = sp.csr_matrix((kept.astype(np.int64), (rows, colidx)), shape=(n, n))
+    either = ((mine + mine.T).multiply(pattern)).tocsr()  # the other end's opinion counts where the reverse edge exists
+    either.eliminate_zeros()
+    either.sort_indices()
+    return either.indptr.astype(np.int64), either.indices.astype(np.int64)
+
+
 def aggregate(rowptr, colidx, visit=None):
-    """Greedy distance-1 aggregation, three passes; returns (agg, n_aggregates).  visit: the order in which the passes
-    meet the nodes (default: aggregation_order); a leftover of pass 1 joins the neighbour that comes first in it."""
+    """Greedy distance-1 aggregation, three passes, on graph_for_aggregation; returns (agg, n_aggregates).  visit: the order in
+    which the passes meet the nodes (default: aggregation_order); a leftover of pass 1 joins the neighbour that comes first in it."""
+    rowptr, colidx = graph_for_aggregation(rowptr, colidx)
     n = len(rowptr) - 1
     agg = -np.ones(n, dtype=np.int64)
     na = 0

@@ -319,3 +319,34 @@ def test_restatement_from_an_initial_guess_and_with_the_adaptive_pass():
     assert len(hs) <= 0.5 * len(h) and np.linalg.norm(xs - x) <= 1e-9 * np.linalg.norm(x)
     xz, hz = amg_oracle.solve(A, b, levels, rtol=1e-10, max_it=300, refine_passes=1, x0=np.zeros_like(b))
     assert abs(len(hz) - len(h)) <= 1 and np.linalg.norm(xz - x) <= 1e-9 * np.linalg.norm(x)
+
+
+def test_aggregation_looks_at_the_twelve_closest_neighbours_of_a_node(monkeypatch):
+    """Rows of more than twelve neighbours (the Galerkin operators of some structured meshes: 17 per node on level 2 of the
+    10M-triangle cylinder) are aggregated on the graph of the neighbours a node shares most neighbours with
+    (csrc/amg_setup.cpp graph_for_aggregation): library and restatement agree on it, and the aggregates get smaller."""
+    ensure_built()
+    b = _binding()
+    rng = np.random.default_rng(11)
+    n = 2500
+    xy = rng.uniform(0.0, 1.0, (n, 2))
+    order = np.lexsort((xy[:, 0], np.floor(xy[:, 1] * 25)))  # a numbering that sweeps the square in strips
+    xy = xy[order]
+    d2 = ((xy[:, None, :] - xy[None, :, :]) ** 2).sum(axis=2)
+    G = sp.csr_matrix(d2 <= (2.3 / np.sqrt(n)) ** 2)  # about 16 neighbours per node, the node itself included
+    G.sort_indices()
+    rowptr, cols = G.indptr.astype(np.int32), G.indices.astype(np.int32)
+    assert np.diff(rowptr).max() > 13
+    fp, fc = amg_oracle.graph_for_aggregation(rowptr, cols, 12)
+    F = sp.csr_matrix((np.ones(len(fc)), fc, fp), shape=(n, n))
+    assert (F != F.T).nnz == 0 and F.diagonal().all() and F.nnz < G.nnz
+    kept = np.diff(fp) - 1
+    assert kept.min() >= np.minimum(np.diff(rowptr) - 1, 12).min() and kept.mean() < (np.diff(rowptr) - 1).mean()
+    agg_lib = np.asarray(b.amg_host_aggregate(rowptr, cols)[0])
+    agg_ref, na_ref = amg_oracle.aggregate(rowptr, cols)
+    assert np.array_equal(agg_lib, agg_ref)
+    monkeypatch.setenv("FEMSHELL_AMG_AGG_KEEP", "0")
+    agg_all = np.asarray(b.amg_host_aggregate(rowptr, cols)[0])
+    agg_ref0, na_ref0 = amg_oracle.aggregate(rowptr, cols)
+    assert np.array_equal(agg_all, agg_ref0)
+    assert agg_lib.max() + 1 > 1.05 * (agg_all.max() + 1)
