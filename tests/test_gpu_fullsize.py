@@ -184,3 +184,33 @@ def test_full_size_coarsest_inverse_on_the_matrix_cores(context, monkeypatch):
     assert info32["converged"] == 1 and abs(info32["iterations"] - info["iterations"]) <= 4
     assert 0.0 < np.abs(inv32 - inv).max() <= 2e-7 * np.abs(inv).max()
     fs.assemble()
+
+
+def test_a_mesh_size_that_draws_the_dense_tiling(monkeypatch):
+    """Four structured sizes in ten end, on level 1, in the tiling whose Galerkin operator has 17 neighbours per node on level 2
+    (profiles/r05_aggregation_lottery.txt): the 1300 x 1300 pinched cylinder is one of them, next to the north-star size.  With
+    the aggregation on the graph of the twelve closest neighbours (csrc/amg_setup.cpp graph_for_aggregation) levels 2 and 3 are
+    coarsened 15 : 1 as on the other sizes and the solve takes 91 iterations; on the whole graph 20 : 1 and 103."""
+    ensure_built()
+    m, mat = fullsize.workload("cylinder", 1300)
+    fs = pkg.FemShell(*mat, device=0)
+    try:
+        fs.set_mesh(m.xyz, m.tri)
+        fs.set_dirichlet(m.dirichlet_mask())
+        fs.set_loads(m.loads)
+        fs.assemble()
+        fs.set_preconditioner("amg")
+        u, info = fs.solve(rtol=1e-10, max_it=400, fetch=False)
+        nodes = [lv["n_nodes"] for lv in fs.amg_levels()]
+        assert info["converged"] == 1 and info["error_estimate"] <= 1e-10
+        assert nodes[2] / nodes[3] < 16.5, nodes
+        monkeypatch.setenv("FEMSHELL_AMG_AGG_KEEP", "0")
+        fs.assemble()  # (a new hierarchy with the setting above)
+        fs.set_preconditioner("amg")
+        u0, info0 = fs.solve(rtol=1e-10, max_it=400, fetch=False)
+        nodes0 = [lv["n_nodes"] for lv in fs.amg_levels()]
+        assert info0["converged"] == 1
+        assert nodes0[:3] == nodes[:3] and nodes0[2] / nodes0[3] > 18.5, (nodes, nodes0)
+        assert info["iterations"] <= 96 and info["iterations"] + 6 <= info0["iterations"], (info["iterations"], info0["iterations"])
+    finally:
+        fs.close()
