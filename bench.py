@@ -6,12 +6,16 @@ into 3,998,792 TRI3 (2,002,225 nodes, 12,013,350 dofs), E=1e7, nu=0.3, t=0.5, al
 supported (boundary id 0), uniform pressure 300 as nodal Fz.  With --gpus N the same mesh is
 row-partitioned over N ranks (strong scaling, as BASELINE.json's 1/2/4/8-GPU curve asks).
 
-A "step" is one full assembly of K and F (inputs resident in HBM).  After the K timed assembly
-steps, K*cg_iters CG iterations (6x6 block-Jacobi, the oracle's method) are timed the same way (barrier +
-synchronize on both sides, max over ranks).  One JSON line is printed by rank 0.  At N=1 it also carries
+A "step" is one full femshell_assemble of K and F (inputs resident in HBM; launch + status round trip).  After W warm-up
+steps (each an assembly + cg_iters CG iterations) the K timed assembly steps run, then K*cg_iters CG iterations (6x6
+block-Jacobi, the oracle's method) are timed the same way (barrier + synchronize on both sides, max over ranks).
+
+Output: rank 0 prints ONE compact JSON line on stdout (< 4 KB: metric, value, ms_per_step, config, roofline, cpu_baseline,
+cg_iters_per_s, time_to_solution_s / _iterations, parity_max_rel) and writes everything else to bench_detail.json next to this
+script (and to gpurun_out/ when it exists).  At N=1 the detail record carries
   time_to_solution  the same 4M-tri system solved to rtol 1e-10 with the multigrid preconditioner
-  parity            the small panel against the oracle, and BASELINE configs[1] at full size (Scordelis-Lo roof,
-                    250,632 tri3, rtol 1e-12) against the oracle's refined direct solve
+  parity            the small panel against the oracle, BASELINE configs[1] at full size (Scordelis-Lo roof, 250,632 tri3,
+                    rtol 1e-12) against the oracle's refined direct solve, configs[2] / [3] / [4] at full size
   cpu_baseline      the oracle (C port of the reference path, -O3 -march=native + OpenMP, built on this host)
 """
 import argparse
@@ -178,10 +182,11 @@ def cpu_baseline_worker(nx):
         "cpu_model": model, "physical_cores": physical, "logical_cpus": logical, "cgroup_cpu_quota": cpu_quota(),
         "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_NUM_THREADS")},
         "build": "gcc -O3 -march=native -fopenmp (oracle/Makefile target `fast`, compiled on this host)",
-        "sample": "the benchmark's own mesh: panel %dx%d squares (%d tri3, %d dofs); per thread count 1 first-touch "
-                  "assembly + up to 10 timed ones, 4-200 PCG iterations (6x6 block-Jacobi, the oracle's method), a "
-                  "STREAM triad of 3 x 1 GiB; `value` / `cg_iters_per_s` are the best of the sweep; "
-                  "oracle/femshell_oracle.c" % (nx, nx, len(m.tri), n_dof),
+        "sample": "panel %dx%d (%d tri3): per thread count <=10 assemblies + <=200 PCG its; best of the sweep" % (nx, nx, len(m.tri)),
+        "sample_detail": "the benchmark's own mesh: panel %dx%d squares (%d tri3, %d dofs); per thread count 1 first-touch "
+                         "assembly + up to 10 timed ones, 4-200 PCG iterations (6x6 block-Jacobi, the oracle's method), a "
+                         "STREAM triad of 3 x 1 GiB; `value` / `cg_iters_per_s` are the best of the sweep; "
+                         "oracle/femshell_oracle.c" % (nx, nx, len(m.tri), n_dof),
     }))
 
 
@@ -375,7 +380,7 @@ def config2_cylinder(pkg, device, steps, warmup, nx, roof):
     fs.sync()
     t0 = time.perf_counter()
     for _ in range(steps):
-        fs.assemble(wait=False)  # (as in the headline leg: status collected by the sync)
+        fs.assemble()  # (as in the headline leg: one full femshell_assemble per step)
     fs.sync()
     t_asm = time.perf_counter() - t0
     asm_ms, asm_bytes = fs.time_kernel(pkg.KERNEL_ASSEMBLE, max(5, steps))  # (right behind the timed steps, as in the headline leg)
@@ -460,6 +465,101 @@ def jacobi_extrapolation(hist, target=1e-10):
     return out
 
 
+METRIC = "elements assembled/s + CG iters/s, 4M-tri shell, 1/2/4/8 MI355X"
+DETAIL_FILE = "bench_detail.json"
+LINE_LIMIT = 4096  # bytes of the final stdout line (the driver's record keeps a tail of stdout; round 5's 20.7 KB line was not parsed)
+
+
+def _walk(d, path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def parity_max_rel(detail):
+    """Worst relative figure of the parity sections of the detail record: assembled K against the oracle's (every mesh the run
+    checked) and the solver term of the displacements (against the refined direct solve of the same matrix on the small meshes,
+    against manufactured solutions at full size).  None when the run carried no parity section (N > 1, --profile)."""
+    paths = [
+        ("parity", "small", "matrix_rel_diff_vs_oracle"),
+        ("parity", "small", "block_jacobi", "rel_err_solver_term_vs_direct_same_matrix"),
+        ("parity", "small", "multigrid", "rel_err_solver_term_vs_direct_same_matrix"),
+        ("parity", "config1_scordelis_lo_250k", "matrix_rel_diff_vs_oracle"),
+        ("parity", "config1_scordelis_lo_250k", "rel_err_solver_term_vs_direct_same_matrix"),
+        ("parity", "config3_flat_panel_4M", "matrix_vs_oracle", "max_entry_diff_over_max_entry"),
+        ("parity", "config3_flat_panel_4M", "manufactured_solution", "rel_err_manufactured"),
+        ("parity", "config3_flat_panel_4M", "manufactured_solution_with_the_load_case_spectrum", "rel_err_manufactured"),
+        ("config2_pinched_cylinder_4M", "parity", "matrix_vs_oracle", "max_entry_diff_over_max_entry"),
+        ("config2_pinched_cylinder_4M", "parity", "manufactured_solution", "rel_err_manufactured"),
+        ("config2_pinched_cylinder_4M", "parity", "manufactured_solution_with_the_load_case_spectrum", "rel_err_manufactured"),
+        ("config4_coupled_flap_1M", "matrix_vs_oracle", "max_entry_diff_over_max_entry"),
+        ("config4_coupled_flap_1M", "manufactured_solution_rel_err"),
+    ]
+    seen = [v for v in (_walk(detail, p) for p in paths) if isinstance(v, (int, float))]
+    return max(seen) if seen else None
+
+
+def compact_line(detail):
+    """The ONE stdout line of the run: what the driver records and nothing else.  Built from the detail
+    record (which goes to bench_detail.json); tests/test_bench_guard.py holds it below LINE_LIMIT bytes on a canned record."""
+    cfg = detail.get("config", {})
+    roof = detail.get("roofline") or {}
+    cpu = detail.get("cpu_baseline") or {}
+    tts = detail.get("time_to_solution") or {}
+    line = {
+        "metric": detail.get("metric", METRIC), "value": detail.get("value"), "unit": detail.get("unit", "elements/s"),
+        "n_gpus": detail.get("n_gpus"), "steps": detail.get("steps"), "warmup": detail.get("warmup"),
+        "ms_per_step": detail.get("ms_per_step"), "higher_is_better": True, "scaling": detail.get("scaling", "strong"),
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {k: cfg.get(k) for k in ("workload", "parallelism", "rccl_ranks_seen", "preconditioner", "assembly_step",
+                                            "warmup_step", "cg_iters_per_step", "time_to_solution_preconditioner") if k in cfg},
+        "roofline": {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "ms_per_launch",
+                                              "algorithmic_bytes_per_launch")} if roof else None,
+        "cpu_baseline": {k: cpu.get(k) for k in ("value", "unit", "cores", "cpu_model", "cg_iters_per_s", "kind", "sample", "error")
+                         if k in cpu} if cpu else None,
+        "cg_iters_per_s": detail.get("cg_iters_per_s"),
+        "time_to_solution_s": tts.get("solve_seconds"),
+        "time_to_solution_iterations": tts.get("iterations"),
+        "parity_max_rel": parity_max_rel(detail),
+        "detail_file": DETAIL_FILE,
+    }
+    if detail.get("error"):
+        line["error"] = str(detail["error"])[:300]
+    s = json.dumps(line)
+    if len(s) > LINE_LIMIT:  # (prose that grew: the numbers stay, the strings are cut)
+        for sect in ("config", "roofline", "cpu_baseline"):
+            for k, v in (line.get(sect) or {}).items():
+                if isinstance(v, str) and len(v) > 60:
+                    line[sect][k] = v[:57] + "..."
+        s = json.dumps(line)
+    if len(s) > LINE_LIMIT:
+        raise RuntimeError("bench line of %d bytes" % len(s))
+    return s
+
+
+def write_detail(detail):
+    """The full record -- witnesses, per-level bytes, counters, the other configs, notes -- next to the script and, where the
+    GPU box collects files (gpurun_out/), there as well.  Never on stdout."""
+    txt = json.dumps(detail, indent=1)
+    where = os.environ.get("FEMSHELL_BENCH_DETAIL_DIR")  # (tests)
+    for d in ((where,) if where else (ROOT, os.path.join(ROOT, "gpurun_out"))):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, DETAIL_FILE), "w") as f:
+                f.write(txt + "\n")
+        except OSError as e:
+            sys.stderr.write("bench: %s not written in %s: %s\n" % (DETAIL_FILE, d, e))
+
+
+def emit(detail):
+    """Rank 0's output: the detail record to its file, then the compact line as the LAST (and only) line on stdout."""
+    write_detail(detail)
+    sys.stdout.flush()
+    print(compact_line(detail), flush=True)
+
+
 def guarded_multi_rank_run():
     """N > 1: the rank's work runs in a CHILD process started before anything has touched the GPU; this parent only waits.
     A first run on real RCCL that stalls (a rank that never joins, a collective a peer never enters) then ends with a
@@ -520,13 +620,13 @@ def guarded_multi_rank_run():
     except OSError:
         pass
     phase = next((ln for ln in reversed(tail) if "[femshell watchdog]" in ln or "femshell error" in ln), None)
-    line = {"metric": "elements assembled/s + CG iters/s, 4M-tri shell, 1/2/4/8 MI355X", "value": None, "unit": "elements/s",
-            "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "error": why, "phase": phase, "stderr_tail": list(tail)[-15:],
-            "rccl_debug_tail": rccl,
-            "retry_hint": "FEMSHELL_HALO_OVERLAP=0 takes the halo send/recv group off its second stream (it shares the communicator "
-                          "with the all-reduce on the main stream, csrc/cg_driver.cpp); FEMSHELL_COMM_TIMEOUT=<s> widens the watchdog"}
+    line = {"metric": METRIC, "value": None, "unit": "elements/s",
+            "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "error": why[:300], "phase": (phase or "")[:300] or None,
+            "retry_hint": "FEMSHELL_HALO_OVERLAP=0 (halo group off its second stream); FEMSHELL_COMM_TIMEOUT=<s> widens the watchdog",
+            "detail_file": DETAIL_FILE}
     sys.stderr.write(why + "\n")
     if rank == 0:
+        write_detail(dict(line, error=why, phase=phase, stderr_tail=list(tail)[-15:], rccl_debug_tail=rccl))
         print(json.dumps(line), flush=True)
     return rc if rc != 0 else 1
 
@@ -658,34 +758,36 @@ def main():
     fs.assemble()
     fs.sync()
     cold_ms = 1e3 * (time.perf_counter() - t0)
-    # ---- device warm-up, then the W warm-up steps of the contract.  The first ~20 launches of a fresh process
-    # run ~12 % slower than the steady state (tools/asm_warm.py: 1.14 ms falling to 1.00 ms over the first 20
-    # assembly launches: clocks, TLBs, first touches); a production run assembles and iterates thousands of times.
-    for _ in range(30):
-        fs.assemble()
-    fs.solve(rtol=0.0, max_it=200, fetch=False)
+    # ---- the W warm-up steps of the contract, each the whole of what a timed step is: one femshell_assemble and cg_iters CG
+    # iterations (the first launches of a fresh process run ~12 % slow -- clocks, TLBs, first touches; five such steps are 0.2 s of
+    # device work, and profiles/r06_warmup_ab.txt shows the timed steps behind them at the rate 30 + 200 extra launches gave).
+    # FEMSHELL_BENCH_EXTRA_WARMUP=1 adds those extra launches for that A/B; the default runs nothing but the W steps.
+    if os.environ.get("FEMSHELL_BENCH_EXTRA_WARMUP") == "1":
+        for _ in range(30):
+            fs.assemble()
+        fs.solve(rtol=0.0, max_it=200, fetch=False)
     for _ in range(args.warmup):
         fs.assemble()
-    fs.solve(rtol=0.0, max_it=max(args.warmup, 1) * 5, fetch=False)
+        fs.solve(rtol=0.0, max_it=args.cg_iters, fetch=False)
 
-    # ---- timed phase 1: K assembly steps.  femshell_assemble_async enqueues a step; the status of all K (a degenerate
-    # element on any rank) is collected once by the closing femshell_sync instead of after every step -- on N ranks that
-    # agreement is an all-reduce plus a host round trip per step, as long as a 1/N-th of the assembly itself.  The same K
-    # steps through the synchronous femshell_assemble are timed beside it (`ms_per_step_with_status_round_trip`).
+    # ---- timed phase 1: K assembly steps, each one full femshell_assemble: launch, the status word's
+    # round trip to the host (a degenerate element on any rank; on N ranks an all-reduce), return.  `value` / `ms_per_step`.
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         fs.assemble()
     fs.sync()
     barrier()
-    t_asm_sync = max_over_ranks(time.perf_counter() - t0)
+    t_asm = max_over_ranks(time.perf_counter() - t0)
+    # beside it: the same K steps enqueued with femshell_assemble_async, the status of all of them collected by one
+    # femshell_sync (`ms_per_step_async`: what a caller that assembles ahead of the device pays)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         fs.assemble(wait=False)
     fs.sync()
     barrier()
-    t_asm = max_over_ranks(time.perf_counter() - t0)
+    t_asm_async = max_over_ranks(time.perf_counter() - t0)
     # the kernel of these steps by HIP events on the library's stream, in the state the timed steps ran in (measured after
     # the CG kernels' event pairs, whose synchronisations let the clocks sag, its first launches run 3-4 % slow)
     asm_ms, asm_bytes = fs.time_kernel(pkg.KERNEL_ASSEMBLE, max(5, args.steps))
@@ -873,37 +975,45 @@ def main():
     asm_kernel = fs.assembly_kernel()
     if rank == 0:
         out = {
-            "metric": "elements assembled/s + CG iters/s, 4M-tri shell, 1/2/4/8 MI355X",
+            "metric": METRIC,
             "value": n_elem * args.steps / t_asm,
             "unit": "elements/s",
             "cg_iters_per_s": info["iterations"] / t_cg,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * t_asm / args.steps,
-            "ms_per_step_with_status_round_trip": 1e3 * t_asm_sync / args.steps,
+            "ms_per_step_async": 1e3 * t_asm_async / args.steps,
+            "elements_per_s_async": n_elem * args.steps / t_asm_async,
             "cg_ms_per_iter": 1e3 * t_cg / max(info["iterations"], 1),
             "ms_first_assembly_cold": cold_ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": {"panel": "flat panel 10x10, simply supported, uniform pressure 300, E=1e7 nu=0.3 t=0.5 "
-                                             "(BASELINE.json configs[3]; configs[2] has the same size)",
-                                    "cylinder": "pinched cylinder R=300 L=600 t=3, E=3e6 nu=0.3 (BASELINE.json configs[2])",
-                                    "roof": "Scordelis-Lo roof R=25 L=50 80deg t=0.25, E=4.32e8 nu=0 (BASELINE.json configs[1])"
-                                    }[args.workload] + ": %dx%d squares -> %d tri3, %d nodes, %d dofs"
-                                   % (args.nx, args.nx, n_elem, n_nodes, 6 * n_nodes),
+            "config": {"workload": {"panel": "configs[3] flat panel", "cylinder": "configs[2] pinched cylinder",
+                                    "roof": "configs[1] Scordelis-Lo roof"}[args.workload]
+                                   + " %dx%d squares: %d tri3, %d dofs" % (args.nx, args.nx, n_elem, 6 * n_nodes),
+                       "workload_parameters": {"panel": "10x10, simply supported, uniform pressure 300, E=1e7 nu=0.3 t=0.5 (configs[2] has the same size)",
+                                               "cylinder": "R=300 L=600 t=3, E=3e6 nu=0.3",
+                                               "roof": "R=25 L=50 80deg t=0.25, E=4.32e8 nu=0"}[args.workload],
+                       "nodes": n_nodes,
                        "parallelism": "row-partition x%d" % world, "cg_iters_per_step": args.cg_iters,
-                       "assembly_step": "femshell_assemble_async x steps, one femshell_sync (status of all steps collected there)",
-                       "untimed_before_the_timed_steps": "1 cold assembly (ms_first_assembly_cold), 30 assemblies + 200 CG iterations of device warm-up "
-                                                         "(clocks, TLBs), then the --warmup steps of the contract",
-                       "preconditioner": "6x6 block-Jacobi", "symbolic_setup_s": setup_s,
+                       "assembly_step": "one femshell_assemble: launch + status round trip",
+                       "warmup_step": "one femshell_assemble + cg_iters CG iterations",
+                       "untimed_before_the_timed_steps": "1 cold assembly (ms_first_assembly_cold), then the --warmup steps"
+                                                         + (" + 30 assemblies + 200 CG iterations (FEMSHELL_BENCH_EXTRA_WARMUP=1)"
+                                                            if os.environ.get("FEMSHELL_BENCH_EXTRA_WARMUP") == "1" else ""),
+                       "preconditioner": "6x6 block-Jacobi (cg_iters_per_s)",
+                       "time_to_solution_preconditioner": "SA multigrid, K cycle, mixed precision",
+                       "symbolic_setup_s": setup_s,
                        "matrix_storage": "symmetric (upper triangles of the diagonal blocks + the blocks of the lower-numbered row)" if symmetric else "full",
                        "rccl_ranks_seen": rccl_ranks, "rccl_selftest_us": fs.comm_selftest(), "box_streaming_copy_gb_per_s": copy_gbs,
                        "box_stream_write_gb_per_s": stream.get("write_gb_per_s") if stream else None,
                        "box_stream_read_gb_per_s": stream.get("read_gb_per_s") if stream else None,
                        "box_stream_copy_gb_per_s": stream.get("copy_gb_per_s") if stream else None,
-                       "box_hipmalloc_plus_free_of_4GiB_ms": alloc_ms},
+                       "box_hipmalloc_plus_free_of_4GiB_ms": alloc_ms,
+                       "kernel_source_digest": kernel_source_digest()},
             # `roofline` belongs to `value`: the kernel the timed assembly steps consist of
-            "roofline": dict(roof(asm_ms, asm_bytes, asm_kernel), kernel=asm_kernel + " (element records -> block slots -> K and F; the kernel "
-                             "`value` / `ms_per_step` time; not HBM-bound: see fp64_* and DESIGN.md section 4)"),
+            "roofline": dict(roof(asm_ms, asm_bytes, asm_kernel), kernel=asm_kernel,
+                             kernel_note="element records -> block slots -> K and F; the kernel `value` / `ms_per_step` time; "
+                                         "not HBM-bound alone: see fp64_* and DESIGN.md section 4"),
             "roofline_cg_spmv": dict(roof(spmv_ms, spmv_bytes, spmv_kernel), kernel=spmv_kernel + " (q = K p, fused p.q" +
                                      ("; symmetric storage: first phase, the update kernel collects the transposed products)" if symmetric else ")")),
             "roofline_cg_update": dict(roof(upd_ms, upd_bytes, "k_cg_update"), kernel="k_cg_update"),
@@ -923,7 +1033,7 @@ def main():
                 out["config4_coupled_flap_1M"] = config4_coupled_flap()
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.nx if args.workload == "panel" else 1414)
-        print(json.dumps(out))
+        emit(out)
     fs.close()
     if world > 1:
         dist.barrier()

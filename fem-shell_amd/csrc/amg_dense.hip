@@ -364,11 +364,11 @@ __device__ __forceinline__ void pivot_block(const double *__restrict__ D, int64_
 // Bounded wait of one workgroup for a counter another launch raises (the look-ahead of the block sweep, below): thread 0 polls
 // with acquire semantics, the others join at the barrier; false when the bound expired (status[0] = 2: the host runs the inverse
 // again without the look-ahead).
-// kFenceAlways = false: for a consumer that has not touched the announced bytes since its launch began and whose producer is
-// a launch that (nearly always) ended before this one began -- the panel kernel waiting for B.  A launch begins with its caches
-// invalidated, so what the producer wrote back before it raised the counter is what the first loads see; the agent-scope
-// acquire is then only paid when the counter was NOT yet up at the first look.  (Paid always, by all 244 workgroups of the panel
-// kernel at once, it cost 15 us per sweep: every one of them an L2 write-back and invalidate.)
+// kFenceAlways = false: for a consumer whose producer is a launch that (nearly always) ended before this one began -- the panel
+// kernel waiting for B.  The full __threadfence (acquire + release: an L2 write-back and an invalidate by each of the 244
+// workgroups of the panel kernel at once, 15 us per sweep) is paid only when the counter was NOT yet up at the first look;
+// otherwise an acquire-only fence at agent scope, which invalidates and writes nothing back.  (Round 5 paid nothing at all on
+// that path and relied on the cache invalidate at the start of a launch: runtime behaviour, not a guarantee -- ADVICE r5.)
 template <bool kFenceAlways = true>
 __device__ __forceinline__ bool wait_for_counter(const unsigned int *counter, unsigned int need, int spin_limit, int32_t *status)
 {
@@ -386,6 +386,8 @@ __device__ __forceinline__ bool wait_for_counter(const unsigned int *counter, un
     }
     __syncthreads();
     if (kFenceAlways || ok == 2) __threadfence(); // (acquire for every thread's loads of what the counter announces)
+    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // counter already up at the first look: an acquire-ONLY fence -- it
+                                                            // invalidates, it does not write L2 back (the 15 us were __threadfence's release half)
     return ok != 0;
 }
 
@@ -429,17 +431,85 @@ __global__ __launch_bounds__(256) void k_dense_pivot(const double *__restrict__ 
 // (kSplit: two workgroups per 64-row block, 32 rows each -- 2 x 116 workgroups instead of 116 on 256 CUs; the panel product
 //  sits between the pivot inverse and the trailing update of every sweep, on the critical path)
 typedef double word16 __attribute__((ext_vector_type(2)));
-// kWords 16-byte loads of one thread, all in flight before the first is waited for (see stage_chunk for why this is assembly)
-template <int kWords> struct WordsInFlight {
-    word16 v[kWords];
-    __device__ __forceinline__ void issue(int q, const double *p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[q]) : "v"(p)); }
-    __device__ __forceinline__ void wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-};
-template <int kCount> struct DoublesInFlight {
-    double v[kCount];
-    __device__ __forceinline__ void issue(int q, const double *p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v[q]) : "v"(p)); }
-    __device__ __forceinline__ void wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-};
+// ---- load batches.  Every load of a batch AND the s_waitcnt that completes them are ONE asm statement, its outputs early-clobber:
+// for the compiler no output register exists before the wait, so it cannot copy, split or spill one while the load that fills it
+// is still in flight (the hardware does not interlock VMEM returns against such a move), and no output shares a register with
+// an address operand.  (Round 5 had one asm per load and the wait in a third: correct only as long as register allocation left
+// the outputs alone between them.)  Addresses: a uniform 64-bit base in SGPRs, one 32-bit byte offset per thread in a VGPR that
+// the statement advances by a uniform stride between the loads -- the q-th word of a thread lies q strides behind its first
+// in every batch of this file -- so a batch of sixteen 16-byte loads needs 16 + 4 operands (the limit is 30).
+// See stage_chunk for why these are assembly at all.
+#define FS_LDW(o, t, b) "global_load_dwordx4 %[" #o "], %[" #t "], %[" #b "]\n\t"
+#define FS_LDD(o, t, b) "global_load_dwordx2 %[" #o "], %[" #t "], %[" #b "]\n\t"
+#define FS_ADV(t, s) "v_add_u32 %[" #t "], %[" #s "], %[" #t "]\n\t"
+#define FS_B8_LOADS                                                                                                              \
+    FS_LDW(b0, bt, bb) FS_ADV(bt, bs) FS_LDW(b1, bt, bb) FS_ADV(bt, bs) FS_LDW(b2, bt, bb) FS_ADV(bt, bs) FS_LDW(b3, bt, bb)      \
+    FS_ADV(bt, bs) FS_LDW(b4, bt, bb) FS_ADV(bt, bs) FS_LDW(b5, bt, bb) FS_ADV(bt, bs) FS_LDW(b6, bt, bb) FS_ADV(bt, bs)          \
+    FS_LDW(b7, bt, bb)
+#define FS_B8_OUTS [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [b2] "=&v"(b[2]), [b3] "=&v"(b[3]), [b4] "=&v"(b[4]), [b5] "=&v"(b[5]), [b6] "=&v"(b[6]), [b7] "=&v"(b[7])
+
+// eight words of B^T and kC words of a tile's rows, all in flight together, then waited for
+template <int kC>
+__device__ __forceinline__ void load_b8_words_wait(word16 (&b)[8], word16 (&c)[kC], const double *bbase, uint32_t boff, uint32_t bstride,
+                                                   const double *cbase, uint32_t coff, uint32_t cstride)
+{
+    static_assert(kC == 2 || kC == 4, "batch sizes of k_dense_panels");
+    if constexpr (kC == 2)
+        asm volatile(FS_B8_LOADS FS_LDW(c0, ct, cb) FS_ADV(ct, cs) FS_LDW(c1, ct, cb) "s_waitcnt vmcnt(0)"
+                     : FS_B8_OUTS, [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [bt] "+v"(boff), [ct] "+v"(coff)
+                     : [bb] "s"(bbase), [cb] "s"(cbase), [bs] "s"(bstride), [cs] "s"(cstride)
+                     : "memory");
+    else
+        asm volatile(FS_B8_LOADS FS_LDW(c0, ct, cb) FS_ADV(ct, cs) FS_LDW(c1, ct, cb) FS_ADV(ct, cs) FS_LDW(c2, ct, cb) FS_ADV(ct, cs)
+                         FS_LDW(c3, ct, cb) "s_waitcnt vmcnt(0)"
+                     : FS_B8_OUTS, [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [c2] "=&v"(c[2]), [c3] "=&v"(c[3]), [bt] "+v"(boff), [ct] "+v"(coff)
+                     : [bb] "s"(bbase), [cb] "s"(cbase), [bs] "s"(bstride), [cs] "s"(cstride)
+                     : "memory");
+}
+// the same with kC single doubles of a transposed tile
+template <int kC>
+__device__ __forceinline__ void load_b8_doubles_wait(word16 (&b)[8], double (&c)[kC], const double *bbase, uint32_t boff, uint32_t bstride,
+                                                     const double *cbase, uint32_t coff, uint32_t cstride)
+{
+    static_assert(kC == 4 || kC == 8, "batch sizes of k_dense_panels");
+    if constexpr (kC == 4)
+        asm volatile(FS_B8_LOADS FS_LDD(c0, ct, cb) FS_ADV(ct, cs) FS_LDD(c1, ct, cb) FS_ADV(ct, cs) FS_LDD(c2, ct, cb) FS_ADV(ct, cs)
+                         FS_LDD(c3, ct, cb) "s_waitcnt vmcnt(0)"
+                     : FS_B8_OUTS, [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [c2] "=&v"(c[2]), [c3] "=&v"(c[3]), [bt] "+v"(boff), [ct] "+v"(coff)
+                     : [bb] "s"(bbase), [cb] "s"(cbase), [bs] "s"(bstride), [cs] "s"(cstride)
+                     : "memory");
+    else
+        asm volatile(FS_B8_LOADS FS_LDD(c0, ct, cb) FS_ADV(ct, cs) FS_LDD(c1, ct, cb) FS_ADV(ct, cs) FS_LDD(c2, ct, cb) FS_ADV(ct, cs)
+                         FS_LDD(c3, ct, cb) FS_ADV(ct, cs) FS_LDD(c4, ct, cb) FS_ADV(ct, cs) FS_LDD(c5, ct, cb) FS_ADV(ct, cs)
+                             FS_LDD(c6, ct, cb) FS_ADV(ct, cs) FS_LDD(c7, ct, cb) "s_waitcnt vmcnt(0)"
+                     : FS_B8_OUTS, [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [c2] "=&v"(c[2]), [c3] "=&v"(c[3]), [c4] "=&v"(c[4]), [c5] "=&v"(c[5]),
+                       [c6] "=&v"(c[6]), [c7] "=&v"(c[7]), [bt] "+v"(boff), [ct] "+v"(coff)
+                     : [bb] "s"(bbase), [cb] "s"(cbase), [bs] "s"(bstride), [cs] "s"(cstride)
+                     : "memory");
+}
+// kW words of each of two operands that share their offsets (the W and C panels of the trailing update)
+template <int kW>
+__device__ __forceinline__ void load_pairs_wait(word16 (&w)[kW], word16 (&c)[kW], const double *wbase, const double *cbase, uint32_t off,
+                                                uint32_t stride)
+{
+    static_assert(kW == 4 || kW == 8, "batch sizes of stage_chunk");
+#define FS_PAIR(q) FS_LDW(w##q, t, wb) FS_LDW(c##q, t, cb)
+    if constexpr (kW == 4)
+        asm volatile(FS_PAIR(0) FS_ADV(t, st) FS_PAIR(1) FS_ADV(t, st) FS_PAIR(2) FS_ADV(t, st) FS_PAIR(3) "s_waitcnt vmcnt(0)"
+                     : [w0] "=&v"(w[0]), [w1] "=&v"(w[1]), [w2] "=&v"(w[2]), [w3] "=&v"(w[3]), [c0] "=&v"(c[0]), [c1] "=&v"(c[1]),
+                       [c2] "=&v"(c[2]), [c3] "=&v"(c[3]), [t] "+v"(off)
+                     : [wb] "s"(wbase), [cb] "s"(cbase), [st] "s"(stride)
+                     : "memory");
+    else
+        asm volatile(FS_PAIR(0) FS_ADV(t, st) FS_PAIR(1) FS_ADV(t, st) FS_PAIR(2) FS_ADV(t, st) FS_PAIR(3) FS_ADV(t, st) FS_PAIR(4)
+                         FS_ADV(t, st) FS_PAIR(5) FS_ADV(t, st) FS_PAIR(6) FS_ADV(t, st) FS_PAIR(7) "s_waitcnt vmcnt(0)"
+                     : [w0] "=&v"(w[0]), [w1] "=&v"(w[1]), [w2] "=&v"(w[2]), [w3] "=&v"(w[3]), [w4] "=&v"(w[4]), [w5] "=&v"(w[5]),
+                       [w6] "=&v"(w[6]), [w7] "=&v"(w[7]), [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [c2] "=&v"(c[2]), [c3] "=&v"(c[3]),
+                       [c4] "=&v"(c[4]), [c5] "=&v"(c[5]), [c6] "=&v"(c[6]), [c7] "=&v"(c[7]), [t] "+v"(off)
+                     : [wb] "s"(wbase), [cb] "s"(cbase), [st] "s"(stride)
+                     : "memory");
+#undef FS_PAIR
+}
 
 // (ready != nullptr: B comes from the look-ahead's launch on the second stream, which raises *ready when it is complete)
 template <bool kSplit>
@@ -463,51 +533,44 @@ __global__ __launch_bounds__(256) void k_dense_panels(const double *D, int64_t l
     const bool below = i > 2 * K + 1;
     for (int ch = 0; ch < kSW / kHalf; ch++) { // columns [32 ch, 32 ch + 32) of C_i = K range of the product
         if (ch) __syncthreads();
-        // B^T[k][n] = B[n][k]: 128 rows x 16 words of 16 bytes, eight per thread, all in flight at once (as scalar loads in a loop
-        // they were sixteen round trips to memory per chunk -- the whole 31 us of this kernel)
+        // B^T[k][n] = B[n][k]: 128 rows x 16 words of 16 bytes, eight per thread, and the rows of C_i beside them -- ONE batch, all
+        // in flight at once (as scalar loads in a loop they were sixteen round trips to memory per chunk: the whole 31 us of
+        // this kernel).  Word q of a thread: e = tid + 256 q, row e / 16 = tid / 16 + 16 q, column 2 (tid % 16).
         constexpr int kBWords = kSW * (kHalf / 2) / 256;
-        WordsInFlight<kBWords> bw;
-#pragma unroll
-        for (int q = 0; q < kBWords; q++) {
-            const int e = tid + 256 * q, n = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));
-            bw.issue(q, B + n * kSW + kHalf * ch + k);
-        }
+        static_assert(kBWords == 8, "load_b8_*");
+        word16 bw[kBWords];
+        const double *bbase = B + kHalf * ch;
+        const uint32_t boff = (uint32_t)(((tid >> 4) * kSW + 2 * (tid & 15)) * 8), bstride = 16u * kSW * 8u;
         if (below) { // rows of the tile: 16 words per row
             constexpr int kCWords = kRows * (kHalf / 2) / 256;
-            WordsInFlight<kCWords> cw;
+            word16 cw[kCWords];
+            const double *cbase = D + ((int64_t)i * kNB + row0) * ld + (int64_t)2 * K * kNB + kHalf * ch;
+            load_b8_words_wait<kCWords>(bw, cw, bbase, boff, bstride, cbase, (uint32_t)(((int64_t)(tid >> 4) * ld + 2 * (tid & 15)) * 8),
+                                        (uint32_t)(16 * ld * 8));
 #pragma unroll
             for (int q = 0; q < kCWords; q++) {
                 const int e = tid + 256 * q, r = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));
-                cw.issue(q, D + ((int64_t)i * kNB + row0 + r) * ld + (int64_t)2 * K * kNB + kHalf * ch + k);
-            }
-            cw.wait();
-#pragma unroll
-            for (int q = 0; q < kCWords; q++) {
-                const int e = tid + 256 * q, r = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));
-                *reinterpret_cast<word16 *>(Cs + r * kLdh + k) = cw.v[q];
-                *reinterpret_cast<word16 *>(Cp + ((int64_t)i * kNB + row0 + r) * kSW + kHalf * ch + k) = cw.v[q];
+                *reinterpret_cast<word16 *>(Cs + r * kLdh + k) = cw[q];
+                *reinterpret_cast<word16 *>(Cp + ((int64_t)i * kNB + row0 + r) * kSW + kHalf * ch + k) = cw[q];
             }
         } else { // above the pivot block: the transposed tiles (2K, i), (2K+1, i), read along their rows (consecutive threads:
-                 // consecutive addresses), eight bytes at a time
+                 // consecutive addresses), eight bytes at a time: e = tid + 256 q, r = e % kRows, k = e / kRows = tid / kRows + (256 / kRows) q
             constexpr int kCount = kRows * kHalf / 256;
-            DoublesInFlight<kCount> cd;
+            double cd[kCount];
+            const double *cbase = D + ((int64_t)2 * K * kNB + kHalf * ch) * ld + (int64_t)i * kNB + row0;
+            load_b8_doubles_wait<kCount>(bw, cd, bbase, boff, bstride, cbase, (uint32_t)(((int64_t)(tid / kRows) * ld + tid % kRows) * 8),
+                                         (uint32_t)((256 / kRows) * ld * 8));
 #pragma unroll
             for (int q = 0; q < kCount; q++) {
                 const int e = tid + 256 * q, r = e % kRows, k = e / kRows;
-                cd.issue(q, D + ((int64_t)2 * K * kNB + kHalf * ch + k) * ld + (int64_t)i * kNB + row0 + r);
-            }
-            cd.wait();
-#pragma unroll
-            for (int q = 0; q < kCount; q++) {
-                const int e = tid + 256 * q, r = e % kRows, k = e / kRows;
-                Cs[r * kLdh + k] = cd.v[q];
-                Cp[((int64_t)i * kNB + row0 + r) * kSW + kHalf * ch + k] = cd.v[q];
+                Cs[r * kLdh + k] = cd[q];
+                Cp[((int64_t)i * kNB + row0 + r) * kSW + kHalf * ch + k] = cd[q];
             }
         }
 #pragma unroll
         for (int q = 0; q < kBWords; q++) {
             const int e = tid + 256 * q, n = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));
-            *reinterpret_cast<word16 *>(Bs + n * kLdh + k) = bw.v[q];
+            *reinterpret_cast<word16 *>(Bs + n * kLdh + k) = bw[q];
         }
         __syncthreads();
 #pragma unroll
@@ -567,8 +630,8 @@ constexpr int kUpdLds = 2 * kNB * kLdh > kNB * kLdp ? 2 * kNB * kLdh : kNB * kLd
 // of registers, sched_group_barrier, amdgpu_waves_per_eu) the compiler's scheduler turns them into load, wait, LDS write, eight
 // times over -- eight memory round trips per chunk instead of one.  One box, 7776 dofs, alternating: 13.5 ms (loop) / 13.2 ms
 // (unrolled, compiler's order) / 12.1 ms (this) for the whole inverse.
-// (The compiler does not count these loads in its own s_waitcnt bookkeeping; they are waited for, all of them, before this function
-//  returns, and loads the compiler issued earlier only complete earlier than it assumes.)
+// (The compiler does not count these loads in its own s_waitcnt bookkeeping; they are waited for, all of them, inside the one asm
+//  statement that issues them -- load_pairs_wait above -- and loads the compiler issued earlier only complete earlier than it assumes.)
 // MEASURED besides (round 5, per-phase clocks inside the workgroups): a tile workgroup lives 24 us, of which its four matrix
 // phases are 10.6 (2.6 each: 0.85 alone, the rest is the pipe shared with the three other workgroups of the CU), staging 7.2,
 // barriers 2.7, the tile's own values 3.0 before and 0.75 behind.  Built, timed and dropped: global_load_lds_dword straight into the
@@ -583,13 +646,8 @@ __device__ __forceinline__ void stage_chunk(double *Ws, double *Cs, const double
 {
     constexpr int kWords = kRows * (kHalf / 2) / 256; // per thread and operand
     word16 wv[kWords], cv[kWords];
-#pragma unroll
-    for (int q = 0; q < kWords; q++) {
-        const int e = tid + 256 * q, r = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wv[q]) : "v"(wsrc + r * kSW + h * kHalf + k));
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cv[q]) : "v"(csrc + r * kSW + h * kHalf + k));
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // word q of a thread: e = tid + 256 q, row e / 16 = tid / 16 + 16 q, column 2 (tid % 16) -- 16 rows of the panel further per q
+    load_pairs_wait<kWords>(wv, cv, wsrc + h * kHalf, csrc + h * kHalf, (uint32_t)(((tid >> 4) * kSW + 2 * (tid & 15)) * 8), 16u * kSW * 8u);
 #pragma unroll
     for (int q = 0; q < kWords; q++) {
         const int e = tid + 256 * q, r = e / (kHalf / 2), k = 2 * (e % (kHalf / 2));

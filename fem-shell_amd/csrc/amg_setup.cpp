@@ -272,7 +272,7 @@ static const Bsr *graph_for_aggregation(const Bsr &A, int keep, Bsr *store)
             for (int k = 0; k < keep && k < (int)cand.size(); k++) {
                 const int32_t j = cand[(size_t)k].second;
                 const int64_t q = std::lower_bound(A.col.begin() + b, A.col.begin() + e, j) - A.col.begin();
-                kept[(size_t)q] = 1;
+                if (q < e && A.col[q] == j) kept[(size_t)q] = 1; // (always, on rows of ascending columns -- what every caller hands over)
             }
         }
     }, 1 << 12);

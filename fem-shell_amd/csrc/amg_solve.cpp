@@ -725,6 +725,14 @@ int fuse_mask()
     return e ? atoi(e) : 3;
 }
 
+// FEMSHELL_AMG_K_LEVELS: the deepest level whose cycle is wrapped into the K cycle's two Krylov steps (levels 1 ... that one; a
+// level below it is visited once per visit of its parent, as in a V cycle).  Default: every level above the coarsest.
+int k_cycle_levels()
+{
+    const char *e = getenv("FEMSHELL_AMG_K_LEVELS");
+    return e && *e ? atoi(e) : 1 << 20;
+}
+
 struct Cycle {
     femshell_ctx *c;
     Amg &H;
@@ -732,6 +740,7 @@ struct Cycle {
     hipStream_t st;
     int rc = FEMSHELL_OK;
     const int fuse = fuse_mask();
+    const int k_levels = k_cycle_levels();
     // level 0: the caller's kernel (k_pcg_update_start) has taken the first step of the pre-smoothing already -- d in L.d, x = d
     bool pre_started0 = false;
 
@@ -981,7 +990,7 @@ struct Cycle {
             launch_spmv(L.R.dm, rf, N.b.p, nullptr, gate, st);
         }
         const bool next_is_coarsest = (size_t)l + 2 == H.levels.size();
-        if (H.opt.cycle == FEMSHELL_CYCLE_K && !next_is_coarsest) kcycle(l + 1);
+        if (H.opt.cycle == FEMSHELL_CYCLE_K && !next_is_coarsest && l + 1 <= k_levels) kcycle(l + 1);
         else cycle(l + 1, N.b.p, N.x.p);
         if (N.dist) halo(l + 1, N.x.p);
         if (increments && post_increment()) {
@@ -1159,6 +1168,7 @@ int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, do
     const bool adaptive_pass = !(getenv("FEMSHELL_REFINE_ADAPTIVE") && atoi(getenv("FEMSHELL_REFINE_ADAPTIVE")) == 0);
     CgVectors v = v0;
     CgScalars hs{};
+    double pass_host[3] = {0.0, 0.0, 0.0}; // source of an asynchronous copy below: lives until the function's next synchronisation
     int32_t it = 0;
     c->refine = femshell_ctx::RefineStats();
     double pass_rhs_rr = 0.0; // ||rhs||^2 of the running refinement pass
@@ -1197,8 +1207,10 @@ int cg_amg(femshell_ctx *c, const CgVectors &v0, double rtol, int32_t max_it, do
                 double xx = 0.0;
                 rc = squared_norm(c, c->xacc.p, n6, &xx);
                 if (rc) return rc;
-                const double pass[3] = {xx, 0.0, rtol};
-                FS_HIP(hipMemcpyAsync(reinterpret_cast<char *>(v.s) + offsetof(CgScalars, pass_xx), pass, sizeof pass, hipMemcpyHostToDevice, st));
+                pass_host[0] = xx;
+                pass_host[1] = 0.0;
+                pass_host[2] = rtol;
+                FS_HIP(hipMemcpyAsync(reinterpret_cast<char *>(v.s) + offsetof(CgScalars, pass_xx), pass_host, sizeof pass_host, hipMemcpyHostToDevice, st));
             }
             launch_pcg_init(m, v, st); // x = 0, r = rhs, partial sums of r.r
             // (rtol = 0: the pass stops on the relative drop kRefineDrop of its own right-hand side alone -- the residual

@@ -1,6 +1,7 @@
 // plan_api.cpp -- host-only inspection of the symbolic phase (include/femshell_plan.h); touches no GPU state.
 #include "femshell_plan.h"
 
+#include <climits>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -128,12 +129,26 @@ struct femshell_amg_coarsening {
 };
 
 namespace {
-void to_bsr(int32_t n, const int32_t *rowptr, const int32_t *colidx, const double *vals, Bsr *A)
+// false: the pattern is not what every routine behind these entry points assumes -- row pointers ascending from 0, the columns
+// of a row strictly ascending and inside [0, n_cols) (merge intersections and binary searches walk them: graph_for_aggregation)
+bool pattern_ok(int32_t n, const int32_t *rowptr, const int32_t *colidx, int32_t n_cols)
 {
+    if (rowptr[0] != 0) return false;
+    for (int32_t i = 0; i < n; i++) {
+        if (rowptr[i + 1] < rowptr[i]) return false;
+        for (int32_t q = rowptr[i]; q < rowptr[i + 1]; q++)
+            if (colidx[q] < 0 || (n_cols != INT32_MAX && colidx[q] >= n_cols) || (q > rowptr[i] && colidx[q] <= colidx[q - 1])) return false;
+    }
+    return true;
+}
+bool to_bsr(int32_t n, const int32_t *rowptr, const int32_t *colidx, const double *vals, Bsr *A, int32_t n_cols = -1)
+{
+    if (!pattern_ok(n, rowptr, colidx, n_cols < 0 ? n : n_cols)) return false;
     A->nr = A->nc = n;
     A->ptr.assign(rowptr, rowptr + n + 1);
     A->col.assign(colidx, colidx + rowptr[n]);
     A->val.assign(vals, vals + 36ll * rowptr[n]);
+    return true;
 }
 } // namespace
 
@@ -152,7 +167,8 @@ int femshell_amg_host_coarsen(int32_t n_nodes, const int32_t *rowptr, const int3
     if (n_nodes <= 0 || !rowptr || !colidx || !vals || !B || !out || !(lambda_max > 0.0))
         return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_host_coarsen: invalid argument");
     Bsr A;
-    to_bsr(n_nodes, rowptr, colidx, vals, &A);
+    if (!to_bsr(n_nodes, rowptr, colidx, vals, &A))
+        return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_host_coarsen: rows of the block CSR pattern must hold strictly ascending columns in [0, n_nodes)");
     femshell_amg_coarsening *h = new femshell_amg_coarsening();
     const int32_t na = aggregate_nodes(A, &h->agg);
     std::vector<double> Bv(B, B + 36ll * n_nodes), Q, Dinv;
@@ -170,6 +186,10 @@ int32_t femshell_amg_host_aggregate(int32_t n_nodes, const int32_t *rowptr, cons
 {
     if (n_nodes <= 0 || !rowptr || !colidx || !agg_out) {
         set_err(FEMSHELL_ERR_INVALID, "femshell_amg_host_aggregate: invalid argument");
+        return -1;
+    }
+    if (!pattern_ok(n_nodes, rowptr, colidx, n_nodes)) {
+        set_err(FEMSHELL_ERR_INVALID, "femshell_amg_host_aggregate: rows of the graph must hold strictly ascending columns in [0, n_nodes)");
         return -1;
     }
     Bsr A;
@@ -221,7 +241,8 @@ int femshell_amg_host_dense_inverse(int32_t n_nodes, const int32_t *rowptr, cons
     if (n_nodes <= 0 || !rowptr || !colidx || !vals || !inv_out)
         return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_host_dense_inverse: invalid argument");
     Bsr A;
-    to_bsr(n_nodes, rowptr, colidx, vals, &A);
+    if (!to_bsr(n_nodes, rowptr, colidx, vals, &A))
+        return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_host_dense_inverse: rows of the block CSR pattern must hold strictly ascending columns in [0, n_nodes)");
     std::vector<double> inv;
     if (!dense_inverse(A, &inv)) return set_err(FEMSHELL_ERR_BREAKDOWN, "femshell_amg_host_dense_inverse: matrix is not positive definite");
     std::memcpy(inv_out, inv.data(), inv.size() * sizeof(double));
@@ -233,7 +254,7 @@ int64_t femshell_amg_host_pack(int32_t n_rows, const int32_t *rowptr, const int3
 {
     if (n_rows <= 0 || !rowptr || !colidx || !vals) return -1;
     Bsr A;
-    to_bsr(n_rows, rowptr, colidx, vals, &A);
+    if (!to_bsr(n_rows, rowptr, colidx, vals, &A, INT32_MAX)) return -1; // (rectangular operators: any column >= 0, ascending per row)
     SlicedEll S;
     pack_sliced_ell(A, diag_first != 0, &S);
     if (slice_width) std::memcpy(slice_width, S.slice_width.data(), S.slice_width.size() * sizeof(int32_t));
@@ -249,7 +270,7 @@ int64_t femshell_amg_host_pack_sym(int32_t n_rows, const int32_t *rowptr, const 
 {
     if (n_rows <= 0 || !rowptr || !colidx || !vals) return -1;
     Bsr A;
-    to_bsr(n_rows, rowptr, colidx, vals, &A);
+    if (!to_bsr(n_rows, rowptr, colidx, vals, &A, INT32_MAX)) return -1; // (rectangular operators: any column >= 0, ascending per row)
     SlicedEllSym S;
     pack_sliced_ell_sym(A, &S);
     if (slice_width) std::memcpy(slice_width, S.slice_width.data(), S.slice_width.size() * sizeof(int32_t));
