@@ -725,12 +725,14 @@ int fuse_mask()
     return e ? atoi(e) : 3;
 }
 
-// FEMSHELL_AMG_K_LEVELS: the deepest level whose cycle is wrapped into the K cycle's two Krylov steps (levels 1 ... that one; a
-// level below it is visited once per visit of its parent, as in a V cycle).  Default: every level above the coarsest.
-int k_cycle_levels()
+// FEMSHELL_AMG_K_MASK (experiments; round 6): bit l set = the cycle of level l is wrapped into the K cycle's two Krylov steps; a
+// level whose bit is clear is visited once per visit of its parent, as in a V cycle.  Default: every level above the coarsest.
+// MEASURED (profiles/r06_kcycle_levels.txt): the Krylov steps cannot be taken off any level -- 4M-triangle panel 100 -> 196
+// iterations with the K cycle on level 1 only.
+int k_cycle_mask()
 {
-    const char *e = getenv("FEMSHELL_AMG_K_LEVELS");
-    return e && *e ? atoi(e) : 1 << 20;
+    const char *e = getenv("FEMSHELL_AMG_K_MASK");
+    return e && *e ? atoi(e) : ~0;
 }
 
 struct Cycle {
@@ -740,7 +742,7 @@ struct Cycle {
     hipStream_t st;
     int rc = FEMSHELL_OK;
     const int fuse = fuse_mask();
-    const int k_levels = k_cycle_levels();
+    const int k_mask = k_cycle_mask();
     // level 0: the caller's kernel (k_pcg_update_start) has taken the first step of the pre-smoothing already -- d in L.d, x = d
     bool pre_started0 = false;
 
@@ -990,7 +992,7 @@ struct Cycle {
             launch_spmv(L.R.dm, rf, N.b.p, nullptr, gate, st);
         }
         const bool next_is_coarsest = (size_t)l + 2 == H.levels.size();
-        if (H.opt.cycle == FEMSHELL_CYCLE_K && !next_is_coarsest && l + 1 <= k_levels) kcycle(l + 1);
+        if (H.opt.cycle == FEMSHELL_CYCLE_K && !next_is_coarsest && ((k_mask >> (l + 1)) & 1)) kcycle(l + 1);
         else cycle(l + 1, N.b.p, N.x.p);
         if (N.dist) halo(l + 1, N.x.p);
         if (increments && post_increment()) {
