@@ -247,6 +247,7 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     // ---- aggregation on the graph
     Bsr G;
     graph_of_pattern(pat, &G);
+    lap("  graph of the level");
     std::vector<int32_t> agg;
     // When the library renumbered the nodes itself (FEMSHELL_REORDER_*: Morton, Cuthill-McKee) the greedy passes of the
     // FINEST level visit the nodes in the caller's order: the index order of a space-filling curve fragments the aggregates
@@ -255,7 +256,7 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     // numbering, whatever the internal one is
     const bool finest_renumbered = &Adev == &c->dm && !c->iperm.empty() && (int32_t)c->iperm.size() == n;
     const int32_t na = aggregate_nodes(G, &agg, finest_renumbered ? &c->iperm : nullptr);
-    lap("graph + aggregation");
+    lap("  aggregation");
     // tentative prolongator on the device: QR of every aggregate's rows of B, one wave each (k_amg_tentative_qr); the host
     // only groups the nodes by aggregate
     DevBuf<double> d_Q;
@@ -312,6 +313,7 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
             for (int64_t a = a0; a < a1; a++) std::copy_n(&tmp_all[(size_t)G.ptr[a]], cnt[a], &pcol[(size_t)pptr[a]]);
         });
     }
+    lap("  pattern of P");
     auto p_index = [&](int32_t row, int32_t J) -> int {
         const int32_t *b = &pcol[(size_t)pptr[row]], *e = &pcol[(size_t)pptr[row + 1]];
         return (int)(std::lower_bound(b, e, J) - b);
@@ -335,6 +337,7 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
                 }
         }
     });
+    lap("  slots of P fed by the blocks of A");
     // A P: per fine row the union of the P rows of its neighbours
     std::vector<int64_t> aptr;
     RawVec<int32_t> acol;
@@ -346,6 +349,7 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
         std::sort(out.begin(), out.end());
         out.erase(std::unique(out.begin(), out.end()), out.end());
     }, &aptr, &acol);
+    lap("  pattern of A P");
     // R = P^T as lists: per aggregate the fine rows (ascending) and the slot of the aggregate in their P row
     std::vector<int64_t> rptr((size_t)na + 1, 0);
     RawVec<int32_t> rrow((size_t)pptr[n]);
@@ -402,6 +406,7 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
             }
         }, 1);
     }
+    lap("  lists of R");
     // A_c: per aggregate the union of the A P rows of its fine rows (symmetric storage: columns >= the row only; the
     // coarse operator is symmetric, the cycle applies the stored blocks to both rows)
     const bool sym_coarse = coarse_symmetric_storage(na);
@@ -416,6 +421,7 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
         out.erase(std::unique(out.begin(), out.end()), out.end());
         if (sym_coarse) out.erase(out.begin(), std::lower_bound(out.begin(), out.end(), I)); // diagonal and upper blocks
     }, &cptr, &ccol);
+    lap("  pattern of Ac");
     EllPattern eP, eAP, eR, eAc;
     if (!pack_pattern(n, pptr.data(), pcol.data(), false, &eP) || !pack_pattern(n, aptr.data(), acol.data(), false, &eAP) ||
         !pack_pattern(na, cptr.data(), ccol.data(), true, &eAc))
@@ -423,7 +429,7 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     // (R's columns are the fine rows, already ascending per aggregate)
     if (!pack_pattern(na, rptr.data(), rrow.data(), false, &eR))
         return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: an aggregate is seen by more than 255 fine rows");
-    lap("patterns of P, AP, R, Ac");
+    lap("  sliced layouts of the four");
 
     // ---- values on the device
     DevBuf<int32_t> d_agg, d_rrow;

@@ -877,14 +877,20 @@ int amg_setup_dist(femshell_ctx *c)
         if (l > 0) {
             FS_HIP(L.minv.alloc((size_t)L.A.dm.n_slices * 21 * kSliceNodes));
             L.A.dm.minv = L.minv.p;
-            L.A.dm.status = c->status.p;
+            L.A.dm.status = c->status_word;
             launch_block_jacobi(L.A.dm, st);
             FS_HIP(hipGetLastError());
-            FS_HIP(hipMemcpyAsync(c->status_host, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            FS_HIP(hipStreamSynchronize(st));
-            const bool bad = *c->status_host != 0; // (seen by the rank that owns the block only: the ranks agree below)
+            int32_t status_now = 0;
+            {
+                const int rcs = fetch_status_word(c, st, &status_now);
+                if (rcs) return rcs;
+            }
+            const bool bad = status_now != 0; // (seen by the rank that owns the block only: the ranks agree below)
             if (bad) {
-                FS_HIP(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), st));
+                {
+                    const int rcc = clear_status_word(c, st);
+                    if (rcc) return rcc;
+                }
                 (void)set_err(FEMSHELL_ERR_BREAKDOWN, "multigrid setup: a diagonal block of coarse level " + std::to_string(l) +
                                                           " is not positive definite");
             }

@@ -24,13 +24,7 @@ void parallel_chunks(int64_t n, const std::function<void(int64_t, int64_t)> &f, 
         f(0, n);
         return;
     }
-    std::vector<std::thread> th;
-    th.reserve((size_t)nt);
-    for (int64_t t = 0; t < nt; t++) {
-        const int64_t b = n * t / nt, e = n * (t + 1) / nt;
-        th.emplace_back([&f, b, e] { f(b, e); });
-    }
-    for (auto &t : th) t.join();
+    run_on_host_threads((int)nt, [&f, n, nt](int t) { f(n * t / nt, n * (t + 1) / nt); });
 }
 
 namespace {
@@ -314,7 +308,83 @@ static int aggregation_keep()
     return e && *e ? atoi(e) : 12;
 }
 
+// FEMSHELL_AMG_AGG_CHUNK: rows per chunk of the chunked aggregation below (default 0: the whole graph in one piece)
+static int64_t aggregation_chunk()
+{
+    const char *e = getenv("FEMSHELL_AMG_AGG_CHUNK"); // (read per setup: the tests switch it inside one process)
+    return e && *e ? atoll(e) : 0;
+}
+
+static int32_t aggregate_piece(const Bsr &Afull, std::vector<int32_t> *aggout, const std::vector<int32_t> *visit);
+
+// The greedy passes are sequential sweeps on one host thread.  MEASURED AND NOT ADOPTED (round 6, profiles/r06_chunked_aggregation.txt):
+// cut into pieces of 131072 rows and aggregated on sixteen threads the passes of a 4M-triangle mesh take 3 ms instead of 7 -- the
+// lap "graph + aggregation" of round 5 was mostly the graph -- and the seams, where the tiling of a structured mesh starts anew,
+// cost iterations: panel 100 -> 106, pinched cylinder 83 -> 107, flap 37 -> 40.  Off by default (FEMSHELL_AMG_AGG_CHUNK=0); with
+// a chunk set, graphs of more than one and a half chunks are cut into pieces of about `chunk` consecutive rows (whole
+// slices of 32; the same boundaries as a row partition over that many ranks: partition_rows), every piece is aggregated on its
+// own -- without the edges that leave it, exactly as the ranks of a row-partitioned level aggregate theirs (amg_dist.cpp) -- on a
+// host thread of its own, and the aggregates are numbered piece by piece.  The pieces depend on the row count alone, never on the
+// number of threads.  Restated by oracle/amg_oracle.py aggregate (aggregate_by_rank over chunk_bounds).
 int32_t aggregate_nodes(const Bsr &Afull, std::vector<int32_t> *aggout, const std::vector<int32_t> *visit)
+{
+    const int64_t chunk = aggregation_chunk();
+    const int32_t n = Afull.nr;
+    if (chunk <= 0 || (int64_t)n <= chunk + chunk / 2) return aggregate_piece(Afull, aggout, visit);
+    const int nc = (int)(((int64_t)n + chunk - 1) / chunk);
+    std::vector<int32_t> bound((size_t)nc + 1);
+    for (int k = 0; k <= nc; k++) {
+        int32_t b, e;
+        partition_rows(n, nc, k < nc ? k : nc - 1, &b, &e);
+        bound[(size_t)k] = k < nc ? b : e;
+    }
+    // the visiting order of a piece: the caller's order restricted to it
+    std::vector<std::vector<int32_t>> vis;
+    const bool have_visit = visit != nullptr && (int32_t)visit->size() == n;
+    if (have_visit) {
+        vis.resize((size_t)nc);
+        for (int k = 0; k < nc; k++) vis[(size_t)k].reserve((size_t)(bound[(size_t)k + 1] - bound[(size_t)k]));
+        std::vector<int32_t> piece_of_slice(((size_t)n + kSliceNodes - 1) / kSliceNodes);
+        for (int k = 0; k < nc; k++)
+            for (int32_t sl = bound[(size_t)k] / kSliceNodes; sl < (bound[(size_t)k + 1] + kSliceNodes - 1) / kSliceNodes; sl++) piece_of_slice[(size_t)sl] = k;
+        for (int32_t v : *visit) {
+            const int k = piece_of_slice[(size_t)(v / kSliceNodes)];
+            vis[(size_t)k].push_back(v - bound[(size_t)k]);
+        }
+    }
+    std::vector<std::vector<int32_t>> part((size_t)nc);
+    std::vector<int32_t> count((size_t)nc, 0);
+    parallel_chunks(nc, [&](int64_t k0, int64_t k1) {
+        for (int64_t k = k0; k < k1; k++) {
+            const int32_t b = bound[(size_t)k], e = bound[(size_t)k + 1];
+            Bsr S;
+            S.nr = S.nc = e - b;
+            S.ptr.assign((size_t)(e - b) + 1, 0);
+            S.col.reserve((size_t)(Afull.ptr[e] - Afull.ptr[b]));
+            for (int32_t i = b; i < e; i++) {
+                for (int64_t q = Afull.ptr[i]; q < Afull.ptr[(size_t)i + 1]; q++) {
+                    const int32_t j = Afull.col[q];
+                    if (j >= b && j < e) S.col.push_back(j - b);
+                }
+                S.ptr[(size_t)(i - b) + 1] = (int64_t)S.col.size();
+            }
+            count[(size_t)k] = aggregate_piece(S, &part[(size_t)k], have_visit ? &vis[(size_t)k] : nullptr);
+        }
+    }, 1);
+    std::vector<int32_t> first((size_t)nc + 1, 0);
+    for (int k = 0; k < nc; k++) first[(size_t)k + 1] = first[(size_t)k] + count[(size_t)k];
+    aggout->resize((size_t)n);
+    parallel_chunks(nc, [&](int64_t k0, int64_t k1) {
+        for (int64_t k = k0; k < k1; k++) {
+            const int32_t b = bound[(size_t)k], off = first[(size_t)k];
+            const std::vector<int32_t> &a = part[(size_t)k];
+            for (size_t i = 0; i < a.size(); i++) (*aggout)[(size_t)b + i] = a[i] + off;
+        }
+    }, 1);
+    return first[(size_t)nc];
+}
+
+static int32_t aggregate_piece(const Bsr &Afull, std::vector<int32_t> *aggout, const std::vector<int32_t> *visit)
 {
     Bsr filtered;
     const Bsr &A = *graph_for_aggregation(Afull, aggregation_keep(), &filtered);

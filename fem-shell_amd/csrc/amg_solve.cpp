@@ -358,8 +358,9 @@ int amg_setup(femshell_ctx *c)
         H.levels.emplace_back(new AmgLevel());
         AmgLevel &L1 = *H.levels.back();
         std::vector<double> Bc;
+        lap("node normals", 0);
         pattern_of_plan(pl, &L0.pattern);
-        lap("node normals, pattern of K", 0);
+        lap("pattern of K", 0);
         {
             // the near-null space of the finest level is generated from the mesh in HBM (never stored: n x 36 doubles)
             NearNullSrc src;
@@ -457,13 +458,19 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
             }
             FS_HIP(L.minv.alloc((size_t)L.A.dm.n_slices * 21 * kSliceNodes));
             L.A.dm.minv = L.minv.p;
-            L.A.dm.status = c->status.p;
+            L.A.dm.status = c->status_word;
             launch_block_jacobi(L.A.dm, st);
             FS_HIP(hipGetLastError());
-            FS_HIP(hipMemcpyAsync(c->status_host, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            FS_HIP(hipStreamSynchronize(st));
-            if (*c->status_host != 0) {
-                FS_HIP(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), st));
+            int32_t status_now = 0;
+            {
+                const int rcs = fetch_status_word(c, st, &status_now);
+                if (rcs) return rcs;
+            }
+            if (status_now != 0) {
+                {
+                    const int rcc = clear_status_word(c, st);
+                    if (rcc) return rcc;
+                }
                 return set_err(FEMSHELL_ERR_BREAKDOWN, "multigrid setup: a diagonal block of coarse level " + std::to_string(l) +
                                                            " is not positive definite");
             }

@@ -68,16 +68,19 @@ int interpret_status(femshell_ctx *c, int32_t st, const char *what);
 
 int check_status(femshell_ctx *c, const char *what)
 {
-    FS_HIP(hipMemcpyAsync(c->status_host, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (!c->status_mapped) FS_HIP(hipMemcpyAsync(c->status_host, c->status_word, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     FS_HIP(hipStreamSynchronize(c->stream));
-    return interpret_status(c, *c->status_host, what);
+    return interpret_status(c, *(volatile int32_t *)c->status_host, what);
 }
 
 // the device status word of this rank as an error code + message (and the word cleared for the next launch)
 int interpret_status(femshell_ctx *c, int32_t st, const char *what)
 {
     if (st == 0) return FEMSHELL_OK;
-    FS_HIP(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), c->stream));
+    {
+        const int rcc = clear_status_word(c, c->stream);
+        if (rcc) return rcc;
+    }
     char buf[160];
     if (st > 0) {
         const Plan &p = c->plan;
@@ -145,10 +148,10 @@ int check_and_agree(femshell_ctx *c, const char *what)
 {
     if (!c->comm.active()) return check_status(c, what);
     FS_HIP(c->agree.alloc(2));
-    launch_status_flags(c->status.p, c->agree.p, c->stream);
+    launch_status_flags(c->status_word, c->agree.p, c->stream);
     std::string e;
     if (!comm_allreduce_sum(c->comm, c->agree.p, 2, c->stream, &e)) return set_err(FEMSHELL_ERR_COMM, e);
-    FS_HIP(hipMemcpyAsync(c->status_host, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (!c->status_mapped) FS_HIP(hipMemcpyAsync(c->status_host, c->status_word, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     FS_HIP(hipMemcpyAsync(c->agree_host, c->agree.p, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     FS_HIP(hipStreamSynchronize(c->stream));
     const int local_rc = interpret_status(c, *c->status_host, what);
@@ -234,18 +237,26 @@ int do_assemble(femshell_ctx *c, bool wait = true)
         rc = finish_pending_assembly(c);
         if (rc) return rc;
     }
-    FS_HIP(hipEventRecord(c->ev0, c->stream));
+    // (the event pair costs the synchronous call its two records: without it assemble_seconds is the host's clock around launch
+    //  and synchronisation; an enqueued assembly always carries the pair -- nobody else could time it)
+    const bool events = c->asm_events || !wait;
+    const auto t_host = std::chrono::steady_clock::now();
+    if (events) FS_HIP(hipEventRecord(c->ev0, c->stream));
     c->dm.rhs_loads = c->loads.p;
     c->dm.rhs_F = c->F.p;
     launch_assemble(c->dm, c->mc, c->stream); // K and F (k_rhs alone serves changes of the loads)
-    FS_HIP(hipEventRecord(c->ev1, c->stream));
+    if (events) FS_HIP(hipEventRecord(c->ev1, c->stream));
     FS_HIP(hipGetLastError());
     if (wait) {
         rc = check_and_agree(c, "femshell_assemble");
         if (rc) return rc;
-        float ms = 0.f;
-        FS_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        c->last_assemble_s = 1e-3 * ms;
+        if (events) {
+            float ms = 0.f;
+            FS_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+            c->last_assemble_s = 1e-3 * ms;
+        } else {
+            c->last_assemble_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_host).count();
+        }
     } else {
         c->assembly_pending = true; // (a failed element leaves its mark in the status word until someone looks)
     }
@@ -287,6 +298,25 @@ double wall_s()
 }
 
 } // namespace
+
+int clear_status_word(femshell_ctx *c, hipStream_t st)
+{
+    if (c->status_word == nullptr) return FEMSHELL_OK;
+    if (c->status_mapped) {
+        FS_HIP(hipStreamSynchronize(st));
+        *(volatile int32_t *)c->status_host = 0;
+    } else {
+        FS_HIP(hipMemsetAsync(c->status_word, 0, sizeof(int32_t), st));
+    }
+    return FEMSHELL_OK;
+}
+int fetch_status_word(femshell_ctx *c, hipStream_t st, int32_t *out)
+{
+    if (!c->status_mapped) FS_HIP(hipMemcpyAsync(c->status_host, c->status_word, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    FS_HIP(hipStreamSynchronize(st));
+    *out = *(volatile int32_t *)c->status_host;
+    return FEMSHELL_OK;
+}
 
 namespace femshell {
 
@@ -415,8 +445,22 @@ int femshell_create(const femshell_config *cfg, femshell_ctx **out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    {
+        const char *sm = getenv("FEMSHELL_STATUS_MAPPED"), *ae = getenv("FEMSHELL_ASM_EVENTS");
+        c->status_mapped = !(sm && atoi(sm) == 0);
+        c->asm_events = !(ae && atoi(ae) == 0);
+    }
     if (e == hipSuccess) e = c->status.alloc(1);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->status_host), sizeof(int32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->status_host), sizeof(int32_t), c->status_mapped ? hipHostMallocMapped : hipHostMallocDefault);
+    if (e == hipSuccess) {
+        *c->status_host = 0;
+        c->status_word = c->status.p;
+        if (c->status_mapped) {
+            void *dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, c->status_host, 0) == hipSuccess && dp != nullptr) c->status_word = static_cast<int32_t *>(dp);
+            else c->status_mapped = false;
+        }
+    }
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->agree_host), 2 * sizeof(double), hipHostMallocDefault);
     if (e == hipSuccess) e = c->status.zero(c->stream);
     if (e == hipSuccess) e = c->scal.alloc(1);
@@ -577,7 +621,10 @@ int femshell_set_mesh(femshell_ctx *c, int32_t n_nodes, const double *xyz, int32
         // an assembly of the previous mesh whose status nobody asked for: its mark in the device status word (a degenerate
         // element of the OLD mesh) must not surface as a failure of the first assembly on the new one
         c->assembly_pending = false;
-        if (c->status.p) FS_HIP(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), c->stream));
+        {
+            const int rcc = clear_status_word(c, c->stream);
+            if (rcc) return rcc;
+        }
     }
     // a failure that only this rank sees (its slices exceed the LDS staging, one of its nodes has too many neighbours, a
     // HIP allocation failed) must reach the others: they would wait in the next collective forever
@@ -738,7 +785,7 @@ static int set_mesh_on_this_rank(femshell_ctx *c, int32_t n_nodes, const double 
     c->dm.max_loc = local_products ? p.max_loc : 0;
     c->dm.tbuf = c->tbuf.p;
     c->dm.minv = c->minv.p;
-    c->dm.status = c->status.p;
+    c->dm.status = c->status_word;
     FS_HIP(c->partials.alloc(4 * (size_t)slice_grid(c->dm))); // r.z | r.r | the SpMV's dot (up to 2 x grid when split)
     // halo lists
     c->send_offsets.clear();

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_assemble(DeviceMatrix m,
                 }
                 ok = quad4_record(X, mc, rec);
             }
-            if (!ok) atomicCAS(m.status, 0, e0 + i + 1);
+            if (!ok) report_status(m.status, e0 + i + 1);
             double2 *dst = reinterpret_cast<double2 *>(lds_rec + (size_t)i * kRec);
 #pragma unroll
             for (int q = 0; q < kRec / 2; q++) dst[q] = make_double2(rec[2 * q], rec[2 * q + 1]);
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
                     double lean[kRec];
                     const bool ok = record_of(X[p], is_quad[p], lean);
                     const int li = r0 + 64 * p + lane;
-                    if (!ok) atomicCAS(m.status, 0, ra.e0 + li + 1);
+                    if (!ok) report_status(m.status, ra.e0 + li + 1);
                     write_lean(buf, li, lean);
                 }
                 // (for every slot, needed by the next iteration or not: loads under a condition cost the wave's memory
@@ -592,10 +592,10 @@ __global__ __launch_bounds__(256, 2) void k_assemble_pipe(DeviceMatrix m, MatCon
                 const bool ok = record_of(X[kPipeRecPasses - 1], is_quad[kPipeRecPasses - 1], held);
                 const int li = r0 + 64 * (np - 1) + lane, li2 = li - ra.ne;
                 if (li < ra.ne) {
-                    if (!ok) atomicCAS(m.status, 0, ra.e0 + li + 1);
+                    if (!ok) report_status(m.status, ra.e0 + li + 1);
                     write_lean(buf, li, held);
                 } else if (li2 < rb.ne) {
-                    if (!ok) atomicCAS(m.status, 0, rb.e0 + li2 + 1);
+                    if (!ok) report_status(m.status, rb.e0 + li2 + 1);
                     held_at = li2;
                 }
             } else { // (every path defines the held record anew: its registers are free during the full passes)

@@ -183,6 +183,12 @@ template <class T> struct DevBuf {
 
 } // namespace femshell
 
+struct femshell_ctx;
+// zero the status word after a failure was read (mapped: by the host, behind a stream synchronisation)
+int clear_status_word(femshell_ctx *c, hipStream_t st);
+// the status word on the host after everything enqueued on st (mapped: no copy)
+int fetch_status_word(femshell_ctx *c, hipStream_t st, int32_t *out);
+
 struct femshell_ctx {
     // (global namespace: the opaque type of include/femshell.h)
     femshell_config cfg{};
@@ -190,6 +196,12 @@ struct femshell_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int32_t *status_host = nullptr; // pinned landing place of the device status word
+    // the status word as the kernels see it: c->status in HBM, or -- FEMSHELL_STATUS_MAPPED, the default -- the device address of
+    // status_host itself (kernels write the word on failure only, with a system-scope compare-and-swap; the host reads it after the
+    // stream synchronisation without a copy: 12 us of every femshell_assemble)
+    int32_t *status_word = nullptr;
+    bool status_mapped = false;
+    bool asm_events = true; // FEMSHELL_ASM_EVENTS=0: no event pair around the assembly kernel (assemble_seconds by the host's clock)
     double *agree_host = nullptr;   // pinned word of the cross-rank agreement on a rank-local failure (api.cpp)
     femshell::DevBuf<double> agree;
     // halo exchange beside the interior SpMV (multi-rank contexts): second stream + hand-off events

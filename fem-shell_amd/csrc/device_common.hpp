@@ -9,6 +9,15 @@
 
 namespace femshell {
 
+// first failure wins: the status word (HBM, or host memory mapped into the device: context.hpp status_word) gets `value` if it
+// still holds zero -- a system-scope compare-and-swap, executed on failures only
+__device__ __forceinline__ void report_status(int32_t *status, int32_t value)
+{
+    int32_t expected = 0;
+    (void)__hip_atomic_compare_exchange_strong(status, &expected, value, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+
 // Workgroup b belongs to XCD group x = b%8 and walks the slices x*per + j, j = b/8, b/8 + G/8, ...
 // of that group's contiguous eighth of the rows (per = ceil(S/8), G = gridDim.x).
 struct SliceWalk {

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(128) void k_element_matrices(DeviceMatrix m, MatCon
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0.0;
     if (ok) block_add_rec<true>(rec, ia, ib, mc, acc);
-    else atomicCAS(m.status, 0, kStatusDirect + first + e);
+    else report_status(m.status, kStatusDirect + first + e);
     const int N = 6 * nn;
     double *Ke = out + (int64_t)e * N * N;
 #pragma unroll
@@ -267,7 +267,7 @@ __global__ void k_block_jacobi(DeviceMatrix m)
             B[i][j2] = v;
         }
     if (!ok) {
-        atomicCAS(m.status, 0, -(a + 1));
+        report_status(m.status, -(a + 1));
 #pragma unroll
         for (int i = 0; i < 6; i++)
 #pragma unroll

@@ -12,6 +12,9 @@
 #include <cstdio>
 #include <atomic>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
+#include <pthread.h>
 #include <thread>
 
 namespace femshell {
@@ -87,6 +90,104 @@ int host_thread_count()
     int t = from_env > 0 ? from_env : available_cpus() / g_host_share.load();
     return t < 1 ? 1 : (t > 64 ? 64 : t);
 }
+// ---- the pool behind run_on_host_threads
+namespace {
+struct HostPool {
+    std::mutex use; // one job at a time
+    std::mutex m;
+    std::condition_variable wake, done;
+    std::vector<std::thread> workers;
+    const std::function<void(int)> *job = nullptr;
+    uint64_t generation = 0;
+    int nt = 0;      // tasks of the current job (task 0 is the caller's; worker w takes task w + 1)
+    int pending = 0; // tasks of the workers that have not finished
+};
+thread_local bool t_pool_worker = false; // this thread is inside a task of a pool job
+std::atomic<HostPool *> g_host_pool{nullptr};
+
+void pool_worker(HostPool *P, int w)
+{
+    t_pool_worker = true;
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(P->m);
+    for (;;) {
+        P->wake.wait(lk, [&] { return P->generation != seen; });
+        seen = P->generation;
+        if (w + 1 >= P->nt) continue; // (a job of fewer tasks)
+        const std::function<void(int)> *job = P->job;
+        lk.unlock();
+        (*job)(w + 1);
+        lk.lock();
+        if (--P->pending == 0) P->done.notify_one();
+    }
+}
+void spawn_and_join(int nt, const std::function<void(int)> &task)
+{
+    std::vector<std::thread> th;
+    th.reserve((size_t)nt);
+    for (int t = 1; t < nt; t++) th.emplace_back([&task, t] { task(t); });
+    task(0);
+    for (auto &t : th) t.join();
+}
+HostPool *host_pool()
+{
+    HostPool *P = g_host_pool.load(std::memory_order_acquire);
+    if (P) return P;
+    static std::mutex create;
+    std::lock_guard<std::mutex> g(create);
+    P = g_host_pool.load(std::memory_order_acquire);
+    if (!P) {
+        P = new HostPool(); // never freed: its workers wait in it until the process ends
+        // a forked child has the parent's memory and none of its threads: it starts a pool of its own when it needs one
+        static std::once_flag once;
+        std::call_once(once, [] { pthread_atfork(nullptr, nullptr, [] { g_host_pool.store(nullptr, std::memory_order_release); }); });
+        g_host_pool.store(P, std::memory_order_release);
+    }
+    return P;
+}
+} // namespace
+
+void run_on_host_threads(int nt, const std::function<void(int)> &task)
+{
+    if (nt <= 1) {
+        task(0);
+        return;
+    }
+    static const bool pool_off = getenv("FEMSHELL_HOST_POOL") && atoi(getenv("FEMSHELL_HOST_POOL")) == 0;
+    if (t_pool_worker) { // a call from inside a task: the cores are taken, the tasks run one after the other
+        for (int t = 0; t < nt; t++) task(t);
+        return;
+    }
+    HostPool *P = pool_off ? nullptr : host_pool();
+    if (P == nullptr || !P->use.try_lock()) { // the pool is at work for another host thread (another context's)
+        spawn_and_join(nt, task);
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> lk(P->m);
+        while ((int)P->workers.size() < nt - 1) {
+            const int w = (int)P->workers.size();
+            P->workers.emplace_back(pool_worker, P, w);
+            P->workers.back().detach();
+        }
+        P->job = &task;
+        P->nt = nt;
+        P->pending = nt - 1;
+        P->generation++;
+    }
+    P->wake.notify_all();
+    t_pool_worker = true; // (the caller's task is a task like the others: calls from inside it run serially)
+    task(0);
+    t_pool_worker = false;
+    {
+        std::unique_lock<std::mutex> lk(P->m);
+        P->done.wait(lk, [&] { return P->pending == 0; });
+        P->job = nullptr;
+        P->nt = 0;
+    }
+    P->use.unlock();
+}
+
 static int plan_threads() { return host_thread_count(); }
 template <class F> static void plan_parallel(int64_t n, int64_t min_chunk, F f) // f(thread, begin, end)
 {
@@ -95,9 +196,7 @@ template <class F> static void plan_parallel(int64_t n, int64_t min_chunk, F f) 
         f(0, (int64_t)0, n);
         return;
     }
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; t++) th.emplace_back([&f, t, n, nt] { f(t, n * t / nt, n * (t + 1) / nt); });
-    for (auto &t : th) t.join();
+    run_on_host_threads(nt, [&f, n, nt](int t) { f(t, n * t / nt, n * (t + 1) / nt); });
 }
 template <class V, class T> static void plan_fill(V &v, T value) // v[i] = value on the host threads (first touch included)
 {

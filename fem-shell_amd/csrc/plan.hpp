@@ -25,6 +25,7 @@
 #include <new>
 #include <string>
 #include <utility>
+#include <functional>
 #include <vector>
 
 namespace femshell {
@@ -160,6 +161,11 @@ struct Plan {
 int available_cpus();
 // threads of the host-side symbolic work (plan.cpp): FEMSHELL_HOST_THREADS, else available_cpus() / ranks on the host, <= 64
 int host_thread_count();
+// task(t) for t = 0 .. nt - 1, each on a thread of its own (task 0 on the caller's), returns when all are through.  The threads
+// are a pool that lives as long as the process: the symbolic phase and the multigrid setup make some sixty such calls per solve,
+// and sixteen std::thread spawns and joins per call were a fifth of the multigrid setup.  A call from inside a task runs its tasks one after
+// the other; a call while another host thread uses the pool runs on threads of its own as before.
+void run_on_host_threads(int nt, const std::function<void(int)> &task);
 void set_host_share(int ranks_on_this_host);
 
 // owned node range of `rank` when n_nodes rows are split over `world` ranks

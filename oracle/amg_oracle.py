@@ -127,7 +127,41 @@ def graph_for_aggregation(rowptr, colidx, keep=None):
     return either.indptr.astype(np.int64), either.indices.astype(np.int64)
 
 
+def aggregation_chunk():
+    """csrc/amg_setup.cpp aggregation_chunk: rows per piece of the chunked aggregation (FEMSHELL_AMG_AGG_CHUNK; default 0 = off)."""
+    e = os.environ.get("FEMSHELL_AMG_AGG_CHUNK")
+    return int(e) if e else 0
+
+
 def aggregate(rowptr, colidx, visit=None):
+    """csrc/amg_setup.cpp aggregate_nodes: graphs of more than one and a half chunks are cut into pieces of consecutive rows (the
+    boundaries of a row partition over ceil(n / chunk) ranks), every piece is aggregated on its own without the edges that leave it
+    (aggregate_piece), the aggregates are numbered piece by piece.  visit: the visiting order, restricted to each piece."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    colidx = np.asarray(colidx, dtype=np.int64)
+    n = len(rowptr) - 1
+    chunk = aggregation_chunk()
+    if chunk <= 0 or n <= chunk + chunk // 2:
+        return aggregate_piece(rowptr, colidx, visit)
+    nc = (n + chunk - 1) // chunk
+    bounds = partition_bounds_equal(n, nc)
+    agg = np.empty(n, dtype=np.int64)
+    total = 0
+    vis = None if visit is None else np.asarray(visit, dtype=np.int64)
+    for k in range(nc):
+        b0, b1 = int(bounds[k]), int(bounds[k + 1])
+        ci = colidx[rowptr[b0]:rowptr[b1]]
+        rows = np.repeat(np.arange(b0, b1), np.diff(rowptr[b0:b1 + 1]))
+        keep = (ci >= b0) & (ci < b1)
+        lp = np.concatenate([[0], np.cumsum(np.bincount(rows[keep] - b0, minlength=b1 - b0))])
+        v = None if vis is None else vis[(vis >= b0) & (vis < b1)] - b0
+        a, na = aggregate_piece(lp, ci[keep] - b0, v)
+        agg[b0:b1] = a + total
+        total += na
+    return agg, total
+
+
+def aggregate_piece(rowptr, colidx, visit=None):
     """Greedy distance-1 aggregation, three passes, on graph_for_aggregation; returns (agg, n_aggregates).  visit: the order in
     which the passes meet the nodes (default: aggregation_order); a leftover of pass 1 joins the neighbour that comes first in it."""
     rowptr, colidx = graph_for_aggregation(rowptr, colidx)

@@ -350,3 +350,48 @@ def test_aggregation_looks_at_the_twelve_closest_neighbours_of_a_node(monkeypatc
     agg_ref0, na_ref0 = amg_oracle.aggregate(rowptr, cols)
     assert np.array_equal(agg_all, agg_ref0)
     assert agg_lib.max() + 1 > 1.05 * (agg_all.max() + 1)
+
+
+@pytest.mark.parametrize("threads", ["1", "5"])
+def test_chunked_aggregation_equals_the_restatement_whatever_the_thread_count(monkeypatch, threads):
+    """Round 6 (an experiment knob, off by default -- the seams cost iterations on structured meshes,
+    profiles/r06_chunked_aggregation.txt): with FEMSHELL_AMG_AGG_CHUNK rows per chunk set, graphs of more than one and a half
+    chunks are aggregated piece by piece -- consecutive rows, the boundaries of a row partition, no edge across a boundary, aggregates numbered piece by piece --
+    on the host's threads (csrc/amg_setup.cpp aggregate_nodes).  The pieces depend on the row count alone: same aggregates on one
+    thread and on five, equal to the restatement's (oracle/amg_oracle.py aggregate), with and without a visiting order; no
+    aggregate spans two pieces; a graph below the threshold is aggregated in one piece as before."""
+    ensure_built()
+    b = _binding()
+    monkeypatch.setenv("FEMSHELL_HOST_THREADS", threads)
+    m = meshes.pinched_cylinder(60, 50)
+    rp, ci, _, _ = oracle.assemble(m.xyz, m.tri, m.quad, oracle.material(*m.material), m.dirichlet_mask(), m.loads)
+    n = len(rp) - 1
+    whole, na_whole = b.amg_host_aggregate(rp, ci)  # default: one piece
+    monkeypatch.setenv("FEMSHELL_AMG_AGG_CHUNK", "0")
+    off, na_off = b.amg_host_aggregate(rp, ci)
+    np.testing.assert_array_equal(whole, off)
+    monkeypatch.setenv("FEMSHELL_AMG_AGG_CHUNK", "700")
+    agg, na = b.amg_host_aggregate(rp, ci)
+    agg_o, na_o = amg_oracle.aggregate(rp, ci)
+    np.testing.assert_array_equal(agg, agg_o)
+    assert na == na_o and not np.array_equal(agg, whole)
+    nc = (n + 699) // 700
+    bounds = amg_oracle.partition_bounds_equal(n, nc)
+    piece_of_node = np.searchsorted(bounds, np.arange(n), side="right") - 1
+    first = {}
+    for i in range(n):  # every aggregate lies in one piece, and the aggregates are numbered piece by piece
+        assert first.setdefault(int(agg[i]), int(piece_of_node[i])) == piece_of_node[i]
+    assert all(first[a] <= first[a + 1] for a in range(na - 1))
+    # close to the aggregates of the whole graph in number (the seams cost a few)
+    assert na_whole <= na <= 1.25 * na_whole
+    # with a visiting order (the caller's numbering of a renumbered mesh): restricted to each piece
+    perm = np.random.default_rng(3).permutation(n)
+    iperm = np.argsort(perm)
+    G = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(n, n))
+    Gp = G[iperm][:, iperm].tocsr()
+    Gp.sort_indices()
+    rpp, cip = Gp.indptr.astype(np.int32), Gp.indices.astype(np.int32)
+    agg1, na1 = b.amg_host_aggregate(rpp, cip, visit=perm)
+    agg1_o, na1_o = amg_oracle.aggregate(rpp, cip, visit=perm)
+    np.testing.assert_array_equal(agg1, agg1_o)
+    assert na1 == na1_o
