@@ -26,6 +26,7 @@ SYMBOLS = [
     "femshell_sync", "femshell_pc_defaults", "femshell_set_preconditioner", "femshell_amg_levels", "femshell_amg_level",
     "femshell_amg_export", "femshell_residual", "femshell_comm_ranks", "femshell_amg_setup_stats", "femshell_amg_dense_stats", "femshell_amg_partition_info", "femshell_assembly_kernel",
     "femshell_amg_cycle_bytes", "femshell_comm_selftest", "femshell_comm_counters", "femshell_owned_nodes", "femshell_comm_bytes", "femshell_set_initial_guess",
+    "femshell_amg_patch_info",
 ]
 
 
@@ -139,6 +140,7 @@ def load_library():
     L.femshell_amg_export.restype = C.c_int64
     L.femshell_amg_setup_stats.argtypes = [vp, dp]
     L.femshell_amg_dense_stats.argtypes = [vp, dp]
+    L.femshell_amg_patch_info.argtypes = [vp, dp]
     L.femshell_amg_partition_info.argtypes = [vp, dp]
     L.femshell_assembly_kernel.argtypes = [vp]
     L.femshell_comm_selftest.argtypes = [vp, dp]
@@ -383,6 +385,13 @@ class FemShell:
         return {"n": int(out[0]), "ms": out[1], "mfma_flops_issued": out[2], "useful_flops": out[3], "dropped_directions": int(out[4]),
                 "bytes": out[5]}
 
+    def amg_patch_info(self):
+        """The patch smoother of level 0 (csrc/amg_patch.hpp): rigid edges, clusters, nodes in them; all zero without rigid edges."""
+        out = np.zeros(6)
+        _check(self._L.femshell_amg_patch_info(self._h, _d(out)))
+        return {"rigid_edges": int(out[0]), "clusters": int(out[1]), "nodes_in_clusters": int(out[2]), "not_positive_definite": int(out[3]),
+                "tau": out[4], "max_nodes": int(out[5])}
+
     def amg_partition_info(self):
         """Row-partitioned hierarchy (femshell_amg_partition_info): levels split over the ranks, bytes that shrink with the
         rank count, bytes every rank holds in full."""
@@ -396,7 +405,8 @@ class FemShell:
         """Host copies of a level (small problems): dict with agg, A (rowptr, cols, vals), P (rowptr, cols, vals)."""
         names = {"agg": (0, np.int32), "A_rowptr": (1, np.int64), "A_cols": (2, np.int32), "A_vals": (3, np.float64),
                  "P_rowptr": (4, np.int64), "P_cols": (5, np.int32), "P_vals": (6, np.float64),
-                 "coarse_inverse": (7, np.float64)}  # (the coarsest level only: its dense inverse, n x n)
+                 "coarse_inverse": (7, np.float64),  # (the coarsest level only: its dense inverse, n x n)
+                 "patch_labels": (8, np.int32)}      # (level 0: cluster of every node or -1; None without clusters)
         out = {}
         for name, (which, dt) in names.items():
             n = self._L.femshell_amg_export(self._h, level, which, None)
@@ -520,6 +530,40 @@ def amg_host_aggregate(rowptr, colidx, visit=None):
     na = L.femshell_amg_host_aggregate(len(rowptr) - 1, _i(rowptr), _i(colidx), None if v is None else _i(v), _i(agg))
     if na < 0:
         _check(-1)  # FEMSHELL_ERR_INVALID; the message is in femshell_last_error
+    return agg, na
+
+
+def amg_host_patch_clusters(rowptr, colidx, vals, tau=0.8, max_nodes=8):
+    """Clusters of rigidly coupled nodes of a host matrix (csrc/amg_patch.hpp): (labels, n_clusters, rigid edges)."""
+    L = load_library()
+    L.femshell_amg_host_patch_clusters.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_double,
+                                                   C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    L.femshell_amg_host_patch_clusters.restype = C.c_int32
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    labels = np.zeros(len(rowptr) - 1, dtype=np.int32)
+    edges = C.c_int64(0)
+    nc = L.femshell_amg_host_patch_clusters(len(rowptr) - 1, _i(rowptr), _i(colidx), _d(vals), tau, max_nodes, _i(labels), C.byref(edges))
+    if nc < 0:
+        _check(-1)
+    return labels, nc, edges.value
+
+
+def amg_host_aggregate_glued(rowptr, colidx, labels, visit=None):
+    """The aggregation with the clusters glued into one node each: (agg, n_aggregates)."""
+    L = load_library()
+    L.femshell_amg_host_aggregate_glued.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.femshell_amg_host_aggregate_glued.restype = C.c_int32
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    agg = np.zeros(len(rowptr) - 1, dtype=np.int32)
+    v = None if visit is None else np.ascontiguousarray(visit, dtype=np.int32)
+    na = L.femshell_amg_host_aggregate_glued(len(rowptr) - 1, _i(rowptr), _i(colidx), _i(labels), None if v is None else _i(v), _i(agg))
+    if na < 0:
+        _check(-1)
     return agg, na
 
 

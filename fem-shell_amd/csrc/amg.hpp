@@ -30,6 +30,7 @@
 #include <utility>
 #include <vector>
 
+#include "amg_patch.hpp"
 #include "plan.hpp"
 
 namespace femshell {
@@ -67,6 +68,23 @@ void node_normals(int32_t n, const double *xyz, int64_t n_tri, const int32_t *tr
 // visit: order in which the greedy passes visit the nodes (visit[v] = node visited v-th); nullptr: index order, or
 // breadth-first order when the numbering is scattered (aggregation_order)
 int32_t aggregate_nodes(const Bsr &A, std::vector<int32_t> *agg, const std::vector<int32_t> *visit = nullptr);
+
+// ---- clusters of rigidly coupled nodes (amg_patch.hpp): the patch smoother of shells of poor element quality
+// Clusters from the rigid edges (sigma2 > tau^2; each pair once, a < c): strongest first -- ties: lower a, then lower c --, two
+// clusters are united while the union stays within max_nodes.  label[i] = cluster of node i or -1; clusters are numbered by their
+// smallest node; members of cluster k: nodes[ptr[k] .. ptr[k+1]) ascending.  Returns the number of clusters.
+int32_t patch_clusters(int32_t n, std::vector<PatchEdge> edges, int max_nodes, std::vector<int32_t> *label, std::vector<int32_t> *ptr,
+                       std::vector<int32_t> *nodes);
+// rigid edges of a host matrix (tests, levels coarsened on the host): patch_sigma2 over the blocks above the diagonal
+void patch_edges_host(const Bsr &A, const std::vector<double> &Dinv, double tau, std::vector<PatchEdge> *edges);
+// M_c = (A_cc)^-1 - blockdiag(D_i^-1) of every cluster from its dense diagonal block Bc (row-major (6 m)^2 at moff[c], overwritten);
+// a block that is not positive definite gives M_c = 0 (the point blocks alone act on its nodes).  Returns the clusters that fell back.
+int32_t patch_matrices(const std::vector<int32_t> &ptr, const std::vector<int64_t> &moff, const double *dinv_of_member /* 36 per member */,
+                       double *Bc);
+// aggregation with every cluster glued into one node first: the greedy passes run on the quotient graph (clusters and single nodes
+// numbered in the order the visiting order meets them), a cluster's nodes share their quotient node's aggregate
+int32_t aggregate_nodes_glued(const Bsr &A, const std::vector<int32_t> &label, std::vector<int32_t> *agg,
+                              const std::vector<int32_t> *visit = nullptr);
 
 // tentative prolongator: per aggregate B_agg = Q R (modified Gram-Schmidt, two passes; dependent columns give a
 // zero column of Q and a zero diagonal of R).  Q[n][6][6] (row block of node n, column block agg[n]),

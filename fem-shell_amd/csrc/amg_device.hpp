@@ -1,5 +1,6 @@
 // amg_device.hpp -- the multigrid hierarchy in HBM (amg_solve.cpp) as the context sees it.
 #pragma once
+#include "amg_patch.hpp"
 
 #include <memory>
 #include <vector>
@@ -52,6 +53,33 @@ struct LevelHalo {
     int sendbuf_width = 0;
 };
 
+// the clusters of a level (amg_patch.hpp) in HBM, and on the host what the aggregation and the inspection export need
+struct AmgPatches {
+    int32_t n_clusters = 0, n_members = 0, fell_back = 0;
+    int64_t edges = 0;          // rigid edges found
+    double tau = 0.0;
+    int max_nodes = 0;
+    bool glue = true;           // the clusters are glued into one node each before the aggregation (off: the second attempt of a
+                                // setup whose glued aggregates were seen by more rows than an operator row can hold)
+    DevBuf<int32_t> ptr, nodes, cluster_of;
+    DevBuf<int64_t> moff;
+    DevBuf<double> M;
+    std::vector<int32_t> label; // per node: its cluster or -1
+    std::vector<int32_t> h_ptr, h_nodes;
+    PatchView view() const
+    {
+        PatchView v;
+        v.n_clusters = n_clusters;
+        v.n_members = n_members;
+        v.ptr = ptr.p;
+        v.nodes = nodes.p;
+        v.moff = moff.p;
+        v.M = M.p;
+        v.cluster_of = cluster_of.p;
+        return v;
+    }
+};
+
 struct AmgLevel {
     int32_t n = 0, n_pad = 0; // nodes (6 dofs each) / padded to whole slices (row-partitioned levels: the rank's own rows)
     // row-partitioned levels (contexts with a communicator, amg_dist.cpp): the rank holds the rows [part[rank], part[rank+1])
@@ -90,6 +118,7 @@ struct AmgLevel {
     // host copies for the inspection exports (small problems only)
     Bsr hA, hP;
     std::vector<int32_t> agg;
+    std::shared_ptr<AmgPatches> patches; // clusters of rigidly coupled nodes and their smoother blocks (level 0; null: none)
 };
 
 // timings of the first coarsening step on the device (amg_device_setup.cpp); zero when the host path ran

@@ -255,7 +255,10 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     // aggregates -- hence every coarser level, whose numbering is the order of creation -- are then those of the caller's
     // numbering, whatever the internal one is
     const bool finest_renumbered = &Adev == &c->dm && !c->iperm.empty() && (int32_t)c->iperm.size() == n;
-    const int32_t na = aggregate_nodes(G, &agg, finest_renumbered ? &c->iperm : nullptr);
+    // (clusters of rigidly coupled nodes -- amg_patch.hpp -- are glued into one node each before the greedy passes)
+    const AmgPatches *patches = L.patches.get();
+    const int32_t na = (patches && patches->glue) ? aggregate_nodes_glued(G, patches->label, &agg, finest_renumbered ? &c->iperm : nullptr)
+                               : aggregate_nodes(G, &agg, finest_renumbered ? &c->iperm : nullptr);
     lap("  aggregation");
     // tentative prolongator on the device: QR of every aggregate's rows of B, one wave each (k_amg_tentative_qr); the host
     // only groups the nodes by aggregate
@@ -297,8 +300,26 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     {
         std::vector<uint8_t> cnt((size_t)n, 0);
         RawVec<int32_t> tmp_all((size_t)G.ptr[n]); // upper bound storage: distinct aggregates per row, compacted below
+        // rows of clustered nodes: the cluster blocks couple a row to what ALL the cluster's members see (P = P0 - omega B^-1 A P0)
+        std::vector<std::vector<int32_t>> cluster_rows(patches ? (size_t)patches->n_clusters : 0);
+        if (patches)
+            parallel_chunks(patches->n_clusters, [&](int64_t k0, int64_t k1) {
+                for (int64_t k = k0; k < k1; k++) {
+                    std::vector<int32_t> &r = cluster_rows[(size_t)k];
+                    for (int32_t t = patches->h_ptr[(size_t)k]; t < patches->h_ptr[(size_t)k + 1]; t++) {
+                        const int32_t j = patches->h_nodes[(size_t)t];
+                        for (int64_t q = G.ptr[j]; q < G.ptr[(size_t)j + 1]; q++) r.push_back(agg[G.col[q]]);
+                    }
+                    std::sort(r.begin(), r.end());
+                    r.erase(std::unique(r.begin(), r.end()), r.end());
+                }
+            }, 64);
         parallel_chunks(n, [&](int64_t a0, int64_t a1) {
             for (int64_t a = a0; a < a1; a++) {
+                if (patches && patches->label[(size_t)a] >= 0) {
+                    cnt[a] = (uint8_t)std::min<size_t>(cluster_rows[(size_t)patches->label[(size_t)a]].size(), 255);
+                    continue;
+                }
                 int32_t *t = &tmp_all[(size_t)G.ptr[a]];
                 int m = 0;
                 for (int64_t q = G.ptr[a]; q < G.ptr[a + 1]; q++) t[m++] = agg[G.col[q]];
@@ -310,7 +331,10 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
         for (int32_t a = 0; a < n; a++) pptr[a + 1] = pptr[a] + cnt[a];
         pcol.resize((size_t)pptr[n]);
         parallel_chunks(n, [&](int64_t a0, int64_t a1) {
-            for (int64_t a = a0; a < a1; a++) std::copy_n(&tmp_all[(size_t)G.ptr[a]], cnt[a], &pcol[(size_t)pptr[a]]);
+            for (int64_t a = a0; a < a1; a++) {
+                if (patches && patches->label[(size_t)a] >= 0) std::copy_n(cluster_rows[(size_t)patches->label[(size_t)a]].data(), cnt[a], &pcol[(size_t)pptr[a]]);
+                else std::copy_n(&tmp_all[(size_t)G.ptr[a]], cnt[a], &pcol[(size_t)pptr[a]]);
+            }
         });
     }
     lap("  pattern of P");
@@ -469,6 +493,11 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     for (auto &e : ev) FS_HIP(hipEventCreate(&e));
     FS_HIP(hipEventRecord(ev[0], st));
     launch_amg_prolongator(Adev, d_agg.p, d_Q.p, (4.0 / 3.0) / lam, d_pmap_own.p, d_pmap_in.p, wP, st);
+    if (patches) { // the cluster blocks' share of the smoothing
+        int width = 0;
+        for (int32_t w : eP.slice_width) width = std::max(width, (int)w);
+        launch_patch_prolongator(Adev, d_agg.p, d_Q.p, (4.0 / 3.0) / lam, wP, patches->view(), width, st);
+    }
     FS_HIP(hipEventRecord(ev[1], st));
     launch_amg_ap(Adev, wP, wAP, st);
     FS_HIP(hipEventRecord(ev[2], st));

@@ -1424,4 +1424,225 @@ void launch_unpack_ell_rows(const double *buf, int32_t count, int W, const EllVi
     hipLaunchKernelGGL(k_unpack_ell_rows, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, buf, count, W, M, contig ? 1 : 0, first_row);
 }
 
+// ---- patch smoother (amg_patch.hpp): clusters of rigidly coupled nodes --------------------------------------------------
+
+namespace {
+__device__ __forceinline__ void load_dinv(const DeviceMatrix &A, int a, double d[36])
+{
+    const double *mi = A.minv + (int64_t)(a / kSliceNodes) * kMinvWords * kSliceNodes + (a % kSliceNodes);
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) d[6 * i + j] = mi[minv_word(i < j ? i : j, i < j ? j : i) * kSliceNodes];
+}
+} // namespace
+
+// one lane per owned row: the stored blocks (a, c) with another owned row c -- each pair once (symmetric storage stores it once;
+// full storage: c > a) -- whose sigma_max^2 exceeds tau2 go to the edge list (order arbitrary: the host sorts)
+// (counter[0]: edges above tau; counter[1]: edges above the trigger level hi2 -- nearly coincident nodes --; counter[2]: pairs looked at)
+__global__ __launch_bounds__(64) void k_patch_sigma(DeviceMatrix A, double tau2, double hi2, PatchEdge *edges, unsigned int *counter, unsigned int cap)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= A.n_own) return;
+    unsigned int pairs = 0, high = 0;
+    const int sl = a / kSliceNodes, n = a % kSliceNodes;
+    const int64_t base = A.slice_base[sl];
+    const int W = A.slice_width[sl];
+    double Da[36];
+    bool have = false;
+    for (int k = 1; k < W; k++) {
+        const int64_t slot = base + (int64_t)k * kSliceNodes + n;
+        const int c = A.cols[slot];
+        if (c == a || c >= A.n_own || (!A.symmetric && c < a)) continue;
+        if (!have) {
+            load_dinv(A, a, Da);
+            have = true;
+        }
+        double blk[36], Dc[36];
+        ell_load(A.vals, slot, blk, false);
+        load_dinv(A, c, Dc);
+        const double s2 = patch_sigma2(Da, blk, Dc, tau2);
+        pairs++;
+        if (s2 > hi2) high++;
+        if (s2 > tau2) {
+            const unsigned int at = atomicAdd(counter, 1u);
+            if (at < cap) {
+                PatchEdge e;
+                e.a = a < c ? a : c;
+                e.c = a < c ? c : a;
+                e.sigma2 = s2;
+                edges[at] = e;
+            }
+        }
+    }
+    if (high) atomicAdd(counter + 1, high);
+    if (pairs) atomicAdd(counter + 2, pairs);
+}
+
+void launch_patch_sigma(const DeviceMatrix &A, double tau, double trigger_sigma, PatchEdge *edges, unsigned int *counter, unsigned int cap,
+                        hipStream_t st)
+{
+    if (A.n_own <= 0) return;
+    hipLaunchKernelGGL(k_patch_sigma, dim3((unsigned)((A.n_own + 63) / 64)), dim3(64), 0, st, A, tau * tau, trigger_sigma * trigger_sigma, edges,
+                       counter, cap);
+}
+
+// the dense diagonal block A_cc of every cluster (row-major (6 m)^2 at moff[c]) and the inverse diagonal blocks of its members
+// (36 doubles per member position): one thread per (cluster, i, j)
+__global__ __launch_bounds__(128) void k_patch_gather(DeviceMatrix A, PatchView pv, double *Bc, double *dinv_of_member)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(t / (kPatchMaxNodes * kPatchMaxNodes)), ij = (int)(t % (kPatchMaxNodes * kPatchMaxNodes));
+    if (c >= pv.n_clusters) return;
+    const int m = pv.ptr[c + 1] - pv.ptr[c], i = ij / kPatchMaxNodes, j = ij % kPatchMaxNodes;
+    if (i >= m || j >= m) return;
+    const int a = pv.nodes[pv.ptr[c] + i], b = pv.nodes[pv.ptr[c] + j];
+    double blk[36];
+#pragma unroll
+    for (int e = 0; e < 36; e++) blk[e] = 0.0;
+    if (i == j) {
+        const int64_t slot = A.slice_base[a / kSliceNodes] + (a % kSliceNodes);
+        if (A.diag_upper) ell_load_sym(A.vals, slot, blk);
+        else ell_load(A.vals, slot, blk, false);
+        double d[36];
+        load_dinv(A, a, d);
+#pragma unroll
+        for (int e = 0; e < 36; e++) dinv_of_member[(int64_t)(pv.ptr[c] + i) * 36 + e] = d[e];
+    } else {
+        // A_ab: a stored block of row a, or the transpose of a stored block of row b
+        bool found = false;
+        for (int pass = 0; pass < 2 && !found; pass++) {
+            const int r = pass == 0 ? a : b, want = pass == 0 ? b : a;
+            const int sl = r / kSliceNodes, n = r % kSliceNodes;
+            const int W = A.slice_width[sl];
+            for (int k = 1; k < W; k++) {
+                const int64_t slot = A.slice_base[sl] + (int64_t)k * kSliceNodes + n;
+                if (A.cols[slot] == want) {
+                    ell_load(A.vals, slot, blk, pass == 1);
+                    found = true;
+                    break;
+                }
+            }
+        }
+    }
+    const int N = 6 * m;
+    double *B = Bc + pv.moff[c];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int q = 0; q < 6; q++) B[(int64_t)(6 * i + r) * N + 6 * j + q] = blk[6 * r + q];
+}
+
+void launch_patch_gather(const DeviceMatrix &A, const PatchView &pv, double *Bc, double *dinv_of_member, hipStream_t st)
+{
+    const int64_t n = (int64_t)pv.n_clusters * kPatchMaxNodes * kPatchMaxNodes;
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_patch_gather, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, A, pv, Bc, dinv_of_member);
+}
+
+// z_c += coef M_c r_c on the clustered nodes, for up to two targets (the Chebyshev direction, as floats where the level keeps it so,
+// and the iterate): one wave per cluster, lane t < 6 m owns dof t of the cluster
+__global__ __launch_bounds__(64) void k_patch_correct(PatchView pv, const double *__restrict__ r, double coef, double *d, int d_float,
+                                                      double *x, const CgScalars *gate)
+{
+    if (gate != nullptr && gate->done != 0) return;
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int m = pv.ptr[c + 1] - pv.ptr[c], N = 6 * m;
+    const int node = t < N ? pv.nodes[pv.ptr[c] + t / 6] : 0;
+    const int64_t row = (int64_t)node * 6 + t % 6;
+    const double rv = t < N ? r[row] : 0.0;
+    const double *Mrow = pv.M + pv.moff[c] + (int64_t)(t < N ? t : 0) * N;
+    double acc = 0.0;
+    for (int s = 0; s < N; s++) acc += Mrow[s] * __shfl(rv, s, 64);
+    if (t >= N) return;
+    const double delta = coef * acc;
+    if (d != nullptr) {
+        if (d_float) reinterpret_cast<float *>(d)[row] = (float)((double)reinterpret_cast<float *>(d)[row] + delta);
+        else d[row] += delta;
+    }
+    if (x != nullptr) x[row] += delta;
+}
+
+void launch_patch_correct(const PatchView &pv, const double *r, double coef, double *d, bool d_float, double *x, const CgScalars *gate,
+                          hipStream_t st)
+{
+    if (pv.n_clusters == 0) return;
+    hipLaunchKernelGGL(k_patch_correct, dim3((unsigned)pv.n_clusters), dim3(64), 0, st, pv, r, coef, d, d_float ? 1 : 0, x, gate);
+}
+
+// The smoothing of the prolongator with the cluster blocks: P = P0 - omega B^-1 A P0 = (the point-block result of k_amg_prolongator)
+// - omega M (A P0) on the rows of clustered nodes.  One thread per (member position, slot of P's row): for the aggregate J of that
+// slot, sum over the cluster's members j of M_ij times row j of A P0 at J = sum over the neighbours k of j in aggregate J of A_jk Q_k.
+__global__ __launch_bounds__(64) void k_patch_prolongator(DeviceMatrix A, const int32_t *__restrict__ agg, const double *__restrict__ Q,
+                                                          double omega, EllView P, PatchView pv, int width)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int pos = (int)(t / width), kP = (int)(t % width);
+    if (pos >= pv.n_members) return;
+    const int a = pv.nodes[pos], c = pv.cluster_of[pos];
+    if (kP >= P.count[a]) return;
+    const int64_t pslot = ell_slot(P, a / kSliceNodes, kP, a % kSliceNodes);
+    const int J = P.cols[pslot];
+    const int m = pv.ptr[c + 1] - pv.ptr[c], N = 6 * m, i = pos - pv.ptr[c];
+    const double *M = pv.M + pv.moff[c];
+    double out[36];
+#pragma unroll
+    for (int e = 0; e < 36; e++) out[e] = 0.0;
+    for (int j = 0; j < m; j++) {
+        const int b = pv.nodes[pv.ptr[c] + j];
+        double T[36];
+#pragma unroll
+        for (int e = 0; e < 36; e++) T[e] = 0.0;
+        bool any = false;
+        for_each_neighbour(A, b, [&](int k, int64_t slot, bool transposed, int64_t) {
+            if (agg[k] != J) return;
+            double blk[36], q[36];
+            if (A.diag_upper && k == b && !transposed) ell_load_sym(A.vals, slot, blk);
+            else ell_load(A.vals, slot, blk, transposed);
+#pragma unroll
+            for (int e = 0; e < 36; e++) q[e] = Q[(int64_t)k * 36 + e];
+            blk_mac(blk, q, T, false);
+            any = true;
+        });
+        if (!any) continue;
+        double Mij[36];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int q = 0; q < 6; q++) Mij[6 * r + q] = M[(int64_t)(6 * i + r) * N + 6 * j + q];
+        blk_mac(Mij, T, out, false);
+    }
+    double cur[36];
+    ell_load(P.vals, pslot, cur, false);
+#pragma unroll
+    for (int e = 0; e < 36; e++) cur[e] -= omega * out[e];
+    ell_store(P.vals, pslot, cur);
+}
+
+void launch_patch_prolongator(const DeviceMatrix &A, const int32_t *agg, const double *Q, double omega, const EllView &P, const PatchView &pv,
+                              int width, hipStream_t st)
+{
+    const int64_t n = (int64_t)pv.n_members * width;
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_patch_prolongator, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, A, agg, Q, omega, P, pv, width);
+}
+
+// partial sums of z.z over the first n entries, one per workgroup of the grid G (the layout launch_minv_apply_norm writes)
+__global__ __launch_bounds__(256) void k_sqnorm_partials(const double *__restrict__ z, int64_t n, double *__restrict__ partials)
+{
+    __shared__ double sh[4];
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x, b = (int64_t)blockIdx.x * per, e = b + per < n ? b + per : n;
+    double acc = 0.0;
+    for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) acc += z[i] * z[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+void launch_sqnorm_partials(const double *z, int64_t n, double *partials, int G, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sqnorm_partials, dim3((unsigned)G), dim3(256), 0, st, z, n, partials);
+}
+
 } // namespace femshell

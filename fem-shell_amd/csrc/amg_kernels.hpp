@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "amg_patch.hpp"
 #include "kernels.hpp"
 
 namespace femshell {
@@ -142,5 +143,20 @@ void launch_pack_ell_rows(const EllView &M, bool contig, const int32_t *nodes, i
 void launch_extract_keys(const double *buf, int64_t entries, int32_t *keys, hipStream_t st);
 // the values of `count` received rows into the rows first_row ... of M (whose cols / count the host filled from the keys)
 void launch_unpack_ell_rows(const double *buf, int32_t count, int W, const EllView &M, bool contig, int32_t first_row, hipStream_t st);
+
+// ---- patch smoother (amg_patch.hpp)
+// rigid edges of the operator in HBM (block-Jacobi inverse valid): counter[0] counts them all, the first cap are stored; counter[1]
+// = edges above trigger_sigma (nearly coincident nodes), counter[2] = pairs of owned rows looked at
+void launch_patch_sigma(const DeviceMatrix &A, double tau, double trigger_sigma, PatchEdge *edges, unsigned int *counter, unsigned int cap,
+                        hipStream_t st);
+// dense diagonal blocks of the clusters and the inverse diagonal blocks of their members
+void launch_patch_gather(const DeviceMatrix &A, const PatchView &pv, double *Bc, double *dinv_of_member, hipStream_t st);
+// d_c += coef M_c r_c, x_c += coef M_c r_c (either may be null; d_float: d is an array of floats)
+void launch_patch_correct(const PatchView &pv, const double *r, double coef, double *d, bool d_float, double *x, const CgScalars *gate,
+                          hipStream_t st);
+// the rows of P of clustered nodes: -= omega M (A P0)  (width: widest row of P)
+void launch_patch_prolongator(const DeviceMatrix &A, const int32_t *agg, const double *Q, double omega, const EllView &P, const PatchView &pv,
+                              int width, hipStream_t st);
+void launch_sqnorm_partials(const double *z, int64_t n, double *partials, int G, hipStream_t st);
 
 } // namespace femshell

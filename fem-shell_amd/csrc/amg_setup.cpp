@@ -448,6 +448,183 @@ static int32_t aggregate_piece(const Bsr &Afull, std::vector<int32_t> *aggout, c
     return na;
 }
 
+// ---- clusters of rigidly coupled nodes (amg_patch.hpp) ---------------------------------------------------------------
+
+int32_t patch_clusters(int32_t n, std::vector<PatchEdge> edges, int max_nodes, std::vector<int32_t> *label, std::vector<int32_t> *ptr,
+                       std::vector<int32_t> *nodes)
+{
+    if (max_nodes > kPatchMaxNodes) max_nodes = kPatchMaxNodes;
+    for (auto &e : edges)
+        if (e.a > e.c) std::swap(e.a, e.c);
+    std::sort(edges.begin(), edges.end(), [](const PatchEdge &x, const PatchEdge &y) {
+        if (x.sigma2 != y.sigma2) return x.sigma2 > y.sigma2;
+        if (x.a != y.a) return x.a < y.a;
+        return x.c < y.c;
+    });
+    std::vector<int32_t> parent((size_t)n), size((size_t)n, 1);
+    for (int32_t i = 0; i < n; i++) parent[(size_t)i] = i;
+    auto find = [&](int32_t a) {
+        while (parent[(size_t)a] != a) {
+            parent[(size_t)a] = parent[(size_t)parent[(size_t)a]];
+            a = parent[(size_t)a];
+        }
+        return a;
+    };
+    for (const PatchEdge &e : edges) {
+        if (e.a < 0 || e.c >= n || e.a == e.c) continue;
+        int32_t ra = find(e.a), rc = find(e.c);
+        if (ra == rc || size[(size_t)ra] + size[(size_t)rc] > max_nodes) continue;
+        if (rc < ra) std::swap(ra, rc); // the root is the cluster's smallest node
+        parent[(size_t)rc] = ra;
+        size[(size_t)ra] += size[(size_t)rc];
+    }
+    label->assign((size_t)n, -1);
+    ptr->assign(1, 0);
+    nodes->clear();
+    int32_t nc = 0;
+    // roots ascending = clusters by their smallest node; members in ascending order
+    std::vector<int32_t> id_of_root((size_t)n, -1);
+    for (int32_t i = 0; i < n; i++) {
+        const int32_t r = find(i);
+        if (size[(size_t)r] < 2) continue;
+        if (id_of_root[(size_t)r] < 0) id_of_root[(size_t)r] = nc++; // (r == its smallest member: met first)
+        (*label)[(size_t)i] = id_of_root[(size_t)r];
+    }
+    std::vector<int32_t> cnt((size_t)nc + 1, 0);
+    for (int32_t i = 0; i < n; i++)
+        if ((*label)[(size_t)i] >= 0) cnt[(size_t)(*label)[(size_t)i] + 1]++;
+    for (int32_t k = 0; k < nc; k++) cnt[(size_t)k + 1] += cnt[(size_t)k];
+    *ptr = cnt;
+    nodes->resize((size_t)cnt[(size_t)nc]);
+    std::vector<int32_t> fill(cnt.begin(), cnt.end() - 1);
+    for (int32_t i = 0; i < n; i++)
+        if ((*label)[(size_t)i] >= 0) (*nodes)[(size_t)fill[(size_t)(*label)[(size_t)i]]++] = i;
+    return nc;
+}
+
+void patch_edges_host(const Bsr &A, const std::vector<double> &Dinv, double tau, std::vector<PatchEdge> *edges)
+{
+    edges->clear();
+    const double tau2 = tau * tau;
+    for (int32_t i = 0; i < A.nr; i++)
+        for (int64_t q = A.ptr[(size_t)i]; q < A.ptr[(size_t)i + 1]; q++) {
+            const int32_t j = A.col[(size_t)q];
+            if (j <= i || j >= A.nr) continue;
+            const double s2 = patch_sigma2(&Dinv[(size_t)i * 36], &A.val[(size_t)q * 36], &Dinv[(size_t)j * 36], tau2);
+            if (s2 > tau2) edges->push_back(PatchEdge{i, j, s2});
+        }
+}
+
+int32_t patch_matrices(const std::vector<int32_t> &ptr, const std::vector<int64_t> &moff, const double *dinv_of_member, double *Bc)
+{
+    const int32_t nc = (int32_t)ptr.size() - 1;
+    std::atomic<int32_t> fell_back{0};
+    parallel_chunks(nc, [&](int64_t c0, int64_t c1) {
+        std::vector<double> L, Li, inv;
+        for (int64_t c = c0; c < c1; c++) {
+            const int m = ptr[(size_t)c + 1] - ptr[(size_t)c], N = 6 * m;
+            double *B = Bc + moff[(size_t)c];
+            // Cholesky B = L L^T, inverse by two triangular solves
+            L.assign((size_t)N * N, 0.0);
+            bool ok = true;
+            for (int j = 0; j < N && ok; j++) {
+                double d = B[(size_t)j * N + j];
+                for (int k = 0; k < j; k++) d -= L[(size_t)j * N + k] * L[(size_t)j * N + k];
+                if (!(d > 0.0)) {
+                    ok = false;
+                    break;
+                }
+                const double ljj = std::sqrt(d);
+                L[(size_t)j * N + j] = ljj;
+                for (int i = j + 1; i < N; i++) {
+                    double v = 0.5 * (B[(size_t)i * N + j] + B[(size_t)j * N + i]);
+                    for (int k = 0; k < j; k++) v -= L[(size_t)i * N + k] * L[(size_t)j * N + k];
+                    L[(size_t)i * N + j] = v / ljj;
+                }
+            }
+            if (!ok) {
+                fell_back.fetch_add(1);
+                std::fill(B, B + (size_t)N * N, 0.0);
+                continue;
+            }
+            Li.assign((size_t)N * N, 0.0); // L^-1, lower triangular
+            for (int j = 0; j < N; j++) {
+                Li[(size_t)j * N + j] = 1.0 / L[(size_t)j * N + j];
+                for (int i = j + 1; i < N; i++) {
+                    double v = 0.0;
+                    for (int k = j; k < i; k++) v -= L[(size_t)i * N + k] * Li[(size_t)k * N + j];
+                    Li[(size_t)i * N + j] = v / L[(size_t)i * N + i];
+                }
+            }
+            for (int i = 0; i < N; i++)
+                for (int j = 0; j <= i; j++) {
+                    double v = 0.0;
+                    for (int k = i; k < N; k++) v += Li[(size_t)k * N + i] * Li[(size_t)k * N + j];
+                    B[(size_t)i * N + j] = B[(size_t)j * N + i] = v; // B^-1 = L^-T L^-1
+                }
+            for (int t = 0; t < m; t++) { // minus the point blocks
+                const double *d = dinv_of_member + (size_t)(ptr[(size_t)c] + t) * 36;
+                for (int i = 0; i < 6; i++)
+                    for (int j = 0; j < 6; j++) B[(size_t)(6 * t + i) * N + 6 * t + j] -= d[6 * i + j];
+            }
+        }
+    }, 16);
+    return fell_back.load();
+}
+
+int32_t aggregate_nodes_glued(const Bsr &A, const std::vector<int32_t> &label, std::vector<int32_t> *aggout, const std::vector<int32_t> *visit)
+{
+    const int32_t n = A.nr;
+    int32_t nclusters = 0;
+    for (int32_t i = 0; i < n; i++) nclusters = std::max(nclusters, label[(size_t)i] + 1);
+    if (nclusters == 0) return aggregate_nodes(A, aggout, visit);
+    // quotient nodes in the order the visiting order meets them
+    std::vector<int32_t> qid((size_t)n, -1), q_of_cluster((size_t)nclusters, -1);
+    int32_t nq = 0;
+    const bool have_visit = visit != nullptr && (int32_t)visit->size() == n;
+    for (int32_t v = 0; v < n; v++) {
+        const int32_t i = have_visit ? (*visit)[(size_t)v] : v;
+        const int32_t c = label[(size_t)i];
+        if (c < 0) qid[(size_t)i] = nq++;
+        else {
+            if (q_of_cluster[(size_t)c] < 0) q_of_cluster[(size_t)c] = nq++;
+            qid[(size_t)i] = q_of_cluster[(size_t)c];
+        }
+    }
+    // members of the quotient nodes, then the quotient graph (rows sorted, the node itself included)
+    std::vector<int32_t> mptr((size_t)nq + 1, 0), mem((size_t)n);
+    for (int32_t i = 0; i < n; i++) mptr[(size_t)qid[(size_t)i] + 1]++;
+    for (int32_t q = 0; q < nq; q++) mptr[(size_t)q + 1] += mptr[(size_t)q];
+    {
+        std::vector<int32_t> fill(mptr.begin(), mptr.end() - 1);
+        for (int32_t i = 0; i < n; i++) mem[(size_t)fill[(size_t)qid[(size_t)i]]++] = i;
+    }
+    Bsr Q;
+    Q.nr = Q.nc = nq;
+    Q.ptr.assign((size_t)nq + 1, 0);
+    std::vector<std::vector<int32_t>> rows((size_t)nq);
+    parallel_chunks(nq, [&](int64_t q0, int64_t q1) {
+        for (int64_t q = q0; q < q1; q++) {
+            std::vector<int32_t> &r = rows[(size_t)q];
+            for (int32_t t = mptr[(size_t)q]; t < mptr[(size_t)q + 1]; t++) {
+                const int32_t i = mem[(size_t)t];
+                for (int64_t e = A.ptr[(size_t)i]; e < A.ptr[(size_t)i + 1]; e++) r.push_back(qid[(size_t)A.col[(size_t)e]]);
+            }
+            r.push_back((int32_t)q);
+            std::sort(r.begin(), r.end());
+            r.erase(std::unique(r.begin(), r.end()), r.end());
+        }
+    }, 1 << 10);
+    for (int32_t q = 0; q < nq; q++) Q.ptr[(size_t)q + 1] = Q.ptr[(size_t)q] + (int64_t)rows[(size_t)q].size();
+    Q.col.resize((size_t)Q.ptr[(size_t)nq]);
+    for (int32_t q = 0; q < nq; q++) std::copy(rows[(size_t)q].begin(), rows[(size_t)q].end(), Q.col.begin() + Q.ptr[(size_t)q]);
+    std::vector<int32_t> aq;
+    const int32_t na = aggregate_nodes(Q, &aq);
+    aggout->resize((size_t)n);
+    for (int32_t i = 0; i < n; i++) (*aggout)[(size_t)i] = aq[(size_t)qid[(size_t)i]];
+    return na;
+}
+
 void tentative_prolongator(const std::vector<int32_t> &agg, int32_t na, const std::vector<double> &B,
                            std::vector<double> *Qout, std::vector<double> *Bcout)
 {

@@ -29,6 +29,12 @@ int smooth_vectors_f32()
     return v < 0 ? 0 : (v > 2 ? 2 : v);
 }
 
+bool setup_verbose_flag()
+{
+    static const bool verbose = getenv("FEMSHELL_AMG_VERBOSE") && atoi(getenv("FEMSHELL_AMG_VERBOSE")) != 0;
+    return verbose;
+}
+
 double now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -88,6 +94,118 @@ struct PowerIteration {
     int G = 0, iterations = 0;
 };
 
+// FEMSHELL_AMG_PATCH_TAU (default 0.8; 0: no patch smoother) and FEMSHELL_AMG_PATCH_MAX (nodes per cluster, default 8): amg_patch.hpp
+double patch_tau()
+{
+    const char *e = getenv("FEMSHELL_AMG_PATCH_TAU"); // (read per setup: the tests switch it inside one process)
+    return e && *e ? atof(e) : 0.8;
+}
+int patch_max_nodes()
+{
+    const char *e = getenv("FEMSHELL_AMG_PATCH_MAX");
+    const int m = e && *e ? atoi(e) : 8;
+    return m < 2 ? 2 : (m > kPatchMaxNodes ? kPatchMaxNodes : m);
+}
+
+// When is a mesh one of poor element quality?  Edges above tau = 0.8 are ordinary on stretched structured elements (a third of the
+// edges of the pinched cylinder's 3 : 1 cells reach 0.836, the coupled flap's 5 : 1 cells 0.965) where the point-block method works;
+// what it does not cope with are NEARLY COINCIDENT nodes, sigma > 0.98: 2.6 % of the edges of the random-point shells, 0.13 % of a
+// jittered-grid Delaunay shell (which converges in 90 iterations without cluster blocks), none of any structured mesh.  The
+// clusters are built when more than FEMSHELL_AMG_PATCH_TRIGGER (default 0.01) of the pairs exceed 0.98; 0: whenever an edge exceeds tau.
+double patch_trigger()
+{
+    const char *e = getenv("FEMSHELL_AMG_PATCH_TRIGGER");
+    return e && *e ? atof(e) : 0.01;
+}
+constexpr double kPatchTriggerSigma = 0.98;
+
+// The clusters of rigidly coupled nodes of a level whose operator is in HBM (block-Jacobi inverse valid) and their smoother
+// blocks M_c: detection on the device (k_patch_sigma), the union of the edges and the 36 x 36 inverses on the host.  A level
+// without a rigid edge -- every structured mesh -- costs one kernel over its blocks and a four-byte copy, and keeps L.patches null.
+int amg_build_patches(femshell_ctx *c, const DeviceMatrix &A, AmgLevel &L, bool collective)
+{
+    L.patches.reset();
+    const double tau = patch_tau();
+    if (!(tau > 0.0) || A.n_own < 2 || A.minv == nullptr) return FEMSHELL_OK;
+    hipStream_t st = c->stream;
+    DevBuf<unsigned int> counter;
+    DevBuf<PatchEdge> edges;
+    FS_HIP(counter.alloc(4));
+    unsigned int cap = (unsigned int)std::max<int64_t>(65536, A.n_own), found = 0;
+    unsigned int counts[4] = {0, 0, 0, 0};
+    for (int attempt = 0; attempt < 2; attempt++) {
+        FS_HIP(edges.alloc(cap));
+        FS_HIP(counter.zero(st));
+        launch_patch_sigma(A, tau, kPatchTriggerSigma, edges.p, counter.p, cap, st);
+        FS_HIP(hipGetLastError());
+        FS_HIP(hipMemcpyAsync(counts, counter.p, sizeof counts, hipMemcpyDeviceToHost, st));
+        FS_HIP(hipStreamSynchronize(st));
+        found = counts[0];
+        if (found <= cap) break;
+        cap = found; // (more rigid edges than nodes: once more with room for all of them)
+    }
+    // the decision belongs to the whole mesh: the ranks of a row partition add their counts up
+    double high = counts[1], pairs = counts[2];
+    if (collective && c->comm.active()) {
+        DevBuf<double> sums;
+        FS_HIP(sums.alloc(2));
+        const double mine[2] = {high, pairs};
+        FS_HIP(hipMemcpyAsync(sums.p, mine, sizeof mine, hipMemcpyHostToDevice, st));
+        std::string e;
+        if (!comm_allreduce_sum(c->comm, sums.p, 2, st, &e)) return set_err(FEMSHELL_ERR_COMM, e);
+        double all[2] = {0.0, 0.0};
+        FS_HIP(hipMemcpyAsync(all, sums.p, sizeof all, hipMemcpyDeviceToHost, st));
+        FS_HIP(hipStreamSynchronize(st));
+        high = all[0];
+        pairs = all[1];
+    }
+    if (setup_verbose_flag())
+        fprintf(stderr, "[femshell amg setup] patch smoother: %u of %.0f pairs above sigma %.2f (%.0f above %.2f: %s)\n", found, pairs, tau, high,
+                kPatchTriggerSigma, high > patch_trigger() * pairs || (patch_trigger() <= 0.0 && found > 0) ? "a mesh of poor element quality" : "no clusters");
+    if (patch_trigger() > 0.0 ? !(high > patch_trigger() * pairs) : found == 0) return FEMSHELL_OK;
+    if (found == 0) return FEMSHELL_OK;
+    std::vector<PatchEdge> h((size_t)found);
+    FS_HIP(hipMemcpyAsync(h.data(), edges.p, h.size() * sizeof(PatchEdge), hipMemcpyDeviceToHost, st));
+    FS_HIP(hipStreamSynchronize(st));
+    auto P = std::make_shared<AmgPatches>();
+    P->tau = tau;
+    P->max_nodes = patch_max_nodes();
+    P->edges = found;
+    P->n_clusters = patch_clusters(A.n_own, std::move(h), P->max_nodes, &P->label, &P->h_ptr, &P->h_nodes);
+    if (P->n_clusters == 0) return FEMSHELL_OK;
+    P->n_members = (int32_t)P->h_nodes.size();
+    std::vector<int64_t> moff((size_t)P->n_clusters);
+    std::vector<int32_t> cluster_of((size_t)P->n_members);
+    int64_t total = 0;
+    for (int32_t k = 0; k < P->n_clusters; k++) {
+        const int64_t m = P->h_ptr[(size_t)k + 1] - P->h_ptr[(size_t)k];
+        moff[(size_t)k] = total;
+        total += 36 * m * m;
+        for (int32_t t = P->h_ptr[(size_t)k]; t < P->h_ptr[(size_t)k + 1]; t++) cluster_of[(size_t)t] = k;
+    }
+    FS_HIP(P->ptr.upload(P->h_ptr, st));
+    FS_HIP(P->nodes.upload(P->h_nodes, st));
+    FS_HIP(P->moff.upload(moff, st));
+    FS_HIP(P->cluster_of.upload(cluster_of, st));
+    FS_HIP(P->M.alloc((size_t)total));
+    DevBuf<double> dinv;
+    FS_HIP(dinv.alloc((size_t)P->n_members * 36));
+    launch_patch_gather(A, P->view(), P->M.p, dinv.p, st);
+    FS_HIP(hipGetLastError());
+    std::vector<double> hB((size_t)total), hD((size_t)P->n_members * 36);
+    FS_HIP(hipMemcpyAsync(hB.data(), P->M.p, hB.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    FS_HIP(hipMemcpyAsync(hD.data(), dinv.p, hD.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    FS_HIP(hipStreamSynchronize(st));
+    P->fell_back = patch_matrices(P->h_ptr, moff, hD.data(), hB.data());
+    FS_HIP(hipMemcpyAsync(P->M.p, hB.data(), hB.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    FS_HIP(hipStreamSynchronize(st)); // (hB goes out of scope)
+    if (setup_verbose_flag())
+        fprintf(stderr, "[femshell amg setup] patch smoother: %lld rigid edges (sigma > %.2f), %d clusters of %d nodes (at most %d each), %d not positive definite\n",
+                (long long)P->edges, tau, P->n_clusters, P->n_members, P->max_nodes, P->fell_back);
+    L.patches = P;
+    return FEMSHELL_OK;
+}
+
 int power_iteration_start(femshell_ctx *c, AmgLevel &L, const DeviceMatrix &A, int iterations, PowerIteration *pw)
 {
     hipStream_t st = c->stream;
@@ -102,6 +220,10 @@ int power_iteration_start(femshell_ctx *c, AmgLevel &L, const DeviceMatrix &A, i
     for (int it = 0; it < iterations; it++) {
         launch_spmv(A, x, L.q.p, nullptr, nullptr, st);
         launch_minv_apply_norm(A, L.q.p, z, pw->part.p + (size_t)(it & 1) * pw->G, st);
+        if (L.patches) { // the level's smoother applies the cluster blocks: lambda_max of THAT operator
+            launch_patch_correct(L.patches->view(), L.q.p, 1.0, z, false, nullptr, nullptr, st);
+            launch_sqnorm_partials(z, 6ll * L.n_pad, pw->part.p + (size_t)(it & 1) * pw->G, pw->G, st);
+        }
         std::swap(x, z);
     }
     FS_HIP(hipGetLastError());
@@ -337,47 +459,69 @@ int amg_setup(femshell_ctx *c)
     };
     int rc = FEMSHELL_OK;
     int first_level = 0;
-    if (!host_only && pl.n_own > opt.coarsest_nodes && opt.max_levels > 1) { // (small meshes: host algebra below)
+    // clusters of rigidly coupled nodes (amg_patch.hpp: none on a mesh of decent element quality); a mesh that has them takes the
+    // device path below whatever its size -- the host path has no cluster blocks
+    std::shared_ptr<AmgPatches> patches0;
+    if (!host_only && opt.max_levels > 1 && pl.n_own > kDirectNodes) {
+        AmgLevel probe;
+        probe.n = pl.n_own;
+        rc = amg_build_patches(c, c->dm, probe, false);
+        if (rc) return rc;
+        patches0 = probe.patches;
+        lap("patch smoother: clusters", 0);
+    }
+    if (!host_only && (pl.n_own > opt.coarsest_nodes || patches0) && opt.max_levels > 1) { // (small meshes: host algebra below)
         H.levels.emplace_back(new AmgLevel());
         AmgLevel &L0 = *H.levels.back();
         L0.n = pl.n_own;
         L0.n_pad = pl.n_pad;
         L0.nnzb = pl.nnz_blocks;
+        L0.patches = patches0;
         rc = alloc_level_vectors(L0, true, kcycle, st);
         if (rc) return rc;
-        PowerIteration pw0; // (its launches now, its result when the prolongator is smoothed: amg_device_coarsen asks for it)
-        rc = power_iteration_start(c, L0, c->dm, amg_power_iterations(), &pw0);
-        if (rc) return rc;
-        auto lam0 = [&](double *out) {
-            double lam = 0.0;
-            const int r2 = power_iteration_finish(c, pw0, &lam);
-            if (r2) return r2;
-            *out = L0.lam = amg_lambda_safety() * lam;
-            return (int)FEMSHELL_OK;
-        };
         H.levels.emplace_back(new AmgLevel());
         AmgLevel &L1 = *H.levels.back();
         std::vector<double> Bc;
         lap("node normals", 0);
         pattern_of_plan(pl, &L0.pattern);
         lap("pattern of K", 0);
-        {
-            // the near-null space of the finest level is generated from the mesh in HBM (never stored: n x 36 doubles)
-            NearNullSrc src;
-            DevBuf<double> d_normals;
-            src.xyz = c->xyz.p;
-            src.dmask = c->dmask.p;
-            if (!plain) {
-                FS_HIP(d_normals.upload(normals, st));
-                src.normals = d_normals.p;
-            }
-            double ctr[3];
-            mesh_centre(pl.n_own, pl.xyz_local.data(), ctr);
-            src.cx = ctr[0];
-            src.cy = ctr[1];
-            src.cz = ctr[2];
+        // the near-null space of the finest level is generated from the mesh in HBM (never stored: n x 36 doubles)
+        NearNullSrc src;
+        DevBuf<double> d_normals;
+        src.xyz = c->xyz.p;
+        src.dmask = c->dmask.p;
+        if (!plain) {
+            FS_HIP(d_normals.upload(normals, st));
+            src.normals = d_normals.p;
+        }
+        double ctr[3];
+        mesh_centre(pl.n_own, pl.xyz_local.data(), ctr);
+        src.cx = ctr[0];
+        src.cy = ctr[1];
+        src.cz = ctr[2];
+        // (with clusters: glued into aggregates; should an aggregate then be seen by more fine rows than a row of R holds, once more
+        //  without the gluing, and without the cluster blocks at all if that fails too)
+        for (int attempt = 0;; attempt++) {
+            PowerIteration pw0; // (its launches now, its result when the prolongator is smoothed: amg_device_coarsen asks for it)
+            rc = power_iteration_start(c, L0, c->dm, amg_power_iterations(), &pw0);
+            if (rc) return rc;
+            auto lam0 = [&](double *out) {
+                double lam = 0.0;
+                const int r2 = power_iteration_finish(c, pw0, &lam);
+                if (r2) return r2;
+                *out = L0.lam = amg_lambda_safety() * lam;
+                return (int)FEMSHELL_OK;
+            };
             rc = amg_device_coarsen(c, c->dm, L0.pattern, L0, L1, src, lam0, keep_host, want_host_matrix(1), &A, &Bc, &Bdev,
                                     [&](const char *what) { lap(what, 0); });
+            if (rc == FEMSHELL_ERR_UNSUPPORTED && L0.patches && attempt < 2) {
+                FS_HIP(hipStreamSynchronize(st)); // (the power iteration of this attempt)
+                if (L0.patches->glue) L0.patches->glue = false;
+                else L0.patches.reset();
+                if (setup_verbose_flag()) fprintf(stderr, "[femshell amg setup] patch smoother: %s\n", L0.patches ? "once more without gluing the clusters" : "given up for this mesh");
+                continue;
+            }
+            break;
         }
         if (rc) return rc;
         L0.pattern = HostEllPattern(); // (the plan holds it)
@@ -644,6 +788,10 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
             //  fallback of femshell_solve -- a collective rebuild -- relies on)
             const int32_t level_nodes = L.dist ? std::max(L.n, L.n_global) : L.n;
             if (mode == 0 || (mode == 2 && l > 0) || (mode == 1 && level_nodes < 4096) || A.vals == nullptr) continue;
+            // a level with clusters of rigidly coupled nodes keeps everything in double precision: what makes the clusters -- pairs of
+            // blocks that nearly cancel -- is what a product in single precision loses (the flexible CG broke down under the copies on
+            // every such shell tried, and the all-FP64 rebuild of femshell_solve did what this line does at once)
+            if (L.patches) continue;
             const int64_t nv = (l == 0 ? (int64_t)pl.total_slots() : (int64_t)L.A.vals.n / 36) * 36;
             {
                 FS_HIP(L.A32.alloc((size_t)nv));
@@ -850,6 +998,13 @@ struct Cycle {
     // (r_given: the residual of x, where the caller has it -- in L.r or a vector of its own, never L.q or L.d)
     // (d_started: the kernel that produced the residual took the first step too -- d = inv_theta D^-1 r in this vector, L.d or, on a
     //  full-storage level, L.q; x updated)
+    // the cluster blocks' share of a smoothing step that applied c D^-1 r with the point blocks (amg_patch.hpp): d += c M r, x += c M r
+    void patch(int l, const double *r, double coef, double *d, bool d_float, double *x)
+    {
+        AmgLevel &L = *H.levels[(size_t)l];
+        if (rc || !L.patches) return;
+        launch_patch_correct(L.patches->view(), r, coef, d, d_float, x, gate, st);
+    }
     void smooth(int l, const double *b, double *x, bool zero_guess, const double *r_given = nullptr, double *d_started = nullptr)
     {
         AmgLevel &L = *H.levels[(size_t)l];
@@ -865,13 +1020,17 @@ struct Cycle {
         if (d_started == nullptr) launch_cheb_start(A, rcur, L.d.p, x, L.inv_theta, !zero_guess, gate, st, v32);
         // full-storage levels: the direction alternates between the two vectors
         double *d_cur = d_started != nullptr ? d_started : L.d.p, *d_next = d_cur == L.d.p ? L.q.p : L.d.p;
+        const bool d_is_float = v32 == 2; // (the direction of a symmetric-storage level that keeps it in single precision)
+        patch(l, rcur, L.inv_theta, d_cur, d_is_float, x); // (behind a fused start as well: the kernel that took it applied the point blocks)
         for (size_t k = 0; k < L.cheb_a.size(); k++) {
             if (l == 0 && dist(0)) {
                 product0(L.d.p, L.q.p, A.symmetric != 0, &A, v32);
                 launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, A.symmetric != 0, v32);
+                patch(l, L.r.p, L.cheb_c[k], L.d.p, d_is_float, x);
             } else if (A.symmetric) { // first phase of the product; the step kernel collects the transposed products
                 sym_phase1(l, A, L.d.p, L.q.p);
                 launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st, true, v32);
+                patch(l, L.r.p, L.cheb_c[k], L.d.p, d_is_float, x);
             } else if (fused_cheb()) { // product and step in one launch (the small levels are bound by launch latency)
                 SpmvEpilogue e;
                 e.base_vec = rcur;
@@ -881,11 +1040,13 @@ struct Cycle {
                 e.a = L.cheb_a[k];
                 e.c = L.cheb_c[k];
                 full_product(l, A, d_cur, L.r.p, e);
+                patch(l, L.r.p, L.cheb_c[k], d_next, false, x);
                 std::swap(d_cur, d_next);
             } else {
                 halo(l, L.d.p);
                 launch_spmv(amg_level_matrix(c, l), L.d.p, L.q.p, nullptr, gate, st);
                 launch_cheb_step(A, rcur, L.q.p, L.r.p, L.d.p, x, L.cheb_a[k], L.cheb_c[k], gate, st);
+                patch(l, L.r.p, L.cheb_c[k], L.d.p, false, x);
             }
             rcur = L.r.p;
         }

@@ -966,6 +966,23 @@ int femshell_amg_level(femshell_ctx *c, int32_t level, femshell_amg_level_info *
     return FEMSHELL_OK;
 }
 
+int femshell_amg_patch_info(femshell_ctx *c, double out[6])
+{
+    if (!c || !out) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_patch_info: null argument");
+    if (!c->amg || !c->amg->valid || c->amg->levels.empty()) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_patch_info: no multigrid hierarchy");
+    for (int i = 0; i < 6; i++) out[i] = 0.0;
+    const AmgLevel &L = *c->amg->levels[0];
+    if (L.patches) {
+        out[0] = (double)L.patches->edges;
+        out[1] = L.patches->n_clusters;
+        out[2] = L.patches->n_members;
+        out[3] = L.patches->fell_back;
+        out[4] = L.patches->tau;
+        out[5] = L.patches->max_nodes;
+    }
+    return FEMSHELL_OK;
+}
+
 int femshell_amg_setup_stats(femshell_ctx *c, double out[7])
 {
     if (!c || !out) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_setup_stats: null argument");
@@ -1057,6 +1074,7 @@ int64_t femshell_amg_export(femshell_ctx *c, int32_t level, int32_t which, void 
         }
         return n * n;
     }
+    if (which == FEMSHELL_AMG_PATCH_LABELS) return L.patches ? give(L.patches->label.data(), L.patches->label.size(), sizeof(int32_t)) : -1;
     const Bsr &M = (which >= FEMSHELL_AMG_P_ROWPTR) ? L.hP : L.hA;
     switch (which) {
     case FEMSHELL_AMG_AGGREGATES: return L.agg.empty() ? -1 : give(L.agg.data(), L.agg.size(), sizeof(int32_t));

@@ -213,6 +213,47 @@ int32_t femshell_amg_host_aggregate(int32_t n_nodes, const int32_t *rowptr, cons
     return na;
 }
 
+int32_t femshell_amg_host_patch_clusters(int32_t n_nodes, const int32_t *rowptr, const int32_t *colidx, const double *vals, double tau,
+                                         int32_t max_nodes, int32_t *labels_out, int64_t *edges_out)
+{
+    if (n_nodes <= 0 || !rowptr || !colidx || !vals || !labels_out || !(tau > 0.0)) {
+        set_err(FEMSHELL_ERR_INVALID, "femshell_amg_host_patch_clusters: invalid argument");
+        return -1;
+    }
+    Bsr A;
+    if (!to_bsr(n_nodes, rowptr, colidx, vals, &A)) {
+        set_err(FEMSHELL_ERR_INVALID, "femshell_amg_host_patch_clusters: rows of the block CSR pattern must hold strictly ascending columns in [0, n_nodes)");
+        return -1;
+    }
+    std::vector<double> Dinv;
+    block_diagonal_inverse(A, &Dinv);
+    std::vector<PatchEdge> edges;
+    patch_edges_host(A, Dinv, tau, &edges);
+    if (edges_out) *edges_out = (int64_t)edges.size();
+    std::vector<int32_t> label, ptr, nodes;
+    const int32_t nc = patch_clusters(n_nodes, std::move(edges), max_nodes, &label, &ptr, &nodes);
+    std::memcpy(labels_out, label.data(), (size_t)n_nodes * sizeof(int32_t));
+    return nc;
+}
+
+int32_t femshell_amg_host_aggregate_glued(int32_t n_nodes, const int32_t *rowptr, const int32_t *colidx, const int32_t *labels,
+                                          const int32_t *visit, int32_t *agg_out)
+{
+    if (n_nodes <= 0 || !rowptr || !colidx || !labels || !agg_out || !pattern_ok(n_nodes, rowptr, colidx, n_nodes)) {
+        set_err(FEMSHELL_ERR_INVALID, "femshell_amg_host_aggregate_glued: invalid argument");
+        return -1;
+    }
+    Bsr A;
+    A.nr = A.nc = n_nodes;
+    A.ptr.assign(rowptr, rowptr + n_nodes + 1);
+    A.col.assign(colidx, colidx + rowptr[n_nodes]);
+    std::vector<int32_t> lab(labels, labels + n_nodes), agg, order;
+    if (visit) order.assign(visit, visit + n_nodes);
+    const int32_t na = aggregate_nodes_glued(A, lab, &agg, visit ? &order : nullptr);
+    std::memcpy(agg_out, agg.data(), (size_t)n_nodes * sizeof(int32_t));
+    return na;
+}
+
 void femshell_amg_coarsening_destroy(femshell_amg_coarsening *h) { delete h; }
 
 int64_t femshell_amg_coarsening_array(const femshell_amg_coarsening *h, int which, void *out)

@@ -205,11 +205,19 @@ enum { FEMSHELL_AMG_AGGREGATES = 0, /* int32 [n_nodes] */
        FEMSHELL_AMG_P_ROWPTR, FEMSHELL_AMG_P_COLS, FEMSHELL_AMG_P_VALS,
        /* the coarsest level only: the dense inverse the cycle multiplies with, double [n][n] row-major (n = 6 x its nodes;
         * the operator it inverts is that level's FEMSHELL_AMG_A_*, kept at every problem size) */
-       FEMSHELL_AMG_COARSE_INVERSE };
+       FEMSHELL_AMG_COARSE_INVERSE,
+       /* level 0: the cluster of rigidly coupled nodes every node belongs to, or -1 (the patch smoother of shells of poor element
+        * quality, csrc/amg_patch.hpp); -1 as a count: the level has no clusters.  int32 [n_nodes], internal numbering */
+       FEMSHELL_AMG_PATCH_LABELS };
 /* returns the element count of the array (-1: not available); copies it to out when out != NULL.  The host copies behind
  * the A_* / P_* / AGGREGATES arrays are kept for problems of up to 300,000 blocks of K (up to 2,000,000 with
  * FEMSHELL_AMG_KEEP_HOST=1 in the environment at setup): an inspection interface, not part of the solve */
 int64_t femshell_amg_export(femshell_ctx *ctx, int32_t level, int32_t which, void *out);
+/* the patch smoother of level 0 of the last setup (csrc/amg_patch.hpp; FEMSHELL_AMG_PATCH_TAU / _MAX in the environment): out[0] =
+ * rigid edges found (sigma_max of the scaled coupling above tau), out[1] = clusters, out[2] = nodes in clusters, out[3] = clusters
+ * whose diagonal block was not positive definite (they keep their point blocks), out[4] = tau, out[5] = nodes per cluster at most.
+ * All zero on a mesh without such edges: nothing of the method runs then. */
+int femshell_amg_patch_info(femshell_ctx *ctx, double out[6]);
 /* device timings of the first coarsening step of the last setup: out[0..3] = milliseconds of the prolongator, A P,
  * restriction and Galerkin kernels, out[4] = useful flops of the Galerkin product, out[5] = flops issued on the
  * matrix cores (v_mfma_f64_16x16x4_f64 tiles; 0 when the vector-ALU kernel ran), out[6] = 1 if the matrix cores ran */

@@ -103,6 +103,14 @@ int64_t femshell_amg_coarsening_array(const femshell_amg_coarsening *h, int whic
  * aggregates are those of the caller's numbering.  Returns the number of aggregates (< 0: invalid argument). */
 int32_t femshell_amg_host_aggregate(int32_t n_nodes, const int32_t *rowptr, const int32_t *colidx, const int32_t *visit,
                                     int32_t *agg_out);
+/* the patch smoother's clusters of rigidly coupled nodes on a host matrix (csrc/amg_patch.hpp; the device finds them with the same
+ * arithmetic): labels_out[i] = cluster of node i or -1, clusters numbered by their smallest node.  Returns the number of clusters
+ * (< 0: invalid argument); *edges_out (may be NULL) = rigid edges found. */
+int32_t femshell_amg_host_patch_clusters(int32_t n_nodes, const int32_t *rowptr, const int32_t *colidx, const double *vals, double tau,
+                                         int32_t max_nodes, int32_t *labels_out, int64_t *edges_out);
+/* the aggregation with every cluster (labels: cluster of a node or -1) glued into one node first */
+int32_t femshell_amg_host_aggregate_glued(int32_t n_nodes, const int32_t *rowptr, const int32_t *colidx, const int32_t *labels,
+                                          const int32_t *visit, int32_t *agg_out);
 /* dense inverse of a small SPD block matrix (coarsest level): inv_out (6n)^2 doubles */
 int femshell_amg_host_dense_inverse(int32_t n_nodes, const int32_t *rowptr, const int32_t *colidx, const double *vals,
                                     double *inv_out);

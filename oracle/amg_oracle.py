@@ -256,6 +256,143 @@ def bd_matrix(Dinv):
     return sp.bsr_matrix((Dinv, np.arange(n, dtype=np.int32), np.arange(n + 1, dtype=np.int32)), shape=(6 * n, 6 * n))
 
 
+# ---- patch smoother: clusters of rigidly coupled nodes (csrc/amg_patch.hpp) ---------------------------------------------
+
+PATCH_POWER_STEPS = 16
+
+
+def patch_sigma2(Di, A, Dj, tau2):
+    """csrc/amg_patch.hpp patch_sigma2, over arrays of blocks: trace(Di A Dj A^T) where it is below tau2, else the norm ratio of the
+    last of 16 power steps on T = Di A Dj A^T from the vector of ones."""
+    Y = np.einsum("eab,ebc,ecd->ead", Di, A, Dj)
+    tr = np.einsum("eab,eab->e", Y, A)
+    out = tr.copy()
+    go = np.flatnonzero(tr >= tau2)
+    if len(go):
+        Yg, Ag = Y[go], A[go]
+        v = np.ones((len(go), 6))
+        lam = np.zeros(len(go))
+        for _ in range(PATCH_POWER_STEPS):
+            w = np.einsum("eij,ei->ej", Ag, v)
+            u = np.einsum("eij,ej->ei", Yg, w)
+            nv, nu = np.einsum("ei,ei->e", v, v), np.einsum("ei,ei->e", u, u)
+            ok = (nu > 0.0) & (nv > 0.0)
+            lam = np.where(ok, np.sqrt(np.where(ok, nu / np.where(nv > 0, nv, 1.0), 0.0)), 0.0)
+            v = np.where(ok[:, None], u / np.sqrt(np.where(nu > 0, nu, 1.0))[:, None], v)
+        out[go] = lam
+    return out
+
+
+def patch_edges(A, Dinv, tau):
+    """Rigid edges (a < c, sigma2) of a level: csrc/amg_kernels.hip k_patch_sigma / amg_setup.cpp patch_edges_host."""
+    A = A.tobsr((6, 6))
+    A.sort_indices()
+    n = A.shape[0] // 6
+    rows = np.repeat(np.arange(n), np.diff(A.indptr))
+    up = np.flatnonzero(A.indices > rows)
+    s2 = patch_sigma2(Dinv[rows[up]], A.data[up], Dinv[A.indices[up]], tau * tau)
+    keep = s2 > tau * tau
+    return rows[up][keep], A.indices[up][keep], s2[keep]
+
+
+def patch_clusters(n, ea, ec, s2, max_nodes=6):
+    """csrc/amg_setup.cpp patch_clusters: edges strongest first (ties: lower a, then lower c), two clusters are united while the
+    union stays within max_nodes; clusters numbered by their smallest node.  Returns (label per node or -1, ptr, nodes)."""
+    order = np.lexsort((ec, ea, -s2))
+    parent = np.arange(n)
+    size = np.ones(n, dtype=np.int64)
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+    for e in order:
+        ra, rc = find(int(ea[e])), find(int(ec[e]))
+        if ra == rc or size[ra] + size[rc] > max_nodes:
+            continue
+        if rc < ra:
+            ra, rc = rc, ra
+        parent[rc] = ra
+        size[ra] += size[rc]
+    roots = np.array([find(i) for i in range(n)])
+    label = -np.ones(n, dtype=np.int64)
+    ids = {}
+    for i in range(n):
+        r = roots[i]
+        if size[r] < 2:
+            continue
+        label[i] = ids.setdefault(int(r), len(ids))
+    nc = len(ids)
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(label[label >= 0], minlength=nc))]).astype(np.int64)
+    nodes = np.argsort(label[label >= 0], kind="stable")
+    nodes = np.flatnonzero(label >= 0)[nodes]
+    return label, ptr, nodes
+
+
+def patch_block_inverse(A, Dinv, label, ptr, nodes):
+    """The smoother's block inverse with one block per cluster: the exact inverse of the cluster's diagonal block of A (point
+    blocks where that block is not positive definite, and for every node outside a cluster).  Sparse (6 n) x (6 n)."""
+    A = A.tocsr()
+    n = len(Dinv)
+    rows, cols, vals = [], [], []
+    single = np.flatnonzero(label < 0)
+    fell_back = 0
+    for c in range(len(ptr) - 1):
+        mem = nodes[ptr[c]:ptr[c + 1]]
+        idx = (6 * mem[:, None] + np.arange(6)[None, :]).ravel()
+        B = A[idx][:, idx].toarray()
+        B = 0.5 * (B + B.T)
+        try:
+            np.linalg.cholesky(B)
+            Bi = np.linalg.inv(B)
+        except np.linalg.LinAlgError:
+            fell_back += 1
+            single = np.concatenate([single, mem])
+            continue
+        rr, cc = np.meshgrid(idx, idx, indexing="ij")
+        rows.append(rr.ravel())
+        cols.append(cc.ravel())
+        vals.append(Bi.ravel())
+    for i in single:
+        idx = 6 * i + np.arange(6)
+        rr, cc = np.meshgrid(idx, idx, indexing="ij")
+        rows.append(rr.ravel())
+        cols.append(cc.ravel())
+        vals.append(Dinv[i].ravel())
+    return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(6 * n, 6 * n))
+
+
+def aggregate_glued(rowptr, colidx, label, visit=None):
+    """csrc/amg_setup.cpp aggregate_nodes_glued: every cluster is one node of the quotient graph (quotient nodes numbered in the
+    order the visiting order meets them), the greedy passes run there, a cluster's nodes share their quotient node's aggregate."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    colidx = np.asarray(colidx, dtype=np.int64)
+    n = len(rowptr) - 1
+    if not np.any(label >= 0):
+        return aggregate(rowptr, colidx, visit)
+    qid = -np.ones(n, dtype=np.int64)
+    q_of_cluster = {}
+    nq = 0
+    for i in (range(n) if visit is None else [int(v) for v in visit]):
+        c = int(label[i])
+        if c < 0:
+            qid[i] = nq
+            nq += 1
+        else:
+            if c not in q_of_cluster:
+                q_of_cluster[c] = nq
+                nq += 1
+            qid[i] = q_of_cluster[c]
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    G = sp.csr_matrix((np.ones(len(colidx)), (qid[rows], qid[colidx])), shape=(nq, nq))
+    G = (G + sp.identity(nq, format="csr")).tocsr()
+    G.sum_duplicates()
+    G.sort_indices()
+    aq, na = aggregate(G.indptr, G.indices)
+    return aq[qid], na
+
+
 def aggregate_by_rank(rowptr, colidx, bounds):
     """Aggregation of a level whose rows are split over ranks (csrc/amg_dist.cpp): every rank aggregates the graph of its
     own rows without the edges that leave it -- aggregates never span ranks -- and the aggregates are numbered rank by
@@ -277,7 +414,7 @@ def aggregate_by_rank(rowptr, colidx, bounds):
     return agg, cb[-1], cb
 
 
-def coarsen(A, B, lam, bounds=None):
+def coarsen(A, B, lam, bounds=None, patch=None):
     """One coarsening step with the upper spectral bound lam of D^-1 A: returns (agg, P, Ac, Bc), and the coarse row
     boundaries as a fifth item when the level is split over ranks (bounds: its row boundaries).  Only the aggregation knows
     about the ranks: tentative prolongator, smoothing with the whole A and the Galerkin product are the single-rank ones (the
@@ -285,13 +422,17 @@ def coarsen(A, B, lam, bounds=None):
     A = A.tobsr((6, 6))
     A.sort_indices()
     n = A.shape[0] // 6
+    # (patch = (label, Dm): the level's clusters of rigidly coupled nodes -- glued into one node each before the greedy passes -- and
+    #  its block inverse with one block per cluster, which smooths the prolongator too: csrc/amg_patch.hpp)
     if bounds is not None:
         agg, na, cbounds = aggregate_by_rank(A.indptr, A.indices, bounds)
+    elif patch is not None:
+        agg, na = aggregate_glued(A.indptr, A.indices, patch[0])
     else:
         agg, na = aggregate(A.indptr, A.indices)
     Q, Bc = tentative(agg, na, B)
     P0 = sp.bsr_matrix((Q, agg.astype(np.int32), np.arange(n + 1, dtype=np.int32)), shape=(6 * n, 6 * na))
-    Dm = bd_matrix(block_diag_inverse(A))
+    Dm = patch[1] if patch is not None else bd_matrix(block_diag_inverse(A))
     P = (P0 - ((4.0 / 3.0) / lam) * (Dm @ (A @ P0))).tobsr((6, 6))
     Ac = (P.T @ (A @ P)).tobsr((6, 6))
     # coarse dofs without fine support: unit diagonal
@@ -328,7 +469,7 @@ def partition_bounds_equal(n, world):
 
 
 def setup(A, xyz, dmask, lams=None, coarsest_nodes=200, max_levels=12, eig_ratio=30.0, degree=3, coarse_degree=4,
-          tri=None, quad=None, bounds=None, dist_min=60000):
+          tri=None, quad=None, bounds=None, dist_min=60000, patch_tau=None, patch_max=6, patch_labels=None):
     """lams: upper bounds of the spectrum per level as the library reports them (femshell_amg_level); computed
     here (1.1 x power iteration) when None.  tri / quad: connectivity for the node normals of rigid_body_modes.
     bounds: row boundaries of a row-partitioned context (world + 1 entries): level 0, and every coarser level of more than
@@ -344,6 +485,23 @@ def setup(A, xyz, dmask, lams=None, coarsest_nodes=200, max_levels=12, eig_ratio
         L.Dm = bd_matrix(block_diag_inverse(A))
         levels.append(L)
         li = len(levels) - 1
+        L.patch = None
+        if li == 0 and (patch_tau or patch_labels is not None) and bounds is None:
+            # the patch smoother of level 0 (csrc/amg_patch.hpp): clusters from the rigid edges -- or the labels the library reports --
+            # and the block inverse with one block per cluster in the smoother, the spectral bound and the smoothing of P
+            Dinv = block_diag_inverse(A)
+            if patch_labels is not None:
+                label = np.asarray(patch_labels, dtype=np.int64)
+                nc = int(label.max()) + 1 if len(label) else 0
+                ptr = np.concatenate([[0], np.cumsum(np.bincount(label[label >= 0], minlength=nc))]).astype(np.int64)
+                nodes = np.flatnonzero(label >= 0)[np.argsort(label[label >= 0], kind="stable")]
+            else:
+                ea, ec, s2 = patch_edges(A, Dinv, patch_tau)
+                label, ptr, nodes = patch_clusters(L.n, ea, ec, s2, patch_max)
+            if len(ptr) > 1:
+                L.Dm = patch_block_inverse(A, Dinv, label, ptr, nodes)
+                L.patch = (label, L.Dm)
+                L.patch_label = label
         split = bounds is not None and (li == 0 or L.n > dist_min)
         L.bounds = list(bounds) if split else None
         # (K itself is the coarsest level only up to 200 nodes: csrc/amg_device.hpp kDirectNodes)
@@ -355,7 +513,7 @@ def setup(A, xyz, dmask, lams=None, coarsest_nodes=200, max_levels=12, eig_ratio
         if split:
             L.agg, L.P, Ac, B, bounds = coarsen(A, B, L.lam, bounds)
         else:
-            L.agg, L.P, Ac, B = coarsen(A, B, L.lam)
+            L.agg, L.P, Ac, B = coarsen(A, B, L.lam, patch=L.patch)
             bounds = None
         L.R = L.P.T.tobsr((6, 6))
         deg = degree if li == 0 else coarse_degree

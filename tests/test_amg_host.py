@@ -395,3 +395,88 @@ def test_chunked_aggregation_equals_the_restatement_whatever_the_thread_count(mo
     agg1_o, na1_o = amg_oracle.aggregate(rpp, cip, visit=perm)
     np.testing.assert_array_equal(agg1, agg1_o)
     assert na1 == na1_o
+
+
+def _poor_shell(n_pts, seed):
+    from tests.test_gpu_parity import delaunay_shell
+
+    xyz, tri = delaunay_shell(n_pts, seed)
+    n = len(xyz)
+    dmask = np.zeros(n, dtype=np.uint8)
+    dmask[xyz[:, 0] < 0.15] = 0x3F
+    loads = np.zeros((n, 6))
+    loads[:, 2] = 1.0
+    rp, ci, vals, F = oracle.assemble(xyz, tri, np.zeros((0, 4), np.int32), oracle.material(0.3, 7.0e4, 0.03), dmask, loads)
+    return xyz, tri, dmask, rp, ci, vals, F
+
+
+def test_patch_smoother_clusters_and_glued_aggregation_follow_the_restatement():
+    """Round 6, csrc/amg_patch.hpp: on a random-point Delaunay shell (nodes a hundredth of the mesh width apart) the edges with
+    sigma_max(D_i^-1/2 A_ij D_j^-1/2) > tau are united into clusters of bounded size, and the aggregation glues every cluster into one
+    node first.  Host side of the library (the device finds the edges with the same arithmetic, amg_patch.hpp patch_sigma2) against
+    oracle/amg_oracle.py: same edges' count, same labels, same aggregates; the estimate of sigma against numpy's SVD; a structured
+    mesh has no such edge."""
+    ensure_built()
+    b = _binding()
+    xyz, tri, dmask, rp, ci, vals, F = _poor_shell(1200, 4)
+    A = oracle.to_scipy(rp, ci, vals).tobsr((6, 6))
+    A.sort_indices()
+    n = len(xyz)
+    Dinv = amg_oracle.block_diag_inverse(A)
+    for tau, mx in ((0.8, 8), (0.7, 6), (0.9, 3)):
+        labels, nc, edges = b.amg_host_patch_clusters(rp, ci, vals, tau=tau, max_nodes=mx)
+        ea, ec, s2 = amg_oracle.patch_edges(A, Dinv, tau)
+        lab_o, ptr_o, nodes_o = amg_oracle.patch_clusters(n, ea, ec, s2, mx)
+        assert edges == len(ea) and nc == len(ptr_o) - 1 and nc > 50
+        np.testing.assert_array_equal(labels, lab_o)
+        sizes = np.bincount(labels[labels >= 0])
+        assert sizes.min() >= 2 and sizes.max() <= mx
+        first = [int(np.flatnonzero(labels == k)[0]) for k in range(nc)]
+        assert first == sorted(first)  # clusters numbered by their smallest node
+    # the estimate against the singular values: every edge it keeps is rigid by numpy's SVD too (the power steps approach from
+    # below), and it misses none that is rigid by a margin
+    rows = np.repeat(np.arange(n), np.diff(A.indptr))
+    up = np.flatnonzero(A.indices > rows)
+    Li = np.linalg.inv(np.linalg.cholesky(amg_oracle.block_diag(A)))
+    S = np.einsum("eab,ebc,edc->ead", Li[rows[up]], A.data[up], Li[A.indices[up]])
+    sv = np.linalg.svd(S, compute_uv=False)[:, 0]
+    ea, ec, s2 = amg_oracle.patch_edges(A, Dinv, 0.8)
+    kept = set(zip(ea.tolist(), ec.tolist()))
+    exact = {(int(rows[e]), int(A.indices[e])): sv[k] for k, e in enumerate(up)}
+    assert all(exact[e] > 0.8 * (1 - 1e-9) for e in kept)
+    assert all(e in kept for e, s in exact.items() if s > 0.81)
+    est = dict(zip(zip(ea.tolist(), ec.tolist()), np.sqrt(s2)))
+    assert max(abs(est[e] - exact[e]) / exact[e] for e in kept) < 0.05  # (16 power steps on a non-symmetric T)
+    # glued aggregation: library == restatement, the nodes of a cluster share an aggregate, with and without a visiting order
+    labels, nc, _ = b.amg_host_patch_clusters(rp, ci, vals, tau=0.8, max_nodes=8)
+    agg, na = b.amg_host_aggregate_glued(rp, ci, labels)
+    agg_o, na_o = amg_oracle.aggregate_glued(rp, ci, labels.astype(np.int64))
+    np.testing.assert_array_equal(agg, agg_o)
+    assert na == na_o
+    for k in range(nc):
+        assert len(set(agg[labels == k].tolist())) == 1
+    perm = np.random.default_rng(9).permutation(n)
+    agg_v, na_v = b.amg_host_aggregate_glued(rp, ci, labels, visit=perm)
+    agg_vo, na_vo = amg_oracle.aggregate_glued(rp, ci, labels.astype(np.int64), visit=perm)
+    np.testing.assert_array_equal(agg_v, agg_vo)
+    # a structured panel: no rigid edge at all
+    _, _, rps, cis, vs, _ = _problem("panel")
+    lab_s, nc_s, edges_s = b.amg_host_patch_clusters(rps, cis, vs, tau=0.8, max_nodes=8)
+    assert nc_s == 0 and edges_s == 0 and (lab_s == -1).all()
+
+
+def test_patch_smoother_restatement_converges_where_point_blocks_do_not():
+    """The numpy restatement of the method on a 1200-point shell: with the cluster blocks (smoother, spectral bound, smoothing of P,
+    glued aggregates) the solve converges in a few hundred iterations; with point blocks alone it does not within 600."""
+    xyz, tri, dmask, rp, ci, vals, F = _poor_shell(1200, 4)
+    A = oracle.to_scipy(rp, ci, vals).tobsr((6, 6))
+    A.sort_indices()
+    lv = amg_oracle.setup(A, xyz, dmask, tri=tri, coarsest_nodes=200, patch_tau=0.8, patch_max=8)
+    assert lv[0].patch is not None
+    u, h = amg_oracle.solve(A, F.ravel(), lv, rtol=1e-10, max_it=600, refine_passes=1)
+    assert len(h) < 450 and h[-1] < 1e-6, (len(h), h[-1])
+    u0 = oracle.refined_solve(rp, ci, vals, F)
+    assert np.linalg.norm(u - u0) <= 1e-6 * np.linalg.norm(u0)
+    plain = amg_oracle.setup(A, xyz, dmask, tri=tri, coarsest_nodes=200)
+    _, hp = amg_oracle.solve(A, F.ravel(), plain, rtol=1e-10, max_it=600, refine_passes=1)
+    assert len(hp) == 600 or len(hp) > 1.5 * len(h), (len(hp), len(h))

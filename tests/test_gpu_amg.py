@@ -215,13 +215,15 @@ def test_very_thin_strip_keeps_its_coarsest_inverse_in_double_precision(monkeypa
     fs.close()
 
 
-def test_breakdown_under_single_precision_copies_runs_again_in_double_precision():
-    # an unstructured Delaunay shell of poor element quality (the mesh of tests/test_gpu_parity.py): the multigrid does not
-    # converge on it in either precision, but with the single-precision copies the flexible CG breaks
+def test_breakdown_under_single_precision_copies_runs_again_in_double_precision(monkeypatch):
+    # an unstructured Delaunay shell of poor element quality (the mesh of tests/test_gpu_parity.py) WITHOUT the patch smoother of
+    # round 6 (FEMSHELL_AMG_PATCH_TAU=0: with it the level keeps FP64 copies from the start and the solve converges, below): the
+    # point-block multigrid does not converge on it in either precision, but with the single-precision copies the flexible CG breaks
     # down early (p.Ap <= 0).  femshell_solve then builds the hierarchy again, all FP64, runs the solve from the start and
     # says so; the context stays with that choice
     from tests.test_gpu_parity import delaunay_shell
 
+    monkeypatch.setenv("FEMSHELL_AMG_PATCH_TAU", "0")
     ensure_built()
     xyz, tri = delaunay_shell(20000, 3)
     dmask = np.zeros(len(xyz), dtype=np.uint8)
@@ -653,3 +655,122 @@ def test_solve_from_an_initial_guess(pc):
         fs2.set_initial_guess(None)
     fs2.close()
     fs.close()
+
+
+def _poor_shell(n_pts, seed, along_x=False):
+    from tests.test_gpu_parity import delaunay_shell
+
+    xyz, tri = delaunay_shell(n_pts, seed)
+    if along_x:  # numbered along x, as tests/helpers/multirank_worker.py numbers the same shell for several ranks
+        order = np.argsort(xyz[:, 0], kind="stable")
+        inv = np.empty_like(order)
+        inv[order] = np.arange(len(order))
+        xyz, tri = np.ascontiguousarray(xyz[order]), inv[tri].astype(np.int32)
+    n = len(xyz)
+    dmask = np.zeros(n, dtype=np.uint8)
+    dmask[xyz[:, 0] < 0.15] = 0x3F
+    loads = np.zeros((n, 6))
+    loads[:, 2] = 1.0
+    return xyz, tri, dmask, loads
+
+
+def test_patch_smoother_on_a_shell_of_poor_element_quality_follows_the_restatement(monkeypatch):
+    """Round 6, csrc/amg_patch.hpp: a 3000-point random Delaunay shell -- nodes a hundredth of the mesh width
+    apart -- on which the point-block multigrid does not converge.  The clusters the device finds equal the restatement's, the
+    hierarchy (glued aggregates, P smoothed with the cluster blocks, Galerkin operator, spectral bound) equals the restatement's
+    level by level, the solve converges in about the restatement's iterations, without the FP64 rebuild, to the direct solve's answer;
+    switched off (FEMSHELL_AMG_PATCH_TAU=0) the same solve does not converge in twice as many iterations."""
+    ensure_built()
+    xyz, tri, dmask, loads = _poor_shell(3000, 2)
+    n = len(xyz)
+    fs = pkg.FemShell(0.3, 7.0e4, 0.03, device=0)
+    fs.set_mesh(xyz, tri)
+    fs.set_dirichlet(dmask)
+    fs.set_loads(loads)
+    fs.set_preconditioner("amg")
+    u, info = fs.solve(rtol=1e-10, max_it=600)
+    assert info["converged"] == 1 and info["pc_fp64_fallback"] == 0 and info["iterations"] <= 400, info
+    pi = fs.amg_patch_info()
+    assert pi["clusters"] > 500 and pi["nodes_in_clusters"] > 1500 and pi["not_positive_definite"] == 0 and pi["max_nodes"] == 8
+    lv = fs.amg_levels()
+    rg, cg, vg, Fg = fs.export_bsr()
+    A = _bsr(rg, cg, vg, n)
+    ex = fs.amg_export(0)
+    labels = ex["patch_labels"]
+    Dinv = amg_oracle.block_diag_inverse(A)
+    ea, ec, s2 = amg_oracle.patch_edges(A, Dinv, 0.8)
+    lab_o, ptr_o, nodes_o = amg_oracle.patch_clusters(n, ea, ec, s2, 8)
+    # (an edge whose sigma sits within rounding of tau may fall on either side -- the device contracts its products into FMAs --: the
+    #  two edge sets agree up to a handful of edges and the partitions up to the clusters those touch; the hierarchy below is restated
+    #  from the library's own labels)
+    assert abs(pi["rigid_edges"] - len(ea)) <= 3, (pi["rigid_edges"], len(ea))
+    members = lambda lab: [frozenset(np.flatnonzero(lab == lab[i]).tolist()) if lab[i] >= 0 else frozenset([i]) for i in range(n)]  # noqa: E731
+    differing = sum(a != b for a, b in zip(members(labels), members(lab_o)))
+    assert differing <= 24, differing
+    sizes = np.bincount(labels[labels >= 0])
+    assert sizes.min() >= 2 and sizes.max() <= 8
+    levels = amg_oracle.setup(A, xyz, dmask, lams=[l["lambda_max"] for l in lv], coarsest_nodes=1400, tri=tri, patch_labels=labels)
+    assert [L.n for L in levels] == [l["n_nodes"] for l in lv]
+    np.testing.assert_array_equal(ex["agg"], levels[0].agg)
+    P = _bsr(ex["P_rowptr"], ex["P_cols"], ex["P_vals"], lv[0]["n_coarse"])
+    # (the inverses of cluster blocks whose nodes nearly coincide -- condition numbers of 1e8 and beyond -- come out of two different
+    #  factorisations: P agrees to the digits those leave, where it agrees to 1e-11 on meshes without clusters)
+    assert abs(P - levels[0].P).max() <= 2e-6 * abs(levels[0].P).max()
+    ex1 = fs.amg_export(1)
+    A1 = _bsr(ex1["A_rowptr"], ex1["A_cols"], ex1["A_vals"], lv[1]["n_nodes"])
+    assert abs(A1 - levels[1].A).max() <= 1e-5 * abs(levels[1].A).max()
+    assert 0.9 * lv[0]["lambda_max"] <= 1.1 * amg_oracle.lambda_max(levels[0].A, levels[0].Dm, 60) <= 1.25 * lv[0]["lambda_max"]
+    u0, hist = amg_oracle.solve(A, Fg, levels, rtol=1e-10, max_it=600, refine_passes=1)
+    assert abs(len(hist) - info["iterations"]) <= 0.1 * len(hist) + 5, (len(hist), info["iterations"])
+    # (slivers make these systems so ill-conditioned that the refined direct solve itself is good to 1e-7 or so:
+    #  tests/test_gpu_parity.py test_unstructured_delaunay_shell holds its 700-point sibling to 1e-5)
+    ug = oracle.refined_solve(rg, cg, vg, Fg)
+    assert np.linalg.norm(u.ravel() - ug) / np.linalg.norm(ug) < 1e-6
+    assert np.linalg.norm(u.ravel() - u0) / np.linalg.norm(u0) < 1e-6
+    fs.close()
+    monkeypatch.setenv("FEMSHELL_AMG_PATCH_TAU", "0")
+    fs = pkg.FemShell(0.3, 7.0e4, 0.03, device=0)
+    fs.set_mesh(xyz, tri)
+    fs.set_dirichlet(dmask)
+    fs.set_loads(loads)
+    fs.set_preconditioner("amg")
+    _, info0 = fs.solve(rtol=1e-10, max_it=2 * info["iterations"])
+    assert info0["converged"] == 0 and fs.amg_patch_info()["clusters"] == 0
+    fs.close()
+
+
+def test_patch_smoother_takes_the_20k_point_shell_below_400_iterations():
+    """The shell of tests/test_multirank_gpu.py (20,000 random points, numbered along x): > 1000 iterations with point blocks in
+    rounds 3-5; with the cluster blocks <= 400, no FP64 rebuild, answer equal to the refined direct solve's."""
+    ensure_built()
+    xyz, tri, dmask, loads = _poor_shell(20000, 3, along_x=True)
+    fs = pkg.FemShell(0.3, 7.0e4, 0.03, device=0)
+    fs.set_mesh(xyz, tri)
+    fs.set_dirichlet(dmask)
+    fs.set_loads(loads)
+    fs.set_preconditioner("amg")
+    u, info = fs.solve(rtol=1e-10, max_it=600)
+    assert info["converged"] == 1 and info["pc_fp64_fallback"] == 0 and info["iterations"] <= 400, info
+    rg, cg, vg, Fg = fs.export_bsr()
+    ug = oracle.refined_solve(rg, cg, vg, Fg)
+    assert np.linalg.norm(u.ravel() - ug) / np.linalg.norm(ug) < 1e-5
+    fs.close()
+
+
+def test_structured_meshes_have_no_clusters_and_keep_their_bits(monkeypatch):
+    """No rigid edge on a mesh of decent element quality: nothing of the patch smoother runs, hierarchy and iterates are the ones of
+    FEMSHELL_AMG_PATCH_TAU=0 bit for bit."""
+    m, mat = _make("cylinder", 48)
+    out = []
+    for tau in (None, "0"):
+        if tau is not None:
+            monkeypatch.setenv("FEMSHELL_AMG_PATCH_TAU", tau)
+        fs = _context(m, mat)
+        fs.set_preconditioner("amg", coarsest_nodes=60)
+        u, info = fs.solve(rtol=1e-10, max_it=400)
+        assert fs.amg_patch_info()["rigid_edges"] == 0 and fs.amg_export(0)["patch_labels"] is None
+        out.append((u.copy(), info["iterations"], fs.residual_history().copy()))
+        fs.close()
+    assert out[0][1] == out[1][1]
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][2], out[1][2])
