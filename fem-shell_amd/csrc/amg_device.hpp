@@ -65,6 +65,10 @@ struct AmgPatches {
     DevBuf<int64_t> moff;
     DevBuf<double> M;
     std::vector<int32_t> label; // per node: its cluster or -1
+    // ... and the same without the clusters that hold a node another rank reads (row-partitioned levels): those smooth -- a purely
+    // local matter -- but neither widen their members' rows of P nor are glued (amg_solve.cpp amg_build_patches)
+    std::vector<int32_t> label_p;
+    DevBuf<uint8_t> in_p;
     std::vector<int32_t> h_ptr, h_nodes;
     PatchView view() const
     {
@@ -76,6 +80,7 @@ struct AmgPatches {
         v.moff = moff.p;
         v.M = M.p;
         v.cluster_of = cluster_of.p;
+        v.in_p = in_p.p;
         return v;
     }
 };
@@ -225,5 +230,10 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &A, const HostEllPatt
                        const std::function<void(const char *)> &lap);
 // the pattern of the context's K (level 0) from the plan
 void pattern_of_plan(const Plan &p, HostEllPattern *out);
+
+// clusters of rigidly coupled nodes of a level whose operator is in HBM, and their smoother blocks (amg_solve.cpp; amg_patch.hpp).
+// collective: the ranks of a row partition decide together whether the mesh needs them.  L.patches stays null when it does not.
+// excluded (optional, one flag per own node): nodes no cluster may take -- those another rank reads.
+int amg_build_patches(femshell_ctx *c, const DeviceMatrix &A, AmgLevel &L, bool collective, const std::vector<uint8_t> *excluded = nullptr);
 
 } // namespace femshell

@@ -257,7 +257,7 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     const bool finest_renumbered = &Adev == &c->dm && !c->iperm.empty() && (int32_t)c->iperm.size() == n;
     // (clusters of rigidly coupled nodes -- amg_patch.hpp -- are glued into one node each before the greedy passes)
     const AmgPatches *patches = L.patches.get();
-    const int32_t na = (patches && patches->glue) ? aggregate_nodes_glued(G, patches->label, &agg, finest_renumbered ? &c->iperm : nullptr)
+    const int32_t na = (patches && patches->glue) ? aggregate_nodes_glued(G, patches->label_p, &agg, finest_renumbered ? &c->iperm : nullptr)
                                : aggregate_nodes(G, &agg, finest_renumbered ? &c->iperm : nullptr);
     lap("  aggregation");
     // tentative prolongator on the device: QR of every aggregate's rows of B, one wave each (k_amg_tentative_qr); the host
@@ -316,8 +316,8 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
             }, 64);
         parallel_chunks(n, [&](int64_t a0, int64_t a1) {
             for (int64_t a = a0; a < a1; a++) {
-                if (patches && patches->label[(size_t)a] >= 0) {
-                    cnt[a] = (uint8_t)std::min<size_t>(cluster_rows[(size_t)patches->label[(size_t)a]].size(), 255);
+                if (patches && patches->label_p[(size_t)a] >= 0) {
+                    cnt[a] = (uint8_t)std::min<size_t>(cluster_rows[(size_t)patches->label_p[(size_t)a]].size(), 255);
                     continue;
                 }
                 int32_t *t = &tmp_all[(size_t)G.ptr[a]];
@@ -332,7 +332,7 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
         pcol.resize((size_t)pptr[n]);
         parallel_chunks(n, [&](int64_t a0, int64_t a1) {
             for (int64_t a = a0; a < a1; a++) {
-                if (patches && patches->label[(size_t)a] >= 0) std::copy_n(cluster_rows[(size_t)patches->label[(size_t)a]].data(), cnt[a], &pcol[(size_t)pptr[a]]);
+                if (patches && patches->label_p[(size_t)a] >= 0) std::copy_n(cluster_rows[(size_t)patches->label_p[(size_t)a]].data(), cnt[a], &pcol[(size_t)pptr[a]]);
                 else std::copy_n(&tmp_all[(size_t)G.ptr[a]], cnt[a], &pcol[(size_t)pptr[a]]);
             }
         });

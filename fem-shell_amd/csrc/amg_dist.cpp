@@ -240,7 +240,8 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
                     if (G.col[(size_t)q] < n) Gown.col[(size_t)w++] = G.col[(size_t)q];
             }
         });
-        na = aggregate_nodes(Gown, &agg);
+        // (clusters of rigidly coupled nodes -- amg_patch.hpp, own rows only -- are glued into one node each first)
+        na = L.patches && L.patches->glue ? aggregate_nodes_glued(Gown, L.patches->label_p, &agg) : aggregate_nodes(Gown, &agg);
     }
     std::vector<int64_t> counts;
     int rc = allgather_i64(c, na, &counts);
@@ -312,8 +313,27 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
     {
         std::vector<uint8_t> cnt((size_t)n, 0);
         RawVec<int32_t> tmp_all((size_t)G.ptr[(size_t)n]);
+        // rows of clustered nodes: what ALL the cluster's members see (amg_device_setup.cpp: P = P0 - omega B^-1 A P0)
+        const AmgPatches *patches = L.patches.get();
+        std::vector<std::vector<int32_t>> cluster_rows(patches ? (size_t)patches->n_clusters : 0);
+        if (patches)
+            parallel_chunks(patches->n_clusters, [&](int64_t k0, int64_t k1) {
+                for (int64_t k = k0; k < k1; k++) {
+                    std::vector<int32_t> &r = cluster_rows[(size_t)k];
+                    for (int32_t t = patches->h_ptr[(size_t)k]; t < patches->h_ptr[(size_t)k + 1]; t++) {
+                        const int32_t j = patches->h_nodes[(size_t)t];
+                        for (int64_t q = G.ptr[(size_t)j]; q < G.ptr[(size_t)j + 1]; q++) r.push_back(key[(size_t)G.col[(size_t)q]]);
+                    }
+                    std::sort(r.begin(), r.end());
+                    r.erase(std::unique(r.begin(), r.end()), r.end());
+                }
+            }, 64);
         parallel_chunks(n, [&](int64_t a0, int64_t a1) {
             for (int64_t a = a0; a < a1; a++) {
+                if (patches && patches->label_p[(size_t)a] >= 0) {
+                    cnt[(size_t)a] = (uint8_t)std::min<size_t>(cluster_rows[(size_t)patches->label_p[(size_t)a]].size(), 255);
+                    continue;
+                }
                 int32_t *t = &tmp_all[(size_t)G.ptr[(size_t)a]];
                 int m = 0;
                 for (int64_t q = G.ptr[(size_t)a]; q < G.ptr[(size_t)a + 1]; q++) t[m++] = key[(size_t)G.col[(size_t)q]];
@@ -325,7 +345,11 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
         for (int32_t a = 0; a < n; a++) pptr[(size_t)a + 1] = pptr[(size_t)a] + cnt[(size_t)a];
         pcol.resize((size_t)pptr[(size_t)n]);
         parallel_chunks(n, [&](int64_t a0, int64_t a1) {
-            for (int64_t a = a0; a < a1; a++) std::copy_n(&tmp_all[(size_t)G.ptr[(size_t)a]], cnt[(size_t)a], &pcol[(size_t)pptr[(size_t)a]]);
+            for (int64_t a = a0; a < a1; a++) {
+                if (patches && patches->label_p[(size_t)a] >= 0)
+                    std::copy_n(cluster_rows[(size_t)patches->label_p[(size_t)a]].data(), cnt[(size_t)a], &pcol[(size_t)pptr[(size_t)a]]);
+                else std::copy_n(&tmp_all[(size_t)G.ptr[(size_t)a]], cnt[(size_t)a], &pcol[(size_t)pptr[(size_t)a]]);
+            }
         });
     }
     auto p_index = [&](int32_t row, int32_t J) -> int {
@@ -370,6 +394,11 @@ int dist_coarsen(femshell_ctx *c, const femshell_pc_options &opt, int level, con
         own.n_slices = n_pad / kSliceNodes;
         own.total = own_total_P;
         launch_amg_prolongator(Adev, d_key.p, d_Q.p, (4.0 / 3.0) / L.lam, d_pmap_own.p, d_pmap_in.p, own, st);
+        if (L.patches) { // the cluster blocks' share of the smoothing (the keys are the global coarse ids here, ghosts included)
+            int width = 0;
+            for (int32_t sl = 0; sl < n_pad / kSliceNodes; sl++) width = std::max(width, (int)eP.slice_width[(size_t)sl]);
+            launch_patch_prolongator(Adev, d_key.p, d_Q.p, (4.0 / 3.0) / L.lam, own, L.patches->view(), width, st);
+        }
         FS_HIP(hipGetLastError());
         return FEMSHELL_OK;
     });
@@ -734,6 +763,10 @@ int power_iteration_dist(femshell_ctx *c, AmgLevel &L, const DeviceMatrix &A, in
         if (rc) return rc;
         launch_spmv(A, x, L.q.p, nullptr, nullptr, st);
         launch_minv_apply_norm(A, L.q.p, z, part.p + (size_t)(it & 1) * G, st);
+        if (L.patches) { // the level's smoother applies the cluster blocks: lambda_max of THAT operator (amg_solve.cpp)
+            launch_patch_correct(L.patches->view(), L.q.p, 1.0, z, false, nullptr, nullptr, st);
+            launch_sqnorm_partials(z, 6ll * L.n_pad, part.p + (size_t)(it & 1) * G, G, st);
+        }
         std::swap(x, z);
     }
     FS_HIP(hipGetLastError());
@@ -904,6 +937,19 @@ int amg_setup_dist(femshell_ctx *c)
         }
         int rc = alloc_level_vectors(L, l == 0, kcycle, st);
         if (rc) return rc;
+        if (l == 0) {
+            // clusters of rigidly coupled nodes (amg_patch.hpp): every rank among its own rows, the ranks decide together whether
+            // the mesh is one that needs them
+            std::vector<uint8_t> read_by_others((size_t)L.n, 0);
+            for (const HaloPeer &pr : L.halo->peers)
+                for (int32_t v : pr.send_nodes)
+                    if (v >= 0 && v < L.n) read_by_others[(size_t)v] = 1;
+            rc = amg_build_patches(c, Adev, L, true, &read_by_others);
+            int64_t unused = 0;
+            const int arc = global_max(c, rc ? -1 : 0, &unused, "the clusters of the patch smoother");
+            if (arc) return rc ? rc : arc;
+            lap("patch smoother: clusters");
+        }
         double lam = 0.0;
         rc = power_iteration_dist(c, L, Adev, amg_power_iterations(), &lam);
         if (rc) return rc;

@@ -1580,7 +1580,7 @@ __global__ __launch_bounds__(64) void k_patch_prolongator(DeviceMatrix A, const 
     const int pos = (int)(t / width), kP = (int)(t % width);
     if (pos >= pv.n_members) return;
     const int a = pv.nodes[pos], c = pv.cluster_of[pos];
-    if (kP >= P.count[a]) return;
+    if (kP >= P.count[a] || (pv.in_p != nullptr && !pv.in_p[c])) return;
     const int64_t pslot = ell_slot(P, a / kSliceNodes, kP, a % kSliceNodes);
     const int J = P.cols[pslot];
     const int m = pv.ptr[c + 1] - pv.ptr[c], N = 6 * m, i = pos - pv.ptr[c];

@@ -96,6 +96,7 @@ struct PatchView {
     const int64_t *moff = nullptr;  // n_clusters: offset of M_c, a (6 m) x (6 m) row-major matrix, in M
     const double *M = nullptr;
     const int32_t *cluster_of = nullptr; // per member position: its cluster
+    const uint8_t *in_p = nullptr;       // per cluster: does it take part in the smoothing of P (null: all do)
 };
 
 } // namespace femshell

@@ -119,10 +119,12 @@ double patch_trigger()
 }
 constexpr double kPatchTriggerSigma = 0.98;
 
+} // namespace
+
 // The clusters of rigidly coupled nodes of a level whose operator is in HBM (block-Jacobi inverse valid) and their smoother
 // blocks M_c: detection on the device (k_patch_sigma), the union of the edges and the 36 x 36 inverses on the host.  A level
 // without a rigid edge -- every structured mesh -- costs one kernel over its blocks and a four-byte copy, and keeps L.patches null.
-int amg_build_patches(femshell_ctx *c, const DeviceMatrix &A, AmgLevel &L, bool collective)
+int amg_build_patches(femshell_ctx *c, const DeviceMatrix &A, AmgLevel &L, bool collective, const std::vector<uint8_t> *excluded)
 {
     L.patches.reset();
     const double tau = patch_tau();
@@ -174,6 +176,21 @@ int amg_build_patches(femshell_ctx *c, const DeviceMatrix &A, AmgLevel &L, bool 
     P->n_clusters = patch_clusters(A.n_own, std::move(h), P->max_nodes, &P->label, &P->h_ptr, &P->h_nodes);
     if (P->n_clusters == 0) return FEMSHELL_OK;
     P->n_members = (int32_t)P->h_nodes.size();
+    // Row-partitioned levels: a cluster that holds a node another rank reads (the nodes of the halo's send lists) smooths like the
+    // others -- z_c += M_c r_c is local -- but stays out of the smoothing of P and of the gluing.  A cluster couples the row of P of
+    // each of its members to the aggregates ALL its members see; were a member adjacent to another rank's nodes, a cluster-mate one
+    // node further from the cut would get a block in a column of that rank -- a fine row the rank does not hold among its ghosts,
+    // whose share of P^T A P it could not add (measured: "coarsest operator is not positive definite").
+    P->label_p = P->label;
+    std::vector<uint8_t> in_p; // (source of an upload: lives until the synchronisations below)
+    if (excluded != nullptr && !excluded->empty()) {
+        in_p.assign((size_t)P->n_clusters, 1);
+        for (int32_t i = 0; i < A.n_own; i++)
+            if (P->label[(size_t)i] >= 0 && (*excluded)[(size_t)i]) in_p[(size_t)P->label[(size_t)i]] = 0;
+        for (int32_t i = 0; i < A.n_own; i++)
+            if (P->label[(size_t)i] >= 0 && !in_p[(size_t)P->label[(size_t)i]]) P->label_p[(size_t)i] = -1;
+        FS_HIP(P->in_p.upload(in_p, st));
+    }
     std::vector<int64_t> moff((size_t)P->n_clusters);
     std::vector<int32_t> cluster_of((size_t)P->n_members);
     int64_t total = 0;
@@ -205,6 +222,8 @@ int amg_build_patches(femshell_ctx *c, const DeviceMatrix &A, AmgLevel &L, bool 
     L.patches = P;
     return FEMSHELL_OK;
 }
+
+namespace {
 
 int power_iteration_start(femshell_ctx *c, AmgLevel &L, const DeviceMatrix &A, int iterations, PowerIteration *pw)
 {

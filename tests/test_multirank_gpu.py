@@ -430,7 +430,27 @@ def test_fp64_fallback_of_the_multigrid_is_taken_by_all_ranks_together(tmp_path)
     """A breakdown of the flexible CG under the single-precision copies of the hierarchy (tests/test_gpu_amg.py has the
     one-rank form) makes femshell_solve rebuild the hierarchy in FP64 and solve again; on a row-partitioned context that
     rebuild is collective, so the ranks must decide alike -- they do, from the all-reduced p.Ap."""
-    ranks = run_ranks(2, "delaunay_hard", tmp_path)
+    # (without the patch smoother of round 6, which keeps such a level in FP64 from the start: the test below)
+    ranks = run_ranks(2, "delaunay_hard", tmp_path, extra_env={"FEMSHELL_AMG_PATCH_TAU": "0"})
     for r in ranks:
         assert int(r["fallback"]) == 1 and int(r["iterations"]) == 120 and int(r["converged"]) == 0 and bool(r["finite"]), dict(r)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_patch_smoother_converges_on_the_poor_shell_on_one_two_and_three_ranks(world, tmp_path):
+    """Round 6, csrc/amg_patch.hpp: the 20,000-point random Delaunay shell numbered along x, on which the
+    point-block multigrid needs more than 1000 iterations on one rank or several.  With the cluster blocks -- every rank finds the
+    clusters among its own rows, the ranks decide together that the mesh needs them -- the solve converges to rtol 1e-10 within 400
+    iterations, without the FP64 rebuild, on 1, 2 and 3 ranks, to the same displacements."""
+    (tmp_path / "w").mkdir()
+    ranks = run_ranks(world, "delaunay_hard", tmp_path / "w", extra_env={"FEMSHELL_TEST_MAX_IT": "600"})
+    for r in ranks:
+        assert int(r["converged"]) == 1 and int(r["fallback"]) == 0 and int(r["iterations"]) <= 400, (int(r["iterations"]), int(r["fallback"]))
+        assert r["patch"][1] > 1000 and r["patch"][3] == 0  # clusters on every rank, none of them indefinite
+        np.testing.assert_array_equal(r["u"], ranks[0]["u"])
+    if world > 1:
+        (tmp_path / "one").mkdir()
+        single = run_ranks(1, "delaunay_hard", tmp_path / "one", extra_env={"FEMSHELL_TEST_MAX_IT": "600"})[0]
+        err = np.linalg.norm(ranks[0]["u"] - single["u"]) / np.linalg.norm(single["u"])
+        assert err < 1e-5, err  # (two solves of a system whose refined direct solve is good to 1e-7: tests/test_gpu_amg.py)
 
