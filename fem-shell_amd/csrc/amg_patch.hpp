@@ -9,13 +9,23 @@
 // diagonal block of A where the point-block smoother has six 6 x 6 inverses -- in the level's Chebyshev smoother, in its spectral
 // bound and in the smoothing of the prolongator, and the clusters glued into one aggregate each.
 //
+// When.  Edges above 0.8 are ordinary on stretched structured elements (a third of the edges of the pinched cylinder's 3 : 1 cells
+// reach 0.836, the coupled flap's 5 : 1 cells 0.965) where the point-block method works; what it does not cope with are NEARLY
+// COINCIDENT nodes, sigma > 0.98: 2.6 % of the edges of the random-point shells, 0.13 % of a jittered-grid Delaunay shell (90
+// iterations without cluster blocks), none of any structured mesh.  The method switches itself on when more than 1 % of the pairs
+// exceed 0.98 (FEMSHELL_AMG_PATCH_TRIGGER; amg_solve.cpp amg_build_patches) -- the ranks of a row partition decide together.
+//
 // How.  Clusters: the edges of the block graph with sigma_max(D_i^-1/2 A_ij D_j^-1/2) > tau (0.8), strongest first, united while a
-// cluster stays within six nodes.  The device keeps its packed 6 x 6 inverses; a cluster c adds the dense matrix
+// cluster stays within eight nodes (FEMSHELL_AMG_PATCH_TAU / _MAX; swept on 700 ... 50,000-point shells in four numberings:
+// profiles/r06_patch_smoother.txt).  The device keeps its packed 6 x 6 inverses; a cluster c adds the dense matrix
 //     M_c = (A_cc)^-1 - blockdiag(D_i^-1, i in c)
 // and every application z = D^-1 r of the level is followed by z_c += M_c r_c for the clustered nodes (k_patch_correct: one wave per
 // cluster) -- linear, so the Chebyshev steps d = a d + c D^-1 r, x += d take it as d += c M r, x += c M r behind the kernel that did the
 // point-block part.  A level without clusters launches nothing: structured meshes keep their hierarchies and iterates bit for bit.
-// Restated in oracle/amg_oracle.py (patch_*).  Level 0 only: the coarse operators of such a mesh are not the problem.
+// Restated in oracle/amg_oracle.py (patch_*).  Level 0 only: the coarse operators of such a mesh are not the problem.  A level with
+// clusters keeps FP64 copies throughout (the flexible CG broke down under the single-precision ones on every such shell tried).
+// Row partitions: every rank clusters its own rows; a cluster that holds a node another rank reads smooths like the others but
+// neither widens its members' rows of P nor is glued (PatchView::in_p; amg_solve.cpp says why).
 #pragma once
 #include <cstdint>
 
@@ -28,7 +38,7 @@
 namespace femshell {
 
 constexpr int kPatchPowerSteps = 16; // power iteration of patch_sigma2
-constexpr int kPatchMaxNodes = 10;   // largest cluster the kernels take (one wave: 60 of 64 lanes); default bound: 6
+constexpr int kPatchMaxNodes = 10;   // largest cluster the kernels take (one wave: 60 of 64 lanes); default bound: 8
 
 struct PatchEdge {
     int32_t a, c;   // a < c
