@@ -415,15 +415,18 @@ def test_bench_runs_row_partitioned_under_the_launcher_the_driver_uses(tmp_path)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nx", "96",
            "--cg-iters", "5", "--jacobi-probe-iters", "0", "--no-cpu-baseline", "--no-full-parity"]
+    env["FEMSHELL_BENCH_DETAIL_DIR"] = str(tmp_path)
     out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
     assert out.returncode == 0, out.stderr.decode(errors="replace")[-3000:]
     lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout.decode()[-2000:]
+    assert len(lines) == 1 and len(lines[0]) < 4096, out.stdout.decode()[-2000:]  # the compact line, and nothing else that looks like one
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks_seen"] == 2 and d["value"] > 0 and d["cg_iters_per_s"] > 0
     assert d["scaling"] == "strong" and d["config"]["parallelism"] == "row-partition x2"
-    tts = d["time_to_solution"]
-    assert tts["converged"] == 1 and tts["levels"] >= 2 and tts["iterations"] < 200
+    assert d["time_to_solution_s"] > 0 and d["time_to_solution_iterations"] < 200 and d["roofline"]["frac"] > 0
+    with open(tmp_path / "bench_detail.json") as f:  # everything else: the detail record
+        tts = json.load(f)["time_to_solution"]
+    assert tts["converged"] == 1 and tts["levels"] >= 2 and tts["iterations"] == d["time_to_solution_iterations"]
 
 
 def test_fp64_fallback_of_the_multigrid_is_taken_by_all_ranks_together(tmp_path):
