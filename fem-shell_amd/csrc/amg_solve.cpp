@@ -453,6 +453,10 @@ int amg_setup(femshell_ctx *c)
     Amg &H = *c->amg;
     H.opt = opt;
     const Plan &pl = c->plan;
+    if (setup_verbose_flag()) {
+        double ps[6];
+        DevPool::get().stats(ps); // (clears the counters: what follows belongs to this setup)
+    }
 
     double tl = now_s();
     auto lap = [&](const char *what, int level) {
@@ -562,6 +566,12 @@ int amg_setup(femshell_ctx *c)
     rc = amg_finish_hierarchy(c, A, B, Bdev, first_level);
     if (rc) return rc;
     H.setup_seconds = now_s() - t0;
+    if (setup_verbose_flag()) {
+        double ps[6];
+        DevPool::get().stats(ps);
+        fprintf(stderr, "[femshell amg setup] device allocator during this setup (and whatever ran since the last one): %.0f hipMalloc %.1f ms, %.0f hipFree %.1f ms, "
+                        "%.0f blocks to the pool behind a device synchronisation %.1f ms\n", ps[0], ps[1], ps[2], ps[3], ps[4], ps[5]);
+    }
     return FEMSHELL_OK;
 }
 

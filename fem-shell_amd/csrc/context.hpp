@@ -6,9 +6,12 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <iterator>
+#include <list>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -41,13 +44,17 @@ inline const char *fs_basename(const char *path)
                                                  " (" + fs_basename(__FILE__) + ":" + std::to_string(__LINE__) + ")"); \
     } while (0)
 
-// Device memory of the library's buffers.  Blocks of 1 MiB and more that a buffer gives back are kept (per device, at most
-// FEMSHELL_POOL_GB gigabytes, default 24; 0 = no pool) and handed to the next request of about their size instead of going
-// through hipFree / hipMalloc again: a multigrid setup at 4M triangles allocates and frees about 10 GB of transient operators
-// (P, A P, R, A_c, Q), every setup after the first of a process -- a changed K in a coupled run, the next context of a test
-// process -- then finds them here, and the card is not left churned for whoever allocates next (on a churned
-// card hipMalloc made a 0.18 s setup take 0.5 s).  A block is reused only after the device has gone idle once since it came
-// back (hipFree synchronises too); the pool empties when the last context of the process is destroyed.
+// Device memory of the library's buffers.
+// (1) ARENAS (round 6).  A multigrid setup at 4M triangles makes about 150 allocations, and hipMalloc costs 0.5 - 2.5 ms a call on
+//     the boxes of this pool whatever the size: 60 to 370 ms of a 0.18 - 0.5 s setup were the driver's allocator
+//     (FEMSHELL_AMG_VERBOSE=1 prints the count).  Requests below kArenaMax are therefore carved out of arenas of kArenaBytes (one
+//     hipMalloc each, bump pointer, 256-byte granules); larger ones -- K's values, the big operators -- go to the driver as before.
+// (2) REUSE.  Blocks a buffer gives back are kept (per device) and handed to the next request of about their size: a setup
+//     allocates and frees about 10 GB of transient operators (P, A P, R, A_c, Q), every setup after the first of a process -- a
+//     changed K in a coupled run, the next context of a test process -- finds them here.  Directly allocated blocks of 1 MiB and
+//     more are kept up to FEMSHELL_POOL_GB gigabytes (default 24; 0 = no pool and no arenas), pieces of arenas always (they cannot go
+//     back to the driver one by one).  A block is reused only after the device has gone idle once since it came back (hipFree
+//     synchronises too); everything goes back to the driver when the last context of the process is destroyed.
 class DevPool {
   public:
     static DevPool &get()
@@ -58,21 +65,56 @@ class DevPool {
     hipError_t alloc(void **out, size_t bytes)
     {
         *out = nullptr;
-        if (bytes >= kMinBytes && limit_ > 0) {
-            int dev = 0;
-            (void)hipGetDevice(&dev);
+        int dev = 0;
+        if (limit_ > 0) (void)hipGetDevice(&dev);
+        const bool small = limit_ > 0 && arena_bytes_ > 0 && bytes < kArenaMax;
+        const size_t need = small ? (bytes + kGranule - 1) / kGranule * kGranule : bytes;
+        if (limit_ > 0 && (small || bytes >= kMinBytes)) {
             std::lock_guard<std::mutex> lock(m_);
             // best fit: the smallest kept block of this device that holds the request without wasting more than a quarter
-            auto it = free_.lower_bound(Key{dev, bytes});
-            if (it != free_.end() && it->first.dev == dev && it->first.bytes <= bytes + bytes / 4) {
+            auto it = free_.lower_bound(Key{dev, need});
+            if (it != free_.end() && it->first.dev == dev && it->first.bytes <= need + need / 4 + (small ? kGranule : 0)) {
                 *out = it->second;
                 live_[*out] = it->first.bytes;
-                cached_ -= it->first.bytes;
+                if (!in_arena(*out)) cached_ -= it->first.bytes;
+                else arena_of(*out)->live++;
                 free_.erase(it);
                 return hipSuccess;
             }
+            if (small) {
+                Arena *a = nullptr;
+                for (auto &ar : arenas_)
+                    if (ar.dev == dev && ar.used + need <= ar.bytes) {
+                        a = &ar;
+                        break;
+                    }
+                if (a == nullptr) {
+                    void *base = nullptr;
+                    const size_t ab = arena_bytes_;
+                    const auto t0 = std::chrono::steady_clock::now();
+                    const hipError_t e = hipMalloc(&base, ab);
+                    stat_malloc_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+                    stat_mallocs_++;
+                    if (e == hipSuccess) {
+                        arenas_.push_back(Arena{dev, static_cast<char *>(base), ab, 0, 0});
+                        a = &arenas_.back();
+                    } else {
+                        (void)hipGetLastError(); // (no room for another arena: the request goes to the driver on its own, below)
+                    }
+                }
+                if (a != nullptr) {
+                    *out = a->base + a->used;
+                    a->used += need;
+                    a->live++;
+                    live_[*out] = need;
+                    return hipSuccess;
+                }
+            }
         }
+        const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(out, bytes);
+        stat_malloc_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        stat_mallocs_++;
         if (e != hipSuccess && trim()) { // out of memory with blocks kept: give them back and try once more
             (void)hipGetLastError();
             e = hipMalloc(out, bytes);
@@ -87,6 +129,7 @@ class DevPool {
     {
         if (p == nullptr) return;
         size_t bytes = 0;
+        bool arena = false;
         {
             std::lock_guard<std::mutex> lock(m_);
             auto it = live_.find(p);
@@ -94,38 +137,95 @@ class DevPool {
                 bytes = it->second;
                 live_.erase(it);
             }
+            arena = in_arena(p);
         }
-        if (bytes == 0 || bytes > limit_) {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (!arena && (bytes == 0 || bytes > limit_)) {
             (void)hipFree(p);
+            stat_free_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            stat_frees_++;
             return;
         }
         (void)hipDeviceSynchronize(); // (what hipFree does: nothing in flight reads or writes the block any more)
+        stat_sync_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        stat_syncs_++;
         int dev = 0;
         (void)hipGetDevice(&dev);
         std::lock_guard<std::mutex> lock(m_);
+        if (arena) {
+            Arena *a = arena_of(p);
+            a->live--;
+            if (a->live == 0) { // nothing of it in use: the arena starts over (its kept pieces leave the free list)
+                for (auto it = free_.begin(); it != free_.end();)
+                    if (arena_of(it->second) == a) it = free_.erase(it);
+                    else ++it;
+                a->used = 0;
+                return;
+            }
+            free_.emplace(Key{a->dev, bytes}, p);
+            return;
+        }
         free_.emplace(Key{dev, bytes}, p);
         cached_ += bytes;
-        while (cached_ > limit_ && !free_.empty()) { // over the limit: the largest kept block goes back to the driver
-            auto big = std::prev(free_.end());
+        while (cached_ > limit_) { // over the limit: the largest kept block that is the driver's goes back to it
+            auto big = free_.end();
+            for (auto it = free_.end(); it != free_.begin();) {
+                --it;
+                if (!in_arena(it->second)) {
+                    big = it;
+                    break;
+                }
+            }
+            if (big == free_.end()) break;
             cached_ -= big->first.bytes;
             (void)hipFree(big->second);
             free_.erase(big);
         }
     }
-    // every kept block back to the driver; true when there was one
+    // every kept block back to the driver, and every arena nothing of which is in use; true when there was one
     bool trim()
     {
         std::lock_guard<std::mutex> lock(m_);
-        const bool any = !free_.empty();
-        for (auto &kv : free_) (void)hipFree(kv.second);
-        free_.clear();
+        bool any = false;
+        for (auto it = free_.begin(); it != free_.end();) {
+            if (in_arena(it->second)) {
+                ++it;
+                continue;
+            }
+            (void)hipFree(it->second);
+            it = free_.erase(it);
+            any = true;
+        }
         cached_ = 0;
+        for (auto ar = arenas_.begin(); ar != arenas_.end();) {
+            if (ar->live != 0) {
+                ++ar;
+                continue;
+            }
+            for (auto it = free_.begin(); it != free_.end();)
+                if (it->second >= ar->base && it->second < ar->base + ar->bytes) it = free_.erase(it);
+                else ++it;
+            (void)hipFree(ar->base);
+            ar = arenas_.erase(ar);
+            any = true;
+        }
         return any;
     }
     void context_opened() { contexts_.fetch_add(1); }
     void context_closed()
     {
         if (contexts_.fetch_sub(1) == 1) (void)trim();
+    }
+    // (FEMSHELL_AMG_VERBOSE: what the driver's allocator cost since the last call -- hipMalloc, hipFree, the synchronisations of
+    //  blocks that went back to the pool)
+    void stats(double out[6])
+    {
+        out[0] = (double)stat_mallocs_.exchange(0);
+        out[1] = 1e-6 * (double)stat_malloc_ns_.exchange(0);
+        out[2] = (double)stat_frees_.exchange(0);
+        out[3] = 1e-6 * (double)stat_free_ns_.exchange(0);
+        out[4] = (double)stat_syncs_.exchange(0);
+        out[5] = 1e-6 * (double)stat_sync_ns_.exchange(0);
     }
     size_t cached_bytes()
     {
@@ -139,18 +239,40 @@ class DevPool {
         size_t bytes;
         bool operator<(const Key &o) const { return dev != o.dev ? dev < o.dev : bytes < o.bytes; }
     };
+    struct Arena {
+        int dev;
+        char *base;
+        size_t bytes, used;
+        int64_t live; // pieces in use
+    };
     static constexpr size_t kMinBytes = 1u << 20;
+    static constexpr size_t kGranule = 256;
+    static constexpr size_t kArenaMax = 96u << 20; // requests below this come out of an arena
     DevPool()
     {
         const char *e = getenv("FEMSHELL_POOL_GB");
         const double gb = e ? atof(e) : 24.0;
         limit_ = gb > 0.0 ? (size_t)(gb * 1073741824.0) : 0;
+        const char *a = getenv("FEMSHELL_POOL_ARENA_MB"); // 0: no arenas (every request to the driver, as in round 5)
+        const double mb = a ? atof(a) : 512.0;
+        arena_bytes_ = mb > 0.0 ? std::max((size_t)(mb * 1048576.0), 2 * kArenaMax) : 0;
     }
+    // (callers hold m_)
+    Arena *arena_of(const void *p)
+    {
+        const char *q = static_cast<const char *>(p);
+        for (auto &a : arenas_)
+            if (q >= a.base && q < a.base + a.bytes) return &a;
+        return nullptr;
+    }
+    bool in_arena(const void *p) { return arena_of(p) != nullptr; }
     std::mutex m_;
     std::multimap<Key, void *> free_;
     std::unordered_map<void *, size_t> live_;
-    size_t cached_ = 0, limit_ = 0;
+    std::list<Arena> arenas_; // (a list: the pointers into it stay valid)
+    size_t cached_ = 0, limit_ = 0, arena_bytes_ = 0;
     std::atomic<int> contexts_{0};
+    std::atomic<uint64_t> stat_mallocs_{0}, stat_malloc_ns_{0}, stat_frees_{0}, stat_free_ns_{0}, stat_syncs_{0}, stat_sync_ns_{0};
 };
 
 template <class T> struct DevBuf {
