@@ -239,6 +239,9 @@ int do_assemble(femshell_ctx *c, bool wait = true)
     }
     // (the event pair costs the synchronous call its two records: without it assemble_seconds is the host's clock around launch
     //  and synchronisation; an enqueued assembly always carries the pair -- nobody else could time it)
+    // (MEASURED, round 6, profiles/r06_sync_step_ab_raw.txt: neither the status word in mapped host memory, nor dropping the event
+    //  pair, nor polling a word that a one-lane kernel writes behind the assembly instead of synchronising the stream, nor polled
+    //  completion signals move the 40-50 us a synchronous step costs beyond its kernel: it is launch latency on an idle queue)
     const bool events = c->asm_events || !wait;
     const auto t_host = std::chrono::steady_clock::now();
     if (events) FS_HIP(hipEventRecord(c->ev0, c->stream));
