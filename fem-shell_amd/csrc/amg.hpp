@@ -69,6 +69,10 @@ void node_normals(int32_t n, const double *xyz, int64_t n_tri, const int32_t *tr
 // breadth-first order when the numbering is scattered (aggregation_order)
 int32_t aggregate_nodes(const Bsr &A, std::vector<int32_t> *agg, const std::vector<int32_t> *visit = nullptr);
 
+// true when aggregate_nodes would run its greedy passes on the unfiltered graph, in one piece, in index order (or the caller's
+// visiting order): widest_row = longest row (the node itself included), edges / neighbour_distance_sum as aggregation_order takes them
+bool aggregation_is_plain(int32_t n, int64_t widest_row, int64_t edges, double neighbour_distance_sum, bool have_visit);
+
 // ---- clusters of rigidly coupled nodes (amg_patch.hpp): the patch smoother of shells of poor element quality
 // Clusters from the rigid edges (sigma2 > tau^2; each pair once, a < c): strongest first -- ties: lower a, then lower c --, two
 // clusters are united while the union stays within max_nodes.  label[i] = cluster of node i or -1; clusters are numbered by their

@@ -15,6 +15,7 @@ namespace femshell {
 struct AmgOperator {
     DevBuf<int32_t> slice_width, cols;
     DevBuf<int64_t> slice_base;
+    DevBuf<uint8_t> count;  // real slots per row (operators whose pattern a coarsening step on the device built; else empty)
     DevBuf<double> vals;
     // symmetric storage (square level operators): in-lists and the transposed products beside the slots
     DevBuf<int32_t> in_width, in_slots, in_rows;
@@ -168,6 +169,9 @@ void amg_default_options(femshell_pc_options *o);
 bool coarse_symmetric_storage(int32_t n_nodes);
 // in-lists of a symmetric-storage operator into HBM and into op.dm (the slot arrays of op are in place already)
 int attach_in_lists(AmgOperator &op, const SlicedEllSym &S, int64_t total_slots, hipStream_t st);
+// ... the same from in-lists that were built in HBM (amg_symbolic.hip): the buffers become the operator's own
+int attach_in_lists_device(AmgOperator &op, DevBuf<int32_t> &in_width, DevBuf<int64_t> &in_base, DevBuf<int32_t> &in_slots, DevBuf<int32_t> &in_rows,
+                           int32_t max_in_width, int64_t total_slots, hipStream_t st);
 int amg_setup(femshell_ctx *c);
 // contexts with a communicator (amg_dist.cpp): levels 0 .. d-1 row-partitioned like K -- aggregates never span ranks, the
 // rows of Q, P and A P of the nodes along the cuts are exchanged once so that every rank computes its rows of the Galerkin
@@ -223,11 +227,12 @@ void launch_dense_gemv_big(const double *A64, const float *A32, int64_t lda, con
 // (B: the level's near-null space in HBM -- generated from the mesh on level 0, the previous step's Bc_dev below; the
 //  tentative prolongator is factorised there.  lam_of: hands over the spectral bound of the level when the prolongator is
 //  smoothed -- its power iteration runs on the device beside this function's host work.  Bc_dev: the coarse level's near-null space in HBM; Bc_out: its host copy,
-//  filled under the same condition as Ac_host)
+//  filled under the same condition as Ac_host.  before_qr: called when the tentative prolongator is about to be enqueued -- the
+//  last moment for whatever B points at to be on its way into HBM on the context's stream)
 int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &A, const HostEllPattern &pat, AmgLevel &L, AmgLevel &next,
                        const NearNullSrc &B, const std::function<int(double *)> &lam_of, bool keep_host, const std::function<bool(int32_t)> &want_host,
                        Bsr *Ac_host, std::vector<double> *Bc_out, DevBuf<double> *Bc_dev,
-                       const std::function<void(const char *)> &lap);
+                       const std::function<void(const char *)> &lap, const std::function<int()> &before_qr = nullptr);
 // the pattern of the context's K (level 0) from the plan
 void pattern_of_plan(const Plan &p, HostEllPattern *out);
 

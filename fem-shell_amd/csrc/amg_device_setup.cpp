@@ -12,6 +12,7 @@
 // everything on the host (the path tests compare this one with).
 #include "amg_device.hpp"
 #include "amg_pattern.hpp"
+#include "amg_symbolic.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -107,6 +108,8 @@ void adopt(AmgOperator &op, const EllPattern &E, DevPattern &D, DevBuf<double> &
     std::swap(op.slice_base.n, D.slice_base.n);
     std::swap(op.cols.p, D.cols.p);
     std::swap(op.cols.n, D.cols.n);
+    std::swap(op.count.p, D.count.p); // (the row lengths: the next coarsening step's symbolic kernels read them)
+    std::swap(op.count.n, D.count.n);
     std::swap(op.vals.p, vals.p);
     std::swap(op.vals.n, vals.n);
     op.nnzb = E.nnzb;
@@ -232,37 +235,125 @@ void graph_of_pattern(const HostEllPattern &H, Bsr *G)
     });
 }
 
-// One coarsening step of level 0 on the device.  In: the context's K (c->dm, block-Jacobi inverse valid), the near-null
-// space B of the fine nodes, the spectral bound lam.  Out: L.P, L.R (operators of the cycle), next.A (the coarse level
-// matrix in HBM, diagonal slot first), Ac_host (its host copy for the remaining levels), Bc, and for small problems the
-// host copies the inspection exports want.
-int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllPattern &pat, AmgLevel &L, AmgLevel &next,
-                       const NearNullSrc &B, const std::function<int(double *)> &lam_of, bool keep_host, const std::function<bool(int32_t)> &want_host,
-                       Bsr *Ac_host, std::vector<double> *Bc_out, DevBuf<double> *Bc_dev,
-                       const std::function<void(const char *)> &lap)
+// The greedy passes of aggregate_nodes (amg_setup.cpp aggregate_piece) on the operator's ELL pattern itself -- own slots and
+// in-list -- when they would run on the unfiltered graph in one piece and in index order (or the caller's visiting order): none of
+// the three passes needs its neighbours sorted (pass 2 takes the LOWEST aggregated neighbour, a minimum), so the 23 ms the sorted
+// graph of a 4M-triangle mesh costs the host are saved.  Returns -1 when the conditions do not hold (the caller builds the graph).
+static int32_t aggregate_on_pattern(const HostEllPattern &H, const std::vector<int32_t> *visit, std::vector<int32_t> *aggout)
+{
+    const int32_t n = H.n;
+    const bool have_visit = visit != nullptr && (int32_t)visit->size() == n;
+    auto for_each_nb = [&](int32_t i, auto f) { // the node itself first
+        const int s = i / kSliceNodes, nn = i % kSliceNodes;
+        const int64_t base = H.slice_base[(size_t)s] + nn;
+        const int cnt = H.count[(size_t)i];
+        for (int k = 0; k < cnt; k++)
+            if (!f(H.cols[(size_t)(base + (int64_t)k * kSliceNodes)])) return;
+        if (H.symmetric) {
+            const int64_t ib = H.in_base[(size_t)s] + nn;
+            for (int k = 0; k < H.in_width[(size_t)s]; k++) {
+                const size_t e = (size_t)(ib + (int64_t)k * kSliceNodes);
+                if (H.in_slots[e] >= 0 && !f(H.in_rows[e])) return;
+            }
+        }
+    };
+    // row lengths, and what aggregation_order looks at
+    std::atomic<int64_t> widest{0}, edges{0}, dist_sum{0};
+    parallel_chunks(n, [&](int64_t i0, int64_t i1) {
+        int64_t w = 0, e = 0, d = 0;
+        for (int64_t i = i0; i < i1; i++) {
+            int64_t deg = 0;
+            for_each_nb((int32_t)i, [&](int32_t j) {
+                deg++;
+                d += std::llabs((int64_t)j - i);
+                return true;
+            });
+            w = std::max(w, deg);
+            e += deg;
+        }
+        int64_t cur = widest.load();
+        while (w > cur && !widest.compare_exchange_weak(cur, w)) {}
+        edges.fetch_add(e);
+        dist_sum.fetch_add(d);
+    }, 1 << 16);
+    if (!aggregation_is_plain(n, widest.load(), edges.load(), (double)dist_sum.load(), have_visit)) return -1;
+    std::vector<int32_t> agg((size_t)n, -1);
+    int32_t na = 0;
+    // pass 1: a node whose whole neighbourhood is free becomes the root of a new aggregate
+    for (int32_t v = 0; v < n; v++) {
+        const int32_t i = have_visit ? (*visit)[(size_t)v] : v;
+        if (agg[(size_t)i] >= 0) continue;
+        int deg = 0;
+        bool free_nb = true;
+        for_each_nb(i, [&](int32_t j) {
+            deg++;
+            free_nb = agg[(size_t)j] < 0;
+            return free_nb;
+        });
+        if (!free_nb || deg <= 1) continue;
+        for_each_nb(i, [&](int32_t j) {
+            agg[(size_t)j] = na;
+            return true;
+        });
+        na++;
+    }
+    // pass 2: leftovers join the aggregate of their first aggregated neighbour in the visiting order (state of pass 1)
+    std::vector<int32_t> rank;
+    if (have_visit) {
+        rank.resize((size_t)n);
+        for (int32_t v = 0; v < n; v++) rank[(size_t)(*visit)[(size_t)v]] = v;
+    }
+    RawVec<int32_t> agg2((size_t)n);
+    parallel_chunks(n, [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; i++) {
+            agg2[(size_t)i] = agg[(size_t)i];
+            if (agg[(size_t)i] >= 0) continue;
+            int32_t best = -1, best_rank = 0;
+            for_each_nb((int32_t)i, [&](int32_t j) {
+                if (agg[(size_t)j] < 0) return true;
+                const int32_t rj = rank.empty() ? j : rank[(size_t)j];
+                if (best < 0 || rj < best_rank) {
+                    best = agg[(size_t)j];
+                    best_rank = rj;
+                }
+                return true;
+            });
+            if (best >= 0) agg2[(size_t)i] = best;
+        }
+    }, 1 << 14);
+    parallel_chunks(n, [&](int64_t i0, int64_t i1) { std::copy(agg2.begin() + i0, agg2.begin() + i1, agg.begin() + i0); }, 1 << 16);
+    // pass 3: what is still free forms aggregates of its own
+    for (int32_t v = 0; v < n; v++) {
+        const int32_t i = have_visit ? (*visit)[(size_t)v] : v;
+        if (agg[(size_t)i] >= 0) continue;
+        for_each_nb(i, [&](int32_t j) {
+            if (agg[(size_t)j] < 0) agg[(size_t)j] = na;
+            return true;
+        });
+        agg[(size_t)i] = na;
+        na++;
+    }
+    aggout->swap(agg);
+    return na;
+}
+
+// FEMSHELL_AMG_SYMBOLIC=host: the patterns of a coarsening step on the host threads as until round 6 (the path tests compare the
+// device's with, and the fallback of rows too long for the lane sets); default: amg_symbolic.hip
+static bool symbolic_on_device()
+{
+    const char *e = getenv("FEMSHELL_AMG_SYMBOLIC"); // (read per setup: the tests switch it inside one process)
+    return !(e && std::strcmp(e, "host") == 0);
+}
+
+// The integer work of a coarsening step on the host threads: the patterns as lists, their sliced ELL images (kept: eP, eAP, eR,
+// eAc), the uploads into S.  G: the level's graph, sorted rows.
+static int symbolic_host(femshell_ctx *c, const HostEllPattern &pat, const Bsr &G, const std::vector<int32_t> &agg, int32_t na, bool sym_coarse,
+                         const AmgPatches *patches, DevSymbolic &S, EllPattern &eP, EllPattern &eAP, EllPattern &eR, EllPattern &eAc,
+                         const std::function<void(const char *)> &lap)
 {
     hipStream_t st = c->stream;
     const int32_t n = pat.n;
-    if (c->cfg.world_size != 1) return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: single-rank contexts only");
-    // ---- aggregation on the graph
-    Bsr G;
-    graph_of_pattern(pat, &G);
-    lap("  graph of the level");
-    std::vector<int32_t> agg;
-    // When the library renumbered the nodes itself (FEMSHELL_REORDER_*: Morton, Cuthill-McKee) the greedy passes of the
-    // FINEST level visit the nodes in the caller's order: the index order of a space-filling curve fragments the aggregates
-    // at its jumps (4M-triangle cylinder, Morton numbering: 443 iterations instead of 137; panel 160 instead of 147), and the
-    // aggregates -- hence every coarser level, whose numbering is the order of creation -- are then those of the caller's
-    // numbering, whatever the internal one is
-    const bool finest_renumbered = &Adev == &c->dm && !c->iperm.empty() && (int32_t)c->iperm.size() == n;
-    // (clusters of rigidly coupled nodes -- amg_patch.hpp -- are glued into one node each before the greedy passes)
-    const AmgPatches *patches = L.patches.get();
-    const int32_t na = (patches && patches->glue) ? aggregate_nodes_glued(G, patches->label_p, &agg, finest_renumbered ? &c->iperm : nullptr)
-                               : aggregate_nodes(G, &agg, finest_renumbered ? &c->iperm : nullptr);
-    lap("  aggregation");
-    // tentative prolongator on the device: QR of every aggregate's rows of B, one wave each (k_amg_tentative_qr); the host
-    // only groups the nodes by aggregate
-    DevBuf<double> d_Q;
+    // the nodes grouped by aggregate (ascending inside an aggregate)
     {
         std::vector<int32_t> gptr((size_t)na + 1, 0), order((size_t)n);
         for (int32_t i = 0; i < n; i++) gptr[(size_t)agg[i] + 1]++;
@@ -275,25 +366,11 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
             std::vector<int32_t> fill(gptr.begin(), gptr.end() - 1);
             for (int32_t i = 0; i < n; i++) order[(size_t)fill[agg[i]]++] = i;
         }
-        DevBuf<int32_t> d_gptr, d_order;
-        FS_HIP(d_gptr.upload(gptr, st));
-        FS_HIP(d_order.upload(order, st));
-        FS_HIP(d_Q.alloc((size_t)n * 36));
-        FS_HIP(Bc_dev->alloc((size_t)na * 36));
-        // FEMSHELL_AMG_QR=memory: every aggregate takes the path of the large ones (rows in Q instead of registers; tests)
-        const bool in_memory = getenv("FEMSHELL_AMG_QR") && std::string(getenv("FEMSHELL_AMG_QR")) == "memory";
-        launch_amg_tentative_qr(B, d_gptr.p, d_order.p, na, largest, d_Q.p, Bc_dev->p, in_memory, st);
-        FS_HIP(hipGetLastError());
-        Bc_out->clear();
-        if (want_host(na) || keep_host) {
-            Bc_out->resize((size_t)na * 36);
-            FS_HIP(hipMemcpyAsync(Bc_out->data(), Bc_dev->p, Bc_out->size() * sizeof(double), hipMemcpyDeviceToHost, st));
-        }
+        S.largest = largest;
+        FS_HIP(S.gptr.upload(gptr, st));
+        FS_HIP(S.order.upload(order, st));
         FS_HIP(hipStreamSynchronize(st)); // gptr / order go out of scope
     }
-    lap("tentative P");
-
-    // ---- patterns
     // P: per fine row the sorted distinct aggregates of its neighbours (the row itself included)
     std::vector<int64_t> pptr((size_t)n + 1, 0);
     RawVec<int32_t> pcol;
@@ -433,7 +510,6 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     lap("  lists of R");
     // A_c: per aggregate the union of the A P rows of its fine rows (symmetric storage: columns >= the row only; the
     // coarse operator is symmetric, the cycle applies the stored blocks to both rows)
-    const bool sym_coarse = coarse_symmetric_storage(na);
     std::vector<int64_t> cptr;
     RawVec<int32_t> ccol;
     build_rows(na, [&](int32_t I, std::vector<int32_t> &out) {
@@ -446,7 +522,6 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
         if (sym_coarse) out.erase(out.begin(), std::lower_bound(out.begin(), out.end(), I)); // diagonal and upper blocks
     }, &cptr, &ccol);
     lap("  pattern of Ac");
-    EllPattern eP, eAP, eR, eAc;
     if (!pack_pattern(n, pptr.data(), pcol.data(), false, &eP) || !pack_pattern(n, aptr.data(), acol.data(), false, &eAP) ||
         !pack_pattern(na, cptr.data(), ccol.data(), true, &eAc))
         return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: a row of an intermediate operator has more than 255 blocks");
@@ -454,73 +529,9 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     if (!pack_pattern(na, rptr.data(), rrow.data(), false, &eR))
         return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: an aggregate is seen by more than 255 fine rows");
     lap("  sliced layouts of the four");
-
-    // ---- values on the device
-    DevBuf<int32_t> d_agg, d_rrow;
-    DevBuf<double> vP, vAP, vR, vAc;
-    DevBuf<uint8_t> d_pmap_own, d_pmap_in, d_rk;
-    DevBuf<int64_t> d_rptr;
-    DevPattern dP, dAP, dR, dAc;
-    FS_HIP(d_agg.upload(agg, st));
-    FS_HIP(d_pmap_own.upload(pmap_own, st));
-    FS_HIP(d_pmap_in.upload(pmap_in, st));
-    FS_HIP(d_rptr.upload(rptr, st));
-    FS_HIP(d_rrow.upload(rrow, st));
-    FS_HIP(d_rk.upload(rk, st));
-    FS_HIP(vP.alloc((size_t)eP.total() * 36));
-    FS_HIP(vAP.alloc((size_t)eAP.total() * 36));
-    FS_HIP(vR.alloc((size_t)eR.total() * 36));
-    FS_HIP(vAc.alloc((size_t)eAc.total() * 36));
-    EllView wP, wAP, wR, wAc;
-    int rc = upload_pattern(eP, dP, vP.p, &wP, st);
-    if (!rc) rc = upload_pattern(eAP, dAP, vAP.p, &wAP, st);
-    if (!rc) rc = upload_pattern(eR, dR, vR.p, &wR, st);
-    if (!rc) rc = upload_pattern(eAc, dAc, vAc.p, &wAc, st);
-    if (rc) return rc;
-    FS_HIP(hipStreamSynchronize(st)); // the host vectors above go out of scope at the end of this function only, but be safe
-    lap("uploads");
-    // FEMSHELL_AMG_GALERKIN=mfma: one wave per coarse row on the matrix cores instead of one lane per result block on the
-    // vector ALUs.  Measured on the 4M-triangle panel with A P stored block-contiguously: 2.5 ms on the vector ALUs, 8.2 ms
-    // on the matrix cores (6-row panels leave 10 of 16 tile rows idle and the operands arrive 8 bytes at a time) -- the
-    // product is a gather of 288-byte blocks at 4 TFLOP/s, not a GEMM, so the vector-ALU kernel is the default and the
-    // matrix-core kernel the measured alternative (tests run both; bench.py reports both).  Read per setup.
-    const bool use_mfma = getenv("FEMSHELL_AMG_GALERKIN") && std::string(getenv("FEMSHELL_AMG_GALERKIN")) == "mfma";
-    // the spectral bound of the level: its power iteration has been running beside the host work above
-    double lam = 0.0;
-    rc = lam_of(&lam);
-    if (rc) return rc;
-    hipEvent_t ev[5];
-    for (auto &e : ev) FS_HIP(hipEventCreate(&e));
-    FS_HIP(hipEventRecord(ev[0], st));
-    launch_amg_prolongator(Adev, d_agg.p, d_Q.p, (4.0 / 3.0) / lam, d_pmap_own.p, d_pmap_in.p, wP, st);
-    if (patches) { // the cluster blocks' share of the smoothing
-        int width = 0;
-        for (int32_t w : eP.slice_width) width = std::max(width, (int)w);
-        launch_patch_prolongator(Adev, d_agg.p, d_Q.p, (4.0 / 3.0) / lam, wP, patches->view(), width, st);
-    }
-    FS_HIP(hipEventRecord(ev[1], st));
-    launch_amg_ap(Adev, wP, wAP, st);
-    FS_HIP(hipEventRecord(ev[2], st));
-    launch_amg_restriction(wP, d_rptr.p, d_rrow.p, d_rk.p, wR, st);
-    FS_HIP(hipEventRecord(ev[3], st));
-    launch_amg_galerkin(wP, wAP, d_rptr.p, d_rrow.p, d_rk.p, wAc, st, use_mfma);
-    FS_HIP(hipEventRecord(ev[4], st));
-    FS_HIP(hipGetLastError());
-    FS_HIP(hipStreamSynchronize(st));
-    if (!c->amg->levels.empty() && &L == c->amg->levels[0].get()) { // the statistics describe the step that matters: level 0
-        AmgSetupStats &S = c->amg->stats;
-        float ms = 0.f;
-        FS_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
-        S.prolongator_ms = ms;
-        FS_HIP(hipEventElapsedTime(&ms, ev[1], ev[2]));
-        S.ap_ms = ms;
-        FS_HIP(hipEventElapsedTime(&ms, ev[2], ev[3]));
-        S.restriction_ms = ms;
-        FS_HIP(hipEventElapsedTime(&ms, ev[3], ev[4]));
-        S.galerkin_ms = ms;
-        S.galerkin_mfma = use_mfma ? 1 : 0;
-        // work of the Galerkin product: useful = one 6x6x6 product per (fine row i, aggregate I in P's row i, block of
-        // (A P)'s row i); issued on the matrix cores = 16x16x4 tiles, two k-steps per fine row and panel tile
+    // work of the Galerkin product: useful = one 6x6x6 product per (fine row i, aggregate I in P's row i, block of
+    // (A P)'s row i); issued on the matrix cores = 16x16x4 tiles, two k-steps per fine row and panel tile
+    {
         double useful = 0.0, issued = 0.0;
         for (int32_t a = 0; a < n; a++) useful += 432.0 * (double)(pptr[a + 1] - pptr[a]) * (double)(aptr[a + 1] - aptr[a]);
         for (int32_t I = 0; I < na; I++) {
@@ -529,13 +540,209 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
             for (int g0 = 0; g0 < cnt; g0 += 16) tiles += (double)((6 * std::min(16, cnt - g0) + 15) / 16);
             issued += 2048.0 * 2.0 * tiles * (double)(rptr[I + 1] - rptr[I]);
         }
-        S.galerkin_useful_flops = useful;
-        S.galerkin_mfma_flops_issued = use_mfma ? issued : 0.0;
+        S.useful_flops = useful;
+        S.mfma_flops = issued;
+    }
+    FS_HIP(S.agg.upload(agg, st));
+    FS_HIP(S.pmap_own.upload(pmap_own, st));
+    FS_HIP(S.pmap_in.upload(pmap_in, st));
+    FS_HIP(S.rptr.upload(rptr, st));
+    FS_HIP(S.rrow.upload(rrow, st));
+    FS_HIP(S.rk.upload(rk, st));
+    auto up = [&](const EllPattern &E, DevPattern &D, int64_t *total) -> int {
+        EllView unused;
+        *total = E.total();
+        return upload_pattern(E, D, nullptr, &unused, st);
+    };
+    int rc = up(eP, S.P, &S.totP);
+    if (!rc) rc = up(eAP, S.AP, &S.totAP);
+    if (!rc) rc = up(eR, S.R, &S.totR);
+    if (!rc) rc = up(eAc, S.Ac, &S.totAc);
+    if (rc) return rc;
+    FS_HIP(hipStreamSynchronize(st)); // the host arrays above go out of scope
+    lap("uploads");
+    return FEMSHELL_OK;
+}
+
+static EllView view_of(const EllPattern &E, const DevPattern &D, double *vals, int64_t total)
+{
+    EllView v;
+    v.n_rows = E.n_rows;
+    v.n_slices = E.n_slices;
+    v.slice_width = D.slice_width.p;
+    v.slice_base = D.slice_base.p;
+    v.cols = D.cols.p;
+    v.count = D.count.p;
+    v.vals = vals;
+    v.total = total;
+    return v;
+}
+
+// One coarsening step on the device.  In: the level operator in HBM (Adev: the context's K on level 0; block-Jacobi inverse
+// valid), the host copy of its pattern, the near-null space B of the fine nodes, the spectral bound lam.  Out: L.P, L.R (operators
+// of the cycle), next.A (the coarse level matrix in HBM, diagonal slot first), Ac_host (its host copy for the remaining levels),
+// Bc, and for small problems the host copies the inspection exports want.  The host runs the greedy passes of the aggregation; the
+// patterns are built in HBM (amg_symbolic.hip) unless the level has clusters of rigidly coupled nodes, a row outgrows the lane
+// sets or FEMSHELL_AMG_SYMBOLIC=host asks for the host's lists.
+int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllPattern &pat, AmgLevel &L, AmgLevel &next,
+                       const NearNullSrc &B, const std::function<int(double *)> &lam_of, bool keep_host, const std::function<bool(int32_t)> &want_host,
+                       Bsr *Ac_host, std::vector<double> *Bc_out, DevBuf<double> *Bc_dev,
+                       const std::function<void(const char *)> &lap, const std::function<int()> &before_qr)
+{
+    hipStream_t st = c->stream;
+    const int32_t n = pat.n;
+    if (c->cfg.world_size != 1) return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: single-rank contexts only");
+    const bool finest = &Adev == &c->dm;
+    // ---- aggregation
+    // When the library renumbered the nodes itself (FEMSHELL_REORDER_*: Morton, Cuthill-McKee) the greedy passes of the
+    // FINEST level visit the nodes in the caller's order: the index order of a space-filling curve fragments the aggregates
+    // at its jumps (4M-triangle cylinder, Morton numbering: 443 iterations instead of 137; panel 160 instead of 147), and the
+    // aggregates -- hence every coarser level, whose numbering is the order of creation -- are then those of the caller's
+    // numbering, whatever the internal one is
+    const bool finest_renumbered = finest && !c->iperm.empty() && (int32_t)c->iperm.size() == n;
+    const std::vector<int32_t> *visit = finest_renumbered ? &c->iperm : nullptr;
+    // (clusters of rigidly coupled nodes -- amg_patch.hpp -- are glued into one node each before the greedy passes)
+    const AmgPatches *patches = L.patches.get();
+    // the level's pattern in HBM as the symbolic kernels walk it (levels >= 1: the row lengths the previous step left beside it)
+    const uint8_t *dev_count = finest ? nullptr : L.A.count.p;
+    const bool try_device = symbolic_on_device() && !patches && (finest || dev_count != nullptr);
+    std::vector<int32_t> agg;
+    Bsr G;
+    int32_t na = -1;
+    if (!(patches && patches->glue) && try_device) na = aggregate_on_pattern(pat, visit, &agg); // (-1: the sorted graph is needed)
+    if (na < 0) {
+        graph_of_pattern(pat, &G);
+        lap("  graph of the level");
+        na = (patches && patches->glue) ? aggregate_nodes_glued(G, patches->label_p, &agg, visit) : aggregate_nodes(G, &agg, visit);
+    }
+    lap("  aggregation");
+    const bool sym_coarse = coarse_symmetric_storage(na);
+
+    // ---- patterns
+    std::unique_ptr<DevSymbolic> Sp(new DevSymbolic());
+    EllPattern eP, eAP, eR, eAc; // host path: complete; device path: the scalars, arrays on demand
+    bool on_device = false;
+    if (try_device) {
+        GraphView gv;
+        gv.n = n;
+        gv.n_slices = (int32_t)pat.slice_width.size();
+        gv.slice_width = Adev.slice_width;
+        gv.slice_base = Adev.slice_base;
+        gv.cols = Adev.cols;
+        gv.count = dev_count;
+        gv.symmetric = pat.symmetric ? 1 : 0;
+        gv.in_width = Adev.in_width;
+        gv.in_base = Adev.in_base;
+        gv.in_slots = Adev.in_slots;
+        gv.in_rows = Adev.in_rows;
+        const int rcd = amg_symbolic_device(st, gv, pat.slice_base.back(), (int64_t)pat.in_slots.size(), agg, na, sym_coarse, Sp.get());
+        if (rcd == FEMSHELL_OK) {
+            on_device = true;
+            eP = Sp->iP;
+            eAP = Sp->iAP;
+            eR = Sp->iR;
+            eAc = Sp->iAc;
+            lap("  patterns in HBM");
+        } else if (rcd != FEMSHELL_ERR_UNSUPPORTED) {
+            return rcd;
+        } else {
+            FS_HIP(hipStreamSynchronize(st));
+            Sp.reset(new DevSymbolic()); // a row too long for the lane sets: the host's lists
+        }
+    }
+    if (!on_device) {
+        if (G.nr != n) {
+            graph_of_pattern(pat, &G);
+            lap("  graph of the level");
+        }
+        const int rch = symbolic_host(c, pat, G, agg, na, sym_coarse, patches, *Sp, eP, eAP, eR, eAc, lap);
+        if (rch) return rch;
+    }
+    DevSymbolic &S = *Sp;
+
+    // ---- tentative prolongator on the device: QR of every aggregate's rows of B, one wave each (k_amg_tentative_qr)
+    DevBuf<double> d_Q;
+    {
+        FS_HIP(d_Q.alloc((size_t)n * 36));
+        FS_HIP(Bc_dev->alloc((size_t)na * 36));
+        // FEMSHELL_AMG_QR=memory: every aggregate takes the path of the large ones (rows in Q instead of registers; tests)
+        const bool in_memory = getenv("FEMSHELL_AMG_QR") && std::string(getenv("FEMSHELL_AMG_QR")) == "memory";
+        if (before_qr) {
+            const int rcq = before_qr();
+            if (rcq) return rcq;
+        }
+        launch_amg_tentative_qr(B, S.gptr.p, S.order.p, na, S.largest, d_Q.p, Bc_dev->p, in_memory, st);
+        FS_HIP(hipGetLastError());
+        Bc_out->clear();
+        if (want_host(na) || keep_host) {
+            Bc_out->resize((size_t)na * 36);
+            FS_HIP(hipMemcpyAsync(Bc_out->data(), Bc_dev->p, Bc_out->size() * sizeof(double), hipMemcpyDeviceToHost, st));
+            FS_HIP(hipStreamSynchronize(st));
+        }
+    }
+    lap("tentative P");
+
+    // ---- values on the device
+    DevBuf<double> vP, vAP, vR, vAc;
+    FS_HIP(vP.alloc((size_t)S.totP * 36));
+    FS_HIP(vAP.alloc((size_t)S.totAP * 36));
+    FS_HIP(vR.alloc((size_t)S.totR * 36));
+    FS_HIP(vAc.alloc((size_t)S.totAc * 36));
+    const EllView wP = view_of(eP, S.P, vP.p, S.totP), wAP = view_of(eAP, S.AP, vAP.p, S.totAP), wR = view_of(eR, S.R, vR.p, S.totR),
+                  wAc = view_of(eAc, S.Ac, vAc.p, S.totAc);
+    // FEMSHELL_AMG_GALERKIN=mfma: one wave per coarse row on the matrix cores instead of one lane per result block on the
+    // vector ALUs.  Measured on the 4M-triangle panel with A P stored block-contiguously: 2.5 ms on the vector ALUs, 8.2 ms
+    // on the matrix cores (6-row panels leave 10 of 16 tile rows idle and the operands arrive 8 bytes at a time) -- the
+    // product is a gather of 288-byte blocks at 4 TFLOP/s, not a GEMM, so the vector-ALU kernel is the default and the
+    // matrix-core kernel the measured alternative (tests run both; bench.py reports both).  Read per setup.
+    const bool use_mfma = getenv("FEMSHELL_AMG_GALERKIN") && std::string(getenv("FEMSHELL_AMG_GALERKIN")) == "mfma";
+    // the spectral bound of the level: its power iteration has been running beside the host work above
+    double lam = 0.0;
+    int rc = lam_of(&lam);
+    if (rc) return rc;
+    hipEvent_t ev[5];
+    for (auto &e : ev) FS_HIP(hipEventCreate(&e));
+    FS_HIP(hipEventRecord(ev[0], st));
+    launch_amg_prolongator(Adev, S.agg.p, d_Q.p, (4.0 / 3.0) / lam, S.pmap_own.p, S.pmap_in.p, wP, st);
+    if (patches) { // the cluster blocks' share of the smoothing
+        launch_patch_prolongator(Adev, S.agg.p, d_Q.p, (4.0 / 3.0) / lam, wP, patches->view(), eP.max_width, st);
+    }
+    FS_HIP(hipEventRecord(ev[1], st));
+    launch_amg_ap(Adev, wP, wAP, st);
+    FS_HIP(hipEventRecord(ev[2], st));
+    launch_amg_restriction(wP, S.rptr.p, S.rrow.p, S.rk.p, wR, st);
+    FS_HIP(hipEventRecord(ev[3], st));
+    launch_amg_galerkin(wP, wAP, S.rptr.p, S.rrow.p, S.rk.p, wAc, st, use_mfma);
+    FS_HIP(hipEventRecord(ev[4], st));
+    FS_HIP(hipGetLastError());
+    FS_HIP(hipStreamSynchronize(st));
+    if (!c->amg->levels.empty() && &L == c->amg->levels[0].get()) { // the statistics describe the step that matters: level 0
+        AmgSetupStats &T = c->amg->stats;
+        float ms = 0.f;
+        FS_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        T.prolongator_ms = ms;
+        FS_HIP(hipEventElapsedTime(&ms, ev[1], ev[2]));
+        T.ap_ms = ms;
+        FS_HIP(hipEventElapsedTime(&ms, ev[2], ev[3]));
+        T.restriction_ms = ms;
+        FS_HIP(hipEventElapsedTime(&ms, ev[3], ev[4]));
+        T.galerkin_ms = ms;
+        T.galerkin_mfma = use_mfma ? 1 : 0;
+        T.galerkin_useful_flops = S.useful_flops;
+        T.galerkin_mfma_flops_issued = use_mfma ? S.mfma_flops : 0.0;
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
     lap("P, AP, R, Ac on the device");
 
     // ---- the coarse operator goes back for the remaining levels; small problems keep P for the inspection exports
+    if (on_device) { // the host copy of the coarse pattern: the next step's aggregation reads it (and the exports below)
+        rc = download_pattern(S.Ac, S.totAc, &eAc, st);
+        if (rc) return rc;
+        if (keep_host) {
+            rc = download_pattern(S.P, S.totP, &eP, st);
+            if (rc) return rc;
+        }
+    }
     {
         ValueArray h;
         *Ac_host = Bsr();
@@ -550,24 +757,41 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
             if (rc) return rc;
             ell_to_bsr(eP, h.data(), na, &L.hP);
         }
-        L.agg = agg; // (row-partitioned contexts look up which coarse rows their nodes reach)
+        L.agg.swap(agg); // (the inspection export; row-partitioned contexts look up which coarse rows their nodes reach)
     }
     const int32_t nc_pad = eAc.n_pad;
-    adopt(L.P, eP, dP, vP, nc_pad);
-    adopt(L.R, eR, dR, vR, eP.n_pad);
-    adopt(next.A, eAc, dAc, vAc, nc_pad);
+    const int64_t total_ac = S.totAc;
+    adopt(L.P, eP, S.P, vP, nc_pad);
+    adopt(L.R, eR, S.R, vR, eP.n_pad);
+    adopt(next.A, eAc, S.Ac, vAc, nc_pad);
     next.pattern = HostEllPattern();
     next.pattern.n = na;
     next.pattern.symmetric = sym_coarse;
     if (sym_coarse) {
-        SlicedEllSym S;
-        build_in_lists(na, eAc.slice_width, eAc.slice_base, eAc.cols.data(), eAc.count, &S);
-        rc = attach_in_lists(next.A, S, eAc.total(), st);
-        if (rc) return rc;
-        next.pattern.in_width.swap(S.in_width);
-        next.pattern.in_base.swap(S.in_base);
-        next.pattern.in_slots.swap(S.in_slots);
-        next.pattern.in_rows.swap(S.in_rows);
+        if (on_device) {
+            HostEllPattern &Np = next.pattern;
+            Np.in_width.resize(S.in_width.n);
+            Np.in_base.resize(S.in_base.n);
+            Np.in_slots.resize((size_t)S.in_total);
+            Np.in_rows.resize((size_t)S.in_total);
+            FS_HIP(hipMemcpyAsync(Np.in_width.data(), S.in_width.p, S.in_width.n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            FS_HIP(hipMemcpyAsync(Np.in_base.data(), S.in_base.p, S.in_base.n * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+            if (S.in_total > 0) {
+                FS_HIP(hipMemcpyAsync(Np.in_slots.data(), S.in_slots.p, (size_t)S.in_total * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                FS_HIP(hipMemcpyAsync(Np.in_rows.data(), S.in_rows.p, (size_t)S.in_total * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            }
+            rc = attach_in_lists_device(next.A, S.in_width, S.in_base, S.in_slots, S.in_rows, S.max_in_width, total_ac, st);
+            if (rc) return rc;
+        } else {
+            SlicedEllSym I;
+            build_in_lists(na, eAc.slice_width, eAc.slice_base, eAc.cols.data(), eAc.count, &I);
+            rc = attach_in_lists(next.A, I, total_ac, st);
+            if (rc) return rc;
+            next.pattern.in_width.swap(I.in_width);
+            next.pattern.in_base.swap(I.in_base);
+            next.pattern.in_slots.swap(I.in_slots);
+            next.pattern.in_rows.swap(I.in_rows);
+        }
     }
     next.pattern.slice_width.swap(eAc.slice_width);
     next.pattern.slice_base.swap(eAc.slice_base);

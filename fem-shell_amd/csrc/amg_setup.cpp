@@ -317,6 +317,22 @@ static int64_t aggregation_chunk()
 
 static int32_t aggregate_piece(const Bsr &Afull, std::vector<int32_t> *aggout, const std::vector<int32_t> *visit);
 
+// Would aggregate_nodes run its greedy passes on the graph itself (no row beyond the filter's width), in one piece, in index order
+// (or in the caller's visiting order)?  Then the passes need no sorted lists and amg_device_setup.cpp runs them on the operator's
+// ELL pattern directly (aggregate_on_pattern) instead of building the graph first.
+bool aggregation_is_plain(int32_t n, int64_t widest_row, int64_t edges, double neighbour_distance_sum, bool have_visit)
+{
+    const int64_t chunk = aggregation_chunk();
+    if (chunk > 0 && (int64_t)n > chunk + chunk / 2) return false;
+    const int keep = aggregation_keep();
+    if (keep > 0 && widest_row > (int64_t)keep + 1) return false;
+    if (have_visit || n < 64) return true;
+    const char *force = getenv("FEMSHELL_AMG_AGG_ORDER");
+    if (force && std::strcmp(force, "index") == 0) return true;
+    if (force && std::strcmp(force, "bfs") == 0) return false;
+    return edges == 0 || neighbour_distance_sum / (double)edges <= 8.0 * std::sqrt((double)n);
+}
+
 // The greedy passes are sequential sweeps on one host thread.  MEASURED AND NOT ADOPTED (round 6, profiles/r06_chunked_aggregation.txt):
 // cut into pieces of 131072 rows and aggregated on sixteen threads the passes of a 4M-triangle mesh take 3 ms instead of 7 -- the
 // lap "graph + aggregation" of round 5 was mostly the graph -- and the seams, where the tiling of a structured mesh starts anew,

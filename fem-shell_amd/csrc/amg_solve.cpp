@@ -2,6 +2,7 @@
 // and the flexible PCG around it.  Replaces what `-pc_type gamg`-style options select inside PETSc's KSPSolve
 // behind equation_systems.solve() (fem-shell.cpp:138, doc/implementation.tex:68-72).
 #include "amg_device.hpp"
+#include <thread>
 #include "trace.hpp"
 
 #include <algorithm>
@@ -83,6 +84,31 @@ int attach_in_lists(AmgOperator &op, const SlicedEllSym &S, int64_t total_slots,
     return FEMSHELL_OK;
 }
 
+int attach_in_lists_device(AmgOperator &op, DevBuf<int32_t> &in_width, DevBuf<int64_t> &in_base, DevBuf<int32_t> &in_slots, DevBuf<int32_t> &in_rows,
+                           int32_t max_in_width, int64_t total_slots, hipStream_t st)
+{
+    std::swap(op.in_width.p, in_width.p);
+    std::swap(op.in_width.n, in_width.n);
+    std::swap(op.in_base.p, in_base.p);
+    std::swap(op.in_base.n, in_base.n);
+    std::swap(op.in_slots.p, in_slots.p);
+    std::swap(op.in_slots.n, in_slots.n);
+    std::swap(op.in_rows.p, in_rows.p);
+    std::swap(op.in_rows.n, in_rows.n);
+    FS_HIP(op.tbuf.alloc((size_t)total_slots * 6));
+    FS_HIP(op.tbuf.zero(st));
+    FS_HIP(hipStreamSynchronize(st));
+    op.dm.symmetric = 1;
+    op.dm.max_in_width = max_in_width;
+    op.dm.in_width = op.in_width.p;
+    op.dm.in_base = op.in_base.p;
+    op.dm.in_slots = op.in_slots.p;
+    op.dm.in_rows = op.in_rows.p;
+    op.dm.gat_slots = op.in_slots.p; // (level operators: every transposed product through tbuf)
+    op.dm.tbuf = op.tbuf.p;
+    return FEMSHELL_OK;
+}
+
 namespace {
 
 // lambda_max(D^-1 A) of a level by power iteration on the device (x <- D^-1 A x, ratio of consecutive norms).  In two halves:
@@ -92,6 +118,7 @@ namespace {
 struct PowerIteration {
     DevBuf<double> part;
     int G = 0, iterations = 0;
+    hipStream_t st = nullptr; // the stream its launches went to
 };
 
 // FEMSHELL_AMG_PATCH_TAU (default 0.8; 0: no patch smoother) and FEMSHELL_AMG_PATCH_MAX (nodes per cluster, default 8): amg_patch.hpp
@@ -225,9 +252,21 @@ int amg_build_patches(femshell_ctx *c, const DeviceMatrix &A, AmgLevel &L, bool 
 
 namespace {
 
-int power_iteration_start(femshell_ctx *c, AmgLevel &L, const DeviceMatrix &A, int iterations, PowerIteration *pw)
+// (beside: on the context's second stream, behind everything the first one holds at this moment -- the symbolic kernels of the
+//  coarsening step, which the first stream gets next, then run beside the products instead of behind them: 30 products of K are
+//  22 ms at 4M triangles, the patterns 10)
+int power_iteration_start(femshell_ctx *c, AmgLevel &L, const DeviceMatrix &A, int iterations, PowerIteration *pw, bool beside = false)
 {
     hipStream_t st = c->stream;
+    if (beside && c->aux_stream != nullptr) {
+        hipEvent_t ev;
+        FS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        FS_HIP(hipEventRecord(ev, c->stream));
+        FS_HIP(hipStreamWaitEvent(c->aux_stream, ev, 0));
+        FS_HIP(hipEventDestroy(ev));
+        st = c->aux_stream;
+    }
+    pw->st = st;
     pw->G = slice_grid(A);
     // lambda is the ratio of the last two norms: only those come back to the host (one synchronisation instead of one per
     // step; without normalisation the iterate grows like lambda^k, lambda ~ 2, which 30 steps of FP64 take easily)
@@ -251,7 +290,7 @@ int power_iteration_start(femshell_ctx *c, AmgLevel &L, const DeviceMatrix &A, i
 
 int power_iteration_finish(femshell_ctx *c, PowerIteration &pw, double *lam_out)
 {
-    hipStream_t st = c->stream;
+    hipStream_t st = pw.st != nullptr ? pw.st : c->stream;
     const int G = pw.G, iterations = pw.iterations;
     std::vector<double> h(2 * (size_t)G);
     FS_HIP(hipMemcpyAsync(h.data(), pw.part.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -329,10 +368,8 @@ bool coarse_symmetric_storage(int32_t n_nodes)
     // diagonal + upper blocks: their products are HBM-bound (4M-triangle panel, level 1 of 222k nodes: 1.63 s against
     // 1.71 s per solve); the smaller levels are launch- and latency-bound, where the two-phase product loses (all
     // levels symmetric: 1.80 s)
-    static const long min_nodes = [] {
-        const char *e = getenv("FEMSHELL_AMG_COARSE_SYM");
-        return e ? atol(e) : 100000l;
-    }();
+    const char *e = getenv("FEMSHELL_AMG_COARSE_SYM"); // (read per call: the tests switch it inside one process)
+    const long min_nodes = e ? atol(e) : 100000l;
     return min_nodes > 0 && n_nodes >= min_nodes && default_symmetric_storage();
 }
 
@@ -473,9 +510,21 @@ int amg_setup(femshell_ctx *c)
     DevBuf<double> Bdev;    // ... and in HBM (levels coarsened on the device, from the second one on)
     // FEMSHELL_AMG_PLAIN_RBM=1: the six plain rigid-body modes (A/B runs)
     static const bool plain = getenv("FEMSHELL_AMG_PLAIN_RBM") && atoi(getenv("FEMSHELL_AMG_PLAIN_RBM")) != 0;
+    // the node normals (11 ms of host loops at 4M triangles) on a thread of their own, beside the search for clusters, the copy of
+    // the pattern and the greedy passes of the aggregation; whoever needs them first waits for them (normals_ready)
     std::vector<double> normals;
+    std::thread normals_thread;
     if (!plain)
-        node_normals(pl.n_own, pl.xyz_local.data(), pl.n_ltri(), pl.tri_local.data(), pl.n_lquad(), pl.quad_local.data(), &normals);
+        normals_thread = std::thread([&] {
+            node_normals(pl.n_own, pl.xyz_local.data(), pl.n_ltri(), pl.tri_local.data(), pl.n_lquad(), pl.quad_local.data(), &normals);
+        });
+    auto normals_ready = [&] {
+        if (normals_thread.joinable()) normals_thread.join();
+    };
+    struct JoinAtExit { // (every early return below)
+        std::function<void()> f;
+        ~JoinAtExit() { f(); }
+    } join_at_exit{normals_ready};
     // (decided by amg_device_coarsen for the level it creates: it knows the coarse size only after the aggregation)
     auto want_host_matrix = [&](int next_level) {
         return std::function<bool(int32_t)>([&, next_level](int32_t na) { return !rules.device_step(next_level, na); });
@@ -514,9 +563,16 @@ int amg_setup(femshell_ctx *c)
         src.xyz = c->xyz.p;
         src.dmask = c->dmask.p;
         if (!plain) {
-            FS_HIP(d_normals.upload(normals, st));
+            FS_HIP(d_normals.alloc((size_t)pl.n_own * 3));
             src.normals = d_normals.p;
         }
+        // (the copy itself is enqueued when the tentative prolongator is about to read them: amg_device_coarsen calls this)
+        auto upload_normals = [&]() -> int {
+            if (plain) return (int)FEMSHELL_OK;
+            normals_ready();
+            FS_HIP(hipMemcpyAsync(d_normals.p, normals.data(), normals.size() * sizeof(double), hipMemcpyHostToDevice, st));
+            return (int)FEMSHELL_OK;
+        };
         double ctr[3];
         mesh_centre(pl.n_own, pl.xyz_local.data(), ctr);
         src.cx = ctr[0];
@@ -526,7 +582,7 @@ int amg_setup(femshell_ctx *c)
         //  without the gluing, and without the cluster blocks at all if that fails too)
         for (int attempt = 0;; attempt++) {
             PowerIteration pw0; // (its launches now, its result when the prolongator is smoothed: amg_device_coarsen asks for it)
-            rc = power_iteration_start(c, L0, c->dm, amg_power_iterations(), &pw0);
+            rc = power_iteration_start(c, L0, c->dm, amg_power_iterations(), &pw0, true);
             if (rc) return rc;
             auto lam0 = [&](double *out) {
                 double lam = 0.0;
@@ -536,9 +592,10 @@ int amg_setup(femshell_ctx *c)
                 return (int)FEMSHELL_OK;
             };
             rc = amg_device_coarsen(c, c->dm, L0.pattern, L0, L1, src, lam0, keep_host, want_host_matrix(1), &A, &Bc, &Bdev,
-                                    [&](const char *what) { lap(what, 0); });
+                                    [&](const char *what) { lap(what, 0); }, upload_normals);
             if (rc == FEMSHELL_ERR_UNSUPPORTED && L0.patches && attempt < 2) {
-                FS_HIP(hipStreamSynchronize(st)); // (the power iteration of this attempt)
+                FS_HIP(hipStreamSynchronize(pw0.st)); // (the power iteration of this attempt)
+                FS_HIP(hipStreamSynchronize(st));
                 if (L0.patches->glue) L0.patches->glue = false;
                 else L0.patches.reset();
                 if (setup_verbose_flag()) fprintf(stderr, "[femshell amg setup] patch smoother: %s\n", L0.patches ? "once more without gluing the clusters" : "given up for this mesh");
@@ -558,9 +615,11 @@ int amg_setup(femshell_ctx *c)
     } else {
         rc = download_matrix(c, &A);
         if (rc) return rc;
+        normals_ready();
         rigid_body_modes(pl.n_own, pl.xyz_local.data(), c->dmask_global.data() + pl.row_begin, &B, plain ? nullptr : normals.data());
         lap("download K", 0);
     }
+    normals_ready();
     normals = std::vector<double>();
 
     rc = amg_finish_hierarchy(c, A, B, Bdev, first_level);

@@ -776,3 +776,54 @@ def test_structured_meshes_have_no_clusters_and_keep_their_bits(monkeypatch):
     assert out[0][1] == out[1][1]
     np.testing.assert_array_equal(out[0][0], out[1][0])
     np.testing.assert_array_equal(out[0][2], out[1][2])
+
+
+def _delaunay_context(n_pts, seed):
+    ensure_built()
+    xyz, tri = meshes.delaunay_patch(n_pts, seed)
+    n = len(xyz)
+    dmask = np.zeros(n, dtype=np.uint8)
+    dmask[xyz[:, 0] < 0.1] = 0x3F
+    loads = np.zeros((n, 6))
+    loads[:, 2] = 1.0
+    fs = pkg.FemShell(0.3, 1e7, 0.05, device=0)
+    fs.set_mesh(xyz, tri)
+    fs.set_dirichlet(dmask)
+    fs.set_loads(loads)
+    return fs
+
+
+@pytest.mark.parametrize("kind,n,coarse_sym", [("panel", 64, "100000"), ("panel", 64, "1"), ("quads", 40, "1"), ("cylinder", 48, "100000"),
+                                               ("delaunay", 6000, "1"), ("delaunay", 6000, "100000")])
+def test_patterns_built_in_hbm_are_the_hosts_lists_slot_for_slot(monkeypatch, kind, n, coarse_sym):
+    """Round 6, csrc/amg_symbolic.hip: the patterns of P, A P, R, A_c, the maps from the blocks of A to the slots
+    of P and the in-lists of a symmetric A_c are built in HBM, one lane per row; the greedy passes of the aggregation run on the
+    operator's ELL pattern without the sorted graph.  FEMSHELL_AMG_SYMBOLIC=host keeps the host's lists of rounds 3-5.  Same
+    aggregates, same operators, same iterates -- bit for bit, on every level coarsened on the device (forced down to 100-node
+    levels), with full and with symmetric storage of the coarse operators, on structured and on Delaunay meshes."""
+    monkeypatch.setenv("FEMSHELL_AMG_DEVICE_MIN", "100")
+    monkeypatch.setenv("FEMSHELL_AMG_COARSE_SYM", coarse_sym)
+    out = []
+    for where in ("device", "host"):
+        monkeypatch.setenv("FEMSHELL_AMG_SYMBOLIC", where)
+        fs = _delaunay_context(n, 5) if kind == "delaunay" else _context(*_make(kind, n))
+        fs.set_preconditioner("amg", coarsest_nodes=60)
+        u, info = fs.solve(rtol=1e-10, max_it=600)
+        assert info["converged"] == 1, info
+        lv = fs.amg_levels()
+        assert len(lv) >= 3
+        ex = [fs.amg_export(li) for li in range(len(lv) - 1)]
+        st = fs.amg_setup_stats()
+        out.append((u.copy(), info["iterations"], fs.residual_history().copy(), lv, ex, st))
+        fs.close()
+    dev, host = out
+    assert dev[3] == host[3]
+    assert dev[5]["galerkin_useful_flops"] == host[5]["galerkin_useful_flops"] > 0
+    for a, b in zip(dev[4], host[4]):
+        for key in ("agg", "A_rowptr", "A_cols", "A_vals", "P_rowptr", "P_cols", "P_vals"):
+            assert (a[key] is None) == (b[key] is None), key
+            if a[key] is not None:
+                np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    assert dev[1] == host[1]
+    np.testing.assert_array_equal(dev[2], host[2])
+    np.testing.assert_array_equal(dev[0], host[0])
