@@ -688,6 +688,7 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     FS_HIP(vAP.alloc((size_t)S.totAP * 36));
     FS_HIP(vR.alloc((size_t)S.totR * 36));
     FS_HIP(vAc.alloc((size_t)S.totAc * 36));
+    lap("  allocation of the values");
     const EllView wP = view_of(eP, S.P, vP.p, S.totP), wAP = view_of(eAP, S.AP, vAP.p, S.totAP), wR = view_of(eR, S.R, vR.p, S.totR),
                   wAc = view_of(eAc, S.Ac, vAc.p, S.totAc);
     // FEMSHELL_AMG_GALERKIN=mfma: one wave per coarse row on the matrix cores instead of one lane per result block on the
@@ -700,6 +701,7 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     double lam = 0.0;
     int rc = lam_of(&lam);
     if (rc) return rc;
+    lap("  spectral bound (the power iteration's end)");
     hipEvent_t ev[5];
     for (auto &e : ev) FS_HIP(hipEventCreate(&e));
     FS_HIP(hipEventRecord(ev[0], st));

@@ -510,13 +510,27 @@ int amg_setup(femshell_ctx *c)
     DevBuf<double> Bdev;    // ... and in HBM (levels coarsened on the device, from the second one on)
     // FEMSHELL_AMG_PLAIN_RBM=1: the six plain rigid-body modes (A/B runs)
     static const bool plain = getenv("FEMSHELL_AMG_PLAIN_RBM") && atoi(getenv("FEMSHELL_AMG_PLAIN_RBM")) != 0;
-    // the node normals (11 ms of host loops at 4M triangles) on a thread of their own, beside the search for clusters, the copy of
-    // the pattern and the greedy passes of the aggregation; whoever needs them first waits for them (normals_ready)
+    // the node normals (11 ms of host loops at 4M triangles, 48 MB to bring over) on a thread of their own, beside the search for
+    // clusters, the copy of the pattern and the greedy passes of the aggregation: the thread computes them and -- when a coarsening
+    // step on the device will read them -- copies them into HBM on a stream of its own; whoever needs them first waits for the
+    // thread (normals_ready: the host array is complete and the device copy has arrived)
     std::vector<double> normals;
+    DevBuf<double> d_normals;
     std::thread normals_thread;
+    hipError_t normals_err = hipSuccess;
+    const bool normals_to_device = !plain && !host_only && opt.max_levels > 1 && pl.n_own > kDirectNodes;
+    if (normals_to_device) FS_HIP(d_normals.alloc((size_t)pl.n_own * 3));
     if (!plain)
         normals_thread = std::thread([&] {
             node_normals(pl.n_own, pl.xyz_local.data(), pl.n_ltri(), pl.tri_local.data(), pl.n_lquad(), pl.quad_local.data(), &normals);
+            if (!normals_to_device) return;
+            hipStream_t s = nullptr;
+            hipError_t e = hipSetDevice(c->device);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_normals.p, normals.data(), normals.size() * sizeof(double), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (s) (void)hipStreamDestroy(s);
+            normals_err = e;
         });
     auto normals_ready = [&] {
         if (normals_thread.joinable()) normals_thread.join();
@@ -559,18 +573,14 @@ int amg_setup(femshell_ctx *c)
         lap("pattern of K", 0);
         // the near-null space of the finest level is generated from the mesh in HBM (never stored: n x 36 doubles)
         NearNullSrc src;
-        DevBuf<double> d_normals;
         src.xyz = c->xyz.p;
         src.dmask = c->dmask.p;
-        if (!plain) {
-            FS_HIP(d_normals.alloc((size_t)pl.n_own * 3));
-            src.normals = d_normals.p;
-        }
-        // (the copy itself is enqueued when the tentative prolongator is about to read them: amg_device_coarsen calls this)
+        if (!plain) src.normals = d_normals.p;
+        // (amg_device_coarsen calls this when the tentative prolongator is about to read them)
         auto upload_normals = [&]() -> int {
             if (plain) return (int)FEMSHELL_OK;
             normals_ready();
-            FS_HIP(hipMemcpyAsync(d_normals.p, normals.data(), normals.size() * sizeof(double), hipMemcpyHostToDevice, st));
+            FS_HIP(normals_err);
             return (int)FEMSHELL_OK;
         };
         double ctr[3];
