@@ -27,5 +27,6 @@ from .binding import (  # noqa: F401
     library_path,
     load_library,
     build_plan,
+    plan_node_normals,
     reorder_host,
 )

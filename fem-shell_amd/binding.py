@@ -470,6 +470,33 @@ def build_plan(xyz, tri=None, quad=None, rank=0, world_size=1):
     return out
 
 
+def plan_node_normals(xyz, tri=None, quad=None, from_gather_lists=True, rank=0, world_size=1):
+    """Unit normals of the owned nodes of one rank's plan (CPU only): by the walk over all elements or from the gather lists."""
+    L = load_library()
+    L.femshell_plan_create.argtypes = [C.c_int32, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_int32),
+                                       C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32,
+                                       C.POINTER(C.c_void_p)]
+    L.femshell_plan_create.restype = C.c_int
+    L.femshell_plan_destroy.argtypes = [C.c_void_p]
+    L.femshell_plan_destroy.restype = None
+    L.femshell_plan_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.femshell_plan_node_normals.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]
+    L.femshell_plan_node_normals.restype = C.c_int
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    tri = np.zeros((0, 3), np.int32) if tri is None else np.ascontiguousarray(tri, dtype=np.int32).reshape(-1, 3)
+    quad = np.zeros((0, 4), np.int32) if quad is None else np.ascontiguousarray(quad, dtype=np.int32).reshape(-1, 4)
+    h = C.c_void_p()
+    _check(L.femshell_plan_create(len(xyz), _d(xyz), len(tri), _i(tri), len(quad), _i(quad), rank, world_size, C.byref(h)))
+    try:
+        info = np.zeros(len(PLAN_INFO), dtype=np.int64)
+        _check(L.femshell_plan_info(h, info.ctypes.data_as(C.POINTER(C.c_int64))))
+        out = np.zeros((int(info[PLAN_INFO.index("n_own")]), 3))
+        _check(L.femshell_plan_node_normals(h, 1 if from_gather_lists else 0, _d(out)))
+    finally:
+        L.femshell_plan_destroy(h)
+    return out
+
+
 # ---- host-only pieces of the multigrid setup (include/femshell_plan.h); need no GPU --------------------------
 
 COARSEN_ARRAYS = {"agg": (0, np.int32), "P_rowptr": (1, np.int64), "P_cols": (2, np.int32), "P_vals": (3, np.float64),

@@ -64,6 +64,9 @@ void mesh_centre(int32_t n, const double *xyz, double c[3]);
 void node_normals(int32_t n, const double *xyz, int64_t n_tri, const int32_t *tri, int64_t n_quad, const int32_t *quad,
                   std::vector<double> *normals);
 
+// ... the same array (bit for bit) for the owned nodes of a plan, from the gather lists of its diagonal slots
+void node_normals_plan(const Plan &p, RawVec<double> *normals);
+
 // greedy distance-1 aggregation of the block graph of A; returns the number of aggregates
 // visit: order in which the greedy passes visit the nodes (visit[v] = node visited v-th); nullptr: index order, or
 // breadth-first order when the numbering is scattered (aggregation_order)

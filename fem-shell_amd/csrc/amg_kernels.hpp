@@ -158,5 +158,7 @@ void launch_patch_correct(const PatchView &pv, const double *r, double coef, dou
 void launch_patch_prolongator(const DeviceMatrix &A, const int32_t *agg, const double *Q, double omega, const EllView &P, const PatchView &pv,
                               int width, hipStream_t st);
 void launch_sqnorm_partials(const double *z, int64_t n, double *partials, int G, hipStream_t st);
+// out2[j] = the sum of part[j G .. (j + 1) G) in index order, j = 0, 1 (the host's loop over the partial norms, on the device)
+void launch_sums_in_order(const double *part, int G, double *out2, hipStream_t st);
 
 } // namespace femshell

@@ -116,7 +116,7 @@ namespace {
 // step on the device does its host-side graph work (aggregation, patterns: 0.16 s on the 4M-triangle meshes) in between
 // while the GPU iterates.
 struct PowerIteration {
-    DevBuf<double> part;
+    DevBuf<double> part, sums;
     int G = 0, iterations = 0;
     hipStream_t st = nullptr; // the stream its launches went to
 };
@@ -292,15 +292,16 @@ int power_iteration_finish(femshell_ctx *c, PowerIteration &pw, double *lam_out)
 {
     hipStream_t st = pw.st != nullptr ? pw.st : c->stream;
     const int G = pw.G, iterations = pw.iterations;
-    std::vector<double> h(2 * (size_t)G);
-    FS_HIP(hipMemcpyAsync(h.data(), pw.part.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    FS_HIP(hipStreamSynchronize(st));
-    double s_last = 0.0, s_prev = 0.0;
+    // the two norms are sums over the G partials in index order, taken on the device (launch_sums_in_order: the host's loop of
+    // rounds 3-5, same bits): 16 bytes come back instead of 16 G
     const size_t last = (size_t)((iterations - 1) & 1) * G, prev = (size_t)((iterations - 2) & 1) * G;
-    for (int g = 0; g < G; g++) {
-        s_last += h[last + g];
-        s_prev += h[prev + g];
-    }
+    FS_HIP(pw.sums.alloc(2));
+    launch_sums_in_order(pw.part.p, G, pw.sums.p, st); // (sums[0] over part[0, G), sums[1] over part[G, 2 G))
+    FS_HIP(hipGetLastError());
+    double h[2] = {0.0, 0.0};
+    FS_HIP(hipMemcpyAsync(h, pw.sums.p, sizeof h, hipMemcpyDeviceToHost, st));
+    FS_HIP(hipStreamSynchronize(st));
+    const double s_last = h[last / (size_t)std::max(G, 1)], s_prev = h[prev / (size_t)std::max(G, 1)];
     const double n_last = std::sqrt(s_last), n_prev = std::sqrt(s_prev);
     if (!(n_prev > 0.0) || !std::isfinite(n_last) || !(n_last > 0.0))
         return set_err(FEMSHELL_ERR_BREAKDOWN, "multigrid setup: power iteration broke down");
@@ -483,6 +484,7 @@ int amg_setup(femshell_ctx *c)
 {
     TraceRange trace("femshell multigrid setup");
     const double t0 = now_s();
+    DevPool::Defer no_sync_per_free; // (buffers released during the setup join the pool at its end: context.hpp)
     hipStream_t st = c->stream;
     const femshell_pc_options opt = c->pc;
     const bool kcycle = opt.cycle == FEMSHELL_CYCLE_K;
@@ -510,11 +512,11 @@ int amg_setup(femshell_ctx *c)
     DevBuf<double> Bdev;    // ... and in HBM (levels coarsened on the device, from the second one on)
     // FEMSHELL_AMG_PLAIN_RBM=1: the six plain rigid-body modes (A/B runs)
     static const bool plain = getenv("FEMSHELL_AMG_PLAIN_RBM") && atoi(getenv("FEMSHELL_AMG_PLAIN_RBM")) != 0;
-    // the node normals (11 ms of host loops at 4M triangles, 48 MB to bring over) on a thread of their own, beside the search for
+    // the node normals (48 MB to bring over at 4M triangles) on a thread of their own, beside the search for
     // clusters, the copy of the pattern and the greedy passes of the aggregation: the thread computes them and -- when a coarsening
     // step on the device will read them -- copies them into HBM on a stream of its own; whoever needs them first waits for the
     // thread (normals_ready: the host array is complete and the device copy has arrived)
-    std::vector<double> normals;
+    RawVec<double> normals;
     DevBuf<double> d_normals;
     std::thread normals_thread;
     hipError_t normals_err = hipSuccess;
@@ -522,7 +524,7 @@ int amg_setup(femshell_ctx *c)
     if (normals_to_device) FS_HIP(d_normals.alloc((size_t)pl.n_own * 3));
     if (!plain)
         normals_thread = std::thread([&] {
-            node_normals(pl.n_own, pl.xyz_local.data(), pl.n_ltri(), pl.tri_local.data(), pl.n_lquad(), pl.quad_local.data(), &normals);
+            node_normals_plan(pl, &normals);
             if (!normals_to_device) return;
             hipStream_t s = nullptr;
             hipError_t e = hipSetDevice(c->device);
@@ -548,6 +550,24 @@ int amg_setup(femshell_ctx *c)
     // clusters of rigidly coupled nodes (amg_patch.hpp: none on a mesh of decent element quality); a mesh that has them takes the
     // device path below whatever its size -- the host path has no cluster blocks
     std::shared_ptr<AmgPatches> patches0;
+    // A mesh that is certain to take its first coarsening step on the device starts the power iteration of level 0 -- 30 products
+    // of K on the second stream, 22 ms at 4M triangles, the longest thing the GPU has to do in a setup -- before anything else; the
+    // search for clusters, the host's copy of the pattern, the aggregation and the symbolic kernels all run beside it.  (A mesh that
+    // turns out to have clusters starts it again: lambda_max is then that of the smoother with the cluster blocks.)
+    PowerIteration pw_early;
+    bool early = false;
+    if (!host_only && opt.max_levels > 1 && pl.n_own > opt.coarsest_nodes && pl.n_own > kDirectNodes) {
+        H.levels.emplace_back(new AmgLevel());
+        AmgLevel &L0 = *H.levels.back();
+        L0.n = pl.n_own;
+        L0.n_pad = pl.n_pad;
+        L0.nnzb = pl.nnz_blocks;
+        rc = alloc_level_vectors(L0, true, kcycle, st);
+        if (rc) return rc;
+        rc = power_iteration_start(c, L0, c->dm, amg_power_iterations(), &pw_early, true);
+        if (rc) return rc;
+        early = true;
+    }
     if (!host_only && opt.max_levels > 1 && pl.n_own > kDirectNodes) {
         AmgLevel probe;
         probe.n = pl.n_own;
@@ -557,14 +577,21 @@ int amg_setup(femshell_ctx *c)
         lap("patch smoother: clusters", 0);
     }
     if (!host_only && (pl.n_own > opt.coarsest_nodes || patches0) && opt.max_levels > 1) { // (small meshes: host algebra below)
-        H.levels.emplace_back(new AmgLevel());
-        AmgLevel &L0 = *H.levels.back();
-        L0.n = pl.n_own;
-        L0.n_pad = pl.n_pad;
-        L0.nnzb = pl.nnz_blocks;
+        if (!early) {
+            H.levels.emplace_back(new AmgLevel());
+            AmgLevel &Lnew = *H.levels.back();
+            Lnew.n = pl.n_own;
+            Lnew.n_pad = pl.n_pad;
+            Lnew.nnzb = pl.nnz_blocks;
+            rc = alloc_level_vectors(Lnew, true, kcycle, st);
+            if (rc) return rc;
+        }
+        AmgLevel &L0 = *H.levels[0];
         L0.patches = patches0;
-        rc = alloc_level_vectors(L0, true, kcycle, st);
-        if (rc) return rc;
+        if (early && patches0) { // (the early power iteration ran without the cluster blocks)
+            FS_HIP(hipStreamSynchronize(pw_early.st));
+            early = false;
+        }
         H.levels.emplace_back(new AmgLevel());
         AmgLevel &L1 = *H.levels.back();
         std::vector<double> Bc;
@@ -591,9 +618,13 @@ int amg_setup(femshell_ctx *c)
         // (with clusters: glued into aggregates; should an aggregate then be seen by more fine rows than a row of R holds, once more
         //  without the gluing, and without the cluster blocks at all if that fails too)
         for (int attempt = 0;; attempt++) {
-            PowerIteration pw0; // (its launches now, its result when the prolongator is smoothed: amg_device_coarsen asks for it)
-            rc = power_iteration_start(c, L0, c->dm, amg_power_iterations(), &pw0, true);
-            if (rc) return rc;
+            PowerIteration pw_now; // (its launches now, its result when the prolongator is smoothed: amg_device_coarsen asks for it)
+            const bool reuse_early = attempt == 0 && early;
+            PowerIteration &pw0 = reuse_early ? pw_early : pw_now;
+            if (!reuse_early) {
+                rc = power_iteration_start(c, L0, c->dm, amg_power_iterations(), &pw0, true);
+                if (rc) return rc;
+            }
             auto lam0 = [&](double *out) {
                 double lam = 0.0;
                 const int r2 = power_iteration_finish(c, pw0, &lam);
@@ -630,7 +661,7 @@ int amg_setup(femshell_ctx *c)
         lap("download K", 0);
     }
     normals_ready();
-    normals = std::vector<double>();
+    RawVec<double>().swap(normals);
 
     rc = amg_finish_hierarchy(c, A, B, Bdev, first_level);
     if (rc) return rc;

@@ -146,12 +146,58 @@ class DevPool {
             stat_frees_++;
             return;
         }
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (defer_depth_.load() > 0) { // (a multigrid setup in progress: see Defer below)
+            std::lock_guard<std::mutex> lock(m_);
+            pending_.push_back(Pending{p, bytes, arena, dev});
+            return;
+        }
         (void)hipDeviceSynchronize(); // (what hipFree does: nothing in flight reads or writes the block any more)
         stat_sync_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         stat_syncs_++;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
         std::lock_guard<std::mutex> lock(m_);
+        keep_block(p, bytes, arena, dev);
+    }
+    // While a Defer object lives, blocks that come back to the pool wait in a list instead of synchronising the device one by one
+    // (the power iteration of a multigrid setup runs on the second stream from the setup's first moment; a temporary buffer of the
+    // search for clusters, released 1 ms in, used to wait 22 ms for it).  They are not handed out again before the last Defer object
+    // is gone: one device synchronisation then, and they join the kept blocks.
+    struct Defer {
+        Defer() { DevPool::get().defer_depth_.fetch_add(1); }
+        ~Defer()
+        {
+            if (DevPool::get().defer_depth_.fetch_sub(1) == 1) DevPool::get().flush_pending();
+        }
+        Defer(const Defer &) = delete;
+        Defer &operator=(const Defer &) = delete;
+    };
+    void flush_pending()
+    {
+        std::vector<Pending> list;
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            list.swap(pending_);
+        }
+        if (list.empty()) return;
+        const auto t0 = std::chrono::steady_clock::now();
+        (void)hipDeviceSynchronize();
+        stat_sync_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        stat_syncs_ += list.size();
+        std::lock_guard<std::mutex> lock(m_);
+        for (const Pending &b : list) keep_block(b.p, b.bytes, b.arena, b.dev);
+    }
+
+  private:
+    struct Pending {
+        void *p;
+        size_t bytes;
+        bool arena;
+        int dev;
+    };
+    // (callers hold m_; the device has been idle since the block came back)
+    void keep_block(void *p, size_t bytes, bool arena, int dev)
+    {
         if (arena) {
             Arena *a = arena_of(p);
             a->live--;
@@ -182,6 +228,8 @@ class DevPool {
             free_.erase(big);
         }
     }
+
+  public:
     // every kept block back to the driver, and every arena nothing of which is in use; true when there was one
     bool trim()
     {
@@ -271,7 +319,8 @@ class DevPool {
     std::unordered_map<void *, size_t> live_;
     std::list<Arena> arenas_; // (a list: the pointers into it stay valid)
     size_t cached_ = 0, limit_ = 0, arena_bytes_ = 0;
-    std::atomic<int> contexts_{0};
+    std::atomic<int> contexts_{0}, defer_depth_{0};
+    std::vector<Pending> pending_;
     std::atomic<uint64_t> stat_mallocs_{0}, stat_malloc_ns_{0}, stat_frees_{0}, stat_free_ns_{0}, stat_syncs_{0}, stat_sync_ns_{0};
 };
 

@@ -256,6 +256,22 @@ int32_t femshell_amg_host_aggregate_glued(int32_t n_nodes, const int32_t *rowptr
 
 void femshell_amg_coarsening_destroy(femshell_amg_coarsening *h) { delete h; }
 
+int femshell_plan_node_normals(const femshell_plan *plan, int32_t from_gather_lists, double *normals_out)
+{
+    if (!plan || !normals_out) return set_err(FEMSHELL_ERR_INVALID, "femshell_plan_node_normals: invalid argument");
+    const Plan &p = plan->p;
+    if (from_gather_lists) {
+        RawVec<double> N;
+        node_normals_plan(p, &N);
+        std::memcpy(normals_out, N.data(), N.size() * sizeof(double));
+    } else {
+        std::vector<double> N;
+        node_normals(p.n_own, p.xyz_local.data(), p.n_ltri(), p.tri_local.data(), p.n_lquad(), p.quad_local.data(), &N);
+        std::memcpy(normals_out, N.data(), N.size() * sizeof(double));
+    }
+    return FEMSHELL_OK;
+}
+
 int64_t femshell_amg_coarsening_array(const femshell_amg_coarsening *h, int which, void *out)
 {
     if (!h) return -1;

@@ -78,6 +78,11 @@ enum {
 /* returns the element count of the array; copies it to out when out != NULL */
 int64_t femshell_plan_array(const femshell_plan *plan, int which, void *out);
 
+/* Area-weighted unit normals of the plan's owned nodes (n_own x 3; what the multigrid setup projects the rotation modes with):
+ * from_gather_lists = 0 walks all elements per range of nodes (rounds 3-5), 1 reads every node's elements from the gather list of
+ * its diagonal slot (round 6).  The two arrays are equal bit for bit. */
+int femshell_plan_node_normals(const femshell_plan *plan, int32_t from_gather_lists, double *normals_out);
+
 /* ---- host-only pieces of the multigrid setup (csrc/amg.hpp), for CPU tests against the numpy restatement
  * oracle/amg_oracle.py.  One coarsening step: aggregation, tentative prolongator from the near-null space B
  * (n x 6 x 6: dof x mode), prolongator smoothing with omega = 4 / (3 lambda_max), Galerkin product. ---- */
