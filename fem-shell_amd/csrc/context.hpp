@@ -115,9 +115,12 @@ class DevPool {
         hipError_t e = hipMalloc(out, bytes);
         stat_malloc_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         stat_mallocs_++;
-        if (e != hipSuccess && trim()) { // out of memory with blocks kept: give them back and try once more
-            (void)hipGetLastError();
-            e = hipMalloc(out, bytes);
+        if (e != hipSuccess) { // out of memory with blocks kept (or waiting for the end of a setup): give them back and try once more
+            const bool waited = flush_pending(), kept = trim();
+            if (waited || kept) {
+                (void)hipGetLastError();
+                e = hipMalloc(out, bytes);
+            }
         }
         if (e == hipSuccess && bytes >= kMinBytes && limit_ > 0) {
             std::lock_guard<std::mutex> lock(m_);
@@ -140,6 +143,16 @@ class DevPool {
             arena = in_arena(p);
         }
         const auto t0 = std::chrono::steady_clock::now();
+        if (!arena && bytes > limit_ && defer_depth_.load() > 0) {
+            // (a block too large to keep, released inside a multigrid setup -- A P of a 32M-triangle mesh, 26 GB: it goes back to the
+            //  driver when the setup is over.  Freed at once, the setup's NEXT requests -- the single-precision copies -- waited for
+            //  the driver to wipe it: 0.65 s of hipMalloc in a 1.05 s setup, profiles/r06_hipmalloc_probe.txt)
+            int dev_now = 0;
+            (void)hipGetDevice(&dev_now);
+            std::lock_guard<std::mutex> lock(m_);
+            pending_.push_back(Pending{p, bytes, false, dev_now, true});
+            return;
+        }
         if (!arena && (bytes == 0 || bytes > limit_)) {
             (void)hipFree(p);
             stat_free_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -150,7 +163,7 @@ class DevPool {
         (void)hipGetDevice(&dev);
         if (defer_depth_.load() > 0) { // (a multigrid setup in progress: see Defer below)
             std::lock_guard<std::mutex> lock(m_);
-            pending_.push_back(Pending{p, bytes, arena, dev});
+            pending_.push_back(Pending{p, bytes, arena, dev, false});
             return;
         }
         (void)hipDeviceSynchronize(); // (what hipFree does: nothing in flight reads or writes the block any more)
@@ -172,20 +185,27 @@ class DevPool {
         Defer(const Defer &) = delete;
         Defer &operator=(const Defer &) = delete;
     };
-    void flush_pending()
+    bool flush_pending()
     {
         std::vector<Pending> list;
         {
             std::lock_guard<std::mutex> lock(m_);
             list.swap(pending_);
         }
-        if (list.empty()) return;
+        if (list.empty()) return false;
         const auto t0 = std::chrono::steady_clock::now();
         (void)hipDeviceSynchronize();
         stat_sync_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         stat_syncs_ += list.size();
+        for (const Pending &b : list)
+            if (b.to_driver) {
+                (void)hipFree(b.p);
+                stat_frees_++;
+            }
         std::lock_guard<std::mutex> lock(m_);
-        for (const Pending &b : list) keep_block(b.p, b.bytes, b.arena, b.dev);
+        for (const Pending &b : list)
+            if (!b.to_driver) keep_block(b.p, b.bytes, b.arena, b.dev);
+        return true;
     }
 
   private:
@@ -194,6 +214,7 @@ class DevPool {
         size_t bytes;
         bool arena;
         int dev;
+        bool to_driver; // larger than the pool keeps: hipFree when the list is flushed
     };
     // (callers hold m_; the device has been idle since the block came back)
     void keep_block(void *p, size_t bytes, bool arena, int dev)
