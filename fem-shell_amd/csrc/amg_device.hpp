@@ -39,6 +39,11 @@ struct HostEllPattern {
     std::vector<int32_t> in_width;
     RawVec<int32_t> in_slots, in_rows;
     std::vector<int64_t> in_base;
+    // Level 0 with its patterns built in HBM (amg_symbolic.hip): the host only runs the greedy passes of the aggregation over K's
+    // pattern, which the plan holds already -- `borrowed` then points at the plan and cols / count / in_slots / in_rows above stay
+    // empty (their copy was 6-8 ms of a 76 ms setup at 4M triangles: 80 MB).  A step that needs the host's lists after all
+    // (clusters, a row too long for the lane sets) fills them first: pattern_of_plan.
+    const Plan *borrowed = nullptr;
     bool empty() const { return slice_base.empty(); }
 };
 
@@ -233,8 +238,9 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &A, const HostEllPatt
                        const NearNullSrc &B, const std::function<int(double *)> &lam_of, bool keep_host, const std::function<bool(int32_t)> &want_host,
                        Bsr *Ac_host, std::vector<double> *Bc_out, DevBuf<double> *Bc_dev,
                        const std::function<void(const char *)> &lap, const std::function<int()> &before_qr = nullptr);
-// the pattern of the context's K (level 0) from the plan
-void pattern_of_plan(const Plan &p, HostEllPattern *out);
+// the pattern of the context's K (level 0) from the plan (light: the slice arrays only, the slot arrays stay the plan's -- see
+// HostEllPattern::borrowed)
+void pattern_of_plan(const Plan &p, HostEllPattern *out, bool light = false);
 
 // clusters of rigidly coupled nodes of a level whose operator is in HBM, and their smoother blocks (amg_solve.cpp; amg_patch.hpp).
 // collective: the ranks of a row partition decide together whether the mesh needs them.  L.patches stays null when it does not.

@@ -164,9 +164,47 @@ int download_vals(const DevBuf<double> &d, ValueArray *h, hipStream_t st)
     return FEMSHELL_OK;
 }
 
+int staged_download(femshell_ctx *c, void *dst_host, const void *src_dev, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return FEMSHELL_OK;
+    if (c == nullptr || c->stage_host == nullptr) {
+        FS_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st));
+        FS_HIP(hipStreamSynchronize(st));
+        return FEMSHELL_OK;
+    }
+    for (size_t off = 0; off < bytes; off += c->stage_bytes) {
+        const size_t m = std::min(c->stage_bytes, bytes - off);
+        FS_HIP(hipMemcpyAsync(c->stage_host, static_cast<const char *>(src_dev) + off, m, hipMemcpyDeviceToHost, st));
+        FS_HIP(hipStreamSynchronize(st));
+        char *d = static_cast<char *>(dst_host) + off;
+        const char *h = static_cast<const char *>(c->stage_host);
+        parallel_chunks((int64_t)m, [&](int64_t b, int64_t e) { std::memcpy(d + b, h + b, (size_t)(e - b)); }, 1 << 20);
+    }
+    return FEMSHELL_OK;
+}
+
+int staged_upload(femshell_ctx *c, void *dst_dev, const void *src_host, size_t bytes, hipStream_t st, int region)
+{
+    if (bytes == 0) return FEMSHELL_OK;
+    if (c == nullptr || c->stage_host == nullptr) {
+        FS_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st));
+        FS_HIP(hipStreamSynchronize(st));
+        return FEMSHELL_OK;
+    }
+    for (size_t off = 0; off < bytes; off += c->stage_bytes) {
+        const size_t m = std::min(c->stage_bytes, bytes - off);
+        const char *s = static_cast<const char *>(src_host) + off;
+        char *h = static_cast<char *>(c->stage_host) + (region ? c->stage_bytes : 0);
+        parallel_chunks((int64_t)m, [&](int64_t b, int64_t e) { std::memcpy(h + b, s + b, (size_t)(e - b)); }, 1 << 20);
+        FS_HIP(hipMemcpyAsync(static_cast<char *>(dst_dev) + off, h, m, hipMemcpyHostToDevice, st));
+        FS_HIP(hipStreamSynchronize(st)); // (the buffer is free again)
+    }
+    return FEMSHELL_OK;
+}
+
 // the pattern of the context's K: the plan's slot arrays (padding slots of a row repeat the row's own index; multi-rank
 // contexts never get here -- their hierarchy is built by the shadow context)
-void pattern_of_plan(const Plan &p, HostEllPattern *out)
+void pattern_of_plan(const Plan &p, HostEllPattern *out, bool light)
 {
     HostEllPattern &H = *out;
     H = HostEllPattern();
@@ -174,6 +212,14 @@ void pattern_of_plan(const Plan &p, HostEllPattern *out)
     H.symmetric = p.symmetric;
     H.slice_width = p.slice_width;
     H.slice_base = p.slice_base;
+    if (light) {
+        H.borrowed = &p;
+        if (p.symmetric) {
+            H.in_width = p.in_width;
+            H.in_base = p.in_base;
+        }
+        return;
+    }
     auto copy_of = [](const RawVec<int32_t> &from, RawVec<int32_t> *to) { // (on the host threads: 32 + 2 x 24 MB at 4M triangles)
         to->resize(from.size());
         parallel_chunks((int64_t)from.size(), [&](int64_t b, int64_t e) { std::copy(from.begin() + b, from.begin() + e, to->begin() + b); }, 1 << 18);
@@ -243,17 +289,31 @@ static int32_t aggregate_on_pattern(const HostEllPattern &H, const std::vector<i
 {
     const int32_t n = H.n;
     const bool have_visit = visit != nullptr && (int32_t)visit->size() == n;
+    // (a borrowed pattern: the plan's arrays, whose padding slots -- behind the real ones -- repeat the row's own index)
+    const Plan *pl = H.borrowed;
+    const int32_t *cols = pl ? pl->cols.data() : H.cols.data();
+    const int32_t *in_slots = pl ? pl->in_slots.data() : H.in_slots.data(), *in_rows = pl ? pl->in_rows.data() : H.in_rows.data();
     auto for_each_nb = [&](int32_t i, auto f) { // the node itself first
         const int s = i / kSliceNodes, nn = i % kSliceNodes;
         const int64_t base = H.slice_base[(size_t)s] + nn;
-        const int cnt = H.count[(size_t)i];
-        for (int k = 0; k < cnt; k++)
-            if (!f(H.cols[(size_t)(base + (int64_t)k * kSliceNodes)])) return;
+        if (pl) {
+            if (!f(i)) return;
+            const int W = H.slice_width[(size_t)s];
+            for (int k = 1; k < W; k++) {
+                const int32_t j = cols[(size_t)(base + (int64_t)k * kSliceNodes)];
+                if (j == i) break; // padding from here on
+                if (!f(j)) return;
+            }
+        } else {
+            const int cnt = H.count[(size_t)i];
+            for (int k = 0; k < cnt; k++)
+                if (!f(cols[(size_t)(base + (int64_t)k * kSliceNodes)])) return;
+        }
         if (H.symmetric) {
             const int64_t ib = H.in_base[(size_t)s] + nn;
             for (int k = 0; k < H.in_width[(size_t)s]; k++) {
                 const size_t e = (size_t)(ib + (int64_t)k * kSliceNodes);
-                if (H.in_slots[e] >= 0 && !f(H.in_rows[e])) return;
+                if (in_slots[e] >= 0 && !f(in_rows[e])) return;
             }
         }
     };
@@ -584,13 +644,22 @@ static EllView view_of(const EllPattern &E, const DevPattern &D, double *vals, i
 // Bc, and for small problems the host copies the inspection exports want.  The host runs the greedy passes of the aggregation; the
 // patterns are built in HBM (amg_symbolic.hip) unless the level has clusters of rigidly coupled nodes, a row outgrows the lane
 // sets or FEMSHELL_AMG_SYMBOLIC=host asks for the host's lists.
-int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllPattern &pat, AmgLevel &L, AmgLevel &next,
+int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllPattern &pat_in, AmgLevel &L, AmgLevel &next,
                        const NearNullSrc &B, const std::function<int(double *)> &lam_of, bool keep_host, const std::function<bool(int32_t)> &want_host,
                        Bsr *Ac_host, std::vector<double> *Bc_out, DevBuf<double> *Bc_dev,
                        const std::function<void(const char *)> &lap, const std::function<int()> &before_qr)
 {
     hipStream_t st = c->stream;
-    const int32_t n = pat.n;
+    // (a light pattern of level 0 -- HostEllPattern::borrowed -- is filled when the host's lists are needed after all)
+    HostEllPattern filled;
+    const HostEllPattern *patp = &pat_in;
+    auto need_lists = [&] {
+        if (patp->borrowed != nullptr && patp->cols.empty()) {
+            pattern_of_plan(*patp->borrowed, &filled, false);
+            patp = &filled;
+        }
+    };
+    const int32_t n = pat_in.n;
     if (c->cfg.world_size != 1) return set_err(FEMSHELL_ERR_UNSUPPORTED, "multigrid setup: single-rank contexts only");
     const bool finest = &Adev == &c->dm;
     // ---- aggregation
@@ -609,9 +678,10 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     std::vector<int32_t> agg;
     Bsr G;
     int32_t na = -1;
-    if (!(patches && patches->glue) && try_device) na = aggregate_on_pattern(pat, visit, &agg); // (-1: the sorted graph is needed)
+    if (!(patches && patches->glue) && try_device) na = aggregate_on_pattern(*patp, visit, &agg); // (-1: the sorted graph is needed)
     if (na < 0) {
-        graph_of_pattern(pat, &G);
+        need_lists();
+        graph_of_pattern(*patp, &G);
         lap("  graph of the level");
         na = (patches && patches->glue) ? aggregate_nodes_glued(G, patches->label_p, &agg, visit) : aggregate_nodes(G, &agg, visit);
     }
@@ -625,17 +695,18 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
     if (try_device) {
         GraphView gv;
         gv.n = n;
-        gv.n_slices = (int32_t)pat.slice_width.size();
+        gv.n_slices = (int32_t)pat_in.slice_width.size();
         gv.slice_width = Adev.slice_width;
         gv.slice_base = Adev.slice_base;
         gv.cols = Adev.cols;
         gv.count = dev_count;
-        gv.symmetric = pat.symmetric ? 1 : 0;
+        gv.symmetric = pat_in.symmetric ? 1 : 0;
         gv.in_width = Adev.in_width;
         gv.in_base = Adev.in_base;
         gv.in_slots = Adev.in_slots;
         gv.in_rows = Adev.in_rows;
-        const int rcd = amg_symbolic_device(st, gv, pat.slice_base.back(), (int64_t)pat.in_slots.size(), agg, na, sym_coarse, Sp.get());
+        const int rcd = amg_symbolic_device(c, st, gv, pat_in.slice_base.back(), pat_in.symmetric ? pat_in.in_base.back() : (int64_t)0, agg, na, sym_coarse,
+                                            Sp.get());
         if (rcd == FEMSHELL_OK) {
             on_device = true;
             eP = Sp->iP;
@@ -651,11 +722,12 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
         }
     }
     if (!on_device) {
+        need_lists();
         if (G.nr != n) {
-            graph_of_pattern(pat, &G);
+            graph_of_pattern(*patp, &G);
             lap("  graph of the level");
         }
-        const int rch = symbolic_host(c, pat, G, agg, na, sym_coarse, patches, *Sp, eP, eAP, eR, eAc, lap);
+        const int rch = symbolic_host(c, *patp, G, agg, na, sym_coarse, patches, *Sp, eP, eAP, eR, eAc, lap);
         if (rch) return rch;
     }
     DevSymbolic &S = *Sp;
@@ -738,13 +810,14 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
 
     // ---- the coarse operator goes back for the remaining levels; small problems keep P for the inspection exports
     if (on_device) { // the host copy of the coarse pattern: the next step's aggregation reads it (and the exports below)
-        rc = download_pattern(S.Ac, S.totAc, &eAc, st);
+        rc = download_pattern(c, S.Ac, S.totAc, &eAc, st);
         if (rc) return rc;
         if (keep_host) {
-            rc = download_pattern(S.P, S.totP, &eP, st);
+            rc = download_pattern(c, S.P, S.totP, &eP, st);
             if (rc) return rc;
         }
     }
+    lap("  host copy of the coarse pattern");
     {
         ValueArray h;
         *Ac_host = Bsr();
@@ -776,14 +849,14 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
             Np.in_base.resize(S.in_base.n);
             Np.in_slots.resize((size_t)S.in_total);
             Np.in_rows.resize((size_t)S.in_total);
-            FS_HIP(hipMemcpyAsync(Np.in_width.data(), S.in_width.p, S.in_width.n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            FS_HIP(hipMemcpyAsync(Np.in_base.data(), S.in_base.p, S.in_base.n * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-            if (S.in_total > 0) {
-                FS_HIP(hipMemcpyAsync(Np.in_slots.data(), S.in_slots.p, (size_t)S.in_total * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-                FS_HIP(hipMemcpyAsync(Np.in_rows.data(), S.in_rows.p, (size_t)S.in_total * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            }
+            rc = staged_download(c, Np.in_width.data(), S.in_width.p, S.in_width.n * sizeof(int32_t), st);
+            if (!rc) rc = staged_download(c, Np.in_base.data(), S.in_base.p, S.in_base.n * sizeof(int64_t), st);
+            if (!rc) rc = staged_download(c, Np.in_slots.data(), S.in_slots.p, (size_t)S.in_total * sizeof(int32_t), st);
+            if (!rc) rc = staged_download(c, Np.in_rows.data(), S.in_rows.p, (size_t)S.in_total * sizeof(int32_t), st);
+            if (rc) return rc;
             rc = attach_in_lists_device(next.A, S.in_width, S.in_base, S.in_slots, S.in_rows, S.max_in_width, total_ac, st);
             if (rc) return rc;
+
         } else {
             SlicedEllSym I;
             build_in_lists(na, eAc.slice_width, eAc.slice_base, eAc.cols.data(), eAc.count, &I);

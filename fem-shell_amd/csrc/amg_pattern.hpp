@@ -69,6 +69,10 @@ void adopt(AmgOperator &op, const EllPattern &E, DevPattern &D, DevBuf<double> &
 // host BSR (ascending columns) from a pattern and the ELL values brought back from the device
 void ell_to_bsr(const EllPattern &E, const double *vals, int32_t n_cols, Bsr *out);
 int download_vals(const DevBuf<double> &d, ValueArray *h, hipStream_t st);
+// index arrays between host and HBM through the context's pinned staging buffer (context.hpp stage_host); both return when the
+// data has arrived
+int staged_download(femshell_ctx *c, void *dst_host, const void *src_dev, size_t bytes, hipStream_t st);
+int staged_upload(femshell_ctx *c, void *dst_dev, const void *src_host, size_t bytes, hipStream_t st, int region = 0);
 // the block graph of a level operator as a pattern-only BSR with ascending columns (both directions of a symmetric one)
 void graph_of_pattern(const HostEllPattern &H, Bsr *G);
 

@@ -2,6 +2,7 @@
 // and the flexible PCG around it.  Replaces what `-pc_type gamg`-style options select inside PETSc's KSPSolve
 // behind equation_systems.solve() (fem-shell.cpp:138, doc/implementation.tex:68-72).
 #include "amg_device.hpp"
+#include "amg_pattern.hpp"
 #include <thread>
 #include "trace.hpp"
 
@@ -526,13 +527,11 @@ int amg_setup(femshell_ctx *c)
         normals_thread = std::thread([&] {
             node_normals_plan(pl, &normals);
             if (!normals_to_device) return;
-            hipStream_t s = nullptr;
-            hipError_t e = hipSetDevice(c->device);
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipMemcpyAsync(d_normals.p, normals.data(), normals.size() * sizeof(double), hipMemcpyHostToDevice, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
-            if (s) (void)hipStreamDestroy(s);
-            normals_err = e;
+            hipStream_t s = c->copy_stream != nullptr ? c->copy_stream : c->stream; // (see context.hpp)
+            normals_err = hipSetDevice(c->device);
+            // (through the pinned staging buffer, region 1: `normals` is freed when the first step is through -- context.hpp stage_host)
+            if (normals_err == hipSuccess && staged_upload(c, d_normals.p, normals.data(), normals.size() * sizeof(double), s, 1) != FEMSHELL_OK)
+                normals_err = hipErrorUnknown;
         });
     auto normals_ready = [&] {
         if (normals_thread.joinable()) normals_thread.join();
@@ -596,7 +595,7 @@ int amg_setup(femshell_ctx *c)
         AmgLevel &L1 = *H.levels.back();
         std::vector<double> Bc;
         lap("node normals", 0);
-        pattern_of_plan(pl, &L0.pattern);
+        pattern_of_plan(pl, &L0.pattern, /*light=*/true); // (amg_device_coarsen fills the slot arrays if it needs the host's lists)
         lap("pattern of K", 0);
         // the near-null space of the finest level is generated from the mesh in HBM (never stored: n x 36 doubles)
         NearNullSrc src;
@@ -739,6 +738,7 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
                 const int rcs = fetch_status_word(c, st, &status_now);
                 if (rcs) return rcs;
             }
+
             if (status_now != 0) {
                 {
                     const int rcc = clear_status_word(c, st);

@@ -479,7 +479,7 @@ PatView view_of(const DevPattern &D)
 
 } // namespace
 
-int amg_symbolic_device(hipStream_t st, const GraphView &G, int64_t total_slots, int64_t in_total, const std::vector<int32_t> &agg, int32_t na,
+int amg_symbolic_device(femshell_ctx *c, hipStream_t st, const GraphView &G, int64_t total_slots, int64_t in_total, const std::vector<int32_t> &agg, int32_t na,
                         bool sym_coarse, DevSymbolic *out)
 {
     DevSymbolic &S = *out;
@@ -487,7 +487,11 @@ int amg_symbolic_device(hipStream_t st, const GraphView &G, int64_t total_slots,
     const int32_t na_pad = (na + kSliceNodes - 1) / kSliceNodes * kSliceNodes;
     DevBuf<unsigned long long> info;
     FS_HIP(info.alloc(kInfoWords));
-    FS_HIP(S.agg.upload(agg, st));
+    FS_HIP(S.agg.alloc(agg.size()));
+    {
+        const int rcu = staged_upload(c, S.agg.p, agg.data(), agg.size() * sizeof(int32_t), st);
+        if (rcu) return rcu;
+    }
     // ---- nodes by aggregate (the tentative prolongator's QR runs per aggregate; R's rows are collected from the members)
     DevBuf<int32_t> gcnt;
     FS_HIP(gcnt.alloc((size_t)na));
@@ -578,18 +582,17 @@ int amg_symbolic_device(hipStream_t st, const GraphView &G, int64_t total_slots,
     return FEMSHELL_OK;
 }
 
-int download_pattern(const DevPattern &D, int64_t total, EllPattern *E, hipStream_t st)
+int download_pattern(femshell_ctx *c, const DevPattern &D, int64_t total, EllPattern *E, hipStream_t st)
 {
     E->slice_width.resize((size_t)E->n_slices);
     E->slice_base.resize((size_t)E->n_slices + 1);
     E->cols.resize((size_t)total);
     E->count.resize((size_t)E->n_pad);
-    FS_HIP(hipMemcpyAsync(E->slice_width.data(), D.slice_width.p, E->slice_width.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    FS_HIP(hipMemcpyAsync(E->slice_base.data(), D.slice_base.p, E->slice_base.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    if (total > 0) FS_HIP(hipMemcpyAsync(E->cols.data(), D.cols.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    FS_HIP(hipMemcpyAsync(E->count.data(), D.count.p, E->count.size(), hipMemcpyDeviceToHost, st));
-    FS_HIP(hipStreamSynchronize(st));
-    return FEMSHELL_OK;
+    int rc = staged_download(c, E->slice_width.data(), D.slice_width.p, E->slice_width.size() * sizeof(int32_t), st);
+    if (!rc) rc = staged_download(c, E->slice_base.data(), D.slice_base.p, E->slice_base.size() * sizeof(int64_t), st);
+    if (!rc) rc = staged_download(c, E->cols.data(), D.cols.p, (size_t)total * sizeof(int32_t), st);
+    if (!rc) rc = staged_download(c, E->count.data(), D.count.p, E->count.size(), st);
+    return rc;
 }
 
 } // namespace femshell

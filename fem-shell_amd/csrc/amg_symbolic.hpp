@@ -51,9 +51,9 @@ struct DevSymbolic {
 // Builds everything above from the operator's pattern G (total_slots / in_total: sizes of its slot and in-list arrays) and the
 // aggregates (host array, n entries, na aggregates).  Returns FEMSHELL_ERR_UNSUPPORTED (without an error text of its own
 // mattering) when a row outgrows the lane sets -- the caller then takes the host path.
-int amg_symbolic_device(hipStream_t st, const GraphView &G, int64_t total_slots, int64_t in_total, const std::vector<int32_t> &agg, int32_t na,
+int amg_symbolic_device(femshell_ctx *c, hipStream_t st, const GraphView &G, int64_t total_slots, int64_t in_total, const std::vector<int32_t> &agg, int32_t na,
                         bool sym_coarse, DevSymbolic *out);
 // host copies (for the inspection exports and for steps that continue on the host)
-int download_pattern(const DevPattern &D, int64_t total, EllPattern *E, hipStream_t st);
+int download_pattern(femshell_ctx *c, const DevPattern &D, int64_t total, EllPattern *E, hipStream_t st);
 
 } // namespace femshell

@@ -465,11 +465,31 @@ int femshell_create(const femshell_config *cfg, femshell_ctx **out)
         }
     }
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->agree_host), 2 * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess) { // (optional: see context.hpp)
+        c->stage_bytes = (size_t)32 << 20;
+        if (hipHostMalloc(&c->stage_host, 2 * c->stage_bytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            c->stage_host = nullptr;
+            c->stage_bytes = 0;
+        }
+    }
     if (e == hipSuccess) e = c->status.zero(c->stream);
     if (e == hipSuccess) e = c->scal.alloc(1);
     if (e == hipSuccess) e = c->scal.zero(c->stream);
+    if (e == hipSuccess && c->stage_host != nullptr) {
+        // the first copy from HBM into pinned memory on a stream takes 6 ms on these boxes (the runtime sets up the engine's queue
+        // for that direction at first use; every later one 20 us): taken here, once per context, not inside the first setup
+        // (64 KB: copies of a few bytes take another path and leave this one cold)
+        femshell::DevBuf<char> warm;
+        e = warm.alloc(65536);
+        if (e == hipSuccess) e = hipMemsetAsync(warm.p, 0, 65536, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->stage_host, warm.p, 65536, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(warm.p, c->stage_host, 65536, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
     // the second stream of the dense inverse's look-ahead (amg_dense.hip): made, and used once, here -- the first launch on a new
     // stream pays for its hardware queue (5 ms), which has no place inside the multigrid setup
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMemsetAsync(c->scal.p, 0, sizeof(*c->scal.p), c->aux_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->aux_stream);
@@ -519,8 +539,10 @@ int femshell_destroy(femshell_ctx *c)
     if (c->ev_halo_done) (void)hipEventDestroy(c->ev_halo_done);
     if (c->halo_stream) (void)hipStreamDestroy(c->halo_stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->status_host) (void)hipHostFree(c->status_host);
     if (c->agree_host) (void)hipHostFree(c->agree_host);
+    if (c->stage_host) (void)hipHostFree(c->stage_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -388,6 +388,15 @@ struct femshell_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int32_t *status_host = nullptr; // pinned landing place of the device status word
+    // Two regions of 32 MB of pinned host memory through which the multigrid setup moves its arrays (staged_download / staged_upload
+    // in amg_device_setup.cpp; region 0: the calling thread, region 1: the setup's helper thread).  Why not plain copies from and to
+    // the arrays themselves: the runtime registers the pages of a large pageable copy with the driver, and a host array that is
+    // FREED soon after -- the 48 MB of node normals, released when the first coarsening step is through -- takes that registration
+    // down through the MMU notifier, which evicts the process's queues: the next launch on the main stream waited 24-31 ms (found
+    // with FEMSHELL_AMG_VERBOSE laps around the block-Jacobi kernel of level 1; gone with the array kept, or copied through here).
+    // nullptr when the allocation failed: the copies then go the pageable way.
+    void *stage_host = nullptr;
+    size_t stage_bytes = 0; // of ONE region
     // the status word as the kernels see it: c->status in HBM, or -- FEMSHELL_STATUS_MAPPED, the default -- the device address of
     // status_host itself (kernels write the word on failure only, with a system-scope compare-and-swap; the host reads it after the
     // stream synchronisation without a copy: 12 us of every femshell_assemble)
@@ -402,6 +411,10 @@ struct femshell_ctx {
     femshell::DevBuf<double> x0;
     bool warm_next = false;
     hipStream_t aux_stream = nullptr; // the look-ahead of the dense inverse (amg_dense.hip)
+    // uploads a helper thread of the multigrid setup makes beside the main stream (the node normals, amg_solve.cpp).  Made once per
+    // context: a stream created AND destroyed by the helper thread inside the setup left a later launch on the main stream waiting
+    // 24-31 ms for its turn (the runtime tearing the hardware queue down), whenever the timing was right for it.
+    hipStream_t copy_stream = nullptr;
     int aux_streams_side_by_side = 0; // 0: not asked yet, 1: stream and aux_stream run concurrently, -1: they share a hardware queue
     // first-contact self-test of femshell_comm_init (comm.cpp comm_selftest): microseconds of its three patterns
     double comm_selftest_us[3] = {-1.0, -1.0, -1.0};
