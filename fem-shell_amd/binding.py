@@ -371,6 +371,13 @@ class FemShell:
         return {"prolongator_ms": out[0], "ap_ms": out[1], "restriction_ms": out[2], "galerkin_ms": out[3],
                 "galerkin_useful_flops": out[4], "galerkin_mfma_flops_issued": out[5], "galerkin_on_matrix_cores": bool(out[6])}
 
+    def amg_symbolic_info(self):
+        """Coarsening steps of the last setup by where their patterns were built."""
+        out = np.zeros(3, dtype=np.int32)
+        self._L.femshell_amg_symbolic_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        _check(self._L.femshell_amg_symbolic_info(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return {"in_hbm": int(out[0]), "host_after_overflow": int(out[1]), "host_by_rule": int(out[2])}
+
     def assembly_kernel(self):
         """Name of the kernel femshell_assemble launches for this mesh."""
         k = self._L.femshell_assembly_kernel(self._h)

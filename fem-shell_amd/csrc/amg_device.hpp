@@ -137,6 +137,8 @@ struct AmgSetupStats {
     double prolongator_ms = 0, ap_ms = 0, restriction_ms = 0, galerkin_ms = 0;
     double galerkin_useful_flops = 0, galerkin_mfma_flops_issued = 0;
     int galerkin_mfma = 0;
+    // coarsening steps by where their patterns were built: in HBM / on the host after the device gave up / on the host by rule
+    int symbolic_device = 0, symbolic_fallback = 0, symbolic_host = 0;
 };
 
 // Level 0 of a row-partitioned context (see amg_solve.cpp): work vectors in the rank's numbering (x0, d0 with ghost

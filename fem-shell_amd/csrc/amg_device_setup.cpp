@@ -709,6 +709,7 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
                                             Sp.get());
         if (rcd == FEMSHELL_OK) {
             on_device = true;
+            c->amg->stats.symbolic_device++;
             eP = Sp->iP;
             eAP = Sp->iAP;
             eR = Sp->iR;
@@ -719,9 +720,11 @@ int amg_device_coarsen(femshell_ctx *c, const DeviceMatrix &Adev, const HostEllP
         } else {
             FS_HIP(hipStreamSynchronize(st));
             Sp.reset(new DevSymbolic()); // a row too long for the lane sets: the host's lists
+            c->amg->stats.symbolic_fallback++;
         }
     }
     if (!on_device) {
+        if (!try_device) c->amg->stats.symbolic_host++;
         need_lists();
         if (G.nr != n) {
             graph_of_pattern(*patp, &G);

@@ -1023,6 +1023,17 @@ int femshell_amg_setup_stats(femshell_ctx *c, double out[7])
     return FEMSHELL_OK;
 }
 
+int femshell_amg_symbolic_info(femshell_ctx *c, int32_t out[3])
+{
+    if (!c || !out) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_symbolic_info: null argument");
+    if (!c->amg || !c->amg->valid) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_symbolic_info: no multigrid hierarchy");
+    const AmgSetupStats &S = c->amg->stats;
+    out[0] = S.symbolic_device;
+    out[1] = S.symbolic_fallback;
+    out[2] = S.symbolic_host;
+    return FEMSHELL_OK;
+}
+
 int femshell_amg_partition_info(femshell_ctx *c, double out[6])
 {
     if (!c || !out) return set_err(FEMSHELL_ERR_INVALID, "femshell_amg_partition_info: null argument");

@@ -222,6 +222,11 @@ int femshell_amg_patch_info(femshell_ctx *ctx, double out[6]);
  * restriction and Galerkin kernels, out[4] = useful flops of the Galerkin product, out[5] = flops issued on the
  * matrix cores (v_mfma_f64_16x16x4_f64 tiles; 0 when the vector-ALU kernel ran), out[6] = 1 if the matrix cores ran */
 int femshell_amg_setup_stats(femshell_ctx *ctx, double out[7]);
+/* Where the integer work of the last multigrid setup's coarsening steps ran (the setup is part of what replaces
+ * equation_systems.solve(), fem-shell.cpp:138 -- PETSc's KSPSetUp): out[0] = steps whose patterns were built in HBM
+ * (csrc/amg_symbolic.hip), out[1] = steps that took the host's lists although the device was asked (a row beyond the lane sets),
+ * out[2] = steps on the host's lists by rule (clusters of rigidly coupled nodes, FEMSHELL_AMG_SYMBOLIC=host). */
+int femshell_amg_symbolic_info(femshell_ctx *ctx, int32_t out[3]);
 /* the dense inverse of the coarsest operator when it was computed on the matrix cores (csrc/amg_dense.hip; symmetric block
  * sweeps on v_mfma_f64_16x16x4_f64): out[0] = dofs n (0: the host inverted a small operator), out[1] = milliseconds,
  * out[2] = flops issued on the matrix cores, out[3] = n^3 (the flops of a symmetric inversion), out[4] = dropped

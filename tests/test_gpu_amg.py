@@ -827,3 +827,54 @@ def test_patterns_built_in_hbm_are_the_hosts_lists_slot_for_slot(monkeypatch, ki
     assert dev[1] == host[1]
     np.testing.assert_array_equal(dev[2], host[2])
     np.testing.assert_array_equal(dev[0], host[0])
+
+
+def _fan_mesh(valence, rings=6):
+    """A dished disc of `rings` rings of `valence` nodes around a hub that is numbered LAST: the greedy passes reach the hub when its
+    neighbours are taken, so its row of P sees every aggregate of the first ring."""
+    pts = []
+    for r in range(1, rings + 1):
+        for k in range(valence):
+            a = 2 * np.pi * (k + 0.5 * (r % 2)) / valence
+            pts.append((r * np.cos(a), r * np.sin(a), 0.05 * r * r))
+    hub = len(pts)
+    pts.append((0.0, 0.0, 0.0))
+
+    def idx(r, k):
+        return (r - 1) * valence + (k % valence)
+
+    tri = [(hub, idx(1, k), idx(1, k + 1)) for k in range(valence)]
+    for r in range(1, rings):
+        for k in range(valence):
+            a, b, c, d = idx(r, k), idx(r, k + 1), idx(r + 1, k), idx(r + 1, k + 1)
+            tri += [(a, c, d), (a, d, b)] if r % 2 else [(a, c, b), (b, c, d)]
+    return np.array(pts), np.array(tri, dtype=np.int32)
+
+
+def test_rows_beyond_the_lane_sets_take_the_hosts_lists(monkeypatch):
+    """csrc/amg_symbolic.hip builds a row of P as a set of at most 64 aggregates in LDS (A P: 128, R and A_c: 256).  A hub of valence
+    200 sees more (tools/lab/fan_probe.py: 67 and more from valence 200 on; beyond 240 an aggregate is seen by more than the 255 rows
+    either path allows): the step says so (femshell_amg_symbolic_info), takes the host's lists and the solve goes on as if nothing had
+    happened -- slowly: the triangles at the hub are needles of 1.8 degrees --; the level below is built in HBM again."""
+    monkeypatch.setenv("FEMSHELL_AMG_PATCH_TAU", "0")  # (needle-shaped triangles at the hub: no cluster blocks, this test is about the lists)
+    monkeypatch.setenv("FEMSHELL_AMG_DEVICE_MIN", "100")
+    ensure_built()
+    xyz, tri = _fan_mesh(200)
+    n = len(xyz)
+    dmask = np.zeros(n, dtype=np.uint8)
+    dmask[np.hypot(xyz[:, 0], xyz[:, 1]) > 5.5] = 0x3F
+    loads = np.zeros((n, 6))
+    loads[:, 2] = 1.0
+    fs = pkg.FemShell(0.3, 1e7, 0.2, device=0)
+    fs.set_mesh(xyz, tri)
+    fs.set_dirichlet(dmask)
+    fs.set_loads(loads)
+    fs.set_preconditioner("amg", coarsest_nodes=60)
+    u, info = fs.solve(rtol=1e-10, max_it=5000)
+    where = fs.amg_symbolic_info()
+    assert where["host_after_overflow"] >= 1 and where["in_hbm"] >= 1, where
+    assert info["converged"] == 1, info
+    rg, cg, vg, Fg = fs.export_bsr()
+    ug = oracle.refined_solve(rg, cg, vg, Fg)
+    assert np.linalg.norm(u.ravel() - ug) / np.linalg.norm(ug) < 1e-7
+    fs.close()
