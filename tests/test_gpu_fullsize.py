@@ -214,3 +214,27 @@ def test_a_mesh_size_that_draws_the_dense_tiling(monkeypatch):
         assert info["iterations"] <= 96 and info["iterations"] + 6 <= info0["iterations"], (info["iterations"], info0["iterations"])
     finally:
         fs.close()
+
+
+def test_full_size_setup_builds_its_patterns_in_hbm_and_keeps_the_hosts_hierarchy(context, monkeypatch):
+    """Round 6: at BASELINE's size the three coarsening steps above 5,000 nodes build their patterns in HBM
+    (csrc/amg_symbolic.hip; the host runs the greedy passes on K's own ELL pattern), and the hierarchy is the one the host's lists
+    give -- level sizes, spectral bounds, operator complexity, iteration count and the residual history bit for bit -- in less of the
+    setup's time (0.075 against 0.15 s on a quiet box; the bound leaves room for the driver's allocator)."""
+    kind, m, mat, fs = context
+    fs.set_loads(m.loads)
+    out = {}
+    for where in ("host", "device"):
+        monkeypatch.setenv("FEMSHELL_AMG_SYMBOLIC", where)
+        fs.set_dirichlet(m.dirichlet_mask())  # (the constraint set handed over again: K is assembled anew and the hierarchy rebuilt)
+        fs.set_preconditioner("amg")
+        u, info = fs.solve(rtol=1e-10, max_it=400, fetch=False)
+        assert info["converged"] == 1 and info["pc_setup_seconds"] > 0.0, info
+        out[where] = (info, fs.amg_levels(), fs.amg_symbolic_info(), fs.residual_history().copy())
+    assert out["device"][2]["in_hbm"] >= 3 and out["device"][2]["host_after_overflow"] == 0, out["device"][2]
+    assert out["host"][2]["in_hbm"] == 0 and out["host"][2]["host_by_rule"] >= 3, out["host"][2]
+    assert out["device"][1] == out["host"][1]
+    assert out["device"][0]["iterations"] == out["host"][0]["iterations"]
+    assert out["device"][0]["operator_complexity"] == out["host"][0]["operator_complexity"]
+    np.testing.assert_array_equal(out["device"][3], out["host"][3])
+    assert out["device"][0]["pc_setup_seconds"] < 0.85 * out["host"][0]["pc_setup_seconds"], (out["device"][0], out["host"][0])
