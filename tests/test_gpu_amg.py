@@ -794,7 +794,7 @@ def _delaunay_context(n_pts, seed):
 
 
 @pytest.mark.parametrize("kind,n,coarse_sym", [("panel", 64, "100000"), ("panel", 64, "1"), ("quads", 40, "1"), ("cylinder", 48, "100000"),
-                                               ("delaunay", 6000, "1"), ("delaunay", 6000, "100000")])
+                                               ("delaunay", 6000, "1"), ("delaunay", 6000, "100000"), ("full", 56, "1"), ("mixed", 40, "1")])
 def test_patterns_built_in_hbm_are_the_hosts_lists_slot_for_slot(monkeypatch, kind, n, coarse_sym):
     """Round 6, csrc/amg_symbolic.hip: the patterns of P, A P, R, A_c, the maps from the blocks of A to the slots
     of P and the in-lists of a symmetric A_c are built in HBM, one lane per row; the greedy passes of the aggregation run on the
@@ -803,10 +803,24 @@ def test_patterns_built_in_hbm_are_the_hosts_lists_slot_for_slot(monkeypatch, ki
     levels), with full and with symmetric storage of the coarse operators, on structured and on Delaunay meshes."""
     monkeypatch.setenv("FEMSHELL_AMG_DEVICE_MIN", "100")
     monkeypatch.setenv("FEMSHELL_AMG_COARSE_SYM", coarse_sym)
+    if kind == "full":  # K itself stored in full (no in-lists on level 0), the coarse operators symmetric
+        monkeypatch.setenv("FEMSHELL_SYMMETRIC", "0")
     out = []
     for where in ("device", "host"):
         monkeypatch.setenv("FEMSHELL_AMG_SYMBOLIC", where)
-        fs = _delaunay_context(n, 5) if kind == "delaunay" else _context(*_make(kind, n))
+        if kind == "delaunay":
+            fs = _delaunay_context(n, 5)
+        elif kind == "mixed":  # triangles and quadrilaterals in one mesh
+            m, mat = _make("quads", n)
+            half = len(m.quad) // 2
+            tri = np.concatenate([m.quad[half:, [0, 1, 2]], m.quad[half:, [0, 2, 3]]]).astype(np.int32)
+            ensure_built()
+            fs = pkg.FemShell(*mat, device=0)
+            fs.set_mesh(m.xyz, tri, m.quad[:half])
+            fs.set_dirichlet(m.dirichlet_mask())
+            fs.set_loads(m.loads)
+        else:
+            fs = _context(*_make("panel" if kind == "full" else kind, n))
         fs.set_preconditioner("amg", coarsest_nodes=60)
         u, info = fs.solve(rtol=1e-10, max_it=600)
         assert info["converged"] == 1, info
