@@ -3,6 +3,7 @@
 # (FEMSHELL_AMG_SYMBOLIC=host), 4M-triangle panel and cylinder: laps of the setup, iterations, time.  One gpurun call.
 out=gpurun_out/r06_symbolic
 mkdir -p $out
+[ -x tools/lab/pagefault_probe ] || g++ -O2 -pthread tools/lab/pagefault_probe.cpp -o tools/lab/pagefault_probe
 tools/lab/pagefault_probe 16 > $out/pagefault.txt 2>&1
 tools/lab/pagefault_probe 1 >> $out/pagefault.txt 2>&1
 cat /sys/kernel/mm/transparent_hugepage/enabled >> $out/pagefault.txt 2>&1
