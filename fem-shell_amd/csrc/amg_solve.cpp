@@ -527,8 +527,9 @@ int amg_setup(femshell_ctx *c)
         normals_thread = std::thread([&] {
             node_normals_plan(pl, &normals);
             if (!normals_to_device) return;
-            hipStream_t s = c->copy_stream != nullptr ? c->copy_stream : c->stream; // (see context.hpp)
             normals_err = hipSetDevice(c->device);
+            if (normals_err == hipSuccess && c->copy_stream == nullptr) normals_err = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+            hipStream_t s = c->copy_stream; // (see context.hpp)
             // (through the pinned staging buffer, region 1: `normals` is freed when the first step is through -- context.hpp stage_host)
             if (normals_err == hipSuccess && staged_upload(c, d_normals.p, normals.data(), normals.size() * sizeof(double), s, 1) != FEMSHELL_OK)
                 normals_err = hipErrorUnknown;
@@ -909,6 +910,9 @@ int amg_finish_hierarchy(femshell_ctx *c, Bsr &A, std::vector<double> &B, DevBuf
         // 1 (default): levels of at least 4096 nodes; 2: level 0 only, 3: every level, whatever their size (A/B runs, tests); 0: off.
         const char *e = getenv("FEMSHELL_AMG_SMOOTH_F32");
         const int mode = c->amg_fp64_only ? 0 : (e ? atoi(e) : 1);
+        // (what the coarsening steps released -- A P, Q, the symbolic buffers -- joins the pool's kept blocks now: the copies below are
+        //  carved from them instead of being fresh requests to the driver, context.hpp DevPool::alloc (3))
+        if (mode != 0) (void)DevPool::get().flush_pending();
         for (size_t l = 0; l + 1 < H.levels.size(); l++) {
             AmgLevel &L = *H.levels[l];
             L.A32.release();

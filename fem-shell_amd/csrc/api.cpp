@@ -489,7 +489,6 @@ int femshell_create(const femshell_config *cfg, femshell_ctx **out)
     }
     // the second stream of the dense inverse's look-ahead (amg_dense.hip): made, and used once, here -- the first launch on a new
     // stream pays for its hardware queue (5 ms), which has no place inside the multigrid setup
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMemsetAsync(c->scal.p, 0, sizeof(*c->scal.p), c->aux_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->aux_stream);

@@ -1,6 +1,7 @@
 // context.hpp -- what the translation units of libfemshell share: error reporting, device buffers, the context
 // behind a femshell_ctx handle and the CG driver's entry points (cg_driver.cpp).
 #pragma once
+#include <cstdio>
 
 #include "femshell.h"
 
@@ -62,7 +63,19 @@ class DevPool {
         static DevPool pool;
         return pool;
     }
+    // FEMSHELL_POOL_POISON=1 (tests, debugging): every block is filled with 0xFF bytes -- NaNs as doubles and floats, -1 as
+    // integers -- before it is handed out.  Fresh memory from the driver is zero and recycled memory is not: whoever relies on
+    // zeros it never wrote works until the pool hands it a used block (found that way: round 6, the carved blocks).
     hipError_t alloc(void **out, size_t bytes)
+    {
+        const hipError_t e = alloc_raw(out, bytes);
+        if (e == hipSuccess && poison_ && *out != nullptr && bytes > 0) {
+            (void)hipMemset(*out, 0xFF, bytes);
+            (void)hipDeviceSynchronize();
+        }
+        return e;
+    }
+    hipError_t alloc_raw(void **out, size_t bytes)
     {
         *out = nullptr;
         int dev = 0;
@@ -88,6 +101,15 @@ class DevPool {
                         a = &ar;
                         break;
                     }
+                if (a == nullptr && carve_) // (a kept block of the driver's that holds the request becomes the next arena: alloc (3) below)
+                    for (auto jt = free_.lower_bound(Key{dev, need}); jt != free_.end() && jt->first.dev == dev; ++jt) {
+                        if (in_arena(jt->second)) continue;
+                        arenas_.push_back(Arena{dev, static_cast<char *>(jt->second), jt->first.bytes, 0, 0, true});
+                        cached_ -= jt->first.bytes;
+                        free_.erase(jt);
+                        a = &arenas_.back();
+                        break;
+                    }
                 if (a == nullptr) {
                     void *base = nullptr;
                     const size_t ab = arena_bytes_;
@@ -95,8 +117,9 @@ class DevPool {
                     const hipError_t e = hipMalloc(&base, ab);
                     stat_malloc_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
                     stat_mallocs_++;
+                    if (getenv("FEMSHELL_POOL_VERBOSE")) fprintf(stderr, "[femshell pool] hipMalloc of an arena, %zu MB (for a request of %zu bytes)\n", ab >> 20, bytes);
                     if (e == hipSuccess) {
-                        arenas_.push_back(Arena{dev, static_cast<char *>(base), ab, 0, 0});
+                        arenas_.push_back(Arena{dev, static_cast<char *>(base), ab, 0, 0, false});
                         a = &arenas_.back();
                     } else {
                         (void)hipGetLastError(); // (no room for another arena: the request goes to the driver on its own, below)
@@ -109,12 +132,44 @@ class DevPool {
                     live_[*out] = need;
                     return hipSuccess;
                 }
+            } else if (arena_bytes_ > 0 && carve_) {
+                // (3) CARVING (round 6).  A large request that no kept block fits within a quarter: (a) room in a block that was
+                // carved before, else (b) the smallest kept block that holds it at all becomes an arena and the request its first
+                // piece; the rest serves the requests that follow.  A multigrid setup ends with the single-precision copies -- 1.1,
+                // 0.8, 0.7 GB at 4M triangles -- right after A P (3.1 GB) has come back: five hipMalloc calls and 2.6 GB of fresh
+                // memory less, which is 35-50 ms on a box whose allocator is in its slow state (profiles/r06_hipmalloc_probe.txt).
+                const size_t need_g = (bytes + kGranule - 1) / kGranule * kGranule;
+                Arena *a = nullptr;
+                for (auto &ar : arenas_)
+                    if (ar.carved && ar.dev == dev && ar.used + need_g <= ar.bytes) {
+                        a = &ar;
+                        break;
+                    }
+                if (a == nullptr)
+                    for (auto jt = free_.lower_bound(Key{dev, need_g}); jt != free_.end() && jt->first.dev == dev; ++jt) {
+                        if (in_arena(jt->second)) continue;
+                        arenas_.push_back(Arena{dev, static_cast<char *>(jt->second), jt->first.bytes, 0, 0, true});
+                        cached_ -= jt->first.bytes;
+                        free_.erase(jt);
+                        a = &arenas_.back();
+                        break;
+                    }
+                if (a != nullptr) {
+                    *out = a->base + a->used;
+                    a->used += need_g;
+                    a->live++;
+                    live_[*out] = need_g;
+                    return hipSuccess;
+                }
             }
         }
         const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(out, bytes);
         stat_malloc_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         stat_mallocs_++;
+        if (getenv("FEMSHELL_POOL_VERBOSE"))
+            fprintf(stderr, "[femshell pool] hipMalloc %.1f MB: %.2f ms\n", (double)bytes / 1048576.0,
+                    1e-6 * (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
         if (e != hipSuccess) { // out of memory with blocks kept (or waiting for the end of a setup): give them back and try once more
             const bool waited = flush_pending(), kept = trim();
             if (waited || kept) {
@@ -143,17 +198,11 @@ class DevPool {
             arena = in_arena(p);
         }
         const auto t0 = std::chrono::steady_clock::now();
-        if (!arena && bytes > limit_ && defer_depth_.load() > 0) {
-            // (a block too large to keep, released inside a multigrid setup -- A P of a 32M-triangle mesh, 26 GB: it goes back to the
-            //  driver when the setup is over.  Freed at once, the setup's NEXT requests -- the single-precision copies -- waited for
-            //  the driver to wipe it: 0.65 s of hipMalloc in a 1.05 s setup, profiles/r06_hipmalloc_probe.txt)
-            int dev_now = 0;
-            (void)hipGetDevice(&dev_now);
-            std::lock_guard<std::mutex> lock(m_);
-            pending_.push_back(Pending{p, bytes, false, dev_now, true});
-            return;
-        }
-        if (!arena && (bytes == 0 || bytes > limit_)) {
+        // (a block too large to keep, released inside a multigrid setup -- A P of a 32M-triangle mesh, 26 GB -- waits with the others:
+        //  freed at once, the setup's NEXT requests -- the single-precision copies -- waited for the driver to wipe it, 0.65 s of
+        //  hipMalloc in a 1.05 s setup; kept until the setup is over it is what those requests are carved from)
+        const bool deferred = defer_depth_.load() > 0 && bytes > 0;
+        if (!deferred && !arena && (bytes == 0 || bytes > limit_)) {
             (void)hipFree(p);
             stat_free_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
             stat_frees_++;
@@ -161,9 +210,9 @@ class DevPool {
         }
         int dev = 0;
         (void)hipGetDevice(&dev);
-        if (defer_depth_.load() > 0) { // (a multigrid setup in progress: see Defer below)
+        if (deferred) { // (a multigrid setup in progress: see Defer below)
             std::lock_guard<std::mutex> lock(m_);
-            pending_.push_back(Pending{p, bytes, arena, dev, false});
+            pending_.push_back(Pending{p, bytes, arena, dev});
             return;
         }
         (void)hipDeviceSynchronize(); // (what hipFree does: nothing in flight reads or writes the block any more)
@@ -180,11 +229,20 @@ class DevPool {
         Defer() { DevPool::get().defer_depth_.fetch_add(1); }
         ~Defer()
         {
-            if (DevPool::get().defer_depth_.fetch_sub(1) == 1) DevPool::get().flush_pending();
+            if (DevPool::get().defer_depth_.fetch_sub(1) == 1) {
+                (void)DevPool::get().flush_pending();
+                DevPool::get().enforce_limit();
+            }
         }
         Defer(const Defer &) = delete;
         Defer &operator=(const Defer &) = delete;
     };
+    // (when the last Defer object is gone: kept blocks beyond the pool's limit go back to the driver, largest first)
+    void enforce_limit()
+    {
+        std::lock_guard<std::mutex> lock(m_);
+        trim_to_limit();
+    }
     bool flush_pending()
     {
         std::vector<Pending> list;
@@ -197,14 +255,8 @@ class DevPool {
         (void)hipDeviceSynchronize();
         stat_sync_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         stat_syncs_ += list.size();
-        for (const Pending &b : list)
-            if (b.to_driver) {
-                (void)hipFree(b.p);
-                stat_frees_++;
-            }
         std::lock_guard<std::mutex> lock(m_);
-        for (const Pending &b : list)
-            if (!b.to_driver) keep_block(b.p, b.bytes, b.arena, b.dev);
+        for (const Pending &b : list) keep_block(b.p, b.bytes, b.arena, b.dev);
         return true;
     }
 
@@ -214,7 +266,6 @@ class DevPool {
         size_t bytes;
         bool arena;
         int dev;
-        bool to_driver; // larger than the pool keeps: hipFree when the list is flushed
     };
     // (callers hold m_; the device has been idle since the block came back)
     void keep_block(void *p, size_t bytes, bool arena, int dev)
@@ -234,6 +285,11 @@ class DevPool {
         }
         free_.emplace(Key{dev, bytes}, p);
         cached_ += bytes;
+        if (defer_depth_.load() > 0) return; // (inside a setup the kept blocks may exceed the limit: enforce_limit() when it is over)
+        trim_to_limit();
+    }
+    void trim_to_limit()
+    {
         while (cached_ > limit_) { // over the limit: the largest kept block that is the driver's goes back to it
             auto big = free_.end();
             for (auto it = free_.end(); it != free_.begin();) {
@@ -313,6 +369,7 @@ class DevPool {
         char *base;
         size_t bytes, used;
         int64_t live; // pieces in use
+        bool carved = false; // a kept block turned into an arena (alloc (3)); large requests are served from these only
     };
     static constexpr size_t kMinBytes = 1u << 20;
     static constexpr size_t kGranule = 256;
@@ -322,6 +379,8 @@ class DevPool {
         const char *e = getenv("FEMSHELL_POOL_GB");
         const double gb = e ? atof(e) : 24.0;
         limit_ = gb > 0.0 ? (size_t)(gb * 1073741824.0) : 0;
+        poison_ = getenv("FEMSHELL_POOL_POISON") && atoi(getenv("FEMSHELL_POOL_POISON")) != 0;
+        carve_ = !(getenv("FEMSHELL_POOL_CARVE") && atoi(getenv("FEMSHELL_POOL_CARVE")) == 0); // (0: no carving of kept blocks, A/B runs)
         const char *a = getenv("FEMSHELL_POOL_ARENA_MB"); // 0: no arenas (every request to the driver, as in round 5)
         const double mb = a ? atof(a) : 512.0;
         arena_bytes_ = mb > 0.0 ? std::max((size_t)(mb * 1048576.0), 2 * kArenaMax) : 0;
@@ -340,6 +399,7 @@ class DevPool {
     std::unordered_map<void *, size_t> live_;
     std::list<Arena> arenas_; // (a list: the pointers into it stay valid)
     size_t cached_ = 0, limit_ = 0, arena_bytes_ = 0;
+    bool poison_ = false, carve_ = true;
     std::atomic<int> contexts_{0}, defer_depth_{0};
     std::vector<Pending> pending_;
     std::atomic<uint64_t> stat_mallocs_{0}, stat_malloc_ns_{0}, stat_frees_{0}, stat_free_ns_{0}, stat_syncs_{0}, stat_sync_ns_{0};
@@ -411,9 +471,10 @@ struct femshell_ctx {
     femshell::DevBuf<double> x0;
     bool warm_next = false;
     hipStream_t aux_stream = nullptr; // the look-ahead of the dense inverse (amg_dense.hip)
-    // uploads a helper thread of the multigrid setup makes beside the main stream (the node normals, amg_solve.cpp).  Made once per
-    // context: a stream created AND destroyed by the helper thread inside the setup left a later launch on the main stream waiting
-    // 24-31 ms for its turn (the runtime tearing the hardware queue down), whenever the timing was right for it.
+    // uploads a helper thread of the multigrid setup makes beside the main stream (the node normals, amg_solve.cpp): made by that
+    // thread at its first use in a single-rank context and kept.  (Not at femshell_create: HIP maps streams onto four hardware queues,
+    // and one stream more per context was enough, with two ranks sharing a card in the tests, for the look-ahead of the dense
+    // inverse -- two streams that must run side by side -- to run into its bounded wait one time in four.)
     hipStream_t copy_stream = nullptr;
     int aux_streams_side_by_side = 0; // 0: not asked yet, 1: stream and aux_stream run concurrently, -1: they share a hardware queue
     // first-contact self-test of femshell_comm_init (comm.cpp comm_selftest): microseconds of its three patterns
