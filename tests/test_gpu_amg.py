@@ -1,6 +1,8 @@
 """Multigrid-preconditioned solves on the GPU (csrc/amg_*.{cpp,hip}) against the CPU oracle: converged
 displacements against the direct solve, the hierarchy against the numpy restatement oracle/amg_oracle.py,
 iteration counts against the restatement's flexible PCG."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -892,3 +894,55 @@ def test_rows_beyond_the_lane_sets_take_the_hosts_lists(monkeypatch):
     ug = oracle.refined_solve(rg, cg, vg, Fg)
     assert np.linalg.norm(u.ravel() - ug) / np.linalg.norm(ug) < 1e-7
     fs.close()
+
+
+def test_results_do_not_depend_on_what_recycled_device_memory_holds(tmp_path):
+    """The device pool hands out used blocks (csrc/context.hpp DevPool: kept blocks, arenas, and since round 6 pieces carved from
+    large kept blocks) where a fresh request to the driver would have been zero-filled.  FEMSHELL_POOL_POISON=1 fills every block
+    with 0xFF bytes (NaN as a number, -1 as an index) before it is handed out: a child process solves the same systems that way --
+    block-Jacobi and multigrid, a hierarchy rebuilt after a change of K, patterns in HBM and on the host -- and has to return the
+    bits this process computes without it."""
+    import subprocess
+    import sys
+
+    from tests.helpers.product import ROOT
+
+    script = r'''
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from tests.helpers import meshes
+pkg = importlib.import_module("fem-shell_amd")
+out = {}
+for kind in ("panel", "quads"):
+    m = meshes.structured(40, 40, 0, 0, 10, 10, kind="t" if kind == "panel" else "q", ul_lr=True, bcids=(0, 0, 0, 0) if kind == "panel" else (1, 1, 1, 1), factor=300.0, loading=2)
+    fs = pkg.FemShell(0.3, 1e7, 0.5, device=0)
+    fs.set_mesh(m.xyz, m.tri, m.quad)
+    fs.set_dirichlet(m.dirichlet_mask())
+    fs.set_loads(m.loads)
+    u, info = fs.solve(rtol=1e-10, max_it=20000)
+    out[kind + "_jacobi"] = u
+    for where in ("device", "host"):
+        os.environ["FEMSHELL_AMG_SYMBOLIC"] = where
+        dm = m.dirichlet_mask()
+        dm[m.n_nodes // 2 + (1 if where == "host" else 0)] = 0x3F   # K changes: the hierarchy is rebuilt
+        fs.set_dirichlet(dm)
+        fs.set_preconditioner("amg", coarsest_nodes=60)
+        u, info = fs.solve(rtol=1e-10, max_it=500)
+        assert info["converged"] == 1
+        out[kind + "_amg_" + where] = u
+        out[kind + "_hist_" + where] = fs.residual_history()
+    fs.close()
+np.savez(sys.argv[1], **out)
+''' % (ROOT,)
+    files = {}
+    for name, poison in (("plain", "0"), ("poisoned", "1")):
+        files[name] = str(tmp_path / (name + ".npz"))
+        env = dict(os.environ, FEMSHELL_POOL_POISON=poison, FEMSHELL_AMG_DEVICE_MIN="100")
+        r = subprocess.run([sys.executable, "-c", script, files[name]], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    a, b = np.load(files["plain"]), np.load(files["poisoned"])
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 10
+    for k in a.files:
+        assert np.isfinite(b[k]).all(), k
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
