@@ -754,7 +754,6 @@ int power_iteration_dist(femshell_ctx *c, AmgLevel &L, const DeviceMatrix &A, in
     const int G = slice_grid(A);
     DevBuf<double> part;
     FS_HIP(part.alloc(2 * (size_t)G + 2));
-    std::vector<double> h(2 * (size_t)G);
     double *x = L.d.p, *z = L.r.p;
     launch_fill_hash(x, 6ll * L.n, 6ll * L.n_pad, st);
     if (iterations < 2) iterations = 2;
@@ -770,21 +769,18 @@ int power_iteration_dist(femshell_ctx *c, AmgLevel &L, const DeviceMatrix &A, in
         std::swap(x, z);
     }
     FS_HIP(hipGetLastError());
-    FS_HIP(hipMemcpyAsync(h.data(), part.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    FS_HIP(hipStreamSynchronize(st));
-    double s[2] = {0.0, 0.0}; // last, previous
-    const size_t last = (size_t)((iterations - 1) & 1) * G, prev = (size_t)((iterations - 2) & 1) * G;
-    for (int g = 0; g < G; g++) {
-        s[0] += h[last + g];
-        s[1] += h[prev + g];
-    }
+    // the rank's two norms: sums over its G partials in index order, taken on the device (launch_sums_in_order -- the host's loop of
+    // rounds 4-5, same bits, without the megabyte that went to the host and the sixteen bytes that came back): stage[j] = the sum
+    // over part[j G, (j + 1) G); all-reduced as they lie, which of the two is the last norm is sorted out afterwards
+    double s[2] = {0.0, 0.0};
     double *stage = part.p + 2 * (size_t)G;
-    FS_HIP(hipMemcpyAsync(stage, s, sizeof s, hipMemcpyHostToDevice, st));
+    launch_sums_in_order(part.p, G, stage, st);
+    FS_HIP(hipGetLastError());
     std::string e;
     if (!comm_allreduce_sum(c->comm, stage, 2, st, &e)) return set_err(FEMSHELL_ERR_COMM, e);
     FS_HIP(hipMemcpyAsync(s, stage, sizeof s, hipMemcpyDeviceToHost, st));
     FS_HIP(hipStreamSynchronize(st));
-    const double n_last = std::sqrt(s[0]), n_prev = std::sqrt(s[1]);
+    const double n_last = std::sqrt(s[(iterations - 1) & 1]), n_prev = std::sqrt(s[(iterations - 2) & 1]);
     if (!(n_prev > 0.0) || !std::isfinite(n_last) || !(n_last > 0.0))
         return set_err(FEMSHELL_ERR_BREAKDOWN, "multigrid setup: power iteration broke down");
     *lam_out = n_last / n_prev;
@@ -823,6 +819,7 @@ int amg_setup_dist(femshell_ctx *c)
 {
     TraceRange trace("femshell multigrid setup (row-partitioned)");
     const double t0 = now_s();
+    DevPool::Defer no_sync_per_free; // (buffers released during the setup join the pool at its end: context.hpp)
     hipStream_t st = c->stream;
     const femshell_pc_options opt = c->pc;
     const bool kcycle = opt.cycle == FEMSHELL_CYCLE_K;
@@ -883,11 +880,16 @@ int amg_setup_dist(femshell_ctx *c)
         src.xyz = c->xyz.p;
         src.dmask = c->dmask.p;
         if (!plain) {
-            std::vector<double> normals;
-            node_normals(pl.n_own, pl.xyz_local.data(), pl.n_ltri(), pl.tri_local.data(), pl.n_lquad(), pl.quad_local.data(), &normals);
-            normals.resize((size_t)pl.n_local_nodes() * 3, 0.0);
-            FS_HIP(d_normals.upload(normals, st));
-            FS_HIP(hipStreamSynchronize(st));
+            // (from the gather lists of the diagonal slots -- amg_setup.cpp node_normals_plan, the bits of node_normals -- and through
+            //  the pinned staging buffer: the host array is freed right below, context.hpp stage_host has why that matters)
+            RawVec<double> normals;
+            node_normals_plan(pl, &normals);
+            FS_HIP(d_normals.alloc((size_t)pl.n_local_nodes() * 3));
+            FS_HIP(d_normals.zero(st)); // (ghost rows: their normals are never read, their Q rows come from the owners)
+            {
+                const int rcu = staged_upload(c, d_normals.p, normals.data(), normals.size() * sizeof(double), st);
+                if (rcu) return rcu;
+            }
             src.normals = d_normals.p;
         }
         double ctr[3];

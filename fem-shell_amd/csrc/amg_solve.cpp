@@ -595,7 +595,6 @@ int amg_setup(femshell_ctx *c)
         H.levels.emplace_back(new AmgLevel());
         AmgLevel &L1 = *H.levels.back();
         std::vector<double> Bc;
-        lap("node normals", 0);
         pattern_of_plan(pl, &L0.pattern, /*light=*/true); // (amg_device_coarsen fills the slot arrays if it needs the host's lists)
         lap("pattern of K", 0);
         // the near-null space of the finest level is generated from the mesh in HBM (never stored: n x 36 doubles)
