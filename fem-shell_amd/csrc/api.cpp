@@ -490,6 +490,14 @@ int femshell_create(const femshell_config *cfg, femshell_ctx **out)
     // the second stream of the dense inverse's look-ahead (amg_dense.hip): made, and used once, here -- the first launch on a new
     // stream pays for its hardware queue (5 ms), which has no place inside the multigrid setup
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    // (the stream of the multigrid setup's helper thread -- context.hpp copy_stream -- for single-rank contexts only, and behind the
+    //  other two: made lazily inside the first setup it cost the 250k-triangle roof 14 of 33 ms, made for every context it was one
+    //  stream too many where two ranks share a card)
+    if (e == hipSuccess && cfg->world_size <= 1) {
+        e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMemsetAsync(c->scal.p, 0, sizeof(*c->scal.p), c->copy_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
+    }
     if (e == hipSuccess) e = hipMemsetAsync(c->scal.p, 0, sizeof(*c->scal.p), c->aux_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->aux_stream);
     if (e == hipSuccess && amg_dense_probe_streams(c) != FEMSHELL_OK) e = hipErrorUnknown; // (do the two run side by side?  10 ms the first time)
