@@ -7,6 +7,7 @@
 #                                            the multigrid solve of the 4M-triangle panel: trace by level, traffic by level
 #   gpurun_out/<tag>_pmc_mfma.json           matrix-core counters of the coarsest inverse (tools/pmc_mfma.py)
 #   gpurun_out/<tag>_bench.json, _bench_roof.json   bench.py default run (reads the summaries above from profiles/) and configs[1]
+#   gpurun_out/<tag>_bench_detail.json, _bench_roof_detail.json   their detail records (bench_detail.json of each run)
 # Every profiler pass runs under its own timeout; no TA_* counters (they hang rocprofv3 on this pool); counters in passes of
 # their own, never together with the runtime / hip / hsa trace domains.
 set -u
@@ -45,7 +46,9 @@ rm -rf $out/${tag}_amg_stats $out/${tag}_amg_fetch $out/${tag}_amg_write $out/${
 # profile taken with the same kernel sources; on the box the copies under profiles/ are scratch -- commit them from gpurun_out/)
 for f in pmc_hbm_traffic.json pmc_fp64.json amg_by_level.json pmc_mfma.json; do cp $out/${tag}_$f profiles/${tag}_$f 2> /dev/null; done
 timeout 1100 python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+cp bench_detail.json $out/${tag}_bench_detail.json 2> /dev/null  # (the detail record of THIS run: the next one writes the same file)
 tail -c 600 $out/${tag}_bench.err
 # configs[1] at full size as a run of its own (configs[2], the cylinder, is part of the default bench line)
 timeout 400 python3 bench.py --workload roof --no-cpu-baseline --no-full-parity --jacobi-probe-iters 0 > $out/${tag}_bench_roof.json 2> $out/${tag}_bench_roof.err
+cp bench_detail.json $out/${tag}_bench_roof_detail.json 2> /dev/null
 python3 tools/bench_summary.py < $out/${tag}_bench.json 2> /dev/null | head -12
