@@ -17,7 +17,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 one() { find "$1" -name "$2" | head -1; }
 # ---- assembly + block-Jacobi CG kernels (bench.py --profile)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o s -- python3 bench.py --steps 10 --warmup 2 --profile > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_stats.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o s -- python3 bench.py --steps 40 --warmup 5 --profile > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_stats.err
 cp $out/${tag}_stats/s_kernel_stats.csv $out/${tag}_kernel_stats.csv 2> /dev/null
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --profile > /dev/null 2> $out/${tag}_pmc_fetch.err
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -o w -- python3 bench.py --steps 3 --warmup 1 --profile > /dev/null 2> $out/${tag}_pmc_write.err
