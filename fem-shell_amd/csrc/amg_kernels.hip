@@ -618,12 +618,17 @@ void launch_sub(const double *a, const double *b, double *out, int64_t n, hipStr
 
 constexpr int kKcycGroups = 128; // stage-1 workgroups of a K-cycle dot product
 
+// (ticket != nullptr -- row-partitioned levels: the workgroup that finishes LAST adds the partial sums up, in the order and with
+//  the adder k_kcyc_finish uses (the same bits), and leaves the rank's three sums in sums_out for the all-reduce: the
+//  one-workgroup launch between this kernel and the collective is gone, 4.3 us of every coefficient step)
 __global__ __launch_bounds__(256) void k_kcyc_dots(const double *__restrict__ a0, const double *__restrict__ b0,
                                                    const double *__restrict__ a1, const double *__restrict__ b1,
                                                    const double *__restrict__ a2, const double *__restrict__ b2, int64_t n,
-                                                   double *__restrict__ scratch, const CgScalars *gate)
+                                                   double *scratch, const CgScalars *gate, unsigned int *ticket = nullptr,
+                                                   double *sums_out = nullptr, int phase = 0)
 {
     __shared__ double sh[4];
+    __shared__ int last_one;
     if (gate != nullptr && gate->done != 0) return;
     // contiguous chunk per workgroup, fixed order: deterministic
     const int64_t chunk = (n + gridDim.x - 1) / gridDim.x;
@@ -641,6 +646,27 @@ __global__ __launch_bounds__(256) void k_kcyc_dots(const double *__restrict__ a0
         scratch[blockIdx.x] = t0;
         scratch[kKcycGroups + blockIdx.x] = t1;
         if (a2 != nullptr) scratch[2 * kKcycGroups + blockIdx.x] = t2; // (two-product callers hand over 2 x kKcycGroups doubles)
+    }
+    if (ticket == nullptr) return;
+    if (threadIdx.x == 0) {
+        __threadfence(); // the partial sums above before the ticket
+        last_one = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last_one) return;
+    __threadfence(); // (acquire for every thread's loads of the others' partial sums)
+    double s[3];
+    for (int a = 0; a < 3; a++) { // k_kcyc_finish's sums: lanes [0, groups) of a block_sum, the lanes beyond add zeros
+        const double part = ((int)threadIdx.x < (int)gridDim.x && (a < 2 || a2 != nullptr))
+                                ? __hip_atomic_load(&scratch[a * kKcycGroups + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : 0.0;
+        s[a] = block_sum(part, sh);
+    }
+    if (threadIdx.x == 0) {
+        sums_out[0] = s[0];
+        sums_out[1] = s[1];
+        sums_out[2] = phase == 1 ? 0.0 : s[2];
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (for the next coefficient step)
     }
 }
 
@@ -700,8 +726,10 @@ void launch_kcyc_dots_local(int phase, const double *a0, const double *b0, const
     int groups = (int)((n6 + 4095) / 4096);
     if (groups > kKcycGroups) groups = kKcycGroups;
     if (groups < 1) groups = 1;
-    hipLaunchKernelGGL(k_kcyc_dots, dim3(groups), dim3(256), 0, st, a0, b0, a1, b1, a2, b2, n6, scratch, gate);
-    hipLaunchKernelGGL(k_kcyc_finish, dim3(1), dim3(128), 0, st, phase, groups, kKcycGroups, scratch, (KcycScalars *)nullptr, gate, sums);
+    // (the ticket of the last-workgroup reduction: the word behind the three sums and a spare -- sums[4], zero since the level's
+    //  vectors were allocated, set back to zero by the workgroup that draws the last ticket)
+    hipLaunchKernelGGL(k_kcyc_dots, dim3(groups), dim3(256), 0, st, a0, b0, a1, b1, a2, b2, n6, scratch, gate,
+                       reinterpret_cast<unsigned int *>(sums + 4), sums, phase);
 }
 
 void launch_kcyc_coefficients(int phase, const double *sums, KcycScalars *ks, const CgScalars *gate, hipStream_t st)
@@ -709,11 +737,25 @@ void launch_kcyc_coefficients(int phase, const double *sums, KcycScalars *ks, co
     hipLaunchKernelGGL(k_kcyc_finish, dim3(1), dim3(128), 0, st, phase, 1, 1, sums, ks, gate, (double *)nullptr);
 }
 
+// (sums != nullptr -- row-partitioned levels: the all-reduced sums of the step; every thread forms the coefficient from them as
+//  k_kcyc_finish does, the first one keeps it in *ks for the second step: no launch of its own for three divisions)
 __global__ __launch_bounds__(256) void k_kcyc_r2(const double *__restrict__ rc, const double *__restrict__ v1,
-                                                 double *__restrict__ r2, int64_t n, const KcycScalars *ks, const CgScalars *gate)
+                                                 double *__restrict__ r2, int64_t n, KcycScalars *ks, const CgScalars *gate,
+                                                 const double *sums = nullptr)
 {
     if (gate != nullptr && gate->done != 0) return;
-    const double t = ks->t;
+    double t;
+    if (sums != nullptr) {
+        const double rho1 = sums[0], a1 = sums[1];
+        t = rho1 > 0.0 ? a1 / rho1 : 0.0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ks->rho1 = rho1;
+            ks->a1 = a1;
+            ks->t = t;
+        }
+    } else {
+        t = ks->t;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         r2[i] = rc[i] - t * v1[i];
 }
@@ -804,28 +846,48 @@ int launch_two_dots(const double *a0, const double *b0, const double *a1, const 
     return groups;
 }
 
-void launch_kcyc_r2(const double *rc, const double *v1, double *r2, int64_t n6, const KcycScalars *ks, const CgScalars *gate,
-                    hipStream_t st)
+void launch_kcyc_r2(const double *rc, const double *v1, double *r2, int64_t n6, KcycScalars *ks, const CgScalars *gate,
+                    hipStream_t st, const double *sums)
 {
     const int64_t blocks = (n6 + 255) / 256;
-    hipLaunchKernelGGL(k_kcyc_r2, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, rc, v1, r2, n6, ks, gate);
+    hipLaunchKernelGGL(k_kcyc_r2, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, rc, v1, r2, n6, ks, gate, sums);
 }
 
 __global__ __launch_bounds__(256) void k_kcyc_combine(const double *__restrict__ c1, const double *__restrict__ c2,
-                                                      double *__restrict__ x, int64_t n, const KcycScalars *ks,
-                                                      const CgScalars *gate)
+                                                      double *__restrict__ x, int64_t n, KcycScalars *ks,
+                                                      const CgScalars *gate, const double *sums = nullptr)
 {
     if (gate != nullptr && gate->done != 0) return;
-    const double w1 = ks->w1, w2 = ks->w2;
+    double w1, w2;
+    if (sums != nullptr) { // (see k_kcyc_r2; the expressions of k_kcyc_finish, phase 2)
+        const double g = sums[0], b2 = sums[1], a2 = sums[2];
+        const double rho1 = ks->rho1, a1 = ks->a1;
+        w1 = ks->t;
+        w2 = 0.0;
+        if (rho1 > 0.0) {
+            const double rho2 = b2 - g * g / rho1;
+            if (rho2 > 0.0) {
+                w1 = a1 / rho1 - g * a2 / (rho1 * rho2);
+                w2 = a2 / rho2;
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ks->w1 = w1;
+            ks->w2 = w2;
+        }
+    } else {
+        w1 = ks->w1;
+        w2 = ks->w2;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         x[i] = w1 * c1[i] + w2 * c2[i];
 }
 
-void launch_kcyc_combine(const double *c1, const double *c2, double *x, int64_t n6, const KcycScalars *ks,
-                         const CgScalars *gate, hipStream_t st)
+void launch_kcyc_combine(const double *c1, const double *c2, double *x, int64_t n6, KcycScalars *ks,
+                         const CgScalars *gate, hipStream_t st, const double *sums)
 {
     const int64_t blocks = (n6 + 255) / 256;
-    hipLaunchKernelGGL(k_kcyc_combine, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, c1, c2, x, n6, ks, gate);
+    hipLaunchKernelGGL(k_kcyc_combine, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, c1, c2, x, n6, ks, gate, sums);
 }
 
 } // namespace femshell

@@ -84,11 +84,11 @@ void launch_kcyc_step2_small(const double *c1, const double *c2, const double *v
 // count (<= 128) hold the partial sums, in a fixed order (error estimate of the refinement passes: the host adds them)
 int launch_two_dots(const double *a0, const double *b0, const double *a1, const double *b1, int64_t n, double *scratch, hipStream_t st);
 // out = in - ks->t * v
-void launch_kcyc_r2(const double *rc, const double *v1, double *r2, int64_t n6, const KcycScalars *ks, const CgScalars *gate,
-                    hipStream_t st);
-// x = ks->w1 c1 + ks->w2 c2
-void launch_kcyc_combine(const double *c1, const double *c2, double *x, int64_t n6, const KcycScalars *ks,
-                         const CgScalars *gate, hipStream_t st);
+// (sums: row-partitioned levels -- the all-reduced sums of the step; the kernel forms the coefficients itself and keeps them in *ks)
+void launch_kcyc_r2(const double *rc, const double *v1, double *r2, int64_t n6, KcycScalars *ks, const CgScalars *gate,
+                    hipStream_t st, const double *sums = nullptr);
+void launch_kcyc_combine(const double *c1, const double *c2, double *x, int64_t n6, KcycScalars *ks,
+                         const CgScalars *gate, hipStream_t st, const double *sums = nullptr);
 
 } // namespace femshell
 

@@ -343,7 +343,7 @@ int alloc_level_vectors(AmgLevel &L, bool top, bool kcycle, hipStream_t st)
         FS_HIP(L.ks.zero(st));
         FS_HIP(L.kscratch.alloc(3 * 128));
         if (L.dist) {
-            FS_HIP(L.ksums.alloc(4));
+            FS_HIP(L.ksums.alloc(8)); // (three sums, a spare; word 4: the ticket of the last-workgroup reduction, amg_kernels.hip)
             FS_HIP(L.ksums.zero(st));
         }
     }
@@ -1328,10 +1328,13 @@ struct Cycle {
         const DeviceMatrix &A = amg_level_matrix(c, l);
         const int64_t n6 = 6ll * L.n_pad;
         const bool small = n6 <= kKcycSmall && !L.dist; // coefficient steps as single launches (amg_kernels.hpp)
-        auto reduce = [&](int phase) { // row-partitioned level: the rank's sums are in L.ksums
+        // row-partitioned level: the rank's sums are in L.ksums (left there by the last workgroup of the dot-product kernel); the
+        // kernel that applies the coefficients forms them from the all-reduced sums itself -- three launches per coefficient step
+        // where rounds 4-5 had five (two one-workgroup kernels around the collective: 12.7 launches of 4.3 us per outer iteration
+        // on the 1/8 strip of the 4M panel, profiles/r06_dist_budget_N8.txt)
+        auto reduce = [&]() {
             std::string e;
             if (!rc && !comm_allreduce_sum(c->comm, L.ksums.p, 3, st, &e)) rc = set_err(FEMSHELL_ERR_COMM, e);
-            launch_kcyc_coefficients(phase, L.ksums.p, L.ks.p, gate, st);
         };
         cycle(l, L.b.p, L.c1.p);
         krylov_product(l, A, L.c1.p, L.v1.p);
@@ -1340,11 +1343,11 @@ struct Cycle {
         } else {
             if (L.dist) {
                 launch_kcyc_dots_local(1, L.c1.p, L.v1.p, L.c1.p, L.b.p, nullptr, nullptr, n6, L.kscratch.p, L.ksums.p, gate, st);
-                reduce(1);
+                reduce();
             } else {
                 launch_kcyc_dots(1, L.c1.p, L.v1.p, L.c1.p, L.b.p, nullptr, nullptr, n6, L.ks.p, L.kscratch.p, gate, st);
             }
-            launch_kcyc_r2(L.b.p, L.v1.p, L.r2.p, n6, L.ks.p, gate, st);
+            launch_kcyc_r2(L.b.p, L.v1.p, L.r2.p, n6, L.ks.p, gate, st, L.dist ? L.ksums.p : nullptr);
         }
         cycle(l, L.r2.p, L.c2.p);
         krylov_product(l, A, L.c2.p, L.v2.p);
@@ -1353,11 +1356,11 @@ struct Cycle {
         } else {
             if (L.dist) {
                 launch_kcyc_dots_local(2, L.c2.p, L.v1.p, L.c2.p, L.v2.p, L.c2.p, L.r2.p, n6, L.kscratch.p, L.ksums.p, gate, st);
-                reduce(2);
+                reduce();
             } else {
                 launch_kcyc_dots(2, L.c2.p, L.v1.p, L.c2.p, L.v2.p, L.c2.p, L.r2.p, n6, L.ks.p, L.kscratch.p, gate, st);
             }
-            launch_kcyc_combine(L.c1.p, L.c2.p, L.x.p, n6, L.ks.p, gate, st);
+            launch_kcyc_combine(L.c1.p, L.c2.p, L.x.p, n6, L.ks.p, gate, st, L.dist ? L.ksums.p : nullptr);
         }
     }
 };
